@@ -1,0 +1,233 @@
+"""Synthetic lid-driven-cavity workloads: everything the multigrid hot path consumes, generated without Firedrake.
+
+Mirrors the roles of alfi/problem.py:5-58 (``NavierStokesProblem`` hooks), examples/ldc2d/ldc2d.py:7-39 and
+examples/ldc3d/ldc3d.py:7-31 (geometry, boundary conditions, lid profile) and of the Firedrake machinery that, in the
+reference, rediscretises the velocity block on every level (alfi/solver.py:565-568 linearised about the current
+state; coarse levels via dmhooks + ``inject`` of the state, solver.py:595).  The "current state" here is the nodal
+interpolant of the regularised lid profile extended into the cavity -- deterministic, no RNG.
+
+Output per level: block-CSR operator with Dirichlet rows/columns replaced by the identity, Dirichlet dof list,
+vertex-star patches; per level pair: prolongation matrices, grad-div matrix rows of the coarse-cell interior dofs
+and the dense interior blocks the Schoeberl transfer inverts.
+"""
+import time
+import numpy as np
+import scipy.sparse as sp
+
+from . import _hostlib
+from .elements import velocity_element
+from .fespace import VectorFunctionSpace, vector_prolongation, nodal_prolongation, coarse_cell_blocks
+from .mesh import rectangle_mesh, box_mesh, mesh_hierarchy
+
+
+class NavierStokesProblem(object):
+    """Hook names follow alfi/problem.py:5-58."""
+
+    def mesh(self, distribution_parameters=None):
+        raise NotImplementedError
+
+    def mesh_hierarchy(self, hierarchy, nref, callbacks=None, distribution_parameters=None):
+        if hierarchy != "uniform":
+            raise NotImplementedError("only the uniform hierarchy is built (bary: SURVEY.md section 8(f))")
+        return mesh_hierarchy(self.mesh(distribution_parameters), nref)
+
+    def driver(self, x):
+        raise NotImplementedError
+
+    def has_nullspace(self):
+        return True
+
+    def char_length(self):
+        return 1.0
+
+    def char_velocity(self):
+        return 1.0
+
+    def relaxation_direction(self):
+        return None
+
+
+class TwoDimLidDrivenCavityProblem(NavierStokesProblem):
+    """examples/ldc2d/ldc2d.py:7-39."""
+
+    def __init__(self, baseN, diagonal=None, regularised=True):
+        self.baseN = baseN
+        self.diagonal = diagonal or "left"
+        self.regularised = regularised
+        self.dim = 2
+
+    def mesh(self, distribution_parameters=None):
+        return rectangle_mesh(self.baseN, self.baseN, 2.0, 2.0, self.diagonal)
+
+    def driver(self, x):
+        w = np.zeros_like(x)
+        if self.regularised:
+            w[:, 0] = x[:, 0] ** 2 * (2 - x[:, 0]) ** 2 * (0.25 * x[:, 1] ** 2)
+        else:
+            w[:, 0] = 0.25 * x[:, 1] ** 2
+        return w
+
+    def char_length(self):
+        return 2.0
+
+    def relaxation_direction(self):
+        return "0+:1-"
+
+
+class ThreeDimLidDrivenCavityProblem(NavierStokesProblem):
+    """examples/ldc3d/ldc3d.py:7-31."""
+
+    def __init__(self, baseN):
+        self.baseN = baseN
+        self.dim = 3
+
+    def mesh(self, distribution_parameters=None):
+        return box_mesh(self.baseN, self.baseN, self.baseN, 2.0, 2.0, 2.0)
+
+    def driver(self, x):
+        w = np.zeros_like(x)
+        w[:, 0] = (x[:, 0] ** 2 * (2 - x[:, 0]) ** 2 * x[:, 2] ** 2 * (2 - x[:, 2]) ** 2 * (0.25 * x[:, 1] ** 2))
+        return w
+
+    def char_length(self):
+        return 2.0
+
+    def relaxation_direction(self):
+        return "0+:1-"
+
+
+class BSR(object):
+    """Plain block-CSR container (node rows x node cols, bs x bs row-major blocks)."""
+
+    def __init__(self, nbrows, nbcols, bs, rowptr, colidx, vals, bs_col=None):
+        self.nbrows, self.nbcols, self.bs = int(nbrows), int(nbcols), int(bs)
+        self.rowptr = np.ascontiguousarray(rowptr, dtype=np.int32)
+        self.colidx = np.ascontiguousarray(colidx, dtype=np.int32)
+        self.vals = np.ascontiguousarray(vals, dtype=np.float64).reshape(-1, bs, bs)
+
+    @property
+    def shape(self):
+        return (self.nbrows * self.bs, self.nbcols * self.bs)
+
+    @property
+    def nnzb(self):
+        return self.colidx.shape[0]
+
+    def to_scipy(self):
+        return sp.bsr_matrix((self.vals, self.colidx, self.rowptr), shape=self.shape)
+
+    @staticmethod
+    def from_scipy(M, bs):
+        B = sp.bsr_matrix(M, blocksize=(bs, bs))
+        B.sort_indices()
+        return BSR(B.shape[0] // bs, B.shape[1] // bs, bs, B.indptr, B.indices, B.data)
+
+    def select_rows(self, rows):
+        """Block rows ``rows`` (in that order) as a new BSR."""
+        rows = np.asarray(rows, dtype=np.int64)
+        cnt = (self.rowptr[rows + 1] - self.rowptr[rows]).astype(np.int64)
+        ptr = np.concatenate([[0], np.cumsum(cnt)])
+        idx = np.repeat(self.rowptr[rows].astype(np.int64) - ptr[:-1], cnt) + np.arange(ptr[-1])
+        return BSR(len(rows), self.nbcols, self.bs, ptr, self.colidx[idx], self.vals[idx])
+
+    def transpose(self):
+        pat = sp.csr_matrix((np.arange(1, self.nnzb + 1, dtype=np.int64), self.colidx, self.rowptr),
+                            shape=(self.nbrows, self.nbcols))
+        T = pat.T.tocsr()
+        T.sort_indices()
+        perm = T.data - 1
+        return BSR(self.nbcols, self.nbrows, self.bs, T.indptr, T.indices,
+                   np.ascontiguousarray(self.vals[perm].transpose(0, 2, 1)))
+
+
+class LevelData(object):
+    pass
+
+
+class TransferData(object):
+    pass
+
+
+def build_level_operator(V, wind, nu, gamma, advect, graph=None, return_parts=False):
+    """BSR operator nu K + gamma D + advect N(wind) with Dirichlet rows/cols -> identity."""
+    m = V.mesh
+    d = V.dim
+    rowptr, colidx = graph if graph is not None else _hostlib.node_graph(V.cell_nodes, V.num_nodes)
+    g, vol = m.cell_geometry()
+    tens = V.element.reference_tensors()
+    vals = _hostlib.assemble_bsr(V.cell_nodes, g, vol, tens, d, rowptr, colidx, nu=nu, gamma=gamma,
+                                 adv=advect, wind=wind if advect else None)
+    return rowptr, colidx, vals
+
+
+def build_hierarchy(problem, nref, k, Re, gamma=1e4, advect=True, patches=True, verbose=False):
+    """Levels 0..nref of the velocity block for ``problem`` at Reynolds number Re.
+
+    nu = char_length * char_velocity / Re (alfi/solver.py:261-267); gamma default 1e4 (alfi/driver.py:30)."""
+    t0 = time.time()
+    dim = problem.dim
+    element = velocity_element(dim, k)
+    mh = problem.mesh_hierarchy("uniform", nref)
+    nu = problem.char_length() * problem.char_velocity() / Re if Re > 0 else problem.char_length() * problem.char_velocity()
+    adv = 1.0 if (advect and Re > 0) else 0.0
+    levels, transfers = [], []
+    Vprev = None
+    for l, mesh in enumerate(mh):
+        V = VectorFunctionSpace(mesh, element)
+        d = V.dim
+        L = LevelData()
+        L.V, L.level, L.n, L.bs = V, l, V.num_dofs, d
+        rowptr, colidx = _hostlib.node_graph(V.cell_nodes, V.num_nodes)
+        g, vol = mesh.cell_geometry()
+        tens = element.reference_tensors()
+        bcmask = np.repeat(V.bc_node_mask, d)
+        wind = problem.driver(V.node_coords)
+        # K and D separately first (the transfer needs their interior blocks), then A = nu K + gamma D + N(w)
+        K = _hostlib.assemble_bsr(V.cell_nodes, g, vol, tens, d, rowptr, colidx, nu=1.0)
+        T = None
+        if l > 0:
+            T = TransferData()
+            blk_nodes = coarse_cell_blocks(V)
+            T.blk_dofs = np.ascontiguousarray(V.node_dofs(blk_nodes), dtype=np.int32)     # (nblk, m)
+            nblk, mm = T.blk_dofs.shape
+            bptr = np.arange(nblk + 1, dtype=np.int64) * mm
+            _, kii = _hostlib.extract_blocks(d, rowptr, colidx, K, bptr, T.blk_dofs.ravel())
+            T.K_II = kii.reshape(nblk, mm, mm)
+        A = K
+        A *= nu
+        D = _hostlib.assemble_bsr(V.cell_nodes, g, vol, tens, d, rowptr, colidx, gamma=1.0)
+        if l > 0:
+            _, dii = _hostlib.extract_blocks(d, rowptr, colidx, D, bptr, T.blk_dofs.ravel())
+            T.D_II = dii.reshape(nblk, mm, mm)
+            Dbsr = BSR(V.num_nodes, V.num_nodes, d, rowptr, colidx, D)
+            T.D_I = Dbsr.select_rows(blk_nodes.ravel())           # rows: interior nodes in block order
+            T.D_IT = T.D_I.transpose()                            # (fine nodes) x (interior nodes)
+        A += gamma * D
+        del D
+        if adv:
+            _hostlib.assemble_bsr(V.cell_nodes, g, vol, tens, d, rowptr, colidx, adv=adv, wind=wind, out=A)
+        _hostlib.apply_bc_bsr(V.num_nodes, d, rowptr, colidx, A, bcmask)
+        L.A = BSR(V.num_nodes, V.num_nodes, d, rowptr, colidx, A)
+        L.bc_dofs = V.bc_dofs
+        L.nu, L.gamma = nu, gamma
+        if patches and l > 0:
+            L.patch_ptr, L.patch_dofs, L.patch_seeds = V.star_patches()
+        if l > 0:
+            Pv = vector_prolongation(Vprev, V)
+            T.P = BSR.from_scipy(Pv, d)
+            T.PT = T.P.transpose()
+            if Vprev.dim == 3 and element.bubble and element.degree == 1:
+                Pn = sp.kron(nodal_prolongation(Vprev, V), sp.identity(d, format="csr"), format="csr")
+                T.PT_plain = BSR.from_scipy(Pn, d).transpose()
+            else:
+                T.PT_plain = T.PT
+            T.nu, T.gamma = nu, gamma
+            T.n_f, T.n_c = V.num_dofs, Vprev.num_dofs
+            T.bc_dofs_f, T.bc_dofs_c = V.bc_dofs, Vprev.bc_dofs
+            transfers.append(T)
+        levels.append(L)
+        Vprev = V
+        if verbose:
+            print("[alfi_amd] level %d: %d cells, %d dofs, %d block nnz (%.1fs)"
+                  % (l, mesh.num_cells, V.num_dofs, L.A.nnzb, time.time() - t0), flush=True)
+    return levels, transfers

@@ -1,0 +1,354 @@
+"""TEST INFRASTRUCTURE ONLY -- CPU (NumPy/SciPy) restatement of the reference's multigrid hot path.
+
+PARITY UNPINNED: the reference (florianwechsung/alfi) ships no tests, golden vectors or logs, and its arithmetic
+lives in un-vendored, un-pinned third-party code (PETSc PCPATCH / PCMG / KSPFGMRES / MatMult, Firedrake PatchPC and
+prolong/restrict, PyOP2 par_loops) that is not installed here.  This oracle therefore follows
+the reference's *call sites and data flow* (cited per function) plus the documented behaviour of those libraries; it
+is pinned only by its own mathematical property tests (tests/test_oracle_*.py) and committed fixtures produced by it
+(tests/golden/).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.  The product path
+(alfi_amd/) never does.
+"""
+import numpy as np
+import scipy.sparse as sp
+import scipy.sparse.linalg as spla
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# S1/S2: vertex-star patches, literal restatement of alfi/relaxation.py:33-34, 110-160
+# ---------------------------------------------------------------------------------------------------------------------
+def star_patches_literal(V):
+    """For every vertex: transitive support closure (vertex + incident edges, faces, cells; relaxation.py:33-34,
+    158-160), then the dofs living on those points minus Dirichlet dofs (what PCPATCH keeps [3P]).  Pure-Python
+    loops over the incidence relation -- small meshes only.  Returns list of (seed vertex, sorted dof array)."""
+    m = V.mesh
+    d = V.dim
+    edges_of_v = [[] for _ in range(m.num_vertices)]
+    for e, (a, b) in enumerate(m.edges):
+        edges_of_v[a].append(e)
+        edges_of_v[b].append(e)
+    faces_of_v = [[] for _ in range(m.num_vertices)]
+    if m.dim == 3:
+        for f, vs in enumerate(m.faces):
+            for a in vs:
+                faces_of_v[a].append(f)
+    out = []
+    for v in range(m.num_vertices):
+        nodes = [int(V.vertex_nodes[v])]
+        if V.element.has_edge_nodes:
+            nodes += [int(V.edge_nodes[e]) for e in edges_of_v[v]]
+        if V.element.has_face_nodes:
+            nodes += [int(V.face_nodes[f]) for f in faces_of_v[v]]
+        nodes = sorted(n for n in set(nodes) if not V.bc_node_mask[n])
+        if nodes:
+            out.append((v, np.array([n * d + c for n in nodes for c in range(d)], dtype=np.int32)))
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# operator: independent quadrature-based assembly of the velocity-block form (alfi/solver.py:565-568 linearised;
+# alfi/transfer.py:319-324 for the symmetric transfer form)
+# ---------------------------------------------------------------------------------------------------------------------
+def assemble_form(V, nu=0.0, gamma=0.0, adv=0.0, wind=None, nq=6):
+    """CSR of nu (2 sym grad u, grad v) + gamma (cell_avg div u, div v) + adv ((w.grad)u + (u.grad)w, v), no BCs."""
+    from alfi_amd.elements import simplex_quadrature
+    m, d, el = V.mesh, V.dim, V.element
+    lam, wq = simplex_quadrature(d, nq)
+    phi, dphi = el.tabulate(lam)                                   # (q, a), (q, a, i)
+    g, vol = m.cell_geometry()                                     # (c, i, x), (c,)
+    nloc, nc = el.nloc, m.num_cells
+    gradphi = np.einsum("qai,cix->cqax", dphi, g)                  # physical gradients (c, q, a, x)
+    Ae = np.zeros((nc, nloc, d, nloc, d))
+    if nu:
+        G = np.einsum("q,cqax,cqbx->cab", wq, gradphi, gradphi)
+        H = np.einsum("q,cqay,cqbx->caxby", wq, gradphi, gradphi)    # entry (a,x),(b,y) = int d_y phi_a d_x phi_b
+        Ae += nu * vol[:, None, None, None, None] * H
+        for x in range(d):
+            Ae[:, :, x, :, x] += nu * vol[:, None, None] * G
+    if gamma:
+        bdiv = np.einsum("q,cqax->cax", wq, gradphi)                 # cell average of d_x phi_a
+        Ae += gamma * vol[:, None, None, None, None] * np.einsum("cax,cby->caxby", bdiv, bdiv)
+    if adv:
+        wloc = wind[V.cell_nodes]                                    # (c, k, x)
+        wq_ = np.einsum("qk,ckx->cqx", phi, wloc)                    # w at quadrature points
+        gradw = np.einsum("cqkx,cky->cqyx", gradphi, wloc)           # gradw[c,q,y,x] = d_x w_y
+        conv = np.einsum("cqx,cqbx->cqb", wq_, gradphi)              # (w . grad) phi_b
+        N1 = np.einsum("q,cqb,qa->cab", wq, conv, phi)
+        for x in range(d):
+            Ae[:, :, x, :, x] += adv * vol[:, None, None] * N1
+        N2 = np.einsum("q,qb,cqyx,qa->caybx", wq, phi, gradw, phi)   # (a,y),(b,x): phi_b d_x w_y phi_a
+        Ae += adv * vol[:, None, None, None, None] * N2
+    dofs = V.node_dofs(V.cell_nodes)                                 # (c, nloc*d)
+    nd = nloc * d
+    rows = np.repeat(dofs, nd, axis=1).ravel()
+    cols = np.tile(dofs, (1, nd)).ravel()
+    A = sp.csr_matrix((Ae.reshape(nc, -1).ravel(), (rows, cols)), shape=(V.num_dofs, V.num_dofs))
+    A.sum_duplicates()
+    return A
+
+
+def apply_bcs_matrix(A, bc_dofs):
+    """Rows and columns of Dirichlet dofs -> identity (firedrake.assemble(a, bcs=bcs) [3P])."""
+    n = A.shape[0]
+    keep = np.ones(n)
+    keep[bc_dofs] = 0.0
+    Dk = sp.diags(keep)
+    return (Dk @ A @ Dk + sp.diags(1.0 - keep)).tocsr()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# S5/S6: PatchPC / PCPATCH additive star smoother, dense explicit inverses (alfi/solver.py:318-328, 599-602)
+# ---------------------------------------------------------------------------------------------------------------------
+class PatchSmoother(object):
+    def __init__(self, A, patch_ptr, patch_dofs, bc_dofs):
+        self.A = sp.csr_matrix(A)
+        self.patch_ptr, self.patch_dofs, self.bc_dofs = patch_ptr, patch_dofs, bc_dofs
+        self.update()
+
+    def update(self, A=None):
+        """Patch operators are principal sub-blocks of the level operator inverted with
+        LAPACK getrf/getri (patch_pc_patch_dense_inverse, solver.py:602)."""
+        if A is not None:
+            self.A = sp.csr_matrix(A)
+        self.inv = []
+        for p in range(len(self.patch_ptr) - 1):
+            dofs = self.patch_dofs[self.patch_ptr[p]:self.patch_ptr[p + 1]]
+            Ap = self.A[dofs][:, dofs].toarray()
+            self.inv.append(np.linalg.inv(Ap))
+
+    def apply(self, x):
+        """y = sum_p R_p^T A_p^{-1} R_p x, no partition of unity (solver.py:321); y[bc] = x[bc]."""
+        y = np.zeros_like(x)
+        for p, Ainv in enumerate(self.inv):
+            dofs = self.patch_dofs[self.patch_ptr[p]:self.patch_ptr[p + 1]]
+            y[dofs] += Ainv @ x[dofs]
+        y[self.bc_dofs] = x[self.bc_dofs]
+        return y
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# S8: KSPFGMRES with classical Gram-Schmidt, exactly k iterations (alfi/solver.py:314-317; PETSc defaults App. C)
+# ---------------------------------------------------------------------------------------------------------------------
+def fgmres(A, M, b, x, k, nonzero_guess=True):
+    """Right-preconditioned flexible GMRES(k), one cycle, ``ksp_convergence_test skip``.  A: matvec callable,
+    M: preconditioner callable.  Returns the new iterate (x is not modified)."""
+    r = b - A(x) if nonzero_guess else b.copy()
+    beta = np.linalg.norm(r)
+    if beta == 0.0:
+        return x.copy()
+    n = b.shape[0]
+    Vb = np.zeros((k + 1, n))
+    Z = np.zeros((k, n))
+    H = np.zeros((k + 1, k))
+    Vb[0] = r / beta
+    cs, sn = np.zeros(k), np.zeros(k)
+    grs = np.zeros(k + 1)
+    grs[0] = beta
+    its = 0
+    for j in range(k):
+        Z[j] = M(Vb[j])
+        w = A(Z[j])
+        h = Vb[:j + 1] @ w                       # classical Gram-Schmidt: all dots from the same w
+        w = w - h @ Vb[:j + 1]
+        H[:j + 1, j] = h
+        tt = np.linalg.norm(w)
+        H[j + 1, j] = tt
+        its = j + 1
+        # Givens update of the Hessenberg column (KSPFGMRESUpdateHessenberg)
+        hcol = H[:j + 2, j].copy()
+        for i in range(j):
+            t = hcol[i]
+            hcol[i] = cs[i] * t + sn[i] * hcol[i + 1]
+            hcol[i + 1] = -sn[i] * t + cs[i] * hcol[i + 1]
+        den = np.hypot(hcol[j], hcol[j + 1])
+        if den == 0.0:
+            break
+        cs[j], sn[j] = hcol[j] / den, hcol[j + 1] / den
+        grs[j + 1] = -sn[j] * grs[j]
+        grs[j] = cs[j] * grs[j]
+        hcol[j] = den
+        hcol[j + 1] = 0.0
+        H[:j + 2, j] = hcol
+        if tt == 0.0:
+            break
+        Vb[j + 1] = w / tt
+    # back substitution on the triangularised Hessenberg (KSPFGMRESBuildSoln)
+    y = np.zeros(its)
+    for i in range(its - 1, -1, -1):
+        y[i] = (grs[i] - H[i, i + 1:its] @ y[i + 1:its]) / H[i, i]
+    return x + y @ Z[:its]
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# T5/T6: Schoeberl prolongation / restriction, literal data flow of alfi/transfer.py:194-275
+# ---------------------------------------------------------------------------------------------------------------------
+class SchoeberlTransfer(object):
+    def __init__(self, P, A_sym, gammaD, blk_dofs, skeleton_dofs, P_restrict=None):
+        """P: standard transfer (fine x coarse, bubble-corrected where transfer.py:334-356 says so); A_sym: the
+        symmetric form nu K + gamma D on the fine level (transfer.py:319-324); gammaD: gamma * D (bform,
+        transfer.py:326-332); blk_dofs: (nblk, m) coarse-cell interior dofs (transfer.py:13-46); skeleton_dofs:
+        Dirichlet set of fix_coarse_boundaries (transfer.py:121-158)."""
+        self.P = sp.csr_matrix(P)
+        self.gD = sp.csr_matrix(gammaD)
+        self.blk_dofs, self.skel = blk_dofs, skeleton_dofs
+        A = sp.csr_matrix(A_sym)
+        # patch_sub_pc_type lu on each coarse-cell patch (transfer.py:100-113)
+        self.lu = [np.linalg.inv(A[d][:, d].toarray()) for d in blk_dofs]
+
+    def _patch_apply(self, x):
+        """PatchPC.apply with the coarse-cell patches: additive, disjoint; y[bc] = x[bc]."""
+        y = np.zeros_like(x)
+        for d, Ainv in zip(self.blk_dofs, self.lu):
+            y[d] = Ainv @ x[d]
+        y[self.skel] = x[self.skel]
+        return y
+
+    def prolong(self, coarse):
+        rhs = self.P @ coarse                                  # standard_transfer(coarse, rhs)   :247
+        b = self.gD @ rhs                                      # assemble(bform, bcs=bcs)         :249
+        b[self.skel] = 0.0
+        tildeu = self._patch_apply(b)                          # ksp.pc.apply                     :254-257
+        return rhs - tildeu                                    #                                  :259
+
+    def restrict(self, fine):
+        tildeu = fine.copy()                                   #                                  :265
+        tildeu[self.skel] = 0.0                                # bcs.apply(tildeu)                :266
+        rhs = self._patch_apply(tildeu)                        #                                  :267-270
+        b = self.gD @ rhs                                      # assemble(bform) -- no bcs        :272
+        rhs = fine - b                                         #                                  :274
+        return self.P.T @ rhs                                  # standard_transfer(rhs, coarse)   :275
+
+
+def bubble_prolong_literal(Vc, Vf, coarse):
+    """alfi/bubble.py:233-265 executed step by step with the per-cell kernels (split :57-91, combine :125-147) and the
+    divide-by-multiplicity steps (:243-244, :265), the facet rescaling (:29-39, 251-253) and nodal prolongation of the
+    P1 and bubble parts (:256-257).  coarse: (num_dofs,) -> fine (num_dofs,)."""
+    from alfi_amd.mesh import TET_FACES
+    from alfi_amd.fespace import nodal_prolongation, _facet_normals
+    from alfi_amd.elements import NodalElement
+    mc, mf = Vc.mesh, Vf.mesh
+    a = np.vstack([np.eye(4), np.zeros((4, 4))])                                         # bubble.py:64-71
+    b = np.vstack([-(np.ones((4, 4)) - np.eye(4)) / 3.0, np.eye(4)])                     # bubble.py:73-80
+    both = coarse.reshape(-1, 3)
+    p1c = np.zeros((mc.num_vertices, 3))
+    fbc = np.zeros((mc.num_faces, 3))
+    cntp1, cntfb = np.zeros(mc.num_vertices), np.zeros(mc.num_faces)
+    for c in range(mc.num_cells):
+        loc = both[Vc.cell_nodes[c]]                      # (8, 3): 4 vertex nodes then 4 face nodes
+        for kk in range(8):
+            for i in range(4):
+                p1c[mc.cells[c, i]] += a[kk, i] * loc[kk]
+                fbc[mc.cell_faces[c, i]] += b[kk, i] * loc[kk]
+        cntp1[mc.cells[c]] += 1
+        cntfb[mc.cell_faces[c]] += 1
+    p1c /= cntp1[:, None]
+    fbc /= cntfb[:, None]
+    nrm = _facet_normals(mc)
+    fbc = fbc + (1.0 / 0.625 - 1.0) * (fbc * nrm).sum(axis=1)[:, None] * nrm
+    p1 = NodalElement(3, 1, False)
+    P1 = nodal_prolongation(Vc, Vf, p1, p1, mf.cells, mc.cells, mf.num_vertices, mc.num_vertices)
+    p1f = P1 @ p1c
+
+    class _FB(object):
+        node_bary = Vc.element.node_bary[-4:]
+
+        @staticmethod
+        def tabulate(lam):
+            return NodalElement._bubbles(np.atleast_2d(lam))
+    PF = nodal_prolongation(Vc, Vf, _FB, _FB, mf.cell_faces, mc.cell_faces, mf.num_faces, mc.num_faces)
+    fbf = PF @ fbc
+    ac = np.hstack([np.eye(4), (np.ones((4, 4)) - np.eye(4)) / 3.0])                     # bubble.py:129-132
+    bc_ = np.hstack([np.zeros((4, 4)), np.eye(4)])                                       # bubble.py:133-136
+    fine = np.zeros((Vf.num_nodes, 3))
+    cnt = np.zeros(Vf.num_nodes)
+    for c in range(mf.num_cells):
+        out = ac.T @ p1f[mf.cells[c]] + bc_.T @ fbf[mf.cell_faces[c]]
+        fine[Vf.cell_nodes[c]] += out
+        cnt[Vf.cell_nodes[c]] += 1
+    fine /= cnt[:, None]
+    return fine.ravel()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# S9: PCMG V-cycle and full cycle (alfi/solver.py:359-379; PETSc PCMGMCycle_Private / PCMGFCycle_Private)
+# ---------------------------------------------------------------------------------------------------------------------
+class Multigrid(object):
+    """levels[l]: dict(A=csr, smoother=PatchSmoother or None (l=0), bc=bc dofs); transfers[l-1]: object with
+    prolong(coarse)->fine and restrict(fine)->coarse between level l-1 and l.  After every transfer the target's
+    Dirichlet dofs are zeroed (firedrake.mg Interpolation.mult / multTranspose [3P])."""
+
+    def __init__(self, levels, transfers, k):
+        self.levels, self.transfers, self.k = levels, transfers, k
+        self.coarse_lu = spla.splu(sp.csc_matrix(levels[0]["A"]))       # AssembledPC + LU, solver.py:369-378
+
+    def smooth(self, l, b, x):
+        L = self.levels[l]
+        return fgmres(lambda v: L["A"] @ v, L["smoother"].apply, b, x, self.k, nonzero_guess=True)
+
+    def prolong(self, l, xc):
+        xf = self.transfers[l - 1].prolong(xc)
+        xf[self.levels[l]["bc"]] = 0.0
+        return xf
+
+    def restrict(self, l, rf):
+        rc = self.transfers[l - 1].restrict(rf)
+        rc[self.levels[l - 1]["bc"]] = 0.0
+        return rc
+
+    def vcycle(self, l, b, x):
+        if l == 0:
+            return self.coarse_lu.solve(b)
+        x = self.smooth(l, b, x)
+        r = b - self.levels[l]["A"] @ x
+        bc = self.restrict(l, r)
+        xc = self.vcycle(l - 1, bc, np.zeros_like(bc))
+        x = x + self.prolong(l, xc)
+        return self.smooth(l, b, x)
+
+    def fcycle(self, b):
+        L = len(self.levels) - 1
+        bs = [None] * (L + 1)
+        bs[L] = b
+        for l in range(L, 0, -1):
+            bs[l - 1] = self.restrict(l, bs[l])
+        x = np.zeros_like(bs[0])
+        for l in range(L):
+            x = self.vcycle(l, bs[l], x)
+            x = self.prolong(l + 1, x)
+        return self.vcycle(L, bs[L], x)
+
+
+def build_oracle_mg(levels, transfers, k, schoeberl_restriction=False):
+    """Oracle multigrid from the host generator's LevelData/TransferData (alfi_amd/problem.py)."""
+    olev = []
+    for L in levels:
+        A = L.A.to_scipy().tocsr()
+        sm = PatchSmoother(A, L.patch_ptr, L.patch_dofs, L.bc_dofs) if L.level > 0 else None
+        olev.append(dict(A=A, smoother=sm, bc=L.bc_dofs))
+    otr = []
+    for T, L in zip(transfers, levels[1:]):
+        otr.append(oracle_transfer(T, L, schoeberl_restriction))
+    return Multigrid(olev, otr, k)
+
+
+class _TransferPair(object):
+    def __init__(self, st, PT_plain, schoeberl_restriction):
+        self.st, self.PT_plain, self.sr = st, PT_plain, schoeberl_restriction
+
+    def prolong(self, xc):
+        return self.st.prolong(xc)
+
+    def restrict(self, rf):
+        # alfi/solver.py:595: vtransfer.restrict if self.restriction else firedrake's plain restrict
+        return self.st.restrict(rf) if self.sr else self.PT_plain @ rf
+
+
+def oracle_transfer(T, L, schoeberl_restriction=False):
+    from alfi_amd.fespace import skeleton_node_mask
+    V = L.V
+    K = assemble_form(V, nu=1.0)
+    D = assemble_form(V, gamma=1.0)
+    skel = np.flatnonzero(np.repeat(skeleton_node_mask(V), V.dim))
+    st = SchoeberlTransfer(T.P.to_scipy(), T.nu * K + T.gamma * D, T.gamma * D, T.blk_dofs, skel)
+    return _TransferPair(st, T.PT_plain.to_scipy().tocsr(), schoeberl_restriction)

@@ -1,0 +1,195 @@
+"""CPU tests of the host-side generator (mesh, spaces, patches, operators, transfers) against the oracle's independent
+restatements, plus the mathematical properties SURVEY.md section 4 lists as the pins for this (test-less) reference."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from alfi_amd.problem import (TwoDimLidDrivenCavityProblem, ThreeDimLidDrivenCavityProblem, build_hierarchy)
+from alfi_amd.fespace import nodal_prolongation, skeleton_node_mask
+from oracle import alfi_oracle as O
+
+CASES = [("2d-P2", lambda: TwoDimLidDrivenCavityProblem(2), 2),
+         ("3d-P1FB", lambda: ThreeDimLidDrivenCavityProblem(1), 1),
+         ("3d-P2FB", lambda: ThreeDimLidDrivenCavityProblem(1), 2)]
+
+
+@pytest.fixture(scope="module", params=CASES, ids=[c[0] for c in CASES])
+def hier(request):
+    name, mk, k = request.param
+    prob = mk()
+    lv, tr = build_hierarchy(prob, 1, k, Re=50)
+    return prob, k, lv, tr
+
+
+def test_sizes_match_survey():
+    """Interior star sizes 14 / 111 / 153 and coarse-cell interior blocks 6 / 24 / 27."""
+    for prob, k, npatch, m in [(TwoDimLidDrivenCavityProblem(4), 2, 14, 6),
+                               (ThreeDimLidDrivenCavityProblem(2), 1, 111, 24),
+                               (ThreeDimLidDrivenCavityProblem(2), 2, 153, 27)]:
+        lv, tr = build_hierarchy(prob, 1, k, Re=10)
+        assert np.diff(lv[-1].patch_ptr).max() == npatch
+        assert tr[-1].blk_dofs.shape[1] == m
+        assert tr[-1].blk_dofs.shape[0] == lv[0].V.mesh.num_cells
+
+
+def test_dof_counts_3d():
+    """V=(N+1)^3, E=7N^3+9N^2+3N, F=12N^3+6N^2 for the Kuhn box."""
+    from alfi_amd.mesh import box_mesh
+    N = 3
+    m = box_mesh(N, N, N, 2, 2, 2)
+    assert m.num_vertices == (N + 1) ** 3
+    assert m.num_edges == 7 * N ** 3 + 9 * N ** 2 + 3 * N
+    assert m.num_faces == 12 * N ** 3 + 6 * N ** 2
+    assert m.num_cells == 6 * N ** 3
+
+
+def test_refinement_reproduces_structured_mesh():
+    """Bey refinement of the Kuhn box with N cubes is the Kuhn box with 2N cubes (same cells as vertex-coordinate sets)."""
+    from alfi_amd.mesh import box_mesh, refine, rectangle_mesh
+    for coarse, fine in [(box_mesh(2, 2, 2, 2, 2, 2), box_mesh(4, 4, 4, 2, 2, 2)),
+                         (rectangle_mesh(3, 3, 2, 2), rectangle_mesh(6, 6, 2, 2))]:
+        r = refine(coarse)
+        assert r.num_cells == fine.num_cells and r.num_vertices == fine.num_vertices
+
+        def key(m):
+            c = np.round(m.coords[m.cells] * 1000).astype(np.int64)            # (nc, d+1, d)
+            c = np.array([sorted(map(tuple, cell)) for cell in c]).reshape(m.num_cells, -1)
+            return set(map(tuple, c))
+        assert key(r) == key(fine)
+
+
+def test_star_patches_match_literal(hier):
+    prob, k, lv, tr = hier
+    L = lv[-1]
+    V = L.V
+    lit = O.star_patches_literal(V)
+    assert len(lit) == len(L.patch_ptr) - 1
+    order = np.argsort([V.vertex_nodes[v] for v, _ in lit])
+    for p, i in enumerate(order):
+        v, dofs = lit[i]
+        assert L.patch_seeds[p] == v
+        assert np.array_equal(dofs, L.patch_dofs[L.patch_ptr[p]:L.patch_ptr[p + 1]])
+
+
+def test_assembly_matches_quadrature_oracle(hier):
+    prob, k, lv, tr = hier
+    for L in lv:
+        V = L.V
+        w = prob.driver(V.node_coords)
+        A_o = O.apply_bcs_matrix(O.assemble_form(V, nu=L.nu, gamma=L.gamma, adv=1.0, wind=w), L.bc_dofs)
+        A_h = L.A.to_scipy().tocsr()
+        assert abs(A_o - A_h).max() <= 1e-12 * abs(A_o).max()
+
+
+def test_symmetric_parts_spd(hier):
+    prob, k, lv, tr = hier
+    V = lv[-1].V
+    K = O.assemble_form(V, nu=1.0)
+    D = O.assemble_form(V, gamma=1.0)
+    assert abs(K - K.T).max() < 1e-12 * abs(K).max()
+    assert abs(D - D.T).max() < 1e-12 * abs(D).max()
+    x = np.random.default_rng(1).standard_normal(V.num_dofs)
+    assert x @ (K @ x) > 0 and x @ (D @ x) >= -1e-10
+    # rigid translations are in the kernel of both
+    assert abs(K @ np.ones(V.num_dofs)).max() < 1e-9 * abs(K).max()
+    assert abs(D @ np.ones(V.num_dofs)).max() < 1e-9 * abs(D).max()
+
+
+def test_nodal_prolongation_reproduces_polynomials(hier):
+    prob, k, lv, tr = hier
+    Vc, Vf = lv[0].V, lv[1].V
+    P = nodal_prolongation(Vc, Vf)
+
+    def poly(x, deg):
+        return (1 + x[:, 0] + 2 * x[:, 1]) ** deg + x[:, -1] ** deg
+    for deg in range(1, Vf.element.degree + 1):
+        assert abs(P @ poly(Vc.node_coords, deg) - poly(Vf.node_coords, deg)).max() < 1e-12
+
+
+def test_bubble_matrix_matches_literal_kernels():
+    prob = ThreeDimLidDrivenCavityProblem(1)
+    lv, tr = build_hierarchy(prob, 1, 1, Re=50)
+    u = np.random.default_rng(0).standard_normal(lv[0].V.num_dofs)
+    ref = O.bubble_prolong_literal(lv[0].V, lv[1].V, u)
+    assert abs(tr[-1].P.to_scipy() @ u - ref).max() < 1e-13 * abs(ref).max()
+
+
+def test_bubble_fix_scales_normal_flux():
+    """The rescaling multiplies the normal component of every coarse bubble dof by 1/0.625 = 1.6 and keeps the
+    tangential part (bubble.py:4-6, 36): check P_bubble - P_nodal acts only through that."""
+    from alfi_amd.fespace import bubble_prolongation, _facet_normals
+    prob = ThreeDimLidDrivenCavityProblem(1)
+    lv, _ = build_hierarchy(prob, 1, 1, Re=50)
+    Vc, Vf = lv[0].V, lv[1].V
+    Pb = bubble_prolongation(Vc, Vf)
+    Pn = sp.kron(nodal_prolongation(Vc, Vf), sp.identity(3))
+    # a coarse function that is a pure tangential bubble on one facet: both transfers agree
+    nrm = _facet_normals(Vc.mesh)
+    f = 5
+    t = np.cross(nrm[f], [0.3, -0.2, 0.9])
+    u = np.zeros((Vc.num_nodes, 3))
+    u[Vc.face_nodes[f]] = t
+    assert abs(Pb @ u.ravel() - Pn @ u.ravel()).max() < 1e-13
+    # pure normal bubble: bubble transfer = 1.6 x nodal transfer
+    u[Vc.face_nodes[f]] = nrm[f]
+    assert abs(Pb @ u.ravel() - 1.6 * (Pn @ u.ravel())).max() < 1e-13
+
+
+def _oracle_transfer(lv, tr):
+    return O.oracle_transfer(tr[-1], lv[-1], schoeberl_restriction=True).st
+
+
+def test_schoeberl_restrict_is_transpose_of_prolong(hier):
+    prob, k, lv, tr = hier
+    st = _oracle_transfer(lv, tr)
+    rng = np.random.default_rng(2)
+    u = rng.standard_normal(lv[0].n)
+    r = rng.standard_normal(lv[1].n)
+    lhs, rhs = st.prolong(u) @ r, u @ st.restrict(r)
+    assert abs(lhs - rhs) < 1e-10 * max(abs(lhs), 1.0)
+
+
+def test_schoeberl_prolongation_preserves_cell_divergence(hier):
+    """Defining property of the robust prolongation: the divergence seen by the fine P0 space of P~ u_H equals the
+    coarse cell average of div u_H up to O(nu/gamma), whereas plain interpolation does not achieve that for the
+    enriched 3-D elements and leaves O(1) defects for general data."""
+    prob, k, lv, tr = hier
+    Vc, Vf = lv[0].V, lv[1].V
+    st = _oracle_transfer(lv, tr)
+    rng = np.random.default_rng(3)
+    u = rng.standard_normal(Vc.num_dofs)
+    u[lv[0].bc_dofs] = 0.0
+
+    def cell_div(V, x):
+        g, vol = V.mesh.cell_geometry()
+        bI = V.element.reference_tensors()["bI"]
+        b = np.einsum("cix,ai->cax", g, bI)                    # cell average of d_x phi_a
+        return np.einsum("cax,cax->c", b, x.reshape(-1, V.dim)[V.cell_nodes])
+    dc = cell_div(Vc, u)
+    df = cell_div(Vf, st.prolong(u))
+    defect = np.abs(df - dc[Vf.mesh.parent_cell]).max()
+    assert defect < 50 * (tr[-1].nu / tr[-1].gamma) * max(np.abs(dc).max(), 1.0) + 1e-9
+
+
+def test_coarse_blocks_are_disjoint_and_off_skeleton(hier):
+    prob, k, lv, tr = hier
+    V = lv[1].V
+    blk = tr[-1].blk_dofs
+    assert len(np.unique(blk)) == blk.size
+    skel = np.repeat(skeleton_node_mask(V), V.dim)
+    assert not skel[blk].any()
+    # every non-skeleton dof is in some block; all Dirichlet dofs are on the skeleton
+    assert blk.size == (~skel).sum()
+    assert skel[lv[1].bc_dofs].all()
+
+
+def test_bsr_helpers():
+    from alfi_amd.problem import BSR
+    rng = np.random.default_rng(0)
+    M = sp.random(12, 8, density=0.4, random_state=1, format="csr")
+    B = BSR.from_scipy(sp.kron(M, np.arange(1, 5).reshape(2, 2)), 2)
+    assert abs(B.transpose().to_scipy() - B.to_scipy().T).max() == 0
+    rows = np.array([5, 0, 3])
+    sub = B.select_rows(rows).to_scipy().toarray()
+    full = B.to_scipy().toarray().reshape(12, 2, -1)
+    assert np.array_equal(sub, full[rows].reshape(6, -1))
