@@ -1,0 +1,81 @@
+"""ctypes binding of libalfi_hip.so -- the product's only compute path.  Fails loudly when the library is missing or
+cannot be loaded; there is no CPU fallback (the oracle under oracle/ is test infrastructure and never imported here)."""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libalfi_hip.so")
+
+c_i32p = ctypes.POINTER(ctypes.c_int32)
+c_i64p = ctypes.POINTER(ctypes.c_int64)
+c_f64p = ctypes.POINTER(ctypes.c_double)
+vp = ctypes.c_void_p
+
+
+class BsrHost(ctypes.Structure):
+    _fields_ = [("nbrows", ctypes.c_int64), ("nbcols", ctypes.c_int64), ("rowptr", vp), ("colidx", vp), ("vals", vp)]
+
+
+# name -> (restype, argtypes); every symbol include/alfi_hip.h declares
+SIGNATURES = {
+    "alfi_ctx_create": (ctypes.c_int, [ctypes.c_int, vp, ctypes.POINTER(vp)]),
+    "alfi_ctx_destroy": (ctypes.c_int, [vp]),
+    "alfi_ctx_sync": (ctypes.c_int, [vp]),
+    "alfi_last_error": (ctypes.c_char_p, [vp]),
+    "alfi_malloc": (ctypes.c_int, [vp, ctypes.c_int64, ctypes.POINTER(vp)]),
+    "alfi_free": (ctypes.c_int, [vp, vp]),
+    "alfi_memcpy_h2d": (ctypes.c_int, [vp, vp, vp, ctypes.c_int64]),
+    "alfi_memcpy_d2h": (ctypes.c_int, [vp, vp, vp, ctypes.c_int64]),
+    "alfi_memset0": (ctypes.c_int, [vp, vp, ctypes.c_int64]),
+    "alfi_prof_enable": (ctypes.c_int, [vp, ctypes.c_int]),
+    "alfi_prof_reset": (ctypes.c_int, [vp]),
+    "alfi_prof_get": (ctypes.c_int, [vp, ctypes.c_int, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int64)]),
+    "alfi_level_create": (ctypes.c_int, [vp, ctypes.c_int64, ctypes.c_int, vp, vp, vp, vp, ctypes.c_int64,
+                                         ctypes.POINTER(vp)]),
+    "alfi_level_destroy": (ctypes.c_int, [vp]),
+    "alfi_level_update_values": (ctypes.c_int, [vp, vp]),
+    "alfi_level_size": (ctypes.c_int, [vp, ctypes.POINTER(ctypes.c_int64)]),
+    "alfi_spmv": (ctypes.c_int, [vp, vp, vp]),
+    "alfi_residual": (ctypes.c_int, [vp, vp, vp, vp]),
+    "alfi_patches_set": (ctypes.c_int, [vp, ctypes.c_int64, vp, vp]),
+    "alfi_patches_factor": (ctypes.c_int, [vp]),
+    "alfi_patch_apply": (ctypes.c_int, [vp, vp, vp]),
+    "alfi_patches_stats": (ctypes.c_int, [vp, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64),
+                                          ctypes.POINTER(ctypes.c_int64)]),
+    "alfi_patch_get_inverse": (ctypes.c_int, [vp, ctypes.c_int64, vp]),
+    "alfi_smooth_fgmres": (ctypes.c_int, [vp, ctypes.c_int, vp, vp, ctypes.c_int]),
+    "alfi_coarse_set_inverse": (ctypes.c_int, [vp, vp, ctypes.c_int]),
+    "alfi_coarse_solve": (ctypes.c_int, [vp, vp, vp]),
+    "alfi_transfer_create": (ctypes.c_int, [vp, vp, vp, ctypes.POINTER(BsrHost), ctypes.POINTER(BsrHost),
+                                            ctypes.POINTER(BsrHost), ctypes.POINTER(BsrHost), ctypes.POINTER(BsrHost),
+                                            ctypes.c_int64, ctypes.c_int, vp, vp, vp, ctypes.POINTER(vp)]),
+    "alfi_transfer_destroy": (ctypes.c_int, [vp]),
+    "alfi_transfer_update": (ctypes.c_int, [vp, ctypes.c_double, ctypes.c_double]),
+    "alfi_prolong": (ctypes.c_int, [vp, vp, vp]),
+    "alfi_restrict": (ctypes.c_int, [vp, vp, vp, ctypes.c_int]),
+    "alfi_mg_create": (ctypes.c_int, [vp, ctypes.c_int, ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.c_int,
+                                      ctypes.c_int, ctypes.POINTER(vp)]),
+    "alfi_mg_destroy": (ctypes.c_int, [vp]),
+    "alfi_mg_vcycle": (ctypes.c_int, [vp, vp, vp]),
+    "alfi_mg_fcycle": (ctypes.c_int, [vp, vp, vp]),
+}
+
+EVENTS = ["PATCH_APPLY", "PATCH_SCATTER", "PATCH_FACTOR", "MATMULT", "BLAS1", "PROLONG", "RESTRICT", "COARSE"]
+
+_lib = None
+
+
+def load():
+    """Load libalfi_hip.so (needs libamdhip64; works without a GPU, but every compute call then returns an error)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError("libalfi_hip.so is missing (%s): build it with `python -m alfi_amd.build`; "
+                           "alfi_amd has no CPU fallback" % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)      # AttributeError = ABI mismatch: fail loudly
+        fn.restype, fn.argtypes = res, args
+    _lib = lib
+    return lib

@@ -1,0 +1,670 @@
+// C ABI of libalfi_hip.so (include/alfi_hip.h): handles, device memory, and the stream-ordered orchestration of the
+// smoother (PETSc KSPFGMRES + PCPATCH), the Schoeberl transfers and the PCMG V / full cycles.  No host synchronisation
+// happens inside the smoother or the cycles: every scalar (norms, Hessenberg, Givens) stays on the device.
+#include <cmath>
+#include <cstdarg>
+#include <cstring>
+#include <algorithm>
+#include "common.h"
+#include "hs_layout.h"
+
+static thread_local std::string g_create_error;
+
+int alfi_set_error(alfi_ctx* ctx, int code, const char* fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  if (ctx)
+    ctx->err = buf;
+  else
+    g_create_error = buf;
+  return code;
+}
+
+// ---- profiling ---------------------------------------------------------------------------------------------------------
+int alfi_prof_begin(alfi_ctx* ctx, int kind) {
+  if (!ctx->prof) return -1;
+  if (ctx->ev_used == ctx->ev_pool.size()) {
+    alfi_ctx::EvPair p;
+    if (hipEventCreate(&p.a) != hipSuccess || hipEventCreate(&p.b) != hipSuccess) return -1;
+    ctx->ev_pool.push_back(p);
+  }
+  const int t = (int)ctx->ev_used++;
+  ctx->ev_pool[t].kind = kind;
+  (void)hipEventRecord(ctx->ev_pool[t].a, ctx->stream);
+  return t;
+}
+int alfi_prof_end(alfi_ctx* ctx, int token) {
+  if (token < 0) return 0;
+  (void)hipEventRecord(ctx->ev_pool[token].b, ctx->stream);
+  return 0;
+}
+
+template <typename T>
+static int dev_alloc(alfi_ctx* ctx, T** p, int64_t count) {
+  *p = nullptr;
+  if (count <= 0) count = 1;
+  ALFI_HIP_CHECK(ctx, hipMalloc((void**)p, (size_t)count * sizeof(T)));
+  return 0;
+}
+template <typename T>
+static int dev_upload(alfi_ctx* ctx, T** p, const T* host, int64_t count) {
+  ALFI_CHECK(dev_alloc(ctx, p, count));
+  if (count > 0) ALFI_HIP_CHECK(ctx, hipMemcpy(*p, host, (size_t)count * sizeof(T), hipMemcpyHostToDevice));
+  return 0;
+}
+static void dev_free(void* p) {
+  if (p) (void)hipFree(p);
+}
+
+static int upload_bsr(alfi_ctx* ctx, DevBSR* d, const alfi_bsr_host* h, int bs) {
+  d->nbrows = h->nbrows;
+  d->nbcols = h->nbcols;
+  d->bs = bs;
+  d->nnzb = h->rowptr[h->nbrows];
+  ALFI_CHECK(dev_upload(ctx, &d->rowptr, h->rowptr, h->nbrows + 1));
+  ALFI_CHECK(dev_upload(ctx, &d->colidx, h->colidx, d->nnzb));
+  ALFI_CHECK(dev_upload(ctx, &d->vals, h->vals, d->nnzb * bs * bs));
+  return 0;
+}
+static void free_bsr(DevBSR* d) {
+  dev_free(d->rowptr);
+  dev_free(d->colidx);
+  dev_free(d->vals);
+  *d = DevBSR();
+}
+
+extern "C" {
+
+// ---- context -------------------------------------------------------------------------------------------------------------
+int alfi_ctx_create(int device, void* stream, alfi_ctx** out) {
+  if (!out) return alfi_set_error(nullptr, ALFI_E_ARG, "out is NULL");
+  *out = nullptr;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+    return alfi_set_error(nullptr, ALFI_E_HIP, "no HIP device available");
+  if (device < 0 || device >= ndev) return alfi_set_error(nullptr, ALFI_E_ARG, "device %d out of range", device);
+  alfi_ctx* ctx = new alfi_ctx();
+  ctx->device = device;
+  if (hipSetDevice(device) != hipSuccess) {
+    delete ctx;
+    return alfi_set_error(nullptr, ALFI_E_HIP, "hipSetDevice(%d) failed", device);
+  }
+  if (stream) {
+    ctx->stream = (hipStream_t)stream;
+  } else {
+    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+      delete ctx;
+      return alfi_set_error(nullptr, ALFI_E_HIP, "hipStreamCreate failed");
+    }
+    ctx->own_stream = true;
+  }
+  if (hipMalloc((void**)&ctx->red_partial, sizeof(double) * RED_BLOCKS * RED_MAXV) != hipSuccess) {
+    delete ctx;
+    return alfi_set_error(nullptr, ALFI_E_HIP, "hipMalloc failed");
+  }
+  *out = ctx;
+  return 0;
+}
+
+int alfi_ctx_destroy(alfi_ctx* ctx) {
+  if (!ctx) return 0;
+  (void)hipStreamSynchronize(ctx->stream);
+  for (auto& p : ctx->ev_pool) {
+    (void)hipEventDestroy(p.a);
+    (void)hipEventDestroy(p.b);
+  }
+  dev_free(ctx->red_partial);
+  if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+  return 0;
+}
+
+int alfi_ctx_sync(alfi_ctx* ctx) {
+  ALFI_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  return 0;
+}
+
+const char* alfi_last_error(alfi_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+int alfi_malloc(alfi_ctx* ctx, int64_t bytes, void** dptr) {
+  ALFI_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  ALFI_HIP_CHECK(ctx, hipMalloc(dptr, (size_t)(bytes > 0 ? bytes : 8)));
+  return 0;
+}
+int alfi_free(alfi_ctx* ctx, void* dptr) {
+  if (dptr) ALFI_HIP_CHECK(ctx, hipFree(dptr));
+  return 0;
+}
+int alfi_memcpy_h2d(alfi_ctx* ctx, void* dst, const void* src, int64_t bytes) {
+  ALFI_HIP_CHECK(ctx, hipMemcpyAsync(dst, src, (size_t)bytes, hipMemcpyHostToDevice, ctx->stream));
+  ALFI_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  return 0;
+}
+int alfi_memcpy_d2h(alfi_ctx* ctx, void* dst, const void* src, int64_t bytes) {
+  ALFI_HIP_CHECK(ctx, hipMemcpyAsync(dst, src, (size_t)bytes, hipMemcpyDeviceToHost, ctx->stream));
+  ALFI_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  return 0;
+}
+int alfi_memset0(alfi_ctx* ctx, void* dst, int64_t bytes) {
+  ALFI_HIP_CHECK(ctx, hipMemsetAsync(dst, 0, (size_t)bytes, ctx->stream));
+  return 0;
+}
+
+int alfi_prof_enable(alfi_ctx* ctx, int on) {
+  ctx->prof = on != 0;
+  return 0;
+}
+int alfi_prof_reset(alfi_ctx* ctx) {
+  ALFI_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  ctx->ev_used = 0;
+  return 0;
+}
+int alfi_prof_get(alfi_ctx* ctx, int ev, double* total_ms, int64_t* count) {
+  ALFI_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  double tot = 0;
+  int64_t cnt = 0;
+  for (size_t i = 0; i < ctx->ev_used; ++i) {
+    if (ctx->ev_pool[i].kind != ev) continue;
+    float ms = 0;
+    ALFI_HIP_CHECK(ctx, hipEventElapsedTime(&ms, ctx->ev_pool[i].a, ctx->ev_pool[i].b));
+    tot += ms;
+    ++cnt;
+  }
+  if (total_ms) *total_ms = tot;
+  if (count) *count = cnt;
+  return 0;
+}
+
+// ---- level ---------------------------------------------------------------------------------------------------------------
+int alfi_level_create(alfi_ctx* ctx, int64_t nbrows, int bs, const int32_t* browptr, const int32_t* bcolidx,
+                      const double* bvals, const int32_t* bc_dofs, int64_t nbc, alfi_level** out) {
+  if (!ctx || !out || !browptr || !bcolidx || !bvals) return alfi_set_error(ctx, ALFI_E_ARG, "NULL argument");
+  if (bs != 2 && bs != 3) return alfi_set_error(ctx, ALFI_E_ARG, "block size must be 2 or 3, got %d", bs);
+  if (nbrows * bs > INT32_MAX) return alfi_set_error(ctx, ALFI_E_ARG, "level too large for int32 dof indices");
+  ALFI_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  alfi_level* L = new alfi_level();
+  L->ctx = ctx;
+  L->bs = bs;
+  L->n = nbrows * bs;
+  alfi_bsr_host h{nbrows, nbrows, browptr, bcolidx, bvals};
+  int rc = upload_bsr(ctx, &L->A, &h, bs);
+  if (rc == 0) rc = dev_upload(ctx, &L->bc_dofs, bc_dofs, nbc);
+  if (rc == 0) rc = dev_alloc(ctx, &L->status, 1);
+  if (rc == 0 && hipMemset(L->status, 0, sizeof(int)) != hipSuccess) rc = ALFI_E_HIP;
+  L->nbc = nbc;
+  if (rc != 0) {
+    alfi_level_destroy(L);
+    return rc;
+  }
+  *out = L;
+  return 0;
+}
+
+int alfi_level_destroy(alfi_level* L) {
+  if (!L) return 0;
+  (void)hipStreamSynchronize(L->ctx->stream);
+  free_bsr(&L->A);
+  dev_free(L->bc_dofs);
+  dev_free(L->patch_ptr);
+  dev_free(L->patch_dofs);
+  dev_free(L->inv_ptr);
+  dev_free(L->stage_ptr);
+  dev_free(L->inv);
+  dev_free(L->stage);
+  dev_free(L->dof_ptr);
+  dev_free(L->dof_pos);
+  dev_free(L->status);
+  dev_free(L->V);
+  dev_free(L->Z);
+  dev_free(L->w);
+  dev_free(L->hs);
+  if (L->cinv_owned) dev_free(L->cinv);
+  dev_free(L->mg_b);
+  dev_free(L->mg_x);
+  dev_free(L->mg_r);
+  delete L;
+  return 0;
+}
+
+int alfi_level_update_values(alfi_level* L, const double* bvals) {
+  alfi_ctx* ctx = L->ctx;
+  ALFI_HIP_CHECK(ctx, hipMemcpyAsync(L->A.vals, bvals, (size_t)L->A.nnzb * L->bs * L->bs * sizeof(double),
+                                     hipMemcpyHostToDevice, ctx->stream));
+  ALFI_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  L->factored = false;
+  return 0;
+}
+
+int alfi_level_size(alfi_level* L, int64_t* n) {
+  *n = L->n;
+  return 0;
+}
+
+int alfi_spmv(alfi_level* L, const double* dx, double* dy) {
+  int t = alfi_prof_begin(L->ctx, ALFI_EV_MATMULT);
+  ALFI_CHECK(launch_bsr_spmv(L->ctx, L->A, dx, dy, nullptr, 0.0, 0));
+  alfi_prof_end(L->ctx, t);
+  return 0;
+}
+
+int alfi_residual(alfi_level* L, const double* db, const double* dx, double* dr) {
+  int t = alfi_prof_begin(L->ctx, ALFI_EV_MATMULT);
+  ALFI_CHECK(launch_bsr_spmv(L->ctx, L->A, dx, dr, db, 1.0, 1));
+  alfi_prof_end(L->ctx, t);
+  return 0;
+}
+
+// ---- patches -------------------------------------------------------------------------------------------------------------
+int alfi_patches_set(alfi_level* L, int64_t npatch, const int64_t* pptr, const int32_t* pdofs) {
+  alfi_ctx* ctx = L->ctx;
+  if (npatch < 0 || (npatch > 0 && (!pptr || !pdofs))) return alfi_set_error(ctx, ALFI_E_ARG, "NULL patch arrays");
+  ALFI_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  ALFI_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  dev_free(L->patch_ptr);
+  dev_free(L->patch_dofs);
+  dev_free(L->inv_ptr);
+  dev_free(L->stage_ptr);
+  dev_free(L->inv);
+  dev_free(L->stage);
+  dev_free(L->dof_ptr);
+  dev_free(L->dof_pos);
+  L->patch_ptr = nullptr; L->patch_dofs = nullptr; L->inv_ptr = nullptr; L->stage_ptr = nullptr;
+  L->inv = nullptr; L->stage = nullptr; L->dof_ptr = nullptr; L->dof_pos = nullptr;
+  L->factored = false;
+  L->npatch = npatch;
+  const int64_t sum_n = npatch > 0 ? pptr[npatch] : 0;
+  if (sum_n > INT32_MAX) return alfi_set_error(ctx, ALFI_E_ARG, "too many patch dofs for int32 staging indices");
+  std::vector<int64_t> inv_ptr(npatch + 1), stage_ptr(npatch + 1);
+  int64_t ip = 0, sp = 0, sum_n2 = 0;
+  int max_np = 0;
+  for (int64_t p = 0; p < npatch; ++p) {
+    const int64_t n = pptr[p + 1] - pptr[p];
+    if (n <= 0 || n > 160)
+      return alfi_set_error(ctx, ALFI_E_ARG, "patch %lld has %lld dofs; supported range is 1..160", (long long)p,
+                            (long long)n);
+    for (int64_t q = pptr[p]; q < pptr[p + 1]; ++q) {
+      if (pdofs[q] < 0 || pdofs[q] >= L->n)
+        return alfi_set_error(ctx, ALFI_E_ARG, "patch %lld: dof %d out of range", (long long)p, pdofs[q]);
+      if (q > pptr[p] && pdofs[q] <= pdofs[q - 1])
+        return alfi_set_error(ctx, ALFI_E_ARG, "patch %lld: dofs must be strictly ascending", (long long)p);
+    }
+    const int64_t ld = (n + 1) & ~(int64_t)1;
+    inv_ptr[p] = ip;
+    stage_ptr[p] = sp;
+    ip += (n * ld + 15) & ~(int64_t)15;
+    sp += ld;
+    sum_n2 += n * n;
+    max_np = std::max<int>(max_np, (int)n);
+  }
+  inv_ptr[npatch] = ip;
+  stage_ptr[npatch] = sp;
+  if (sp > INT32_MAX) return alfi_set_error(ctx, ALFI_E_ARG, "staging buffer exceeds int32 indexing");
+  L->sum_n = sum_n;
+  L->sum_n2 = sum_n2;
+  L->max_np = max_np;
+  L->inv_doubles = ip;
+  L->stage_len = sp;
+  // dof -> staged positions (counting sort; patch order = fixed summation order)
+  std::vector<int32_t> dof_ptr(L->n + 1, 0), dof_pos(sum_n > 0 ? sum_n : 1);
+  for (int64_t q = 0; q < sum_n; ++q) dof_ptr[pdofs[q] + 1]++;
+  for (int64_t i = 0; i < L->n; ++i) dof_ptr[i + 1] += dof_ptr[i];
+  {
+    std::vector<int32_t> fill(dof_ptr.begin(), dof_ptr.end() - 1);
+    for (int64_t p = 0; p < npatch; ++p)
+      for (int64_t q = pptr[p]; q < pptr[p + 1]; ++q)
+        dof_pos[fill[pdofs[q]]++] = (int32_t)(stage_ptr[p] + (q - pptr[p]));
+  }
+  ALFI_CHECK(dev_upload(ctx, &L->patch_ptr, pptr, npatch + 1));
+  ALFI_CHECK(dev_upload(ctx, &L->patch_dofs, pdofs, sum_n));
+  ALFI_CHECK(dev_upload(ctx, &L->inv_ptr, inv_ptr.data(), npatch + 1));
+  ALFI_CHECK(dev_upload(ctx, &L->stage_ptr, stage_ptr.data(), npatch + 1));
+  ALFI_CHECK(dev_upload(ctx, &L->dof_ptr, dof_ptr.data(), L->n + 1));
+  ALFI_CHECK(dev_upload(ctx, &L->dof_pos, dof_pos.data(), sum_n));
+  ALFI_CHECK(dev_alloc(ctx, &L->inv, ip));
+  ALFI_CHECK(dev_alloc(ctx, &L->stage, sp));
+  ALFI_HIP_CHECK(ctx, hipMemset(L->stage, 0, (size_t)std::max<int64_t>(sp, 1) * sizeof(double)));
+  L->h_patch_ptr.assign(pptr, pptr + npatch + 1);
+  L->h_inv_ptr = inv_ptr;
+  return 0;
+}
+
+int alfi_patches_factor(alfi_level* L) {
+  alfi_ctx* ctx = L->ctx;
+  if (!L->patch_ptr) return alfi_set_error(ctx, ALFI_E_STATE, "alfi_patches_factor before alfi_patches_set");
+  int t = alfi_prof_begin(ctx, ALFI_EV_PATCH_FACTOR);
+  ALFI_HIP_CHECK(ctx, hipMemsetAsync(L->status, 0, sizeof(int), ctx->stream));
+  ALFI_CHECK(launch_patch_gather_dense(L));
+  ALFI_CHECK(launch_patch_invert(L));
+  alfi_prof_end(ctx, t);
+  int st = 0;
+  ALFI_HIP_CHECK(ctx, hipMemcpyAsync(&st, L->status, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+  ALFI_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  if (st != 0) return alfi_set_error(ctx, ALFI_E_SINGULAR, "zero pivot while inverting a patch operator");
+  L->factored = true;
+  return 0;
+}
+
+int alfi_patch_apply(alfi_level* L, const double* dx, double* dy) {
+  if (!L->factored) return alfi_set_error(L->ctx, ALFI_E_STATE, "alfi_patch_apply before alfi_patches_factor");
+  if (dx == dy) return alfi_set_error(L->ctx, ALFI_E_ARG, "alfi_patch_apply: x and y must not alias");
+  return launch_patch_apply(L, dx, dy);
+}
+
+int alfi_patches_stats(alfi_level* L, int64_t* npatch, int64_t* sum_n, int64_t* sum_n2) {
+  if (npatch) *npatch = L->npatch;
+  if (sum_n) *sum_n = L->sum_n;
+  if (sum_n2) *sum_n2 = L->sum_n2;
+  return 0;
+}
+
+int alfi_patch_get_inverse(alfi_level* L, int64_t p, double* out) {
+  alfi_ctx* ctx = L->ctx;
+  if (!L->factored) return alfi_set_error(ctx, ALFI_E_STATE, "patches not factored");
+  if (p < 0 || p >= L->npatch) return alfi_set_error(ctx, ALFI_E_ARG, "patch index out of range");
+  const int64_t n = L->h_patch_ptr[p + 1] - L->h_patch_ptr[p];
+  const int64_t ld = (n + 1) & ~(int64_t)1;
+  std::vector<double> tmp(n * ld);
+  ALFI_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  ALFI_HIP_CHECK(ctx, hipMemcpy(tmp.data(), L->inv + L->h_inv_ptr[p], tmp.size() * sizeof(double),
+                                hipMemcpyDeviceToHost));
+  for (int64_t i = 0; i < n; ++i)
+    for (int64_t j = 0; j < n; ++j) out[i * n + j] = tmp[j * ld + i];
+  return 0;
+}
+
+// ---- FGMRES(k) smoother ----------------------------------------------------------------------------------------------------
+static int ensure_fgmres_workspace(alfi_level* L, int k) {
+  alfi_ctx* ctx = L->ctx;
+  if (k <= L->kmax) return 0;
+  if (k > RED_MAXV - 1) return alfi_set_error(ctx, ALFI_E_ARG, "k = %d exceeds the supported maximum %d", k, RED_MAXV - 1);
+  ALFI_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  dev_free(L->V);
+  dev_free(L->Z);
+  dev_free(L->w);
+  dev_free(L->hs);
+  L->V = L->Z = L->w = L->hs = nullptr;
+  L->kmax = 0;
+  ALFI_CHECK(dev_alloc(ctx, &L->V, (int64_t)(k + 1) * L->n));
+  ALFI_CHECK(dev_alloc(ctx, &L->Z, (int64_t)k * L->n));
+  ALFI_CHECK(dev_alloc(ctx, &L->w, L->n));
+  HsLayout hl(k);
+  ALFI_CHECK(dev_alloc(ctx, &L->hs, hl.total));
+  ALFI_HIP_CHECK(ctx, hipMemset(L->hs, 0, sizeof(double) * hl.total));
+  L->kmax = k;
+  return 0;
+}
+
+int alfi_smooth_fgmres(alfi_level* L, int k, const double* db, double* dx, int nonzero_guess) {
+  alfi_ctx* ctx = L->ctx;
+  if (k < 1) return alfi_set_error(ctx, ALFI_E_ARG, "k must be >= 1");
+  if (!L->factored) return alfi_set_error(ctx, ALFI_E_STATE, "alfi_smooth_fgmres before alfi_patches_factor");
+  ALFI_CHECK(ensure_fgmres_workspace(L, k));
+  const int K = L->kmax;
+  const int64_t n = L->n;
+  HsLayout hl(K);
+  double* V = L->V;
+  double* Z = L->Z;
+  double* w = L->w;
+  double* hs = L->hs;
+  int t;
+  // r0 = b - A x (MatMult), beta = |r0|, v0 = r0 / beta
+  if (nonzero_guess) {
+    ALFI_CHECK(alfi_residual(L, db, dx, w));
+  } else {
+    ALFI_HIP_CHECK(ctx, hipMemsetAsync(dx, 0, sizeof(double) * n, ctx->stream));
+    t = alfi_prof_begin(ctx, ALFI_EV_BLAS1);
+    ALFI_CHECK(launch_copy(ctx, w, db, n));
+    alfi_prof_end(ctx, t);
+  }
+  t = alfi_prof_begin(ctx, ALFI_EV_BLAS1);
+  ALFI_CHECK(launch_norm_init(ctx, w, hs, K, n));
+  ALFI_CHECK(launch_scale_by_inv(ctx, V, w, hs + hl.beta, n));
+  alfi_prof_end(ctx, t);
+  for (int j = 0; j < k; ++j) {
+    ALFI_CHECK(launch_patch_apply(L, V + (int64_t)j * n, Z + (int64_t)j * n));   // z_j = M^-1 v_j
+    ALFI_CHECK(alfi_spmv(L, Z + (int64_t)j * n, w));                              // w = A z_j
+    t = alfi_prof_begin(ctx, ALFI_EV_BLAS1);
+    ALFI_CHECK(launch_multi_dot(ctx, V, n, j + 1, w, hs + hl.hd, n));             // h = V^T w (classical GS)
+    ALFI_CHECK(launch_multi_axpy_norm(ctx, V, n, j + 1, hs + hl.hd, w, hs, j, K, n));  // w -= V h, |w|, Givens
+    if (j + 1 < k) ALFI_CHECK(launch_scale_by_inv(ctx, V + (int64_t)(j + 1) * n, w, hs + hl.tt, n));
+    alfi_prof_end(ctx, t);
+  }
+  t = alfi_prof_begin(ctx, ALFI_EV_BLAS1);
+  ALFI_CHECK(launch_fgmres_finish(ctx, hs, k, K));
+  ALFI_CHECK(launch_update_solution(ctx, dx, Z, n, k, hs + hl.y, n));
+  alfi_prof_end(ctx, t);
+  return 0;
+}
+
+// ---- coarse solve ------------------------------------------------------------------------------------------------------------
+int alfi_coarse_set_inverse(alfi_level* L, const double* inv, int inv_is_device) {
+  alfi_ctx* ctx = L->ctx;
+  ALFI_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  if (L->cinv_owned) dev_free(L->cinv);
+  L->cinv = nullptr;
+  L->cinv_owned = false;
+  if (inv_is_device) {
+    L->cinv = const_cast<double*>(inv);
+  } else {
+    ALFI_CHECK(dev_upload(ctx, &L->cinv, inv, L->n * L->n));
+    L->cinv_owned = true;
+  }
+  return 0;
+}
+
+int alfi_coarse_solve(alfi_level* L, const double* db, double* dx) {
+  if (!L->cinv) return alfi_set_error(L->ctx, ALFI_E_STATE, "alfi_coarse_solve before alfi_coarse_set_inverse");
+  int t = alfi_prof_begin(L->ctx, ALFI_EV_COARSE);
+  ALFI_CHECK(launch_dense_gemv(L->ctx, L->cinv, db, dx, L->n));
+  alfi_prof_end(L->ctx, t);
+  return 0;
+}
+
+// ---- transfer ------------------------------------------------------------------------------------------------------------------
+int alfi_transfer_create(alfi_ctx* ctx, alfi_level* coarse, alfi_level* fine, const alfi_bsr_host* P,
+                         const alfi_bsr_host* PT, const alfi_bsr_host* PT_plain, const alfi_bsr_host* D_I,
+                         const alfi_bsr_host* D_IT, int64_t nblk, int m, const int32_t* blk_dofs, const double* K_II,
+                         const double* D_II, alfi_transfer** out) {
+  if (!ctx || !coarse || !fine || !P || !PT || !D_I || !D_IT || !blk_dofs || !K_II || !D_II || !out)
+    return alfi_set_error(ctx, ALFI_E_ARG, "NULL argument");
+  const int bs = fine->bs;
+  if (coarse->bs != bs) return alfi_set_error(ctx, ALFI_E_ARG, "block size mismatch");
+  if (m < 1 || m > 32) return alfi_set_error(ctx, ALFI_E_ARG, "interior block size %d not in 1..32", m);
+  if (P->nbrows * bs != fine->n || P->nbcols * bs != coarse->n || PT->nbrows * bs != coarse->n ||
+      PT->nbcols * bs != fine->n)
+    return alfi_set_error(ctx, ALFI_E_ARG, "prolongation shape does not match the levels");
+  if ((nblk * m) % bs != 0 || D_I->nbrows * bs != nblk * m || D_I->nbcols * bs != fine->n ||
+      D_IT->nbrows * bs != fine->n || D_IT->nbcols * bs != nblk * m)
+    return alfi_set_error(ctx, ALFI_E_ARG, "grad-div interior rows shape mismatch");
+  for (int64_t i = 0; i < nblk * m; ++i)
+    if (blk_dofs[i] < 0 || blk_dofs[i] >= fine->n) return alfi_set_error(ctx, ALFI_E_ARG, "blk_dofs out of range");
+  ALFI_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  alfi_transfer* T = new alfi_transfer();
+  T->ctx = ctx;
+  T->coarse = coarse;
+  T->fine = fine;
+  T->bs = bs;
+  T->nblk = nblk;
+  T->m = m;
+  T->ld = (m + 1) & ~1;
+  int rc = upload_bsr(ctx, &T->P, P, bs);
+  if (rc == 0) rc = upload_bsr(ctx, &T->PT, PT, bs);
+  if (rc == 0) {
+    if (PT_plain) {
+      rc = upload_bsr(ctx, &T->PTp, PT_plain, bs);
+    } else {
+      T->PTp = T->PT;
+      T->ptp_alias = true;
+    }
+  }
+  if (rc == 0) rc = upload_bsr(ctx, &T->DI, D_I, bs);
+  if (rc == 0) rc = upload_bsr(ctx, &T->DIT, D_IT, bs);
+  if (rc == 0) rc = dev_upload(ctx, &T->blk_dofs, blk_dofs, nblk * m);
+  if (rc == 0) rc = dev_upload(ctx, &T->KII, K_II, nblk * m * m);
+  if (rc == 0) rc = dev_upload(ctx, &T->DII, D_II, nblk * m * m);
+  if (rc == 0) rc = dev_alloc(ctx, &T->binv, nblk * m * T->ld);
+  if (rc == 0) rc = dev_alloc(ctx, &T->tI, nblk * m);
+  if (rc == 0) rc = dev_alloc(ctx, &T->bI, nblk * m);
+  if (rc == 0) rc = dev_alloc(ctx, &T->tmp_f, fine->n);
+  if (rc == 0) rc = dev_alloc(ctx, &T->status, 1);
+  if (rc != 0) {
+    alfi_transfer_destroy(T);
+    return rc;
+  }
+  *out = T;
+  return 0;
+}
+
+int alfi_transfer_destroy(alfi_transfer* T) {
+  if (!T) return 0;
+  (void)hipStreamSynchronize(T->ctx->stream);
+  free_bsr(&T->P);
+  free_bsr(&T->PT);
+  if (!T->ptp_alias) free_bsr(&T->PTp);
+  free_bsr(&T->DI);
+  free_bsr(&T->DIT);
+  dev_free(T->blk_dofs);
+  dev_free(T->KII);
+  dev_free(T->DII);
+  dev_free(T->binv);
+  dev_free(T->tI);
+  dev_free(T->bI);
+  dev_free(T->tmp_f);
+  dev_free(T->status);
+  delete T;
+  return 0;
+}
+
+int alfi_transfer_update(alfi_transfer* T, double nu, double gamma) {
+  alfi_ctx* ctx = T->ctx;
+  T->nu = nu;
+  T->gamma = gamma;
+  ALFI_HIP_CHECK(ctx, hipMemsetAsync(T->status, 0, sizeof(int), ctx->stream));
+  ALFI_CHECK(launch_block_build_invert(T));
+  int st = 0;
+  ALFI_HIP_CHECK(ctx, hipMemcpyAsync(&st, T->status, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+  ALFI_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  if (st != 0) return alfi_set_error(ctx, ALFI_E_SINGULAR, "zero pivot while inverting a coarse-cell interior block");
+  T->ready = true;
+  return 0;
+}
+
+int alfi_prolong(alfi_transfer* T, const double* dxc, double* dxf) {
+  alfi_ctx* ctx = T->ctx;
+  if (!T->ready) return alfi_set_error(ctx, ALFI_E_STATE, "alfi_prolong before alfi_transfer_update");
+  int t = alfi_prof_begin(ctx, ALFI_EV_PROLONG);
+  ALFI_CHECK(launch_bsr_spmv(ctx, T->P, dxc, dxf, nullptr, 0.0, 0));                 // rhs = P coarse        :247
+  ALFI_CHECK(launch_bsr_spmv(ctx, T->DI, dxf, T->bI, nullptr, 0.0, 0));              // b_I = (D rhs)_I       :249
+  ALFI_CHECK(launch_block_gemv(T, T->bI, T->tI, false));                              // t = inv(A_II) b_I     :254-257
+  ALFI_CHECK(launch_scatter_sub(ctx, dxf, T->blk_dofs, T->tI, T->gamma, T->nblk * T->m));  // fine = rhs - gamma t  :259
+  ALFI_CHECK(launch_zero_dofs(ctx, dxf, T->fine->bc_dofs, T->fine->nbc));
+  alfi_prof_end(ctx, t);
+  return 0;
+}
+
+int alfi_restrict(alfi_transfer* T, const double* drf, double* drc, int robust) {
+  alfi_ctx* ctx = T->ctx;
+  if (robust && !T->ready) return alfi_set_error(ctx, ALFI_E_STATE, "alfi_restrict before alfi_transfer_update");
+  int t = alfi_prof_begin(ctx, ALFI_EV_RESTRICT);
+  if (robust) {
+    ALFI_CHECK(launch_block_gemv(T, drf, T->tI, true));                               // t = inv(A_II) r_I     :265-270
+    ALFI_CHECK(launch_bsr_spmv(ctx, T->DIT, T->tI, T->tmp_f, drf, T->gamma, 1));      // s = r - gamma D t     :272-274
+    ALFI_CHECK(launch_bsr_spmv(ctx, T->PT, T->tmp_f, drc, nullptr, 0.0, 0));          // coarse = P^T s        :275
+  } else {
+    ALFI_CHECK(launch_bsr_spmv(ctx, T->PTp, drf, drc, nullptr, 0.0, 0));              // firedrake.restrict
+  }
+  ALFI_CHECK(launch_zero_dofs(ctx, drc, T->coarse->bc_dofs, T->coarse->nbc));
+  alfi_prof_end(ctx, t);
+  return 0;
+}
+
+// ---- multigrid --------------------------------------------------------------------------------------------------------------------
+int alfi_mg_create(alfi_ctx* ctx, int nlevels, alfi_level** levels, alfi_transfer** transfers, int k,
+                   int robust_restriction, alfi_mg** out) {
+  if (!ctx || nlevels < 1 || !levels || (nlevels > 1 && !transfers) || !out)
+    return alfi_set_error(ctx, ALFI_E_ARG, "bad arguments");
+  for (int l = 1; l < nlevels; ++l) {
+    if (transfers[l - 1]->coarse != levels[l - 1] || transfers[l - 1]->fine != levels[l])
+      return alfi_set_error(ctx, ALFI_E_ARG, "transfer %d does not link levels %d and %d", l - 1, l - 1, l);
+    if (!levels[l]->factored) return alfi_set_error(ctx, ALFI_E_STATE, "level %d: patches not factored", l);
+  }
+  if (!levels[0]->cinv) return alfi_set_error(ctx, ALFI_E_STATE, "coarse level has no inverse");
+  alfi_mg* mg = new alfi_mg();
+  mg->ctx = ctx;
+  mg->levels.assign(levels, levels + nlevels);
+  if (nlevels > 1) mg->transfers.assign(transfers, transfers + nlevels - 1);
+  mg->k = k;
+  mg->robust = robust_restriction;
+  for (int l = 0; l < nlevels; ++l) {
+    alfi_level* L = levels[l];
+    int rc = 0;
+    if (!L->mg_b) rc = dev_alloc(ctx, &L->mg_b, L->n);
+    if (rc == 0 && !L->mg_x) rc = dev_alloc(ctx, &L->mg_x, L->n);
+    if (rc == 0 && !L->mg_r) rc = dev_alloc(ctx, &L->mg_r, L->n);
+    if (rc == 0 && l > 0) rc = ensure_fgmres_workspace(L, k);
+    if (rc != 0) {
+      delete mg;
+      return rc;
+    }
+  }
+  *out = mg;
+  return 0;
+}
+
+int alfi_mg_destroy(alfi_mg* mg) {
+  delete mg;
+  return 0;
+}
+
+// PCMGMCycle_Private [3P]: x_l <- V(b_l, x_l)
+static int vcycle(alfi_mg* mg, int l, const double* b, double* x) {
+  alfi_ctx* ctx = mg->ctx;
+  alfi_level* L = mg->levels[l];
+  if (l == 0) return alfi_coarse_solve(L, b, x);
+  alfi_level* C = mg->levels[l - 1];
+  alfi_transfer* T = mg->transfers[l - 1];
+  ALFI_CHECK(alfi_smooth_fgmres(L, mg->k, b, x, 1));                 // pre-smooth
+  ALFI_CHECK(alfi_residual(L, b, x, L->mg_r));                       // r = b - A x
+  ALFI_CHECK(alfi_restrict(T, L->mg_r, C->mg_b, mg->robust));        // b_{l-1} = R r
+  ALFI_HIP_CHECK(ctx, hipMemsetAsync(C->mg_x, 0, sizeof(double) * C->n, ctx->stream));
+  ALFI_CHECK(vcycle(mg, l - 1, C->mg_b, C->mg_x));
+  ALFI_CHECK(alfi_prolong(T, C->mg_x, L->mg_r));                     // x += P x_{l-1}
+  int t = alfi_prof_begin(ctx, ALFI_EV_BLAS1);
+  ALFI_CHECK(launch_axpy(ctx, x, L->mg_r, 1.0, L->n));
+  alfi_prof_end(ctx, t);
+  ALFI_CHECK(alfi_smooth_fgmres(L, mg->k, b, x, 1));                 // post-smooth
+  return 0;
+}
+
+int alfi_mg_vcycle(alfi_mg* mg, const double* db, double* dx) {
+  return vcycle(mg, (int)mg->levels.size() - 1, db, dx);
+}
+
+// PCMGFCycle_Private [3P]
+int alfi_mg_fcycle(alfi_mg* mg, const double* db, double* dx) {
+  alfi_ctx* ctx = mg->ctx;
+  const int Lmax = (int)mg->levels.size() - 1;
+  if (Lmax == 0) return alfi_coarse_solve(mg->levels[0], db, dx);
+  // restrict the right-hand side through all levels
+  const double* bf = db;
+  for (int l = Lmax; l >= 1; --l) {
+    ALFI_CHECK(alfi_restrict(mg->transfers[l - 1], bf, mg->levels[l - 1]->mg_b, mg->robust));
+    bf = mg->levels[l - 1]->mg_b;
+  }
+  ALFI_HIP_CHECK(ctx, hipMemsetAsync(mg->levels[0]->mg_x, 0, sizeof(double) * mg->levels[0]->n, ctx->stream));
+  for (int l = 0; l < Lmax; ++l) {
+    alfi_level* L = mg->levels[l];
+    // note: inside vcycle(l) the coarser levels' mg_b / mg_x are overwritten; level l's own b must survive, and it
+    // does: vcycle(l) only writes mg_b of levels < l.  But the restricted rhs of levels < l is then gone -- it is
+    // not needed any more at that point (levels are visited in increasing order).
+    ALFI_CHECK(vcycle(mg, l, L->mg_b, L->mg_x));
+    double* xnext = (l + 1 == Lmax) ? dx : mg->levels[l + 1]->mg_x;
+    ALFI_CHECK(alfi_prolong(mg->transfers[l], L->mg_x, xnext));
+  }
+  return vcycle(mg, Lmax, db, dx);
+}
+
+}  // extern "C"

@@ -1,0 +1,144 @@
+// Internal structures of libalfi_hip.so (not part of the ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <string>
+#include <vector>
+#include "alfi_hip.h"
+
+struct alfi_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  std::string err;
+  // profiling
+  bool prof = false;
+  struct EvPair {
+    hipEvent_t a, b;
+    int kind;
+  };
+  std::vector<EvPair> ev_pool;   // all created pairs
+  size_t ev_used = 0;            // pairs in use since last reset
+  // scratch for reductions: partial sums [RED_BLOCKS][RED_MAXV]
+  double* red_partial = nullptr;
+};
+
+constexpr int RED_BLOCKS = 1024;  // blocks used by the two-stage dot/norm reductions
+constexpr int RED_MAXV = 32;      // max simultaneous dot products
+
+int alfi_set_error(alfi_ctx* ctx, int code, const char* fmt, ...);
+
+#define ALFI_HIP_CHECK(ctx, call)                                                                      \
+  do {                                                                                                 \
+    hipError_t e_ = (call);                                                                            \
+    if (e_ != hipSuccess)                                                                              \
+      return alfi_set_error(ctx, ALFI_E_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_),    \
+                            __FILE__, __LINE__);                                                       \
+  } while (0)
+
+#define ALFI_CHECK(expr)     \
+  do {                       \
+    int rc_ = (expr);        \
+    if (rc_ != 0) return rc_; \
+  } while (0)
+
+// RAII-less profiling scope: begin/end record events on the ctx stream when profiling is on.
+int alfi_prof_begin(alfi_ctx* ctx, int kind);
+int alfi_prof_end(alfi_ctx* ctx, int token);
+
+struct DevBSR {
+  int64_t nbrows = 0, nbcols = 0, nnzb = 0;
+  int bs = 0;
+  int32_t* rowptr = nullptr;
+  int32_t* colidx = nullptr;
+  double* vals = nullptr;
+};
+
+struct alfi_level {
+  alfi_ctx* ctx = nullptr;
+  int64_t n = 0;  // scalar dofs
+  int bs = 0;
+  DevBSR A;
+  int32_t* bc_dofs = nullptr;
+  int64_t nbc = 0;
+  // patches
+  int64_t npatch = 0, sum_n = 0, sum_n2 = 0, inv_doubles = 0;
+  int max_np = 0;
+  int64_t* patch_ptr = nullptr;   // (npatch+1) offsets into patch_dofs / staging buffer
+  int32_t* patch_dofs = nullptr;  // (sum_n)
+  int64_t* inv_ptr = nullptr;     // (npatch+1) offsets (doubles) into inv
+  int64_t* stage_ptr = nullptr;   // (npatch+1) offsets into stage (ld_p slots per patch, so 16-byte aligned)
+  double* inv = nullptr;          // column-major padded inverses
+  double* stage = nullptr;        // (sum ld_p) staged patch results
+  int64_t stage_len = 0;
+  int32_t* dof_ptr = nullptr;     // (n+1) CSR dof -> positions in stage
+  int32_t* dof_pos = nullptr;     // (sum_n)
+  bool factored = false;
+  int* status = nullptr;          // device flag: nonzero if a zero pivot was met
+  // FGMRES workspace
+  int kmax = 0;
+  double* V = nullptr;   // (kmax+1) x n
+  double* Z = nullptr;   // kmax x n
+  double* w = nullptr;   // n
+  double* hs = nullptr;  // small device arrays: Hessenberg etc.
+  // coarse dense inverse
+  double* cinv = nullptr;
+  bool cinv_owned = false;
+  // multigrid work vectors (owned by alfi_mg but stored per level)
+  double *mg_b = nullptr, *mg_x = nullptr, *mg_r = nullptr;
+  std::vector<int64_t> h_patch_ptr;  // host copy (for get_inverse)
+  std::vector<int64_t> h_inv_ptr;
+};
+
+struct alfi_transfer {
+  alfi_ctx* ctx = nullptr;
+  alfi_level *coarse = nullptr, *fine = nullptr;
+  int bs = 0;
+  DevBSR P, PT, PTp, DI, DIT;
+  bool ptp_alias = false;
+  int64_t nblk = 0;
+  int m = 0, ld = 0;
+  int32_t* blk_dofs = nullptr;  // (nblk*m)
+  double *KII = nullptr, *DII = nullptr;
+  double* binv = nullptr;  // (nblk, m cols, ld) column-major padded inverses
+  double *tI = nullptr, *bI = nullptr;  // compact interior vectors (nblk*m)
+  double* tmp_f = nullptr;              // fine work vector
+  double gamma = 0, nu = 0;
+  bool ready = false;
+  int* status = nullptr;
+};
+
+struct alfi_mg {
+  alfi_ctx* ctx = nullptr;
+  std::vector<alfi_level*> levels;
+  std::vector<alfi_transfer*> transfers;
+  int k = 0;
+  int robust = 0;
+};
+
+// ---- kernel launch wrappers (defined in the .hip files) --------------------------------------------------------------
+// y = A x (mode 0) or y = b - alpha * A x (mode 1)
+int launch_bsr_spmv(alfi_ctx* ctx, const DevBSR& A, const double* x, double* y, const double* b, double alpha, int mode);
+int launch_patch_gather_dense(alfi_level* lvl);
+int launch_patch_invert(alfi_level* lvl);
+int launch_patch_apply(alfi_level* lvl, const double* x, double* y);
+int launch_invert_small_any(alfi_ctx* ctx, int nmax, int64_t nmat, const int64_t* ptr, const int64_t* inv_ptr,
+                            int fixed_n, int64_t fixed_stride, double* inv, int* status);
+int launch_block_build_invert(alfi_transfer* tr);
+// out_compact = binv * in;  gather != nullptr: in is a level vector indexed through blk_dofs
+int launch_block_gemv(alfi_transfer* tr, const double* in, double* out, bool gather_in);
+int launch_scatter_sub(alfi_ctx* ctx, double* x, const int32_t* idx, const double* t, double alpha, int64_t n);
+int launch_zero_dofs(alfi_ctx* ctx, double* x, const int32_t* idx, int64_t n);
+int launch_copy_dofs(alfi_ctx* ctx, double* y, const double* x, const int32_t* idx, int64_t n);
+int launch_dense_gemv(alfi_ctx* ctx, const double* A, const double* x, double* y, int64_t n);
+// blas1
+int launch_copy(alfi_ctx* ctx, double* y, const double* x, int64_t n);
+int launch_axpy(alfi_ctx* ctx, double* y, const double* x, double a, int64_t n);                 // y += a x
+int launch_norm_init(alfi_ctx* ctx, const double* r, double* hs, int K, int64_t n);  // beta = |r|, grs = beta e_1
+int launch_scale_by_inv(alfi_ctx* ctx, double* v, const double* w, const double* scal, int64_t n);  // v = w / *scal
+int launch_multi_dot(alfi_ctx* ctx, const double* V, int64_t stride, int nv, const double* w, double* out, int64_t n);
+int launch_multi_axpy_norm(alfi_ctx* ctx, const double* V, int64_t stride, int nv, const double* h, double* w,
+                           double* hs, int j, int k, int64_t n);
+int launch_fgmres_finish(alfi_ctx* ctx, double* hs, int k, int K);  // back substitution -> y
+int launch_update_solution(alfi_ctx* ctx, double* x, const double* Z, int64_t stride, int k, const double* y, int64_t n);

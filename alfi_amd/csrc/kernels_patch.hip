@@ -1,0 +1,362 @@
+// Patch smoother kernels for gfx950 (wave64): PCPATCH setup (gather + dense inversion) and additive apply.
+//
+// Storage of the inverses (owned layout, chosen for the apply kernel): patch p holds an n_p x n_p inverse in
+// column-major order with leading dimension ld_p = n_p rounded up to even, at inv + inv_ptr[p] (inv_ptr is a multiple
+// of 16 doubles), so that lane l of a wave reads rows (2l, 2l+1) of one column as one aligned 16-byte load and a wave
+// reads 1 KiB contiguous per instruction.  y_p = inv(A_p) x_p then needs no cross-lane reduction: each lane pair of
+// rows accumulates over the columns, x_p is broadcast from LDS.
+//
+// Roofline: apply is a GEMV streaming every inverse once (0.25 flop/B) -> HBM-bound; algorithmic bytes per patch
+// 8 n_p^2 + 28 n_p.  Inversion is 2 n_p^3 flops per patch in FP64; gfx950's FP64 MFMA rate
+// equals its FP64 vector rate (78.6 TF), so the inversion runs as a register-tiled Gauss-Jordan on the vector ALUs.
+#include "common.h"
+
+// ---------------------------------------------------------------------------------------------------------------------
+// 1. gather A_p = A[dofs_p, dofs_p] from the BSR operator into row-major dense storage (ld_p columns per row)
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int MAX_NP = 160;
+
+template <int BS>
+__global__ __launch_bounds__(256) void patch_gather_dense_kernel(const int32_t* __restrict__ rowptr,
+                                                                  const int32_t* __restrict__ colidx,
+                                                                  const double* __restrict__ vals,
+                                                                  const int64_t* __restrict__ patch_ptr,
+                                                                  const int32_t* __restrict__ patch_dofs,
+                                                                  const int64_t* __restrict__ inv_ptr,
+                                                                  double* __restrict__ inv) {
+  __shared__ int32_t dofs_s[MAX_NP];
+  __shared__ double rowbuf[4][MAX_NP];
+  const int64_t p = blockIdx.x;
+  const int64_t off = patch_ptr[p];
+  const int n = (int)(patch_ptr[p + 1] - off);
+  const int ld = (n + 1) & ~1;
+  double* S = inv + inv_ptr[p];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  for (int i = threadIdx.x; i < n; i += 256) dofs_s[i] = patch_dofs[off + i];
+  __syncthreads();
+  for (int r0 = 0; r0 < n; r0 += 4) {
+    const int r = r0 + wave;
+    const bool active = r < n;
+    if (active)
+      for (int c = lane; c < ld; c += 64) rowbuf[wave][c] = 0.0;
+    __syncthreads();
+    if (active) {
+      const int gr = dofs_s[r];
+      const int brow = gr / BS, rr = gr % BS;
+      const int32_t lo = rowptr[brow], hi = rowptr[brow + 1];
+      const int nent = (hi - lo) * BS;
+      for (int e = lane; e < nent; e += 64) {
+        const int blk = e / BS, cc = e % BS;
+        const int gcol = colidx[lo + blk] * BS + cc;
+        // binary search gcol in dofs_s[0..n)
+        int a = 0, b = n;
+        while (a < b) {
+          const int mid = (a + b) >> 1;
+          if (dofs_s[mid] < gcol) a = mid + 1; else b = mid;
+        }
+        if (a < n && dofs_s[a] == gcol) rowbuf[wave][a] = vals[(int64_t)(lo + blk) * BS * BS + rr * BS + cc];
+      }
+    }
+    __syncthreads();
+    if (active)
+      for (int c = lane; c < ld; c += 64) S[(int64_t)r * ld + c] = rowbuf[wave][c];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// 2a. in-place inversion, big patches (n <= 16 B): one 256-thread workgroup per patch, the matrix lives in registers as
+//     a 16 x 16 grid of B x B tiles (thread (ti, tj) owns rows ti*B.., cols tj*B..); Gauss-Jordan without pivoting (the
+//     patch operators are principal sub-blocks of an SPD-dominated operator); per step the pivot row and column travel
+//     through double-buffered LDS (one barrier per step).  Reads row-major, writes column-major (transposed store), both
+//     with leading dimension ld.
+// ---------------------------------------------------------------------------------------------------------------------
+template <int B>
+__global__ __launch_bounds__(256) void patch_invert_big_kernel(const int64_t* __restrict__ patch_ptr,
+                                                                const int64_t* __restrict__ inv_ptr,
+                                                                double* __restrict__ inv, int* __restrict__ status) {
+  constexpr int NMAX = 16 * B;
+  __shared__ double rowbuf[2][NMAX];
+  __shared__ double colbuf[2][NMAX];
+  const int64_t p = blockIdx.x;
+  const int n = (int)(patch_ptr[p + 1] - patch_ptr[p]);
+  const int ld = (n + 1) & ~1;
+  double* S = inv + inv_ptr[p];
+  const int ti = threadIdx.x >> 4, tj = threadIdx.x & 15;
+  const int r0 = ti * B, c0 = tj * B;
+  double a[B][B];
+#pragma unroll
+  for (int li = 0; li < B; ++li)
+#pragma unroll
+    for (int lj = 0; lj < B; ++lj) {
+      const int r = r0 + li, c = c0 + lj;
+      a[li][lj] = (r < n && c < n) ? S[(int64_t)r * ld + c] : (r == c ? 1.0 : 0.0);
+    }
+  __syncthreads();  // all loads done before anyone stores (in-place transposition at the end)
+  const int nkb = (n + B - 1) / B;
+  bool bad = false;
+  for (int kb = 0; kb < nkb; ++kb) {
+    const bool own_row = (ti == kb), own_col = (tj == kb);
+#pragma unroll
+    for (int kl = 0; kl < B; ++kl) {
+      const int k = kb * B + kl;
+      const int buf = k & 1;
+      if (own_row) {
+#pragma unroll
+        for (int lj = 0; lj < B; ++lj) rowbuf[buf][c0 + lj] = a[kl][lj];
+      }
+      if (own_col) {
+#pragma unroll
+        for (int li = 0; li < B; ++li) colbuf[buf][r0 + li] = a[li][kl];
+      }
+      __syncthreads();
+      const double piv = rowbuf[buf][k];
+      if (piv == 0.0) bad = true;
+      const double ip = 1.0 / piv;
+      double rr[B], cc[B], rm[B], cm[B];
+#pragma unroll
+      for (int l = 0; l < B; ++l) {
+        rr[l] = rowbuf[buf][c0 + l];
+        cc[l] = colbuf[buf][r0 + l] * ip;
+        rm[l] = (own_col && l == kl) ? 0.0 : rr[l];
+        cm[l] = (own_row && l == kl) ? 0.0 : cc[l];
+      }
+#pragma unroll
+      for (int li = 0; li < B; ++li)
+#pragma unroll
+        for (int lj = 0; lj < B; ++lj) a[li][lj] = __builtin_fma(-cm[li], rm[lj], a[li][lj]);
+      if (own_row) {
+#pragma unroll
+        for (int lj = 0; lj < B; ++lj) a[kl][lj] = rr[lj] * ip;
+      }
+      if (own_col) {
+#pragma unroll
+        for (int li = 0; li < B; ++li) a[li][kl] = -cm[li];
+      }
+      if (own_row && own_col) a[kl][kl] = ip;
+    }
+  }
+  if (bad && threadIdx.x == 0) atomicExch(status, 1);
+#pragma unroll
+  for (int li = 0; li < B; ++li)
+#pragma unroll
+    for (int lj = 0; lj < B; ++lj) {
+      const int r = r0 + li, c = c0 + lj;
+      if (r < n && c < n) S[(int64_t)c * ld + r] = a[li][lj];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// 2b. in-place inversion, small matrices (n <= N <= 32): N lanes per matrix, lane i holds row i in registers, 64/N
+//     matrices per wave, pivot rows broadcast with shuffles.  Same storage convention as above.
+// ---------------------------------------------------------------------------------------------------------------------
+template <int N>
+__global__ __launch_bounds__(256) void invert_small_kernel(int64_t nmat, const int64_t* __restrict__ ptr,
+                                                            const int64_t* __restrict__ inv_ptr, int fixed_n,
+                                                            int64_t fixed_stride, double* __restrict__ inv,
+                                                            int* __restrict__ status) {
+  const int64_t g = ((int64_t)blockIdx.x * 256 + threadIdx.x) / N;
+  const int i = threadIdx.x % N;
+  const bool valid = g < nmat;
+  int n = 0;
+  double* S = inv;
+  if (valid) {
+    if (ptr) {
+      n = (int)(ptr[g + 1] - ptr[g]);
+      S = inv + inv_ptr[g];
+    } else {
+      n = fixed_n;
+      S = inv + g * fixed_stride;
+    }
+  }
+  const int ld = (n + 1) & ~1;
+  double a[N];
+#pragma unroll
+  for (int j = 0; j < N; ++j) a[j] = (i < n && j < n) ? S[(int64_t)i * ld + j] : (i == j ? 1.0 : 0.0);
+  bool bad = false;
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+    const double piv = __shfl(a[k], k, N);
+    if (piv == 0.0) bad = true;
+    const double ip = 1.0 / piv;
+    const double m = (i == k) ? 0.0 : a[k] * ip;
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+      const double rk = __shfl(a[j], k, N);
+      if (j == k)
+        a[j] = (i == k) ? ip : -m;
+      else
+        a[j] = (i == k) ? rk * ip : __builtin_fma(-m, rk, a[j]);
+    }
+  }
+  // all lanes of the group have read their rows before the first shuffle round completed -> safe to store transposed
+  if (valid) {
+    if (bad && i == 0) atomicExch(status, 1);
+#pragma unroll
+    for (int j = 0; j < N; ++j)
+      if (i < n && j < n) S[(int64_t)j * ld + i] = a[j];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// 3. additive apply, stage 1: one wave per patch.  stage[patch_ptr[p] + r] = sum_c inv_p[r][c] * x[dofs_p[c]]
+// ---------------------------------------------------------------------------------------------------------------------
+template <int G>
+__device__ __forceinline__ void apply_tile(const double* __restrict__ Ainv, int ld, int n, int row0, int rows_tile,
+                                           const double* __restrict__ xs, int lane, double* __restrict__ out) {
+  constexpr int C = 64 / G;  // columns handled per wave-instruction
+  constexpr int U = 8;       // loads kept in flight per lane
+  const int cg = lane / G, l = lane % G;
+  const bool active = 2 * l < rows_tile;
+  const double* base = Ainv + row0 + 2 * l;
+  double acc0 = 0.0, acc1 = 0.0;
+  int j = cg;
+  if (active) {
+    for (; j + (U - 1) * C < n; j += U * C) {
+      double2 v[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) v[u] = *reinterpret_cast<const double2*>(base + (int64_t)(j + u * C) * ld);
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const double xj = xs[j + u * C];
+        acc0 = __builtin_fma(v[u].x, xj, acc0);
+        acc1 = __builtin_fma(v[u].y, xj, acc1);
+      }
+    }
+    for (; j < n; j += C) {
+      const double2 v = *reinterpret_cast<const double2*>(base + (int64_t)j * ld);
+      const double xj = xs[j];
+      acc0 = __builtin_fma(v.x, xj, acc0);
+      acc1 = __builtin_fma(v.y, xj, acc1);
+    }
+  }
+  if (C > 1) {
+#pragma unroll
+    for (int o = G; o < 64; o <<= 1) {
+      acc0 += __shfl_xor(acc0, o);
+      acc1 += __shfl_xor(acc1, o);
+    }
+  }
+  // the padding row (n odd) of the inverse is zero, so storing both rows is always valid (stage has ld slots)
+  if (active && cg == 0) *reinterpret_cast<double2*>(out + row0 + 2 * l) = make_double2(acc0, acc1);
+}
+
+__global__ __launch_bounds__(256) void patch_apply_kernel(int64_t npatch, const int64_t* __restrict__ patch_ptr,
+                                                           const int32_t* __restrict__ patch_dofs,
+                                                           const int64_t* __restrict__ inv_ptr,
+                                                           const int64_t* __restrict__ stage_ptr,
+                                                           const double* __restrict__ inv,
+                                                           const double* __restrict__ x, double* __restrict__ stage) {
+  __shared__ double xs_all[4][MAX_NP];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int64_t p = (int64_t)blockIdx.x * 4 + wave;
+  double* xs = xs_all[wave];
+  int n = 0;
+  if (p < npatch) {
+    const int64_t off = patch_ptr[p];
+    n = (int)(patch_ptr[p + 1] - off);
+    for (int i = lane; i < n; i += 64) xs[i] = x[patch_dofs[off + i]];
+  }
+  __syncthreads();
+  if (p >= npatch) return;
+  const int ld = (n + 1) & ~1;
+  const double* Ainv = inv + inv_ptr[p];
+  double* out = stage + stage_ptr[p];
+  int row0 = 0;
+  for (; row0 + 128 <= ld; row0 += 128) apply_tile<64>(Ainv, ld, n, row0, 128, xs, lane, out);
+  const int rem = ld - row0;  // even, < 128
+  if (rem > 64)
+    apply_tile<64>(Ainv, ld, n, row0, rem, xs, lane, out);
+  else if (rem > 32)
+    apply_tile<32>(Ainv, ld, n, row0, rem, xs, lane, out);
+  else if (rem > 16)
+    apply_tile<16>(Ainv, ld, n, row0, rem, xs, lane, out);
+  else if (rem > 0)
+    apply_tile<8>(Ainv, ld, n, row0, rem, xs, lane, out);
+}
+
+// stage 2: dof-wise sum of the staged patch results in a fixed order (deterministic; replaces PETSc's scatter-add)
+__global__ __launch_bounds__(256) void patch_sum_kernel(int64_t n, const int32_t* __restrict__ dof_ptr,
+                                                         const int32_t* __restrict__ dof_pos,
+                                                         const double* __restrict__ stage, double* __restrict__ y) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  double s = 0.0;
+  for (int32_t q = dof_ptr[i]; q < dof_ptr[i + 1]; ++q) s += stage[dof_pos[q]];
+  y[i] = s;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// launch wrappers
+// ---------------------------------------------------------------------------------------------------------------------
+int launch_patch_gather_dense(alfi_level* L) {
+  alfi_ctx* ctx = L->ctx;
+  if (L->npatch == 0) return 0;
+  dim3 grid((unsigned)L->npatch), block(256);
+  if (L->bs == 2)
+    hipLaunchKernelGGL(patch_gather_dense_kernel<2>, grid, block, 0, ctx->stream, L->A.rowptr, L->A.colidx, L->A.vals,
+                       L->patch_ptr, L->patch_dofs, L->inv_ptr, L->inv);
+  else if (L->bs == 3)
+    hipLaunchKernelGGL(patch_gather_dense_kernel<3>, grid, block, 0, ctx->stream, L->A.rowptr, L->A.colidx, L->A.vals,
+                       L->patch_ptr, L->patch_dofs, L->inv_ptr, L->inv);
+  else
+    return alfi_set_error(ctx, ALFI_E_ARG, "unsupported block size %d", L->bs);
+  ALFI_HIP_CHECK(ctx, hipGetLastError());
+  return 0;
+}
+
+template <int N>
+static int launch_invert_small(alfi_ctx* ctx, int64_t nmat, const int64_t* ptr, const int64_t* inv_ptr, int fixed_n,
+                               int64_t fixed_stride, double* inv, int* status) {
+  const int per_block = 256 / N;
+  dim3 grid((unsigned)((nmat + per_block - 1) / per_block)), block(256);
+  hipLaunchKernelGGL(invert_small_kernel<N>, grid, block, 0, ctx->stream, nmat, ptr, inv_ptr, fixed_n, fixed_stride,
+                     inv, status);
+  ALFI_HIP_CHECK(ctx, hipGetLastError());
+  return 0;
+}
+
+int launch_invert_small_any(alfi_ctx* ctx, int nmax, int64_t nmat, const int64_t* ptr, const int64_t* inv_ptr,
+                            int fixed_n, int64_t fixed_stride, double* inv, int* status) {
+  if (nmat == 0) return 0;
+  if (nmax <= 8) return launch_invert_small<8>(ctx, nmat, ptr, inv_ptr, fixed_n, fixed_stride, inv, status);
+  if (nmax <= 16) return launch_invert_small<16>(ctx, nmat, ptr, inv_ptr, fixed_n, fixed_stride, inv, status);
+  if (nmax <= 32) return launch_invert_small<32>(ctx, nmat, ptr, inv_ptr, fixed_n, fixed_stride, inv, status);
+  return alfi_set_error(ctx, ALFI_E_ARG, "small inversion supports n <= 32, got %d", nmax);
+}
+
+int launch_patch_invert(alfi_level* L) {
+  alfi_ctx* ctx = L->ctx;
+  if (L->npatch == 0) return 0;
+  if (L->max_np <= 32)
+    return launch_invert_small_any(ctx, L->max_np, L->npatch, L->patch_ptr, L->inv_ptr, 0, 0, L->inv, L->status);
+  dim3 grid((unsigned)L->npatch), block(256);
+  if (L->max_np <= 112)
+    hipLaunchKernelGGL(patch_invert_big_kernel<7>, grid, block, 0, ctx->stream, L->patch_ptr, L->inv_ptr, L->inv,
+                       L->status);
+  else if (L->max_np <= 160)
+    hipLaunchKernelGGL(patch_invert_big_kernel<10>, grid, block, 0, ctx->stream, L->patch_ptr, L->inv_ptr, L->inv,
+                       L->status);
+  else
+    return alfi_set_error(ctx, ALFI_E_ARG, "patch size %d > 160 not supported (macro-star: SURVEY.md 8(f))", L->max_np);
+  ALFI_HIP_CHECK(ctx, hipGetLastError());
+  return 0;
+}
+
+int launch_patch_apply(alfi_level* L, const double* x, double* y) {
+  alfi_ctx* ctx = L->ctx;
+  if (L->npatch > 0) {
+    int t = alfi_prof_begin(ctx, ALFI_EV_PATCH_APPLY);
+    dim3 grid((unsigned)((L->npatch + 3) / 4)), block(256);
+    hipLaunchKernelGGL(patch_apply_kernel, grid, block, 0, ctx->stream, L->npatch, L->patch_ptr, L->patch_dofs,
+                       L->inv_ptr, L->stage_ptr, L->inv, x, L->stage);
+    ALFI_HIP_CHECK(ctx, hipGetLastError());
+    alfi_prof_end(ctx, t);
+  }
+  int t = alfi_prof_begin(ctx, ALFI_EV_PATCH_SCATTER);
+  dim3 grid((unsigned)((L->n + 255) / 256)), block(256);
+  hipLaunchKernelGGL(patch_sum_kernel, grid, block, 0, ctx->stream, L->n, L->dof_ptr, L->dof_pos, L->stage, y);
+  ALFI_HIP_CHECK(ctx, hipGetLastError());
+  if (L->nbc > 0) ALFI_CHECK(launch_copy_dofs(ctx, y, x, L->bc_dofs, L->nbc));
+  alfi_prof_end(ctx, t);
+  return 0;
+}

@@ -1,0 +1,486 @@
+// Level SpMV / residual (PETSc MatMult on BAIJ), FGMRES vector kernels, small dense block kernels of the Schoeberl
+// transfer and the dense coarse GEMV.  All HBM-bound; wave64, FP64.
+#include "common.h"
+#include "hs_layout.h"
+
+// ---------------------------------------------------------------------------------------------------------------------
+// BSR SpMV: LPR lanes cooperate on one block row (each lane takes whole bs x bs blocks), shuffle-reduce the bs sums.
+//   mode 0: y = A x          mode 1: y = b - alpha A x
+// Algorithmic bytes: (8 bs^2 + 4) nnzb + 4 (nbrows + 1) + 16 n   (SURVEY.md section 8(d)).
+// ---------------------------------------------------------------------------------------------------------------------
+template <int BS, int LPR>
+__global__ __launch_bounds__(256) void bsr_spmv_kernel(int64_t nbrows, const int32_t* __restrict__ rowptr,
+                                                        const int32_t* __restrict__ colidx,
+                                                        const double* __restrict__ vals, const double* __restrict__ x,
+                                                        double* __restrict__ y, const double* __restrict__ b,
+                                                        double alpha, int mode) {
+  const int64_t row = ((int64_t)blockIdx.x * 256 + threadIdx.x) / LPR;
+  const int l = threadIdx.x % LPR;
+  double acc[BS];
+#pragma unroll
+  for (int r = 0; r < BS; ++r) acc[r] = 0.0;
+  if (row < nbrows) {
+    const int32_t lo = rowptr[row], hi = rowptr[row + 1];
+    for (int32_t k = lo + l; k < hi; k += LPR) {
+      const int64_t col = colidx[k];
+      const double* v = vals + (int64_t)k * BS * BS;
+      double xv[BS];
+#pragma unroll
+      for (int c = 0; c < BS; ++c) xv[c] = x[col * BS + c];
+#pragma unroll
+      for (int r = 0; r < BS; ++r)
+#pragma unroll
+        for (int c = 0; c < BS; ++c) acc[r] = __builtin_fma(v[r * BS + c], xv[c], acc[r]);
+    }
+  }
+#pragma unroll
+  for (int o = LPR / 2; o > 0; o >>= 1)
+#pragma unroll
+    for (int r = 0; r < BS; ++r) acc[r] += __shfl_xor(acc[r], o);
+  if (row < nbrows && l == 0) {
+#pragma unroll
+    for (int r = 0; r < BS; ++r) {
+      const int64_t i = row * BS + r;
+      y[i] = mode == 0 ? acc[r] : b[i] - alpha * acc[r];
+    }
+  }
+}
+
+template <int BS>
+static int launch_bsr_spmv_bs(alfi_ctx* ctx, const DevBSR& A, const double* x, double* y, const double* b, double alpha,
+                              int mode) {
+  const double avg = A.nbrows > 0 ? (double)A.nnzb / (double)A.nbrows : 0.0;
+  int lpr = 4;
+  while (lpr < 64 && lpr < avg) lpr <<= 1;
+  const int64_t threads = A.nbrows * lpr;
+  dim3 grid((unsigned)((threads + 255) / 256)), block(256);
+#define ALFI_SPMV_CASE(L)                                                                                       \
+  case L:                                                                                                       \
+    hipLaunchKernelGGL((bsr_spmv_kernel<BS, L>), grid, block, 0, ctx->stream, A.nbrows, A.rowptr, A.colidx,     \
+                       A.vals, x, y, b, alpha, mode);                                                           \
+    break;
+  switch (lpr) {
+    ALFI_SPMV_CASE(4)
+    ALFI_SPMV_CASE(8)
+    ALFI_SPMV_CASE(16)
+    ALFI_SPMV_CASE(32)
+    ALFI_SPMV_CASE(64)
+  }
+#undef ALFI_SPMV_CASE
+  ALFI_HIP_CHECK(ctx, hipGetLastError());
+  return 0;
+}
+
+int launch_bsr_spmv(alfi_ctx* ctx, const DevBSR& A, const double* x, double* y, const double* b, double alpha,
+                    int mode) {
+  if (A.nbrows == 0) return 0;
+  if (A.bs == 2) return launch_bsr_spmv_bs<2>(ctx, A, x, y, b, alpha, mode);
+  if (A.bs == 3) return launch_bsr_spmv_bs<3>(ctx, A, x, y, b, alpha, mode);
+  return alfi_set_error(ctx, ALFI_E_ARG, "unsupported block size %d", A.bs);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// elementwise helpers
+// ---------------------------------------------------------------------------------------------------------------------
+static inline dim3 ew_grid(int64_t n) {
+  int64_t b = (n + 255) / 256;
+  if (b > 8192) b = 8192;
+  if (b < 1) b = 1;
+  return dim3((unsigned)b);
+}
+
+__global__ void copy_kernel(double* __restrict__ y, const double* __restrict__ x, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    y[i] = x[i];
+}
+__global__ void axpy_kernel(double* __restrict__ y, const double* __restrict__ x, double a, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    y[i] = __builtin_fma(a, x[i], y[i]);
+}
+__global__ void scale_by_inv_kernel(double* __restrict__ v, const double* __restrict__ w,
+                                    const double* __restrict__ scal, int64_t n) {
+  const double s = *scal;
+  const double f = s != 0.0 ? 1.0 / s : 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    v[i] = w[i] * f;
+}
+__global__ void scatter_sub_kernel(double* __restrict__ x, const int32_t* __restrict__ idx,
+                                   const double* __restrict__ t, double alpha, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    x[idx[i]] -= alpha * t[i];
+}
+__global__ void zero_dofs_kernel(double* __restrict__ x, const int32_t* __restrict__ idx, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    x[idx[i]] = 0.0;
+}
+__global__ void copy_dofs_kernel(double* __restrict__ y, const double* __restrict__ x, const int32_t* __restrict__ idx,
+                                 int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    y[idx[i]] = x[idx[i]];
+}
+
+#define ALFI_LAUNCH_EW(kern, n, ...)                                                       \
+  do {                                                                                     \
+    if ((n) > 0) {                                                                         \
+      hipLaunchKernelGGL(kern, ew_grid(n), dim3(256), 0, ctx->stream, __VA_ARGS__);        \
+      ALFI_HIP_CHECK(ctx, hipGetLastError());                                              \
+    }                                                                                      \
+  } while (0)
+
+int launch_copy(alfi_ctx* ctx, double* y, const double* x, int64_t n) {
+  ALFI_LAUNCH_EW(copy_kernel, n, y, x, n);
+  return 0;
+}
+int launch_axpy(alfi_ctx* ctx, double* y, const double* x, double a, int64_t n) {
+  ALFI_LAUNCH_EW(axpy_kernel, n, y, x, a, n);
+  return 0;
+}
+int launch_scale_by_inv(alfi_ctx* ctx, double* v, const double* w, const double* scal, int64_t n) {
+  ALFI_LAUNCH_EW(scale_by_inv_kernel, n, v, w, scal, n);
+  return 0;
+}
+int launch_scatter_sub(alfi_ctx* ctx, double* x, const int32_t* idx, const double* t, double alpha, int64_t n) {
+  ALFI_LAUNCH_EW(scatter_sub_kernel, n, x, idx, t, alpha, n);
+  return 0;
+}
+int launch_zero_dofs(alfi_ctx* ctx, double* x, const int32_t* idx, int64_t n) {
+  ALFI_LAUNCH_EW(zero_dofs_kernel, n, x, idx, n);
+  return 0;
+}
+int launch_copy_dofs(alfi_ctx* ctx, double* y, const double* x, const int32_t* idx, int64_t n) {
+  ALFI_LAUNCH_EW(copy_dofs_kernel, n, y, x, idx, n);
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// reductions: two-stage (RED_BLOCKS partials, then one block sums them in a fixed order) -> deterministic
+// ---------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+template <int NV>
+__device__ __forceinline__ void block_store_partials(double (&acc)[NV], double* __restrict__ partial) {
+  __shared__ double red[4][NV];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+  for (int v = 0; v < NV; ++v) {
+    const double s = wave_sum(acc[v]);
+    if (lane == 0) red[wave][v] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x < NV)
+    partial[(int64_t)blockIdx.x * RED_MAXV + threadIdx.x] =
+        red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+
+// partial[b][v] = sum over the block's slice of V_v[i] * w[i]
+template <int NV>
+__global__ __launch_bounds__(256) void multi_dot_kernel(const double* __restrict__ V, int64_t stride,
+                                                         const double* __restrict__ w, double* __restrict__ partial,
+                                                         int64_t n) {
+  double acc[NV];
+#pragma unroll
+  for (int v = 0; v < NV; ++v) acc[v] = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)RED_BLOCKS * 256) {
+    const double wi = w[i];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) acc[v] = __builtin_fma(V[v * stride + i], wi, acc[v]);
+  }
+  block_store_partials<NV>(acc, partial);
+}
+
+// out[v] = sum_b partial[b][v]   (one block, fixed order)
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const double* __restrict__ partial, int nv,
+                                                               double* __restrict__ out) {
+  __shared__ double red[256];
+  for (int v = 0; v < nv; ++v) {
+    double s = 0.0;
+    for (int b = threadIdx.x; b < RED_BLOCKS; b += 256) s += partial[(int64_t)b * RED_MAXV + v];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+      if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) out[v] = red[0];
+    __syncthreads();
+  }
+}
+
+// w -= sum_v h[v] V_v ; partial[b][0] = sum of w^2 over the block's slice
+template <int NV>
+__global__ __launch_bounds__(256) void multi_axpy_norm_kernel(const double* __restrict__ V, int64_t stride,
+                                                               const double* __restrict__ h, double* __restrict__ w,
+                                                               double* __restrict__ partial, int64_t n) {
+  double hv[NV];
+#pragma unroll
+  for (int v = 0; v < NV; ++v) hv[v] = h[v];
+  double acc[1] = {0.0};
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)RED_BLOCKS * 256) {
+    double wi = w[i];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) wi = __builtin_fma(-hv[v], V[v * stride + i], wi);
+    w[i] = wi;
+    acc[0] = __builtin_fma(wi, wi, acc[0]);
+  }
+  block_store_partials<1>(acc, partial);
+}
+
+// x += sum_v y[v] Z_v
+template <int NV>
+__global__ __launch_bounds__(256) void multi_axpy_add_kernel(const double* __restrict__ Z, int64_t stride,
+                                                              const double* __restrict__ y, double* __restrict__ x,
+                                                              int64_t n) {
+  double yv[NV];
+#pragma unroll
+  for (int v = 0; v < NV; ++v) yv[v] = y[v];
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    double xi = x[i];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) xi = __builtin_fma(yv[v], Z[v * stride + i], xi);
+    x[i] = xi;
+  }
+}
+
+// beta = sqrt(sum partial); hs[beta] = beta; grs[0] = beta
+__global__ __launch_bounds__(256) void norm_init_finish_kernel(const double* __restrict__ partial,
+                                                                double* __restrict__ hs, int K) {
+  __shared__ double red[256];
+  double s = 0.0;
+  for (int b = threadIdx.x; b < RED_BLOCKS; b += 256) s += partial[(int64_t)b * RED_MAXV];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    HsLayout L(K);
+    const double beta = sqrt(red[0]);
+    hs[L.beta] = beta;
+    hs[L.grs] = beta;
+    for (int i = 1; i <= K; ++i) hs[L.grs + i] = 0.0;
+  }
+}
+
+// column j of the Hessenberg: h[0..j] = hd (the CGS dots), h[j+1] = tt = sqrt(sum partial); Givens update
+// (KSPFGMRESUpdateHessenberg [3P])
+__global__ __launch_bounds__(256) void hessenberg_update_kernel(const double* __restrict__ partial,
+                                                                 double* __restrict__ hs, int j, int K) {
+  __shared__ double red[256];
+  double s = 0.0;
+  for (int b = threadIdx.x; b < RED_BLOCKS; b += 256) s += partial[(int64_t)b * RED_MAXV];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    HsLayout L(K);
+    const double tt = sqrt(red[0]);
+    hs[L.tt] = tt;
+    double* hcol = hs + L.H(j);
+    for (int i = 0; i <= j; ++i) hcol[i] = hs[L.hd + i];
+    hcol[j + 1] = tt;
+    double* cs = hs + L.cs;
+    double* sn = hs + L.sn;
+    double* grs = hs + L.grs;
+    for (int i = 0; i < j; ++i) {
+      const double t = hcol[i];
+      hcol[i] = cs[i] * t + sn[i] * hcol[i + 1];
+      hcol[i + 1] = -sn[i] * t + cs[i] * hcol[i + 1];
+    }
+    const double den = hypot(hcol[j], hcol[j + 1]);
+    if (den != 0.0) {
+      cs[j] = hcol[j] / den;
+      sn[j] = hcol[j + 1] / den;
+    } else {
+      cs[j] = 1.0;
+      sn[j] = 0.0;
+    }
+    grs[j + 1] = -sn[j] * grs[j];
+    grs[j] = cs[j] * grs[j];
+    hcol[j] = den;
+    hcol[j + 1] = 0.0;
+  }
+}
+
+// back substitution on the triangularised Hessenberg (KSPFGMRESBuildSoln [3P]) -> y
+__global__ void fgmres_finish_kernel(double* __restrict__ hs, int k, int K) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  HsLayout L(K);
+  double* y = hs + L.y;
+  const double* grs = hs + L.grs;
+  for (int i = k - 1; i >= 0; --i) {
+    double s = grs[i];
+    for (int q = i + 1; q < k; ++q) s -= hs[L.H(q) + i] * y[q];
+    const double d = hs[L.H(i) + i];
+    y[i] = d != 0.0 ? s / d : 0.0;
+  }
+}
+
+#define ALFI_NV_SWITCH(NVAL, MACRO) \
+  switch (NVAL) {                   \
+    MACRO(1) MACRO(2) MACRO(3) MACRO(4) MACRO(5) MACRO(6) MACRO(7) MACRO(8) MACRO(9) MACRO(10) MACRO(11) MACRO(12) \
+    MACRO(13) MACRO(14) MACRO(15) MACRO(16)                                                                         \
+  }
+
+int launch_multi_dot(alfi_ctx* ctx, const double* V, int64_t stride, int nv, const double* w, double* out, int64_t n) {
+  // out[0..nv) = V_v . w ; more than 16 vectors: passes of 16
+  for (int v0 = 0; v0 < nv; v0 += 16) {
+    const int cnt = nv - v0 < 16 ? nv - v0 : 16;
+#define ALFI_CASE(N)                                                                                              \
+  case N:                                                                                                         \
+    hipLaunchKernelGGL(multi_dot_kernel<N>, dim3(RED_BLOCKS), dim3(256), 0, ctx->stream, V + (int64_t)v0 * stride, \
+                       stride, w, ctx->red_partial, n);                                                           \
+    break;
+    ALFI_NV_SWITCH(cnt, ALFI_CASE)
+#undef ALFI_CASE
+    ALFI_HIP_CHECK(ctx, hipGetLastError());
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(256), 0, ctx->stream, ctx->red_partial, cnt, out + v0);
+    ALFI_HIP_CHECK(ctx, hipGetLastError());
+  }
+  return 0;
+}
+
+int launch_multi_axpy_norm(alfi_ctx* ctx, const double* V, int64_t stride, int nv, const double* h, double* w,
+                           double* hs, int j, int k, int64_t n) {
+  // w -= sum h_v V_v (passes of 16; the last pass also produces |w|^2 partials), then the Hessenberg column update
+  for (int v0 = 0; v0 < nv; v0 += 16) {
+    const int cnt = nv - v0 < 16 ? nv - v0 : 16;
+#define ALFI_CASE(N)                                                                                             \
+  case N:                                                                                                        \
+    hipLaunchKernelGGL(multi_axpy_norm_kernel<N>, dim3(RED_BLOCKS), dim3(256), 0, ctx->stream,                   \
+                       V + (int64_t)v0 * stride, stride, h + v0, w, ctx->red_partial, n);                        \
+    break;
+    ALFI_NV_SWITCH(cnt, ALFI_CASE)
+#undef ALFI_CASE
+    ALFI_HIP_CHECK(ctx, hipGetLastError());
+  }
+  hipLaunchKernelGGL(hessenberg_update_kernel, dim3(1), dim3(256), 0, ctx->stream, ctx->red_partial, hs, j, k);
+  ALFI_HIP_CHECK(ctx, hipGetLastError());
+  return 0;
+}
+
+int launch_norm_init(alfi_ctx* ctx, const double* r, double* hs, int K, int64_t n) {
+  // |r|^2 partials via the dot kernel with V = w = r, then beta = sqrt(sum), grs = beta e_1
+  hipLaunchKernelGGL(multi_dot_kernel<1>, dim3(RED_BLOCKS), dim3(256), 0, ctx->stream, r, (int64_t)0, r,
+                     ctx->red_partial, n);
+  ALFI_HIP_CHECK(ctx, hipGetLastError());
+  hipLaunchKernelGGL(norm_init_finish_kernel, dim3(1), dim3(256), 0, ctx->stream, ctx->red_partial, hs, K);
+  ALFI_HIP_CHECK(ctx, hipGetLastError());
+  return 0;
+}
+
+int launch_fgmres_finish(alfi_ctx* ctx, double* hs, int k, int K) {
+  hipLaunchKernelGGL(fgmres_finish_kernel, dim3(1), dim3(64), 0, ctx->stream, hs, k, K);
+  ALFI_HIP_CHECK(ctx, hipGetLastError());
+  return 0;
+}
+
+int launch_update_solution(alfi_ctx* ctx, double* x, const double* Z, int64_t stride, int k, const double* y,
+                           int64_t n) {
+  for (int v0 = 0; v0 < k; v0 += 16) {
+    const int cnt = k - v0 < 16 ? k - v0 : 16;
+#define ALFI_CASE(N)                                                                                                \
+  case N:                                                                                                           \
+    hipLaunchKernelGGL(multi_axpy_add_kernel<N>, ew_grid(n), dim3(256), 0, ctx->stream, Z + (int64_t)v0 * stride,    \
+                       stride, y + v0, x, n);                                                                       \
+    break;
+    ALFI_NV_SWITCH(cnt, ALFI_CASE)
+#undef ALFI_CASE
+    ALFI_HIP_CHECK(ctx, hipGetLastError());
+  }
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Schoeberl transfer: interior blocks.  binv holds nblk inverses, column-major, leading dimension ld (m rounded up to
+// even), stride m_cols * ld per block -- the same convention as the patch inverses.
+// ---------------------------------------------------------------------------------------------------------------------
+// S = nu K_II + gamma D_II in row-major padded form (input of invert_small_kernel)
+__global__ void block_build_kernel(int64_t nblk, int m, int ld, const double* __restrict__ K,
+                                   const double* __restrict__ D, double nu, double gamma, double* __restrict__ S) {
+  const int64_t total = nblk * m * ld;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t blk = e / (m * ld);
+    const int r = (int)((e / ld) % m), c = (int)(e % ld);
+    S[e] = c < m ? nu * K[(blk * m + r) * m + c] + gamma * D[(blk * m + r) * m + c] : 0.0;
+  }
+}
+
+int launch_block_build_invert(alfi_transfer* tr) {
+  alfi_ctx* ctx = tr->ctx;
+  const int64_t total = tr->nblk * tr->m * tr->ld;
+  ALFI_LAUNCH_EW(block_build_kernel, total, tr->nblk, tr->m, tr->ld, tr->KII, tr->DII, tr->nu, tr->gamma, tr->binv);
+  return launch_invert_small_any(ctx, tr->m, tr->nblk, nullptr, nullptr, tr->m, (int64_t)tr->m * tr->ld, tr->binv,
+                                 tr->status);
+}
+
+// out[blk*m + i] = sum_j binv_blk[i][j] * in_j ; in_j = in[blk_dofs[blk*m + j]] (gather) or in[blk*m + j].
+// G lanes per block (G >= m, power of two), lane i owns row i, x_j broadcast by shuffle.
+template <int G>
+__global__ __launch_bounds__(256) void block_gemv_kernel(int64_t nblk, int m, int ld, const double* __restrict__ binv,
+                                                          const int32_t* __restrict__ blk_dofs,
+                                                          const double* __restrict__ in, double* __restrict__ out,
+                                                          int gather) {
+  const int64_t blk = ((int64_t)blockIdx.x * 256 + threadIdx.x) / G;
+  const int i = threadIdx.x % G;
+  const bool valid = blk < nblk && i < m;
+  double xi = 0.0;
+  if (valid) xi = gather ? in[blk_dofs[blk * m + i]] : in[blk * m + i];
+  const double* T = binv + (valid ? blk * (int64_t)m * ld : 0);
+  double acc = 0.0;
+  for (int j = 0; j < m; ++j) {
+    const double xj = __shfl(xi, j, G);
+    if (valid) acc = __builtin_fma(T[(int64_t)j * ld + i], xj, acc);
+  }
+  if (valid) out[blk * m + i] = acc;
+}
+
+int launch_block_gemv(alfi_transfer* tr, const double* in, double* out, bool gather_in) {
+  alfi_ctx* ctx = tr->ctx;
+  if (tr->nblk == 0) return 0;
+  const int m = tr->m;
+  const int G = m <= 8 ? 8 : (m <= 16 ? 16 : 32);
+  const int64_t threads = tr->nblk * G;
+  dim3 grid((unsigned)((threads + 255) / 256)), block(256);
+  if (G == 8)
+    hipLaunchKernelGGL(block_gemv_kernel<8>, grid, block, 0, ctx->stream, tr->nblk, m, tr->ld, tr->binv, tr->blk_dofs,
+                       in, out, gather_in ? 1 : 0);
+  else if (G == 16)
+    hipLaunchKernelGGL(block_gemv_kernel<16>, grid, block, 0, ctx->stream, tr->nblk, m, tr->ld, tr->binv, tr->blk_dofs,
+                       in, out, gather_in ? 1 : 0);
+  else
+    hipLaunchKernelGGL(block_gemv_kernel<32>, grid, block, 0, ctx->stream, tr->nblk, m, tr->ld, tr->binv, tr->blk_dofs,
+                       in, out, gather_in ? 1 : 0);
+  ALFI_HIP_CHECK(ctx, hipGetLastError());
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// coarse solve: y = Ainv x, Ainv dense row-major n x n; one workgroup per row
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void dense_gemv_kernel(const double* __restrict__ A, const double* __restrict__ x,
+                                                          double* __restrict__ y, int64_t n) {
+  __shared__ double red[4];
+  const int64_t row = blockIdx.x;
+  const double* a = A + row * n;
+  double acc = 0.0;
+  for (int64_t j = threadIdx.x; j < n; j += 256) acc = __builtin_fma(a[j], x[j], acc);
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) y[row] = red[0] + red[1] + red[2] + red[3];
+}
+
+int launch_dense_gemv(alfi_ctx* ctx, const double* A, const double* x, double* y, int64_t n) {
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(dense_gemv_kernel, dim3((unsigned)n), dim3(256), 0, ctx->stream, A, x, y, n);
+  ALFI_HIP_CHECK(ctx, hipGetLastError());
+  return 0;
+}

@@ -1,0 +1,258 @@
+"""Thin object layer over the C ABI (include/alfi_hip.h): Context, DeviceVec, Level, Transfer, Multigrid.
+
+All arithmetic happens in libalfi_hip.so; this module only moves arrays across the boundary and keeps handles alive.
+Errors from the library become ``RuntimeError`` (the reference's plug-ins raise Python exceptions, solver.py:37-38).
+"""
+import ctypes
+import numpy as np
+
+from . import _lib
+from ._lib import BsrHost, vp
+
+
+class AlfiHipError(RuntimeError):
+    pass
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(vp)
+
+
+class Context(object):
+    def __init__(self, device=0, stream=None):
+        self.lib = _lib.load()
+        h = vp()
+        rc = self.lib.alfi_ctx_create(int(device), vp(stream) if stream else None, ctypes.byref(h))
+        if rc != 0:
+            raise AlfiHipError("alfi_ctx_create failed (%d): %s -- alfi_amd needs an MI355X; there is no CPU fallback"
+                               % (rc, self.lib.alfi_last_error(None).decode()))
+        self.h = h
+        self.device = device
+
+    def check(self, rc):
+        if rc != 0:
+            raise AlfiHipError("libalfi_hip error %d: %s" % (rc, self.lib.alfi_last_error(self.h).decode()))
+
+    def sync(self):
+        self.check(self.lib.alfi_ctx_sync(self.h))
+
+    def close(self):
+        if self.h:
+            self.lib.alfi_ctx_destroy(self.h)
+            self.h = None
+
+    # vectors ----------------------------------------------------------------------------------------------------------
+    def vec(self, n_or_array):
+        if isinstance(n_or_array, (int, np.integer)):
+            v = DeviceVec(self, int(n_or_array))
+            v.zero()
+            return v
+        a = np.ascontiguousarray(n_or_array, dtype=np.float64)
+        v = DeviceVec(self, a.shape[0])
+        v.set(a)
+        return v
+
+    # profiling (PETSc-event style report, driver.py:77-92) ----------------------------------------------------------------
+    def prof_enable(self, on=True):
+        self.check(self.lib.alfi_prof_enable(self.h, 1 if on else 0))
+
+    def prof_reset(self):
+        self.check(self.lib.alfi_prof_reset(self.h))
+
+    def prof_get(self):
+        out = {}
+        for i, name in enumerate(_lib.EVENTS):
+            ms, cnt = ctypes.c_double(), ctypes.c_int64()
+            self.check(self.lib.alfi_prof_get(self.h, i, ctypes.byref(ms), ctypes.byref(cnt)))
+            out[name] = (ms.value, cnt.value)
+        return out
+
+
+class DeviceVec(object):
+    """A level vector resident in HBM (the analogue of a PETSc Vec's local array)."""
+
+    def __init__(self, ctx, n):
+        self.ctx, self.n = ctx, int(n)
+        p = vp()
+        ctx.check(ctx.lib.alfi_malloc(ctx.h, self.n * 8, ctypes.byref(p)))
+        self.ptr = p
+
+    def set(self, a):
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        assert a.shape == (self.n,)
+        self.ctx.check(self.ctx.lib.alfi_memcpy_h2d(self.ctx.h, self.ptr, _ptr(a), self.n * 8))
+
+    def get(self):
+        out = np.empty(self.n, dtype=np.float64)
+        self.ctx.check(self.ctx.lib.alfi_memcpy_d2h(self.ctx.h, _ptr(out), self.ptr, self.n * 8))
+        return out
+
+    def zero(self):
+        self.ctx.check(self.ctx.lib.alfi_memset0(self.ctx.h, self.ptr, self.n * 8))
+
+    def __del__(self):
+        try:
+            if self.ptr and self.ctx.h:
+                self.ctx.lib.alfi_free(self.ctx.h, self.ptr)
+        except Exception:
+            pass
+        self.ptr = None
+
+
+def _bsr_struct(B, keep):
+    rowptr = np.ascontiguousarray(B.rowptr, dtype=np.int32)
+    colidx = np.ascontiguousarray(B.colidx, dtype=np.int32)
+    vals = np.ascontiguousarray(B.vals, dtype=np.float64)
+    keep.extend([rowptr, colidx, vals])
+    return BsrHost(B.nbrows, B.nbcols, _ptr(rowptr), _ptr(colidx), _ptr(vals))
+
+
+class Level(object):
+    """One multigrid level: BSR operator + Dirichlet dofs (+ patches)."""
+
+    def __init__(self, ctx, A, bc_dofs):
+        self.ctx = ctx
+        self.n, self.bs = A.nbrows * A.bs, A.bs
+        bc = np.ascontiguousarray(bc_dofs, dtype=np.int32)
+        h = vp()
+        ctx.check(ctx.lib.alfi_level_create(ctx.h, A.nbrows, A.bs, _ptr(A.rowptr), _ptr(A.colidx),
+                                            _ptr(np.ascontiguousarray(A.vals)), _ptr(bc), len(bc), ctypes.byref(h)))
+        self.h = h
+        self.nnzb = A.nnzb
+
+    def update_values(self, vals):
+        vals = np.ascontiguousarray(vals, dtype=np.float64)
+        self.ctx.check(self.ctx.lib.alfi_level_update_values(self.h, _ptr(vals)))
+
+    def set_patches(self, patch_ptr, patch_dofs):
+        pp = np.ascontiguousarray(patch_ptr, dtype=np.int64)
+        pd = np.ascontiguousarray(patch_dofs, dtype=np.int32)
+        self.ctx.check(self.ctx.lib.alfi_patches_set(self.h, len(pp) - 1, _ptr(pp), _ptr(pd)))
+
+    def factor(self):
+        self.ctx.check(self.ctx.lib.alfi_patches_factor(self.h))
+
+    def patch_stats(self):
+        a, b, c = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int64()
+        self.ctx.check(self.ctx.lib.alfi_patches_stats(self.h, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)))
+        return a.value, b.value, c.value
+
+    def patch_inverse(self, p, n):
+        out = np.empty((n, n))
+        self.ctx.check(self.ctx.lib.alfi_patch_get_inverse(self.h, int(p), _ptr(out)))
+        return out
+
+    def patch_apply(self, x, y):
+        self.ctx.check(self.ctx.lib.alfi_patch_apply(self.h, x.ptr, y.ptr))
+
+    def spmv(self, x, y):
+        self.ctx.check(self.ctx.lib.alfi_spmv(self.h, x.ptr, y.ptr))
+
+    def residual(self, b, x, r):
+        self.ctx.check(self.ctx.lib.alfi_residual(self.h, b.ptr, x.ptr, r.ptr))
+
+    def smooth(self, k, b, x, nonzero_guess=True):
+        self.ctx.check(self.ctx.lib.alfi_smooth_fgmres(self.h, int(k), b.ptr, x.ptr, 1 if nonzero_guess else 0))
+
+    def set_coarse_inverse(self, inv):
+        """inv: dense (n, n) numpy array (copied) or a device pointer (int) that stays owned by the caller."""
+        if isinstance(inv, (int, np.integer)):
+            self.ctx.check(self.ctx.lib.alfi_coarse_set_inverse(self.h, vp(int(inv)), 1))
+        else:
+            inv = np.ascontiguousarray(inv, dtype=np.float64)
+            assert inv.shape == (self.n, self.n)
+            self.ctx.check(self.ctx.lib.alfi_coarse_set_inverse(self.h, _ptr(inv), 0))
+
+    def coarse_solve(self, b, x):
+        self.ctx.check(self.ctx.lib.alfi_coarse_solve(self.h, b.ptr, x.ptr))
+
+    def close(self):
+        if self.h:
+            self.ctx.lib.alfi_level_destroy(self.h)
+            self.h = None
+
+
+class Transfer(object):
+    def __init__(self, ctx, coarse, fine, T):
+        """T: alfi_amd.problem.TransferData."""
+        self.ctx, self.coarse, self.fine = ctx, coarse, fine
+        keep = []
+        P, PT = _bsr_struct(T.P, keep), _bsr_struct(T.PT, keep)
+        PTp = _bsr_struct(T.PT_plain, keep) if T.PT_plain is not T.PT else None
+        DI, DIT = _bsr_struct(T.D_I, keep), _bsr_struct(T.D_IT, keep)
+        blk = np.ascontiguousarray(T.blk_dofs, dtype=np.int32)
+        K = np.ascontiguousarray(T.K_II, dtype=np.float64)
+        D = np.ascontiguousarray(T.D_II, dtype=np.float64)
+        h = vp()
+        ctx.check(ctx.lib.alfi_transfer_create(ctx.h, coarse.h, fine.h, ctypes.byref(P), ctypes.byref(PT),
+                                               ctypes.byref(PTp) if PTp is not None else None, ctypes.byref(DI),
+                                               ctypes.byref(DIT), blk.shape[0], blk.shape[1], _ptr(blk), _ptr(K),
+                                               _ptr(D), ctypes.byref(h)))
+        self.h = h
+
+    def update(self, nu, gamma):
+        self.ctx.check(self.ctx.lib.alfi_transfer_update(self.h, float(nu), float(gamma)))
+
+    def prolong(self, xc, xf):
+        self.ctx.check(self.ctx.lib.alfi_prolong(self.h, xc.ptr, xf.ptr))
+
+    def restrict(self, rf, rc, robust=True):
+        self.ctx.check(self.ctx.lib.alfi_restrict(self.h, rf.ptr, rc.ptr, 1 if robust else 0))
+
+    def close(self):
+        if self.h:
+            self.ctx.lib.alfi_transfer_destroy(self.h)
+            self.h = None
+
+
+def coarse_inverse(A_bsr):
+    """Dense inverse of the coarsest operator (stands in for AssembledPC + LU, solver.py:369-378).  Setup only."""
+    A = A_bsr.to_scipy().toarray()
+    return np.linalg.inv(A)
+
+
+class Multigrid(object):
+    """Device-resident PCMG (solver.py:359-379) built from alfi_amd.problem.build_hierarchy output."""
+
+    def __init__(self, ctx, levels, transfers, k, robust_restriction=False, coarse_inv=None, verbose=False):
+        import time
+        self.ctx = ctx
+        self.levels, self.transfers = [], []
+        t0 = time.time()
+        for L in levels:
+            dl = Level(ctx, L.A, L.bc_dofs)
+            if L.level > 0:
+                dl.set_patches(L.patch_ptr, L.patch_dofs)
+                dl.factor()
+            else:
+                dl.set_coarse_inverse(coarse_inv if coarse_inv is not None else coarse_inverse(L.A))
+            self.levels.append(dl)
+        for i, T in enumerate(transfers):
+            dt = Transfer(ctx, self.levels[i], self.levels[i + 1], T)
+            dt.update(T.nu, T.gamma)
+            self.transfers.append(dt)
+        lv = (vp * len(self.levels))(*[l.h for l in self.levels])
+        tr = (vp * max(1, len(self.transfers)))(*[t.h for t in self.transfers])
+        h = vp()
+        ctx.check(ctx.lib.alfi_mg_create(ctx.h, len(self.levels), lv, tr, int(k), 1 if robust_restriction else 0,
+                                         ctypes.byref(h)))
+        self.h = h
+        self.k = k
+        ctx.sync()
+        if verbose:
+            print("[alfi_amd] device hierarchy ready in %.1fs" % (time.time() - t0), flush=True)
+
+    def vcycle(self, b, x):
+        self.ctx.check(self.ctx.lib.alfi_mg_vcycle(self.h, b.ptr, x.ptr))
+
+    def fcycle(self, b, x):
+        self.ctx.check(self.ctx.lib.alfi_mg_fcycle(self.h, b.ptr, x.ptr))
+
+    def close(self):
+        if self.h:
+            self.ctx.lib.alfi_mg_destroy(self.h)
+            self.h = None
+        for t in self.transfers:
+            t.close()
+        for l in self.levels:
+            l.close()

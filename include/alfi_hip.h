@@ -1,0 +1,143 @@
+/* alfi_hip.h -- C ABI of libalfi_hip.so: the MI355X (gfx950) implementation of alfi's multigrid hot path.
+ *
+ * Every entry point replaces one piece of third-party machinery that florianwechsung/alfi configures but does not
+ * contain (file:line = where the reference selects / calls it; [3P] = PETSc / Firedrake code that is not in the
+ * reference tree).  The reference-side binding a maintainer would add is shown in
+ * INTEGRATION.md (a PCPython class and a transfer object calling these through ctypes).
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative ALFI_E_* code otherwise; alfi_last_error() gives the message.
+ *     No exception or abort crosses this boundary; HIP errors are captured and reported.
+ *   - `const T* host` arguments are borrowed for the duration of the call and copied to the device.
+ *   - `double* dvec` / `const double* dvec` arguments are DEVICE pointers (from alfi_malloc or any hipMalloc'ed
+ *     buffer on the ctx's device) holding a level vector: n = nbrows * bs doubles, node-major / component-minor
+ *     (alfi/bubble.py:86; PETSc block size = tdim, alfi/solver.py:512).
+ *   - one ctx = one device = one HIP stream; calls are stream-ordered and asynchronous unless they return host data.
+ *     A ctx is not thread-safe; use one ctx per thread / process (1 process per GPU, as 1 MPI rank in the reference).
+ *   - all floating point is FP64, all indices int32 (PETSC_ARCH ...-int32, examples/submission_template.pbs:28)
+ *     except offsets into per-patch storage (int64).
+ */
+#ifndef ALFI_HIP_H
+#define ALFI_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ALFI_OK 0
+#define ALFI_E_HIP -1      /* a HIP runtime call failed */
+#define ALFI_E_ARG -2      /* invalid argument / unsupported size */
+#define ALFI_E_STATE -3    /* call sequence error (e.g. apply before factor) */
+#define ALFI_E_SINGULAR -4 /* zero pivot met while inverting a patch or transfer block */
+
+typedef struct alfi_ctx alfi_ctx;
+typedef struct alfi_level alfi_level;
+typedef struct alfi_transfer alfi_transfer;
+typedef struct alfi_mg alfi_mg;
+
+/* ---- context, memory --------------------------------------------------------------------------------------------- */
+/* stream: a hipStream_t to launch on (e.g. torch.cuda.current_stream().cuda_stream), or NULL to create one. */
+int alfi_ctx_create(int device, void* stream, alfi_ctx** out);
+int alfi_ctx_destroy(alfi_ctx* ctx);
+int alfi_ctx_sync(alfi_ctx* ctx);
+const char* alfi_last_error(alfi_ctx* ctx); /* ctx may be NULL: last error of a failed alfi_ctx_create */
+int alfi_malloc(alfi_ctx* ctx, int64_t bytes, void** dptr);
+int alfi_free(alfi_ctx* ctx, void* dptr);
+int alfi_memcpy_h2d(alfi_ctx* ctx, void* dst, const void* src, int64_t bytes); /* synchronous */
+int alfi_memcpy_d2h(alfi_ctx* ctx, void* dst, const void* src, int64_t bytes); /* synchronous */
+int alfi_memset0(alfi_ctx* ctx, void* dst, int64_t bytes);                     /* stream-ordered */
+
+/* ---- per-kernel-class timers (the reference's PETSc event report, alfi/driver.py:77-92) -------------------------- */
+enum {
+  ALFI_EV_PATCH_APPLY = 0,   /* PCPATCHApply: per-patch gather + dense GEMV into the staging buffer */
+  ALFI_EV_PATCH_SCATTER = 1, /* PCPATCHScatter: dof-wise sum of the staged patch results */
+  ALFI_EV_PATCH_FACTOR = 2,  /* PCPatchComputeOp + inversion */
+  ALFI_EV_MATMULT = 3,       /* MatMult */
+  ALFI_EV_BLAS1 = 4,         /* FGMRES orthogonalisation / updates */
+  ALFI_EV_PROLONG = 5,       /* SchoeberlProlong */
+  ALFI_EV_RESTRICT = 6,      /* SchoeberlRestrict */
+  ALFI_EV_COARSE = 7,        /* coarse solve */
+  ALFI_EV_COUNT = 8
+};
+int alfi_prof_enable(alfi_ctx* ctx, int on); /* records a hipEvent pair around every launch of the classes above */
+int alfi_prof_reset(alfi_ctx* ctx);
+/* synchronises, then returns summed device time (ms) and launch count of one class since the last reset */
+int alfi_prof_get(alfi_ctx* ctx, int ev, double* total_ms, int64_t* count);
+
+/* ---- level operator: PETSc MatMult on the BAIJ level matrix [3P], alfi/solver.py:512 ----------------------------- */
+/* Block-CSR, bs x bs row-major blocks (bs = 2 or 3), nbrows block rows; bc_dofs: Dirichlet dofs of the level
+ * (their rows/columns of the operator are expected to be the identity, as firedrake.assemble(a, bcs) gives [3P]). */
+int alfi_level_create(alfi_ctx* ctx, int64_t nbrows, int bs, const int32_t* browptr_host, const int32_t* bcolidx_host,
+                      const double* bvals_host, const int32_t* bc_dofs_host, int64_t nbc, alfi_level** out);
+int alfi_level_destroy(alfi_level* lvl);
+/* new Newton step / new Reynolds number: same sparsity, new values (PatchPC.update -> PCSetUp_PATCH [3P]). */
+int alfi_level_update_values(alfi_level* lvl, const double* bvals_host);
+int alfi_level_size(alfi_level* lvl, int64_t* n);
+int alfi_spmv(alfi_level* lvl, const double* dx, double* dy);                        /* y = A x      */
+int alfi_residual(alfi_level* lvl, const double* db, const double* dx, double* dr); /* r = b - A x  */
+
+/* ---- patch smoother: firedrake.PatchPC -> PETSc PCPATCH [3P], alfi/solver.py:318-328, 599-602 -------------------- */
+/* Patches as produced by a patch-construction callable (alfi/relaxation.py:110-150) after PCPATCH's dof mapping:
+ * patch p owns dofs patch_dofs[patch_ptr[p] .. patch_ptr[p+1]), ascending, Dirichlet dofs excluded, sizes <= 160. */
+int alfi_patches_set(alfi_level* lvl, int64_t npatch, const int64_t* patch_ptr_host, const int32_t* patch_dofs_host);
+/* PCSetUp_PATCH with save_operators + dense_inverse (solver.py:320, 602): A_p = A[dofs_p, dofs_p], store inv(A_p). */
+int alfi_patches_factor(alfi_level* lvl);
+/* PCApply_PATCH, additive, no partition of unity (solver.py:321-322): y = sum_p R_p^T inv(A_p) R_p x; y[bc] = x[bc].
+ * x is not modified.  Deterministic (no atomics): patch results are staged and summed dof-wise in a fixed order. */
+int alfi_patch_apply(alfi_level* lvl, const double* dx, double* dy);
+/* sum_p n_p^2 (doubles held as inverses) and sum_p n_p, for roofline accounting */
+int alfi_patches_stats(alfi_level* lvl, int64_t* npatch, int64_t* sum_n, int64_t* sum_n2);
+/* debugging / parity tests: copy the dense inverse of patch p (row-major n_p x n_p) to the host */
+int alfi_patch_get_inverse(alfi_level* lvl, int64_t p, double* out_host);
+
+/* ---- level smoother: PETSc KSPFGMRES, k iterations, convergence_test skip [3P], alfi/solver.py:314-317 ----------- */
+/* Right-preconditioned FGMRES(k) with classical Gram-Schmidt, preconditioned by alfi_patch_apply; x is updated in
+ * place; nonzero_guess = 0 treats the incoming x as zero.  Entirely device-resident (no host synchronisation). */
+int alfi_smooth_fgmres(alfi_level* lvl, int k, const double* db, double* dx, int nonzero_guess);
+
+/* ---- coarse solve: firedrake.AssembledPC + LU [3P], alfi/solver.py:369-378 ---------------------------------------- */
+/* The coarse operator's dense inverse (row-major n x n), computed by the caller; applied as a device GEMV. */
+int alfi_coarse_set_inverse(alfi_level* lvl, const double* inv, int inv_is_device);
+int alfi_coarse_solve(alfi_level* lvl, const double* db, double* dx);
+
+/* ---- grid transfer: alfi/transfer.py:91-356 (PkP0SchoeberlTransfer), alfi/bubble.py (standard transfer) ----------- */
+typedef struct {
+  int64_t nbrows, nbcols;
+  const int32_t* rowptr; /* host */
+  const int32_t* colidx; /* host */
+  const double* vals;    /* host, (nnzb, bs, bs) */
+} alfi_bsr_host;
+/* P: standard prolongation (fine x coarse; bubble-corrected for 3-D P1+FB, transfer.py:334-356), PT its transpose,
+ * PT_plain: transpose of the plain nodal interpolation used when restriction is not robust (solver.py:595; may be
+ * NULL = same as PT).  D_I: rows of the cell-averaged grad-div matrix (gamma = 1) for the coarse-cell interior dofs
+ * in block order; D_IT its transpose.  blk_dofs: (nblk, m) interior dofs per coarse cell (transfer.py:13-46, m <= 32);
+ * K_II, D_II: (nblk, m, m) dense interior blocks of (2 sym grad u, grad v) and (cell_avg div u, div v). */
+int alfi_transfer_create(alfi_ctx* ctx, alfi_level* coarse, alfi_level* fine, const alfi_bsr_host* P,
+                         const alfi_bsr_host* PT, const alfi_bsr_host* PT_plain, const alfi_bsr_host* D_I,
+                         const alfi_bsr_host* D_IT, int64_t nblk, int m, const int32_t* blk_dofs_host,
+                         const double* K_II_host, const double* D_II_host, alfi_transfer** out);
+int alfi_transfer_destroy(alfi_transfer* tr);
+/* (re)build the interior solves for new (nu, gamma): AutoSchoeberlTransfer.rebuild, transfer.py:173-184, 238-244 */
+int alfi_transfer_update(alfi_transfer* tr, double nu, double gamma);
+/* prolong: fine = (I - E_I inv(A_II) E_I^T gamma D) P coarse   (transfer.py:246-259); fine Dirichlet dofs zeroed */
+int alfi_prolong(alfi_transfer* tr, const double* dxc, double* dxf);
+/* restrict: robust = 1: coarse = P^T (I - gamma D E_I inv(A_II) E_I^T) fine (transfer.py:261-275);
+ *           robust = 0: coarse = P_plain^T fine (firedrake.restrict).  Coarse Dirichlet dofs zeroed; fine untouched. */
+int alfi_restrict(alfi_transfer* tr, const double* drf, double* drc, int robust);
+
+/* ---- multigrid cycle: PETSc PCMG [3P], alfi/solver.py:359-379 ------------------------------------------------------ */
+/* levels[0] = coarsest (needs alfi_coarse_set_inverse), levels[l] l >= 1 need factored patches; transfers[l-1] links
+ * level l-1 and l.  k = smoother iterations (solver.py:309-310), robust_restriction = the --restriction flag. */
+int alfi_mg_create(alfi_ctx* ctx, int nlevels, alfi_level** levels, alfi_transfer** transfers, int k,
+                   int robust_restriction, alfi_mg** out);
+int alfi_mg_destroy(alfi_mg* mg);
+/* one multiplicative V-cycle on the finest level: x <- V(b, x) (PCMGMCycle_Private) */
+int alfi_mg_vcycle(alfi_mg* mg, const double* db, double* dx);
+/* pc_mg_type full (solver.py:366): x <- F(b), x need not be initialised (PCMGFCycle_Private) */
+int alfi_mg_fcycle(alfi_mg* mg, const double* db, double* dx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

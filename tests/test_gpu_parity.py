@@ -1,0 +1,184 @@
+"""Parity of the HIP path (through the C ABI) against the oracle, on the same seeded inputs.  -m gpu.
+
+Floating-point tolerances (FP64 everywhere).  The patch operators have condition numbers up to ~1e7 (gamma/nu), so two
+backward-stable inversions (LAPACK getrf/getri in the oracle, unpivoted register Gauss-Jordan on the GPU) agree to about
+cond * eps ~ 1e-9 relative in anything that applies the inverses; summation order differs as well.  Tolerances below:
+SpMV 1e-13, patch apply / smoother / transfers / cycles 1e-7 relative to the max-norm of the oracle result."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from alfi_amd.problem import (TwoDimLidDrivenCavityProblem, ThreeDimLidDrivenCavityProblem, build_hierarchy)
+
+CASES = [("2d-P2", lambda: TwoDimLidDrivenCavityProblem(4), 2, 2, 100.0, 6),
+         ("3d-P1FB", lambda: ThreeDimLidDrivenCavityProblem(2), 1, 1, 100.0, 4),
+         ("3d-P2FB", lambda: ThreeDimLidDrivenCavityProblem(2), 2, 1, 1000.0, 4)]
+
+
+def relerr(a, b):
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-300)
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from alfi_amd import hip
+    c = hip.Context(0)
+    yield c
+    c.close()
+
+
+@pytest.fixture(scope="module", params=CASES, ids=[c[0] for c in CASES])
+def setup(request, ctx):
+    from alfi_amd import hip
+    from oracle import alfi_oracle as O
+    name, mk, k, nref, Re, ksm = request.param
+    lv, tr = build_hierarchy(mk(), nref, k, Re=Re)
+    omg = {sr: O.build_oracle_mg(lv, tr, ksm, schoeberl_restriction=sr) for sr in (False, True)}
+    dmg = {sr: hip.Multigrid(ctx, lv, tr, ksm, robust_restriction=sr) for sr in (False, True)}
+    yield dict(lv=lv, tr=tr, omg=omg, dmg=dmg, k=ksm, name=name)
+    for m in dmg.values():
+        m.close()
+
+
+def rhs(n, bc, seed=0):
+    b = np.random.default_rng(seed).standard_normal(n)
+    b[bc] = 0.0
+    return b
+
+
+def test_spmv_and_residual(ctx, setup):
+    for L, dl, ol in zip(setup["lv"], setup["dmg"][False].levels, setup["omg"][False].levels):
+        x, b = rhs(L.n, [], 1), rhs(L.n, [], 2)
+        dx, db, dy = ctx.vec(x), ctx.vec(b), ctx.vec(L.n)
+        dl.spmv(dx, dy)
+        assert relerr(dy.get(), ol["A"] @ x) < 1e-13
+        dl.residual(db, dx, dy)
+        assert relerr(dy.get(), b - ol["A"] @ x) < 1e-13
+
+
+def test_patch_inverses(ctx, setup):
+    L, dl, ol = setup["lv"][-1], setup["dmg"][False].levels[-1], setup["omg"][False].levels[-1]
+    n = np.diff(L.patch_ptr)
+    worst = 0.0
+    for p in range(0, len(n), max(1, len(n) // 40)):
+        worst = max(worst, relerr(dl.patch_inverse(p, int(n[p])), ol["smoother"].inv[p]))
+    assert worst < 1e-7
+    npatch, sum_n, sum_n2 = dl.patch_stats()
+    assert (npatch, sum_n, sum_n2) == (len(n), n.sum(), (n * n).sum())
+
+
+def test_patch_apply(ctx, setup):
+    for L, dl, ol in list(zip(setup["lv"], setup["dmg"][False].levels, setup["omg"][False].levels))[1:]:
+        x = rhs(L.n, [], 3)          # Dirichlet entries non-zero on purpose: y[bc] must equal x[bc]
+        dx, dy = ctx.vec(x), ctx.vec(L.n)
+        dl.patch_apply(dx, dy)
+        y = dy.get()
+        ref = ol["smoother"].apply(x)
+        assert relerr(y, ref) < 1e-7
+        assert np.array_equal(y[L.bc_dofs], x[L.bc_dofs])
+        assert np.array_equal(dx.get(), x)                    # x untouched
+        dl.patch_apply(dx, dy)                                 # deterministic: bitwise reproducible
+        assert np.array_equal(dy.get(), y)
+
+
+def test_fgmres_smoother(ctx, setup):
+    from oracle import alfi_oracle as O
+    k = setup["k"]
+    for L, dl, ol in list(zip(setup["lv"], setup["dmg"][False].levels, setup["omg"][False].levels))[1:]:
+        b, x0 = rhs(L.n, L.bc_dofs, 4), rhs(L.n, L.bc_dofs, 5)
+        for nonzero in (True, False):
+            dx, db = ctx.vec(x0), ctx.vec(b)
+            dl.smooth(k, db, dx, nonzero_guess=nonzero)
+            ref = O.fgmres(lambda v: ol["A"] @ v, ol["smoother"].apply, b, x0 if nonzero else np.zeros_like(x0), k,
+                           nonzero_guess=nonzero)
+            assert relerr(dx.get(), ref) < 1e-7
+    # zero right-hand side and zero guess: iterate stays zero (no NaN from 0/0)
+    dx, db = ctx.vec(L.n), ctx.vec(L.n)
+    dl.smooth(k, db, dx, nonzero_guess=True)
+    assert np.array_equal(dx.get(), np.zeros(L.n))
+
+
+def test_transfers(ctx, setup):
+    lv = setup["lv"]
+    for i, (dt, ot) in enumerate(zip(setup["dmg"][True].transfers, setup["omg"][True].transfers)):
+        Lc, Lf = lv[i], lv[i + 1]
+        xc, rf = rhs(Lc.n, Lc.bc_dofs, 6), rhs(Lf.n, [], 7)
+        dxc, dxf, drf, drc = ctx.vec(xc), ctx.vec(Lf.n), ctx.vec(rf), ctx.vec(Lc.n)
+        dt.prolong(dxc, dxf)
+        ref = ot.st.prolong(xc)
+        ref[Lf.bc_dofs] = 0
+        assert relerr(dxf.get(), ref) < 1e-7
+        dt.restrict(drf, drc, robust=True)
+        ref = ot.st.restrict(rf)
+        ref[Lc.bc_dofs] = 0
+        assert relerr(drc.get(), ref) < 1e-7
+        assert np.array_equal(drf.get(), rf)        # the reference's in-place division of its input is not reproduced
+        dt.restrict(drf, drc, robust=False)
+        ref = ot.PT_plain @ rf
+        ref[Lc.bc_dofs] = 0
+        assert relerr(drc.get(), ref) < 1e-12
+        # adjointness on the device: <P~ u, r> == <u, R~ r> for u, r vanishing on the Dirichlet dofs
+        rf0 = rhs(Lf.n, Lf.bc_dofs, 11)
+        drf.set(rf0)
+        dt.restrict(drf, drc, robust=True)
+        lhs, rhs_ = dxf.get() @ rf0, xc @ drc.get()
+        assert abs(lhs - rhs_) < 1e-9 * max(abs(lhs), 1.0)
+
+
+@pytest.mark.parametrize("robust", [False, True])
+def test_vcycle_and_fcycle(ctx, setup, robust):
+    lv = setup["lv"]
+    L = lv[-1]
+    omg, dmg = setup["omg"][robust], setup["dmg"][robust]
+    b = rhs(L.n, L.bc_dofs, 8)
+    db, dx = ctx.vec(b), ctx.vec(L.n)
+    dmg.vcycle(db, dx)
+    ref = omg.vcycle(len(lv) - 1, b, np.zeros(L.n))
+    assert relerr(dx.get(), ref) < 1e-7
+    # second cycle from the first iterate: residual norms match
+    dmg.vcycle(db, dx)
+    ref2 = omg.vcycle(len(lv) - 1, b, ref)
+    A = omg.levels[-1]["A"]
+    r_dev, r_ref = np.linalg.norm(b - A @ dx.get()), np.linalg.norm(b - A @ ref2)
+    assert abs(r_dev - r_ref) < 1e-6 * np.linalg.norm(b)
+    assert r_ref < 0.5 * np.linalg.norm(b)            # and the cycle actually converges
+    dxf = ctx.vec(L.n)
+    dmg.fcycle(db, dxf)
+    assert relerr(dxf.get(), omg.fcycle(b)) < 1e-7
+
+
+def test_operator_update_refactors(ctx, setup):
+    """PatchPC.update: new values, same sparsity -> patches must be refactored before the next apply."""
+    from alfi_amd import hip
+    L = setup["lv"][-1]
+    dl = hip.Level(ctx, L.A, L.bc_dofs)
+    dl.set_patches(L.patch_ptr, L.patch_dofs)
+    x, y = ctx.vec(rhs(L.n, [], 9)), ctx.vec(L.n)
+    with pytest.raises(hip.AlfiHipError):
+        dl.patch_apply(x, y)                      # not factored yet
+    dl.factor()
+    dl.patch_apply(x, y)
+    y1 = y.get()
+    dl.update_values(2.0 * L.A.vals)
+    with pytest.raises(hip.AlfiHipError):
+        dl.patch_apply(x, y)
+    dl.factor()
+    dl.patch_apply(x, y)
+    y2 = y.get()
+    free = np.setdiff1d(np.arange(L.n), L.bc_dofs)
+    assert relerr(y2[free], 0.5 * y1[free]) < 1e-9
+    dl.close()
+
+
+def test_bad_arguments_are_reported(ctx, setup):
+    from alfi_amd import hip
+    L = setup["lv"][-1]
+    dl = hip.Level(ctx, L.A, L.bc_dofs)
+    with pytest.raises(hip.AlfiHipError):
+        dl.set_patches(np.array([0, 2]), np.array([5, 5]))            # not strictly ascending
+    with pytest.raises(hip.AlfiHipError):
+        dl.set_patches(np.array([0, 1]), np.array([L.n]))             # out of range
+    with pytest.raises(hip.AlfiHipError):
+        dl.set_patches(np.array([0, 161]), np.arange(161))            # too large
+    dl.close()
