@@ -18,6 +18,8 @@ def lib():
         _lib.alfi_host_assemble_bsr.restype = ctypes.c_int
         _lib.alfi_host_apply_bc_bsr.restype = ctypes.c_int
         _lib.alfi_host_extract_blocks.restype = ctypes.c_int
+        _lib.alfi_host_interior_blocks.restype = ctypes.c_int
+        _lib.alfi_host_bsr_transpose.restype = ctypes.c_int
     return _lib
 
 
@@ -39,7 +41,8 @@ def node_graph(cell_nodes, nnode):
     return rowptr, colidx
 
 
-def assemble_bsr(cell_nodes, g, vol, tensors, d, rowptr, colidx, nu=0.0, gamma=0.0, adv=0.0, wind=None, out=None):
+def assemble_bsr(cell_nodes, g, vol, tensors, d, rowptr, colidx, nu=0.0, gamma=0.0, adv=0.0, wind=None, out=None,
+                 row_map=None):
     cn = np.ascontiguousarray(cell_nodes, dtype=np.int32)
     ncell, nloc = cn.shape
     g = np.ascontiguousarray(g, dtype=np.float64)
@@ -49,9 +52,12 @@ def assemble_bsr(cell_nodes, g, vol, tensors, d, rowptr, colidx, nu=0.0, gamma=0
         wind = np.ascontiguousarray(wind, dtype=np.float64)
     if out is None:
         out = np.zeros((colidx.shape[0], d, d), dtype=np.float64)
+    if row_map is not None:
+        row_map = np.ascontiguousarray(row_map, dtype=np.int32)
     rc = lib().alfi_host_assemble_bsr(ctypes.c_int64(ncell), ctypes.c_int(nloc), ctypes.c_int(d), _p(cn), _p(g),
                                       _p(vol), _p(S), _p(bI), _p(T1), _p(wind), ctypes.c_double(nu),
-                                      ctypes.c_double(gamma), ctypes.c_double(adv), _p(rowptr), _p(colidx), _p(out))
+                                      ctypes.c_double(gamma), ctypes.c_double(adv), _p(row_map), _p(rowptr), _p(colidx),
+                                      _p(out))
     if rc != 0:
         raise RuntimeError("assemble_bsr failed (%d): sparsity pattern does not cover the mesh" % rc)
     return out
@@ -72,3 +78,30 @@ def extract_blocks(d, rowptr, colidx, vals, blk_ptr, blk_dofs):
     lib().alfi_host_extract_blocks(ctypes.c_int(d), _p(rowptr), _p(colidx), _p(vals), ctypes.c_int64(len(n)),
                                    _p(blk_ptr), _p(blk_dofs), _p(out_ptr), _p(out))
     return out_ptr, out
+
+
+def interior_blocks(cell_nodes, g, vol, tensors, d, blk_nodes, num_nodes, nch):
+    """K_II, D_II (nblk, m, m) of the coarse-cell interior dofs; children of block b are cells b*nch .. b*nch+nch-1."""
+    cn = np.ascontiguousarray(cell_nodes, dtype=np.int32)
+    nloc = cn.shape[1]
+    nblk, mn = blk_nodes.shape
+    m = mn * d
+    blk_local = np.full(num_nodes, -1, dtype=np.int32)
+    blk_local[blk_nodes.ravel()] = np.tile(np.arange(mn, dtype=np.int32), nblk)
+    g = np.ascontiguousarray(g, dtype=np.float64)
+    vol = np.ascontiguousarray(vol, dtype=np.float64)
+    S, bI = (np.ascontiguousarray(tensors[k], dtype=np.float64) for k in ("S", "bI"))
+    K = np.empty((nblk, m, m))
+    D = np.empty((nblk, m, m))
+    lib().alfi_host_interior_blocks(ctypes.c_int64(nblk), ctypes.c_int(nch), ctypes.c_int(nloc), ctypes.c_int(d),
+                                    _p(cn), _p(g), _p(vol), _p(S), _p(bI), _p(blk_local), ctypes.c_int(m), _p(K), _p(D))
+    return K, D
+
+
+def bsr_transpose(nbrows, nbcols, bs, rowptr, colidx, vals):
+    rowptr_t = np.empty(nbcols + 1, dtype=np.int32)
+    colidx_t = np.empty(colidx.shape[0], dtype=np.int32)
+    vals_t = np.empty_like(vals)
+    lib().alfi_host_bsr_transpose(ctypes.c_int64(nbrows), ctypes.c_int64(nbcols), ctypes.c_int(bs), _p(rowptr),
+                                  _p(colidx), _p(vals), _p(rowptr_t), _p(colidx_t), _p(vals_t))
+    return rowptr_t, colidx_t, vals_t

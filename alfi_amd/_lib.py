@@ -30,6 +30,9 @@ SIGNATURES = {
     "alfi_prof_enable": (ctypes.c_int, [vp, ctypes.c_int]),
     "alfi_prof_reset": (ctypes.c_int, [vp]),
     "alfi_prof_get": (ctypes.c_int, [vp, ctypes.c_int, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int64)]),
+    "alfi_prof_get_level": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_double),
+                                           ctypes.POINTER(ctypes.c_int64)]),
+    "alfi_level_id": (ctypes.c_int, [vp, ctypes.POINTER(ctypes.c_int)]),
     "alfi_level_create": (ctypes.c_int, [vp, ctypes.c_int64, ctypes.c_int, vp, vp, vp, vp, ctypes.c_int64,
                                          ctypes.POINTER(vp)]),
     "alfi_level_destroy": (ctypes.c_int, [vp]),

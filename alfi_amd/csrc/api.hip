@@ -33,6 +33,7 @@ int alfi_prof_begin(alfi_ctx* ctx, int kind) {
   }
   const int t = (int)ctx->ev_used++;
   ctx->ev_pool[t].kind = kind;
+  ctx->ev_pool[t].tag = ctx->cur_tag;
   (void)hipEventRecord(ctx->ev_pool[t].a, ctx->stream);
   return t;
 }
@@ -163,11 +164,15 @@ int alfi_prof_reset(alfi_ctx* ctx) {
   return 0;
 }
 int alfi_prof_get(alfi_ctx* ctx, int ev, double* total_ms, int64_t* count) {
+  return alfi_prof_get_level(ctx, ev, -1, total_ms, count);
+}
+int alfi_prof_get_level(alfi_ctx* ctx, int ev, int level_id, double* total_ms, int64_t* count) {
   ALFI_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
   double tot = 0;
   int64_t cnt = 0;
   for (size_t i = 0; i < ctx->ev_used; ++i) {
     if (ctx->ev_pool[i].kind != ev) continue;
+    if (level_id >= 0 && ctx->ev_pool[i].tag != level_id) continue;
     float ms = 0;
     ALFI_HIP_CHECK(ctx, hipEventElapsedTime(&ms, ctx->ev_pool[i].a, ctx->ev_pool[i].b));
     tot += ms;
@@ -187,6 +192,7 @@ int alfi_level_create(alfi_ctx* ctx, int64_t nbrows, int bs, const int32_t* brow
   ALFI_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   alfi_level* L = new alfi_level();
   L->ctx = ctx;
+  L->id = ctx->next_level_id++;
   L->bs = bs;
   L->n = nbrows * bs;
   alfi_bsr_host h{nbrows, nbrows, browptr, bcolidx, bvals};
@@ -242,8 +248,13 @@ int alfi_level_size(alfi_level* L, int64_t* n) {
   *n = L->n;
   return 0;
 }
+int alfi_level_id(alfi_level* L, int* id) {
+  *id = L->id;
+  return 0;
+}
 
 int alfi_spmv(alfi_level* L, const double* dx, double* dy) {
+  L->ctx->cur_tag = L->id;
   int t = alfi_prof_begin(L->ctx, ALFI_EV_MATMULT);
   ALFI_CHECK(launch_bsr_spmv(L->ctx, L->A, dx, dy, nullptr, 0.0, 0));
   alfi_prof_end(L->ctx, t);
@@ -251,6 +262,7 @@ int alfi_spmv(alfi_level* L, const double* dx, double* dy) {
 }
 
 int alfi_residual(alfi_level* L, const double* db, const double* dx, double* dr) {
+  L->ctx->cur_tag = L->id;
   int t = alfi_prof_begin(L->ctx, ALFI_EV_MATMULT);
   ALFI_CHECK(launch_bsr_spmv(L->ctx, L->A, dx, dr, db, 1.0, 1));
   alfi_prof_end(L->ctx, t);
@@ -350,6 +362,7 @@ int alfi_patches_factor(alfi_level* L) {
 int alfi_patch_apply(alfi_level* L, const double* dx, double* dy) {
   if (!L->factored) return alfi_set_error(L->ctx, ALFI_E_STATE, "alfi_patch_apply before alfi_patches_factor");
   if (dx == dy) return alfi_set_error(L->ctx, ALFI_E_ARG, "alfi_patch_apply: x and y must not alias");
+  L->ctx->cur_tag = L->id;
   return launch_patch_apply(L, dx, dy);
 }
 
@@ -402,6 +415,7 @@ int alfi_smooth_fgmres(alfi_level* L, int k, const double* db, double* dx, int n
   if (k < 1) return alfi_set_error(ctx, ALFI_E_ARG, "k must be >= 1");
   if (!L->factored) return alfi_set_error(ctx, ALFI_E_STATE, "alfi_smooth_fgmres before alfi_patches_factor");
   ALFI_CHECK(ensure_fgmres_workspace(L, k));
+  ctx->cur_tag = L->id;
   const int K = L->kmax;
   const int64_t n = L->n;
   HsLayout hl(K);
@@ -457,6 +471,7 @@ int alfi_coarse_set_inverse(alfi_level* L, const double* inv, int inv_is_device)
 
 int alfi_coarse_solve(alfi_level* L, const double* db, double* dx) {
   if (!L->cinv) return alfi_set_error(L->ctx, ALFI_E_STATE, "alfi_coarse_solve before alfi_coarse_set_inverse");
+  L->ctx->cur_tag = L->id;
   int t = alfi_prof_begin(L->ctx, ALFI_EV_COARSE);
   ALFI_CHECK(launch_dense_gemv(L->ctx, L->cinv, db, dx, L->n));
   alfi_prof_end(L->ctx, t);
@@ -555,6 +570,7 @@ int alfi_transfer_update(alfi_transfer* T, double nu, double gamma) {
 int alfi_prolong(alfi_transfer* T, const double* dxc, double* dxf) {
   alfi_ctx* ctx = T->ctx;
   if (!T->ready) return alfi_set_error(ctx, ALFI_E_STATE, "alfi_prolong before alfi_transfer_update");
+  ctx->cur_tag = T->fine->id;
   int t = alfi_prof_begin(ctx, ALFI_EV_PROLONG);
   ALFI_CHECK(launch_bsr_spmv(ctx, T->P, dxc, dxf, nullptr, 0.0, 0));                 // rhs = P coarse        :247
   ALFI_CHECK(launch_bsr_spmv(ctx, T->DI, dxf, T->bI, nullptr, 0.0, 0));              // b_I = (D rhs)_I       :249
@@ -568,6 +584,7 @@ int alfi_prolong(alfi_transfer* T, const double* dxc, double* dxf) {
 int alfi_restrict(alfi_transfer* T, const double* drf, double* drc, int robust) {
   alfi_ctx* ctx = T->ctx;
   if (robust && !T->ready) return alfi_set_error(ctx, ALFI_E_STATE, "alfi_restrict before alfi_transfer_update");
+  ctx->cur_tag = T->fine->id;
   int t = alfi_prof_begin(ctx, ALFI_EV_RESTRICT);
   if (robust) {
     ALFI_CHECK(launch_block_gemv(T, drf, T->tI, true));                               // t = inv(A_II) r_I     :265-270
@@ -632,6 +649,7 @@ static int vcycle(alfi_mg* mg, int l, const double* b, double* x) {
   ALFI_HIP_CHECK(ctx, hipMemsetAsync(C->mg_x, 0, sizeof(double) * C->n, ctx->stream));
   ALFI_CHECK(vcycle(mg, l - 1, C->mg_b, C->mg_x));
   ALFI_CHECK(alfi_prolong(T, C->mg_x, L->mg_r));                     // x += P x_{l-1}
+  ctx->cur_tag = L->id;
   int t = alfi_prof_begin(ctx, ALFI_EV_BLAS1);
   ALFI_CHECK(launch_axpy(ctx, x, L->mg_r, 1.0, L->n));
   alfi_prof_end(ctx, t);

@@ -17,9 +17,12 @@ struct alfi_ctx {
   struct EvPair {
     hipEvent_t a, b;
     int kind;
+    int tag;
   };
   std::vector<EvPair> ev_pool;   // all created pairs
   size_t ev_used = 0;            // pairs in use since last reset
+  int cur_tag = -1;      // level id attached to profiling records
+  int next_level_id = 0;
   // scratch for reductions: partial sums [RED_BLOCKS][RED_MAXV]
   double* red_partial = nullptr;
 };
@@ -57,6 +60,7 @@ struct DevBSR {
 
 struct alfi_level {
   alfi_ctx* ctx = nullptr;
+  int id = 0;
   int64_t n = 0;  // scalar dofs
   int bs = 0;
   DevBSR A;

@@ -70,115 +70,138 @@ static inline int64_t find_col(const int32_t* colidx, int64_t lo, int64_t hi, in
   return p - colidx;
 }
 
-// vals (nnzb, d, d) += nu*K + gamma*D + adv*N(w).  g: (ncell, d+1, d) gradients of the barycentric coordinates,
-// vol: (ncell).  S: (nloc,nloc,d+1,d+1) avg d_i phi_a d_j phi_b; bI: (nloc,d+1) avg d_i phi_a;
-// T1: (nloc,d+1,nloc,nloc) avg phi_k d_i phi_b phi_a (index order k,i,b,a).  w: (nnode, d) wind or nullptr.
+// Element matrix Ae (ndof x ndof, dof = a*d + c) = nu*K + gamma*D + adv*N(w) of one affine simplex.
+// gc: (d+1, d) gradients of the barycentric coordinates, vc: volume.  S: (nloc,nloc,d+1,d+1) avg d_i phi_a d_j phi_b;
+// bI: (nloc,d+1) avg d_i phi_a; T1: (nloc,d+1,nloc,nloc) avg phi_k d_i phi_b phi_a (index order k,i,b,a);
+// wk: (nloc, d) wind at the cell's nodes (only read when adv != 0).
+struct ElemWork {
+  std::vector<double> G, Hij, bvec, cki;
+  ElemWork(int nloc, int d) : G((d + 1) * (d + 1)), Hij((size_t)(d + 1) * (d + 1) * d * d), bvec(nloc * d),
+                               cki((size_t)nloc * (d + 1)) {}
+};
+
+static void element_matrix(int nloc, int d, const double* gc, double vc, const double* S, const double* bI,
+                           const double* T1, const double* wk, double nu, double gamma, double adv, ElemWork& W,
+                           double* Ae) {
+  const int nv = d + 1;
+  const int ndof = nloc * d;
+  double* G = W.G.data();
+  double* Hij = W.Hij.data();
+  double* bvec = W.bvec.data();
+  double* cki = W.cki.data();
+  std::fill(Ae, Ae + (size_t)ndof * ndof, 0.0);
+  if (nu != 0.0) {
+    for (int i = 0; i < nv; ++i)
+      for (int j = 0; j < nv; ++j) {
+        double s = 0;
+        for (int x = 0; x < d; ++x) s += gc[i * d + x] * gc[j * d + x];
+        G[i * nv + j] = s;
+        for (int dd = 0; dd < d; ++dd)
+          for (int cc = 0; cc < d; ++cc) Hij[((i * nv + j) * d + dd) * d + cc] = gc[i * d + dd] * gc[j * d + cc];
+      }
+    for (int a = 0; a < nloc; ++a)
+      for (int b = 0; b < nloc; ++b) {
+        const double* Sab = S + ((size_t)(a * nloc + b)) * nv * nv;
+        double gab = 0;
+        double h[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};  // h[dd][cc] = int d_dd phi_a d_cc phi_b
+        for (int i = 0; i < nv; ++i)
+          for (int j = 0; j < nv; ++j) {
+            const double s = Sab[i * nv + j];
+            if (s == 0.0) continue;
+            gab += s * G[i * nv + j];
+            const double* hh = &Hij[((i * nv + j) * d) * d];
+            for (int q = 0; q < d * d; ++q) h[q] += s * hh[q];
+          }
+        // K_(a,c),(b,dd) = delta_{c,dd} G_ab + int d_dd phi_a d_c phi_b
+        for (int cc = 0; cc < d; ++cc)
+          for (int dd = 0; dd < d; ++dd) {
+            double v = h[dd * d + cc];
+            if (cc == dd) v += gab;
+            Ae[(size_t)(a * d + cc) * ndof + b * d + dd] += nu * vc * v;
+          }
+      }
+  }
+  if (gamma != 0.0) {
+    for (int a = 0; a < nloc; ++a)
+      for (int cc = 0; cc < d; ++cc) {
+        double s = 0;
+        for (int i = 0; i < nv; ++i) s += gc[i * d + cc] * bI[a * nv + i];
+        bvec[a * d + cc] = s;  // (1/vol) int d_cc phi_a
+      }
+    const double f = gamma * vc;
+    for (int p = 0; p < ndof; ++p) {
+      const double bp = f * bvec[p];
+      if (bp == 0.0) continue;
+      for (int q = 0; q < ndof; ++q) Ae[(size_t)p * ndof + q] += bp * bvec[q];
+    }
+  }
+  if (adv != 0.0) {
+    // term 1: delta_{cd} * vol * sum_{k,i} (w_k . g_i) T1[k,i,b,a]
+    for (int k = 0; k < nloc; ++k)
+      for (int i = 0; i < nv; ++i) {
+        double s = 0;
+        for (int x = 0; x < d; ++x) s += wk[k * d + x] * gc[i * d + x];
+        cki[k * nv + i] = s;
+      }
+    const double f = adv * vc;
+    for (int k = 0; k < nloc; ++k)
+      for (int i = 0; i < nv; ++i) {
+        const double cc1 = f * cki[k * nv + i];
+        if (cc1 == 0.0) continue;
+        const double* T = T1 + ((size_t)(k * nv + i)) * nloc * nloc;  // T[b][a]
+        for (int b = 0; b < nloc; ++b)
+          for (int a = 0; a < nloc; ++a) {
+            const double t = cc1 * T[b * nloc + a];
+            for (int x = 0; x < d; ++x) Ae[(size_t)(a * d + x) * ndof + b * d + x] += t;
+          }
+      }
+    // term 2: (a,c),(b,dd) += vol * w_k^c g_i^dd * T1[b,i,k,a]
+    for (int b = 0; b < nloc; ++b)
+      for (int i = 0; i < nv; ++i) {
+        const double* T = T1 + ((size_t)(b * nv + i)) * nloc * nloc;  // T[k][a]
+        for (int k = 0; k < nloc; ++k)
+          for (int a = 0; a < nloc; ++a) {
+            const double t = f * T[k * nloc + a];
+            if (t == 0.0) continue;
+            for (int cc = 0; cc < d; ++cc) {
+              const double tw = t * wk[k * d + cc];
+              for (int dd = 0; dd < d; ++dd) Ae[(size_t)(a * d + cc) * ndof + b * d + dd] += tw * gc[i * d + dd];
+            }
+          }
+      }
+  }
+}
+
+// vals (nnzb, d, d) += nu*K + gamma*D + adv*N(w), scattered into a BSR matrix whose block rows are the nodes mapped
+// through row_map (nullptr: identity; row_map[node] < 0: row skipped) and whose block columns are all nodes.
 int alfi_host_assemble_bsr(int64_t ncell, int nloc, int d, const int32_t* cell_nodes, const double* g,
                            const double* vol, const double* S, const double* bI, const double* T1, const double* w,
-                           double nu, double gamma, double adv, const int32_t* rowptr, const int32_t* colidx,
-                           double* vals) {
+                           double nu, double gamma, double adv, const int32_t* row_map, const int32_t* rowptr,
+                           const int32_t* colidx, double* vals) {
   const int nv = d + 1;
   const int ndof = nloc * d;
   const bool do_adv = (adv != 0.0) && (w != nullptr);
   int err = 0;
 #pragma omp parallel
   {
-    std::vector<double> Ae((size_t)ndof * ndof), G((size_t)nv * nv), bvec(ndof), cki((size_t)nloc * nv),
-        wk((size_t)nloc * d), Hij((size_t)nv * nv * d * d);
+    ElemWork W(nloc, d);
+    std::vector<double> Ae((size_t)ndof * ndof), wk((size_t)nloc * d);
 #pragma omp for schedule(dynamic, 256)
     for (int64_t c = 0; c < ncell; ++c) {
-      const double* gc = g + c * nv * d;
-      const double vc = vol[c];
       const int32_t* cn = cell_nodes + c * nloc;
-      std::fill(Ae.begin(), Ae.end(), 0.0);
-      // geometry products: G[i][j] = g_i . g_j ; Hij[i][j][dd][cc] = g_i^dd g_j^cc
-      for (int i = 0; i < nv; ++i)
-        for (int j = 0; j < nv; ++j) {
-          double s = 0;
-          for (int x = 0; x < d; ++x) s += gc[i * d + x] * gc[j * d + x];
-          G[i * nv + j] = s;
-          for (int dd = 0; dd < d; ++dd)
-            for (int cc = 0; cc < d; ++cc) Hij[((i * nv + j) * d + dd) * d + cc] = gc[i * d + dd] * gc[j * d + cc];
-        }
-      if (nu != 0.0) {
-        for (int a = 0; a < nloc; ++a)
-          for (int b = 0; b < nloc; ++b) {
-            const double* Sab = S + ((size_t)(a * nloc + b)) * nv * nv;
-            double gab = 0;
-            double h[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};  // h[dd][cc] = int d_dd phi_a d_cc phi_b
-            for (int i = 0; i < nv; ++i)
-              for (int j = 0; j < nv; ++j) {
-                const double s = Sab[i * nv + j];
-                if (s == 0.0) continue;
-                gab += s * G[i * nv + j];
-                const double* hh = &Hij[((i * nv + j) * d) * d];
-                for (int q = 0; q < d * d; ++q) h[q] += s * hh[q];
-              }
-            // K_(a,c),(b,dd) = delta_{c,dd} G_ab + int d_dd phi_a d_c phi_b
-            for (int cc = 0; cc < d; ++cc)
-              for (int dd = 0; dd < d; ++dd) {
-                double v = h[dd * d + cc];
-                if (cc == dd) v += gab;
-                Ae[(size_t)(a * d + cc) * ndof + b * d + dd] += nu * vc * v;
-              }
-          }
+      if (row_map) {
+        bool any = false;
+        for (int a = 0; a < nloc; ++a) any |= row_map[cn[a]] >= 0;
+        if (!any) continue;
       }
-      if (gamma != 0.0) {
-        for (int a = 0; a < nloc; ++a)
-          for (int cc = 0; cc < d; ++cc) {
-            double s = 0;
-            for (int i = 0; i < nv; ++i) s += gc[i * d + cc] * bI[a * nv + i];
-            bvec[a * d + cc] = s;  // (1/vol) int d_cc phi_a
-          }
-        const double f = gamma * vc;
-        for (int p = 0; p < ndof; ++p) {
-          const double bp = f * bvec[p];
-          if (bp == 0.0) continue;
-          for (int q = 0; q < ndof; ++q) Ae[(size_t)p * ndof + q] += bp * bvec[q];
-        }
-      }
-      if (do_adv) {
+      if (do_adv)
         for (int k = 0; k < nloc; ++k)
           for (int x = 0; x < d; ++x) wk[k * d + x] = w[(int64_t)cn[k] * d + x];
-        // term 1: delta_{cd} * vol * sum_{k,i} (w_k . g_i) T1[k,i,b,a]
-        for (int k = 0; k < nloc; ++k)
-          for (int i = 0; i < nv; ++i) {
-            double s = 0;
-            for (int x = 0; x < d; ++x) s += wk[k * d + x] * gc[i * d + x];
-            cki[k * nv + i] = s;
-          }
-        const double f = adv * vc;
-        for (int k = 0; k < nloc; ++k)
-          for (int i = 0; i < nv; ++i) {
-            const double cc1 = f * cki[k * nv + i];
-            const double* T = T1 + ((size_t)(k * nv + i)) * nloc * nloc;  // T[b][a]
-            if (cc1 != 0.0) {
-              for (int b = 0; b < nloc; ++b)
-                for (int a = 0; a < nloc; ++a) {
-                  const double t = cc1 * T[b * nloc + a];
-                  for (int x = 0; x < d; ++x) Ae[(size_t)(a * d + x) * ndof + b * d + x] += t;
-                }
-            }
-            // term 2: (a,c),(b,dd) += vol * w_k^c g_i^dd * T1[b,i,k,a]   (here the loop variable k is "k", and
-            // T1 is indexed [b][i][k][a])
-          }
-        for (int b = 0; b < nloc; ++b)
-          for (int i = 0; i < nv; ++i) {
-            const double* T = T1 + ((size_t)(b * nv + i)) * nloc * nloc;  // T[k][a]
-            for (int k = 0; k < nloc; ++k)
-              for (int a = 0; a < nloc; ++a) {
-                const double t = f * T[k * nloc + a];
-                if (t == 0.0) continue;
-                for (int cc = 0; cc < d; ++cc) {
-                  const double tw = t * wk[k * d + cc];
-                  for (int dd = 0; dd < d; ++dd) Ae[(size_t)(a * d + cc) * ndof + b * d + dd] += tw * gc[i * d + dd];
-                }
-              }
-          }
-      }
-      // scatter
+      element_matrix(nloc, d, g + c * nv * d, vol[c], S, bI, T1, wk.data(), nu, gamma, do_adv ? adv : 0.0, W,
+                     Ae.data());
       for (int a = 0; a < nloc; ++a) {
-        const int32_t ra = cn[a];
+        const int32_t ra = row_map ? row_map[cn[a]] : cn[a];
+        if (ra < 0) continue;
         const int64_t lo = rowptr[ra], hi = rowptr[ra + 1];
         for (int b = 0; b < nloc; ++b) {
           const int64_t pos = find_col(colidx, lo, hi, cn[b]);
@@ -198,6 +221,76 @@ int alfi_host_assemble_bsr(int64_t ncell, int nloc, int d, const int32_t* cell_n
     }
   }
   return err ? -2 : 0;
+}
+
+// Dense interior blocks of the Schoeberl transfer, assembled directly: block `blk` (= coarse cell) receives the
+// contributions of its nch children (fine cells blk*nch .. blk*nch+nch-1) restricted to the block's interior dofs.
+// blk_local[node] = position of the node inside its block (0..m/d-1) or -1.  KII, DII: (nblk, m, m) row-major.
+int alfi_host_interior_blocks(int64_t nblk, int nch, int nloc, int d, const int32_t* cell_nodes, const double* g,
+                              const double* vol, const double* S, const double* bI, const int32_t* blk_local, int m,
+                              double* KII, double* DII) {
+  const int nv = d + 1;
+  const int ndof = nloc * d;
+#pragma omp parallel
+  {
+    ElemWork W(nloc, d);
+    std::vector<double> Ke((size_t)ndof * ndof), De((size_t)ndof * ndof);
+#pragma omp for schedule(static)
+    for (int64_t blk = 0; blk < nblk; ++blk) {
+      double* Kb = KII + blk * m * m;
+      double* Db = DII + blk * m * m;
+      std::fill(Kb, Kb + (size_t)m * m, 0.0);
+      std::fill(Db, Db + (size_t)m * m, 0.0);
+      for (int ch = 0; ch < nch; ++ch) {
+        const int64_t c = blk * nch + ch;
+        const int32_t* cn = cell_nodes + c * nloc;
+        element_matrix(nloc, d, g + c * nv * d, vol[c], S, bI, nullptr, nullptr, 1.0, 0.0, 0.0, W, Ke.data());
+        element_matrix(nloc, d, g + c * nv * d, vol[c], S, bI, nullptr, nullptr, 0.0, 1.0, 0.0, W, De.data());
+        for (int a = 0; a < nloc; ++a) {
+          const int la = blk_local[cn[a]];
+          if (la < 0) continue;
+          for (int b = 0; b < nloc; ++b) {
+            const int lb = blk_local[cn[b]];
+            if (lb < 0) continue;
+            for (int cc = 0; cc < d; ++cc)
+              for (int dd = 0; dd < d; ++dd) {
+                const size_t src = (size_t)(a * d + cc) * ndof + b * d + dd;
+                const size_t dst = (size_t)(la * d + cc) * m + lb * d + dd;
+                Kb[dst] += Ke[src];
+                Db[dst] += De[src];
+              }
+          }
+        }
+      }
+    }
+  }
+  return 0;
+}
+
+// Transpose of a BSR matrix (counting sort; output columns ascending because rows are visited in order).
+int alfi_host_bsr_transpose(int64_t nbrows, int64_t nbcols, int bs, const int32_t* rowptr, const int32_t* colidx,
+                            const double* vals, int32_t* rowptr_t, int32_t* colidx_t, double* vals_t) {
+  const int64_t nnzb = rowptr[nbrows];
+  std::fill(rowptr_t, rowptr_t + nbcols + 1, 0);
+  for (int64_t k = 0; k < nnzb; ++k) rowptr_t[colidx[k] + 1]++;
+  for (int64_t j = 0; j < nbcols; ++j) rowptr_t[j + 1] += rowptr_t[j];
+  std::vector<int32_t> fill(rowptr_t, rowptr_t + nbcols);
+  std::vector<int32_t> src(nnzb);
+  for (int64_t r = 0; r < nbrows; ++r)
+    for (int64_t k = rowptr[r]; k < rowptr[r + 1]; ++k) {
+      const int32_t q = fill[colidx[k]]++;
+      colidx_t[q] = (int32_t)r;
+      src[q] = (int32_t)k;
+    }
+  const int bb = bs * bs;
+#pragma omp parallel for schedule(static)
+  for (int64_t q = 0; q < nnzb; ++q) {
+    const double* s = vals + (int64_t)src[q] * bb;
+    double* t = vals_t + q * bb;
+    for (int i = 0; i < bs; ++i)
+      for (int j = 0; j < bs; ++j) t[j * bs + i] = s[i * bs + j];
+  }
+  return 0;
 }
 
 // Dirichlet rows and columns -> identity (what firedrake.assemble(a, bcs=...) produces).  bcmask: (nnode*d) bytes.

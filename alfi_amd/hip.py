@@ -59,11 +59,12 @@ class Context(object):
     def prof_reset(self):
         self.check(self.lib.alfi_prof_reset(self.h))
 
-    def prof_get(self):
+    def prof_get(self, level_id=-1):
+        """{event name: (total device ms, launches)} since the last reset, optionally for one level only."""
         out = {}
         for i, name in enumerate(_lib.EVENTS):
             ms, cnt = ctypes.c_double(), ctypes.c_int64()
-            self.check(self.lib.alfi_prof_get(self.h, i, ctypes.byref(ms), ctypes.byref(cnt)))
+            self.check(self.lib.alfi_prof_get_level(self.h, i, int(level_id), ctypes.byref(ms), ctypes.byref(cnt)))
             out[name] = (ms.value, cnt.value)
         return out
 
@@ -119,6 +120,9 @@ class Level(object):
                                             _ptr(np.ascontiguousarray(A.vals)), _ptr(bc), len(bc), ctypes.byref(h)))
         self.h = h
         self.nnzb = A.nnzb
+        i = ctypes.c_int()
+        ctx.check(ctx.lib.alfi_level_id(h, ctypes.byref(i)))
+        self.id = i.value
 
     def update_values(self, vals):
         vals = np.ascontiguousarray(vals, dtype=np.float64)

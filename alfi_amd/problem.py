@@ -131,13 +131,8 @@ class BSR(object):
         return BSR(len(rows), self.nbcols, self.bs, ptr, self.colidx[idx], self.vals[idx])
 
     def transpose(self):
-        pat = sp.csr_matrix((np.arange(1, self.nnzb + 1, dtype=np.int64), self.colidx, self.rowptr),
-                            shape=(self.nbrows, self.nbcols))
-        T = pat.T.tocsr()
-        T.sort_indices()
-        perm = T.data - 1
-        return BSR(self.nbcols, self.nbrows, self.bs, T.indptr, T.indices,
-                   np.ascontiguousarray(self.vals[perm].transpose(0, 2, 1)))
+        rp, ci, v = _hostlib.bsr_transpose(self.nbrows, self.nbcols, self.bs, self.rowptr, self.colidx, self.vals)
+        return BSR(self.nbcols, self.nbrows, self.bs, rp, ci, v)
 
 
 class LevelData(object):
@@ -182,31 +177,31 @@ def build_hierarchy(problem, nref, k, Re, gamma=1e4, advect=True, patches=True, 
         tens = element.reference_tensors()
         bcmask = np.repeat(V.bc_node_mask, d)
         wind = problem.driver(V.node_coords)
-        # K and D separately first (the transfer needs their interior blocks), then A = nu K + gamma D + N(w)
-        K = _hostlib.assemble_bsr(V.cell_nodes, g, vol, tens, d, rowptr, colidx, nu=1.0)
+        # level operator in one pass over the cells
+        A = _hostlib.assemble_bsr(V.cell_nodes, g, vol, tens, d, rowptr, colidx, nu=nu, gamma=gamma, adv=adv,
+                                  wind=wind if adv else None)
+        _hostlib.apply_bc_bsr(V.num_nodes, d, rowptr, colidx, A, bcmask)
         T = None
         if l > 0:
             T = TransferData()
-            blk_nodes = coarse_cell_blocks(V)
+            blk_nodes = coarse_cell_blocks(V)                      # (coarse cells, interior nodes), parent-major
             T.blk_dofs = np.ascontiguousarray(V.node_dofs(blk_nodes), dtype=np.int32)     # (nblk, m)
-            nblk, mm = T.blk_dofs.shape
-            bptr = np.arange(nblk + 1, dtype=np.int64) * mm
-            _, kii = _hostlib.extract_blocks(d, rowptr, colidx, K, bptr, T.blk_dofs.ravel())
-            T.K_II = kii.reshape(nblk, mm, mm)
-        A = K
-        A *= nu
-        D = _hostlib.assemble_bsr(V.cell_nodes, g, vol, tens, d, rowptr, colidx, gamma=1.0)
-        if l > 0:
-            _, dii = _hostlib.extract_blocks(d, rowptr, colidx, D, bptr, T.blk_dofs.ravel())
-            T.D_II = dii.reshape(nblk, mm, mm)
-            Dbsr = BSR(V.num_nodes, V.num_nodes, d, rowptr, colidx, D)
-            T.D_I = Dbsr.select_rows(blk_nodes.ravel())           # rows: interior nodes in block order
+            # dense interior blocks of (2 sym grad u, grad v) and (cell_avg div u, div v), assembled directly
+            T.K_II, T.D_II = _hostlib.interior_blocks(V.cell_nodes, g, vol, tens, d, blk_nodes, V.num_nodes,
+                                                      2 ** dim)
+            # rows of the grad-div matrix (gamma = 1, no BCs) for the interior nodes, in block order
+            rows = blk_nodes.ravel().astype(np.int64)
+            cnt = (rowptr[rows + 1] - rowptr[rows]).astype(np.int64)
+            ptr = np.concatenate([[0], np.cumsum(cnt)])
+            idx = np.repeat(rowptr[rows].astype(np.int64) - ptr[:-1], cnt) + np.arange(ptr[-1])
+            di_rowptr, di_colidx = ptr.astype(np.int32), colidx[idx]
+            del idx
+            row_map = np.full(V.num_nodes, -1, dtype=np.int32)
+            row_map[rows] = np.arange(rows.shape[0], dtype=np.int32)
+            di_vals = _hostlib.assemble_bsr(V.cell_nodes, g, vol, tens, d, di_rowptr, di_colidx, gamma=1.0,
+                                            row_map=row_map)
+            T.D_I = BSR(rows.shape[0], V.num_nodes, d, di_rowptr, di_colidx, di_vals)
             T.D_IT = T.D_I.transpose()                            # (fine nodes) x (interior nodes)
-        A += gamma * D
-        del D
-        if adv:
-            _hostlib.assemble_bsr(V.cell_nodes, g, vol, tens, d, rowptr, colidx, adv=adv, wind=wind, out=A)
-        _hostlib.apply_bc_bsr(V.num_nodes, d, rowptr, colidx, A, bcmask)
         L.A = BSR(V.num_nodes, V.num_nodes, d, rowptr, colidx, A)
         L.bc_dofs = V.bc_dofs
         L.nu, L.gamma = nu, gamma

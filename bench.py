@@ -1,0 +1,216 @@
+#!/usr/bin/env python3
+"""Benchmark of the multigrid hot path: V-cycles/s (and DoF*smooths/s) on the synthetic lid-driven cavity.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--config cfg4]
+
+A "step" is one multiplicative V-cycle (k pre- and post-smoothing FGMRES iterations with the additive vertex-star
+patch smoother on every level, Schoeberl prolongation, dense coarse solve) on the finest level, with all operators,
+patch inverses and vectors resident in HBM before the timed region starts.  Default workload = BASELINE.json config 4:
+ldc3d [P2+FB]^3-P0, N = 56 (10 707 315 velocity dofs, 185 193 star patches of up to 153 dofs), Re = 1000, k = 10.
+
+Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (patch_apply_kernel: streams every dense patch
+inverse once per smoother iteration); its `achieved` is algorithmic bytes / device time measured live with HIP events on
+the library's stream during the timed region.  `cpu_baseline` times the C/OpenMP oracle port on the host cores on a
+bounded sample (the same hierarchy truncated by one level, scaled by the dof ratio).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+CONFIGS = {
+    # name: (dim, baseN, nref, k_element, Re, smoothing k)  -- BASELINE.md table
+    "cfg1": (2, 16, 2, 2, 10.0, 6),
+    "cfg2": (2, 6, 6, 2, 100.0, 6),
+    "cfg3": (3, 2, 4, 1, 100.0, 10),
+    "cfg4": (3, 7, 3, 2, 1000.0, 10),
+    "cfg4s": (3, 7, 2, 2, 1000.0, 10),   # config 4 truncated by one level (N = 28), for quick tuning runs
+    "tiny": (3, 2, 1, 2, 1000.0, 4),
+}
+HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 TB/s achievable)
+
+
+def describe(cfg):
+    dim, baseN, nref, ke, Re, k = CONFIGS[cfg]
+    el = "[P2]^2" if dim == 2 else ("[P1+FB]^3" if ke == 1 else "[P2+FB]^3")
+    return "ldc%dd %s-P0, N=%d (baseN %d, nref %d), Re=%g, gamma=1e4, FGMRES(%d)+star patches" % (
+        dim, el, baseN * 2 ** nref, baseN, nref, Re, k)
+
+
+def build_problem(cfg, verbose):
+    from alfi_amd.problem import TwoDimLidDrivenCavityProblem, ThreeDimLidDrivenCavityProblem, build_hierarchy
+    dim, baseN, nref, ke, Re, k = CONFIGS[cfg]
+    prob = TwoDimLidDrivenCavityProblem(baseN) if dim == 2 else ThreeDimLidDrivenCavityProblem(baseN)
+    lv, tr = build_hierarchy(prob, nref, ke, Re=Re, verbose=verbose)
+    return lv, tr, k
+
+
+def coarse_inverse_device(A_bsr):
+    """Dense inverse of the coarsest operator.  Small: LAPACK on the host.  Large (config 4: 23 355 dofs): FP64
+    inversion on the GPU through torch (setup only; stands in for the reference's SuperLU_DIST factorisation)."""
+    n = A_bsr.shape[0]
+    if n <= 4096:
+        return np.linalg.inv(A_bsr.to_scipy().toarray()), None
+    import torch
+    A = torch.from_numpy(A_bsr.to_scipy().toarray()).to("cuda")
+    Ainv = torch.linalg.inv(A).contiguous()
+    del A
+    torch.cuda.synchronize()
+    return int(Ainv.data_ptr()), Ainv
+
+
+def vcycle_bytes(levels, dmg, k):
+    """Algorithmic HBM bytes of one V-cycle and of one patch_apply_kernel launch per level."""
+    total = 0.0
+    per_level_apply = {}
+    for L, dl in zip(levels, dmg.levels):
+        if L.level == 0:
+            total += 8.0 * L.n * L.n
+            continue
+        npatch, sum_n, sum_n2 = dl.patch_stats()
+        b_apply_kernel = 8.0 * sum_n2 + 20.0 * sum_n          # inverse + int32 dofs + gathered x + staged result
+        b_patch = 8.0 * sum_n2 + 28.0 * sum_n + 8.0 * L.n      # + dof-wise sum (read staged, write y)
+        bs = L.bs
+        b_spmv = (8.0 * bs * bs + 4.0) * L.A.nnzb + 4.0 * (L.A.nbrows + 1) + 16.0 * L.n
+        b_blas1 = 8.0 * L.n * (k * k + 3 * k + 2)
+        total += 2 * (k * (b_patch + b_spmv) + b_blas1) + b_spmv
+        per_level_apply[dl.id] = b_apply_kernel
+    return total, per_level_apply
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--config", default=os.environ.get("ALFI_BENCH_CONFIG", "cfg4"), choices=sorted(CONFIGS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--verbose", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        from bench_dist import main_distributed
+        return main_distributed(args, rank, world, local_rank)
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    torch.cuda.set_device(0)
+    from alfi_amd import hip
+
+    t0 = time.time()
+    lv, tr, k = build_problem(args.config, args.verbose)
+    t_gen = time.time() - t0
+    ctx = hip.Context(0)
+    inv, keep = coarse_inverse_device(lv[0].A)
+    t0 = time.time()
+    dmg = hip.Multigrid(ctx, lv, tr, k, robust_restriction=False, coarse_inv=inv, verbose=args.verbose)
+    ctx.sync()
+    t_setup = time.time() - t0
+    L = lv[-1]
+    b = np.random.default_rng(0).standard_normal(L.n)
+    b[L.bc_dofs] = 0.0
+    db, dx = ctx.vec(b), ctx.vec(L.n)
+
+    for _ in range(args.warmup):
+        dmg.vcycle(db, dx)
+    ctx.sync()
+    ctx.prof_enable(True)
+    ctx.prof_reset()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        dmg.vcycle(db, dx)
+    ctx.sync()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    ctx.prof_enable(False)
+
+    # convergence sanity: the timed cycles must have reduced the residual (no skipped work)
+    dr = ctx.vec(L.n)
+    dmg.levels[-1].residual(db, dx, dr)
+    res = float(np.linalg.norm(dr.get()) / np.linalg.norm(b))
+
+    ms_per_step = 1e3 * elapsed / args.steps
+    vps = args.steps / elapsed
+    nlev = len(lv)
+    smooths_per_cycle_finest = 2 * k
+    total_bytes, apply_bytes = vcycle_bytes(lv, dmg, k)
+    # dominant kernel: patch_apply_kernel, all launches of the timed region
+    prof_all = ctx.prof_get()
+    t_apply_ms, n_apply = prof_all["PATCH_APPLY"]
+    bytes_apply_total = 0.0
+    per_level = {}
+    for dl in dmg.levels[1:]:
+        ms, cnt = ctx.prof_get(dl.id)["PATCH_APPLY"]
+        bytes_apply_total += apply_bytes[dl.id] * cnt
+        per_level[dl.id] = (ms, cnt)
+    achieved = bytes_apply_total / (t_apply_ms * 1e-3) / 1e9 if t_apply_ms > 0 else 0.0
+    fin = dmg.levels[-1]
+    ms_f, cnt_f = per_level[fin.id]
+    finest_gbs = apply_bytes[fin.id] * cnt_f / (ms_f * 1e-3) / 1e9 if ms_f > 0 else 0.0
+    t_spmv_ms, n_spmv = ctx.prof_get(fin.id)["MATMULT"]
+    bsz = L.bs
+    b_spmv = (8.0 * bsz * bsz + 4.0) * L.A.nnzb + 4.0 * (L.A.nbrows + 1) + 16.0 * L.n
+    spmv_gbs = b_spmv * n_spmv / (t_spmv_ms * 1e-3) / 1e9 if t_spmv_ms > 0 else 0.0
+
+    traffic = None
+    pmc_file = os.path.join(ROOT, "profiles", "pmc_patch_apply_%s.json" % args.config)
+    if os.path.exists(pmc_file):
+        traffic = json.load(open(pmc_file)).get("hbm_bytes_per_launch")
+
+    out = {
+        "metric": "V-cycles/sec on ldc3d P2-P0 (DoF*smooths/sec in dof_smooths_per_s)",
+        "value": vps,
+        "unit": "V-cycles/s",
+        "n_gpus": 1,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": ms_per_step,
+        "higher_is_better": True,
+        "scaling": "strong",
+        "vs_baseline": None,
+        "dtype": "f64",
+        "data": "synthetic",
+        "config": {"workload": describe(args.config), "name": args.config, "velocity_dofs": int(L.n),
+                   "levels": nlev, "patches_finest": int(dmg.levels[-1].patch_stats()[0]),
+                   "cycle": "V(k,k), 1 cycle per step", "parallelism": "1 GPU"},
+        "dof_smooths_per_s": L.n * smooths_per_cycle_finest * vps,
+        "vcycle_algorithmic_GB": total_bytes / 1e9,
+        "vcycle_hbm_frac_of_peak": total_bytes / 1e9 / (elapsed / args.steps) / HBM_PEAK_GBS,
+        "roofline": {"kernel": "patch_apply_kernel", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                     "avg_launch_us": 1e3 * t_apply_ms / max(n_apply, 1), "launches": int(n_apply),
+                     "bytes_per_launch_avg": bytes_apply_total / max(n_apply, 1),
+                     "finest_level_GBps": finest_gbs, "finest_level_avg_launch_us": 1e3 * ms_f / max(cnt_f, 1)},
+        "spmv_finest": {"achieved_GBps": spmv_gbs, "frac": spmv_gbs / HBM_PEAK_GBS,
+                        "avg_launch_us": 1e3 * t_spmv_ms / max(n_spmv, 1)},
+        "events_ms": {kname: round(v[0], 3) for kname, v in prof_all.items()},
+        "rel_residual_after_timed_cycles": res,
+        "setup_s": {"host_generation": round(t_gen, 1), "device_setup_incl_patch_inversion": round(t_setup, 1)},
+    }
+    if not args.no_cpu_baseline:
+        try:
+            from bench_cpu import cpu_baseline
+            out["cpu_baseline"] = cpu_baseline(args.config, lv, tr, k, vps)
+        except Exception as e:       # the baseline is a reported extra; never let it take the GPU number down
+            out["cpu_baseline"] = {"value": None, "unit": "V-cycles/s", "cores": 0, "kind": "port",
+                                   "sample": "failed: %r" % (e,)}
+    else:
+        out["cpu_baseline"] = {"value": None, "unit": "V-cycles/s", "cores": 0, "kind": "port", "sample": "skipped"}
+    print(json.dumps(out), flush=True)
+    dmg.close()
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -64,6 +64,8 @@ int alfi_prof_enable(alfi_ctx* ctx, int on); /* records a hipEvent pair around e
 int alfi_prof_reset(alfi_ctx* ctx);
 /* synchronises, then returns summed device time (ms) and launch count of one class since the last reset */
 int alfi_prof_get(alfi_ctx* ctx, int ev, double* total_ms, int64_t* count);
+/* same, restricted to launches issued on behalf of one level (level_id from alfi_level_id; -1 = all levels) */
+int alfi_prof_get_level(alfi_ctx* ctx, int ev, int level_id, double* total_ms, int64_t* count);
 
 /* ---- level operator: PETSc MatMult on the BAIJ level matrix [3P], alfi/solver.py:512 ----------------------------- */
 /* Block-CSR, bs x bs row-major blocks (bs = 2 or 3), nbrows block rows; bc_dofs: Dirichlet dofs of the level
@@ -74,6 +76,7 @@ int alfi_level_destroy(alfi_level* lvl);
 /* new Newton step / new Reynolds number: same sparsity, new values (PatchPC.update -> PCSetUp_PATCH [3P]). */
 int alfi_level_update_values(alfi_level* lvl, const double* bvals_host);
 int alfi_level_size(alfi_level* lvl, int64_t* n);
+int alfi_level_id(alfi_level* lvl, int* id); /* creation-order id within the ctx, used by alfi_prof_get_level */
 int alfi_spmv(alfi_level* lvl, const double* dx, double* dy);                        /* y = A x      */
 int alfi_residual(alfi_level* lvl, const double* db, const double* dx, double* dr); /* r = b - A x  */
 

@@ -3,7 +3,11 @@
 Floating-point tolerances (FP64 everywhere).  The patch operators have condition numbers up to ~1e7 (gamma/nu), so two
 backward-stable inversions (LAPACK getrf/getri in the oracle, unpivoted register Gauss-Jordan on the GPU) agree to about
 cond * eps ~ 1e-9 relative in anything that applies the inverses; summation order differs as well.  Tolerances below:
-SpMV 1e-13, patch apply / smoother / transfers / cycles 1e-7 relative to the max-norm of the oracle result."""
+SpMV 1e-13, patch apply / smoother / transfers 1e-7 relative to the max-norm of the oracle result.  Whole cycles chain
+2k..2k(L+1) smoother calls whose FGMRES least-squares problems amplify those 1e-10-level differences: perturbing the
+ORACLE's own patch inverses by 1e-10 relative changes its V- and F-cycle output by 4e-6 (measured, 3-D P2+FB, Re 1000),
+so cycles are compared at 1e-5 and, in addition, through their residual norms."""
+CYCLE_TOL = 1e-5
 import numpy as np
 import pytest
 
@@ -135,7 +139,7 @@ def test_vcycle_and_fcycle(ctx, setup, robust):
     db, dx = ctx.vec(b), ctx.vec(L.n)
     dmg.vcycle(db, dx)
     ref = omg.vcycle(len(lv) - 1, b, np.zeros(L.n))
-    assert relerr(dx.get(), ref) < 1e-7
+    assert relerr(dx.get(), ref) < CYCLE_TOL
     # second cycle from the first iterate: residual norms match
     dmg.vcycle(db, dx)
     ref2 = omg.vcycle(len(lv) - 1, b, ref)
@@ -145,7 +149,10 @@ def test_vcycle_and_fcycle(ctx, setup, robust):
     assert r_ref < 0.5 * np.linalg.norm(b)            # and the cycle actually converges
     dxf = ctx.vec(L.n)
     dmg.fcycle(db, dxf)
-    assert relerr(dxf.get(), omg.fcycle(b)) < 1e-7
+    ref_f = omg.fcycle(b)
+    assert relerr(dxf.get(), ref_f) < CYCLE_TOL
+    rf_dev, rf_ref = np.linalg.norm(b - A @ dxf.get()), np.linalg.norm(b - A @ ref_f)
+    assert abs(rf_dev - rf_ref) < 1e-6 * np.linalg.norm(b)
 
 
 def test_operator_update_refactors(ctx, setup):
