@@ -215,6 +215,37 @@ def coarse_inverse(A_bsr):
     return np.linalg.inv(A)
 
 
+def dense_inverse_gpu(A_bsr, nb=256, refine=1):
+    """Dense FP64 inverse of a (coarse) operator as a torch CUDA tensor, by blocked Gauss-Jordan: the rank-nb trailing
+    updates run as plain library GEMMs (torch.addmm -> rocBLAS), the nb x nb pivot blocks are inverted with LAPACK on
+    the host.  No pivoting across blocks (the operator is SPD-dominated, like the patch operators).  Setup only: stands
+    in for the factorisation of the reference's coarse LU (solver.py:369-378); the solve itself is the library's GEMV."""
+    import torch
+    A = torch.from_numpy(A_bsr.to_scipy().toarray()).to("cuda")
+    n = A.shape[0]
+    for k0 in range(0, n, nb):
+        k1 = min(n, k0 + nb)
+        Dinv = torch.from_numpy(np.linalg.inv(A[k0:k1, k0:k1].cpu().numpy())).to("cuda")
+        R = A[k0:k1, :].clone()
+        R[:, k0:k1] = 0.0
+        C = A[:, k0:k1] @ Dinv
+        C[k0:k1, :] = 0.0
+        A.addmm_(C, R, alpha=-1.0)
+        A[k0:k1, :] = Dinv @ R
+        A[:, k0:k1] = -C
+        A[k0:k1, k0:k1] = Dinv
+    if refine:
+        # Newton-Schulz polish X <- X (2I - A X): squares the residual left by the unpivoted block elimination
+        A0 = torch.from_numpy(A_bsr.to_scipy().toarray()).to("cuda")
+        for _ in range(refine):
+            R = A0 @ A
+            R.mul_(-1.0)
+            R.diagonal().add_(2.0)
+            A = A @ R
+        del A0, R
+    return A.contiguous()
+
+
 class Multigrid(object):
     """Device-resident PCMG (solver.py:359-379) built from alfi_amd.problem.build_hierarchy output."""
 

@@ -53,14 +53,14 @@ def build_problem(cfg, verbose):
 
 def coarse_inverse_device(A_bsr):
     """Dense inverse of the coarsest operator.  Small: LAPACK on the host.  Large (config 4: 23 355 dofs): FP64
-    inversion on the GPU through torch (setup only; stands in for the reference's SuperLU_DIST factorisation)."""
+    blocked Gauss-Jordan on the GPU with library GEMMs (setup only; stands in for the reference's SuperLU_DIST
+    factorisation)."""
     n = A_bsr.shape[0]
     if n <= 4096:
         return np.linalg.inv(A_bsr.to_scipy().toarray()), None
     import torch
-    A = torch.from_numpy(A_bsr.to_scipy().toarray()).to("cuda")
-    Ainv = torch.linalg.inv(A).contiguous()
-    del A
+    from alfi_amd.hip import dense_inverse_gpu
+    Ainv = dense_inverse_gpu(A_bsr)
     torch.cuda.synchronize()
     return int(Ainv.data_ptr()), Ainv
 
