@@ -251,9 +251,8 @@ class Multigrid(object):
 
     def __init__(self, ctx, levels, transfers, k, robust_restriction=False, coarse_inv=None, verbose=False):
         import time
-        self.ctx = ctx
-        self.levels, self.transfers = [], []
         t0 = time.time()
+        dlevels = []
         for L in levels:
             dl = Level(ctx, L.A, L.bc_dofs)
             if L.level > 0:
@@ -261,7 +260,15 @@ class Multigrid(object):
                 dl.factor()
             else:
                 dl.set_coarse_inverse(coarse_inv if coarse_inv is not None else coarse_inverse(L.A))
-            self.levels.append(dl)
+            dlevels.append(dl)
+        self._from_device_levels(ctx, dlevels, transfers, k, robust_restriction)
+        if verbose:
+            print("[alfi_amd] device hierarchy ready in %.1fs" % (time.time() - t0), flush=True)
+
+    def _from_device_levels(self, ctx, dlevels, transfers, k, robust_restriction):
+        """dlevels: hip.Level objects (level 0 with a coarse inverse, the others with factored patches)."""
+        self.ctx = ctx
+        self.levels, self.transfers = list(dlevels), []
         for i, T in enumerate(transfers):
             dt = Transfer(ctx, self.levels[i], self.levels[i + 1], T)
             dt.update(T.nu, T.gamma)
@@ -274,8 +281,6 @@ class Multigrid(object):
         self.h = h
         self.k = k
         ctx.sync()
-        if verbose:
-            print("[alfi_amd] device hierarchy ready in %.1fs" % (time.time() - t0), flush=True)
 
     def vcycle(self, b, x):
         self.ctx.check(self.ctx.lib.alfi_mg_vcycle(self.h, b.ptr, x.ptr))

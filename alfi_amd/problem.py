@@ -143,16 +143,45 @@ class TransferData(object):
     pass
 
 
-def build_level_operator(V, wind, nu, gamma, advect, graph=None, return_parts=False):
-    """BSR operator nu K + gamma D + advect N(wind) with Dirichlet rows/cols -> identity."""
-    m = V.mesh
-    d = V.dim
-    rowptr, colidx = graph if graph is not None else _hostlib.node_graph(V.cell_nodes, V.num_nodes)
-    g, vol = m.cell_geometry()
-    tens = V.element.reference_tensors()
-    vals = _hostlib.assemble_bsr(V.cell_nodes, g, vol, tens, d, rowptr, colidx, nu=nu, gamma=gamma,
-                                 adv=advect, wind=wind if advect else None)
-    return rowptr, colidx, vals
+def build_transfer_data(Vc, Vf, nu, gamma, graph=None):
+    """Everything the Schoeberl transfer between two nested spaces needs (alfi/transfer.py:194-259): standard
+    prolongation P (bubble-corrected for 3-D P1+FB, transfer.py:334-356) and its transpose, the plain nodal P^T for
+    non-robust restriction (solver.py:595), coarse-cell interior blocks (transfer.py:13-46), their dense K / D blocks
+    (forms of transfer.py:319-332) and the interior rows of the grad-div matrix."""
+    mesh, d, dim = Vf.mesh, Vf.dim, Vf.dim
+    element = Vf.element
+    rowptr, colidx = graph if graph is not None else _hostlib.node_graph(Vf.cell_nodes, Vf.num_nodes)
+    g, vol = mesh.cell_geometry()
+    tens = element.reference_tensors()
+    T = TransferData()
+    blk_nodes = coarse_cell_blocks(Vf)                      # (coarse cells, interior nodes), parent-major
+    T.blk_dofs = np.ascontiguousarray(Vf.node_dofs(blk_nodes), dtype=np.int32)     # (nblk, m)
+    # dense interior blocks of (2 sym grad u, grad v) and (cell_avg div u, div v), assembled directly
+    T.K_II, T.D_II = _hostlib.interior_blocks(Vf.cell_nodes, g, vol, tens, d, blk_nodes, Vf.num_nodes, 2 ** dim)
+    # rows of the grad-div matrix (gamma = 1, no BCs) for the interior nodes, in block order
+    rows = blk_nodes.ravel().astype(np.int64)
+    cnt = (rowptr[rows + 1] - rowptr[rows]).astype(np.int64)
+    ptr = np.concatenate([[0], np.cumsum(cnt)])
+    idx = np.repeat(rowptr[rows].astype(np.int64) - ptr[:-1], cnt) + np.arange(ptr[-1])
+    di_rowptr, di_colidx = ptr.astype(np.int32), colidx[idx]
+    del idx
+    row_map = np.full(Vf.num_nodes, -1, dtype=np.int32)
+    row_map[rows] = np.arange(rows.shape[0], dtype=np.int32)
+    di_vals = _hostlib.assemble_bsr(Vf.cell_nodes, g, vol, tens, d, di_rowptr, di_colidx, gamma=1.0, row_map=row_map)
+    T.D_I = BSR(rows.shape[0], Vf.num_nodes, d, di_rowptr, di_colidx, di_vals)
+    T.D_IT = T.D_I.transpose()                            # (fine nodes) x (interior nodes)
+    Pv = vector_prolongation(Vc, Vf)
+    T.P = BSR.from_scipy(Pv, d)
+    T.PT = T.P.transpose()
+    if dim == 3 and element.bubble and element.degree == 1:
+        Pn = sp.kron(nodal_prolongation(Vc, Vf), sp.identity(d, format="csr"), format="csr")
+        T.PT_plain = BSR.from_scipy(Pn, d).transpose()
+    else:
+        T.PT_plain = T.PT
+    T.nu, T.gamma = nu, gamma
+    T.n_f, T.n_c = Vf.num_dofs, Vc.num_dofs
+    T.bc_dofs_f, T.bc_dofs_c = Vf.bc_dofs, Vc.bc_dofs
+    return T
 
 
 def build_hierarchy(problem, nref, k, Re, gamma=1e4, advect=True, patches=True, verbose=False):
@@ -181,45 +210,13 @@ def build_hierarchy(problem, nref, k, Re, gamma=1e4, advect=True, patches=True, 
         A = _hostlib.assemble_bsr(V.cell_nodes, g, vol, tens, d, rowptr, colidx, nu=nu, gamma=gamma, adv=adv,
                                   wind=wind if adv else None)
         _hostlib.apply_bc_bsr(V.num_nodes, d, rowptr, colidx, A, bcmask)
-        T = None
-        if l > 0:
-            T = TransferData()
-            blk_nodes = coarse_cell_blocks(V)                      # (coarse cells, interior nodes), parent-major
-            T.blk_dofs = np.ascontiguousarray(V.node_dofs(blk_nodes), dtype=np.int32)     # (nblk, m)
-            # dense interior blocks of (2 sym grad u, grad v) and (cell_avg div u, div v), assembled directly
-            T.K_II, T.D_II = _hostlib.interior_blocks(V.cell_nodes, g, vol, tens, d, blk_nodes, V.num_nodes,
-                                                      2 ** dim)
-            # rows of the grad-div matrix (gamma = 1, no BCs) for the interior nodes, in block order
-            rows = blk_nodes.ravel().astype(np.int64)
-            cnt = (rowptr[rows + 1] - rowptr[rows]).astype(np.int64)
-            ptr = np.concatenate([[0], np.cumsum(cnt)])
-            idx = np.repeat(rowptr[rows].astype(np.int64) - ptr[:-1], cnt) + np.arange(ptr[-1])
-            di_rowptr, di_colidx = ptr.astype(np.int32), colidx[idx]
-            del idx
-            row_map = np.full(V.num_nodes, -1, dtype=np.int32)
-            row_map[rows] = np.arange(rows.shape[0], dtype=np.int32)
-            di_vals = _hostlib.assemble_bsr(V.cell_nodes, g, vol, tens, d, di_rowptr, di_colidx, gamma=1.0,
-                                            row_map=row_map)
-            T.D_I = BSR(rows.shape[0], V.num_nodes, d, di_rowptr, di_colidx, di_vals)
-            T.D_IT = T.D_I.transpose()                            # (fine nodes) x (interior nodes)
         L.A = BSR(V.num_nodes, V.num_nodes, d, rowptr, colidx, A)
         L.bc_dofs = V.bc_dofs
         L.nu, L.gamma = nu, gamma
         if patches and l > 0:
             L.patch_ptr, L.patch_dofs, L.patch_seeds = V.star_patches()
         if l > 0:
-            Pv = vector_prolongation(Vprev, V)
-            T.P = BSR.from_scipy(Pv, d)
-            T.PT = T.P.transpose()
-            if Vprev.dim == 3 and element.bubble and element.degree == 1:
-                Pn = sp.kron(nodal_prolongation(Vprev, V), sp.identity(d, format="csr"), format="csr")
-                T.PT_plain = BSR.from_scipy(Pn, d).transpose()
-            else:
-                T.PT_plain = T.PT
-            T.nu, T.gamma = nu, gamma
-            T.n_f, T.n_c = V.num_dofs, Vprev.num_dofs
-            T.bc_dofs_f, T.bc_dofs_c = V.bc_dofs, Vprev.bc_dofs
-            transfers.append(T)
+            transfers.append(build_transfer_data(Vprev, V, nu, gamma, graph=(rowptr, colidx)))
         levels.append(L)
         Vprev = V
         if verbose:

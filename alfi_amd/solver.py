@@ -1,0 +1,248 @@
+"""Front end with the reference's plug-in surface for the velocity-block multigrid (alfi/solver.py).
+
+* ``HipPatchPC``: a PCPython-protocol class (``initialize / update / apply / applyTranspose``; the in-tree example of
+  that protocol is ``DGMassInv``, solver.py:15-38) that is selected exactly like the reference selects
+  ``firedrake.PatchPC``: ``"pc_type": "python", "pc_python_type": "alfi_amd.HipPatchPC"`` (solver.py:318-319).  It reads
+  the ``patch_pc_patch_*`` / ``patch_sub_*`` keys the reference sets (solver.py:320-344, 599-602) and runs PCPATCH's
+  setup and apply on the GPU.
+* ``mg_levels_solver`` / ``fieldsplit_0_mg``: the option dictionaries of ``get_parameters`` (solver.py:313-344, 359-379)
+  with the PatchPC swapped for ``HipPatchPC``.
+* ``HipMG``: drives PCMG (full or multiplicative V) + FGMRES(k) from such a dictionary -- the stand-in for PETSc when
+  petsc4py is not importable (it is not, in this image).  One ``apply`` = what ``fieldsplit_0``'s Richardson(1)/PCMG
+  does to a right-hand side.
+"""
+import importlib
+
+import numpy as np
+
+from . import hip
+from .relaxation import Options, PlexLike, patch_points_to_dofs
+
+SUPPORTED_PATCH_KEYS = {
+    "patch_pc_patch_save_operators", "patch_pc_patch_partition_of_unity", "patch_pc_patch_local_type",
+    "patch_pc_patch_statistics", "patch_pc_patch_symmetrise_sweep", "patch_pc_patch_precompute_element_tensors",
+    "patch_pc_patch_construct_type", "patch_pc_patch_construct_dim", "patch_pc_patch_construct_python_type",
+    "patch_pc_patch_sub_mat_type", "patch_pc_patch_dense_inverse", "patch_pc_patch_multiplicative",
+    "patch_sub_ksp_type", "patch_sub_pc_type", "patch_sub_pc_factor_mat_solver_type",
+}
+
+
+def _truthy(v):
+    return v if isinstance(v, bool) else str(v).lower() in ("1", "true", "yes")
+
+
+def mg_levels_solver(tdim, patch="star", patch_composition="additive", smoothing=None, relaxation_direction=None):
+    """The ``mg_levels_solver`` dictionary of alfi/solver.py:313-344 with ``configure_patch_solver`` of
+    ConstantPressureSolver (solver.py:599-602) applied."""
+    multiplicative = patch_composition == "multiplicative"
+    if multiplicative and relaxation_direction is None:
+        raise NotImplementedError("Need to specify a relaxation_direction in the problem.")
+    if smoothing is None:
+        smoothing = 10 if tdim > 2 else 6
+    opts = {
+        "ksp_type": "fgmres",
+        "ksp_norm_type": "unpreconditioned",
+        "ksp_max_it": smoothing,
+        "ksp_convergence_test": "skip",
+        "pc_type": "python",
+        "pc_python_type": "alfi_amd.HipPatchPC",
+        "patch_pc_patch_save_operators": True,
+        "patch_pc_patch_partition_of_unity": False,
+        "patch_pc_patch_local_type": "multiplicative" if multiplicative else "additive",
+        "patch_pc_patch_statistics": False,
+        "patch_pc_patch_symmetrise_sweep": multiplicative,
+        "patch_pc_patch_precompute_element_tensors": True,
+        "patch_sub_ksp_type": "preonly",
+        "patch_sub_pc_type": "lu",
+        "patch_pc_patch_sub_mat_type": "seqdense",
+        "patch_sub_pc_factor_mat_solver_type": "petsc",
+        "patch_pc_patch_dense_inverse": True,
+    }
+    if patch == "star":
+        if multiplicative:
+            opts["patch_pc_patch_construct_type"] = "python"
+            opts["patch_pc_patch_construct_python_type"] = "alfi_amd.Star"
+            opts["patch_pc_patch_construction_Star_sort_order"] = relaxation_direction
+        else:
+            opts["patch_pc_patch_construct_type"] = "star"
+            opts["patch_pc_patch_construct_dim"] = 0
+    elif patch == "macro":
+        opts["patch_pc_patch_construct_type"] = "python"
+        opts["patch_pc_patch_construct_python_type"] = "alfi_amd.MacroStar"
+        opts["patch_pc_patch_construction_MacroStar_sort_order"] = relaxation_direction
+    else:
+        raise NotImplementedError("Unknown patch type %s" % patch)
+    return opts
+
+
+def fieldsplit_0_mg(mg_levels):
+    """alfi/solver.py:359-379 (the coarse solve is a dense inverse applied on the GPU instead of telescoped
+    SuperLU_DIST; the keys are accepted and ignored)."""
+    return {
+        "ksp_type": "richardson",
+        "ksp_richardson_self_scale": False,
+        "ksp_max_it": 1,
+        "ksp_norm_type": "unpreconditioned",
+        "ksp_convergence_test": "skip",
+        "pc_type": "mg",
+        "pc_mg_type": "full",
+        "pc_mg_log": None,
+        "mg_levels": mg_levels,
+        "mg_coarse_pc_type": "python",
+        "mg_coarse_pc_python_type": "firedrake.AssembledPC",
+        "mg_coarse_assembled": {"mat_type": "aij", "pc_type": "lu"},
+    }
+
+
+def _resolve(dotted):
+    mod, _, name = dotted.rpartition(".")
+    return getattr(importlib.import_module(mod), name)
+
+
+class PC(object):
+    """The small part of a PETSc PC object a PCPython class touches: operators, DM, options prefix (+ attributes)."""
+
+    def __init__(self, ctx, level_data, options=None, prefix=""):
+        self.ctx = ctx                  # alfi_amd.hip.Context
+        self.level_data = level_data    # alfi_amd.problem.LevelData (operator, space, Dirichlet dofs)
+        self.options = dict(options or {})
+        self.prefix = prefix
+        self._dm = PlexLike(level_data.V.mesh)
+        self.attrs = {}
+
+    def getOperators(self):
+        return self.level_data.A, self.level_data.A
+
+    def getDM(self):
+        return self._dm
+
+    def getOptionsPrefix(self):
+        return self.prefix
+
+    def getAttr(self, k):
+        return self.attrs.get(k)
+
+    def setAttr(self, k, v):
+        self.attrs[k] = v
+
+
+def _as_device(ctx, v, n):
+    """(DeviceVec, writeback) for a DeviceVec, a NumPy array, or anything with getArray() (petsc4py Vec)."""
+    if isinstance(v, hip.DeviceVec):
+        return v, None
+    arr = v.getArray() if hasattr(v, "getArray") else v
+    arr = np.asarray(arr)
+    assert arr.shape == (n,)
+    return ctx.vec(arr), arr
+
+
+class HipPatchPC(object):
+    """PCPATCH on the GPU behind the PCPython protocol (solver.py:15-38 shows the protocol)."""
+
+    def initialize(self, pc):
+        opts = Options(pc.getOptionsPrefix(), pc.options)
+        L = pc.level_data
+        unknown = [k for k in pc.options if k.startswith(pc.getOptionsPrefix() + "patch_")
+                   and k[len(pc.getOptionsPrefix()):] not in SUPPORTED_PATCH_KEYS
+                   and "patch_pc_patch_construction_" not in k]
+        if unknown:
+            raise ValueError("unsupported PatchPC options: %s" % unknown)
+        local_type = opts.getString("patch_pc_patch_local_type", "additive")
+        if _truthy(opts.getString("patch_pc_patch_multiplicative", "false")):
+            local_type = "multiplicative"
+        if local_type != "additive":
+            raise NotImplementedError("multiplicative patch sweeps are not implemented yet (SURVEY.md section 8(f), "
+                                      "rank 1); use --patch-composition additive")
+        if _truthy(opts.getString("patch_pc_patch_partition_of_unity", "false")):
+            raise NotImplementedError("partition_of_unity weighting (the reference always sets it False, solver.py:321)")
+        sub_mat = opts.getString("patch_pc_patch_sub_mat_type", "seqdense")
+        if sub_mat not in ("seqdense", "dense"):
+            raise NotImplementedError("patch sub_mat_type %r: only dense patch solves (ConstantPressureSolver, "
+                                      "solver.py:599-602) are implemented" % sub_mat)
+        ctype = opts.getString("patch_pc_patch_construct_type", "star")
+        if ctype == "star":
+            if opts.getInt("patch_pc_patch_construct_dim", 0) != 0:
+                raise NotImplementedError("only vertex stars (construct_dim 0)")
+            ptr, dofs, _ = L.V.star_patches()
+            self.iterset = np.arange(len(ptr) - 1)
+        elif ctype == "python":
+            ctor = _resolve(opts.getString("patch_pc_patch_construct_python_type"))()
+            patches, self.iterset = ctor(pc)
+            ptr, dofs, kept = patch_points_to_dofs(L.V, pc.getDM(), patches)
+        else:
+            raise NotImplementedError("patch construct_type %r" % ctype)
+        self.patch_ptr, self.patch_dofs = ptr, dofs
+        self.level = hip.Level(pc.ctx, L.A, L.bc_dofs)
+        self.level.set_patches(ptr, dofs)
+        self.level.factor()
+        self.n = L.n
+
+    def update(self, pc):
+        """New operator values (Newton step / Reynolds continuation): re-gather and re-invert every patch, which is what
+        PatchPC.update -> PCSetUp_PATCH does with save_operators (solver.py:320)."""
+        self.level.update_values(pc.level_data.A.vals)
+        self.level.factor()
+
+    def apply(self, pc, x, y):
+        dx, _ = _as_device(pc.ctx, x, self.n)
+        dy, ywb = _as_device(pc.ctx, y, self.n)
+        self.level.patch_apply(dx, dy)
+        if ywb is not None:
+            ywb[:] = dy.get()
+
+    def applyTranspose(self, pc, x, y):
+        raise NotImplementedError("Sorry!")
+
+
+class HipMG(object):
+    """PCMG + KSPFGMRES(k) driven by the reference's option dictionary (solver.py:359-379), device resident."""
+
+    def __init__(self, ctx, levels, transfers, params, restriction=False, coarse_inv=None):
+        if params.get("pc_type") != "mg":
+            raise ValueError("expected the fieldsplit_0_mg dictionary (pc_type mg)")
+        mgl = params["mg_levels"]
+        if mgl.get("ksp_type") != "fgmres" or mgl.get("ksp_convergence_test") != "skip":
+            raise NotImplementedError("level smoother must be fgmres with convergence_test skip (solver.py:314-317)")
+        if mgl.get("pc_type") != "python":
+            raise NotImplementedError("level pc_type must be python")
+        self.k = int(mgl["ksp_max_it"])
+        self.full = params.get("pc_mg_type", "multiplicative") == "full"
+        pc_cls = _resolve(mgl["pc_python_type"])
+        self.ctx = ctx
+        self.pcs, self.pc_objs = [], []
+        dlevels = []
+        for L in levels:
+            if L.level == 0:
+                dl = hip.Level(ctx, L.A, L.bc_dofs)
+                dl.set_coarse_inverse(coarse_inv if coarse_inv is not None else hip.coarse_inverse(L.A))
+                dlevels.append(dl)
+                self.pcs.append(None)
+                self.pc_objs.append(None)
+                continue
+            pc = PC(ctx, L, options=mgl)
+            obj = pc_cls()
+            obj.initialize(pc)
+            self.pcs.append(pc)
+            self.pc_objs.append(obj)
+            dlevels.append(obj.level)
+        self.mg = hip.Multigrid.__new__(hip.Multigrid)
+        hip.Multigrid._from_device_levels(self.mg, ctx, dlevels, transfers, self.k, restriction)
+        self.n = levels[-1].n
+
+    def update(self, levels):
+        for pc, obj, L in zip(self.pcs, self.pc_objs, levels):
+            if obj is not None:
+                pc.level_data = L
+                obj.update(pc)
+
+    def apply(self, b, x):
+        """x <- PCMG(b): one full cycle (pc_mg_type full) or one V-cycle from a zero initial guess."""
+        db, _ = _as_device(self.ctx, b, self.n)
+        dx, xwb = _as_device(self.ctx, x, self.n)
+        if self.full:
+            self.mg.fcycle(db, dx)
+        else:
+            dx.zero()
+            self.mg.vcycle(db, dx)
+        if xwb is not None:
+            xwb[:] = dx.get()

@@ -1,0 +1,41 @@
+"""Generates tests/golden/*.npz with the oracle (there are no reference fixtures to take: SURVEY.md section 4).
+Run from the repo root: python tests/golden/make_golden.py"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from alfi_amd.problem import TwoDimLidDrivenCavityProblem, ThreeDimLidDrivenCavityProblem, build_hierarchy  # noqa: E402
+from oracle import alfi_oracle as O  # noqa: E402
+
+CASES = {"ldc2d_p2_N4": (lambda: TwoDimLidDrivenCavityProblem(2), 2, 1, 10.0, 6),
+         "ldc3d_p1fb_N2": (lambda: ThreeDimLidDrivenCavityProblem(1), 1, 1, 100.0, 4),
+         "ldc3d_p2fb_N2": (lambda: ThreeDimLidDrivenCavityProblem(1), 2, 1, 100.0, 4)}
+
+
+def make(name):
+    mk, k, nref, Re, ks = CASES[name]
+    lv, tr = build_hierarchy(mk(), nref, k, Re=Re)
+    mg = O.build_oracle_mg(lv, tr, ks, schoeberl_restriction=True)
+    L = lv[-1]
+    rng = np.random.default_rng(42)
+    x = rng.standard_normal(L.n)
+    b = rng.standard_normal(L.n)
+    b[L.bc_dofs] = 0
+    uc = rng.standard_normal(lv[0].n)
+    uc[lv[0].bc_dofs] = 0
+    out = dict(x=x, b=b, uc=uc, patch_ptr=L.patch_ptr, patch_dofs=L.patch_dofs, n=L.n,
+               A_x=mg.levels[-1]["A"] @ x, patch_apply_x=mg.levels[-1]["smoother"].apply(x),
+               smooth_b=mg.smooth(len(lv) - 1, b, np.zeros(L.n)),
+               prolong_uc=mg.prolong(len(lv) - 1, uc), restrict_b=mg.restrict(len(lv) - 1, x),
+               vcycle_b=mg.vcycle(len(lv) - 1, b, np.zeros(L.n)), fcycle_b=mg.fcycle(b),
+               inv_patch0=mg.levels[-1]["smoother"].inv[0])
+    np.savez_compressed(os.path.join(os.path.dirname(os.path.abspath(__file__)), name + ".npz"), **out)
+
+
+if __name__ == "__main__":
+    for name in CASES:
+        make(name)
+        print("wrote", name)

@@ -1,0 +1,144 @@
+"""Front end with the reference's plug-in surface: option dictionaries, patch constructors (CPU) and, on the GPU,
+HipPatchPC / HipMG / PkP0SchoeberlTransfer driven the way alfi drives PatchPC, PCMG and its transfer objects."""
+import numpy as np
+import pytest
+
+import alfi_amd
+from alfi_amd.problem import TwoDimLidDrivenCavityProblem, ThreeDimLidDrivenCavityProblem, build_hierarchy
+from alfi_amd.relaxation import Options, PlexLike, Star, OrderedRelaxation, patch_points_to_dofs
+
+
+class _FakePC(object):
+    def __init__(self, L, options=None, prefix=""):
+        self.level_data, self.options, self.prefix = L, options or {}, prefix
+        self._dm = PlexLike(L.V.mesh)
+
+    def getDM(self):
+        return self._dm
+
+    def getOptionsPrefix(self):
+        return self.prefix
+
+
+@pytest.mark.parametrize("mk,k", [(lambda: TwoDimLidDrivenCavityProblem(2), 2),
+                                  (lambda: ThreeDimLidDrivenCavityProblem(1), 2)])
+def test_python_star_constructor_equals_builtin_star(mk, k):
+    lv, _ = build_hierarchy(mk(), 1, k, Re=10)
+    L = lv[-1]
+    pc = _FakePC(L)
+    patches, iterset = Star()(pc)
+    assert np.array_equal(iterset, np.arange(len(patches)))
+    ptr, dofs, kept = patch_points_to_dofs(L.V, pc.getDM(), patches)
+    # built-in patches are ordered by the seed's node number; python ones by vertex number
+    got = {tuple(dofs[ptr[i]:ptr[i + 1]]) for i in range(len(ptr) - 1)}
+    ref = {tuple(L.patch_dofs[L.patch_ptr[i]:L.patch_ptr[i + 1]]) for i in range(len(L.patch_ptr) - 1)}
+    assert got == ref
+
+
+def test_sort_order_grammar_and_sweeps():
+    assert OrderedRelaxation.parse_sort_order("0+:1-|1+") == [[(0, 1), (1, -1)], [(1, 1)]]
+    assert OrderedRelaxation.parse_sort_order("None") is None
+    lv, _ = build_hierarchy(TwoDimLidDrivenCavityProblem(2), 1, 2, Re=10)
+    L = lv[-1]
+    pc = _FakePC(L, {"pc_patch_construction_Star_sort_order": "0+:1-"})
+    patches, iterset = Star()(pc)
+    assert sorted(iterset) == list(range(len(patches)))
+    dm = pc.getDM()
+    xy = np.array([dm.point_coords(dm.vStart + v) for v in range(L.V.mesh.num_vertices)])[iterset]
+    key = list(zip(xy[:, 0], -xy[:, 1]))
+    assert key == sorted(key)                                   # ascending x, then descending y (ldc2d.py:39)
+    pc2 = _FakePC(L, {"pc_patch_construction_Star_sort_order": "0+|0-"})
+    _, it2 = Star()(pc2)
+    assert len(it2) == 2 * len(patches)                         # one permutation per '|' sweep (relaxation.py:145-147)
+
+
+def test_option_dictionary_has_the_reference_keys():
+    o = alfi_amd.mg_levels_solver(3)
+    assert o["ksp_type"] == "fgmres" and o["ksp_max_it"] == 10 and o["ksp_convergence_test"] == "skip"
+    assert o["pc_python_type"] == "alfi_amd.HipPatchPC"
+    assert o["patch_pc_patch_construct_type"] == "star" and o["patch_pc_patch_construct_dim"] == 0
+    assert o["patch_pc_patch_dense_inverse"] is True and o["patch_pc_patch_sub_mat_type"] == "seqdense"
+    assert alfi_amd.mg_levels_solver(2)["ksp_max_it"] == 6
+    m = alfi_amd.mg_levels_solver(2, patch_composition="multiplicative", relaxation_direction="0+:1-")
+    assert m["patch_pc_patch_construct_python_type"] == "alfi_amd.Star"
+    assert m["patch_pc_patch_construction_Star_sort_order"] == "0+:1-"
+    with pytest.raises(NotImplementedError):
+        alfi_amd.mg_levels_solver(2, patch_composition="multiplicative")
+    f = alfi_amd.fieldsplit_0_mg(o)
+    assert f["pc_mg_type"] == "full" and f["ksp_type"] == "richardson" and f["ksp_max_it"] == 1
+
+
+@pytest.mark.gpu
+def test_hip_patch_pc_and_mg_from_options():
+    from alfi_amd import hip
+    from oracle import alfi_oracle as O
+    lv, tr = build_hierarchy(ThreeDimLidDrivenCavityProblem(2), 1, 1, Re=100.0)
+    ctx = hip.Context(0)
+    params = alfi_amd.fieldsplit_0_mg(alfi_amd.mg_levels_solver(3, smoothing=3))
+    mg = alfi_amd.HipMG(ctx, lv, tr, params)
+    L = lv[-1]
+    rng = np.random.default_rng(0)
+    # PCPython protocol: apply(pc, x, y) with host arrays
+    x, y = rng.standard_normal(L.n), np.zeros(L.n)
+    mg.pc_objs[-1].apply(mg.pcs[-1], x, y)
+    omg = O.build_oracle_mg(lv, tr, 3)
+    ref = omg.levels[-1]["smoother"].apply(x)
+    assert np.abs(y - ref).max() < 1e-7 * np.abs(ref).max()
+    with pytest.raises(NotImplementedError):
+        mg.pc_objs[-1].applyTranspose(mg.pcs[-1], x, y)
+    # one PCMG(full) application
+    b = rng.standard_normal(L.n)
+    b[L.bc_dofs] = 0
+    out = np.zeros(L.n)
+    mg.apply(b, out)
+    ref = omg.fcycle(b)
+    assert np.abs(out - ref).max() < 1e-5 * np.abs(ref).max()
+    # python-constructed Star patches give the same preconditioner as the built-in star
+    o2 = alfi_amd.mg_levels_solver(3, smoothing=3)
+    o2["patch_pc_patch_construct_type"] = "python"
+    o2["patch_pc_patch_construct_python_type"] = "alfi_amd.Star"
+    pc = alfi_amd.PC(ctx, L, options=o2)
+    obj = alfi_amd.HipPatchPC()
+    obj.initialize(pc)
+    y2 = np.zeros(L.n)
+    obj.apply(pc, x, y2)
+    assert np.abs(y2 - y).max() < 1e-10 * np.abs(y).max()
+    # unsupported modes are refused loudly
+    o3 = alfi_amd.mg_levels_solver(3, patch_composition="multiplicative", relaxation_direction="0+:1-")
+    with pytest.raises(NotImplementedError):
+        alfi_amd.HipPatchPC().initialize(alfi_amd.PC(ctx, L, options=o3))
+
+
+@pytest.mark.gpu
+def test_schoeberl_transfer_object_protocol():
+    from alfi_amd import hip, Constant, Function, PkP0SchoeberlTransfer
+    from oracle import alfi_oracle as O
+    lv, tr = build_hierarchy(TwoDimLidDrivenCavityProblem(4), 1, 2, Re=100.0)
+    nu, gamma = Constant(lv[-1].nu), Constant(lv[-1].gamma)
+    vt = PkP0SchoeberlTransfer((nu, gamma), 2, "uniform")
+    Vc, Vf = lv[0].V, lv[1].V
+    rng = np.random.default_rng(1)
+    uc = rng.standard_normal(Vc.num_dofs)
+    uc[lv[0].bc_dofs] = 0
+    coarse, fine = Function(Vc, uc), Function(Vf)
+    vt.prolong(coarse, fine)
+    ot = O.oracle_transfer(tr[-1], lv[-1], True).st
+    ref = ot.prolong(uc)
+    ref[lv[1].bc_dofs] = 0
+    assert np.abs(fine.dat.data.ravel() - ref).max() < 1e-8 * np.abs(ref).max()
+    r = rng.standard_normal(Vf.num_dofs)
+    fr, cr = Function(Vf, r), Function(Vc)
+    vt.restrict(fr, cr)
+    ref = ot.restrict(r)
+    ref[lv[0].bc_dofs] = 0
+    assert np.abs(cr.dat.data.ravel() - ref).max() < 1e-8 * np.abs(ref).max()
+    assert np.array_equal(fr.dat.data.ravel(), r)
+    # changing gamma triggers a rebuild of the interior solves (transfer.py:173-184)
+    gamma.assign(10.0)
+    vt.prolong(coarse, fine)
+    tr2 = build_hierarchy(TwoDimLidDrivenCavityProblem(4), 1, 2, Re=100.0, gamma=10.0)
+    ot2 = O.oracle_transfer(tr2[1][-1], tr2[0][-1], True).st
+    ref2 = ot2.prolong(uc)
+    ref2[lv[1].bc_dofs] = 0
+    assert np.abs(fine.dat.data.ravel() - ref2).max() < 1e-8 * np.abs(ref2).max()
+    vt.break_ref_cycles()

@@ -1,0 +1,76 @@
+"""Committed fixtures (tests/golden/*.npz, produced by tests/golden/make_golden.py with the oracle): the oracle and the C
+port must keep reproducing them (CPU); the HIP path must match them (GPU)."""
+import os
+
+import numpy as np
+import pytest
+
+from alfi_amd.problem import build_hierarchy
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def load(name):
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_golden", os.path.join(HERE, "golden", "make_golden.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    mk, k, nref, Re, ks = mod.CASES[name]
+    lv, tr = build_hierarchy(mk(), nref, k, Re=Re)
+    return lv, tr, ks, np.load(os.path.join(HERE, "golden", name + ".npz"))
+
+
+NAMES = ["ldc2d_p2_N4", "ldc3d_p1fb_N2", "ldc3d_p2fb_N2"]
+
+
+def rel(a, b):
+    return np.abs(a - b).max() / np.abs(b).max()
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_oracles_reproduce_golden(name):
+    from oracle import alfi_oracle as O
+    from oracle import c_oracle as C
+    lv, tr, ks, g = load(name)
+    L = lv[-1]
+    assert np.array_equal(L.patch_ptr, g["patch_ptr"]) and np.array_equal(L.patch_dofs, g["patch_dofs"])
+    mg = O.build_oracle_mg(lv, tr, ks, schoeberl_restriction=True)
+    assert rel(mg.levels[-1]["A"] @ g["x"], g["A_x"]) < 1e-14
+    assert rel(mg.levels[-1]["smoother"].apply(g["x"]), g["patch_apply_x"]) < 1e-10
+    assert rel(mg.vcycle(len(lv) - 1, g["b"], np.zeros(L.n)), g["vcycle_b"]) < 1e-8
+    cmg = C.CMultigrid(lv, tr, ks, robust_restriction=True)
+    assert rel(cmg.levels[-1].patch_apply(g["x"]), g["patch_apply_x"]) < 1e-8
+    assert rel(cmg.vcycle(len(lv) - 1, g["b"], np.zeros(L.n)), g["vcycle_b"]) < 1e-6
+    assert rel(cmg.transfers[-1].prolong(g["uc"]), g["prolong_uc"]) < 1e-10
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", NAMES)
+def test_hip_matches_golden(name):
+    from alfi_amd import hip
+    lv, tr, ks, g = load(name)
+    L = lv[-1]
+    ctx = hip.Context(0)
+    mg = hip.Multigrid(ctx, lv, tr, ks, robust_restriction=True)
+    fin = mg.levels[-1]
+    dx, dy, db = ctx.vec(g["x"]), ctx.vec(L.n), ctx.vec(g["b"])
+    fin.spmv(dx, dy)
+    assert rel(dy.get(), g["A_x"]) < 1e-13
+    fin.patch_apply(dx, dy)
+    assert rel(dy.get(), g["patch_apply_x"]) < 1e-7
+    assert rel(fin.patch_inverse(0, g["inv_patch0"].shape[0]), g["inv_patch0"]) < 1e-7
+    dz = ctx.vec(L.n)
+    fin.smooth(ks, db, dz, nonzero_guess=False)
+    assert rel(dz.get(), g["smooth_b"]) < 1e-7
+    duc, dxf, drc = ctx.vec(g["uc"]), ctx.vec(L.n), ctx.vec(lv[0].n)
+    mg.transfers[-1].prolong(duc, dxf)
+    assert rel(dxf.get(), g["prolong_uc"]) < 1e-7
+    mg.transfers[-1].restrict(dx, drc, robust=True)
+    assert rel(drc.get(), g["restrict_b"]) < 1e-7
+    dv = ctx.vec(L.n)
+    mg.vcycle(db, dv)
+    assert rel(dv.get(), g["vcycle_b"]) < 1e-5
+    mg.fcycle(db, dv)
+    assert rel(dv.get(), g["fcycle_b"]) < 1e-5
+    mg.close()
+    ctx.close()
