@@ -1,0 +1,490 @@
+"""Mesh-partition data parallelism of the multigrid hot path: one process per GPU, halos over torch.distributed.
+
+The reference distributes every level's mesh over MPI ranks with a vertex-star overlap (``distribution_parameters``,
+alfi/solver.py:604-605) and builds one patch per *owned* vertex (``ownership_ranges``, alfi/relaxation.py:120-121);
+PETSc then scatters ghost values before and adds ghost contributions after every patch apply, and MatMult scatters
+ghost columns [3P].  The same decomposition here, sized for 8 MI355X on xGMI:
+
+* nodes of a level are numbered along a Morton curve (fespace.py), so a contiguous index range is a box-like sub-domain:
+  rank r **owns** the node range ``[splits[r], splits[r+1])`` (balanced by patch-inverse + operator bytes) and the
+  patches seeded in it.  Its **ghosts** are every other node its owned rows, owned patches, coarse-cell transfer blocks
+  or (as the coarse side of a transfer) its fine rows' prolongation stencils touch.  Local numbering = owned nodes
+  first, then ghosts ascending (= grouped by owner), so all vector kernels run on the owned prefix.
+* per level ONE halo plan, two exchanges: *forward* (owner -> ghost copies) and *reverse-add* (ghost contributions ->
+  owner), both one ``all_to_all_single`` of surface-sized buffers (RCCL grouped send/recv over the xGMI links), plus an
+  all-reduce of <= k+1 doubles per Gram-Schmidt step.  There is no other collective on the data path.
+* levels below ``min_dofs`` live on rank 0 alone (the reference telescopes the coarse grid the same way,
+  solver.py:354-358); the other ranks only hold the ghost copies the transfer to the first distributed level needs.
+
+The cycle itself stays inside libalfi_hip.so: the library packs/unpacks halo buffers and calls back
+(``alfi_ctx_set_comm``) at the exchange points; this module answers the callback with torch.distributed.  With the NCCL
+(= RCCL) backend the buffers are exchanged device to device on the library's stream; with gloo (CPU tests, or several
+ranks sharing one GPU) they are staged through the host.
+"""
+import ctypes
+
+import numpy as np
+
+from .problem import BSR
+
+COMM_ALLREDUCE, COMM_HALO_FWD, COMM_HALO_REV = 0, 1, 2
+RED_LEN = 64
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# partition (host, NumPy; identical on every rank because every rank generates the same global hierarchy)
+# ---------------------------------------------------------------------------------------------------------------------
+def level_weights(L):
+    """HBM bytes a node causes per smoother iteration: its operator row and, for patch seeds, the patch inverse."""
+    A = L.A
+    w = np.diff(A.rowptr).astype(np.float64) * (8.0 * A.bs * A.bs + 4.0) + 16.0 * A.bs
+    if getattr(L, "patch_ptr", None) is not None and L.level > 0:
+        npd = np.diff(L.patch_ptr).astype(np.float64)
+        w[L.V.vertex_nodes[L.patch_seeds]] += 8.0 * npd * npd
+    return w
+
+
+def choose_splits(levels, world, min_dofs=400000):
+    """splits[l]: int64 (world+1) node split points of level l.  Levels with fewer than ``min_dofs`` dofs -- and, so that
+    the coarse solve needs no exchange, always level 0 -- belong to rank 0 entirely."""
+    out = []
+    for L in levels:
+        nb = L.A.nbrows
+        if world == 1 or L.level == 0 or L.n < min_dofs:
+            out.append(np.array([0] + [nb] * world, dtype=np.int64))
+            continue
+        c = np.cumsum(level_weights(L))
+        s = np.searchsorted(c, c[-1] * np.arange(1, world) / world, side="left") + 1
+        s = np.maximum.accumulate(np.concatenate([[0], np.minimum(s, nb), [nb]]).astype(np.int64))
+        if (np.diff(s) <= 0).any():
+            raise ValueError("level %d (%d nodes) is too small to split over %d ranks" % (L.level, nb, world))
+        out.append(s)
+    # a single-owner level above a distributed one would serialise the fine work: not produced by the rule above
+    # because dofs grow with the level, but guard against odd hierarchies
+    for l in range(1, len(out)):
+        if out[l][1] == levels[l].A.nbrows and out[l - 1][1] != levels[l - 1].A.nbrows:
+            raise ValueError("level %d is single-owner above a distributed level" % l)
+    return out
+
+
+class LevelPart(object):
+    """One rank's view of one level: owned range, ghosts, local numbering, halo plan."""
+
+    def __init__(self, level, bs, splits, rank, ghosts):
+        self.level, self.bs, self.splits, self.rank = level, bs, np.asarray(splits, dtype=np.int64), rank
+        self.lo, self.hi = int(splits[rank]), int(splits[rank + 1])
+        self.nb_own = self.hi - self.lo
+        self.ghosts = np.asarray(ghosts, dtype=np.int64)              # global ids, ascending => grouped by owner
+        self.nb_ghost = self.ghosts.shape[0]
+        self.nb_loc = self.nb_own + self.nb_ghost
+        self.distributed = bool(np.count_nonzero(np.diff(self.splits)) > 1)
+        owner = np.searchsorted(self.splits, self.ghosts, side="right") - 1
+        world = len(splits) - 1
+        self.recv_counts = np.bincount(owner, minlength=world).astype(np.int64)   # ghost nodes per owner
+        self.send_nodes = [np.zeros(0, dtype=np.int64)] * world                   # filled by set_send_lists
+        self.send_counts = np.zeros(world, dtype=np.int64)
+
+    @property
+    def nodes(self):
+        return np.concatenate([np.arange(self.lo, self.hi, dtype=np.int64), self.ghosts])
+
+    def ghosts_by_owner(self):
+        off = np.concatenate([[0], np.cumsum(self.recv_counts)])
+        return [self.ghosts[off[q]:off[q + 1]] for q in range(len(self.recv_counts))]
+
+    def set_send_lists(self, wanted):
+        """wanted[q]: global node ids rank q holds as ghosts of mine (ascending, q's ghost order)."""
+        self.send_nodes = [np.asarray(w, dtype=np.int64) - self.lo for w in wanted]
+        for q, s in enumerate(self.send_nodes):
+            assert s.size == 0 or (s.min() >= 0 and s.max() < self.nb_own), "rank %d asked for nodes I do not own" % q
+        self.send_counts = np.array([s.shape[0] for s in self.send_nodes], dtype=np.int64)
+
+    @property
+    def has_halo(self):
+        return bool(self.recv_counts.sum() + self.send_counts.sum() > 0)
+
+    def g2l(self, g):
+        """Local index of global nodes (-1 where absent)."""
+        g = np.asarray(g, dtype=np.int64)
+        out = np.full(g.shape, -1, dtype=np.int64)
+        own = (g >= self.lo) & (g < self.hi)
+        out[own] = g[own] - self.lo
+        if self.nb_ghost:
+            pos = np.searchsorted(self.ghosts, g)
+            pos[pos >= self.nb_ghost] = self.nb_ghost - 1
+            hit = (~own) & (self.ghosts[pos] == g)
+            out[hit] = self.nb_own + pos[hit]
+        return out
+
+
+def _rows_with_cols_in(B, lo, hi):
+    """Mask over the block rows of BSR B: rows holding at least one column in [lo, hi)."""
+    m = (B.colidx >= lo) & (B.colidx < hi)
+    rows = np.repeat(np.arange(B.nbrows, dtype=np.int64), np.diff(B.rowptr))[m]
+    out = np.zeros(B.nbrows, dtype=bool)
+    out[rows] = True
+    return out
+
+
+def _ragged_take(ptr, sel):
+    """Index array gathering the ragged segments ``sel`` of a CSR-like ``ptr``; also the new ptr."""
+    ptr = np.asarray(ptr, dtype=np.int64)
+    cnt = ptr[sel + 1] - ptr[sel]
+    nptr = np.concatenate([[0], np.cumsum(cnt)])
+    idx = np.repeat(ptr[sel] - nptr[:-1], cnt) + np.arange(nptr[-1])
+    return idx, nptr
+
+
+def owned_patches(L, lo, hi):
+    seed_nodes = L.V.vertex_nodes[L.patch_seeds].astype(np.int64)
+    return np.flatnonzero((seed_nodes >= lo) & (seed_nodes < hi))
+
+
+def transfer_blocks(T, bs, lo, hi):
+    """Coarse-cell blocks (transfer.py:13-46) whose closure holds a fine node in [lo, hi): the rows of D_I of a block
+    reach exactly the fine nodes of the coarse cell's closure."""
+    mb = T.blk_dofs.shape[1] // bs
+    return np.flatnonzero(_rows_with_cols_in(T.D_I, lo, hi).reshape(-1, mb).any(axis=1))
+
+
+def compute_ghosts(levels, transfers, splits, l, rank):
+    """Global ids (ascending) of the nodes of level l that rank needs but does not own."""
+    L = levels[l]
+    lo, hi = int(splits[l][rank]), int(splits[l][rank + 1])
+    need = []
+    if hi > lo:
+        A = L.A
+        need.append(A.colidx[A.rowptr[lo]:A.rowptr[hi]])                          # SpMV columns of owned rows
+        if l > 0 and getattr(L, "patch_ptr", None) is not None:
+            idx, _ = _ragged_take(L.patch_ptr, owned_patches(L, lo, hi))
+            need.append(L.patch_dofs[idx][::L.bs] // L.bs)                        # star patches of owned vertices
+        if l > 0:
+            T = transfers[l - 1]
+            mb = T.blk_dofs.shape[1] // L.bs
+            blocks = transfer_blocks(T, L.bs, lo, hi)
+            rows = (blocks[:, None] * mb + np.arange(mb)).ravel()
+            idx, _ = _ragged_take(T.D_I.rowptr, rows)
+            need.append(T.D_I.colidx[idx])                                        # closures of those coarse cells
+    if l + 1 < len(levels):
+        T = transfers[l]
+        flo, fhi = int(splits[l + 1][rank]), int(splits[l + 1][rank + 1])
+        if fhi > flo:
+            need.append(T.P.colidx[T.P.rowptr[flo]:T.P.rowptr[fhi]])              # prolongation stencils
+            if T.PT_plain is not T.PT:
+                need.append(np.flatnonzero(_rows_with_cols_in(T.PT_plain, flo, fhi)))
+    if not need:
+        return np.zeros(0, dtype=np.int64)
+    g = np.unique(np.concatenate([np.asarray(x, dtype=np.int64) for x in need]))
+    return g[(g < lo) | (g >= hi)]
+
+
+def build_parts(levels, transfers, splits, rank, exchange_lists=None):
+    """LevelPart for every level on ``rank``.  ``exchange_lists(obj) -> list over ranks`` is an all-gather of Python
+    objects (torch.distributed.all_gather_object); None = compute every rank's ghost lists locally (tests)."""
+    world = len(splits[0]) - 1
+    parts = []
+    mine = []
+    for l, L in enumerate(levels):
+        p = LevelPart(l, L.bs, splits[l], rank, compute_ghosts(levels, transfers, splits, l, rank))
+        parts.append(p)
+        mine.append(p.ghosts_by_owner())
+    if exchange_lists is not None:
+        everyone = exchange_lists(mine)                  # everyone[q][l][owner] = ghosts of rank q owned by owner
+        for l, p in enumerate(parts):
+            p.set_send_lists([everyone[q][l][rank] for q in range(world)])
+    else:
+        for l, p in enumerate(parts):
+            wanted = []
+            for q in range(world):
+                if q == rank:
+                    wanted.append(np.zeros(0, dtype=np.int64))
+                    continue
+                g = compute_ghosts(levels, transfers, splits, l, q)
+                wanted.append(g[(g >= p.lo) & (g < p.hi)])
+            p.set_send_lists(wanted)
+    return parts
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# localisation: the rank's pieces of the operators, patches and transfers in local numbering
+# ---------------------------------------------------------------------------------------------------------------------
+class LocalLevel(object):
+    pass
+
+
+class LocalTransfer(object):
+    pass
+
+
+def _map_cols(B, part, nbcols, allow_drop=False):
+    """BSR with columns renumbered to part's local numbering; entries with absent columns are dropped (only legal for
+    ghost rows, whose remote couplings no owned patch needs)."""
+    lc = part.g2l(B.colidx)
+    if (lc < 0).any():
+        if not allow_drop:
+            raise AssertionError("a needed column is not in the local node set")
+        keep = lc >= 0
+        csum = np.concatenate([[0], np.cumsum(keep)])
+        rowptr = csum[B.rowptr.astype(np.int64)]
+        return BSR(B.nbrows, nbcols, B.bs, rowptr, lc[keep], B.vals[keep])
+    return BSR(B.nbrows, nbcols, B.bs, B.rowptr, lc, B.vals)
+
+
+def _sort_cols(B):
+    """Columns ascending within each block row (the patch gather bisects nothing here, but keep BSR canonical)."""
+    rows = np.repeat(np.arange(B.nbrows, dtype=np.int64), np.diff(B.rowptr))
+    order = np.lexsort((B.colidx, rows))
+    return BSR(B.nbrows, B.nbcols, B.bs, B.rowptr, B.colidx[order], B.vals[order])
+
+
+def localize_level(L, part):
+    """Operator rows of all local nodes (owned rows complete; ghost rows restricted to local columns -- they only feed the
+    patch sub-matrix gather), owned Dirichlet dofs, owned patches; everything in local numbering."""
+    out = LocalLevel()
+    bs = L.bs
+    out.level, out.bs, out.part = L.level, bs, part
+    out.n, out.n_own = part.nb_loc * bs, part.nb_own * bs
+    rows = L.A.select_rows(part.nodes)
+    own = BSR(part.nb_own, L.A.nbcols, bs, rows.rowptr[:part.nb_own + 1],
+              rows.colidx[:rows.rowptr[part.nb_own]], rows.vals[:rows.rowptr[part.nb_own]])
+    own = _map_cols(own, part, part.nb_loc)                                   # asserts completeness
+    gh_ptr = rows.rowptr[part.nb_own:].astype(np.int64) - rows.rowptr[part.nb_own]
+    gh = BSR(part.nb_ghost, L.A.nbcols, bs, gh_ptr, rows.colidx[rows.rowptr[part.nb_own]:],
+             rows.vals[rows.rowptr[part.nb_own]:])
+    gh = _map_cols(gh, part, part.nb_loc, allow_drop=True)
+    A = BSR(part.nb_loc, part.nb_loc, bs,
+            np.concatenate([own.rowptr.astype(np.int64), own.rowptr[-1] + gh.rowptr[1:].astype(np.int64)]),
+            np.concatenate([own.colidx, gh.colidx]), np.concatenate([own.vals, gh.vals]))
+    out.A = A
+    bcn = np.asarray(L.bc_dofs, dtype=np.int64)[::bs] // bs
+    bcn = bcn[(bcn >= part.lo) & (bcn < part.hi)] - part.lo
+    out.bc_dofs = (bcn[:, None] * bs + np.arange(bs)).ravel().astype(np.int32)
+    if L.level > 0 and part.nb_own > 0:
+        sel = owned_patches(L, part.lo, part.hi)
+        idx, nptr = _ragged_take(L.patch_ptr, sel)
+        gd = L.patch_dofs[idx].astype(np.int64)
+        ld = part.g2l(gd // bs) * bs + gd % bs
+        assert (ld >= 0).all()
+        pid = np.repeat(np.arange(len(sel)), np.diff(nptr))
+        order = np.lexsort((ld, pid))                                          # ascending within each patch
+        out.patch_ptr, out.patch_dofs = nptr.astype(np.int64), ld[order].astype(np.int32)
+        out.patch_ids = sel
+    else:
+        out.patch_ptr, out.patch_dofs = np.zeros(1, dtype=np.int64), np.zeros(0, dtype=np.int32)
+        out.patch_ids = np.zeros(0, dtype=np.int64)
+    return out
+
+
+def localize_transfer(T, Lf, pc, pf):
+    """The rank's share of the transfer between levels pc.level and pf.level (pf.nb_own > 0)."""
+    out = LocalTransfer()
+    bs = Lf.bs
+    mb = T.blk_dofs.shape[1] // bs
+    blocks = transfer_blocks(T, bs, pf.lo, pf.hi)
+    gd = T.blk_dofs[blocks].astype(np.int64)
+    ld = pf.g2l(gd // bs) * bs + gd % bs
+    assert (ld >= 0).all()
+    out.blocks = blocks
+    out.blk_dofs = ld.astype(np.int32)
+    out.K_II, out.D_II = np.ascontiguousarray(T.K_II[blocks]), np.ascontiguousarray(T.D_II[blocks])
+    rows = (blocks[:, None] * mb + np.arange(mb)).ravel()
+    out.D_I = _map_cols(T.D_I.select_rows(rows), pf, pf.nb_loc)
+    # rows of D_I^T for the owned fine nodes only: s = r - gamma D_I^T t is formed on owned rows
+    out.D_IT = out.D_I.transpose().select_rows(np.arange(pf.nb_own))
+    P = _map_cols(T.P.select_rows(np.arange(pf.lo, pf.hi)), pc, pc.nb_loc)
+    out.P = P
+    out.PT = P.transpose()                                  # (coarse local) x (fine owned): partial sums, reverse-added
+    if T.PT_plain is not T.PT:
+        Pp = T.PT_plain.transpose().select_rows(np.arange(pf.lo, pf.hi))
+        out.PT_plain = _map_cols(Pp, pc, pc.nb_loc).transpose()
+    else:
+        out.PT_plain = out.PT
+    out.nu, out.gamma = T.nu, T.gamma
+    return out
+
+
+def localize(levels, transfers, parts):
+    """(local levels, local transfers, first level present) for the rank the parts belong to."""
+    present = [p.nb_loc > 0 for p in parts]
+    lmin = present.index(True)
+    assert all(present[lmin:]), "levels present on a rank must be contiguous"
+    llev = [localize_level(levels[l], parts[l]) for l in range(lmin, len(levels))]
+    ltr = []
+    for l in range(lmin + 1, len(levels)):
+        if parts[l].nb_own > 0:
+            ltr.append(localize_transfer(transfers[l - 1], levels[l], parts[l - 1], parts[l]))
+        else:
+            raise AssertionError("a level above a present one must be owned in part")
+    return llev, ltr, lmin
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# communication (torch.distributed)
+# ---------------------------------------------------------------------------------------------------------------------
+class Comm(object):
+    """Halo exchange and all-reduce on torch tensors.  CPU tensors go straight to the backend; device tensors go
+    straight to NCCL/RCCL, or are staged through the host when the backend is gloo."""
+
+    def __init__(self, group=None):
+        import torch.distributed as dist
+        self.dist = dist
+        self.group = group
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        self.backend = dist.get_backend(group)
+
+    def all_gather_object(self, obj):
+        out = [None] * self.world
+        self.dist.all_gather_object(out, obj, group=self.group)
+        return out
+
+    def _staged(self, t):
+        return t.is_cuda and self.backend != "nccl"
+
+    def allreduce(self, t):
+        if self._staged(t):
+            import torch
+            torch.cuda.current_stream().synchronize()
+            h = t.cpu()
+            self.dist.all_reduce(h, group=self.group)
+            t.copy_(h)
+        else:
+            self.dist.all_reduce(t, group=self.group)
+
+    def exchange(self, send, recv, send_counts, recv_counts):
+        """recv[segment q] <- rank q's send[segment me]; counts in elements of the tensors."""
+        sc, rc = [int(c) for c in send_counts], [int(c) for c in recv_counts]
+        if self._staged(send):
+            import torch
+            torch.cuda.current_stream().synchronize()
+            hs, hr = send.cpu(), torch.empty(recv.shape, dtype=recv.dtype)
+            self.dist.all_to_all_single(hr, hs, rc, sc, group=self.group)
+            recv.copy_(hr)
+        else:
+            self.dist.all_to_all_single(recv, send, rc, sc, group=self.group)
+
+
+class HaloBuffers(object):
+    """Per level: the torch-owned buffers the library packs into / unpacks from, and the exchange split sizes."""
+
+    def __init__(self, part, device):
+        import torch
+        bs = part.bs
+        self.part = part
+        self.send_counts = part.send_counts * bs
+        self.recv_counts = part.recv_counts * bs
+        self.sendbuf = torch.zeros(max(int(self.send_counts.sum()), 1), dtype=torch.float64, device=device)
+        self.recvbuf = torch.zeros(max(int(self.recv_counts.sum()), 1), dtype=torch.float64, device=device)
+        self.nsend, self.nrecv = int(self.send_counts.sum()), int(self.recv_counts.sum())
+
+    def forward(self, comm):
+        comm.exchange(self.sendbuf[:self.nsend], self.recvbuf[:self.nrecv], self.send_counts, self.recv_counts)
+
+    def reverse(self, comm):
+        comm.exchange(self.recvbuf[:self.nrecv], self.sendbuf[:self.nsend], self.recv_counts, self.send_counts)
+
+
+CommFn = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int64, ctypes.c_int64)
+
+
+class DistMultigrid(object):
+    """The rank's share of PCMG (alfi/solver.py:359-379) on its GPU; collective over the process group.
+
+    ``levels, transfers``: the *global* hierarchy of alfi_amd.problem.build_hierarchy (every rank generates the same one;
+    only the rank's rows are uploaded)."""
+
+    def __init__(self, levels, transfers, k, robust_restriction=False, group=None, device=None, min_dofs=400000,
+                 coarse_inverse=None, verbose=False):
+        import torch
+        from . import hip
+        self.comm = Comm(group)
+        rank = self.comm.rank
+        if device is None:
+            device = torch.device("cuda", torch.cuda.current_device())
+        self.device = device
+        self.stream = torch.cuda.Stream(device=device)
+        self.splits = choose_splits(levels, self.comm.world, min_dofs)
+        self.parts = build_parts(levels, transfers, self.splits, rank, self.comm.all_gather_object)
+        llev, ltr, self.lmin = localize(levels, transfers, self.parts)
+        self.local_levels, self.local_transfers = llev, ltr
+        self.k = k
+        with torch.cuda.stream(self.stream):
+            self.ctx = ctx = hip.Context(device.index or 0, stream=self.stream.cuda_stream)
+            self.red = torch.zeros(RED_LEN, dtype=torch.float64, device=device)
+            self._cb = CommFn(self._callback)
+            ctx.set_comm(self._cb, self.red.data_ptr(), RED_LEN)
+            self.halos = {}
+            self.levels = []
+            for LL in llev:
+                p = LL.part
+                dl = hip.Level(ctx, LL.A, LL.bc_dofs)
+                hb = HaloBuffers(p, device)
+                send_nodes = np.concatenate(p.send_nodes).astype(np.int32) if p.send_counts.sum() else \
+                    np.zeros(0, dtype=np.int32)
+                dl.set_partition(p.nb_own, p.distributed, send_nodes, hb.sendbuf.data_ptr(), hb.recvbuf.data_ptr(),
+                                 p.nb_ghost)
+                self.halos[dl.id] = hb
+                if LL.level > 0:
+                    dl.set_patches(LL.patch_ptr, LL.patch_dofs)
+                    dl.factor()
+                elif p.nb_own > 0:
+                    inv = coarse_inverse(levels[0].A) if coarse_inverse is not None else hip.coarse_inverse(levels[0].A)
+                    if isinstance(inv, tuple):
+                        inv, self._keep_inv = inv
+                    dl.set_coarse_inverse(inv)
+                self.levels.append(dl)
+            self.mg = hip.Multigrid.__new__(hip.Multigrid)
+            self.mg._from_device_levels(ctx, self.levels, ltr, k, robust_restriction)
+        self.fine = llev[-1]
+        self.n_own = self.fine.n_own
+        self.n_loc = self.fine.n
+        if verbose:
+            print("[alfi_amd.dist] rank %d: levels %d..%d, finest owns %d of %d dofs (+%d ghost), %d patches"
+                  % (rank, self.lmin, len(levels) - 1, self.n_own, levels[-1].n, self.n_loc - self.n_own,
+                     len(self.fine.patch_ptr) - 1), flush=True)
+
+    # the library calls this at every exchange point of the cycle (alfi_ctx_set_comm)
+    def _callback(self, user, op, level_id, offset, count):
+        try:
+            if op == COMM_ALLREDUCE:
+                self.comm.allreduce(self.red[offset:offset + count])
+            elif op == COMM_HALO_FWD:
+                self.halos[level_id].forward(self.comm)
+            elif op == COMM_HALO_REV:
+                self.halos[level_id].reverse(self.comm)
+            else:
+                return -2
+            return 0
+        except Exception:                                   # never let an exception cross the C boundary
+            import traceback
+            traceback.print_exc()
+            return -1
+
+    def local_vec(self, global_array=None):
+        """Device vector of the finest level in local numbering (owned + ghost slots), filled from a global array."""
+        v = self.ctx.vec(self.n_loc)
+        if global_array is not None:
+            p, bs = self.fine.part, self.fine.bs
+            loc = np.zeros(self.n_loc)
+            loc[:self.n_own] = np.asarray(global_array)[p.lo * bs:p.hi * bs]
+            v.set(loc)
+        return v
+
+    def owned(self, v):
+        return v.get()[:self.n_own]
+
+    def vcycle(self, b, x):
+        import torch
+        with torch.cuda.stream(self.stream):
+            self.mg.vcycle(b, x)
+
+    def fcycle(self, b, x):
+        import torch
+        with torch.cuda.stream(self.stream):
+            self.mg.fcycle(b, x)
+
+    def sync(self):
+        self.ctx.sync()
+
+    def close(self):
+        self.mg.close()
+        self.ctx.close()

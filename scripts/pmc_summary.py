@@ -1,0 +1,38 @@
+#!/usr/bin/env python3
+"""Summarise rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (separate runs) into profiles/pmc_<kernel>_<cfg>.json.
+
+gfx950 corrections (MI355X_MICROARCH.md, HBM section): FETCH_SIZE is reported in KiB and tallies the 128-B requests of a
+wide streaming read at 64 B => bytes = 2 * 1024 * FETCH_SIZE; WRITE_SIZE (KiB) is exact for streaming stores.
+
+usage: pmc_summary.py <fetch_dir> <write_dir> <kernel-name-prefix> <out.json> [tag]
+"""
+import glob
+import json
+import sys
+
+import pandas as pd
+
+
+def per_kernel(d, counter, prefix):
+    f = glob.glob(d + "/**/*_counter_collection.csv", recursive=True)[0]
+    t = pd.read_csv(f)
+    t = t[(t["Counter_Name"] == counter) & t["Kernel_Name"].str.startswith(prefix)]
+    return t["Counter_Value"].to_numpy()
+
+
+def main():
+    fetch_dir, write_dir, prefix, out = sys.argv[1:5]
+    tag = sys.argv[5] if len(sys.argv) > 5 else ""
+    f, w = per_kernel(fetch_dir, "FETCH_SIZE", prefix), per_kernel(write_dir, "WRITE_SIZE", prefix)
+    fb, wb = 2.0 * 1024.0 * f.mean(), 1024.0 * w.mean()
+    res = {"kernel": prefix, "tag": tag, "launches": int(len(f)),
+           "fetch_size_KiB_avg_raw": float(f.mean()), "write_size_KiB_avg_raw": float(w.mean()),
+           "fetch_bytes_per_launch": fb, "write_bytes_per_launch": wb, "hbm_bytes_per_launch": fb + wb,
+           "fetch_bytes_per_launch_max": 2048.0 * float(f.max()),
+           "correction": "FETCH_SIZE KiB x 1024 x 2 (gfx950 tallies 128-B requests at 64 B); WRITE_SIZE KiB x 1024"}
+    json.dump(res, open(out, "w"), indent=1)
+    print(json.dumps(res))
+
+
+if __name__ == "__main__":
+    main()
