@@ -20,6 +20,10 @@ def lib():
         _lib.alfi_host_extract_blocks.restype = ctypes.c_int
         _lib.alfi_host_interior_blocks.restype = ctypes.c_int
         _lib.alfi_host_bsr_transpose.restype = ctypes.c_int
+        # ALFI_HOST_THREADS overrides OMP_NUM_THREADS (torch.distributed.run exports OMP_NUM_THREADS=1 to every rank)
+        nthr = int(os.environ.get("ALFI_HOST_THREADS", "0"))
+        if nthr > 0:
+            _lib.alfi_host_set_num_threads(ctypes.c_int(nthr))
     return _lib
 
 

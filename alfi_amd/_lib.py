@@ -32,6 +32,9 @@ SIGNATURES = {
     "alfi_prof_get": (ctypes.c_int, [vp, ctypes.c_int, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int64)]),
     "alfi_prof_get_level": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_double),
                                            ctypes.POINTER(ctypes.c_int64)]),
+    "alfi_ctx_set_comm": (ctypes.c_int, [vp, vp, vp, vp, ctypes.c_int64]),
+    "alfi_level_set_partition": (ctypes.c_int, [vp, ctypes.c_int64, ctypes.c_int, ctypes.c_int64, vp, vp, vp,
+                                                ctypes.c_int64]),
     "alfi_level_id": (ctypes.c_int, [vp, ctypes.POINTER(ctypes.c_int)]),
     "alfi_level_create": (ctypes.c_int, [vp, ctypes.c_int64, ctypes.c_int, vp, vp, vp, vp, ctypes.c_int64,
                                          ctypes.POINTER(vp)]),
@@ -63,7 +66,7 @@ SIGNATURES = {
     "alfi_mg_fcycle": (ctypes.c_int, [vp, vp, vp]),
 }
 
-EVENTS = ["PATCH_APPLY", "PATCH_SCATTER", "PATCH_FACTOR", "MATMULT", "BLAS1", "PROLONG", "RESTRICT", "COARSE"]
+EVENTS = ["PATCH_APPLY", "PATCH_SCATTER", "PATCH_FACTOR", "MATMULT", "BLAS1", "PROLONG", "RESTRICT", "COARSE", "COMM"]
 
 _lib = None
 

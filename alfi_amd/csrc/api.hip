@@ -77,6 +77,51 @@ static void free_bsr(DevBSR* d) {
   *d = DevBSR();
 }
 
+// ---- mesh-partition exchanges (alfi_ctx_set_comm) ------------------------------------------------------------------------
+static int comm_call(alfi_ctx* ctx, int op, int level_id, int64_t offset, int64_t count) {
+  if (!ctx->comm) return alfi_set_error(ctx, ALFI_E_STATE, "partitioned level used before alfi_ctx_set_comm");
+  const int rc = ctx->comm(ctx->comm_user, op, level_id, offset, count);
+  if (rc != 0) return alfi_set_error(ctx, ALFI_E_STATE, "communication callback failed (op %d, rc %d)", op, rc);
+  return 0;
+}
+
+// sum dred[offset .. offset+count) over the ranks
+static int comm_allreduce(alfi_level* L, int64_t offset, int64_t count) {
+  alfi_ctx* ctx = L->ctx;
+  int t = alfi_prof_begin(ctx, ALFI_EV_COMM);
+  ALFI_CHECK(comm_call(ctx, ALFI_COMM_ALLREDUCE, L->id, offset, count));
+  alfi_prof_end(ctx, t);
+  return 0;
+}
+
+// owner -> ghost copies of level vector v (ghost slots of v are overwritten)
+static int halo_fwd(alfi_level* L, double* v) {
+  alfi_ctx* ctx = L->ctx;
+  if (!L->has_halo) return alfi_set_error(ctx, ALFI_E_STATE, "halo exchange on a level without alfi_level_set_partition");
+  int t = alfi_prof_begin(ctx, ALFI_EV_COMM);
+  ALFI_CHECK(launch_halo_pack(ctx, L->halo_sendbuf, v, L->halo_send_nodes, L->halo_nsend, L->bs));
+  ALFI_CHECK(comm_call(ctx, ALFI_COMM_HALO_FWD, L->id, 0, 0));
+  if (L->halo_nghost > 0)
+    ALFI_HIP_CHECK(ctx, hipMemcpyAsync(v + L->n_own, L->halo_recvbuf, sizeof(double) * L->halo_nghost * L->bs,
+                                       hipMemcpyDeviceToDevice, ctx->stream));
+  alfi_prof_end(ctx, t);
+  return 0;
+}
+
+// ghost contributions of v added onto their owners (ghost slots of v keep their local values)
+static int halo_rev(alfi_level* L, double* v) {
+  alfi_ctx* ctx = L->ctx;
+  if (!L->has_halo) return alfi_set_error(ctx, ALFI_E_STATE, "halo exchange on a level without alfi_level_set_partition");
+  int t = alfi_prof_begin(ctx, ALFI_EV_COMM);
+  if (L->halo_nghost > 0)
+    ALFI_HIP_CHECK(ctx, hipMemcpyAsync(L->halo_recvbuf, v + L->n_own, sizeof(double) * L->halo_nghost * L->bs,
+                                       hipMemcpyDeviceToDevice, ctx->stream));
+  ALFI_CHECK(comm_call(ctx, ALFI_COMM_HALO_REV, L->id, 0, 0));
+  ALFI_CHECK(launch_halo_add(ctx, v, L->halo_sendbuf, L->rev_nodes, L->rev_ptr, L->rev_pos, L->rev_nuniq, L->bs));
+  alfi_prof_end(ctx, t);
+  return 0;
+}
+
 extern "C" {
 
 // ---- context -------------------------------------------------------------------------------------------------------------
@@ -154,6 +199,15 @@ int alfi_memset0(alfi_ctx* ctx, void* dst, int64_t bytes) {
   return 0;
 }
 
+int alfi_ctx_set_comm(alfi_ctx* ctx, alfi_comm_fn fn, void* user, double* dred, int64_t dred_len) {
+  if (fn && (!dred || dred_len < 2 * RED_MAXV))
+    return alfi_set_error(ctx, ALFI_E_ARG, "alfi_ctx_set_comm needs a device buffer of >= %d doubles", 2 * RED_MAXV);
+  ctx->comm = fn;
+  ctx->comm_user = user;
+  ctx->dred = dred;
+  return 0;
+}
+
 int alfi_prof_enable(alfi_ctx* ctx, int on) {
   ctx->prof = on != 0;
   return 0;
@@ -205,7 +259,60 @@ int alfi_level_create(alfi_ctx* ctx, int64_t nbrows, int bs, const int32_t* brow
     alfi_level_destroy(L);
     return rc;
   }
+  L->n_own = L->n;
+  L->A_own = L->A;
   *out = L;
+  return 0;
+}
+
+int alfi_level_set_partition(alfi_level* L, int64_t nb_owned, int distributed, int64_t nsend,
+                             const int32_t* send_nodes, double* d_sendbuf, double* d_recvbuf, int64_t nb_ghost) {
+  alfi_ctx* ctx = L->ctx;
+  if (nb_owned < 0 || nb_ghost < 0 || nb_owned + nb_ghost != L->A.nbrows)
+    return alfi_set_error(ctx, ALFI_E_ARG, "owned (%lld) + ghost (%lld) nodes != %lld block rows", (long long)nb_owned,
+                          (long long)nb_ghost, (long long)L->A.nbrows);
+  if (nsend < 0 || (nsend > 0 && (!send_nodes || !d_sendbuf)) || (nb_ghost > 0 && !d_recvbuf))
+    return alfi_set_error(ctx, ALFI_E_ARG, "NULL halo buffers");
+  for (int64_t i = 0; i < nsend; ++i)
+    if (send_nodes[i] < 0 || send_nodes[i] >= nb_owned)
+      return alfi_set_error(ctx, ALFI_E_ARG, "send node %d is not an owned node", send_nodes[i]);
+  if (L->patch_ptr || L->V) return alfi_set_error(ctx, ALFI_E_STATE, "alfi_level_set_partition must precede patches");
+  ALFI_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  ALFI_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  dev_free(L->halo_send_nodes);
+  dev_free(L->rev_nodes);
+  dev_free(L->rev_ptr);
+  dev_free(L->rev_pos);
+  L->halo_send_nodes = L->rev_nodes = L->rev_ptr = L->rev_pos = nullptr;
+  // reverse-add plan: positions of the send buffer grouped by node, in buffer order (fixed summation order)
+  std::vector<int32_t> order(nsend);
+  for (int64_t i = 0; i < nsend; ++i) order[i] = (int32_t)i;
+  std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return send_nodes[a] < send_nodes[b]; });
+  std::vector<int32_t> rev_nodes, rev_ptr;
+  for (int64_t i = 0; i < nsend; ++i) {
+    if (i == 0 || send_nodes[order[i]] != send_nodes[order[i - 1]]) {
+      rev_nodes.push_back(send_nodes[order[i]]);
+      rev_ptr.push_back((int32_t)i);
+    }
+  }
+  rev_ptr.push_back((int32_t)nsend);
+  ALFI_CHECK(dev_upload(ctx, &L->halo_send_nodes, send_nodes, nsend));
+  ALFI_CHECK(dev_upload(ctx, &L->rev_nodes, rev_nodes.data(), (int64_t)rev_nodes.size()));
+  ALFI_CHECK(dev_upload(ctx, &L->rev_ptr, rev_ptr.data(), (int64_t)rev_ptr.size()));
+  ALFI_CHECK(dev_upload(ctx, &L->rev_pos, order.data(), nsend));
+  L->rev_nuniq = (int64_t)rev_nodes.size();
+  L->halo_nsend = nsend;
+  L->halo_nghost = nb_ghost;
+  L->halo_sendbuf = d_sendbuf;
+  L->halo_recvbuf = d_recvbuf;
+  L->has_halo = true;
+  L->distributed = distributed != 0;
+  L->n_own = nb_owned * L->bs;
+  L->A_own = L->A;
+  L->A_own.nbrows = nb_owned;
+  int32_t nnz_own = 0;
+  ALFI_HIP_CHECK(ctx, hipMemcpy(&nnz_own, L->A.rowptr + nb_owned, sizeof(int32_t), hipMemcpyDeviceToHost));
+  L->A_own.nnzb = nnz_own;
   return 0;
 }
 
@@ -214,6 +321,10 @@ int alfi_level_destroy(alfi_level* L) {
   (void)hipStreamSynchronize(L->ctx->stream);
   free_bsr(&L->A);
   dev_free(L->bc_dofs);
+  dev_free(L->halo_send_nodes);
+  dev_free(L->rev_nodes);
+  dev_free(L->rev_ptr);
+  dev_free(L->rev_pos);
   dev_free(L->patch_ptr);
   dev_free(L->patch_dofs);
   dev_free(L->inv_ptr);
@@ -253,19 +364,38 @@ int alfi_level_id(alfi_level* L, int* id) {
   return 0;
 }
 
+// Partitioned levels: x's ghost slots are refreshed from their owners first (they are scratch: see alfi_hip.h), the
+// product is formed on the owned rows.
 int alfi_spmv(alfi_level* L, const double* dx, double* dy) {
   L->ctx->cur_tag = L->id;
+  if (L->distributed) ALFI_CHECK(halo_fwd(L, const_cast<double*>(dx)));
   int t = alfi_prof_begin(L->ctx, ALFI_EV_MATMULT);
-  ALFI_CHECK(launch_bsr_spmv(L->ctx, L->A, dx, dy, nullptr, 0.0, 0));
+  ALFI_CHECK(launch_bsr_spmv(L->ctx, L->A_own, dx, dy, nullptr, 0.0, 0));
   alfi_prof_end(L->ctx, t);
   return 0;
 }
 
 int alfi_residual(alfi_level* L, const double* db, const double* dx, double* dr) {
   L->ctx->cur_tag = L->id;
+  if (L->distributed) ALFI_CHECK(halo_fwd(L, const_cast<double*>(dx)));
   int t = alfi_prof_begin(L->ctx, ALFI_EV_MATMULT);
-  ALFI_CHECK(launch_bsr_spmv(L->ctx, L->A, dx, dr, db, 1.0, 1));
+  ALFI_CHECK(launch_bsr_spmv(L->ctx, L->A_own, dx, dr, db, 1.0, 1));
   alfi_prof_end(L->ctx, t);
+  return 0;
+}
+
+// PCApply_PATCH on a (possibly partitioned) level: ghost values in, local patch solves, ghost contributions back to
+// their owners, Dirichlet dofs copied
+static int level_patch_apply(alfi_level* L, const double* dx, double* dy) {
+  alfi_ctx* ctx = L->ctx;
+  if (L->distributed) ALFI_CHECK(halo_fwd(L, const_cast<double*>(dx)));
+  ALFI_CHECK(launch_patch_apply(L, dx, dy));
+  if (L->distributed) ALFI_CHECK(halo_rev(L, dy));
+  if (L->nbc > 0) {
+    int t = alfi_prof_begin(ctx, ALFI_EV_PATCH_SCATTER);
+    ALFI_CHECK(launch_copy_dofs(ctx, dy, dx, L->bc_dofs, L->nbc));
+    alfi_prof_end(ctx, t);
+  }
   return 0;
 }
 
@@ -363,7 +493,7 @@ int alfi_patch_apply(alfi_level* L, const double* dx, double* dy) {
   if (!L->factored) return alfi_set_error(L->ctx, ALFI_E_STATE, "alfi_patch_apply before alfi_patches_factor");
   if (dx == dy) return alfi_set_error(L->ctx, ALFI_E_ARG, "alfi_patch_apply: x and y must not alias");
   L->ctx->cur_tag = L->id;
-  return launch_patch_apply(L, dx, dy);
+  return level_patch_apply(L, dx, dy);
 }
 
 int alfi_patches_stats(alfi_level* L, int64_t* npatch, int64_t* sum_n, int64_t* sum_n2) {
@@ -417,38 +547,56 @@ int alfi_smooth_fgmres(alfi_level* L, int k, const double* db, double* dx, int n
   ALFI_CHECK(ensure_fgmres_workspace(L, k));
   ctx->cur_tag = L->id;
   const int K = L->kmax;
-  const int64_t n = L->n;
+  const int64_t n = L->n_own;    // vector kernels and reductions run on the owned prefix
+  const int64_t ldv = L->n;      // stride of the Krylov bases (local length incl. ghost slots)
+  const bool par = L->distributed;
   HsLayout hl(K);
   double* V = L->V;
   double* Z = L->Z;
   double* w = L->w;
   double* hs = L->hs;
+  // partitioned level: dots / norms are reduced into the caller's buffer and all-reduced there
+  double* hdots = par ? ctx->dred : hs + hl.hd;
+  double* nrm2 = par ? ctx->dred + RED_MAXV : nullptr;
   int t;
   // r0 = b - A x (MatMult), beta = |r0|, v0 = r0 / beta
   if (nonzero_guess) {
     ALFI_CHECK(alfi_residual(L, db, dx, w));
   } else {
-    ALFI_HIP_CHECK(ctx, hipMemsetAsync(dx, 0, sizeof(double) * n, ctx->stream));
+    ALFI_HIP_CHECK(ctx, hipMemsetAsync(dx, 0, sizeof(double) * L->n, ctx->stream));
     t = alfi_prof_begin(ctx, ALFI_EV_BLAS1);
     ALFI_CHECK(launch_copy(ctx, w, db, n));
     alfi_prof_end(ctx, t);
   }
   t = alfi_prof_begin(ctx, ALFI_EV_BLAS1);
-  ALFI_CHECK(launch_norm_init(ctx, w, hs, K, n));
+  ALFI_CHECK(launch_norm_partials(ctx, w, n));
+  if (par) ALFI_CHECK(launch_reduce_partials(ctx, 1, nrm2));
+  alfi_prof_end(ctx, t);
+  if (par) ALFI_CHECK(comm_allreduce(L, RED_MAXV, 1));
+  t = alfi_prof_begin(ctx, ALFI_EV_BLAS1);
+  ALFI_CHECK(launch_norm_init_finish(ctx, par ? nrm2 : ctx->red_partial, par ? 1 : RED_BLOCKS, hs, K));
   ALFI_CHECK(launch_scale_by_inv(ctx, V, w, hs + hl.beta, n));
   alfi_prof_end(ctx, t);
   for (int j = 0; j < k; ++j) {
-    ALFI_CHECK(launch_patch_apply(L, V + (int64_t)j * n, Z + (int64_t)j * n));   // z_j = M^-1 v_j
-    ALFI_CHECK(alfi_spmv(L, Z + (int64_t)j * n, w));                              // w = A z_j
+    ALFI_CHECK(level_patch_apply(L, V + (int64_t)j * ldv, Z + (int64_t)j * ldv));   // z_j = M^-1 v_j
+    ALFI_CHECK(alfi_spmv(L, Z + (int64_t)j * ldv, w));                               // w = A z_j
     t = alfi_prof_begin(ctx, ALFI_EV_BLAS1);
-    ALFI_CHECK(launch_multi_dot(ctx, V, n, j + 1, w, hs + hl.hd, n));             // h = V^T w (classical GS)
-    ALFI_CHECK(launch_multi_axpy_norm(ctx, V, n, j + 1, hs + hl.hd, w, hs, j, K, n));  // w -= V h, |w|, Givens
-    if (j + 1 < k) ALFI_CHECK(launch_scale_by_inv(ctx, V + (int64_t)(j + 1) * n, w, hs + hl.tt, n));
+    ALFI_CHECK(launch_multi_dot(ctx, V, ldv, j + 1, w, hdots, n));                   // h = V^T w (classical GS)
+    alfi_prof_end(ctx, t);
+    if (par) ALFI_CHECK(comm_allreduce(L, 0, j + 1));
+    t = alfi_prof_begin(ctx, ALFI_EV_BLAS1);
+    ALFI_CHECK(launch_multi_axpy_norm(ctx, V, ldv, j + 1, hdots, w, n));             // w -= V h, |w|^2 partials
+    if (par) ALFI_CHECK(launch_reduce_partials(ctx, 1, nrm2));
+    alfi_prof_end(ctx, t);
+    if (par) ALFI_CHECK(comm_allreduce(L, RED_MAXV, 1));
+    t = alfi_prof_begin(ctx, ALFI_EV_BLAS1);
+    ALFI_CHECK(launch_hessenberg_update(ctx, par ? nrm2 : ctx->red_partial, par ? 1 : RED_BLOCKS, hdots, hs, j, K));
+    if (j + 1 < k) ALFI_CHECK(launch_scale_by_inv(ctx, V + (int64_t)(j + 1) * ldv, w, hs + hl.tt, n));
     alfi_prof_end(ctx, t);
   }
   t = alfi_prof_begin(ctx, ALFI_EV_BLAS1);
   ALFI_CHECK(launch_fgmres_finish(ctx, hs, k, K));
-  ALFI_CHECK(launch_update_solution(ctx, dx, Z, n, k, hs + hl.y, n));
+  ALFI_CHECK(launch_update_solution(ctx, dx, Z, ldv, k, hs + hl.y, n));
   alfi_prof_end(ctx, t);
   return 0;
 }
@@ -488,12 +636,16 @@ int alfi_transfer_create(alfi_ctx* ctx, alfi_level* coarse, alfi_level* fine, co
   const int bs = fine->bs;
   if (coarse->bs != bs) return alfi_set_error(ctx, ALFI_E_ARG, "block size mismatch");
   if (m < 1 || m > 32) return alfi_set_error(ctx, ALFI_E_ARG, "interior block size %d not in 1..32", m);
-  if (P->nbrows * bs != fine->n || P->nbcols * bs != coarse->n || PT->nbrows * bs != coarse->n ||
-      PT->nbcols * bs != fine->n)
+  // partitioned fine level: P and D_I^T hold the owned fine rows, P^T the owned fine columns (its rows are partial sums
+  // over the local coarse numbering, reverse-added to their owners); serial: n_own == n
+  if (P->nbrows * bs != fine->n_own || P->nbcols * bs != coarse->n || PT->nbrows * bs != coarse->n ||
+      (PT->nbcols * bs != fine->n_own && PT->nbcols * bs != fine->n))
     return alfi_set_error(ctx, ALFI_E_ARG, "prolongation shape does not match the levels");
   if ((nblk * m) % bs != 0 || D_I->nbrows * bs != nblk * m || D_I->nbcols * bs != fine->n ||
-      D_IT->nbrows * bs != fine->n || D_IT->nbcols * bs != nblk * m)
+      D_IT->nbrows * bs != fine->n_own || D_IT->nbcols * bs != nblk * m)
     return alfi_set_error(ctx, ALFI_E_ARG, "grad-div interior rows shape mismatch");
+  if (fine->distributed && !coarse->has_halo)
+    return alfi_set_error(ctx, ALFI_E_STATE, "coarse level of a partitioned transfer needs alfi_level_set_partition");
   for (int64_t i = 0; i < nblk * m; ++i)
     if (blk_dofs[i] < 0 || blk_dofs[i] >= fine->n) return alfi_set_error(ctx, ALFI_E_ARG, "blk_dofs out of range");
   ALFI_HIP_CHECK(ctx, hipSetDevice(ctx->device));
@@ -571,8 +723,15 @@ int alfi_prolong(alfi_transfer* T, const double* dxc, double* dxf) {
   alfi_ctx* ctx = T->ctx;
   if (!T->ready) return alfi_set_error(ctx, ALFI_E_STATE, "alfi_prolong before alfi_transfer_update");
   ctx->cur_tag = T->fine->id;
+  // partitioned fine level: coarse ghosts in, rhs on the owned fine rows, fine ghosts in; the interior solves of every
+  // coarse cell touching an owned node run locally (redundantly at partition boundaries), writes to ghost slots are scratch
+  const bool par = T->fine->distributed;
+  if (par) ALFI_CHECK(halo_fwd(T->coarse, const_cast<double*>(dxc)));
   int t = alfi_prof_begin(ctx, ALFI_EV_PROLONG);
   ALFI_CHECK(launch_bsr_spmv(ctx, T->P, dxc, dxf, nullptr, 0.0, 0));                 // rhs = P coarse        :247
+  alfi_prof_end(ctx, t);
+  if (par) ALFI_CHECK(halo_fwd(T->fine, dxf));
+  t = alfi_prof_begin(ctx, ALFI_EV_PROLONG);
   ALFI_CHECK(launch_bsr_spmv(ctx, T->DI, dxf, T->bI, nullptr, 0.0, 0));              // b_I = (D rhs)_I       :249
   ALFI_CHECK(launch_block_gemv(T, T->bI, T->tI, false));                              // t = inv(A_II) b_I     :254-257
   ALFI_CHECK(launch_scatter_sub(ctx, dxf, T->blk_dofs, T->tI, T->gamma, T->nblk * T->m));  // fine = rhs - gamma t  :259
@@ -585,6 +744,8 @@ int alfi_restrict(alfi_transfer* T, const double* drf, double* drc, int robust) 
   alfi_ctx* ctx = T->ctx;
   if (robust && !T->ready) return alfi_set_error(ctx, ALFI_E_STATE, "alfi_restrict before alfi_transfer_update");
   ctx->cur_tag = T->fine->id;
+  const bool par = T->fine->distributed;
+  if (par && robust) ALFI_CHECK(halo_fwd(T->fine, const_cast<double*>(drf)));
   int t = alfi_prof_begin(ctx, ALFI_EV_RESTRICT);
   if (robust) {
     ALFI_CHECK(launch_block_gemv(T, drf, T->tI, true));                               // t = inv(A_II) r_I     :265-270
@@ -593,6 +754,9 @@ int alfi_restrict(alfi_transfer* T, const double* drf, double* drc, int robust) 
   } else {
     ALFI_CHECK(launch_bsr_spmv(ctx, T->PTp, drf, drc, nullptr, 0.0, 0));              // firedrake.restrict
   }
+  alfi_prof_end(ctx, t);
+  if (par) ALFI_CHECK(halo_rev(T->coarse, drc));   // partial sums over the owned fine nodes -> the coarse owners
+  t = alfi_prof_begin(ctx, ALFI_EV_RESTRICT);
   ALFI_CHECK(launch_zero_dofs(ctx, drc, T->coarse->bc_dofs, T->coarse->nbc));
   alfi_prof_end(ctx, t);
   return 0;
@@ -606,9 +770,11 @@ int alfi_mg_create(alfi_ctx* ctx, int nlevels, alfi_level** levels, alfi_transfe
   for (int l = 1; l < nlevels; ++l) {
     if (transfers[l - 1]->coarse != levels[l - 1] || transfers[l - 1]->fine != levels[l])
       return alfi_set_error(ctx, ALFI_E_ARG, "transfer %d does not link levels %d and %d", l - 1, l - 1, l);
-    if (!levels[l]->factored) return alfi_set_error(ctx, ALFI_E_STATE, "level %d: patches not factored", l);
+    if (levels[l]->n_own > 0 && !levels[l]->factored)
+      return alfi_set_error(ctx, ALFI_E_STATE, "level %d: patches not factored", l);
   }
-  if (!levels[0]->cinv) return alfi_set_error(ctx, ALFI_E_STATE, "coarse level has no inverse");
+  // a rank that only holds ghost copies of its lowest level (the owner solves it) needs no coarse inverse
+  if (levels[0]->n_own > 0 && !levels[0]->cinv) return alfi_set_error(ctx, ALFI_E_STATE, "coarse level has no inverse");
   alfi_mg* mg = new alfi_mg();
   mg->ctx = ctx;
   mg->levels.assign(levels, levels + nlevels);
@@ -621,7 +787,7 @@ int alfi_mg_create(alfi_ctx* ctx, int nlevels, alfi_level** levels, alfi_transfe
     if (!L->mg_b) rc = dev_alloc(ctx, &L->mg_b, L->n);
     if (rc == 0 && !L->mg_x) rc = dev_alloc(ctx, &L->mg_x, L->n);
     if (rc == 0 && !L->mg_r) rc = dev_alloc(ctx, &L->mg_r, L->n);
-    if (rc == 0 && l > 0) rc = ensure_fgmres_workspace(L, k);
+    if (rc == 0 && l > 0 && L->n_own > 0) rc = ensure_fgmres_workspace(L, k);
     if (rc != 0) {
       delete mg;
       return rc;
@@ -640,7 +806,9 @@ int alfi_mg_destroy(alfi_mg* mg) {
 static int vcycle(alfi_mg* mg, int l, const double* b, double* x) {
   alfi_ctx* ctx = mg->ctx;
   alfi_level* L = mg->levels[l];
-  if (l == 0) return alfi_coarse_solve(L, b, x);
+  // partitioned hierarchies: a rank's lowest level is either the coarse grid it owns or ghost copies of a level another
+  // rank owns and solves (then there is nothing to do here); every level above is owned in part by every rank
+  if (l == 0) return L->n_own > 0 ? alfi_coarse_solve(L, b, x) : 0;
   alfi_level* C = mg->levels[l - 1];
   alfi_transfer* T = mg->transfers[l - 1];
   ALFI_CHECK(alfi_smooth_fgmres(L, mg->k, b, x, 1));                 // pre-smooth
@@ -651,7 +819,7 @@ static int vcycle(alfi_mg* mg, int l, const double* b, double* x) {
   ALFI_CHECK(alfi_prolong(T, C->mg_x, L->mg_r));                     // x += P x_{l-1}
   ctx->cur_tag = L->id;
   int t = alfi_prof_begin(ctx, ALFI_EV_BLAS1);
-  ALFI_CHECK(launch_axpy(ctx, x, L->mg_r, 1.0, L->n));
+  ALFI_CHECK(launch_axpy(ctx, x, L->mg_r, 1.0, L->n_own));
   alfi_prof_end(ctx, t);
   ALFI_CHECK(alfi_smooth_fgmres(L, mg->k, b, x, 1));                 // post-smooth
   return 0;
@@ -665,7 +833,7 @@ int alfi_mg_vcycle(alfi_mg* mg, const double* db, double* dx) {
 int alfi_mg_fcycle(alfi_mg* mg, const double* db, double* dx) {
   alfi_ctx* ctx = mg->ctx;
   const int Lmax = (int)mg->levels.size() - 1;
-  if (Lmax == 0) return alfi_coarse_solve(mg->levels[0], db, dx);
+  if (Lmax == 0) return mg->levels[0]->n_own > 0 ? alfi_coarse_solve(mg->levels[0], db, dx) : 0;
   // restrict the right-hand side through all levels
   const double* bf = db;
   for (int l = Lmax; l >= 1; --l) {

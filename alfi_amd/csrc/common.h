@@ -25,6 +25,10 @@ struct alfi_ctx {
   int next_level_id = 0;
   // scratch for reductions: partial sums [RED_BLOCKS][RED_MAXV]
   double* red_partial = nullptr;
+  // mesh-partition parallelism (alfi_ctx_set_comm)
+  alfi_comm_fn comm = nullptr;
+  void* comm_user = nullptr;
+  double* dred = nullptr;  // caller-owned device buffer the callback all-reduces: [0, RED_MAXV) dots, [RED_MAXV] norm^2
 };
 
 constexpr int RED_BLOCKS = 1024;  // blocks used by the two-stage dot/norm reductions
@@ -64,6 +68,16 @@ struct alfi_level {
   int64_t n = 0;  // scalar dofs
   int bs = 0;
   DevBSR A;
+  // partition: owned prefix [0, n_own) of the local numbering, then ghosts (serial: n_own == n)
+  int64_t n_own = 0;
+  DevBSR A_own;             // view of A restricted to the owned block rows
+  bool distributed = false;  // smoother / SpMV exchange halos and all-reduce
+  bool has_halo = false;
+  int64_t halo_nsend = 0, halo_nghost = 0;  // nodes
+  int32_t* halo_send_nodes = nullptr;       // (nsend) owned nodes, grouped by destination
+  double *halo_sendbuf = nullptr, *halo_recvbuf = nullptr;  // caller-owned
+  int64_t rev_nuniq = 0;                    // reverse-add: unique owned nodes receiving contributions
+  int32_t *rev_nodes = nullptr, *rev_ptr = nullptr, *rev_pos = nullptr;
   int32_t* bc_dofs = nullptr;
   int64_t nbc = 0;
   // patches
@@ -139,10 +153,20 @@ int launch_dense_gemv(alfi_ctx* ctx, const double* A, const double* x, double* y
 // blas1
 int launch_copy(alfi_ctx* ctx, double* y, const double* x, int64_t n);
 int launch_axpy(alfi_ctx* ctx, double* y, const double* x, double a, int64_t n);                 // y += a x
-int launch_norm_init(alfi_ctx* ctx, const double* r, double* hs, int K, int64_t n);  // beta = |r|, grs = beta e_1
+// |r|^2 partials (RED_BLOCKS of them) into ctx->red_partial; then beta = sqrt(sum of nblocks partials), grs = beta e_1
+int launch_norm_partials(alfi_ctx* ctx, const double* r, int64_t n);
+int launch_norm_init_finish(alfi_ctx* ctx, const double* partial, int nblocks, double* hs, int K);
+int launch_reduce_partials(alfi_ctx* ctx, int nv, double* out);  // out[v] = sum_b red_partial[b][v]
+int launch_hessenberg_update(alfi_ctx* ctx, const double* partial, int nblocks, const double* h, double* hs, int j,
+                             int K);
+// halo helpers
+int launch_halo_pack(alfi_ctx* ctx, double* buf, const double* v, const int32_t* nodes, int64_t nnodes, int bs);
+int launch_halo_add(alfi_ctx* ctx, double* v, const double* buf, const int32_t* rev_nodes, const int32_t* rev_ptr,
+                    const int32_t* rev_pos, int64_t nuniq, int bs);
 int launch_scale_by_inv(alfi_ctx* ctx, double* v, const double* w, const double* scal, int64_t n);  // v = w / *scal
 int launch_multi_dot(alfi_ctx* ctx, const double* V, int64_t stride, int nv, const double* w, double* out, int64_t n);
+// w -= sum_v h[v] V_v; |w|^2 partials into ctx->red_partial
 int launch_multi_axpy_norm(alfi_ctx* ctx, const double* V, int64_t stride, int nv, const double* h, double* w,
-                           double* hs, int j, int k, int64_t n);
+                           int64_t n);
 int launch_fgmres_finish(alfi_ctx* ctx, double* hs, int k, int K);  // back substitution -> y
 int launch_update_solution(alfi_ctx* ctx, double* x, const double* Z, int64_t stride, int k, const double* y, int64_t n);

@@ -334,5 +334,10 @@ int alfi_host_extract_blocks(int d, const int32_t* rowptr, const int32_t* colidx
 }
 
 int alfi_host_num_threads() { return omp_get_max_threads(); }
+// launchers such as torch.distributed.run export OMP_NUM_THREADS=1; the generator's own thread count is set explicitly
+int alfi_host_set_num_threads(int n) {
+  if (n > 0) omp_set_num_threads(n);
+  return omp_get_max_threads();
+}
 
 }  // extern "C"

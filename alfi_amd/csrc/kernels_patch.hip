@@ -356,7 +356,6 @@ int launch_patch_apply(alfi_level* L, const double* x, double* y) {
   dim3 grid((unsigned)((L->n + 255) / 256)), block(256);
   hipLaunchKernelGGL(patch_sum_kernel, grid, block, 0, ctx->stream, L->n, L->dof_ptr, L->dof_pos, L->stage, y);
   ALFI_HIP_CHECK(ctx, hipGetLastError());
-  if (L->nbc > 0) ALFI_CHECK(launch_copy_dofs(ctx, y, x, L->bc_dofs, L->nbc));
   alfi_prof_end(ctx, t);
   return 0;
 }

@@ -246,11 +246,11 @@ __global__ __launch_bounds__(256) void multi_axpy_add_kernel(const double* __res
 }
 
 // beta = sqrt(sum partial); hs[beta] = beta; grs[0] = beta
-__global__ __launch_bounds__(256) void norm_init_finish_kernel(const double* __restrict__ partial,
+__global__ __launch_bounds__(256) void norm_init_finish_kernel(const double* __restrict__ partial, int nblocks,
                                                                 double* __restrict__ hs, int K) {
   __shared__ double red[256];
   double s = 0.0;
-  for (int b = threadIdx.x; b < RED_BLOCKS; b += 256) s += partial[(int64_t)b * RED_MAXV];
+  for (int b = threadIdx.x; b < nblocks; b += 256) s += partial[(int64_t)b * RED_MAXV];
   red[threadIdx.x] = s;
   __syncthreads();
   for (int o = 128; o > 0; o >>= 1) {
@@ -266,13 +266,14 @@ __global__ __launch_bounds__(256) void norm_init_finish_kernel(const double* __r
   }
 }
 
-// column j of the Hessenberg: h[0..j] = hd (the CGS dots), h[j+1] = tt = sqrt(sum partial); Givens update
-// (KSPFGMRESUpdateHessenberg [3P])
-__global__ __launch_bounds__(256) void hessenberg_update_kernel(const double* __restrict__ partial,
+// column j of the Hessenberg: h[0..j] = the CGS dots, h[j+1] = tt = sqrt(sum of nblocks partials); Givens update
+// (KSPFGMRESUpdateHessenberg [3P]).  Partitioned levels pass the all-reduced values (nblocks = 1).
+__global__ __launch_bounds__(256) void hessenberg_update_kernel(const double* __restrict__ partial, int nblocks,
+                                                                 const double* __restrict__ h,
                                                                  double* __restrict__ hs, int j, int K) {
   __shared__ double red[256];
   double s = 0.0;
-  for (int b = threadIdx.x; b < RED_BLOCKS; b += 256) s += partial[(int64_t)b * RED_MAXV];
+  for (int b = threadIdx.x; b < nblocks; b += 256) s += partial[(int64_t)b * RED_MAXV];
   red[threadIdx.x] = s;
   __syncthreads();
   for (int o = 128; o > 0; o >>= 1) {
@@ -284,7 +285,7 @@ __global__ __launch_bounds__(256) void hessenberg_update_kernel(const double* __
     const double tt = sqrt(red[0]);
     hs[L.tt] = tt;
     double* hcol = hs + L.H(j);
-    for (int i = 0; i <= j; ++i) hcol[i] = hs[L.hd + i];
+    for (int i = 0; i <= j; ++i) hcol[i] = h[i];
     hcol[j + 1] = tt;
     double* cs = hs + L.cs;
     double* sn = hs + L.sn;
@@ -348,8 +349,8 @@ int launch_multi_dot(alfi_ctx* ctx, const double* V, int64_t stride, int nv, con
 }
 
 int launch_multi_axpy_norm(alfi_ctx* ctx, const double* V, int64_t stride, int nv, const double* h, double* w,
-                           double* hs, int j, int k, int64_t n) {
-  // w -= sum h_v V_v (passes of 16; the last pass also produces |w|^2 partials), then the Hessenberg column update
+                           int64_t n) {
+  // w -= sum h_v V_v (passes of 16; the last pass also produces |w|^2 partials)
   for (int v0 = 0; v0 < nv; v0 += 16) {
     const int cnt = nv - v0 < 16 ? nv - v0 : 16;
 #define ALFI_CASE(N)                                                                                             \
@@ -361,18 +362,67 @@ int launch_multi_axpy_norm(alfi_ctx* ctx, const double* V, int64_t stride, int n
 #undef ALFI_CASE
     ALFI_HIP_CHECK(ctx, hipGetLastError());
   }
-  hipLaunchKernelGGL(hessenberg_update_kernel, dim3(1), dim3(256), 0, ctx->stream, ctx->red_partial, hs, j, k);
+  return 0;
+}
+
+int launch_hessenberg_update(alfi_ctx* ctx, const double* partial, int nblocks, const double* h, double* hs, int j,
+                             int K) {
+  hipLaunchKernelGGL(hessenberg_update_kernel, dim3(1), dim3(256), 0, ctx->stream, partial, nblocks, h, hs, j, K);
   ALFI_HIP_CHECK(ctx, hipGetLastError());
   return 0;
 }
 
-int launch_norm_init(alfi_ctx* ctx, const double* r, double* hs, int K, int64_t n) {
-  // |r|^2 partials via the dot kernel with V = w = r, then beta = sqrt(sum), grs = beta e_1
+int launch_norm_partials(alfi_ctx* ctx, const double* r, int64_t n) {
+  // |r|^2 partials via the dot kernel with V = w = r
   hipLaunchKernelGGL(multi_dot_kernel<1>, dim3(RED_BLOCKS), dim3(256), 0, ctx->stream, r, (int64_t)0, r,
                      ctx->red_partial, n);
   ALFI_HIP_CHECK(ctx, hipGetLastError());
-  hipLaunchKernelGGL(norm_init_finish_kernel, dim3(1), dim3(256), 0, ctx->stream, ctx->red_partial, hs, K);
+  return 0;
+}
+
+int launch_norm_init_finish(alfi_ctx* ctx, const double* partial, int nblocks, double* hs, int K) {
+  hipLaunchKernelGGL(norm_init_finish_kernel, dim3(1), dim3(256), 0, ctx->stream, partial, nblocks, hs, K);
   ALFI_HIP_CHECK(ctx, hipGetLastError());
+  return 0;
+}
+
+int launch_reduce_partials(alfi_ctx* ctx, int nv, double* out) {
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(256), 0, ctx->stream, ctx->red_partial, nv, out);
+  ALFI_HIP_CHECK(ctx, hipGetLastError());
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// halo exchange helpers (partitioned levels): pack owned nodes into the send buffer; add received ghost contributions
+// onto their owners node by node in a fixed order (deterministic)
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ void halo_pack_kernel(double* __restrict__ buf, const double* __restrict__ v,
+                                 const int32_t* __restrict__ nodes, int64_t total, int bs) {
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t i = e / bs;
+    const int c = (int)(e - i * bs);
+    buf[e] = v[(int64_t)nodes[i] * bs + c];
+  }
+}
+__global__ void halo_add_kernel(double* __restrict__ v, const double* __restrict__ buf,
+                                const int32_t* __restrict__ rev_nodes, const int32_t* __restrict__ rev_ptr,
+                                const int32_t* __restrict__ rev_pos, int64_t total, int bs) {
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t u = e / bs;
+    const int c = (int)(e - u * bs);
+    const int64_t at = (int64_t)rev_nodes[u] * bs + c;
+    double s = v[at];
+    for (int32_t q = rev_ptr[u]; q < rev_ptr[u + 1]; ++q) s += buf[(int64_t)rev_pos[q] * bs + c];
+    v[at] = s;
+  }
+}
+int launch_halo_pack(alfi_ctx* ctx, double* buf, const double* v, const int32_t* nodes, int64_t nnodes, int bs) {
+  ALFI_LAUNCH_EW(halo_pack_kernel, nnodes * bs, buf, v, nodes, nnodes * bs, bs);
+  return 0;
+}
+int launch_halo_add(alfi_ctx* ctx, double* v, const double* buf, const int32_t* rev_nodes, const int32_t* rev_ptr,
+                    const int32_t* rev_pos, int64_t nuniq, int bs) {
+  ALFI_LAUNCH_EW(halo_add_kernel, nuniq * bs, v, buf, rev_nodes, rev_ptr, rev_pos, nuniq * bs, bs);
   return 0;
 }
 

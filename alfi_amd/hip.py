@@ -41,6 +41,10 @@ class Context(object):
             self.lib.alfi_ctx_destroy(self.h)
             self.h = None
 
+    def set_comm(self, callback, dred_ptr, dred_len):
+        """callback: a ctypes function pointer of type alfi_amd.dist.CommFn (kept alive by the caller)."""
+        self.check(self.lib.alfi_ctx_set_comm(self.h, ctypes.cast(callback, vp), None, vp(int(dred_ptr)), int(dred_len)))
+
     # vectors ----------------------------------------------------------------------------------------------------------
     def vec(self, n_or_array):
         if isinstance(n_or_array, (int, np.integer)):
@@ -123,6 +127,13 @@ class Level(object):
         i = ctypes.c_int()
         ctx.check(ctx.lib.alfi_level_id(h, ctypes.byref(i)))
         self.id = i.value
+
+    def set_partition(self, nb_owned, distributed, send_nodes, sendbuf_ptr, recvbuf_ptr, nb_ghost):
+        sn = np.ascontiguousarray(send_nodes, dtype=np.int32)
+        self.ctx.check(self.ctx.lib.alfi_level_set_partition(self.h, int(nb_owned), 1 if distributed else 0, len(sn),
+                                                             _ptr(sn), vp(int(sendbuf_ptr)), vp(int(recvbuf_ptr)),
+                                                             int(nb_ghost)))
+        self.n_own = int(nb_owned) * self.bs
 
     def update_values(self, vals):
         vals = np.ascontiguousarray(vals, dtype=np.float64)

@@ -84,6 +84,115 @@ def vcycle_bytes(levels, dmg, k):
     return total, per_level_apply
 
 
+def main_distributed(args, rank, world, local_rank):
+    """One process per GPU: the fixed config-4 mesh partitioned over the ranks (strong scaling), halos and reductions over
+    RCCL.  Every rank generates the same global hierarchy on its host cores and uploads its own share."""
+    import torch
+    import torch.distributed as dist
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs MI355X GPUs: the HIP path has no CPU fallback")
+    # ALFI_DIST_BACKEND=gloo: functional check of this leg with several ranks sharing one GPU (halos staged through the
+    # host) -- never a performance number
+    backend = os.environ.get("ALFI_DIST_BACKEND", "nccl")
+    local_rank = local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(local_rank)
+    if backend == "nccl":
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        dist.init_process_group(backend)
+    ncpu = len(os.sched_getaffinity(0))
+    os.environ.setdefault("ALFI_HOST_THREADS", str(max(1, ncpu // world)))    # host generator threads of this rank
+    from alfi_amd.dist import DistMultigrid
+    t0 = time.time()
+    lv, tr, k = build_problem(args.config, args.verbose and rank == 0)
+    t_gen = time.time() - t0
+
+    def coarse_inv(A_bsr):
+        inv, keep = coarse_inverse_device(A_bsr)
+        return (inv, keep)
+
+    t0 = time.time()
+    dmg = DistMultigrid(lv, tr, k, robust_restriction=False, coarse_inverse=coarse_inv,
+                        min_dofs=int(os.environ.get("ALFI_DIST_MIN_DOFS", "400000")), verbose=args.verbose)
+    dmg.sync()
+    t_setup = time.time() - t0
+    L = lv[-1]
+    b = np.random.default_rng(0).standard_normal(L.n)
+    b[L.bc_dofs] = 0.0
+    db, dx = dmg.local_vec(b), dmg.local_vec()
+    ctx = dmg.ctx
+    for _ in range(args.warmup):
+        dmg.vcycle(db, dx)
+    dmg.sync()
+    ctx.prof_enable(True)
+    ctx.prof_reset()
+    dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        dmg.vcycle(db, dx)
+    dmg.sync()
+    torch.cuda.synchronize()
+    dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    ctx.prof_enable(False)
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    elapsed = float(tmax.item())
+
+    # convergence sanity on the timed iterate: global residual norm
+    dr = dmg.local_vec()
+    with torch.cuda.stream(dmg.stream):
+        dmg.levels[-1].residual(db, dx, dr)
+    r2 = torch.tensor([float(np.sum(dmg.owned(dr) ** 2))], dtype=torch.float64, device="cuda")
+    dist.all_reduce(r2)
+    res = float(np.sqrt(r2.item()) / np.linalg.norm(b))
+
+    fin = dmg.levels[-1]
+    npatch, sum_n, sum_n2 = fin.patch_stats()
+    prof = ctx.prof_get()
+    ms_f, cnt_f = ctx.prof_get(fin.id)["PATCH_APPLY"]
+    bytes_apply = 8.0 * sum_n2 + 20.0 * sum_n
+    local_gbs = bytes_apply * cnt_f / (ms_f * 1e-3) / 1e9 if ms_f > 0 else 0.0
+    stats = torch.tensor([float(npatch), float(dmg.n_own), float(dmg.n_loc - dmg.n_own), local_gbs,
+                          prof["COMM"][0] / args.steps], dtype=torch.float64, device="cuda")
+    allstats = [torch.zeros_like(stats) for _ in range(world)]
+    dist.all_gather(allstats, stats)
+    if rank == 0:
+        vps = args.steps / elapsed
+        per_rank = [[float(v) for v in t.tolist()] for t in allstats]
+        out = {
+            "metric": "V-cycles/sec on ldc3d P2-P0 (DoF*smooths/sec in dof_smooths_per_s)",
+            "value": vps, "unit": "V-cycles/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": describe(args.config), "name": args.config, "velocity_dofs": int(L.n),
+                       "levels": len(lv), "patches_finest": int(len(L.patch_ptr) - 1),
+                       "cycle": "V(k,k), 1 cycle per step",
+                       "parallelism": "mesh partition over %d GPUs (Morton boxes, RCCL halos + all-reduce)" % world,
+                       "backend": backend,
+                       "distributed_levels": [int(p.level) for p in dmg.parts if p.distributed]},
+            "dof_smooths_per_s": L.n * 2 * k * vps,
+            "roofline": {"kernel": "patch_apply_kernel", "bound": "hbm", "achieved": local_gbs, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": local_gbs / HBM_PEAK_GBS, "traffic": None,
+                         "note": "rank 0's finest-level launches (its share of the patches), HIP events",
+                         "avg_launch_us": 1e3 * ms_f / max(cnt_f, 1), "launches": int(cnt_f)},
+            "events_ms_rank0": {kname: round(v[0], 3) for kname, v in prof.items()},
+            "per_rank": {"patches_finest": [r[0] for r in per_rank], "owned_dofs": [r[1] for r in per_rank],
+                         "ghost_dofs": [r[2] for r in per_rank], "patch_apply_GBps": [round(r[3], 1) for r in per_rank],
+                         "comm_ms_per_cycle": [round(r[4], 3) for r in per_rank]},
+            "rel_residual_after_timed_cycles": res,
+            "setup_s": {"host_generation": round(t_gen, 1), "partition_and_device_setup": round(t_setup, 1)},
+            "cpu_baseline": {"value": None, "unit": "V-cycles/s", "cores": 0, "kind": "port",
+                             "sample": "reported at N=1 only"},
+        }
+        print(json.dumps(out), flush=True)
+    dist.barrier()
+    dmg.close()
+    dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -98,8 +207,11 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        from bench_dist import main_distributed
+    if world > 1 or args.gpus > 1:
+        if world != args.gpus:
+            raise SystemExit("--gpus %d needs %d ranks: launch with python -m torch.distributed.run --nnodes=1 "
+                             "--nproc-per-node %d --master-addr 127.0.0.1 bench.py --gpus %d ..."
+                             % (args.gpus, args.gpus, args.gpus, args.gpus))
         return main_distributed(args, rank, world, local_rank)
 
     if not torch.cuda.is_available():

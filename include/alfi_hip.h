@@ -58,7 +58,8 @@ enum {
   ALFI_EV_PROLONG = 5,       /* SchoeberlProlong */
   ALFI_EV_RESTRICT = 6,      /* SchoeberlRestrict */
   ALFI_EV_COARSE = 7,        /* coarse solve */
-  ALFI_EV_COUNT = 8
+  ALFI_EV_COMM = 8,          /* halo pack/exchange/unpack and all-reduces (VecScatter / MPI_Allreduce in the reference) */
+  ALFI_EV_COUNT = 9
 };
 int alfi_prof_enable(alfi_ctx* ctx, int on); /* records a hipEvent pair around every launch of the classes above */
 int alfi_prof_reset(alfi_ctx* ctx);
@@ -67,12 +68,35 @@ int alfi_prof_get(alfi_ctx* ctx, int ev, double* total_ms, int64_t* count);
 /* same, restricted to launches issued on behalf of one level (level_id from alfi_level_id; -1 = all levels) */
 int alfi_prof_get_level(alfi_ctx* ctx, int ev, int level_id, double* total_ms, int64_t* count);
 
+/* ---- mesh-partition parallelism: one ctx per GPU / process, exchanges delegated to the host program ---------------- */
+/* The reference runs one MPI rank per mesh partition (alfi/solver.py:604-605, alfi/relaxation.py:120-121) and PETSc
+ * performs the ghost exchanges [3P].  Here the library packs / unpacks halo buffers and calls `fn` at every exchange
+ * point of a smoother, transfer or cycle; the host program performs the exchange (torch.distributed over RCCL in
+ * alfi_amd/dist.py) stream-ordered on the ctx's stream and returns 0.  ops:
+ *   ALFI_COMM_ALLREDUCE: sum dred[offset .. offset+count) over all ranks, in place;
+ *   ALFI_COMM_HALO_FWD : level `level_id`: every owner's send buffer -> the ghosts' receive buffers;
+ *   ALFI_COMM_HALO_REV : the reverse route: receive buffers (ghost contributions) -> owners' send buffers.
+ * Every rank of the group reaches every call (the exchanges are collective). */
+enum { ALFI_COMM_ALLREDUCE = 0, ALFI_COMM_HALO_FWD = 1, ALFI_COMM_HALO_REV = 2 };
+typedef int (*alfi_comm_fn)(void* user, int op, int level_id, int64_t offset, int64_t count);
+/* dred: device buffer of dred_len >= 64 doubles owned by the caller (reduction scratch the callback all-reduces). */
+int alfi_ctx_set_comm(alfi_ctx* ctx, alfi_comm_fn fn, void* user, double* dred, int64_t dred_len);
+
 /* ---- level operator: PETSc MatMult on the BAIJ level matrix [3P], alfi/solver.py:512 ----------------------------- */
 /* Block-CSR, bs x bs row-major blocks (bs = 2 or 3), nbrows block rows; bc_dofs: Dirichlet dofs of the level
  * (their rows/columns of the operator are expected to be the identity, as firedrake.assemble(a, bcs) gives [3P]). */
 int alfi_level_create(alfi_ctx* ctx, int64_t nbrows, int bs, const int32_t* browptr_host, const int32_t* bcolidx_host,
                       const double* bvals_host, const int32_t* bc_dofs_host, int64_t nbc, alfi_level** out);
 int alfi_level_destroy(alfi_level* lvl);
+/* Partitioned level: the first nb_owned block rows (nodes) are owned by this rank, the remaining nb_ghost are ghost
+ * copies of nodes owned elsewhere (local numbering: owned first).  Vector kernels, reductions and the SpMV then run on
+ * the owned prefix; ghost slots of any vector handed to the library are scratch.  distributed != 0: the level's
+ * smoother and SpMV exchange halos and all-reduce (needs alfi_ctx_set_comm); distributed == 0: a level owned by one
+ * rank whose halo is only used by the transfer to a distributed finer level.  send_nodes_host: owned nodes other ranks
+ * hold as ghosts, grouped by destination rank (the layout of d_sendbuf: nsend * bs doubles); d_recvbuf: nb_ghost * bs
+ * doubles in ghost order.  Both buffers are device memory owned by the caller. */
+int alfi_level_set_partition(alfi_level* lvl, int64_t nb_owned, int distributed, int64_t nsend,
+                             const int32_t* send_nodes_host, double* d_sendbuf, double* d_recvbuf, int64_t nb_ghost);
 /* new Newton step / new Reynolds number: same sparsity, new values (PatchPC.update -> PCSetUp_PATCH [3P]). */
 int alfi_level_update_values(alfi_level* lvl, const double* bvals_host);
 int alfi_level_size(alfi_level* lvl, int64_t* n);

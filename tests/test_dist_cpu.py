@@ -1,0 +1,124 @@
+"""Multi-rank path on CPU (gloo, world size 2 and 3): the product's partitioner / halo plans / exchange
+(alfi_amd/dist.py) driven by the SPMD NumPy oracle (oracle/dist_oracle.py) must reproduce the serial oracle's cycles.
+
+The HIP library performs the same exchange sequence through the same Comm object (tests/test_gpu_dist.py, -m gpu)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+CASES = {
+    # name: (dim, baseN, nref, element k, Re, smoother k, min_dofs)
+    "2d-all-distributed": (2, 4, 2, 2, 100.0, 3, 1),
+    "2d-coarse-on-rank0": (2, 4, 2, 2, 100.0, 3, 500),
+    "3d-P2FB": (3, 2, 1, 2, 1000.0, 2, 1),
+    "3d-P1FB": (3, 2, 1, 1, 100.0, 2, 1),
+}
+
+
+def _hier(case):
+    from alfi_amd.problem import TwoDimLidDrivenCavityProblem, ThreeDimLidDrivenCavityProblem, build_hierarchy
+    dim, baseN, nref, ke, Re, k, min_dofs = CASES[case]
+    prob = TwoDimLidDrivenCavityProblem(baseN) if dim == 2 else ThreeDimLidDrivenCavityProblem(baseN)
+    lv, tr = build_hierarchy(prob, nref, ke, Re=Re)
+    return lv, tr, k, min_dofs
+
+
+def _worker(rank, world, port, case, robust, q):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from alfi_amd import dist as D
+        from oracle.dist_oracle import DistOracle
+        lv, tr, k, min_dofs = _hier(case)
+        comm = D.Comm()
+        splits = D.choose_splits(lv, world, min_dofs)
+        parts = D.build_parts(lv, tr, splits, rank, comm.all_gather_object)
+        llev, ltr, lmin = D.localize(lv, tr, parts)
+        mg = DistOracle(llev, ltr, lmin, k, comm, robust=robust)
+        F = llev[-1]
+        p, bs = F.part, F.bs
+        b = np.random.default_rng(0).standard_normal(lv[-1].n)
+        b[lv[-1].bc_dofs] = 0.0
+        bl = np.zeros(F.n)
+        bl[:F.n_own] = b[p.lo * bs:p.hi * bs]
+        xv = mg.vcycle(len(llev) - 1, bl, np.zeros(F.n))
+        xv = mg.vcycle(len(llev) - 1, bl, xv)
+        xf = mg.fcycle(bl)
+        q.put((rank, p.lo * bs, p.hi * bs, xv[:F.n_own], xf[:F.n_own]))
+    finally:
+        dist.destroy_process_group()
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+@pytest.mark.parametrize("case,world,robust", [("2d-all-distributed", 2, False), ("2d-all-distributed", 3, True),
+                                               ("2d-coarse-on-rank0", 2, True), ("3d-P2FB", 2, False),
+                                               ("3d-P1FB", 2, True)])
+def test_spmd_oracle_matches_serial(case, world, robust):
+    import torch.multiprocessing as mp
+    from oracle import alfi_oracle as O
+    lv, tr, k, _ = _hier(case)
+    ser = O.build_oracle_mg(lv, tr, k, schoeberl_restriction=robust)
+    b = np.random.default_rng(0).standard_normal(lv[-1].n)
+    b[lv[-1].bc_dofs] = 0.0
+    top = len(lv) - 1
+    xv = ser.vcycle(top, b, np.zeros_like(b))
+    xv = ser.vcycle(top, b, xv)
+    xf = ser.fcycle(b)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, case, robust, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=300) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    dv, df = np.full_like(b, np.nan), np.full_like(b, np.nan)
+    for rank, lo, hi, v, f in got:
+        dv[lo:hi], df[lo:hi] = v, f
+    assert not np.isnan(dv).any()
+    # 2-D: 1e-8.  3-D (patch condition numbers ~1e7 at Re 1000): LAPACK inverts the same patch operators with the dofs in
+    # local instead of global order, a cond*eps ~ 1e-9 difference per apply that the chained FGMRES least-squares problems
+    # amplify exactly as in tests/test_gpu_parity.py (CYCLE_TOL 1e-5); a wrong halo or a missing ghost shows up at 1e-2.
+    tol = 1e-8 if case.startswith("2d") else 1e-5
+    assert np.abs(dv - xv).max() / np.abs(xv).max() < tol
+    assert np.abs(df - xf).max() / np.abs(xf).max() < tol
+
+
+def test_partition_covers_and_plans_are_consistent():
+    """Single process: every rank's plan computed locally; owners' send lists mirror the ghosts' receive lists."""
+    from alfi_amd import dist as D
+    lv, tr, k, _ = _hier("3d-P2FB")
+    world = 3
+    splits = D.choose_splits(lv, world, 1)
+    allparts = [D.build_parts(lv, tr, splits, r, None) for r in range(world)]
+    for l in range(len(lv)):
+        owned = np.concatenate([np.arange(allparts[r][l].lo, allparts[r][l].hi) for r in range(world)])
+        assert np.array_equal(owned, np.arange(lv[l].A.nbrows))
+        for r in range(world):
+            pr = allparts[r][l]
+            gb = pr.ghosts_by_owner()
+            for q in range(world):
+                pq = allparts[q][l]
+                assert np.array_equal(gb[q], pq.send_nodes[r] + pq.lo)
+            # owned rows see all their columns locally; owned patches are complete
+            LL = D.localize_level(lv[l], pr)
+            assert LL.A.nbrows == pr.nb_loc and LL.A.colidx.max(initial=0) < pr.nb_loc
+            if l > 0:
+                assert sum(len(D.owned_patches(lv[l], allparts[q][l].lo, allparts[q][l].hi)) for q in range(world)) \
+                    == len(lv[l].patch_ptr) - 1

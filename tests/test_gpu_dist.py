@@ -1,0 +1,64 @@
+"""Partitioned HIP multigrid (alfi_amd/dist.py + the library's exchange callbacks) against the single-GPU HIP result and
+the oracle.  -m gpu.  The box has one GPU, so 2 or 3 ranks share it and exchange through gloo (host-staged); the library's
+pack / callback / unpack sequence is exactly what runs over RCCL on 8 GPUs."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CYCLE_TOL = 1e-5      # see tests/test_gpu_parity.py
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+@pytest.mark.parametrize("case,world,robust", [("2d-all-distributed", 2, 0), ("2d-coarse-on-rank0", 3, 1),
+                                               ("3d-P2FB", 2, 0), ("3d-P1FB", 3, 1)])
+def test_partitioned_cycles_match_single_gpu(case, world, robust, tmp_path):
+    from alfi_amd import hip
+    from oracle import alfi_oracle as O
+    from tests.test_dist_cpu import _hier
+    lv, tr, k, _ = _hier(case)
+    b = np.random.default_rng(0).standard_normal(lv[-1].n)
+    b[lv[-1].bc_dofs] = 0.0
+    port = _free_port()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), OMP_NUM_THREADS="4")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dist_gpu_worker.py"), case,
+                                       str(robust), str(tmp_path)], env=env, cwd=ROOT))
+    # the single-GPU references while the ranks run
+    ctx = hip.Context(0)
+    mg = hip.Multigrid(ctx, lv, tr, k, robust_restriction=bool(robust))
+    db, dx = ctx.vec(b), ctx.vec(lv[-1].n)
+    mg.vcycle(db, dx)
+    mg.vcycle(db, dx)
+    sv = dx.get()
+    mg.fcycle(db, dx)
+    sf = dx.get()
+    mg.close()
+    ctx.close()
+    omg = O.build_oracle_mg(lv, tr, k, schoeberl_restriction=bool(robust))
+    top = len(lv) - 1
+    ov = omg.vcycle(top, b, omg.vcycle(top, b, np.zeros_like(b)))
+    for p in procs:
+        assert p.wait(timeout=600) == 0
+    dv, df = np.full_like(b, np.nan), np.full_like(b, np.nan)
+    for r in range(world):
+        z = np.load(os.path.join(str(tmp_path), "rank%d.npz" % r))
+        dv[int(z["lo"]):int(z["hi"])], df[int(z["lo"]):int(z["hi"])] = z["xv"], z["xf"]
+    assert not np.isnan(dv).any() and not np.isnan(df).any()
+    assert np.abs(dv - sv).max() / np.abs(sv).max() < CYCLE_TOL
+    assert np.abs(df - sf).max() / np.abs(sf).max() < CYCLE_TOL
+    assert np.abs(dv - ov).max() / np.abs(ov).max() < CYCLE_TOL
