@@ -514,7 +514,7 @@ int alfi_patch_get_inverse(alfi_level* L, int64_t p, double* out) {
   ALFI_HIP_CHECK(ctx, hipMemcpy(tmp.data(), L->inv + L->h_inv_ptr[p], tmp.size() * sizeof(double),
                                 hipMemcpyDeviceToHost));
   for (int64_t i = 0; i < n; ++i)
-    for (int64_t j = 0; j < n; ++j) out[i * n + j] = tmp[j * ld + i];
+    for (int64_t j = 0; j < n; ++j) out[i * n + j] = tmp[patch_inv_index((int)i, (int)j, (int)n, (int)ld)];
   return 0;
 }
 

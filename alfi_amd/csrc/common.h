@@ -54,6 +54,30 @@ int alfi_set_error(alfi_ctx* ctx, int code, const char* fmt, ...);
 int alfi_prof_begin(alfi_ctx* ctx, int kind);
 int alfi_prof_end(alfi_ctx* ctx, int token);
 
+// ---- storage of one dense patch inverse (n x n, rows padded to ld = n rounded up to even) --------------------------------
+// Row pieces: as many 128-row pieces as fit, then the binary digits of the remainder (64, 32, ..., 2).  A piece of R rows
+// is stored [column][R] contiguously, pieces follow each other, so the whole inverse is ld * n contiguous doubles that
+// the apply kernel streams front to back exactly once, every wave instruction reading 1 KiB of consecutive bytes
+// (64 / (R/2) columns at a time).  Offset of entry (r, c):
+__host__ __device__ inline int64_t patch_inv_index(int r, int c, int n, int ld) {
+  int row0 = r & ~127, rows = 128;
+  if (row0 + 128 > ld) {
+    const int rem = ld - row0;
+    int rr = r - row0;
+    for (int bit = 64; bit >= 2; bit >>= 1) {
+      if (rem & bit) {
+        if (rr < bit) {
+          rows = bit;
+          break;
+        }
+        rr -= bit;
+        row0 += bit;
+      }
+    }
+  }
+  return (int64_t)row0 * n + (int64_t)c * rows + (r - row0);
+}
+
 struct DevBSR {
   int64_t nbrows = 0, nbcols = 0, nnzb = 0;
   int bs = 0;

@@ -1,10 +1,12 @@
 // Patch smoother kernels for gfx950 (wave64): PCPATCH setup (gather + dense inversion) and additive apply.
 //
-// Storage of the inverses (owned layout, chosen for the apply kernel): patch p holds an n_p x n_p inverse in
-// column-major order with leading dimension ld_p = n_p rounded up to even, at inv + inv_ptr[p] (inv_ptr is a multiple
-// of 16 doubles), so that lane l of a wave reads rows (2l, 2l+1) of one column as one aligned 16-byte load and a wave
-// reads 1 KiB contiguous per instruction.  y_p = inv(A_p) x_p then needs no cross-lane reduction: each lane pair of
-// rows accumulates over the columns, x_p is broadcast from LDS.
+// Storage of the inverses (owned layout, chosen for the apply kernel; patch_inv_index in common.h): patch p holds an
+// n_p x n_p inverse at inv + inv_ptr[p] (a multiple of 16 doubles = 128 B) as row pieces of 128, 64, ..., 2 rows, each
+// piece stored [column][rows of the piece].  Lane l of a wave reads a row pair of one column as one aligned 16-byte load,
+// a wave instruction covers 1 KiB of consecutive bytes, and consecutive instructions continue where the previous one
+// stopped: every 128-B line of the inverse is fetched exactly once and fully used.  (Round 1 stored plain column-major
+// with ld = 154: the 26-row tail of each column was read in a second pass through lines shared with the next column,
+// FETCH_SIZE showed 1.19 x the algorithmic bytes -- profiles/pmc_patch_apply_cfg4.json.)
 //
 // Roofline: apply is a GEMV streaming every inverse once (0.25 flop/B) -> HBM-bound; algorithmic bytes per patch
 // 8 n_p^2 + 28 n_p.  Inversion is 2 n_p^3 flops per patch in FP64; gfx950's FP64 MFMA rate
@@ -68,7 +70,7 @@ __global__ __launch_bounds__(256) void patch_gather_dense_kernel(const int32_t* 
 //     a 16 x 16 grid of B x B tiles (thread (ti, tj) owns rows ti*B.., cols tj*B..); Gauss-Jordan without pivoting (the
 //     patch operators are principal sub-blocks of an SPD-dominated operator); per step the pivot row and column travel
 //     through double-buffered LDS (one barrier per step).  Reads row-major, writes column-major (transposed store), both
-//     with leading dimension ld.
+//     with leading dimension ld; the result is written in the row-piece layout of patch_inv_index.
 // ---------------------------------------------------------------------------------------------------------------------
 template <int B>
 __global__ __launch_bounds__(256) void patch_invert_big_kernel(const int64_t* __restrict__ patch_ptr,
@@ -141,15 +143,18 @@ __global__ __launch_bounds__(256) void patch_invert_big_kernel(const int64_t* __
 #pragma unroll
     for (int lj = 0; lj < B; ++lj) {
       const int r = r0 + li, c = c0 + lj;
-      if (r < n && c < n) S[(int64_t)c * ld + r] = a[li][lj];
+      // r == n < ld: the padding row; its entries stayed 0 through the elimination (identity padding) and must be stored,
+      // the apply kernel reads row pairs
+      if (r < ld && c < n) S[patch_inv_index(r, c, n, ld)] = a[li][lj];
     }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
 // 2b. in-place inversion, small matrices (n <= N <= 32): N lanes per matrix, lane i holds row i in registers, 64/N
-//     matrices per wave, pivot rows broadcast with shuffles.  Same storage convention as above.
+//     matrices per wave, pivot rows broadcast with shuffles.  Output: TILED = the patch layout (patch_inv_index),
+//     otherwise column-major with leading dimension ld (the Schoeberl interior blocks, kernels_vec.hip).
 // ---------------------------------------------------------------------------------------------------------------------
-template <int N>
+template <int N, bool TILED>
 __global__ __launch_bounds__(256) void invert_small_kernel(int64_t nmat, const int64_t* __restrict__ ptr,
                                                             const int64_t* __restrict__ inv_ptr, int fixed_n,
                                                             int64_t fixed_stride, double* __restrict__ inv,
@@ -193,41 +198,39 @@ __global__ __launch_bounds__(256) void invert_small_kernel(int64_t nmat, const i
     if (bad && i == 0) atomicExch(status, 1);
 #pragma unroll
     for (int j = 0; j < N; ++j)
-      if (i < n && j < n) S[(int64_t)j * ld + i] = a[j];
+      if (i < ld && j < n) S[TILED ? patch_inv_index(i, j, n, ld) : (int64_t)j * ld + i] = a[j];  // incl. zero pad row
   }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
 // 3. additive apply, stage 1: one wave per patch.  stage[patch_ptr[p] + r] = sum_c inv_p[r][c] * x[dofs_p[c]]
 // ---------------------------------------------------------------------------------------------------------------------
+// one row piece of 2G rows, stored [column][2G]: G lanes per column, 64/G columns per wave instruction
 template <int G>
-__device__ __forceinline__ void apply_tile(const double* __restrict__ Ainv, int ld, int n, int row0, int rows_tile,
-                                           const double* __restrict__ xs, int lane, double* __restrict__ out) {
-  constexpr int C = 64 / G;  // columns handled per wave-instruction
+__device__ __forceinline__ void apply_piece(const double* __restrict__ T, int n, const double* __restrict__ xs,
+                                            int lane, double* __restrict__ out) {
+  constexpr int C = 64 / G;  // columns handled per wave instruction
   constexpr int U = 8;       // loads kept in flight per lane
   const int cg = lane / G, l = lane % G;
-  const bool active = 2 * l < rows_tile;
-  const double* base = Ainv + row0 + 2 * l;
+  const double* base = T + 2 * l;
   double acc0 = 0.0, acc1 = 0.0;
   int j = cg;
-  if (active) {
-    for (; j + (U - 1) * C < n; j += U * C) {
-      double2 v[U];
+  for (; j + (U - 1) * C < n; j += U * C) {
+    double2 v[U];
 #pragma unroll
-      for (int u = 0; u < U; ++u) v[u] = *reinterpret_cast<const double2*>(base + (int64_t)(j + u * C) * ld);
+    for (int u = 0; u < U; ++u) v[u] = *reinterpret_cast<const double2*>(base + (int64_t)(j + u * C) * (2 * G));
 #pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const double xj = xs[j + u * C];
-        acc0 = __builtin_fma(v[u].x, xj, acc0);
-        acc1 = __builtin_fma(v[u].y, xj, acc1);
-      }
+    for (int u = 0; u < U; ++u) {
+      const double xj = xs[j + u * C];
+      acc0 = __builtin_fma(v[u].x, xj, acc0);
+      acc1 = __builtin_fma(v[u].y, xj, acc1);
     }
-    for (; j < n; j += C) {
-      const double2 v = *reinterpret_cast<const double2*>(base + (int64_t)j * ld);
-      const double xj = xs[j];
-      acc0 = __builtin_fma(v.x, xj, acc0);
-      acc1 = __builtin_fma(v.y, xj, acc1);
-    }
+  }
+  for (; j < n; j += C) {
+    const double2 v = *reinterpret_cast<const double2*>(base + (int64_t)j * (2 * G));
+    const double xj = xs[j];
+    acc0 = __builtin_fma(v.x, xj, acc0);
+    acc1 = __builtin_fma(v.y, xj, acc1);
   }
   if (C > 1) {
 #pragma unroll
@@ -237,7 +240,7 @@ __device__ __forceinline__ void apply_tile(const double* __restrict__ Ainv, int 
     }
   }
   // the padding row (n odd) of the inverse is zero, so storing both rows is always valid (stage has ld slots)
-  if (active && cg == 0) *reinterpret_cast<double2*>(out + row0 + 2 * l) = make_double2(acc0, acc1);
+  if (cg == 0) *reinterpret_cast<double2*>(out + 2 * l) = make_double2(acc0, acc1);
 }
 
 __global__ __launch_bounds__(256) void patch_apply_kernel(int64_t npatch, const int64_t* __restrict__ patch_ptr,
@@ -259,19 +262,23 @@ __global__ __launch_bounds__(256) void patch_apply_kernel(int64_t npatch, const 
   __syncthreads();
   if (p >= npatch) return;
   const int ld = (n + 1) & ~1;
-  const double* Ainv = inv + inv_ptr[p];
+  const double* T = inv + inv_ptr[p];
   double* out = stage + stage_ptr[p];
   int row0 = 0;
-  for (; row0 + 128 <= ld; row0 += 128) apply_tile<64>(Ainv, ld, n, row0, 128, xs, lane, out);
-  const int rem = ld - row0;  // even, < 128
-  if (rem > 64)
-    apply_tile<64>(Ainv, ld, n, row0, rem, xs, lane, out);
-  else if (rem > 32)
-    apply_tile<32>(Ainv, ld, n, row0, rem, xs, lane, out);
-  else if (rem > 16)
-    apply_tile<16>(Ainv, ld, n, row0, rem, xs, lane, out);
-  else if (rem > 0)
-    apply_tile<8>(Ainv, ld, n, row0, rem, xs, lane, out);
+  for (; row0 + 128 <= ld; row0 += 128) apply_piece<64>(T + (int64_t)row0 * n, n, xs, lane, out + row0);
+  const int rem = ld - row0;  // even, < 128: one piece per binary digit
+#define ALFI_PIECE(R)                                                        \
+  if (rem & R) {                                                             \
+    apply_piece<R / 2>(T + (int64_t)row0 * n, n, xs, lane, out + row0);      \
+    row0 += R;                                                               \
+  }
+  ALFI_PIECE(64)
+  ALFI_PIECE(32)
+  ALFI_PIECE(16)
+  ALFI_PIECE(8)
+  ALFI_PIECE(4)
+  ALFI_PIECE(2)
+#undef ALFI_PIECE
 }
 
 // stage 2: dof-wise sum of the staged patch results in a fixed order (deterministic; replaces PETSc's scatter-add)
@@ -309,8 +316,12 @@ static int launch_invert_small(alfi_ctx* ctx, int64_t nmat, const int64_t* ptr, 
                                int64_t fixed_stride, double* inv, int* status) {
   const int per_block = 256 / N;
   dim3 grid((unsigned)((nmat + per_block - 1) / per_block)), block(256);
-  hipLaunchKernelGGL(invert_small_kernel<N>, grid, block, 0, ctx->stream, nmat, ptr, inv_ptr, fixed_n, fixed_stride,
-                     inv, status);
+  if (ptr)   // patches: row-piece layout
+    hipLaunchKernelGGL((invert_small_kernel<N, true>), grid, block, 0, ctx->stream, nmat, ptr, inv_ptr, fixed_n,
+                       fixed_stride, inv, status);
+  else
+    hipLaunchKernelGGL((invert_small_kernel<N, false>), grid, block, 0, ctx->stream, nmat, ptr, inv_ptr, fixed_n,
+                       fixed_stride, inv, status);
   ALFI_HIP_CHECK(ctx, hipGetLastError());
   return 0;
 }
