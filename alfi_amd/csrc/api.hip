@@ -3,6 +3,7 @@
 // happens inside the smoother or the cycles: every scalar (norms, Hessenberg, Givens) stays on the device.
 #include <cmath>
 #include <cstdarg>
+#include <cstdlib>
 #include <cstring>
 #include <algorithm>
 #include "common.h"
@@ -65,15 +66,45 @@ static int upload_bsr(alfi_ctx* ctx, DevBSR* d, const alfi_bsr_host* h, int bs) 
   d->nbcols = h->nbcols;
   d->bs = bs;
   d->nnzb = h->rowptr[h->nbrows];
+  // lane-major layout + segmented SpMV needs every block row non-empty (the row of a block is found by counting row
+  // starts); ALFI_SPMV=legacy keeps the host layout and the row-per-lane-group kernel (A/B measurements)
+  bool flat = d->nnzb > 0;
+  for (int64_t i = 0; i < h->nbrows && flat; ++i) flat = h->rowptr[i + 1] > h->rowptr[i];
+  const char* env = getenv("ALFI_SPMV");
+  if (env && strcmp(env, "legacy") == 0) flat = false;
+  d->flat = flat ? 1 : 0;
   ALFI_CHECK(dev_upload(ctx, &d->rowptr, h->rowptr, h->nbrows + 1));
-  ALFI_CHECK(dev_upload(ctx, &d->colidx, h->colidx, d->nnzb));
-  ALFI_CHECK(dev_upload(ctx, &d->vals, h->vals, d->nnzb * bs * bs));
-  return 0;
+  if (!flat) {
+    ALFI_CHECK(dev_upload(ctx, &d->colidx, h->colidx, d->nnzb));
+    ALFI_CHECK(dev_alloc(ctx, &d->vals, d->nnzb * bs * bs));
+  } else {
+    std::vector<int32_t> cf(h->colidx, h->colidx + d->nnzb);
+    for (int64_t i = 0; i < h->nbrows; ++i) cf[h->rowptr[i]] |= (int32_t)0x80000000;
+    d->nchunks = (d->nnzb + SPMV_CHUNK - 1) / SPMV_CHUNK;
+    std::vector<int32_t> chunk_row(d->nchunks);
+    int64_t row = 0;
+    for (int64_t c = 0; c < d->nchunks; ++c) {
+      const int64_t k = c * SPMV_CHUNK;
+      while (h->rowptr[row + 1] <= k) ++row;
+      chunk_row[c] = (int32_t)row;
+    }
+    ALFI_CHECK(dev_upload(ctx, &d->colidx, cf.data(), d->nnzb));
+    ALFI_CHECK(dev_upload(ctx, &d->chunk_row, chunk_row.data(), d->nchunks));
+    ALFI_CHECK(dev_alloc(ctx, &d->carry, d->nchunks * bs));
+    ALFI_CHECK(dev_alloc(ctx, &d->carry_row, d->nchunks));
+    const int64_t padded = ((d->nnzb + 63) / 64) * 64 * bs * bs;
+    ALFI_CHECK(dev_alloc(ctx, &d->vals, padded));
+    ALFI_HIP_CHECK(ctx, hipMemset(d->vals, 0, sizeof(double) * padded));
+  }
+  return upload_bsr_values(ctx, d, h->vals);
 }
 static void free_bsr(DevBSR* d) {
   dev_free(d->rowptr);
   dev_free(d->colidx);
   dev_free(d->vals);
+  dev_free(d->chunk_row);
+  dev_free(d->carry);
+  dev_free(d->carry_row);
   *d = DevBSR();
 }
 
@@ -348,9 +379,9 @@ int alfi_level_destroy(alfi_level* L) {
 
 int alfi_level_update_values(alfi_level* L, const double* bvals) {
   alfi_ctx* ctx = L->ctx;
-  ALFI_HIP_CHECK(ctx, hipMemcpyAsync(L->A.vals, bvals, (size_t)L->A.nnzb * L->bs * L->bs * sizeof(double),
-                                     hipMemcpyHostToDevice, ctx->stream));
   ALFI_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  ALFI_CHECK(upload_bsr_values(ctx, &L->A, bvals));
+  L->A_own.vals = L->A.vals;
   L->factored = false;
   return 0;
 }

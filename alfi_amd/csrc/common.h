@@ -78,13 +78,29 @@ __host__ __device__ inline int64_t patch_inv_index(int r, int c, int n, int ld) 
   return (int64_t)row0 * n + (int64_t)c * rows + (r - row0);
 }
 
+// Block-CSR on the device.  Two value layouts:
+//   flat == 0: vals[k][bs*bs] (the host layout); one group of lanes per block row (bsr_spmv_kernel);
+//   flat == 1: "lane-major": blocks in groups of 64, vals[k / 64][bs*bs][k % 64], so that a wave handling 64 consecutive
+//              blocks reads each of the bs*bs value planes as one contiguous 512-B request; the sign bit of colidx[k]
+//              marks the first block of a block row; chunk_row[c] = block row of block c * SPMV_CHUNK.  Used by the
+//              nnz-balanced segmented SpMV (bsr_spmv_flat_kernel) whenever every block row is non-empty.
+constexpr int SPMV_U = 4;                 // wave iterations of 64 blocks
+constexpr int SPMV_CHUNK = 64 * SPMV_U;   // blocks per wave
 struct DevBSR {
   int64_t nbrows = 0, nbcols = 0, nnzb = 0;
   int bs = 0;
   int32_t* rowptr = nullptr;
   int32_t* colidx = nullptr;
   double* vals = nullptr;
+  int flat = 0;
+  int64_t nchunks = 0;
+  int32_t* chunk_row = nullptr;
+  double* carry = nullptr;      // (nchunks, bs): partial sums of block rows that continue into the next chunk
+  int32_t* carry_row = nullptr;  // (nchunks): that block row, or -1
 };
+__host__ __device__ inline int64_t bsr_val_index(int flat, int64_t k, int rc, int bb) {
+  return flat ? (k >> 6) * 64 * bb + (int64_t)rc * 64 + (k & 63) : k * bb + rc;
+}
 
 struct alfi_level {
   alfi_ctx* ctx = nullptr;
@@ -162,6 +178,8 @@ struct alfi_mg {
 // ---- kernel launch wrappers (defined in the .hip files) --------------------------------------------------------------
 // y = A x (mode 0) or y = b - alpha * A x (mode 1)
 int launch_bsr_spmv(alfi_ctx* ctx, const DevBSR& A, const double* x, double* y, const double* b, double alpha, int mode);
+// host (nnzb, bs, bs) values -> d->vals in d's layout (staged through a bounded device buffer)
+int upload_bsr_values(alfi_ctx* ctx, DevBSR* d, const double* host_vals);
 int launch_patch_gather_dense(alfi_level* lvl);
 int launch_patch_invert(alfi_level* lvl);
 int launch_patch_apply(alfi_level* lvl, const double* x, double* y);

@@ -25,7 +25,7 @@ __global__ __launch_bounds__(256) void patch_gather_dense_kernel(const int32_t* 
                                                                   const int64_t* __restrict__ patch_ptr,
                                                                   const int32_t* __restrict__ patch_dofs,
                                                                   const int64_t* __restrict__ inv_ptr,
-                                                                  double* __restrict__ inv) {
+                                                                  double* __restrict__ inv, int flat) {
   __shared__ int32_t dofs_s[MAX_NP];
   __shared__ double rowbuf[4][MAX_NP];
   const int64_t p = blockIdx.x;
@@ -49,14 +49,14 @@ __global__ __launch_bounds__(256) void patch_gather_dense_kernel(const int32_t* 
       const int nent = (hi - lo) * BS;
       for (int e = lane; e < nent; e += 64) {
         const int blk = e / BS, cc = e % BS;
-        const int gcol = colidx[lo + blk] * BS + cc;
+        const int gcol = (colidx[lo + blk] & 0x7fffffff) * BS + cc;  // sign bit = row-start mark (flat layout)
         // binary search gcol in dofs_s[0..n)
         int a = 0, b = n;
         while (a < b) {
           const int mid = (a + b) >> 1;
           if (dofs_s[mid] < gcol) a = mid + 1; else b = mid;
         }
-        if (a < n && dofs_s[a] == gcol) rowbuf[wave][a] = vals[(int64_t)(lo + blk) * BS * BS + rr * BS + cc];
+        if (a < n && dofs_s[a] == gcol) rowbuf[wave][a] = vals[bsr_val_index(flat, lo + blk, rr * BS + cc, BS * BS)];
       }
     }
     __syncthreads();
@@ -301,10 +301,10 @@ int launch_patch_gather_dense(alfi_level* L) {
   dim3 grid((unsigned)L->npatch), block(256);
   if (L->bs == 2)
     hipLaunchKernelGGL(patch_gather_dense_kernel<2>, grid, block, 0, ctx->stream, L->A.rowptr, L->A.colidx, L->A.vals,
-                       L->patch_ptr, L->patch_dofs, L->inv_ptr, L->inv);
+                       L->patch_ptr, L->patch_dofs, L->inv_ptr, L->inv, L->A.flat);
   else if (L->bs == 3)
     hipLaunchKernelGGL(patch_gather_dense_kernel<3>, grid, block, 0, ctx->stream, L->A.rowptr, L->A.colidx, L->A.vals,
-                       L->patch_ptr, L->patch_dofs, L->inv_ptr, L->inv);
+                       L->patch_ptr, L->patch_dofs, L->inv_ptr, L->inv, L->A.flat);
   else
     return alfi_set_error(ctx, ALFI_E_ARG, "unsupported block size %d", L->bs);
   ALFI_HIP_CHECK(ctx, hipGetLastError());

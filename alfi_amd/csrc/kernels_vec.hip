@@ -46,9 +46,181 @@ __global__ __launch_bounds__(256) void bsr_spmv_kernel(int64_t nbrows, const int
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// nnz-balanced BSR SpMV on the lane-major layout (DevBSR::flat): a wave takes SPMV_CHUNK consecutive blocks whatever rows
+// they belong to (block rows of the P2+FB operator hold 14 .. 125 blocks, so one-wave-per-row leaves most lanes idle), lane
+// l of iteration u owns block base + 64 u + l: one coalesced 256-B colidx request and bs*bs coalesced 512-B value requests
+// per 64 blocks, x gathered through L2.  Per-row sums by a segmented inclusive scan over the wave (row starts = sign bit
+// of colidx); a row running on into the next iteration travels in a wave-uniform carry, a row running on into the next
+// chunk leaves its partial sum in carry[chunk] and bsr_spmv_fixup_kernel adds it to the row in chunk order
+// (deterministic, no atomics).  The wave holding a row's LAST block stores y, everything earlier is a carry.
+// ---------------------------------------------------------------------------------------------------------------------
+template <int BS>
+__global__ __launch_bounds__(256) void bsr_spmv_flat_kernel(int64_t nnzb, int64_t nchunks,
+                                                             const int32_t* __restrict__ colflag,
+                                                             const double* __restrict__ vals,
+                                                             const int32_t* __restrict__ chunk_row,
+                                                             const double* __restrict__ x, double* __restrict__ y,
+                                                             const double* __restrict__ b, double alpha, int mode,
+                                                             double* __restrict__ carry_out,
+                                                             int32_t* __restrict__ carry_row) {
+  constexpr int BB = BS * BS;
+  const int lane = threadIdx.x & 63;
+  const int64_t chunk = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (chunk >= nchunks) return;
+  const int64_t base = chunk * SPMV_CHUNK;
+  int R = chunk_row[chunk];  // block row of lane 0's block
+  int Rlast = R;
+  double carry[BS];
+#pragma unroll
+  for (int r = 0; r < BS; ++r) carry[r] = 0.0;
+  auto store_row = [&](int row, const double* s) {
+#pragma unroll
+    for (int r = 0; r < BS; ++r) {
+      const int64_t i = (int64_t)row * BS + r;
+      y[i] = mode == 0 ? s[r] : b[i] - alpha * s[r];
+    }
+  };
+#pragma unroll
+  for (int u = 0; u < SPMV_U; ++u) {
+    const int64_t k = base + u * 64 + lane;
+    const bool valid = k < nnzb;
+    const int32_t cf = valid ? colflag[k] : 0;
+    const bool head = cf < 0;
+    const int64_t col = cf & 0x7fffffff;
+    double p[BS];
+#pragma unroll
+    for (int r = 0; r < BS; ++r) p[r] = 0.0;
+    if (valid) {
+      const double* v = vals + (k >> 6) * (64 * BB) + lane;
+      double a[BB], xv[BS];
+#pragma unroll
+      for (int e = 0; e < BB; ++e) a[e] = v[e * 64];
+#pragma unroll
+      for (int c = 0; c < BS; ++c) xv[c] = x[col * BS + c];
+#pragma unroll
+      for (int r = 0; r < BS; ++r)
+#pragma unroll
+        for (int c = 0; c < BS; ++c) p[r] = __builtin_fma(a[r * BS + c], xv[c], p[r]);
+    }
+    const unsigned long long hm = __ballot(head);
+    if (u > 0) {
+      // lane 0 starts a new row: the row carried over from the previous iteration is complete
+      if ((hm & 1ull) && lane == 0) store_row(Rlast, carry);
+      R = Rlast + (int)(hm & 1ull);
+    }
+    const int row = R + __popcll(hm & ((2ull << lane) - 2ull));  // row starts at lanes 1 .. lane
+    // segmented inclusive scan; f = a row start lies at or before this lane (in this iteration)
+    int f = head ? 1 : 0;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      double tp[BS];
+#pragma unroll
+      for (int r = 0; r < BS; ++r) tp[r] = __shfl_up(p[r], d);
+      const int tf = __shfl_up(f, d);
+      if (lane >= d && !f) {
+#pragma unroll
+        for (int r = 0; r < BS; ++r) p[r] += tp[r];
+        f = tf;
+      }
+    }
+    if (!f) {
+#pragma unroll
+      for (int r = 0; r < BS; ++r) p[r] += carry[r];
+    }
+    // rows ending inside this iteration (the next lane starts a new one); lane 63's row is carried on
+    if (lane < 63 && ((hm >> (lane + 1)) & 1ull)) store_row(row, p);
+#pragma unroll
+    for (int r = 0; r < BS; ++r) carry[r] = __shfl(p[r], 63);
+    Rlast = __shfl(row, 63);
+  }
+  const int64_t kend = base + SPMV_CHUNK;
+  if (lane == 0) {
+    const bool closed = kend >= nnzb || colflag[kend] < 0;
+    if (closed) {
+      store_row(Rlast, carry);
+      carry_row[chunk] = -1;
+    } else {
+#pragma unroll
+      for (int r = 0; r < BS; ++r) carry_out[chunk * BS + r] = carry[r];
+      carry_row[chunk] = Rlast;
+    }
+  }
+}
+
+template <int BS>
+__global__ __launch_bounds__(256) void bsr_spmv_fixup_kernel(int64_t nchunks, const double* __restrict__ carry,
+                                                              const int32_t* __restrict__ carry_row,
+                                                              double* __restrict__ y, double alpha, int mode) {
+  const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (c >= nchunks) return;
+  const int32_t R = carry_row[c];
+  if (R < 0 || (c > 0 && carry_row[c - 1] == R)) return;  // only the first chunk of a run adds, in chunk order
+  double s[BS];
+#pragma unroll
+  for (int r = 0; r < BS; ++r) s[r] = 0.0;
+  for (int64_t cc = c; cc < nchunks && carry_row[cc] == R; ++cc)
+#pragma unroll
+    for (int r = 0; r < BS; ++r) s[r] += carry[cc * BS + r];
+#pragma unroll
+  for (int r = 0; r < BS; ++r) y[(int64_t)R * BS + r] += mode == 0 ? s[r] : -alpha * s[r];
+}
+
+// host-layout values of blocks [k0, k0 + nblk) -> lane-major
+__global__ void bsr_vals_to_lanes_kernel(const double* __restrict__ src, double* __restrict__ dst, int64_t k0,
+                                         int64_t total, int bb) {
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t k = k0 + e / bb;
+    const int rc = (int)(e % bb);
+    dst[bsr_val_index(1, k, rc, bb)] = src[e];
+  }
+}
+
+int upload_bsr_values(alfi_ctx* ctx, DevBSR* d, const double* host_vals) {
+  const int bb = d->bs * d->bs;
+  if (d->nnzb == 0) return 0;
+  if (!d->flat) {
+    ALFI_HIP_CHECK(ctx, hipMemcpy(d->vals, host_vals, (size_t)d->nnzb * bb * sizeof(double), hipMemcpyHostToDevice));
+    return 0;
+  }
+  const int64_t slab = (int64_t)1 << 22;  // blocks per staging slab (<= 302 MB at bs = 3)
+  const int64_t nslab = d->nnzb < slab ? d->nnzb : slab;
+  double* stage = nullptr;
+  ALFI_HIP_CHECK(ctx, hipMalloc((void**)&stage, (size_t)nslab * bb * sizeof(double)));
+  for (int64_t k0 = 0; k0 < d->nnzb; k0 += slab) {
+    const int64_t nb = d->nnzb - k0 < slab ? d->nnzb - k0 : slab;
+    hipError_t e = hipMemcpyAsync(stage, host_vals + k0 * bb, (size_t)nb * bb * sizeof(double), hipMemcpyHostToDevice,
+                                  ctx->stream);
+    if (e == hipSuccess) {
+      int64_t blocks = (nb * bb + 255) / 256;
+      if (blocks > 65536) blocks = 65536;
+      hipLaunchKernelGGL(bsr_vals_to_lanes_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, stage, d->vals, k0,
+                         nb * bb, bb);
+      e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) {
+      (void)hipFree(stage);
+      return alfi_set_error(ctx, ALFI_E_HIP, "value upload failed: %s", hipGetErrorString(e));
+    }
+  }
+  ALFI_HIP_CHECK(ctx, hipFree(stage));
+  return 0;
+}
+
 template <int BS>
 static int launch_bsr_spmv_bs(alfi_ctx* ctx, const DevBSR& A, const double* x, double* y, const double* b, double alpha,
                               int mode) {
+  if (A.flat) {
+    const int64_t nchunks = (A.nnzb + SPMV_CHUNK - 1) / SPMV_CHUNK;   // A may be a row-prefix view of the upload
+    hipLaunchKernelGGL((bsr_spmv_flat_kernel<BS>), dim3((unsigned)((nchunks + 3) / 4)), dim3(256), 0, ctx->stream,
+                       A.nnzb, nchunks, A.colidx, A.vals, A.chunk_row, x, y, b, alpha, mode, A.carry, A.carry_row);
+    ALFI_HIP_CHECK(ctx, hipGetLastError());
+    hipLaunchKernelGGL((bsr_spmv_fixup_kernel<BS>), dim3((unsigned)((nchunks + 255) / 256)), dim3(256), 0, ctx->stream,
+                       nchunks, A.carry, A.carry_row, y, alpha, mode);
+    ALFI_HIP_CHECK(ctx, hipGetLastError());
+    return 0;
+  }
   const double avg = A.nbrows > 0 ? (double)A.nnzb / (double)A.nbrows : 0.0;
   int lpr = 4;
   while (lpr < 64 && lpr < avg) lpr <<= 1;
@@ -73,7 +245,14 @@ static int launch_bsr_spmv_bs(alfi_ctx* ctx, const DevBSR& A, const double* x, d
 
 int launch_bsr_spmv(alfi_ctx* ctx, const DevBSR& A, const double* x, double* y, const double* b, double alpha,
                     int mode) {
-  if (A.nbrows == 0) return 0;
+  if (A.nbrows == 0 || A.nnzb == 0) {
+    // no entries: y = 0 or y = b on the rows of A
+    if (A.nbrows > 0) {
+      if (mode == 0) ALFI_HIP_CHECK(ctx, hipMemsetAsync(y, 0, sizeof(double) * A.nbrows * A.bs, ctx->stream));
+      else ALFI_HIP_CHECK(ctx, hipMemcpyAsync(y, b, sizeof(double) * A.nbrows * A.bs, hipMemcpyDeviceToDevice, ctx->stream));
+    }
+    return 0;
+  }
   if (A.bs == 2) return launch_bsr_spmv_bs<2>(ctx, A, x, y, b, alpha, mode);
   if (A.bs == 3) return launch_bsr_spmv_bs<3>(ctx, A, x, y, b, alpha, mode);
   return alfi_set_error(ctx, ALFI_E_ARG, "unsupported block size %d", A.bs);

@@ -189,3 +189,36 @@ def test_bad_arguments_are_reported(ctx, setup):
     with pytest.raises(hip.AlfiHipError):
         dl.set_patches(np.array([0, 161]), np.arange(161))            # too large
     dl.close()
+
+
+@pytest.mark.parametrize("bs", [2, 3])
+def test_spmv_segmented_kernel_on_ragged_rows(ctx, bs):
+    """The nnz-balanced SpMV (csrc/kernels_vec.hip: bsr_spmv_flat_kernel) on block rows of very different lengths: rows
+    shorter than a wave, rows spanning several 64-block iterations and rows spanning several 256-block chunks (carry +
+    fix-up path), for y = A x and r = b - A x."""
+    import scipy.sparse as sp
+    from alfi_amd import hip
+    from alfi_amd.problem import BSR
+    rng = np.random.default_rng(5)
+    nb = 1500
+    rows, cols = [], []
+    for i in range(nb):
+        cnt = 900 if i % 97 == 0 else (260 if i % 31 == 0 else int(rng.integers(1, 70)))
+        c = np.unique(np.concatenate([[i], rng.integers(0, nb, cnt)]))
+        rows.append(np.full(c.shape[0], i))
+        cols.append(c)
+    rows, cols = np.concatenate(rows), np.concatenate(cols)
+    blocks = rng.standard_normal((rows.shape[0], bs, bs))
+    order = np.lexsort((cols, rows))
+    rowptr = np.concatenate([[0], np.cumsum(np.bincount(rows, minlength=nb))])
+    A = BSR(nb, nb, bs, rowptr, cols[order], blocks[order])
+    S = A.to_scipy().tocsr()
+    lvl = hip.Level(ctx, A, np.zeros(0, dtype=np.int32))
+    x, b = rng.standard_normal(nb * bs), rng.standard_normal(nb * bs)
+    dx, db, dy = ctx.vec(x), ctx.vec(b), ctx.vec(nb * bs)
+    lvl.spmv(dx, dy)
+    ref = S @ x
+    assert np.abs(dy.get() - ref).max() / np.abs(ref).max() < 1e-13
+    lvl.residual(db, dx, dy)
+    assert np.abs(dy.get() - (b - ref)).max() / np.abs(ref).max() < 1e-13
+    lvl.close()
