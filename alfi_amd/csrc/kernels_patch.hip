@@ -11,6 +11,7 @@
 // Roofline: apply is a GEMV streaming every inverse once (0.25 flop/B) -> HBM-bound; algorithmic bytes per patch
 // 8 n_p^2 + 28 n_p.  Inversion is 2 n_p^3 flops per patch in FP64; gfx950's FP64 MFMA rate
 // equals its FP64 vector rate (78.6 TF), so the inversion runs as a register-tiled Gauss-Jordan on the vector ALUs.
+#include <cstdlib>
 #include "common.h"
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -206,7 +207,15 @@ __global__ __launch_bounds__(256) void invert_small_kernel(int64_t nmat, const i
 // 3. additive apply, stage 1: one wave per patch.  stage[patch_ptr[p] + r] = sum_c inv_p[r][c] * x[dofs_p[c]]
 // ---------------------------------------------------------------------------------------------------------------------
 // one row piece of 2G rows, stored [column][2G]: G lanes per column, 64/G columns per wave instruction
-template <int G>
+typedef double alfi_d2 __attribute__((ext_vector_type(2)));
+template <bool NT>
+__device__ __forceinline__ double2 load_pair(const double* p) {   // one aligned 16-byte load
+  const alfi_d2* q = reinterpret_cast<const alfi_d2*>(p);
+  const alfi_d2 v = NT ? __builtin_nontemporal_load(q) : *q;
+  return make_double2(v.x, v.y);
+}
+
+template <int G, bool NT>
 __device__ __forceinline__ void apply_piece(const double* __restrict__ T, int n, const double* __restrict__ xs,
                                             int lane, double* __restrict__ out) {
   constexpr int C = 64 / G;  // columns handled per wave instruction
@@ -218,7 +227,7 @@ __device__ __forceinline__ void apply_piece(const double* __restrict__ T, int n,
   for (; j + (U - 1) * C < n; j += U * C) {
     double2 v[U];
 #pragma unroll
-    for (int u = 0; u < U; ++u) v[u] = *reinterpret_cast<const double2*>(base + (int64_t)(j + u * C) * (2 * G));
+    for (int u = 0; u < U; ++u) v[u] = load_pair<NT>(base + (int64_t)(j + u * C) * (2 * G));
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const double xj = xs[j + u * C];
@@ -227,7 +236,7 @@ __device__ __forceinline__ void apply_piece(const double* __restrict__ T, int n,
     }
   }
   for (; j < n; j += C) {
-    const double2 v = *reinterpret_cast<const double2*>(base + (int64_t)j * (2 * G));
+    const double2 v = load_pair<NT>(base + (int64_t)j * (2 * G));
     const double xj = xs[j];
     acc0 = __builtin_fma(v.x, xj, acc0);
     acc1 = __builtin_fma(v.y, xj, acc1);
@@ -243,6 +252,7 @@ __device__ __forceinline__ void apply_piece(const double* __restrict__ T, int n,
   if (cg == 0) *reinterpret_cast<double2*>(out + 2 * l) = make_double2(acc0, acc1);
 }
 
+template <bool NT>
 __global__ __launch_bounds__(256) void patch_apply_kernel(int64_t npatch, const int64_t* __restrict__ patch_ptr,
                                                            const int32_t* __restrict__ patch_dofs,
                                                            const int64_t* __restrict__ inv_ptr,
@@ -265,11 +275,11 @@ __global__ __launch_bounds__(256) void patch_apply_kernel(int64_t npatch, const 
   const double* T = inv + inv_ptr[p];
   double* out = stage + stage_ptr[p];
   int row0 = 0;
-  for (; row0 + 128 <= ld; row0 += 128) apply_piece<64>(T + (int64_t)row0 * n, n, xs, lane, out + row0);
+  for (; row0 + 128 <= ld; row0 += 128) apply_piece<64, NT>(T + (int64_t)row0 * n, n, xs, lane, out + row0);
   const int rem = ld - row0;  // even, < 128: one piece per binary digit
 #define ALFI_PIECE(R)                                                        \
   if (rem & R) {                                                             \
-    apply_piece<R / 2>(T + (int64_t)row0 * n, n, xs, lane, out + row0);      \
+    apply_piece<R / 2, NT>(T + (int64_t)row0 * n, n, xs, lane, out + row0);  \
     row0 += R;                                                               \
   }
   ALFI_PIECE(64)
@@ -358,8 +368,14 @@ int launch_patch_apply(alfi_level* L, const double* x, double* y) {
   if (L->npatch > 0) {
     int t = alfi_prof_begin(ctx, ALFI_EV_PATCH_APPLY);
     dim3 grid((unsigned)((L->npatch + 3) / 4)), block(256);
-    hipLaunchKernelGGL(patch_apply_kernel, grid, block, 0, ctx->stream, L->npatch, L->patch_ptr, L->patch_dofs,
-                       L->inv_ptr, L->stage_ptr, L->inv, x, L->stage);
+    // the inverses are read once per apply: nontemporal loads keep x, the staging buffer and the index arrays in cache
+    static const bool nt = !(getenv("ALFI_NT") && atoi(getenv("ALFI_NT")) == 0);
+    if (nt)
+      hipLaunchKernelGGL(patch_apply_kernel<true>, grid, block, 0, ctx->stream, L->npatch, L->patch_ptr, L->patch_dofs,
+                         L->inv_ptr, L->stage_ptr, L->inv, x, L->stage);
+    else
+      hipLaunchKernelGGL(patch_apply_kernel<false>, grid, block, 0, ctx->stream, L->npatch, L->patch_ptr, L->patch_dofs,
+                         L->inv_ptr, L->stage_ptr, L->inv, x, L->stage);
     ALFI_HIP_CHECK(ctx, hipGetLastError());
     alfi_prof_end(ctx, t);
   }

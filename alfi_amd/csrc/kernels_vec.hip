@@ -1,5 +1,6 @@
 // Level SpMV / residual (PETSc MatMult on BAIJ), FGMRES vector kernels, small dense block kernels of the Schoeberl
 // transfer and the dense coarse GEMV.  All HBM-bound; wave64, FP64.
+#include <cstdlib>
 #include "common.h"
 #include "hs_layout.h"
 
@@ -55,7 +56,7 @@ __global__ __launch_bounds__(256) void bsr_spmv_kernel(int64_t nbrows, const int
 // chunk leaves its partial sum in carry[chunk] and bsr_spmv_fixup_kernel adds it to the row in chunk order
 // (deterministic, no atomics).  The wave holding a row's LAST block stores y, everything earlier is a carry.
 // ---------------------------------------------------------------------------------------------------------------------
-template <int BS>
+template <int BS, bool NT>
 __global__ __launch_bounds__(256) void bsr_spmv_flat_kernel(int64_t nnzb, int64_t nchunks,
                                                              const int32_t* __restrict__ colflag,
                                                              const double* __restrict__ vals,
@@ -85,7 +86,7 @@ __global__ __launch_bounds__(256) void bsr_spmv_flat_kernel(int64_t nnzb, int64_
   for (int u = 0; u < SPMV_U; ++u) {
     const int64_t k = base + u * 64 + lane;
     const bool valid = k < nnzb;
-    const int32_t cf = valid ? colflag[k] : 0;
+    const int32_t cf = valid ? (NT ? __builtin_nontemporal_load(colflag + k) : colflag[k]) : 0;
     const bool head = cf < 0;
     const int64_t col = cf & 0x7fffffff;
     double p[BS];
@@ -95,7 +96,7 @@ __global__ __launch_bounds__(256) void bsr_spmv_flat_kernel(int64_t nnzb, int64_
       const double* v = vals + (k >> 6) * (64 * BB) + lane;
       double a[BB], xv[BS];
 #pragma unroll
-      for (int e = 0; e < BB; ++e) a[e] = v[e * 64];
+      for (int e = 0; e < BB; ++e) a[e] = NT ? __builtin_nontemporal_load(v + e * 64) : v[e * 64];
 #pragma unroll
       for (int c = 0; c < BS; ++c) xv[c] = x[col * BS + c];
 #pragma unroll
@@ -213,8 +214,17 @@ static int launch_bsr_spmv_bs(alfi_ctx* ctx, const DevBSR& A, const double* x, d
                               int mode) {
   if (A.flat) {
     const int64_t nchunks = (A.nnzb + SPMV_CHUNK - 1) / SPMV_CHUNK;   // A may be a row-prefix view of the upload
-    hipLaunchKernelGGL((bsr_spmv_flat_kernel<BS>), dim3((unsigned)((nchunks + 3) / 4)), dim3(256), 0, ctx->stream,
-                       A.nnzb, nchunks, A.colidx, A.vals, A.chunk_row, x, y, b, alpha, mode, A.carry, A.carry_row);
+    // operator values and indices are used once per product: stream them past the caches (nontemporal) so that x and y
+    // keep the L2 / Infinity Cache.  ALFI_NT=0 switches to plain loads (A/B measurements).
+    static const bool nt = !(getenv("ALFI_NT") && atoi(getenv("ALFI_NT")) == 0);
+    if (nt)
+      hipLaunchKernelGGL((bsr_spmv_flat_kernel<BS, true>), dim3((unsigned)((nchunks + 3) / 4)), dim3(256), 0,
+                         ctx->stream, A.nnzb, nchunks, A.colidx, A.vals, A.chunk_row, x, y, b, alpha, mode, A.carry,
+                         A.carry_row);
+    else
+      hipLaunchKernelGGL((bsr_spmv_flat_kernel<BS, false>), dim3((unsigned)((nchunks + 3) / 4)), dim3(256), 0,
+                         ctx->stream, A.nnzb, nchunks, A.colidx, A.vals, A.chunk_row, x, y, b, alpha, mode, A.carry,
+                         A.carry_row);
     ALFI_HIP_CHECK(ctx, hipGetLastError());
     hipLaunchKernelGGL((bsr_spmv_fixup_kernel<BS>), dim3((unsigned)((nchunks + 255) / 256)), dim3(256), 0, ctx->stream,
                        nchunks, A.carry, A.carry_row, y, alpha, mode);
