@@ -45,6 +45,8 @@ SIGNATURES = {
     "alfi_residual": (ctypes.c_int, [vp, vp, vp, vp]),
     "alfi_patches_set": (ctypes.c_int, [vp, ctypes.c_int64, vp, vp]),
     "alfi_patches_factor": (ctypes.c_int, [vp]),
+    "alfi_patches_set_multiplicative": (ctypes.c_int, [vp, ctypes.c_int64, vp, ctypes.c_int]),
+    "alfi_patches_multiplicative_levels": (ctypes.c_int, [vp, ctypes.POINTER(ctypes.c_int64)]),
     "alfi_patch_apply": (ctypes.c_int, [vp, vp, vp]),
     "alfi_patches_stats": (ctypes.c_int, [vp, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64),
                                           ctypes.POINTER(ctypes.c_int64)]),

@@ -94,7 +94,9 @@ static int upload_bsr(alfi_ctx* ctx, DevBSR* d, const alfi_bsr_host* h, int bs) 
     ALFI_CHECK(dev_alloc(ctx, &d->carry_row, d->nchunks));
     const int64_t padded = ((d->nnzb + 63) / 64) * 64 * bs * bs;
     ALFI_CHECK(dev_alloc(ctx, &d->vals, padded));
-    ALFI_HIP_CHECK(ctx, hipMemset(d->vals, 0, sizeof(double) * padded));
+    // on the ctx stream: a memset on the null stream is asynchronous and NOT ordered against this (non-blocking) stream,
+    // it could land after the value upload below
+    ALFI_HIP_CHECK(ctx, hipMemsetAsync(d->vals, 0, sizeof(double) * padded, ctx->stream));
   }
   return upload_bsr_values(ctx, d, h->vals);
 }
@@ -284,7 +286,7 @@ int alfi_level_create(alfi_ctx* ctx, int64_t nbrows, int bs, const int32_t* brow
   int rc = upload_bsr(ctx, &L->A, &h, bs);
   if (rc == 0) rc = dev_upload(ctx, &L->bc_dofs, bc_dofs, nbc);
   if (rc == 0) rc = dev_alloc(ctx, &L->status, 1);
-  if (rc == 0 && hipMemset(L->status, 0, sizeof(int)) != hipSuccess) rc = ALFI_E_HIP;
+  if (rc == 0 && hipMemsetAsync(L->status, 0, sizeof(int), ctx->stream) != hipSuccess) rc = ALFI_E_HIP;
   L->nbc = nbc;
   if (rc != 0) {
     alfi_level_destroy(L);
@@ -364,6 +366,7 @@ int alfi_level_destroy(alfi_level* L) {
   dev_free(L->stage);
   dev_free(L->dof_ptr);
   dev_free(L->dof_pos);
+  dev_free(L->mult_seq);
   dev_free(L->status);
   dev_free(L->V);
   dev_free(L->Z);
@@ -419,6 +422,27 @@ int alfi_residual(alfi_level* L, const double* db, const double* dx, double* dr)
 // their owners, Dirichlet dofs copied
 static int level_patch_apply(alfi_level* L, const double* dx, double* dy) {
   alfi_ctx* ctx = L->ctx;
+  if (L->mult) {
+    // multiplicative sweep (PCApply_PATCH, local_type multiplicative [3P]): y = 0, then wavefront by wavefront in
+    // iteration order and, with symmetrise_sweep, back again in reverse order
+    ALFI_HIP_CHECK(ctx, hipMemsetAsync(dy, 0, sizeof(double) * L->n, ctx->stream));
+    int t = alfi_prof_begin(ctx, ALFI_EV_PATCH_APPLY);
+    const int64_t nw = (int64_t)L->mult_wave_ptr.size() - 1;
+    for (int64_t w = 0; w < nw; ++w)
+      ALFI_CHECK(launch_patch_mult_wave(L, L->mult_seq + L->mult_wave_ptr[w], L->mult_wave_ptr[w + 1] - L->mult_wave_ptr[w],
+                                        dx, dy));
+    if (L->mult_symmetrise)
+      for (int64_t w = nw - 1; w >= 0; --w)
+        ALFI_CHECK(launch_patch_mult_wave(L, L->mult_seq + L->mult_wave_ptr[w],
+                                          L->mult_wave_ptr[w + 1] - L->mult_wave_ptr[w], dx, dy));
+    alfi_prof_end(ctx, t);
+    if (L->nbc > 0) {
+      t = alfi_prof_begin(ctx, ALFI_EV_PATCH_SCATTER);
+      ALFI_CHECK(launch_copy_dofs(ctx, dy, dx, L->bc_dofs, L->nbc));
+      alfi_prof_end(ctx, t);
+    }
+    return 0;
+  }
   if (L->distributed) ALFI_CHECK(halo_fwd(L, const_cast<double*>(dx)));
   ALFI_CHECK(launch_patch_apply(L, dx, dy));
   if (L->distributed) ALFI_CHECK(halo_rev(L, dy));
@@ -498,9 +522,86 @@ int alfi_patches_set(alfi_level* L, int64_t npatch, const int64_t* pptr, const i
   ALFI_CHECK(dev_upload(ctx, &L->dof_pos, dof_pos.data(), sum_n));
   ALFI_CHECK(dev_alloc(ctx, &L->inv, ip));
   ALFI_CHECK(dev_alloc(ctx, &L->stage, sp));
-  ALFI_HIP_CHECK(ctx, hipMemset(L->stage, 0, (size_t)std::max<int64_t>(sp, 1) * sizeof(double)));
+  ALFI_HIP_CHECK(ctx, hipMemsetAsync(L->stage, 0, (size_t)std::max<int64_t>(sp, 1) * sizeof(double), ctx->stream));
   L->h_patch_ptr.assign(pptr, pptr + npatch + 1);
+  L->h_patch_dofs.assign(pdofs, pdofs + sum_n);
   L->h_inv_ptr = inv_ptr;
+  dev_free(L->mult_seq);
+  L->mult_seq = nullptr;
+  L->mult = false;
+  L->mult_wave_ptr.clear();
+  return 0;
+}
+
+int alfi_patches_set_multiplicative(alfi_level* L, int64_t nit, const int64_t* iterset, int symmetrise) {
+  alfi_ctx* ctx = L->ctx;
+  if (!L->patch_ptr) return alfi_set_error(ctx, ALFI_E_STATE, "alfi_patches_set_multiplicative before alfi_patches_set");
+  ALFI_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  ALFI_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  dev_free(L->mult_seq);
+  L->mult_seq = nullptr;
+  L->mult = false;
+  L->mult_wave_ptr.clear();
+  if (nit == 0) return 0;
+  if (nit < 0 || !iterset) return alfi_set_error(ctx, ALFI_E_ARG, "bad iteration set");
+  if (L->has_halo && L->distributed)
+    return alfi_set_error(ctx, ALFI_E_ARG, "multiplicative sweeps are not available on partitioned levels");
+  if (nit > INT32_MAX) return alfi_set_error(ctx, ALFI_E_ARG, "iteration set too long");
+  const int bs = L->bs;
+  // patches must be unions of whole nodes (the sweep works on block rows)
+  for (int64_t p = 0; p < L->npatch; ++p) {
+    const int64_t a = L->h_patch_ptr[p], b = L->h_patch_ptr[p + 1];
+    if ((b - a) % bs != 0 || (b - a) / bs > 64)
+      return alfi_set_error(ctx, ALFI_E_ARG, "patch %lld: multiplicative sweeps need whole nodes, at most 64 per patch",
+                            (long long)p);
+    for (int64_t q = a; q < b; ++q)
+      if (L->h_patch_dofs[q] != (L->h_patch_dofs[a + ((q - a) / bs) * bs] / bs) * bs + (int32_t)((q - a) % bs))
+        return alfi_set_error(ctx, ALFI_E_ARG, "patch %lld does not consist of whole nodes", (long long)p);
+  }
+  for (int64_t t = 0; t < nit; ++t)
+    if (iterset[t] < 0 || iterset[t] >= L->npatch) return alfi_set_error(ctx, ALFI_E_ARG, "iteration set entry out of range");
+  // sparsity of the operator on the host (row starts are marked in the sign bit of the flat layout)
+  const int64_t nb = L->A.nbrows, nnzb = L->A.nnzb;
+  std::vector<int32_t> rowptr(nb + 1), colidx(nnzb > 0 ? nnzb : 1);
+  ALFI_HIP_CHECK(ctx, hipMemcpy(rowptr.data(), L->A.rowptr, sizeof(int32_t) * (nb + 1), hipMemcpyDeviceToHost));
+  if (nnzb > 0) ALFI_HIP_CHECK(ctx, hipMemcpy(colidx.data(), L->A.colidx, sizeof(int32_t) * nnzb, hipMemcpyDeviceToHost));
+  // wavefront of position t = 1 + max wavefront of earlier positions whose patch holds a node in the closure of patch t
+  // (closure = columns of the patch's block rows).  node_wave[c] = last wavefront that wrote node c.
+  std::vector<int32_t> node_wave(nb, -1), wave_of(nit);
+  int32_t nwave = 0;
+  for (int64_t t = 0; t < nit; ++t) {
+    const int64_t p = iterset[t];
+    const int64_t a = L->h_patch_ptr[p], b = L->h_patch_ptr[p + 1];
+    int32_t w = -1;
+    for (int64_t q = a; q < b; q += bs) {
+      const int32_t node = L->h_patch_dofs[q] / bs;
+      for (int32_t k = rowptr[node]; k < rowptr[node + 1]; ++k) {
+        const int32_t c = colidx[k] & 0x7fffffff;
+        if (node_wave[c] > w) w = node_wave[c];
+      }
+    }
+    ++w;
+    wave_of[t] = w;
+    if (w + 1 > nwave) nwave = w + 1;
+    for (int64_t q = a; q < b; q += bs) node_wave[L->h_patch_dofs[q] / bs] = w;
+  }
+  // counting sort of the positions by wavefront (stable)
+  L->mult_wave_ptr.assign(nwave + 1, 0);
+  for (int64_t t = 0; t < nit; ++t) L->mult_wave_ptr[wave_of[t] + 1]++;
+  for (int32_t w = 0; w < nwave; ++w) L->mult_wave_ptr[w + 1] += L->mult_wave_ptr[w];
+  std::vector<int32_t> seq(nit);
+  {
+    std::vector<int64_t> fill(L->mult_wave_ptr.begin(), L->mult_wave_ptr.end() - 1);
+    for (int64_t t = 0; t < nit; ++t) seq[fill[wave_of[t]]++] = (int32_t)iterset[t];
+  }
+  ALFI_CHECK(dev_upload(ctx, &L->mult_seq, seq.data(), nit));
+  L->mult = true;
+  L->mult_symmetrise = symmetrise != 0;
+  return 0;
+}
+
+int alfi_patches_multiplicative_levels(alfi_level* L, int64_t* nwave) {
+  *nwave = L->mult ? (int64_t)L->mult_wave_ptr.size() - 1 : 0;
   return 0;
 }
 
@@ -566,7 +667,7 @@ static int ensure_fgmres_workspace(alfi_level* L, int k) {
   ALFI_CHECK(dev_alloc(ctx, &L->w, L->n));
   HsLayout hl(k);
   ALFI_CHECK(dev_alloc(ctx, &L->hs, hl.total));
-  ALFI_HIP_CHECK(ctx, hipMemset(L->hs, 0, sizeof(double) * hl.total));
+  ALFI_HIP_CHECK(ctx, hipMemsetAsync(L->hs, 0, sizeof(double) * hl.total, ctx->stream));
   L->kmax = k;
   return 0;
 }

@@ -134,6 +134,11 @@ struct alfi_level {
   int32_t* dof_pos = nullptr;     // (sum_n)
   bool factored = false;
   int* status = nullptr;          // device flag: nonzero if a zero pivot was met
+  // multiplicative sweeps: positions of the iteration sequence grouped into dependency wavefronts
+  bool mult = false, mult_symmetrise = false;
+  int32_t* mult_seq = nullptr;          // (nit) patch ids, wavefront-major
+  std::vector<int64_t> mult_wave_ptr;   // (nwave+1) offsets into mult_seq
+  std::vector<int32_t> h_patch_dofs;    // host copy of the patch dofs (needed to build the wavefronts)
   // FGMRES workspace
   int kmax = 0;
   double* V = nullptr;   // (kmax+1) x n
@@ -183,6 +188,8 @@ int upload_bsr_values(alfi_ctx* ctx, DevBSR* d, const double* host_vals);
 int launch_patch_gather_dense(alfi_level* lvl);
 int launch_patch_invert(alfi_level* lvl);
 int launch_patch_apply(alfi_level* lvl, const double* x, double* y);
+// one dependency wavefront of a multiplicative sweep: patches seq[0..count): y_p += inv(A_p) (x - A y)_p
+int launch_patch_mult_wave(alfi_level* lvl, const int32_t* seq, int64_t count, const double* x, double* y);
 int launch_invert_small_any(alfi_ctx* ctx, int nmax, int64_t nmat, const int64_t* ptr, const int64_t* inv_ptr,
                             int fixed_n, int64_t fixed_stride, double* inv, int* status);
 int launch_block_build_invert(alfi_transfer* tr);

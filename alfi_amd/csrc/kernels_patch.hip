@@ -291,6 +291,160 @@ __global__ __launch_bounds__(256) void patch_apply_kernel(int64_t npatch, const 
 #undef ALFI_PIECE
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// 3b. multiplicative sweep, one dependency wavefront: one wave per patch p of the wavefront,
+//       r_p = x_p - (A y)_p ,   y_p += inv(A_p) r_p .
+//     The patches of a wavefront are mutually uncoupled (no operator entry links them), so they neither read what another
+//     one writes nor write the same dofs: plain stores, result identical to the sequential sweep.
+//     Residual: the block rows of the patch's nodes are treated as ONE flat list of blocks (prefix sums of the row
+//     lengths in LDS, lane = block, coalesced value planes because a row's blocks are consecutive), row sums by the same
+//     segmented wave scan as bsr_spmv_flat_kernel.  Then the apply pieces of section 3 with r_p in LDS.
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int MAX_PNODES = 64;
+
+template <int BS, bool NT>
+__global__ __launch_bounds__(256) void patch_mult_kernel(int64_t count, const int32_t* __restrict__ seq,
+                                                          const int64_t* __restrict__ patch_ptr,
+                                                          const int32_t* __restrict__ patch_dofs,
+                                                          const int64_t* __restrict__ inv_ptr,
+                                                          const double* __restrict__ inv,
+                                                          const int32_t* __restrict__ rowptr,
+                                                          const int32_t* __restrict__ colidx,
+                                                          const double* __restrict__ vals, int flat,
+                                                          const double* __restrict__ x, double* __restrict__ y) {
+  constexpr int BB = BS * BS;
+  __shared__ double rs_all[4][MAX_NP];          // r_p
+  __shared__ double ys_all[4][MAX_NP];          // inv(A_p) r_p
+  __shared__ int32_t pre_all[4][MAX_PNODES + 1];  // exclusive prefix of the rows' block counts
+  __shared__ int32_t k0_all[4][MAX_PNODES];       // first block of each row
+  __shared__ int32_t nd_all[4][MAX_PNODES];       // node (block row) of each patch node
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int64_t q = (int64_t)blockIdx.x * 4 + wave;
+  double* rs = rs_all[wave];
+  double* ys = ys_all[wave];
+  int32_t* pre = pre_all[wave];
+  int32_t* k0 = k0_all[wave];
+  int32_t* nd = nd_all[wave];
+  const bool live = q < count;
+  int64_t p = 0, off = 0;
+  int n = 0, nn = 0, total = 0;
+  if (live) {
+    p = seq[q];
+    off = patch_ptr[p];
+    n = (int)(patch_ptr[p + 1] - off);
+    nn = n / BS;
+    int node = 0, len = 0;
+    if (lane < nn) {
+      node = patch_dofs[off + lane * BS] / BS;
+      const int32_t lo = rowptr[node];
+      len = rowptr[node + 1] - lo;
+      k0[lane] = lo;
+      nd[lane] = node;
+    }
+    int incl = len;   // inclusive wave scan
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const int t = __shfl_up(incl, d);
+      if (lane >= d) incl += t;
+    }
+    if (lane < nn) pre[lane + 1] = incl;
+    if (lane == 0) pre[0] = 0;
+    total = __shfl(incl, 63);
+  }
+  __syncthreads();
+  if (live) {
+    double carry[BS];
+#pragma unroll
+    for (int r = 0; r < BS; ++r) carry[r] = 0.0;
+    for (int f0 = 0; f0 < total; f0 += 64) {
+      const int f = f0 + lane;
+      const bool valid = f < total;
+      // row of this lane's block: largest i with pre[i] <= f
+      int lo = 0, hi = nn;
+      while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (pre[mid] <= f) lo = mid; else hi = mid;
+      }
+      const int row = lo;
+      const bool head = valid && f == pre[row];
+      const bool last = valid && f + 1 == pre[row + 1];
+      double s[BS];
+#pragma unroll
+      for (int r = 0; r < BS; ++r) s[r] = 0.0;
+      if (valid) {
+        const int64_t k = (int64_t)k0[row] + (f - pre[row]);
+        const int64_t col = colidx[k] & 0x7fffffff;
+        double a[BB], yv[BS];
+#pragma unroll
+        for (int e = 0; e < BB; ++e) {
+          const double* v = vals + bsr_val_index(flat, k, e, BB);
+          a[e] = NT ? __builtin_nontemporal_load(v) : *v;
+        }
+#pragma unroll
+        for (int c = 0; c < BS; ++c) yv[c] = y[col * BS + c];
+#pragma unroll
+        for (int r = 0; r < BS; ++r)
+#pragma unroll
+          for (int c = 0; c < BS; ++c) s[r] = __builtin_fma(a[r * BS + c], yv[c], s[r]);
+      }
+      int fl = head ? 1 : 0;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        double tp[BS];
+#pragma unroll
+        for (int r = 0; r < BS; ++r) tp[r] = __shfl_up(s[r], d);
+        const int tf = __shfl_up(fl, d);
+        if (lane >= d && !fl) {
+#pragma unroll
+          for (int r = 0; r < BS; ++r) s[r] += tp[r];
+          fl = tf;
+        }
+      }
+      if (!fl) {
+#pragma unroll
+        for (int r = 0; r < BS; ++r) s[r] += carry[r];
+      }
+      if (last) {
+#pragma unroll
+        for (int r = 0; r < BS; ++r) rs[row * BS + r] = x[(int64_t)nd[row] * BS + r] - s[r];
+      }
+      // a row running on into the next 64 blocks is carried; a row closed at lane 63 is not
+      const int last63 = __shfl(last ? 1 : 0, 63);
+#pragma unroll
+      for (int r = 0; r < BS; ++r) {
+        const double c63 = __shfl(s[r], 63);
+        carry[r] = last63 ? 0.0 : c63;
+      }
+    }
+  }
+  __syncthreads();
+  if (live) {
+    const int ld = (n + 1) & ~1;
+    const double* T = inv + inv_ptr[p];
+    int row0 = 0;
+    for (; row0 + 128 <= ld; row0 += 128) apply_piece<64, NT>(T + (int64_t)row0 * n, n, rs, lane, ys + row0);
+    const int rem = ld - row0;
+#define ALFI_PIECE(R)                                                      \
+  if (rem & R) {                                                           \
+    apply_piece<R / 2, NT>(T + (int64_t)row0 * n, n, rs, lane, ys + row0); \
+    row0 += R;                                                             \
+  }
+    ALFI_PIECE(64)
+    ALFI_PIECE(32)
+    ALFI_PIECE(16)
+    ALFI_PIECE(8)
+    ALFI_PIECE(4)
+    ALFI_PIECE(2)
+#undef ALFI_PIECE
+  }
+  __syncthreads();
+  if (live)
+    for (int i = lane; i < n; i += 64) {
+      const int64_t dof = patch_dofs[off + i];
+      y[dof] += ys[i];
+    }
+}
+
 // stage 2: dof-wise sum of the staged patch results in a fixed order (deterministic; replaces PETSc's scatter-add)
 __global__ __launch_bounds__(256) void patch_sum_kernel(int64_t n, const int32_t* __restrict__ dof_ptr,
                                                          const int32_t* __restrict__ dof_pos,
@@ -359,6 +513,26 @@ int launch_patch_invert(alfi_level* L) {
                        L->status);
   else
     return alfi_set_error(ctx, ALFI_E_ARG, "patch size %d > 160 not supported (macro-star: SURVEY.md 8(f))", L->max_np);
+  ALFI_HIP_CHECK(ctx, hipGetLastError());
+  return 0;
+}
+
+int launch_patch_mult_wave(alfi_level* L, const int32_t* seq, int64_t count, const double* x, double* y) {
+  alfi_ctx* ctx = L->ctx;
+  if (count == 0) return 0;
+  static const bool nt = !(getenv("ALFI_NT") && atoi(getenv("ALFI_NT")) == 0);
+  dim3 grid((unsigned)((count + 3) / 4)), block(256);
+#define ALFI_MULT(BSV, NTV)                                                                                           \
+  hipLaunchKernelGGL((patch_mult_kernel<BSV, NTV>), grid, block, 0, ctx->stream, count, seq, L->patch_ptr,            \
+                     L->patch_dofs, L->inv_ptr, L->inv, L->A.rowptr, L->A.colidx, L->A.vals, L->A.flat, x, y)
+  if (L->bs == 2) {
+    if (nt) ALFI_MULT(2, true); else ALFI_MULT(2, false);
+  } else if (L->bs == 3) {
+    if (nt) ALFI_MULT(3, true); else ALFI_MULT(3, false);
+  } else {
+    return alfi_set_error(ctx, ALFI_E_ARG, "unsupported block size %d", L->bs);
+  }
+#undef ALFI_MULT
   ALFI_HIP_CHECK(ctx, hipGetLastError());
   return 0;
 }

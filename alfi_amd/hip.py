@@ -144,6 +144,15 @@ class Level(object):
         pd = np.ascontiguousarray(patch_dofs, dtype=np.int32)
         self.ctx.check(self.ctx.lib.alfi_patches_set(self.h, len(pp) - 1, _ptr(pp), _ptr(pd)))
 
+    def set_multiplicative(self, iterset, symmetrise):
+        """Multiplicative sweeps in the order ``iterset`` (None / empty = back to additive); returns the number of
+        dependency wavefronts one sweep was scheduled into."""
+        it = np.ascontiguousarray(iterset if iterset is not None else [], dtype=np.int64)
+        self.ctx.check(self.ctx.lib.alfi_patches_set_multiplicative(self.h, len(it), _ptr(it), 1 if symmetrise else 0))
+        nw = ctypes.c_int64()
+        self.ctx.check(self.ctx.lib.alfi_patches_multiplicative_levels(self.h, ctypes.byref(nw)))
+        return nw.value
+
     def factor(self):
         self.ctx.check(self.ctx.lib.alfi_patches_factor(self.h))
 

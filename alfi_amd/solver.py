@@ -150,9 +150,10 @@ class HipPatchPC(object):
         local_type = opts.getString("patch_pc_patch_local_type", "additive")
         if _truthy(opts.getString("patch_pc_patch_multiplicative", "false")):
             local_type = "multiplicative"
-        if local_type != "additive":
-            raise NotImplementedError("multiplicative patch sweeps are not implemented yet (SURVEY.md section 8(f), "
-                                      "rank 1); use --patch-composition additive")
+        if local_type not in ("additive", "multiplicative"):
+            raise NotImplementedError("patch local_type %r" % local_type)
+        self.multiplicative = local_type == "multiplicative"
+        self.symmetrise = _truthy(opts.getString("patch_pc_patch_symmetrise_sweep", "false"))
         if _truthy(opts.getString("patch_pc_patch_partition_of_unity", "false")):
             raise NotImplementedError("partition_of_unity weighting (the reference always sets it False, solver.py:321)")
         sub_mat = opts.getString("patch_pc_patch_sub_mat_type", "seqdense")
@@ -167,14 +168,25 @@ class HipPatchPC(object):
             self.iterset = np.arange(len(ptr) - 1)
         elif ctype == "python":
             ctor = _resolve(opts.getString("patch_pc_patch_construct_python_type"))()
-            patches, self.iterset = ctor(pc)
+            # firedrake.PatchPC hands the constructor its inner PCPATCH object, whose options prefix is the outer one
+            # + "patch_" [3P]: that is where pc_patch_construction_<Name>_sort_order lives (solver.py:335, 342)
+            inner = PC(pc.ctx, pc.level_data, options=pc.options, prefix=pc.getOptionsPrefix() + "patch_")
+            inner._dm = pc.getDM()
+            patches, iterset = ctor(inner)
             ptr, dofs, kept = patch_points_to_dofs(L.V, pc.getDM(), patches)
+            # the iteration set indexes the constructor's patch list; patches without free dofs were dropped (PCPATCH
+            # skips them in the sweep: `if (len <= 0) continue` [3P])
+            new = np.full(len(patches), -1, dtype=np.int64)
+            new[np.asarray(kept, dtype=np.int64)] = np.arange(len(kept))
+            it = new[np.asarray(iterset, dtype=np.int64)]
+            self.iterset = it[it >= 0]
         else:
             raise NotImplementedError("patch construct_type %r" % ctype)
         self.patch_ptr, self.patch_dofs = ptr, dofs
         self.level = hip.Level(pc.ctx, L.A, L.bc_dofs)
         self.level.set_patches(ptr, dofs)
         self.level.factor()
+        self.wavefronts = self.level.set_multiplicative(self.iterset, self.symmetrise) if self.multiplicative else 0
         self.n = L.n
 
     def update(self, pc):

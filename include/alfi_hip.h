@@ -113,6 +113,17 @@ int alfi_patches_factor(alfi_level* lvl);
 /* PCApply_PATCH, additive, no partition of unity (solver.py:321-322): y = sum_p R_p^T inv(A_p) R_p x; y[bc] = x[bc].
  * x is not modified.  Deterministic (no atomics): patch results are staged and summed dof-wise in a fixed order. */
 int alfi_patch_apply(alfi_level* lvl, const double* dx, double* dy);
+/* PCPATCH local_type multiplicative (solver.py:322-324, 332-335): visit the patches in the order `iterset_host` (nit
+ * positions; the concatenation of one coordinate-sorted permutation per '|' sweep of the constructor's sort_order,
+ * relaxation.py:139-150, so a patch may appear more than once), each solve seeing the residual left by all earlier
+ * ones; symmetrise != 0 appends the same sequence reversed (patch_pc_patch_symmetrise_sweep).  The library orders
+ * the positions into dependency wavefronts (two patches are independent when no operator entry couples them), which
+ * reproduces the sequential sweep exactly.  Afterwards alfi_patch_apply and alfi_smooth_fgmres on this level use the
+ * multiplicative sweep; nit == 0 switches back to additive.  Patches must consist of whole nodes (all bs components),
+ * at most 64 nodes per patch; not available on partitioned levels. */
+int alfi_patches_set_multiplicative(alfi_level* lvl, int64_t nit, const int64_t* iterset_host, int symmetrise);
+/* number of dependency wavefronts of one sweep (0 = additive) */
+int alfi_patches_multiplicative_levels(alfi_level* lvl, int64_t* nwave);
 /* sum_p n_p^2 (doubles held as inverses) and sum_p n_p, for roofline accounting */
 int alfi_patches_stats(alfi_level* lvl, int64_t* npatch, int64_t* sum_n, int64_t* sum_n2);
 /* debugging / parity tests: copy the dense inverse of patch p (row-major n_p x n_p) to the host */

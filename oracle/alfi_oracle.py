@@ -101,9 +101,13 @@ def apply_bcs_matrix(A, bc_dofs):
 # S5/S6: PatchPC / PCPATCH additive star smoother, dense explicit inverses (alfi/solver.py:318-328, 599-602)
 # ---------------------------------------------------------------------------------------------------------------------
 class PatchSmoother(object):
-    def __init__(self, A, patch_ptr, patch_dofs, bc_dofs):
+    def __init__(self, A, patch_ptr, patch_dofs, bc_dofs, local_type="additive", iterset=None, symmetrise=False):
+        """local_type / iterset / symmetrise: ``patch_pc_patch_local_type``, the iteration set returned by the patch
+        constructor (relaxation.py:139-150) and ``patch_pc_patch_symmetrise_sweep`` (solver.py:322-324)."""
         self.A = sp.csr_matrix(A)
         self.patch_ptr, self.patch_dofs, self.bc_dofs = patch_ptr, patch_dofs, bc_dofs
+        self.local_type, self.symmetrise = local_type, symmetrise
+        self.iterset = np.arange(len(patch_ptr) - 1) if iterset is None else np.asarray(iterset)
         self.update()
 
     def update(self, A=None):
@@ -118,6 +122,31 @@ class PatchSmoother(object):
             self.inv.append(np.linalg.inv(Ap))
 
     def apply(self, x):
+        if self.local_type == "multiplicative":
+            return self.apply_multiplicative(x)
+        return self.apply_additive(x)
+
+    def apply_multiplicative(self, x):
+        """PCApply_PATCH with local_type multiplicative [3P]: patches are visited in iteration-set order (then, with
+        symmetrise_sweep, once more in reverse order); each solve sees the residual left by all earlier ones --
+        PCPATCH keeps a running local right-hand side and subtracts A[closure(p), p] dy_p after every solve
+        (its 'matrix with artificial dofs'), which equals solving with r_p = (x - A y)_p since every row that couples
+        to a star patch's dofs lies in the closure of the star.  y[bc] = x[bc] at the end."""
+        y = np.zeros_like(x)
+        r = x.copy()
+        Acsc = self.A.tocsc()
+        seq = list(self.iterset)
+        if self.symmetrise:
+            seq = seq + seq[::-1]
+        for p in seq:
+            dofs = self.patch_dofs[self.patch_ptr[p]:self.patch_ptr[p + 1]]
+            dy = self.inv[p] @ r[dofs]
+            y[dofs] += dy
+            r -= Acsc[:, dofs] @ dy
+        y[self.bc_dofs] = x[self.bc_dofs]
+        return y
+
+    def apply_additive(self, x):
         """y = sum_p R_p^T A_p^{-1} R_p x, no partition of unity (solver.py:321); y[bc] = x[bc]."""
         y = np.zeros_like(x)
         for p, Ainv in enumerate(self.inv):
@@ -319,12 +348,16 @@ class Multigrid(object):
         return self.vcycle(L, bs[L], x)
 
 
-def build_oracle_mg(levels, transfers, k, schoeberl_restriction=False):
-    """Oracle multigrid from the host generator's LevelData/TransferData (alfi_amd/problem.py)."""
+def build_oracle_mg(levels, transfers, k, schoeberl_restriction=False, local_type="additive", itersets=None,
+                    symmetrise=False):
+    """Oracle multigrid from the host generator's LevelData/TransferData (alfi_amd/problem.py).  itersets[l]: patch
+    iteration order of level l for multiplicative sweeps (None = patch order)."""
     olev = []
     for L in levels:
         A = L.A.to_scipy().tocsr()
-        sm = PatchSmoother(A, L.patch_ptr, L.patch_dofs, L.bc_dofs) if L.level > 0 else None
+        its = None if itersets is None else itersets[L.level]
+        sm = PatchSmoother(A, L.patch_ptr, L.patch_dofs, L.bc_dofs, local_type, its, symmetrise) \
+            if L.level > 0 else None
         olev.append(dict(A=A, smoother=sm, bc=L.bc_dofs))
     otr = []
     for T, L in zip(transfers, levels[1:]):

@@ -104,9 +104,56 @@ def test_hip_patch_pc_and_mg_from_options():
     obj.apply(pc, x, y2)
     assert np.abs(y2 - y).max() < 1e-10 * np.abs(y).max()
     # unsupported modes are refused loudly
-    o3 = alfi_amd.mg_levels_solver(3, patch_composition="multiplicative", relaxation_direction="0+:1-")
+    o3 = alfi_amd.mg_levels_solver(3, smoothing=3)
+    o3["patch_pc_patch_partition_of_unity"] = True
     with pytest.raises(NotImplementedError):
         alfi_amd.HipPatchPC().initialize(alfi_amd.PC(ctx, L, options=o3))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dim", [2, 3])
+def test_multiplicative_sweeps_through_the_option_dictionary(dim):
+    """--patch-composition multiplicative (solver.py:306, 322-324, 332-335): python-constructed Star patches ordered by
+    the problem's relaxation_direction, symmetrised sweep; PatchPC.apply and the whole PCMG against the oracle."""
+    import alfi_amd
+    from alfi_amd import hip
+    from oracle import alfi_oracle as O
+    prob = TwoDimLidDrivenCavityProblem(4) if dim == 2 else ThreeDimLidDrivenCavityProblem(2)
+    lv, tr = build_hierarchy(prob, 1, 2, Re=100.0)
+    ctx = hip.Context(0)
+    L = lv[-1]
+    opts = alfi_amd.mg_levels_solver(dim, patch_composition="multiplicative", smoothing=3,
+                                     relaxation_direction=prob.relaxation_direction())
+    assert opts["patch_pc_patch_local_type"] == "multiplicative" and opts["patch_pc_patch_symmetrise_sweep"]
+    pc = alfi_amd.PC(ctx, L, options=opts)
+    obj = alfi_amd.HipPatchPC()
+    obj.initialize(pc)
+    assert obj.wavefronts > 1 and len(obj.iterset) == len(obj.patch_ptr) - 1
+    x = np.random.default_rng(3).standard_normal(L.n)
+    y = np.zeros(L.n)
+    obj.apply(pc, x, y)
+    sm = O.PatchSmoother(L.A.to_scipy().tocsr(), obj.patch_ptr, obj.patch_dofs, L.bc_dofs, "multiplicative",
+                         obj.iterset, True)
+    ref = sm.apply(x)
+    assert np.abs(y - ref).max() < 1e-7 * np.abs(ref).max()
+    # the sweep order matters: the reversed order gives a different (but equally valid) preconditioner
+    sm_rev = O.PatchSmoother(L.A.to_scipy().tocsr(), obj.patch_ptr, obj.patch_dofs, L.bc_dofs, "multiplicative",
+                             obj.iterset[::-1], False)
+    assert np.abs(sm_rev.apply(x) - ref).max() > 1e-3 * np.abs(ref).max()
+    # whole multigrid with the multiplicative smoother
+    mg = alfi_amd.HipMG(ctx, lv, tr, alfi_amd.fieldsplit_0_mg(opts))
+    b = np.random.default_rng(4).standard_normal(L.n)
+    b[L.bc_dofs] = 0.0
+    out = np.zeros(L.n)
+    mg.apply(b, out)
+    itersets = [None] + [o.iterset for o in mg.pc_objs[1:]]
+    olev_patches = [None] + [(o.patch_ptr, o.patch_dofs) for o in mg.pc_objs[1:]]
+    for Lv, pp in zip(lv, olev_patches):
+        if pp is not None:
+            Lv.patch_ptr, Lv.patch_dofs = pp
+    omg = O.build_oracle_mg(lv, tr, 3, local_type="multiplicative", itersets=itersets, symmetrise=True)
+    ref = omg.fcycle(b)
+    assert np.abs(out - ref).max() < 1e-5 * np.abs(ref).max()
 
 
 @pytest.mark.gpu
