@@ -80,8 +80,10 @@ __host__ __device__ inline int64_t patch_inv_index(int r, int c, int n, int ld) 
 
 // Block-CSR on the device.  Two value layouts:
 //   flat == 0: vals[k][bs*bs] (the host layout); one group of lanes per block row (bsr_spmv_kernel);
-//   flat == 1: "lane-major": blocks in groups of 64, vals[k / 64][bs*bs][k % 64], so that a wave handling 64 consecutive
-//              blocks reads each of the bs*bs value planes as one contiguous 512-B request; the sign bit of colidx[k]
+//   flat == 1: "lane-major": blocks in groups of 64; within a group the bs*bs entries of a block are taken in pairs
+//              (e0,e1), (e2,e3), ... and stored vals[k / 64][pair][k % 64][2] (a trailing unpaired entry as [k % 64]), so
+//              that a wave handling 64 consecutive blocks reads each pair plane as one contiguous 1-KiB request of
+//              16 B per lane (bs = 3: four of those plus one 512-B request); the sign bit of colidx[k]
 //              marks the first block of a block row; chunk_row[c] = block row of block c * SPMV_CHUNK.  Used by the
 //              nnz-balanced segmented SpMV (bsr_spmv_flat_kernel) whenever every block row is non-empty.
 constexpr int SPMV_U = 4;                 // wave iterations of 64 blocks
@@ -99,7 +101,11 @@ struct DevBSR {
   int32_t* carry_row = nullptr;  // (nchunks): that block row, or -1
 };
 __host__ __device__ inline int64_t bsr_val_index(int flat, int64_t k, int rc, int bb) {
-  return flat ? (k >> 6) * 64 * bb + (int64_t)rc * 64 + (k & 63) : k * bb + rc;
+  if (!flat) return k * bb + rc;
+  const int64_t g = (k >> 6) * 64 * bb;
+  const int l = (int)(k & 63), npair = bb >> 1;
+  if (rc < 2 * npair) return g + (int64_t)(rc >> 1) * 128 + l * 2 + (rc & 1);
+  return g + (int64_t)npair * 128 + l;
 }
 
 struct alfi_level {

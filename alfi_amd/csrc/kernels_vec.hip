@@ -50,12 +50,13 @@ __global__ __launch_bounds__(256) void bsr_spmv_kernel(int64_t nbrows, const int
 // ---------------------------------------------------------------------------------------------------------------------
 // nnz-balanced BSR SpMV on the lane-major layout (DevBSR::flat): a wave takes SPMV_CHUNK consecutive blocks whatever rows
 // they belong to (block rows of the P2+FB operator hold 14 .. 125 blocks, so one-wave-per-row leaves most lanes idle), lane
-// l of iteration u owns block base + 64 u + l: one coalesced 256-B colidx request and bs*bs coalesced 512-B value requests
-// per 64 blocks, x gathered through L2.  Per-row sums by a segmented inclusive scan over the wave (row starts = sign bit
+// l of iteration u owns block base + 64 u + l: one coalesced 256-B colidx request and (bs*bs)/2 coalesced 1-KiB value
+// requests (16 B per lane) per 64 blocks, x gathered through L2.  Per-row sums by a segmented inclusive scan over the wave (row starts = sign bit
 // of colidx); a row running on into the next iteration travels in a wave-uniform carry, a row running on into the next
 // chunk leaves its partial sum in carry[chunk] and bsr_spmv_fixup_kernel adds it to the row in chunk order
 // (deterministic, no atomics).  The wave holding a row's LAST block stores y, everything earlier is a carry.
 // ---------------------------------------------------------------------------------------------------------------------
+typedef double spmv_d2 __attribute__((ext_vector_type(2)));
 template <int BS, bool NT>
 __global__ __launch_bounds__(256) void bsr_spmv_flat_kernel(int64_t nnzb, int64_t nchunks,
                                                              const int32_t* __restrict__ colflag,
@@ -93,10 +94,19 @@ __global__ __launch_bounds__(256) void bsr_spmv_flat_kernel(int64_t nnzb, int64_
 #pragma unroll
     for (int r = 0; r < BS; ++r) p[r] = 0.0;
     if (valid) {
-      const double* v = vals + (k >> 6) * (64 * BB) + lane;
+      const double* v = vals + (k >> 6) * (64 * BB);
       double a[BB], xv[BS];
 #pragma unroll
-      for (int e = 0; e < BB; ++e) a[e] = NT ? __builtin_nontemporal_load(v + e * 64) : v[e * 64];
+      for (int q = 0; q < BB / 2; ++q) {   // pair planes: one aligned 16-byte load per lane
+        const spmv_d2* pq = reinterpret_cast<const spmv_d2*>(v + q * 128) + lane;
+        const spmv_d2 t = NT ? __builtin_nontemporal_load(pq) : *pq;
+        a[2 * q] = t.x;
+        a[2 * q + 1] = t.y;
+      }
+      if (BB & 1) {
+        const double* pl = v + (BB / 2) * 128 + lane;
+        a[BB - 1] = NT ? __builtin_nontemporal_load(pl) : *pl;
+      }
 #pragma unroll
       for (int c = 0; c < BS; ++c) xv[c] = x[col * BS + c];
 #pragma unroll
