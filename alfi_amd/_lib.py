@@ -78,6 +78,14 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # One HIP runtime per process: PyTorch-ROCm ships its own libamdhip64.so.7, and whichever copy is loaded first serves
+    # both (same SONAME).  Loaded in the other order -- ours from /opt/rocm first, torch later -- torch's device init
+    # reports "No HIP GPUs are available" (seen on the MI355X box).  torch supplies streams / torch.distributed to
+    # alfi_amd.dist anyway, so import it first when it is installed.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     if not os.path.exists(LIB_PATH):
         raise RuntimeError("libalfi_hip.so is missing (%s): build it with `python -m alfi_amd.build`; "
                            "alfi_amd has no CPU fallback" % LIB_PATH)
