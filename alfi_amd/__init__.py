@@ -8,7 +8,8 @@ from .problem import (NavierStokesProblem, TwoDimLidDrivenCavityProblem,        
 
 def __getattr__(name):
     # the GPU-facing classes load libalfi_hip.so on first use (and fail loudly if it is missing)
-    if name in ("HipPatchPC", "HipMG", "PC", "mg_levels_solver", "fieldsplit_0_mg"):
+    if name in ("HipPatchPC", "HipMG", "PC", "mg_levels_solver", "fieldsplit_0_mg", "DGMassInv", "outer_solver",
+                "HipOuterSolver"):
         from . import solver
         return getattr(solver, name)
     if name in ("PkP0SchoeberlTransfer", "AutoSchoeberlTransfer", "CoarseCellPatches", "NullTransfer", "Constant",

@@ -12,6 +12,10 @@ c_f64p = ctypes.POINTER(ctypes.c_double)
 vp = ctypes.c_void_p
 
 
+class CsrHost(ctypes.Structure):
+    _fields_ = [("nrows", ctypes.c_int64), ("ncols", ctypes.c_int64), ("rowptr", vp), ("colidx", vp), ("vals", vp)]
+
+
 class BsrHost(ctypes.Structure):
     _fields_ = [("nbrows", ctypes.c_int64), ("nbcols", ctypes.c_int64), ("rowptr", vp), ("colidx", vp), ("vals", vp)]
 
@@ -60,12 +64,22 @@ SIGNATURES = {
     "alfi_transfer_destroy": (ctypes.c_int, [vp]),
     "alfi_transfer_update": (ctypes.c_int, [vp, ctypes.c_double, ctypes.c_double]),
     "alfi_prolong": (ctypes.c_int, [vp, vp, vp]),
+    "alfi_transfer_set_injection": (ctypes.c_int, [vp, vp]),
+    "alfi_inject": (ctypes.c_int, [vp, vp, vp]),
     "alfi_restrict": (ctypes.c_int, [vp, vp, vp, ctypes.c_int]),
     "alfi_mg_create": (ctypes.c_int, [vp, ctypes.c_int, ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.c_int,
                                       ctypes.c_int, ctypes.POINTER(vp)]),
     "alfi_mg_destroy": (ctypes.c_int, [vp]),
     "alfi_mg_vcycle": (ctypes.c_int, [vp, vp, vp]),
     "alfi_mg_fcycle": (ctypes.c_int, [vp, vp, vp]),
+    "alfi_saddle_create": (ctypes.c_int, [vp, ctypes.POINTER(CsrHost), ctypes.POINTER(CsrHost), vp, ctypes.c_double,
+                                          ctypes.c_double, ctypes.c_int, ctypes.POINTER(vp)]),
+    "alfi_saddle_destroy": (ctypes.c_int, [vp]),
+    "alfi_saddle_update": (ctypes.c_int, [vp, ctypes.c_double, ctypes.c_double]),
+    "alfi_saddle_solve": (ctypes.c_int, [vp, vp, vp, ctypes.c_double, ctypes.c_double, ctypes.c_int, ctypes.c_int,
+                                         ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_double)]),
+    "alfi_saddle_mult": (ctypes.c_int, [vp, vp, vp]),
+    "alfi_saddle_precond": (ctypes.c_int, [vp, vp, vp]),
 }
 
 EVENTS = ["PATCH_APPLY", "PATCH_SCATTER", "PATCH_FACTOR", "MATMULT", "BLAS1", "PROLONG", "RESTRICT", "COARSE", "COMM"]

@@ -832,9 +832,29 @@ int alfi_transfer_destroy(alfi_transfer* T) {
   dev_free(T->tI);
   dev_free(T->bI);
   dev_free(T->tmp_f);
+  dev_free(T->inj);
   dev_free(T->status);
   delete T;
   return 0;
+}
+
+int alfi_transfer_set_injection(alfi_transfer* T, const int32_t* fine_node) {
+  alfi_ctx* ctx = T->ctx;
+  if (!fine_node) return alfi_set_error(ctx, ALFI_E_ARG, "NULL injection map");
+  if (T->fine->has_halo || T->coarse->has_halo)
+    return alfi_set_error(ctx, ALFI_E_ARG, "alfi_inject is not available on partitioned levels");
+  const int64_t nc = T->coarse->n / T->bs, nf = T->fine->n / T->bs;
+  for (int64_t i = 0; i < nc; ++i)
+    if (fine_node[i] < 0 || fine_node[i] >= nf) return alfi_set_error(ctx, ALFI_E_ARG, "injection map entry out of range");
+  ALFI_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  dev_free(T->inj);
+  T->inj = nullptr;
+  return dev_upload(ctx, &T->inj, fine_node, nc);
+}
+
+int alfi_inject(alfi_transfer* T, const double* dxf, double* dxc) {
+  if (!T->inj) return alfi_set_error(T->ctx, ALFI_E_STATE, "alfi_inject before alfi_transfer_set_injection");
+  return launch_halo_pack(T->ctx, dxc, dxf, T->inj, T->coarse->n / T->bs, T->bs);   // coarse[i] = fine[inj[i]]
 }
 
 int alfi_transfer_update(alfi_transfer* T, double nu, double gamma) {
@@ -983,6 +1003,187 @@ int alfi_mg_fcycle(alfi_mg* mg, const double* db, double* dx) {
     ALFI_CHECK(alfi_prolong(mg->transfers[l], L->mg_x, xnext));
   }
   return vcycle(mg, Lmax, db, dx);
+}
+
+// ---- outer saddle-point solve (alfi/solver.py:386-422) ----------------------------------------------------------------------------
+static int upload_csr(alfi_ctx* ctx, DevCSR* d, const alfi_csr_host* h) {
+  d->nrows = h->nrows;
+  d->ncols = h->ncols;
+  d->nnz = h->rowptr[h->nrows];
+  ALFI_CHECK(dev_upload(ctx, &d->rowptr, h->rowptr, h->nrows + 1));
+  ALFI_CHECK(dev_upload(ctx, &d->colidx, h->colidx, d->nnz));
+  ALFI_CHECK(dev_upload(ctx, &d->vals, h->vals, d->nnz));
+  return 0;
+}
+static void free_csr(DevCSR* d) {
+  dev_free(d->rowptr);
+  dev_free(d->colidx);
+  dev_free(d->vals);
+  *d = DevCSR();
+}
+
+int alfi_saddle_create(alfi_mg* mg, const alfi_csr_host* B, const alfi_csr_host* BT, const double* mass_diag,
+                       double nu, double gamma, int remove_constant_nullspace, alfi_saddle** out) {
+  if (!mg || !B || !BT || !mass_diag || !out) return alfi_set_error(mg ? mg->ctx : nullptr, ALFI_E_ARG, "NULL argument");
+  alfi_ctx* ctx = mg->ctx;
+  alfi_level* F = mg->levels.back();
+  if (F->has_halo) return alfi_set_error(ctx, ALFI_E_ARG, "the outer solve is not available on partitioned levels");
+  if (B->ncols != F->n || BT->nrows != F->n || BT->ncols != B->nrows)
+    return alfi_set_error(ctx, ALFI_E_ARG, "divergence matrix shape does not match the finest level");
+  for (int64_t i = 0; i < B->nrows; ++i)
+    if (!(mass_diag[i] > 0.0)) return alfi_set_error(ctx, ALFI_E_ARG, "pressure mass matrix entry %lld is not positive", (long long)i);
+  ALFI_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  alfi_saddle* S = new alfi_saddle();
+  S->ctx = ctx;
+  S->mg = mg;
+  S->fine = F;
+  S->nu_dofs = F->n;
+  S->np_dofs = B->nrows;
+  S->nu = nu;
+  S->gamma = gamma;
+  S->remove_nullspace = remove_constant_nullspace != 0;
+  std::vector<double> minv(B->nrows);
+  for (int64_t i = 0; i < B->nrows; ++i) minv[i] = 1.0 / mass_diag[i];
+  int rc = upload_csr(ctx, &S->B, B);
+  if (rc == 0) rc = upload_csr(ctx, &S->BT, BT);
+  if (rc == 0) rc = dev_upload(ctx, &S->minv, minv.data(), B->nrows);
+  if (rc == 0) rc = dev_alloc(ctx, &S->tmp_u, S->nu_dofs);
+  if (rc == 0) rc = dev_alloc(ctx, &S->tmp_p, S->np_dofs);
+  if (rc != 0) {
+    alfi_saddle_destroy(S);
+    return rc;
+  }
+  *out = S;
+  return 0;
+}
+
+int alfi_saddle_destroy(alfi_saddle* S) {
+  if (!S) return 0;
+  (void)hipStreamSynchronize(S->ctx->stream);
+  free_csr(&S->B);
+  free_csr(&S->BT);
+  dev_free(S->minv);
+  dev_free(S->V);
+  dev_free(S->Z);
+  dev_free(S->w);
+  dev_free(S->hs);
+  dev_free(S->tmp_u);
+  dev_free(S->tmp_p);
+  delete S;
+  return 0;
+}
+
+int alfi_saddle_update(alfi_saddle* S, double nu, double gamma) {
+  S->nu = nu;
+  S->gamma = gamma;
+  return 0;
+}
+
+// y = [A B^T; B 0] x
+int alfi_saddle_mult(alfi_saddle* S, const double* dx, double* dy) {
+  alfi_ctx* ctx = S->ctx;
+  const int64_t nu = S->nu_dofs;
+  ALFI_CHECK(alfi_spmv(S->fine, dx, dy));                                       // y_u = A x_u
+  ALFI_CHECK(launch_csr_spmv(ctx, S->BT, dx + nu, dy, nullptr, 0.0, 2));        // y_u += B^T x_p
+  ALFI_CHECK(launch_csr_spmv(ctx, S->B, dx, dy + nu, nullptr, 0.0, 0));         // y_p = B x_u
+  return 0;
+}
+
+// PCFIELDSPLIT, Schur, full factorisation [3P] with the sub-solvers of solver.py:359-391
+int alfi_saddle_precond(alfi_saddle* S, const double* dx, double* dy) {
+  alfi_ctx* ctx = S->ctx;
+  const int64_t nu = S->nu_dofs, np = S->np_dofs;
+  ALFI_CHECK(alfi_mg_fcycle(S->mg, dx, dy));                                    // y_u = MG(b_u)
+  ALFI_CHECK(launch_csr_spmv(ctx, S->B, dy, S->tmp_p, dx + nu, 1.0, 1));        // q = b_p - B y_u
+  ALFI_CHECK(launch_scale_rows(ctx, dy + nu, S->tmp_p, S->minv, -(S->nu + S->gamma), np));   // y_p = -(nu+gamma) M^-1 q
+  ALFI_CHECK(launch_csr_spmv(ctx, S->BT, dy + nu, S->tmp_u, dx, 1.0, 1));       // t = b_u - B^T y_p
+  ALFI_CHECK(alfi_mg_fcycle(S->mg, S->tmp_u, dy));                              // y_u = MG(t)
+  if (S->remove_nullspace) ALFI_CHECK(launch_remove_mean(ctx, dy + nu, np));
+  return 0;
+}
+
+int alfi_saddle_solve(alfi_saddle* S, const double* db, double* dx, double rtol, double atol, int max_it, int restart,
+                      int* iterations, double* residual_norm) {
+  alfi_ctx* ctx = S->ctx;
+  const int64_t n = S->nu_dofs + S->np_dofs;
+  if (restart < 1 || restart > RED_MAXV - 2) return alfi_set_error(ctx, ALFI_E_ARG, "restart must be in 1..%d", RED_MAXV - 2);
+  if (restart != S->restart) {
+    ALFI_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    dev_free(S->V);
+    dev_free(S->Z);
+    dev_free(S->w);
+    dev_free(S->hs);
+    S->V = S->Z = S->w = S->hs = nullptr;
+    S->restart = 0;
+    ALFI_CHECK(dev_alloc(ctx, &S->V, (int64_t)(restart + 1) * n));
+    ALFI_CHECK(dev_alloc(ctx, &S->Z, (int64_t)restart * n));
+    ALFI_CHECK(dev_alloc(ctx, &S->w, n));
+    HsLayout hl0(restart);
+    ALFI_CHECK(dev_alloc(ctx, &S->hs, hl0.total));
+    S->restart = restart;
+  }
+  const int K = restart;
+  HsLayout hl(K);
+  double *V = S->V, *Z = S->Z, *w = S->w, *hs = S->hs;
+  ALFI_HIP_CHECK(ctx, hipMemsetAsync(hs, 0, sizeof(double) * hl.total, ctx->stream));
+  ALFI_HIP_CHECK(ctx, hipMemsetAsync(dx, 0, sizeof(double) * n, ctx->stream));
+  auto read = [&](const double* p, double* out) -> int {
+    ALFI_HIP_CHECK(ctx, hipMemcpyAsync(out, p, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    ALFI_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    return 0;
+  };
+  int its = 0;
+  double bnorm = 0.0, rnorm = 0.0;
+  // r = b (zero initial guess)
+  ALFI_CHECK(launch_copy(ctx, w, db, n));
+  ALFI_CHECK(launch_norm_partials(ctx, w, n));
+  ALFI_CHECK(launch_norm_init_finish(ctx, ctx->red_partial, RED_BLOCKS, hs, K));
+  ALFI_CHECK(read(hs + hl.beta, &bnorm));
+  rnorm = bnorm;
+  const double tol = std::max(rtol * bnorm, atol);
+  bool converged = rnorm <= tol;
+  while (!converged && its < max_it) {
+    ALFI_CHECK(launch_scale_by_inv(ctx, V, w, hs + hl.beta, n));            // v_0 = r / |r|
+    int j = 0;
+    for (; j < K && its < max_it; ++j) {
+      double* zj = Z + (int64_t)j * n;
+      ALFI_CHECK(alfi_saddle_precond(S, V + (int64_t)j * n, zj));            // z_j = P^-1 v_j
+      ALFI_CHECK(alfi_saddle_mult(S, zj, w));                               // w = K z_j
+      ALFI_CHECK(launch_multi_dot(ctx, V, n, j + 1, w, hs + hl.hd, n));
+      ALFI_CHECK(launch_multi_axpy_norm(ctx, V, n, j + 1, hs + hl.hd, w, n));
+      ALFI_CHECK(launch_hessenberg_update(ctx, ctx->red_partial, RED_BLOCKS, hs + hl.hd, hs, j, K));
+      ++its;
+      double g = 0.0;
+      ALFI_CHECK(read(hs + hl.grs + j + 1, &g));                            // |rotated rhs| = residual norm estimate
+      rnorm = std::fabs(g);
+      if (rnorm <= tol) {
+        converged = true;
+        ++j;
+        break;
+      }
+      if (j + 1 < K) ALFI_CHECK(launch_scale_by_inv(ctx, V + (int64_t)(j + 1) * n, w, hs + hl.tt, n));
+    }
+    ALFI_CHECK(launch_fgmres_finish(ctx, hs, j, K));
+    ALFI_CHECK(launch_update_solution(ctx, dx, Z, n, j, hs + hl.y, n));
+    if (converged || its >= max_it) break;
+    // restart: true residual
+    ALFI_CHECK(alfi_saddle_mult(S, dx, w));
+    ALFI_CHECK(launch_xmy(ctx, w, db, n));                                   // w = b - K x
+    ALFI_CHECK(launch_norm_partials(ctx, w, n));
+    ALFI_CHECK(launch_norm_init_finish(ctx, ctx->red_partial, RED_BLOCKS, hs, K));
+    ALFI_CHECK(read(hs + hl.beta, &rnorm));
+    converged = rnorm <= tol;
+  }
+  // final true residual norm
+  ALFI_CHECK(alfi_saddle_mult(S, dx, w));
+  ALFI_CHECK(launch_xmy(ctx, w, db, n));
+  ALFI_CHECK(launch_norm_partials(ctx, w, n));
+  ALFI_CHECK(launch_norm_init_finish(ctx, ctx->red_partial, RED_BLOCKS, hs, K));
+  double tn = 0.0;
+  ALFI_CHECK(read(hs + hl.beta, &tn));
+  if (iterations) *iterations = its;
+  if (residual_norm) *residual_norm = tn;
+  return 0;
 }
 
 }  // extern "C"

@@ -173,6 +173,7 @@ struct alfi_transfer {
   double* binv = nullptr;  // (nblk, m cols, ld) column-major padded inverses
   double *tI = nullptr, *bI = nullptr;  // compact interior vectors (nblk*m)
   double* tmp_f = nullptr;              // fine work vector
+  int32_t* inj = nullptr;               // (coarse nodes) fine node coinciding with each coarse node
   double gamma = 0, nu = 0;
   bool ready = false;
   int* status = nullptr;
@@ -184,6 +185,27 @@ struct alfi_mg {
   std::vector<alfi_transfer*> transfers;
   int k = 0;
   int robust = 0;
+};
+
+struct DevCSR {
+  int64_t nrows = 0, ncols = 0, nnz = 0;
+  int32_t* rowptr = nullptr;
+  int32_t* colidx = nullptr;
+  double* vals = nullptr;
+};
+
+struct alfi_saddle {
+  alfi_ctx* ctx = nullptr;
+  alfi_mg* mg = nullptr;
+  alfi_level* fine = nullptr;
+  int64_t nu_dofs = 0, np_dofs = 0;
+  DevCSR B, BT;
+  double* minv = nullptr;  // 1 / diag(M_p)
+  double nu = 0, gamma = 0;
+  bool remove_nullspace = false;
+  // outer FGMRES workspace
+  int restart = 0;
+  double *V = nullptr, *Z = nullptr, *w = nullptr, *hs = nullptr, *tmp_u = nullptr, *tmp_p = nullptr;
 };
 
 // ---- kernel launch wrappers (defined in the .hip files) --------------------------------------------------------------
@@ -214,6 +236,11 @@ int launch_norm_init_finish(alfi_ctx* ctx, const double* partial, int nblocks, d
 int launch_reduce_partials(alfi_ctx* ctx, int nv, double* out);  // out[v] = sum_b red_partial[b][v]
 int launch_hessenberg_update(alfi_ctx* ctx, const double* partial, int nblocks, const double* h, double* hs, int j,
                              int K);
+// scalar CSR: mode 0: y = A x; 1: y = b - alpha A x; 2: y += A x
+int launch_csr_spmv(alfi_ctx* ctx, const DevCSR& A, const double* x, double* y, const double* b, double alpha, int mode);
+int launch_scale_rows(alfi_ctx* ctx, double* y, const double* x, const double* d, double a, int64_t n);  // y = a d x
+int launch_remove_mean(alfi_ctx* ctx, double* x, int64_t n);
+int launch_xmy(alfi_ctx* ctx, double* w, const double* b, int64_t n);                                   // w = b - w                                            // x -= mean(x)
 // halo helpers
 int launch_halo_pack(alfi_ctx* ctx, double* buf, const double* v, const int32_t* nodes, int64_t nnodes, int bs);
 int launch_halo_add(alfi_ctx* ctx, double* v, const double* buf, const int32_t* rev_nodes, const int32_t* rev_ptr,

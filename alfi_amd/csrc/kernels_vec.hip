@@ -733,3 +733,90 @@ int launch_dense_gemv(alfi_ctx* ctx, const double* A, const double* x, double* y
   ALFI_HIP_CHECK(ctx, hipGetLastError());
   return 0;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// outer saddle-point solve: scalar CSR products with the discrete divergence B / its transpose, diagonal mass scaling,
+// removal of the constant pressure mode.  Off the roofline path (B holds 3 % of the operator's entries).
+// ---------------------------------------------------------------------------------------------------------------------
+template <int LPR>
+__global__ __launch_bounds__(256) void csr_spmv_kernel(int64_t nrows, const int32_t* __restrict__ rowptr,
+                                                        const int32_t* __restrict__ colidx,
+                                                        const double* __restrict__ vals, const double* __restrict__ x,
+                                                        double* __restrict__ y, const double* __restrict__ b,
+                                                        double alpha, int mode) {
+  const int64_t row = ((int64_t)blockIdx.x * 256 + threadIdx.x) / LPR;
+  const int l = threadIdx.x % LPR;
+  double acc = 0.0;
+  if (row < nrows)
+    for (int32_t k = rowptr[row] + l; k < rowptr[row + 1]; k += LPR) acc = __builtin_fma(vals[k], x[colidx[k]], acc);
+#pragma unroll
+  for (int o = LPR / 2; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+  if (row < nrows && l == 0) y[row] = mode == 0 ? acc : (mode == 1 ? b[row] - alpha * acc : y[row] + acc);
+}
+
+int launch_csr_spmv(alfi_ctx* ctx, const DevCSR& A, const double* x, double* y, const double* b, double alpha,
+                    int mode) {
+  if (A.nrows == 0) return 0;
+  const double avg = (double)A.nnz / (double)A.nrows;
+  dim3 block(256);
+  if (avg > 24) {
+    hipLaunchKernelGGL(csr_spmv_kernel<32>, dim3((unsigned)((A.nrows * 32 + 255) / 256)), block, 0, ctx->stream, A.nrows,
+                       A.rowptr, A.colidx, A.vals, x, y, b, alpha, mode);
+  } else if (avg > 6) {
+    hipLaunchKernelGGL(csr_spmv_kernel<8>, dim3((unsigned)((A.nrows * 8 + 255) / 256)), block, 0, ctx->stream, A.nrows,
+                       A.rowptr, A.colidx, A.vals, x, y, b, alpha, mode);
+  } else {
+    hipLaunchKernelGGL(csr_spmv_kernel<2>, dim3((unsigned)((A.nrows * 2 + 255) / 256)), block, 0, ctx->stream, A.nrows,
+                       A.rowptr, A.colidx, A.vals, x, y, b, alpha, mode);
+  }
+  ALFI_HIP_CHECK(ctx, hipGetLastError());
+  return 0;
+}
+
+__global__ void scale_rows_kernel(double* __restrict__ y, const double* __restrict__ x, const double* __restrict__ d,
+                                  double a, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    y[i] = a * d[i] * x[i];
+}
+int launch_scale_rows(alfi_ctx* ctx, double* y, const double* x, const double* d, double a, int64_t n) {
+  ALFI_LAUNCH_EW(scale_rows_kernel, n, y, x, d, a, n);
+  return 0;
+}
+
+__global__ __launch_bounds__(256) void sum_partials_kernel(const double* __restrict__ x, double* __restrict__ partial,
+                                                            int64_t n) {
+  double acc[1] = {0.0};
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)RED_BLOCKS * 256) acc[0] += x[i];
+  block_store_partials<1>(acc, partial);
+}
+__global__ __launch_bounds__(256) void subtract_mean_kernel(double* __restrict__ x, const double* __restrict__ partial,
+                                                             int64_t n) {
+  __shared__ double red[256];
+  double s = 0.0;
+  for (int b = threadIdx.x; b < RED_BLOCKS; b += 256) s += partial[(int64_t)b * RED_MAXV];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  const double mean = red[0] / (double)n;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) x[i] -= mean;
+}
+int launch_remove_mean(alfi_ctx* ctx, double* x, int64_t n) {
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(sum_partials_kernel, dim3(RED_BLOCKS), dim3(256), 0, ctx->stream, x, ctx->red_partial, n);
+  ALFI_HIP_CHECK(ctx, hipGetLastError());
+  hipLaunchKernelGGL(subtract_mean_kernel, ew_grid(n), dim3(256), 0, ctx->stream, x, ctx->red_partial, n);
+  ALFI_HIP_CHECK(ctx, hipGetLastError());
+  return 0;
+}
+
+__global__ void xmy_kernel(double* __restrict__ w, const double* __restrict__ b, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    w[i] = b[i] - w[i];
+}
+int launch_xmy(alfi_ctx* ctx, double* w, const double* b, int64_t n) {
+  ALFI_LAUNCH_EW(xmy_kernel, n, w, b, n);
+  return 0;
+}

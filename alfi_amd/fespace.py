@@ -284,3 +284,29 @@ def coarse_cell_blocks(Vf):
     counts = np.bincount(parent)
     assert counts.min() == counts.max(), "non-uniform interior blocks"
     return node.reshape(-1, counts[0]).astype(np.int32)
+
+
+def injection_map(Vc, Vf):
+    """Fine node carrying each coarse node: the velocity dofs are point evaluations and every
+    coarse node -- vertex, edge midpoint, face barycentre -- is also a node of the once-refined space (coarse edge
+    midpoints become fine vertices, the central child of a coarse face has the coarse face's barycentre), so Firedrake's
+    ``inject`` for these spaces (the third entry of the transfer tuple, alfi/solver.py:595; used to move the Newton state
+    to the coarse levels, alfi/stabilisation.py:41) is the index map returned here.  (num coarse nodes,) int32."""
+    scale = 3.0 * 2.0 ** 12    # integer lattice fine enough to separate nodes (spacing >= span / (6 N)), 3 axes fit int64
+    lo = Vf.node_coords.min(axis=0)
+    span = (Vf.node_coords.max(axis=0) - lo).max()
+
+    def key(x):
+        q = np.rint((x - lo) / span * scale).astype(np.int64)
+        k = q[:, 0]
+        for a in range(1, x.shape[1]):
+            k = k * np.int64(4 * scale) + q[:, a]
+        return k
+    kf, kc = key(Vf.node_coords), key(Vc.node_coords)
+    order = np.argsort(kf)
+    pos = np.searchsorted(kf[order], kc)
+    pos[pos >= len(kf)] = len(kf) - 1
+    out = order[pos]
+    if not np.array_equal(kf[out], kc):
+        raise ValueError("a coarse node is not a node of the fine space: inject is not a nodal map for this element")
+    return out.astype(np.int32)

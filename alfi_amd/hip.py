@@ -7,7 +7,7 @@ import ctypes
 import numpy as np
 
 from . import _lib
-from ._lib import BsrHost, vp
+from ._lib import BsrHost, CsrHost, vp
 
 
 class AlfiHipError(RuntimeError):
@@ -213,6 +213,13 @@ class Transfer(object):
                                                ctypes.byref(DIT), blk.shape[0], blk.shape[1], _ptr(blk), _ptr(K),
                                                _ptr(D), ctypes.byref(h)))
         self.h = h
+        inj = getattr(T, "inject_map", None)
+        if inj is not None and not getattr(coarse, "n_own", None) and not getattr(fine, "n_own", None):
+            inj = np.ascontiguousarray(inj, dtype=np.int32)
+            ctx.check(ctx.lib.alfi_transfer_set_injection(h, _ptr(inj)))
+
+    def inject(self, xf, xc):
+        self.ctx.check(self.ctx.lib.alfi_inject(self.h, xf.ptr, xc.ptr))
 
     def update(self, nu, gamma):
         self.ctx.check(self.ctx.lib.alfi_transfer_update(self.h, float(nu), float(gamma)))
@@ -316,3 +323,55 @@ class Multigrid(object):
             t.close()
         for l in self.levels:
             l.close()
+
+
+class Saddle(object):
+    """Outer solve of one Newton step (alfi/solver.py:386-422): FGMRES around PCFIELDSPLIT-Schur-full with the device
+    multigrid as fieldsplit_0 and DGMassInv (solver.py:15-38) as fieldsplit_1."""
+
+    def __init__(self, mg, B, mass_diag, nu, gamma, remove_constant_nullspace=True):
+        """mg: hip.Multigrid; B: scipy CSR (pressure dofs x velocity dofs); mass_diag: diagonal of the P0 mass matrix."""
+        import scipy.sparse as sp
+        self.mg, self.ctx = mg, mg.ctx
+        B = sp.csr_matrix(B)
+        B.sort_indices()
+        BT = B.T.tocsr()
+        BT.sort_indices()
+        keep = []
+
+        def st(M):
+            rp = np.ascontiguousarray(M.indptr, dtype=np.int32)
+            ci = np.ascontiguousarray(M.indices, dtype=np.int32)
+            va = np.ascontiguousarray(M.data, dtype=np.float64)
+            keep.extend([rp, ci, va])
+            return CsrHost(M.shape[0], M.shape[1], _ptr(rp), _ptr(ci), _ptr(va))
+        sB, sBT = st(B), st(BT)
+        md = np.ascontiguousarray(mass_diag, dtype=np.float64)
+        h = vp()
+        self.ctx.check(self.ctx.lib.alfi_saddle_create(mg.h, ctypes.byref(sB), ctypes.byref(sBT), _ptr(md), float(nu),
+                                                       float(gamma), 1 if remove_constant_nullspace else 0,
+                                                       ctypes.byref(h)))
+        self.h = h
+        self.n_u, self.n_p = B.shape[1], B.shape[0]
+        self.n = self.n_u + self.n_p
+
+    def update(self, nu, gamma):
+        self.ctx.check(self.ctx.lib.alfi_saddle_update(self.h, float(nu), float(gamma)))
+
+    def mult(self, x, y):
+        self.ctx.check(self.ctx.lib.alfi_saddle_mult(self.h, x.ptr, y.ptr))
+
+    def precond(self, x, y):
+        self.ctx.check(self.ctx.lib.alfi_saddle_precond(self.h, x.ptr, y.ptr))
+
+    def solve(self, b, x, rtol=1e-8, atol=1e-8, max_it=500, restart=30):
+        """Returns (iterations, true residual norm)."""
+        its, rn = ctypes.c_int(), ctypes.c_double()
+        self.ctx.check(self.ctx.lib.alfi_saddle_solve(self.h, b.ptr, x.ptr, float(rtol), float(atol), int(max_it),
+                                                      int(restart), ctypes.byref(its), ctypes.byref(rn)))
+        return its.value, rn.value
+
+    def close(self):
+        if self.h:
+            self.ctx.lib.alfi_saddle_destroy(self.h)
+            self.h = None

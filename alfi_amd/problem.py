@@ -16,7 +16,8 @@ import scipy.sparse as sp
 
 from . import _hostlib
 from .elements import velocity_element
-from .fespace import VectorFunctionSpace, vector_prolongation, nodal_prolongation, coarse_cell_blocks
+from .fespace import (VectorFunctionSpace, vector_prolongation, nodal_prolongation, coarse_cell_blocks,
+                      injection_map)
 from .mesh import rectangle_mesh, box_mesh, mesh_hierarchy
 
 
@@ -178,10 +179,34 @@ def build_transfer_data(Vc, Vf, nu, gamma, graph=None):
         T.PT_plain = BSR.from_scipy(Pn, d).transpose()
     else:
         T.PT_plain = T.PT
+    T.inject_map = injection_map(Vc, Vf)
     T.nu, T.gamma = nu, gamma
     T.n_f, T.n_c = Vf.num_dofs, Vc.num_dofs
     T.bc_dofs_f, T.bc_dofs_c = Vf.bc_dofs, Vc.bc_dofs
     return T
+
+
+def build_pressure_coupling(L):
+    """P0 pressure space of the finest level (solver.py:574-586: ``Q = FunctionSpace(mesh, "DG", 0)``): the discrete
+    divergence B (cells x velocity dofs, B[c, (a, x)] = -int_c d_x phi_a, Dirichlet velocity columns zeroed) and the
+    diagonal pressure mass matrix (cell volumes).  With these the augmented-Lagrangian term of the level operator is
+    gamma B^T M_p^-1 B (solver.py:565-568: ``gamma * inner(cell_avg(div(u)), div(v))``).  Returns scipy CSR B, vol."""
+    V = L.V
+    mesh, d, el = V.mesh, V.dim, V.element
+    g, vol = mesh.cell_geometry()
+    bI = el.reference_tensors()["bI"]                          # (nloc, d+1): cell average of d_i phi_a
+    bdiv = np.einsum("cix,ai->cax", g, bI)                     # cell average of d_x phi_a
+    nc, nloc = V.cell_nodes.shape
+    rows = np.repeat(np.arange(nc), nloc * d)
+    cols = (V.cell_nodes[:, :, None] * d + np.arange(d)[None, None, :]).reshape(nc, -1).ravel()
+    vals = (-vol[:, None, None] * bdiv).reshape(nc, -1).ravel()
+    B = sp.csr_matrix((vals, (rows, cols)), shape=(nc, V.num_dofs))
+    keep = np.ones(V.num_dofs)
+    keep[V.bc_dofs] = 0.0
+    B = (B @ sp.diags(keep)).tocsr()
+    B.eliminate_zeros()
+    B.sort_indices()
+    return B, vol
 
 
 def build_hierarchy(problem, nref, k, Re, gamma=1e4, advect=True, patches=True, verbose=False):

@@ -258,3 +258,80 @@ class HipMG(object):
             self.mg.vcycle(db, dx)
         if xwb is not None:
             xwb[:] = dx.get()
+
+
+class DGMassInv(object):
+    """The pressure-block preconditioner of the reference (alfi/solver.py:15-38), same PCPython protocol:
+    ``y = -(nu + gamma) M_p^-1 x`` with the (diagonal, P0) pressure mass matrix.  ``pc.getAttr`` style context: the
+    ``PC`` passed in must carry ``attrs["nu"], attrs["gamma"], attrs["mass_diag"]`` (the reference pulls nu and gamma
+    from the application context, solver.py:17-21)."""
+
+    def initialize(self, pc):
+        self.update(pc)
+
+    def update(self, pc):
+        self.nu, self.gamma = float(pc.getAttr("nu")), float(pc.getAttr("gamma"))
+        self.minv = 1.0 / np.asarray(pc.getAttr("mass_diag"), dtype=np.float64)
+
+    def apply(self, pc, x, y):
+        y[...] = -(self.nu + self.gamma) * self.minv * np.asarray(x)
+
+    def applyTranspose(self, pc, x, y):
+        raise NotImplementedError("Sorry!")
+
+
+def outer_solver(tdim, fieldsplit_0, high_accuracy=False):
+    """The ``outer`` dictionary of alfi/solver.py:402-499 for solver_type almg (Newton keys included verbatim; only the
+    linear-solve keys are acted on by ``HipOuterSolver``)."""
+    outer = {
+        "snes_type": "newtonls", "snes_max_it": 20, "snes_linesearch_type": "basic", "snes_linesearch_maxstep": 1.0,
+        "snes_monitor": None, "snes_linesearch_monitor": None, "snes_converged_reason": None,
+        "ksp_type": "fgmres", "ksp_monitor_true_residual": None, "ksp_converged_reason": None,
+        "mat_type": "nest", "ksp_max_it": 500,
+        "pc_type": "fieldsplit", "pc_fieldsplit_type": "schur",
+        "pc_fieldsplit_schur_factorization_type": "full", "pc_fieldsplit_schur_precondition": "user",
+        "fieldsplit_0": fieldsplit_0,
+        "fieldsplit_1": {"ksp_type": "preonly", "pc_type": "python", "pc_python_type": "alfi_amd.solver.DGMassInv"},
+    }
+    if high_accuracy:
+        outer.update({"ksp_rtol": 1.0e-12, "ksp_atol": 1.0e-12})
+    elif tdim == 2:
+        outer.update({"ksp_rtol": 1.0e-9, "ksp_atol": 1.0e-10})
+    else:
+        outer.update({"ksp_rtol": 1.0e-8, "ksp_atol": 1.0e-8})
+    return outer
+
+
+class HipOuterSolver(object):
+    """One linear solve of the reference's outer iteration (solver.py:386-422) on the GPU: KSPFGMRES (restart 30, the
+    PETSc default the reference does not override) around PCFIELDSPLIT-Schur-full, fieldsplit_0 = the device PCMG
+    (``HipMG``), fieldsplit_1 = ``DGMassInv``.  ``solve(f, g)`` returns (u, p, iterations, true residual norm)."""
+
+    def __init__(self, ctx, levels, transfers, params, restriction=False, coarse_inv=None):
+        from .problem import build_pressure_coupling
+        if params.get("ksp_type") != "fgmres" or params.get("pc_type") != "fieldsplit" \
+                or params.get("pc_fieldsplit_type") != "schur" \
+                or params.get("pc_fieldsplit_schur_factorization_type") != "full" \
+                or params.get("pc_fieldsplit_schur_precondition") != "user":
+            raise NotImplementedError("outer solver must be fgmres + fieldsplit schur/full/user (solver.py:402-411)")
+        fs1 = params.get("fieldsplit_1", {})
+        if fs1.get("ksp_type") != "preonly" or not str(fs1.get("pc_python_type", "")).endswith("DGMassInv"):
+            raise NotImplementedError("fieldsplit_1 must be preonly + DGMassInv (solver.py:386-390)")
+        self.ctx = ctx
+        self.hmg = HipMG(ctx, levels, transfers, params["fieldsplit_0"], restriction=restriction, coarse_inv=coarse_inv)
+        if not self.hmg.full:
+            raise NotImplementedError("fieldsplit_0 must use pc_mg_type full (solver.py:366)")
+        L = levels[-1]
+        self.B, self.mass_diag = build_pressure_coupling(L)
+        self.saddle = hip.Saddle(self.hmg.mg, self.B, self.mass_diag, L.nu, L.gamma, remove_constant_nullspace=True)
+        self.rtol, self.atol = float(params.get("ksp_rtol", 1e-5)), float(params.get("ksp_atol", 1e-50))
+        self.max_it = int(params.get("ksp_max_it", 10000))
+        self.restart = int(params.get("ksp_gmres_restart", 30))
+        self.n_u, self.n_p = self.saddle.n_u, self.saddle.n_p
+
+    def solve(self, f, g=None):
+        b = np.concatenate([np.asarray(f, dtype=np.float64), np.zeros(self.n_p) if g is None else np.asarray(g)])
+        db, dx = self.ctx.vec(b), self.ctx.vec(self.n_u + self.n_p)
+        its, rn = self.saddle.solve(db, dx, self.rtol, self.atol, self.max_it, self.restart)
+        x = dx.get()
+        return x[:self.n_u], x[self.n_u:], its, rn

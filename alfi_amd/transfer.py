@@ -133,6 +133,19 @@ class AutoSchoeberlTransfer(object):
             coarse.dat.data[:] = drc.get().reshape(coarse.dat.data.shape)
 
 
+    def inject(self, fine, coarse):
+        """firedrake.inject for the nodal velocity spaces (the third entry of the transfer tuple, solver.py:595)."""
+        Vc, Vf = coarse.function_space(), fine.function_space()
+        key = Vf.num_dofs
+        if key not in self.solver:
+            self.solver[key] = self._setup(Vc, Vf)
+            self.prev_parameters[key] = [float(p) for p in self.parameters]
+        dev, ctx = self.solver[key][0], self.ctx
+        dxf, dxc = ctx.vec(fine.dat.data.ravel()), ctx.vec(Vc.num_dofs)
+        dev.inject(dxf, dxc)
+        coarse.dat.data[:] = dxc.get().reshape(coarse.dat.data.shape)
+
+
 class PkP0SchoeberlTransfer(AutoSchoeberlTransfer):
     """transfer.py:312-356: forms nu (2 sym grad u, grad v) + gamma (cell_avg div u, div v); the standard transfer is
     the bubble transfer for 3-D P1+FB and nodal interpolation otherwise (decided in fespace.vector_prolongation)."""

@@ -164,6 +164,12 @@ int alfi_prolong(alfi_transfer* tr, const double* dxc, double* dxf);
  *           robust = 0: coarse = P_plain^T fine (firedrake.restrict).  Coarse Dirichlet dofs zeroed; fine untouched. */
 int alfi_restrict(alfi_transfer* tr, const double* drf, double* drc, int robust);
 
+/* inject: coarse = nodal values of fine at the coarse nodes (firedrake.inject, the third entry of the transfer tuple,
+ * alfi/solver.py:595; moves the Newton state to the coarse levels, alfi/stabilisation.py:41).  fine_node_host[i] = fine
+ * node coinciding with coarse node i (all velocity dofs are point evaluations).  Serial levels only. */
+int alfi_transfer_set_injection(alfi_transfer* tr, const int32_t* fine_node_host);
+int alfi_inject(alfi_transfer* tr, const double* dxf, double* dxc);
+
 /* ---- multigrid cycle: PETSc PCMG [3P], alfi/solver.py:359-379 ------------------------------------------------------ */
 /* levels[0] = coarsest (needs alfi_coarse_set_inverse), levels[l] l >= 1 need factored patches; transfers[l-1] links
  * level l-1 and l.  k = smoother iterations (solver.py:309-310), robust_restriction = the --restriction flag. */
@@ -174,6 +180,36 @@ int alfi_mg_destroy(alfi_mg* mg);
 int alfi_mg_vcycle(alfi_mg* mg, const double* db, double* dx);
 /* pc_mg_type full (solver.py:366): x <- F(b), x need not be initialised (PCMGFCycle_Private) */
 int alfi_mg_fcycle(alfi_mg* mg, const double* db, double* dx);
+
+/* ---- outer solve around the path: alfi/solver.py:386-422, 463-499 ------------------------------------------------------- */
+/* The linear system of one Newton step, [A B^T; B 0] [u; p] = [f; g], solved as the reference configures PETSc:
+ * KSPFGMRES(restart), right-preconditioned by PCFIELDSPLIT Schur with the FULL factorisation (solver.py:407-411):
+ *   y_u = MG(b_u);  y_p = S~^-1 (b_p - B y_u);  y_u = MG(b_u - B^T y_p),
+ * fieldsplit_0 = one PCMG full cycle (alfi_mg_fcycle; solver.py:359-379), fieldsplit_1 = DGMassInv:
+ * S~^-1 q = -(nu + gamma) M_p^-1 q (solver.py:15-38) with the diagonal P0 mass matrix M_p.  A is the finest level's
+ * operator (with the augmented-Lagrangian term), B the discrete divergence (rows = pressure dofs, Dirichlet velocity
+ * columns zero), BT its transpose; scalar CSR, host arrays.  remove_constant_nullspace: orthogonalise the pressure part
+ * against constants after every preconditioner application (the nullspace alfi attaches for enclosed flows,
+ * alfi/solver.py:267-272 / problem has_nullspace). */
+typedef struct alfi_saddle alfi_saddle;
+typedef struct {
+  int64_t nrows, ncols;
+  const int32_t* rowptr; /* host */
+  const int32_t* colidx; /* host */
+  const double* vals;    /* host */
+} alfi_csr_host;
+int alfi_saddle_create(alfi_mg* mg, const alfi_csr_host* B, const alfi_csr_host* BT, const double* mass_diag_host,
+                       double nu, double gamma, int remove_constant_nullspace, alfi_saddle** out);
+int alfi_saddle_destroy(alfi_saddle* s);
+int alfi_saddle_update(alfi_saddle* s, double nu, double gamma);
+/* db, dx: device vectors of n_u + n_p doubles (velocity dofs first).  Zero initial guess.  Convergence as KSP's default
+ * test on the (recurrence) residual norm: ||r|| <= max(rtol ||b||, atol); max_it iterations at most (solver.py:404,
+ * 463-499).  Returns the iteration count and the final true residual norm. */
+int alfi_saddle_solve(alfi_saddle* s, const double* db, double* dx, double rtol, double atol, int max_it, int restart,
+                      int* iterations, double* residual_norm);
+/* y = [A B^T; B 0] x and y = P^-1 x on device vectors (tests, monitors) */
+int alfi_saddle_mult(alfi_saddle* s, const double* dx, double* dy);
+int alfi_saddle_precond(alfi_saddle* s, const double* dx, double* dy);
 
 #ifdef __cplusplus
 }

@@ -385,3 +385,78 @@ def oracle_transfer(T, L, schoeberl_restriction=False):
     skel = np.flatnonzero(np.repeat(skeleton_node_mask(V), V.dim))
     st = SchoeberlTransfer(T.P.to_scipy(), T.nu * K + T.gamma * D, T.gamma * D, T.blk_dofs, skel)
     return _TransferPair(st, T.PT_plain.to_scipy().tocsr(), schoeberl_restriction)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# outer solve of one Newton step: KSPFGMRES + PCFIELDSPLIT Schur (full factorisation) with fieldsplit_0 = PCMG full cycle
+# and fieldsplit_1 = DGMassInv (alfi/solver.py:15-38, 386-422, 463-499)
+# ---------------------------------------------------------------------------------------------------------------------
+def saddle_solve(mg, A, B, mass_diag, nu, gamma, b, rtol=1e-8, atol=1e-8, max_it=500, restart=30,
+                 remove_constant_nullspace=True):
+    """[A B^T; B 0] x = b by right-preconditioned FGMRES(restart), classical Gram-Schmidt, zero initial guess, KSP's
+    default convergence test on the recurrence residual.  Preconditioner (PCApply_FieldSplit_Schur, FULL [3P]):
+    y_u = MG(b_u); y_p = -(nu + gamma) M_p^-1 (b_p - B y_u)  (DGMassInv.apply, solver.py:26-35); y_u = MG(b_u - B^T y_p);
+    constants removed from y_p (the nullspace attached for enclosed flows).  Returns (x, iterations, residual history)."""
+    nu_ = A.shape[0]
+    n = nu_ + B.shape[0]
+    minv = 1.0 / np.asarray(mass_diag)
+
+    def K(x):
+        return np.concatenate([A @ x[:nu_] + B.T @ x[nu_:], B @ x[:nu_]])
+
+    def P(v):
+        yu = mg.fcycle(v[:nu_])
+        yp = -(nu + gamma) * minv * (v[nu_:] - B @ yu)
+        yu = mg.fcycle(v[:nu_] - B.T @ yp)
+        if remove_constant_nullspace:
+            yp = yp - yp.mean()
+        return np.concatenate([yu, yp])
+    x = np.zeros(n)
+    r = b.copy()
+    bnorm = np.linalg.norm(b)
+    tol = max(rtol * bnorm, atol)
+    hist = [bnorm]
+    its = 0
+    converged = bnorm <= tol
+    while not converged and its < max_it:
+        beta = np.linalg.norm(r)
+        V = np.zeros((restart + 1, n))
+        Z = np.zeros((restart, n))
+        H = np.zeros((restart + 1, restart))
+        cs, sn, grs = np.zeros(restart), np.zeros(restart), np.zeros(restart + 1)
+        V[0], grs[0] = r / beta, beta
+        j = 0
+        while j < restart and its < max_it:
+            Z[j] = P(V[j])
+            w = K(Z[j])
+            h = V[:j + 1] @ w
+            w = w - h @ V[:j + 1]
+            tt = np.linalg.norm(w)
+            hcol = np.concatenate([h, [tt]])
+            for i in range(j):
+                t = hcol[i]
+                hcol[i] = cs[i] * t + sn[i] * hcol[i + 1]
+                hcol[i + 1] = -sn[i] * t + cs[i] * hcol[i + 1]
+            den = np.hypot(hcol[j], hcol[j + 1])
+            cs[j], sn[j] = hcol[j] / den, hcol[j + 1] / den
+            grs[j + 1] = -sn[j] * grs[j]
+            grs[j] = cs[j] * grs[j]
+            hcol[j], hcol[j + 1] = den, 0.0
+            H[:j + 2, j] = hcol
+            its += 1
+            hist.append(abs(grs[j + 1]))
+            j += 1
+            if abs(grs[j]) <= tol:
+                converged = True
+                break
+            if j < restart:
+                V[j] = w / tt
+        y = np.zeros(j)
+        for i in range(j - 1, -1, -1):
+            y[i] = (grs[i] - H[i, i + 1:j] @ y[i + 1:j]) / H[i, i]
+        x = x + y @ Z[:j]
+        if converged:
+            break
+        r = b - K(x)
+        converged = np.linalg.norm(r) <= tol
+    return x, its, hist

@@ -180,6 +180,11 @@ def test_schoeberl_transfer_object_protocol():
     ref[lv[0].bc_dofs] = 0
     assert np.abs(cr.dat.data.ravel() - ref).max() < 1e-8 * np.abs(ref).max()
     assert np.array_equal(fr.dat.data.ravel(), r)
+    # inject (solver.py:595): nodal values at the coarse nodes; inject(plain prolongation) is the identity
+    fi, ci = Function(Vf, tr[-1].PT_plain.to_scipy().T @ uc), Function(Vc)
+    vt.inject(fi, ci)
+    assert np.abs(ci.dat.data.ravel() - uc).max() < 1e-13
+    assert np.array_equal(ci.dat.data, fi.dat.data[tr[-1].inject_map])
     # changing gamma triggers a rebuild of the interior solves (transfer.py:173-184)
     gamma.assign(10.0)
     vt.prolong(coarse, fine)

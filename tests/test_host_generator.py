@@ -193,3 +193,27 @@ def test_bsr_helpers():
     sub = B.select_rows(rows).to_scipy().toarray()
     full = B.to_scipy().toarray().reshape(12, 2, -1)
     assert np.array_equal(sub, full[rows].reshape(6, -1))
+
+
+@pytest.mark.parametrize("mk,k", [(lambda: TwoDimLidDrivenCavityProblem(3), 2),
+                                  (lambda: ThreeDimLidDrivenCavityProblem(2), 1),
+                                  (lambda: ThreeDimLidDrivenCavityProblem(2), 2)])
+def test_divergence_matrix_reproduces_the_augmented_lagrangian_term(mk, k):
+    """gamma (cell_avg div u, div v) = gamma B^T M_p^-1 B with P0 pressures (solver.py:565-568):
+    the level operator at two values of gamma differs by exactly that on the free dofs; B annihilates nothing else."""
+    from alfi_amd.problem import build_pressure_coupling
+    import scipy.sparse as sp
+    lv1, _ = build_hierarchy(mk(), 1, k, Re=10.0, gamma=0.0)
+    lv2, _ = build_hierarchy(mk(), 1, k, Re=10.0, gamma=7.0)
+    L = lv2[-1]
+    B, vol = build_pressure_coupling(L)
+    diff = (L.A.to_scipy() - lv1[-1].A.to_scipy()).tocsr()
+    ref = (7.0 * (B.T @ sp.diags(1.0 / vol) @ B)).tocsr()
+    assert abs(diff - ref).max() < 1e-11 * abs(ref).max()
+    assert np.isclose(vol.sum(), 2.0 ** L.V.dim)
+    # divergence of a linear field u = (x, 0, ..): -int div u = -|cell| on cells away from the Dirichlet boundary
+    u = np.zeros((L.V.num_nodes, L.V.dim))
+    u[:, 0] = L.V.node_coords[:, 0]
+    Bfull_u = B @ u.ravel()
+    interior = ~L.V.bc_node_mask[L.V.cell_nodes].any(axis=1)
+    assert interior.any() and np.allclose(Bfull_u[interior], -vol[interior])
