@@ -222,3 +222,84 @@ def test_spmv_segmented_kernel_on_ragged_rows(ctx, bs):
     lvl.residual(db, dx, dy)
     assert np.abs(dy.get() - (b - ref)).max() / np.abs(ref).max() < 1e-13
     lvl.close()
+
+
+@pytest.mark.parametrize("bs", [2, 3])
+def test_patch_sizes_1_to_160_all_row_piece_combinations(ctx, bs):
+    """Ragged synthetic patches of every size the library accepts (n_p = bs .. 160, i.e. every combination of the row
+    pieces 128/64/32/16/8/4/2 of the inverse layout, odd n_p with the zero padding row, single-node patches, nodes shared
+    by many patches and nodes in no patch) on a random diagonally dominant block operator: inverses, additive apply and a
+    multiplicative sweep against NumPy; the empty patch set; sizes above 160 are refused."""
+    import scipy.sparse as sp
+    from alfi_amd import hip
+    from alfi_amd.problem import BSR
+    rng = np.random.default_rng(bs)
+    nb = 400
+    M = sp.random(nb * bs, nb * bs, density=0.02, random_state=7, format="csr")
+    M = M + M.T + sp.identity(nb * bs) * 25.0
+    A = BSR.from_scipy(sp.csr_matrix(M), bs)
+    S = A.to_scipy().tocsr()
+    max_nodes = 160 // bs
+    sizes = list(range(1, max_nodes + 1)) + [1, 2, max_nodes, max_nodes]
+    ptr, dofs = [0], []
+    for sz in sizes:
+        nodes = np.sort(rng.choice(nb - 5, sz, replace=False))        # the last 5 nodes are in no patch
+        d = (nodes[:, None] * bs + np.arange(bs)).ravel()
+        dofs.append(d)
+        ptr.append(ptr[-1] + len(d))
+    ptr, dofs = np.array(ptr, dtype=np.int64), np.concatenate(dofs).astype(np.int32)
+    bc = np.array([0, 1], dtype=np.int32)
+    lvl = hip.Level(ctx, A, bc)
+    lvl.set_patches(ptr, dofs)
+    lvl.factor()
+    x = rng.standard_normal(nb * bs)
+    ref = np.zeros_like(x)
+    invs = []
+    for p in range(len(sizes)):
+        d = dofs[ptr[p]:ptr[p + 1]]
+        Ainv = np.linalg.inv(S[d][:, d].toarray())
+        invs.append(Ainv)
+        got = lvl.patch_inverse(p, len(d))
+        assert np.abs(got - Ainv).max() < 1e-11 * np.abs(Ainv).max(), (p, len(d))
+        ref[d] += Ainv @ x[d]
+    ref[bc] = x[bc]
+    dx, dy = ctx.vec(x), ctx.vec(nb * bs)
+    lvl.patch_apply(dx, dy)
+    assert np.abs(dy.get() - ref).max() < 1e-12 * np.abs(ref).max()
+    # multiplicative sweep in a scrambled order, symmetrised (patches of at most 64 nodes: larger ones are refused)
+    if max(sizes) > 64:
+        with pytest.raises(hip.AlfiHipError):
+            lvl.set_multiplicative(np.arange(len(sizes)), True)
+        keep = [p for p, sz in enumerate(sizes) if sz <= 64]
+        dofs = np.concatenate([dofs[ptr[p]:ptr[p + 1]] for p in keep]).astype(np.int32)
+        invs = [invs[p] for p in keep]
+        sizes = [sizes[p] for p in keep]
+        ptr = np.concatenate([[0], np.cumsum([s_ * bs for s_ in sizes])]).astype(np.int64)
+        lvl.set_patches(ptr, dofs)
+        lvl.factor()
+    order = rng.permutation(len(sizes))
+    nw = lvl.set_multiplicative(order, True)
+    assert 1 <= nw <= len(sizes)
+    y, r = np.zeros_like(x), x.copy()
+    Sc = S.tocsc()
+    for p in list(order) + list(order[::-1]):
+        d = dofs[ptr[p]:ptr[p + 1]]
+        dyp = invs[p] @ r[d]
+        y[d] += dyp
+        r -= Sc[:, d] @ dyp
+    y[bc] = x[bc]
+    lvl.patch_apply(dx, dy)
+    assert np.abs(dy.get() - y).max() < 1e-11 * np.abs(y).max()
+    lvl.set_multiplicative(None, False)
+    # empty patch set: the smoother reduces to the Dirichlet copy
+    lvl.set_patches(np.zeros(1, dtype=np.int64), np.zeros(0, dtype=np.int32))
+    lvl.factor()
+    lvl.patch_apply(dx, dy)
+    e = np.zeros_like(x)
+    e[bc] = x[bc]
+    assert np.array_equal(dy.get(), e)
+    # one patch too large
+    big = (np.arange(max_nodes + 1)[:, None] * bs + np.arange(bs)).ravel().astype(np.int32)
+    with pytest.raises(hip.AlfiHipError):
+        lvl.set_patches(np.array([0, len(big)], dtype=np.int64), big)
+    lvl.close()
