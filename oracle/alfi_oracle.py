@@ -4,8 +4,9 @@ PARITY UNPINNED: the reference (florianwechsung/alfi) ships no tests, golden vec
 lives in un-vendored, un-pinned third-party code (PETSc PCPATCH / PCMG / KSPFGMRES / MatMult, Firedrake PatchPC and
 prolong/restrict, PyOP2 par_loops) that is not installed here.  This oracle therefore follows
 the reference's *call sites and data flow* (cited per function) plus the documented behaviour of those libraries; it
-is pinned only by its own mathematical property tests (tests/test_oracle_*.py) and committed fixtures produced by it
-(tests/golden/).
+is pinned only by its own mathematical property tests (tests/test_host_generator.py, tests/test_graddiv.py), committed
+fixtures produced by it (tests/golden/) and -- for the bubble transfer, the one place where the reference ships native
+code -- by the reference's own C kernels compiled into oracle/_ref/ (oracle/build_ref.py, tests/test_ref_kernels.py).
 
 Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.  The product path
 (alfi_amd/) never does.
