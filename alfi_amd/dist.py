@@ -70,14 +70,16 @@ def choose_splits(levels, world, min_dofs=400000):
 class LevelPart(object):
     """One rank's view of one level: owned range, ghosts, local numbering, halo plan."""
 
-    def __init__(self, level, bs, splits, rank, ghosts):
+    def __init__(self, level, bs, splits, rank, ghosts, force_distributed=False):
         self.level, self.bs, self.splits, self.rank = level, bs, np.asarray(splits, dtype=np.int64), rank
         self.lo, self.hi = int(splits[rank]), int(splits[rank + 1])
         self.nb_own = self.hi - self.lo
         self.ghosts = np.asarray(ghosts, dtype=np.int64)              # global ids, ascending => grouped by owner
         self.nb_ghost = self.ghosts.shape[0]
         self.nb_loc = self.nb_own + self.nb_ghost
-        self.distributed = bool(np.count_nonzero(np.diff(self.splits)) > 1)
+        # force_distributed: run the exchange points even when one rank owns everything (a 1-rank NCCL group on the
+        # single-GPU test box exercises the RCCL code path: empty halos, 1-rank all-reduces)
+        self.distributed = bool(np.count_nonzero(np.diff(self.splits)) > 1) or bool(force_distributed)
         owner = np.searchsorted(self.splits, self.ghosts, side="right") - 1
         world = len(splits) - 1
         self.recv_counts = np.bincount(owner, minlength=world).astype(np.int64)   # ghost nodes per owner
@@ -178,14 +180,15 @@ def compute_ghosts(levels, transfers, splits, l, rank):
     return g[(g < lo) | (g >= hi)]
 
 
-def build_parts(levels, transfers, splits, rank, exchange_lists=None):
+def build_parts(levels, transfers, splits, rank, exchange_lists=None, force_distributed_above=None):
     """LevelPart for every level on ``rank``.  ``exchange_lists(obj) -> list over ranks`` is an all-gather of Python
     objects (torch.distributed.all_gather_object); None = compute every rank's ghost lists locally (tests)."""
     world = len(splits[0]) - 1
     parts = []
     mine = []
     for l, L in enumerate(levels):
-        p = LevelPart(l, L.bs, splits[l], rank, compute_ghosts(levels, transfers, splits, l, rank))
+        force = force_distributed_above is not None and l > 0 and L.n >= force_distributed_above
+        p = LevelPart(l, L.bs, splits[l], rank, compute_ghosts(levels, transfers, splits, l, rank), force)
         parts.append(p)
         mine.append(p.ghosts_by_owner())
     if exchange_lists is not None:
@@ -393,7 +396,7 @@ class DistMultigrid(object):
     only the rank's rows are uploaded)."""
 
     def __init__(self, levels, transfers, k, robust_restriction=False, group=None, device=None, min_dofs=400000,
-                 coarse_inverse=None, verbose=False):
+                 coarse_inverse=None, verbose=False, force_distributed=False):
         import torch
         from . import hip
         self.comm = Comm(group)
@@ -403,7 +406,8 @@ class DistMultigrid(object):
         self.device = device
         self.stream = torch.cuda.Stream(device=device)
         self.splits = choose_splits(levels, self.comm.world, min_dofs)
-        self.parts = build_parts(levels, transfers, self.splits, rank, self.comm.all_gather_object)
+        self.parts = build_parts(levels, transfers, self.splits, rank, self.comm.all_gather_object,
+                                 force_distributed_above=min_dofs if force_distributed else None)
         llev, ltr, self.lmin = localize(levels, transfers, self.parts)
         self.local_levels, self.local_transfers = llev, ltr
         self.k = k

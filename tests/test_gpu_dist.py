@@ -62,3 +62,48 @@ def test_partitioned_cycles_match_single_gpu(case, world, robust, tmp_path):
     assert np.abs(dv - sv).max() / np.abs(sv).max() < CYCLE_TOL
     assert np.abs(df - sf).max() / np.abs(sf).max() < CYCLE_TOL
     assert np.abs(dv - ov).max() / np.abs(ov).max() < CYCLE_TOL
+
+
+def test_rccl_code_path_with_a_one_rank_group(tmp_path):
+    """The NCCL (= RCCL) transport of alfi_amd.dist on the one GPU of the box: a 1-rank process group with the exchange
+    points forced on (empty halos, 1-rank all-reduces issued on the library's stream from inside the callbacks).  Checks
+    that torch's RCCL backend accepts exactly the calls the 8-GPU run makes and that the cycle still matches the
+    single-GPU result."""
+    import textwrap
+    script = tmp_path / "one_rank.py"
+    script.write_text(textwrap.dedent('''
+        import os, sys
+        import numpy as np
+        sys.path.insert(0, %r)
+        import torch, torch.distributed as dist
+        torch.cuda.set_device(0)
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+        from tests.test_dist_cpu import _hier
+        from alfi_amd import hip
+        from alfi_amd.dist import DistMultigrid
+        lv, tr, k, _ = _hier("3d-P2FB")
+        dmg = DistMultigrid(lv, tr, k, robust_restriction=True, min_dofs=1, force_distributed=True)
+        assert dmg.comm.backend == "nccl" and all(p.distributed for p in dmg.parts[1:])
+        b = np.random.default_rng(0).standard_normal(lv[-1].n)
+        b[lv[-1].bc_dofs] = 0.0
+        db, dx = dmg.local_vec(b), dmg.local_vec()
+        dmg.vcycle(db, dx); dmg.vcycle(db, dx)
+        xv = dmg.owned(dx)
+        dmg.fcycle(db, dx)
+        xf = dmg.owned(dx)
+        comm_ms = dmg.ctx.prof_get()["COMM"]
+        mg = hip.Multigrid(dmg.ctx, lv, tr, k, robust_restriction=True)
+        sb, sx = dmg.ctx.vec(b), dmg.ctx.vec(lv[-1].n)
+        with torch.cuda.stream(dmg.stream):
+            mg.vcycle(sb, sx); mg.vcycle(sb, sx)
+            sv = sx.get()
+            mg.fcycle(sb, sx)
+            sf = sx.get()
+        assert np.abs(xv - sv).max() <= 1e-12 * np.abs(sv).max(), np.abs(xv - sv).max()
+        assert np.abs(xf - sf).max() <= 1e-12 * np.abs(sf).max()
+        dist.destroy_process_group()
+        print("ONE-RANK-RCCL-OK")
+    ''' % ROOT))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    out = subprocess.run([sys.executable, str(script)], env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "ONE-RANK-RCCL-OK" in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]
