@@ -85,11 +85,25 @@ def vcycle_bytes(levels, dmg, k):
     return total, per_level_apply
 
 
+def claim_stdout():
+    """The contract is ONE JSON line on stdout.  Native libraries write there too (RCCL prints a version banner at
+    communicator creation): point file descriptor 1 at stderr for the rest of the run and return a function that writes
+    to the real stdout."""
+    sys.stdout.flush()
+    real = os.dup(1)
+    os.dup2(2, 1)
+
+    def emit(line):
+        os.write(real, (line + "\n").encode())
+    return emit
+
+
 def main_distributed(args, rank, world, local_rank):
     """One process per GPU: the fixed config-4 mesh partitioned over the ranks (strong scaling), halos and reductions over
     RCCL.  Every rank generates the same global hierarchy on its host cores and uploads its own share."""
     import torch
     import torch.distributed as dist
+    emit = claim_stdout()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs MI355X GPUs: the HIP path has no CPU fallback")
     # ALFI_DIST_BACKEND=gloo: functional check of this leg with several ranks sharing one GPU (halos staged through the
@@ -114,7 +128,8 @@ def main_distributed(args, rank, world, local_rank):
 
     t0 = time.time()
     dmg = DistMultigrid(lv, tr, k, robust_restriction=False, coarse_inverse=coarse_inv,
-                        min_dofs=int(os.environ.get("ALFI_DIST_MIN_DOFS", "400000")), verbose=args.verbose)
+                        min_dofs=int(os.environ.get("ALFI_DIST_MIN_DOFS", "400000")), verbose=args.verbose,
+                        force_distributed=os.environ.get("ALFI_DIST_FORCE") == "1")
     dmg.sync()
     t_setup = time.time() - t0
     L = lv[-1]
@@ -189,7 +204,7 @@ def main_distributed(args, rank, world, local_rank):
             "cpu_baseline": {"value": None, "unit": "V-cycles/s", "cores": 0, "kind": "port",
                              "sample": "reported at N=1 only"},
         }
-        print(json.dumps(out), flush=True)
+        emit(json.dumps(out))
     dist.barrier()
     dmg.close()
     dist.destroy_process_group()
@@ -215,13 +230,20 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 or args.gpus > 1:
+    force_dist = os.environ.get("ALFI_DIST_FORCE") == "1"       # 1-rank RCCL group: fixed cost of the exchange points
+    if force_dist and world == 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29577")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+    if world > 1 or args.gpus > 1 or force_dist:
         if world != args.gpus:
             raise SystemExit("--gpus %d needs %d ranks: launch with python -m torch.distributed.run --nnodes=1 "
                              "--nproc-per-node %d --master-addr 127.0.0.1 bench.py --gpus %d ..."
                              % (args.gpus, args.gpus, args.gpus, args.gpus))
         return main_distributed(args, rank, world, local_rank)
 
+    emit = claim_stdout()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
     torch.cuda.set_device(0)
@@ -358,7 +380,7 @@ def main():
                                    "sample": "failed: %r" % (e,)}
     else:
         out["cpu_baseline"] = {"value": None, "unit": "V-cycles/s", "cores": 0, "kind": "port", "sample": "skipped"}
-    print(json.dumps(out), flush=True)
+    emit(json.dumps(out))
     dmg.close()
     ctx.close()
 
