@@ -1,0 +1,155 @@
+"""The solve loop around the hot path: Newton on the stationary Navier-Stokes equations with Reynolds continuation, as
+``alfi.solver.NavierStokesSolver.solve`` / ``alfi.driver.run_solver`` organise it (alfi/solver.py:257-300,
+alfi/driver.py:95-128), every linear solve on the GPU.
+
+Per Newton step (``snes_type newtonls``, basic line search, solver.py:463-472):
+
+1. host: rediscretise the velocity block about the current velocity on every level -- the state reaches the coarse
+   levels by ``inject`` (solver.py:595; here the index map of ``fespace.injection_map``) -- and hand the new values to
+   the device hierarchy (``HipPatchPC.update`` -> re-gather and re-invert every patch, new coarse inverse);
+2. host: nonlinear residual F(u, p) of solver.py:565-568 with the [P_k(+FB)]^d - P0 pair,
+   F_u = A0 u + 1/2 N(u) u + B^T p,  F_p = B u   (N(u) v = (u.grad) v + (v.grad) u, so N(u) u = 2 (u.grad) u);
+3. device: J d = -F by ``alfi_saddle_solve`` (FGMRES + fieldsplit Schur full, PCMG full cycles, DGMassInv).
+
+The generator plays Firedrake's role (assembly, setup time); the arithmetic of the solves is libalfi_hip.so's.
+"""
+import time
+
+import numpy as np
+
+from . import _hostlib, hip
+from .problem import BSR, build_hierarchy, build_pressure_coupling
+from .solver import HipMG, mg_levels_solver, fieldsplit_0_mg, outer_solver
+
+
+def _assemble(L, nu, gamma, adv, wind, with_bc):
+    V = L.V
+    g, vol = V.mesh.cell_geometry()
+    tens = V.element.reference_tensors()
+    A = _hostlib.assemble_bsr(V.cell_nodes, g, vol, tens, V.dim, L.A.rowptr, L.A.colidx, nu=nu, gamma=gamma, adv=adv,
+                              wind=wind if adv else None)
+    if with_bc:
+        _hostlib.apply_bc_bsr(V.num_nodes, V.dim, L.A.rowptr, L.A.colidx, A, np.repeat(V.bc_node_mask, V.dim))
+    return A
+
+
+class HipNavierStokesSolver(object):
+    """``solve(re)`` mirrors NavierStokesSolver.solve (solver.py:257-300): returns (z, info_dict) with the reference's
+    keys Re, nu, linear_iter, nonlinear_iter, time."""
+
+    def __init__(self, problem, nref, k, gamma=1e4, smoothing=None, restriction=False, ctx=None, verbose=False,
+                 snes_rtol=None, snes_atol=None, snes_max_it=20):
+        self.problem, self.gamma, self.verbose = problem, float(gamma), verbose
+        self.ctx = ctx or hip.Context(0)
+        dim = problem.dim
+        self.char_L, self.char_U = problem.char_length(), problem.char_velocity()
+        # hierarchy and device objects are created once (Stokes operator); values are replaced per Newton step
+        self.levels, self.transfers = build_hierarchy(problem, nref, k, Re=0.0, gamma=gamma)
+        self.params = outer_solver(dim, fieldsplit_0_mg(mg_levels_solver(dim, smoothing=smoothing)))
+        self.hmg = HipMG(self.ctx, self.levels, self.transfers, self.params["fieldsplit_0"], restriction=restriction)
+        L = self.levels[-1]
+        self.B, self.vol = build_pressure_coupling(L)                     # Dirichlet columns zeroed: the Jacobian's B
+        self.B_raw, _ = build_pressure_coupling(L, zero_bc_columns=False)  # all columns: the residual's B
+        self.nu = self.char_L * self.char_U
+        self.saddle = hip.Saddle(self.hmg.mg, self.B, self.vol, self.nu, self.gamma, remove_constant_nullspace=True)
+        self.rtol, self.atol = self.params["ksp_rtol"], self.params["ksp_atol"]
+        tol2, tol3 = (1e-9, 1e-8), (1e-8, 1e-8)                            # snes_rtol / snes_atol, solver.py:484-499
+        self.snes_rtol = snes_rtol if snes_rtol is not None else (tol2 if dim == 2 else tol3)[0]
+        self.snes_atol = snes_atol if snes_atol is not None else (tol2 if dim == 2 else tol3)[1]
+        self.snes_max_it = snes_max_it
+        self.n_u, self.n_p = L.n, self.B.shape[0]
+        # state z = (u, p): zero with the Dirichlet values imposed (what Firedrake does to the initial guess)
+        self.u = np.zeros(self.n_u)
+        bc_nodes = L.V.bc_nodes
+        self.u.reshape(-1, dim)[bc_nodes] = problem.driver(L.V.node_coords[bc_nodes])
+        self.p = np.zeros(self.n_p)
+        self.area = float(self.vol.sum())
+
+    # -- host side: state on all levels, operators, residual -------------------------------------------------------------
+    def _winds(self, u):
+        """Current velocity as nodal field on every level (finest given, coarser by inject, solver.py:595)."""
+        d = self.problem.dim
+        w = [None] * len(self.levels)
+        w[-1] = u.reshape(-1, d)
+        for l in range(len(self.levels) - 1, 0, -1):
+            w[l - 1] = w[l][self.transfers[l - 1].inject_map]
+        return w
+
+    def _rediscretise(self, u, adv):
+        winds = self._winds(u)
+        for L, w in zip(self.levels, winds):
+            L.A = BSR(L.A.nbrows, L.A.nbcols, L.bs, L.A.rowptr, L.A.colidx,
+                      _assemble(L, self.nu, self.gamma, adv, np.ascontiguousarray(w), True))
+            L.nu = self.nu
+        self.hmg.update(self.levels)
+        self.hmg.mg.levels[0].update_values(self.levels[0].A.vals)
+        self.hmg.mg.levels[0].set_coarse_inverse(hip.coarse_inverse(self.levels[0].A))
+
+    def residual(self, u, p, adv):
+        """F(u, p) of solver.py:565-568 (rhs = 0), Dirichlet rows zeroed (``bc.zero(F)``, solver.py:282-286)."""
+        L = self.levels[-1]
+        d = self.problem.dim
+        wind = np.ascontiguousarray(u.reshape(-1, d))
+        A0 = BSR(L.A.nbrows, L.A.nbcols, L.bs, L.A.rowptr, L.A.colidx,
+                 _assemble(L, self.nu, self.gamma, 0.0, None, False)).to_scipy()
+        Fu = A0 @ u
+        if adv:
+            J = BSR(L.A.nbrows, L.A.nbcols, L.bs, L.A.rowptr, L.A.colidx,
+                    _assemble(L, self.nu, self.gamma, 1.0, wind, False)).to_scipy()
+            Fu = 0.5 * (Fu + J @ u)                  # A0 u + 1/2 N(u) u with N = J - A0
+        Fu = Fu + self.B_raw.T @ p
+        Fu[L.bc_dofs] = 0.0
+        Fp = self.B_raw @ u
+        return Fu, Fp
+
+    # -- the solve loop ---------------------------------------------------------------------------------------------------
+    def solve(self, re):
+        t0 = time.time()
+        if re == 0:
+            adv, self.nu = 0.0, self.char_L * self.char_U                   # Stokes, solver.py:261-264
+        else:
+            adv, self.nu = 1.0, self.char_L * self.char_U / re
+        for T, dt in zip(self.transfers, self.hmg.mg.transfers):            # AutoSchoeberlTransfer.rebuild, transfer.py:173-184
+            if T.nu != self.nu:
+                T.nu = self.nu
+                dt.update(self.nu, self.gamma)
+        self.saddle.update(self.nu, self.gamma)
+        u, p = self.u.copy(), self.p.copy()
+        lin_its, newton_its = 0, 0
+        Fu, Fp = self.residual(u, p, adv)
+        f0 = fnorm = float(np.sqrt(Fu @ Fu + Fp @ Fp))
+        hist = [fnorm]
+        while fnorm > max(self.snes_rtol * f0, self.snes_atol) and newton_its < self.snes_max_it:
+            self._rediscretise(u, adv)
+            rhs = -np.concatenate([Fu, Fp])
+            db, dx = self.ctx.vec(rhs), self.ctx.vec(self.n_u + self.n_p)
+            its, rn = self.saddle.solve(db, dx, self.rtol, self.atol, self.params["ksp_max_it"], 30)
+            delta = dx.get()
+            u += delta[:self.n_u]
+            p += delta[self.n_u:]
+            lin_its += its
+            newton_its += 1
+            Fu, Fp = self.residual(u, p, adv)
+            fnorm = float(np.sqrt(Fu @ Fu + Fp @ Fp))
+            hist.append(fnorm)
+            if self.verbose:
+                print("[alfi_amd] Re %g  Newton %d  |F| %.3e  (%d Krylov its, linear residual %.2e)"
+                      % (re, newton_its, fnorm, its, rn), flush=True)
+        p -= (self.vol @ p) / self.area                                      # zero pressure integral, solver.py:273-277
+        self.u, self.p = u, p
+        info = {"Re": re, "nu": self.nu, "linear_iter": lin_its, "nonlinear_iter": newton_its,
+                "time": (time.time() - t0) / 60.0, "residual_history": hist,
+                "converged": fnorm <= max(self.snes_rtol * f0, self.snes_atol)}
+        return (u, p), info
+
+    def close(self):
+        self.saddle.close()
+        self.hmg.mg.close()
+
+
+def run_solver(solver, res):
+    """alfi.driver.run_solver (driver.py:95-128) without checkpoints / ParaView output: continuation in Re."""
+    results = {}
+    for re in res:
+        _, results[re] = solver.solve(re)
+    return results

@@ -186,7 +186,7 @@ def build_transfer_data(Vc, Vf, nu, gamma, graph=None):
     return T
 
 
-def build_pressure_coupling(L):
+def build_pressure_coupling(L, zero_bc_columns=True):
     """P0 pressure space of the finest level (solver.py:574-586: ``Q = FunctionSpace(mesh, "DG", 0)``): the discrete
     divergence B (cells x velocity dofs, B[c, (a, x)] = -int_c d_x phi_a, Dirichlet velocity columns zeroed) and the
     diagonal pressure mass matrix (cell volumes).  With these the augmented-Lagrangian term of the level operator is
@@ -201,9 +201,10 @@ def build_pressure_coupling(L):
     cols = (V.cell_nodes[:, :, None] * d + np.arange(d)[None, None, :]).reshape(nc, -1).ravel()
     vals = (-vol[:, None, None] * bdiv).reshape(nc, -1).ravel()
     B = sp.csr_matrix((vals, (rows, cols)), shape=(nc, V.num_dofs))
-    keep = np.ones(V.num_dofs)
-    keep[V.bc_dofs] = 0.0
-    B = (B @ sp.diags(keep)).tocsr()
+    if zero_bc_columns:        # the Jacobian's block; with all columns it is the divergence used in the nonlinear residual
+        keep = np.ones(V.num_dofs)
+        keep[V.bc_dofs] = 0.0
+        B = (B @ sp.diags(keep)).tocsr()
     B.eliminate_zeros()
     B.sort_indices()
     return B, vol
