@@ -233,13 +233,6 @@ def _map_cols(B, part, nbcols, allow_drop=False):
     return BSR(B.nbrows, nbcols, B.bs, B.rowptr, lc, B.vals)
 
 
-def _sort_cols(B):
-    """Columns ascending within each block row (the patch gather bisects nothing here, but keep BSR canonical)."""
-    rows = np.repeat(np.arange(B.nbrows, dtype=np.int64), np.diff(B.rowptr))
-    order = np.lexsort((B.colidx, rows))
-    return BSR(B.nbrows, B.nbcols, B.bs, B.rowptr, B.colidx[order], B.vals[order])
-
-
 def localize_level(L, part):
     """Operator rows of all local nodes (owned rows complete; ghost rows restricted to local columns -- they only feed the
     patch sub-matrix gather), owned Dirichlet dofs, owned patches; everything in local numbering."""
@@ -355,7 +348,9 @@ class Comm(object):
 
     def exchange(self, send, recv, send_counts, recv_counts):
         """recv[segment q] <- rank q's send[segment me]; counts in elements of the tensors."""
-        sc, rc = [int(c) for c in send_counts], [int(c) for c in recv_counts]
+        sc, rc = send_counts, recv_counts
+        if not isinstance(sc, list):
+            sc, rc = [int(c) for c in sc], [int(c) for c in rc]
         if self._staged(send):
             import torch
             torch.cuda.current_stream().synchronize()
@@ -378,12 +373,15 @@ class HaloBuffers(object):
         self.sendbuf = torch.zeros(max(int(self.send_counts.sum()), 1), dtype=torch.float64, device=device)
         self.recvbuf = torch.zeros(max(int(self.recv_counts.sum()), 1), dtype=torch.float64, device=device)
         self.nsend, self.nrecv = int(self.send_counts.sum()), int(self.recv_counts.sum())
+        # the callbacks run ~200 times per cycle: keep the per-call host work to the collective itself
+        self._send, self._recv = self.sendbuf[:self.nsend], self.recvbuf[:self.nrecv]
+        self._sc, self._rc = [int(c) for c in self.send_counts], [int(c) for c in self.recv_counts]
 
     def forward(self, comm):
-        comm.exchange(self.sendbuf[:self.nsend], self.recvbuf[:self.nrecv], self.send_counts, self.recv_counts)
+        comm.exchange(self._send, self._recv, self._sc, self._rc)
 
     def reverse(self, comm):
-        comm.exchange(self.recvbuf[:self.nrecv], self.sendbuf[:self.nsend], self.recv_counts, self.send_counts)
+        comm.exchange(self._recv, self._send, self._rc, self._sc)
 
 
 CommFn = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int64, ctypes.c_int64)

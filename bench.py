@@ -179,7 +179,7 @@ def main_distributed(args, rank, world, local_rank):
         vps = args.steps / elapsed
         per_rank = [[float(v) for v in t.tolist()] for t in allstats]
         out = {
-            "metric": "V-cycles/sec on ldc3d P2-P0 (DoF*smooths/sec in dof_smooths_per_s)",
+            "metric": "V-cycles/sec on ldc%dd P2-P0 (DoF*smooths/sec in dof_smooths_per_s)" % CONFIGS[args.config][0],
             "value": vps, "unit": "V-cycles/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
@@ -321,7 +321,7 @@ def main():
         traffic = json.load(open(pmc_file)).get("hbm_bytes_per_launch")
 
     out = {
-        "metric": "V-cycles/sec on ldc3d P2-P0 (DoF*smooths/sec in dof_smooths_per_s)",
+        "metric": "V-cycles/sec on ldc%dd P2-P0 (DoF*smooths/sec in dof_smooths_per_s)" % CONFIGS[args.config][0],
         "value": vps,
         "unit": "V-cycles/s",
         "n_gpus": 1,
