@@ -292,6 +292,66 @@ __global__ __launch_bounds__(256) void patch_apply_kernel(int64_t npatch, const 
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// 3a. additive apply for levels of small patches (all n_p <= 2 G, G = 8 or 16: the 2-D stars with n_p = 14): a wave per
+//     patch would stream 1.5 KB per wave, so G lanes share a patch and a wave handles 64 / G patches.  Lane l owns the row
+//     pair (2l, 2l+1) -- a row pair never straddles two row pieces -- and walks the columns of its piece: one aligned
+//     16-byte load per column, x_p broadcast within the lane group by shuffles.  Same storage, same staging as section 3.
+// ---------------------------------------------------------------------------------------------------------------------
+template <int G, bool NT>
+__global__ __launch_bounds__(256) void patch_apply_small_kernel(int64_t npatch, const int64_t* __restrict__ patch_ptr,
+                                                                 const int32_t* __restrict__ patch_dofs,
+                                                                 const int64_t* __restrict__ inv_ptr,
+                                                                 const int64_t* __restrict__ stage_ptr,
+                                                                 const double* __restrict__ inv,
+                                                                 const double* __restrict__ x,
+                                                                 double* __restrict__ stage) {
+  const int64_t p = ((int64_t)blockIdx.x * 256 + threadIdx.x) / G;
+  const int l = threadIdx.x % G;
+  const bool live = p < npatch;
+  int n = 0;
+  int64_t off = 0;
+  if (live) {
+    off = patch_ptr[p];
+    n = (int)(patch_ptr[p + 1] - off);
+  }
+  const int ld = (n + 1) & ~1;
+  double xa = 0.0, xb = 0.0;   // x_p[l], x_p[l + G]
+  if (l < n) xa = x[patch_dofs[off + l]];
+  if (l + G < n) xb = x[patch_dofs[off + l + G]];
+  const int r = 2 * l;
+  const bool active = live && r < ld;
+  // the piece holding this lane's row pair: entry (r, c) sits at base + c * rows
+  const double* base = inv;
+  int rows = 2;
+  if (active) {
+    base = inv + inv_ptr[p] + patch_inv_index(r, 0, n, ld);
+    rows = (int)(patch_inv_index(r, 1, n, ld) - patch_inv_index(r, 0, n, ld));
+  }
+  double acc0 = 0.0, acc1 = 0.0;
+  // all lanes of the wave run the same trip count (the shuffles need them); n differs between the groups of a wave
+  int nmax = n;
+#pragma unroll
+  for (int o = G; o < 64; o <<= 1) nmax = max(nmax, __shfl_xor(nmax, o));
+  for (int c0 = 0; c0 < nmax; c0 += 4) {
+    double2 v[4];
+    double xc[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int c = c0 + u;
+      const double lo = __shfl(xa, c & (G - 1), G), hi = __shfl(xb, c & (G - 1), G);
+      xc[u] = c < G ? lo : hi;
+      v[u] = (active && c < n) ? load_pair<NT>(base + (int64_t)c * rows) : make_double2(0.0, 0.0);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      acc0 = __builtin_fma(v[u].x, xc[u], acc0);
+      acc1 = __builtin_fma(v[u].y, xc[u], acc1);
+    }
+  }
+  if (active) *reinterpret_cast<double2*>(stage + stage_ptr[p] + r) = make_double2(acc0, acc1);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // 3b. multiplicative sweep, one dependency wavefront: one wave per patch p of the wavefront,
 //       r_p = x_p - (A y)_p ,   y_p += inv(A_p) r_p .
 //     The patches of a wavefront are mutually uncoupled (no operator entry links them), so they neither read what another
@@ -544,7 +604,21 @@ int launch_patch_apply(alfi_level* L, const double* x, double* y) {
     dim3 grid((unsigned)((L->npatch + 3) / 4)), block(256);
     // the inverses are read once per apply: nontemporal loads keep x, the staging buffer and the index arrays in cache
     static const bool nt = !(getenv("ALFI_NT") && atoi(getenv("ALFI_NT")) == 0);
-    if (nt)
+    static const bool small_ok = !(getenv("ALFI_SMALL_PATCH") && atoi(getenv("ALFI_SMALL_PATCH")) == 0);
+    if (small_ok && L->max_np <= 32) {
+      // small patches: G lanes per patch, 64 / G patches per wave
+      const int G = L->max_np <= 16 ? 8 : 16;
+      dim3 sgrid((unsigned)((L->npatch * G + 255) / 256));
+#define ALFI_SMALL(GV, NTV)                                                                                            \
+  hipLaunchKernelGGL((patch_apply_small_kernel<GV, NTV>), sgrid, block, 0, ctx->stream, L->npatch, L->patch_ptr,       \
+                     L->patch_dofs, L->inv_ptr, L->stage_ptr, L->inv, x, L->stage)
+      if (G == 8) {
+        if (nt) ALFI_SMALL(8, true); else ALFI_SMALL(8, false);
+      } else {
+        if (nt) ALFI_SMALL(16, true); else ALFI_SMALL(16, false);
+      }
+#undef ALFI_SMALL
+    } else if (nt)
       hipLaunchKernelGGL(patch_apply_kernel<true>, grid, block, 0, ctx->stream, L->npatch, L->patch_ptr, L->patch_dofs,
                          L->inv_ptr, L->stage_ptr, L->inv, x, L->stage);
     else

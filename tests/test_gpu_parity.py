@@ -303,3 +303,38 @@ def test_patch_sizes_1_to_160_all_row_piece_combinations(ctx, bs):
     with pytest.raises(hip.AlfiHipError):
         lvl.set_patches(np.array([0, len(big)], dtype=np.int64), big)
     lvl.close()
+
+
+@pytest.mark.parametrize("bs,max_n", [(2, 16), (2, 32), (3, 15), (3, 30)])
+def test_small_patch_kernel_ragged_sizes(ctx, bs, max_n):
+    """Levels whose patches all have n_p <= 32 take the lane-group kernel (patch_apply_small_kernel: 8 or 16 lanes per
+    patch): every size bs .. max_n, more patches than fit a wave, against NumPy."""
+    import scipy.sparse as sp
+    from alfi_amd import hip
+    from alfi_amd.problem import BSR
+    rng = np.random.default_rng(100 + max_n)
+    nb = 300
+    M = sp.random(nb * bs, nb * bs, density=0.03, random_state=3, format="csr")
+    M = M + M.T + sp.identity(nb * bs) * 20.0
+    A = BSR.from_scipy(sp.csr_matrix(M), bs)
+    S = A.to_scipy().tocsr()
+    sizes = [int(s_) for s_ in rng.integers(1, max_n // bs + 1, 700)] + list(range(1, max_n // bs + 1))
+    ptr, dofs = [0], []
+    for sz in sizes:
+        nodes = np.sort(rng.choice(nb, sz, replace=False))
+        d = (nodes[:, None] * bs + np.arange(bs)).ravel()
+        dofs.append(d)
+        ptr.append(ptr[-1] + len(d))
+    ptr, dofs = np.array(ptr, dtype=np.int64), np.concatenate(dofs).astype(np.int32)
+    lvl = hip.Level(ctx, A, np.zeros(0, dtype=np.int32))
+    lvl.set_patches(ptr, dofs)
+    lvl.factor()
+    x = rng.standard_normal(nb * bs)
+    ref = np.zeros_like(x)
+    for p in range(len(sizes)):
+        d = dofs[ptr[p]:ptr[p + 1]]
+        ref[d] += np.linalg.solve(S[d][:, d].toarray(), x[d])
+    dx, dy = ctx.vec(x), ctx.vec(nb * bs)
+    lvl.patch_apply(dx, dy)
+    assert np.abs(dy.get() - ref).max() < 1e-12 * np.abs(ref).max()
+    lvl.close()
