@@ -285,6 +285,14 @@ int alfi_level_create(alfi_ctx* ctx, int64_t nbrows, int bs, const int32_t* brow
   alfi_bsr_host h{nbrows, nbrows, browptr, bcolidx, bvals};
   int rc = upload_bsr(ctx, &L->A, &h, bs);
   if (rc == 0) rc = dev_upload(ctx, &L->bc_dofs, bc_dofs, nbc);
+  if (rc == 0) {
+    std::vector<uint8_t> mask((size_t)std::max<int64_t>(L->n, 1), 0);
+    for (int64_t i = 0; i < nbc && rc == 0; ++i) {
+      if (bc_dofs[i] < 0 || bc_dofs[i] >= L->n) rc = alfi_set_error(ctx, ALFI_E_ARG, "Dirichlet dof %d out of range", bc_dofs[i]);
+      else mask[bc_dofs[i]] = 1;
+    }
+    if (rc == 0) rc = dev_upload(ctx, &L->bc_mask, mask.data(), (int64_t)mask.size());
+  }
   if (rc == 0) rc = dev_alloc(ctx, &L->status, 1);
   if (rc == 0 && hipMemsetAsync(L->status, 0, sizeof(int), ctx->stream) != hipSuccess) rc = ALFI_E_HIP;
   L->nbc = nbc;
@@ -354,6 +362,7 @@ int alfi_level_destroy(alfi_level* L) {
   (void)hipStreamSynchronize(L->ctx->stream);
   free_bsr(&L->A);
   dev_free(L->bc_dofs);
+  dev_free(L->bc_mask);
   dev_free(L->halo_send_nodes);
   dev_free(L->rev_nodes);
   dev_free(L->rev_ptr);
@@ -444,13 +453,8 @@ static int level_patch_apply(alfi_level* L, const double* dx, double* dy) {
     return 0;
   }
   if (L->distributed) ALFI_CHECK(halo_fwd(L, const_cast<double*>(dx)));
-  ALFI_CHECK(launch_patch_apply(L, dx, dy));
-  if (L->distributed) ALFI_CHECK(halo_rev(L, dy));
-  if (L->nbc > 0) {
-    int t = alfi_prof_begin(ctx, ALFI_EV_PATCH_SCATTER);
-    ALFI_CHECK(launch_copy_dofs(ctx, dy, dx, L->bc_dofs, L->nbc));
-    alfi_prof_end(ctx, t);
-  }
+  ALFI_CHECK(launch_patch_apply(L, dx, dy));    // includes y[bc] = x[bc] (no patch holds a Dirichlet dof, so the
+  if (L->distributed) ALFI_CHECK(halo_rev(L, dy));  // reverse-add brings nothing to those entries)
   return 0;
 }
 
@@ -722,8 +726,11 @@ int alfi_smooth_fgmres(alfi_level* L, int k, const double* db, double* dx, int n
     alfi_prof_end(ctx, t);
     if (par) ALFI_CHECK(comm_allreduce(L, RED_MAXV, 1));
     t = alfi_prof_begin(ctx, ALFI_EV_BLAS1);
-    ALFI_CHECK(launch_hessenberg_update(ctx, par ? nrm2 : ctx->red_partial, par ? 1 : RED_BLOCKS, hdots, hs, j, K));
-    if (j + 1 < k) ALFI_CHECK(launch_scale_by_inv(ctx, V + (int64_t)(j + 1) * ldv, w, hs + hl.tt, n));
+    if (j + 1 < k)   // Hessenberg column + v_{j+1} = w / |w| in one launch
+      ALFI_CHECK(launch_hessenberg_scale(ctx, par ? nrm2 : ctx->red_partial, par ? 1 : RED_BLOCKS, hdots, hs, j, K,
+                                         V + (int64_t)(j + 1) * ldv, w, n));
+    else
+      ALFI_CHECK(launch_hessenberg_update(ctx, par ? nrm2 : ctx->red_partial, par ? 1 : RED_BLOCKS, hdots, hs, j, K));
     alfi_prof_end(ctx, t);
   }
   t = alfi_prof_begin(ctx, ALFI_EV_BLAS1);

@@ -126,6 +126,7 @@ struct alfi_level {
   int32_t *rev_nodes = nullptr, *rev_ptr = nullptr, *rev_pos = nullptr;
   int32_t* bc_dofs = nullptr;
   int64_t nbc = 0;
+  uint8_t* bc_mask = nullptr;  // (n) 1 on Dirichlet dofs: the dof-wise sum of the patch results copies x there
   // patches
   int64_t npatch = 0, sum_n = 0, sum_n2 = 0, inv_doubles = 0;
   int max_np = 0;
@@ -236,6 +237,8 @@ int launch_norm_init_finish(alfi_ctx* ctx, const double* partial, int nblocks, d
 int launch_reduce_partials(alfi_ctx* ctx, int nv, double* out);  // out[v] = sum_b red_partial[b][v]
 int launch_hessenberg_update(alfi_ctx* ctx, const double* partial, int nblocks, const double* h, double* hs, int j,
                              int K);
+int launch_hessenberg_scale(alfi_ctx* ctx, const double* partial, int nblocks, const double* h, double* hs, int j, int K,
+                            double* vnext, const double* w, int64_t n);
 // scalar CSR: mode 0: y = A x; 1: y = b - alpha A x; 2: y += A x
 int launch_csr_spmv(alfi_ctx* ctx, const DevCSR& A, const double* x, double* y, const double* b, double alpha, int mode);
 int launch_scale_rows(alfi_ctx* ctx, double* y, const double* x, const double* d, double a, int64_t n);  // y = a d x

@@ -508,12 +508,14 @@ __global__ __launch_bounds__(256) void patch_mult_kernel(int64_t count, const in
 // stage 2: dof-wise sum of the staged patch results in a fixed order (deterministic; replaces PETSc's scatter-add)
 __global__ __launch_bounds__(256) void patch_sum_kernel(int64_t n, const int32_t* __restrict__ dof_ptr,
                                                          const int32_t* __restrict__ dof_pos,
-                                                         const double* __restrict__ stage, double* __restrict__ y) {
+                                                         const double* __restrict__ stage,
+                                                         const uint8_t* __restrict__ bc_mask,
+                                                         const double* __restrict__ x, double* __restrict__ y) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
   double s = 0.0;
   for (int32_t q = dof_ptr[i]; q < dof_ptr[i + 1]; ++q) s += stage[dof_pos[q]];
-  y[i] = s;
+  y[i] = bc_mask[i] ? x[i] : s;   // Dirichlet dofs: y[bc] = x[bc]
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -629,7 +631,8 @@ int launch_patch_apply(alfi_level* L, const double* x, double* y) {
   }
   int t = alfi_prof_begin(ctx, ALFI_EV_PATCH_SCATTER);
   dim3 grid((unsigned)((L->n + 255) / 256)), block(256);
-  hipLaunchKernelGGL(patch_sum_kernel, grid, block, 0, ctx->stream, L->n, L->dof_ptr, L->dof_pos, L->stage, y);
+  hipLaunchKernelGGL(patch_sum_kernel, grid, block, 0, ctx->stream, L->n, L->dof_ptr, L->dof_pos, L->stage, L->bc_mask, x,
+                     y);
   ALFI_HIP_CHECK(ctx, hipGetLastError());
   alfi_prof_end(ctx, t);
   return 0;

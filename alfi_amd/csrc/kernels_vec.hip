@@ -564,6 +564,62 @@ int launch_multi_axpy_norm(alfi_ctx* ctx, const double* V, int64_t stride, int n
   return 0;
 }
 
+// the same, fused with v_next = w / tt (one launch less per smoother iteration; matters on the small levels, which are
+// launch-bound).  Every block reduces the partials itself in the same fixed order, so all use the identical tt; block 0
+// also performs the Hessenberg / Givens update.  Nobody reads what block 0 writes before the kernel ends.
+__global__ __launch_bounds__(256) void hessenberg_scale_kernel(const double* __restrict__ partial, int nblocks,
+                                                                const double* __restrict__ h, double* __restrict__ hs,
+                                                                int j, int K, double* __restrict__ vnext,
+                                                                const double* __restrict__ w, int64_t n) {
+  __shared__ double red[256];
+  double s = 0.0;
+  for (int b = threadIdx.x; b < nblocks; b += 256) s += partial[(int64_t)b * RED_MAXV];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  const double tt = sqrt(red[0]);
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    HsLayout L(K);
+    hs[L.tt] = tt;
+    double* hcol = hs + L.H(j);
+    for (int i = 0; i <= j; ++i) hcol[i] = h[i];
+    hcol[j + 1] = tt;
+    double* cs = hs + L.cs;
+    double* sn = hs + L.sn;
+    double* grs = hs + L.grs;
+    for (int i = 0; i < j; ++i) {
+      const double t = hcol[i];
+      hcol[i] = cs[i] * t + sn[i] * hcol[i + 1];
+      hcol[i + 1] = -sn[i] * t + cs[i] * hcol[i + 1];
+    }
+    const double den = hypot(hcol[j], hcol[j + 1]);
+    if (den != 0.0) {
+      cs[j] = hcol[j] / den;
+      sn[j] = hcol[j + 1] / den;
+    } else {
+      cs[j] = 1.0;
+      sn[j] = 0.0;
+    }
+    grs[j + 1] = -sn[j] * grs[j];
+    grs[j] = cs[j] * grs[j];
+    hcol[j] = den;
+    hcol[j + 1] = 0.0;
+  }
+  const double f = tt != 0.0 ? 1.0 / tt : 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) vnext[i] = w[i] * f;
+}
+
+int launch_hessenberg_scale(alfi_ctx* ctx, const double* partial, int nblocks, const double* h, double* hs, int j, int K,
+                            double* vnext, const double* w, int64_t n) {
+  hipLaunchKernelGGL(hessenberg_scale_kernel, ew_grid(n), dim3(256), 0, ctx->stream, partial, nblocks, h, hs, j, K, vnext,
+                     w, n);
+  ALFI_HIP_CHECK(ctx, hipGetLastError());
+  return 0;
+}
+
 int launch_hessenberg_update(alfi_ctx* ctx, const double* partial, int nblocks, const double* h, double* hs, int j,
                              int K) {
   hipLaunchKernelGGL(hessenberg_update_kernel, dim3(1), dim3(256), 0, ctx->stream, partial, nblocks, h, hs, j, K);
