@@ -17,6 +17,8 @@ CASES = {
     "2d-coarse-on-rank0": (2, 4, 2, 2, 100.0, 3, 500),
     "3d-P2FB": (3, 2, 1, 2, 1000.0, 2, 1),
     "3d-P1FB": (3, 2, 1, 1, 100.0, 2, 1),
+    # three 3-D levels, the middle one owned by rank 0 alone, the finest split (the shape of the config-4 run)
+    "3d-P2FB-3lev": (3, 1, 2, 2, 100.0, 2, 3000),
 }
 
 
@@ -66,7 +68,7 @@ def _free_port():
 
 @pytest.mark.parametrize("case,world,robust", [("2d-all-distributed", 2, False), ("2d-all-distributed", 3, True),
                                                ("2d-coarse-on-rank0", 2, True), ("3d-P2FB", 2, False),
-                                               ("3d-P1FB", 2, True)])
+                                               ("3d-P1FB", 2, True), ("3d-P2FB-3lev", 4, True)])
 def test_spmd_oracle_matches_serial(case, world, robust):
     import torch.multiprocessing as mp
     from oracle import alfi_oracle as O

@@ -23,7 +23,7 @@ def _free_port():
 
 
 @pytest.mark.parametrize("case,world,robust", [("2d-all-distributed", 2, 0), ("2d-coarse-on-rank0", 3, 1),
-                                               ("3d-P2FB", 2, 0), ("3d-P1FB", 3, 1)])
+                                               ("3d-P2FB", 2, 0), ("3d-P1FB", 3, 1), ("3d-P2FB-3lev", 4, 1)])
 def test_partitioned_cycles_match_single_gpu(case, world, robust, tmp_path):
     from alfi_amd import hip
     from oracle import alfi_oracle as O
