@@ -6,6 +6,27 @@ import numpy as np
 _lib = None
 
 
+def cpu_share():
+    """CPUs this process may actually use: the affinity mask capped by the cgroup CPU quota (a GPU box hands out a share
+    of its cores; OpenMP teams larger than the quota are throttled into the ground)."""
+    n = len(os.sched_getaffinity(0))
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(float(txt[0]) / float(txt[1]) + 0.5)))
+            else:
+                q = float(txt[0])
+                per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if q > 0:
+                    n = min(n, max(1, int(q / per + 0.5)))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return n
+
+
 def lib():
     global _lib
     if _lib is None:
@@ -21,9 +42,8 @@ def lib():
         _lib.alfi_host_interior_blocks.restype = ctypes.c_int
         _lib.alfi_host_bsr_transpose.restype = ctypes.c_int
         # ALFI_HOST_THREADS overrides OMP_NUM_THREADS (torch.distributed.run exports OMP_NUM_THREADS=1 to every rank)
-        nthr = int(os.environ.get("ALFI_HOST_THREADS", "0"))
-        if nthr > 0:
-            _lib.alfi_host_set_num_threads(ctypes.c_int(nthr))
+        nthr = int(os.environ.get("ALFI_HOST_THREADS", "0")) or cpu_share()
+        _lib.alfi_host_set_num_threads(ctypes.c_int(nthr))
     return _lib
 
 

@@ -115,8 +115,8 @@ def main_distributed(args, rank, world, local_rank):
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     else:
         dist.init_process_group(backend)
-    ncpu = len(os.sched_getaffinity(0))
-    os.environ.setdefault("ALFI_HOST_THREADS", str(max(1, ncpu // world)))    # host generator threads of this rank
+    from alfi_amd._hostlib import cpu_share
+    os.environ.setdefault("ALFI_HOST_THREADS", str(max(1, cpu_share() // world)))    # host generator threads of this rank
     from alfi_amd.dist import DistMultigrid
     t0 = time.time()
     lv, tr, k = build_problem(args.config, args.verbose and rank == 0)

@@ -17,6 +17,23 @@
 #include <omp.h>
 
 int oracle_num_threads(void) { return omp_get_max_threads(); }
+int oracle_set_num_threads(int n) {
+  if (n > 0) omp_set_num_threads(n);
+  return omp_get_max_threads();
+}
+
+/* NUMA first touch for the timed baseline: copy into freshly allocated (untouched) memory with the static schedule the
+ * kernels below use, so every thread later reads mostly node-local pages (PETSc gets the same from MPI-rank-local
+ * allocation). */
+void oracle_parallel_copy(void* dst, const void* src, int64_t nbytes) {
+  const int64_t chunk = 1 << 16;
+  const int64_t nchunk = (nbytes + chunk - 1) / chunk;
+#pragma omp parallel for schedule(static)
+  for (int64_t c = 0; c < nchunk; ++c) {
+    const int64_t o = c * chunk;
+    memcpy((char*)dst + o, (const char*)src + o, (size_t)(nbytes - o < chunk ? nbytes - o : chunk));
+  }
+}
 
 /* y = A x (mode 0) or y = b - alpha A x (mode 1); A block-CSR with bs x bs row-major blocks */
 void oracle_bsr_spmv(int64_t nbrows, int bs, const int32_t* rowptr, const int32_t* colidx, const double* vals,
@@ -24,11 +41,23 @@ void oracle_bsr_spmv(int64_t nbrows, int bs, const int32_t* rowptr, const int32_
 #pragma omp parallel for schedule(static)
   for (int64_t r = 0; r < nbrows; ++r) {
     double acc[3] = {0, 0, 0};
-    for (int32_t k = rowptr[r]; k < rowptr[r + 1]; ++k) {
-      const double* v = vals + (int64_t)k * bs * bs;
-      const double* xv = x + (int64_t)colidx[k] * bs;
-      for (int i = 0; i < bs; ++i)
-        for (int j = 0; j < bs; ++j) acc[i] += v[i * bs + j] * xv[j];
+    if (bs == 3) {                       /* the hot case, unrolled so that the compiler keeps it in registers */
+      double a0 = 0, a1 = 0, a2 = 0;
+      for (int32_t k = rowptr[r]; k < rowptr[r + 1]; ++k) {
+        const double* v = vals + (int64_t)k * 9;
+        const double* xv = x + (int64_t)colidx[k] * 3;
+        a0 += v[0] * xv[0] + v[1] * xv[1] + v[2] * xv[2];
+        a1 += v[3] * xv[0] + v[4] * xv[1] + v[5] * xv[2];
+        a2 += v[6] * xv[0] + v[7] * xv[1] + v[8] * xv[2];
+      }
+      acc[0] = a0; acc[1] = a1; acc[2] = a2;
+    } else {
+      for (int32_t k = rowptr[r]; k < rowptr[r + 1]; ++k) {
+        const double* v = vals + (int64_t)k * bs * bs;
+        const double* xv = x + (int64_t)colidx[k] * bs;
+        for (int i = 0; i < bs; ++i)
+          for (int j = 0; j < bs; ++j) acc[i] += v[i * bs + j] * xv[j];
+      }
     }
     for (int i = 0; i < bs; ++i) y[r * bs + i] = mode ? b[r * bs + i] - alpha * acc[i] : acc[i];
   }
@@ -109,9 +138,10 @@ void oracle_patch_apply(int64_t npatch, const int64_t* patch_ptr, const int32_t*
       const double* a = inv + inv_ptr[p];
       for (int j = 0; j < np; ++j) xp[j] = x[dofs[j]];
       double* out = stage + patch_ptr[p];
-      for (int i = 0; i < np; ++i) {
+      for (int i = 0; i < np; ++i) {     /* dgemv, row-major: vectorised dot products (PETSc calls BLAS here) */
         double s = 0.0;
         const double* ai = a + (int64_t)i * np;
+#pragma omp simd reduction(+ : s)
         for (int j = 0; j < np; ++j) s += ai[j] * xp[j];
         out[i] = s;
       }

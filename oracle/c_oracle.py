@@ -26,6 +26,11 @@ def lib():
         _lib.oracle_num_threads.restype = ctypes.c_int
         _lib.oracle_invert_patches.restype = ctypes.c_int
         _lib.oracle_block_invert.restype = ctypes.c_int
+        _lib.oracle_set_num_threads.restype = ctypes.c_int
+        # one thread per CPU the process may really use (cgroup share), OMP_NUM_THREADS overrides
+        if "OMP_NUM_THREADS" not in os.environ:
+            from alfi_amd._hostlib import cpu_share
+            _lib.oracle_set_num_threads(ctypes.c_int(cpu_share()))
     return _lib
 
 
@@ -48,9 +53,29 @@ def spmv(B, x, y=None, b=None, alpha=1.0):
     return y
 
 
+def _numa_copy(a):
+    """Copy of a NumPy array whose pages are first touched by the OpenMP threads (static schedule), see
+    oracle_parallel_copy in alfi_oracle.c."""
+    a = np.ascontiguousarray(a)
+    if os.environ.get("ALFI_ORACLE_NUMA", "1") == "0":
+        return a
+    out = np.empty_like(a)
+    if a.nbytes:
+        lib().oracle_parallel_copy(_p(out), _p(a), ctypes.c_int64(a.nbytes))
+    return out
+
+
+class _BSRView(object):
+    pass
+
+
 class CLevel(object):
     def __init__(self, L, with_patches=True):
-        self.L, self.A = L, L.A
+        self.L = L
+        # operator arrays re-homed for the timed baseline (NUMA first touch by the threads that will read them)
+        self.A = _BSRView()
+        self.A.nbrows, self.A.nbcols, self.A.bs = L.A.nbrows, L.A.nbcols, L.A.bs
+        self.A.rowptr, self.A.colidx, self.A.vals = L.A.rowptr, _numa_copy(L.A.colidx), _numa_copy(L.A.vals)
         self.n, self.bs = L.n, L.bs
         self.bc = np.ascontiguousarray(L.bc_dofs, dtype=np.int32)
         self.has_patches = with_patches
