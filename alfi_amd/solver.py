@@ -99,6 +99,18 @@ def _resolve(dotted):
     return getattr(importlib.import_module(mod), name)
 
 
+def macro_vertex_labels(mesh):
+    """``MacroVertices`` label (alfi/bary.py:18-19 sets it to 1 on the vertices of the mesh that is then split).  For a
+    uniformly refined mesh the analogous macro vertices are the vertices inherited from the parent mesh; a mesh without
+    parent information carries no label."""
+    if getattr(mesh, "vertex_parents", None) is None:
+        return {}
+    vp_ = np.asarray(mesh.vertex_parents)
+    macro = np.flatnonzero(vp_[:, 0] == vp_[:, 1])
+    nc = mesh.num_cells
+    return {"MacroVertices": {int(nc + v): 1 for v in macro}}
+
+
 class PC(object):
     """The small part of a PETSc PC object a PCPython class touches: operators, DM, options prefix (+ attributes)."""
 
@@ -107,7 +119,7 @@ class PC(object):
         self.level_data = level_data    # alfi_amd.problem.LevelData (operator, space, Dirichlet dofs)
         self.options = dict(options or {})
         self.prefix = prefix
-        self._dm = PlexLike(level_data.V.mesh)
+        self._dm = PlexLike(level_data.V.mesh, labels=macro_vertex_labels(level_data.V.mesh))
         self.attrs = {}
 
     def getOperators(self):

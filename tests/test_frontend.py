@@ -194,3 +194,31 @@ def test_schoeberl_transfer_object_protocol():
     ref2[lv[1].bc_dofs] = 0
     assert np.abs(fine.dat.data.ravel() - ref2).max() < 1e-8 * np.abs(ref2).max()
     vt.break_ref_cycles()
+
+
+@pytest.mark.gpu
+def test_macro_star_patches_through_the_option_dictionary():
+    """``patch="macro"`` (solver.py:339-343): python-constructed ``MacroStar`` patches (relaxation.py:163-177) -- one per
+    MacroVertices-labelled vertex, the union of the stars of every vertex of its macro neighbourhood; 74 dofs for an
+    interior macro vertex of a once-refined ldc2d mesh -- gathered, inverted and applied on the GPU, against the
+    oracle's dense patch solves on the same dof sets."""
+    import alfi_amd
+    from alfi_amd import hip
+    from oracle import alfi_oracle as O
+    lv, tr = build_hierarchy(TwoDimLidDrivenCavityProblem(4), 1, 2, Re=100.0)
+    L = lv[-1]
+    ctx = hip.Context(0)
+    opts = alfi_amd.mg_levels_solver(2, patch="macro", smoothing=3)
+    assert opts["patch_pc_patch_construct_python_type"] == "alfi_amd.MacroStar"
+    pc = alfi_amd.PC(ctx, L, options=opts)
+    obj = alfi_amd.HipPatchPC()
+    obj.initialize(pc)
+    sizes = np.diff(obj.patch_ptr)
+    assert len(sizes) == 25 and sizes.max() == 74                 # 5 x 5 macro vertices
+    x = np.random.default_rng(5).standard_normal(L.n)
+    y = np.zeros(L.n)
+    obj.apply(pc, x, y)
+    ref = O.PatchSmoother(L.A.to_scipy().tocsr(), obj.patch_ptr, obj.patch_dofs, L.bc_dofs).apply(x)
+    assert np.abs(y - ref).max() < 1e-8 * np.abs(ref).max()
+    obj.level.close()
+    ctx.close()
