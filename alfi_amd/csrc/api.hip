@@ -238,6 +238,8 @@ int alfi_ctx_set_comm(alfi_ctx* ctx, alfi_comm_fn fn, void* user, double* dred, 
   ctx->comm = fn;
   ctx->comm_user = user;
   ctx->dred = dred;
+  const char* e = getenv("ALFI_DIST_EXACT_NORM");   // 1: |w| by its own all-reduce, as PETSc's VecNorm (A/B, parity checks)
+  ctx->exact_norm = e && atoi(e) == 1;
   return 0;
 }
 
@@ -718,19 +720,27 @@ int alfi_smooth_fgmres(alfi_level* L, int k, const double* db, double* dx, int n
     ALFI_CHECK(alfi_spmv(L, Z + (int64_t)j * ldv, w));                               // w = A z_j
     t = alfi_prof_begin(ctx, ALFI_EV_BLAS1);
     ALFI_CHECK(launch_multi_dot(ctx, V, ldv, j + 1, w, hdots, n));                   // h = V^T w (classical GS)
+    // partitioned: |w|^2 rides along in the same all-reduce; |w - V h|^2 = |w|^2 - |h|^2 then needs no second one
+    const bool pyth = par && !ctx->exact_norm;
+    const double* ww = pyth ? hdots + (j + 1) : nullptr;
+    if (pyth) {
+      ALFI_CHECK(launch_norm_partials(ctx, w, n));
+      ALFI_CHECK(launch_reduce_partials(ctx, 1, hdots + (j + 1)));
+    }
     alfi_prof_end(ctx, t);
-    if (par) ALFI_CHECK(comm_allreduce(L, 0, j + 1));
+    if (par) ALFI_CHECK(comm_allreduce(L, 0, pyth ? j + 2 : j + 1));
     t = alfi_prof_begin(ctx, ALFI_EV_BLAS1);
     ALFI_CHECK(launch_multi_axpy_norm(ctx, V, ldv, j + 1, hdots, w, n));             // w -= V h, |w|^2 partials
-    if (par) ALFI_CHECK(launch_reduce_partials(ctx, 1, nrm2));
+    if (par && !pyth) ALFI_CHECK(launch_reduce_partials(ctx, 1, nrm2));
     alfi_prof_end(ctx, t);
-    if (par) ALFI_CHECK(comm_allreduce(L, RED_MAXV, 1));
+    if (par && !pyth) ALFI_CHECK(comm_allreduce(L, RED_MAXV, 1));
     t = alfi_prof_begin(ctx, ALFI_EV_BLAS1);
+    const double* part = par ? nrm2 : ctx->red_partial;
+    const int nblk = par ? 1 : RED_BLOCKS;
     if (j + 1 < k)   // Hessenberg column + v_{j+1} = w / |w| in one launch
-      ALFI_CHECK(launch_hessenberg_scale(ctx, par ? nrm2 : ctx->red_partial, par ? 1 : RED_BLOCKS, hdots, hs, j, K,
-                                         V + (int64_t)(j + 1) * ldv, w, n));
+      ALFI_CHECK(launch_hessenberg_scale(ctx, part, nblk, hdots, hs, j, K, V + (int64_t)(j + 1) * ldv, w, n, ww));
     else
-      ALFI_CHECK(launch_hessenberg_update(ctx, par ? nrm2 : ctx->red_partial, par ? 1 : RED_BLOCKS, hdots, hs, j, K));
+      ALFI_CHECK(launch_hessenberg_update(ctx, part, nblk, hdots, hs, j, K, ww));
     alfi_prof_end(ctx, t);
   }
   t = alfi_prof_begin(ctx, ALFI_EV_BLAS1);
@@ -1158,7 +1168,7 @@ int alfi_saddle_solve(alfi_saddle* S, const double* db, double* dx, double rtol,
       ALFI_CHECK(alfi_saddle_mult(S, zj, w));                               // w = K z_j
       ALFI_CHECK(launch_multi_dot(ctx, V, n, j + 1, w, hs + hl.hd, n));
       ALFI_CHECK(launch_multi_axpy_norm(ctx, V, n, j + 1, hs + hl.hd, w, n));
-      ALFI_CHECK(launch_hessenberg_update(ctx, ctx->red_partial, RED_BLOCKS, hs + hl.hd, hs, j, K));
+      ALFI_CHECK(launch_hessenberg_update(ctx, ctx->red_partial, RED_BLOCKS, hs + hl.hd, hs, j, K, nullptr));
       ++its;
       double g = 0.0;
       ALFI_CHECK(read(hs + hl.grs + j + 1, &g));                            // |rotated rhs| = residual norm estimate

@@ -28,6 +28,7 @@ struct alfi_ctx {
   // mesh-partition parallelism (alfi_ctx_set_comm)
   alfi_comm_fn comm = nullptr;
   void* comm_user = nullptr;
+  bool exact_norm = false;  // partitioned FGMRES: second all-reduce for |w| instead of the Pythagorean identity
   double* dred = nullptr;  // caller-owned device buffer the callback all-reduces: [0, RED_MAXV) dots, [RED_MAXV] norm^2
 };
 
@@ -235,10 +236,11 @@ int launch_axpy(alfi_ctx* ctx, double* y, const double* x, double a, int64_t n);
 int launch_norm_partials(alfi_ctx* ctx, const double* r, int64_t n);
 int launch_norm_init_finish(alfi_ctx* ctx, const double* partial, int nblocks, double* hs, int K);
 int launch_reduce_partials(alfi_ctx* ctx, int nv, double* out);  // out[v] = sum_b red_partial[b][v]
+// ww: nullptr, or (partitioned levels) the all-reduced |w|^2 before the projection -> |w_new|^2 by Pythagoras
 int launch_hessenberg_update(alfi_ctx* ctx, const double* partial, int nblocks, const double* h, double* hs, int j,
-                             int K);
+                             int K, const double* ww);
 int launch_hessenberg_scale(alfi_ctx* ctx, const double* partial, int nblocks, const double* h, double* hs, int j, int K,
-                            double* vnext, const double* w, int64_t n);
+                            double* vnext, const double* w, int64_t n, const double* ww);
 // scalar CSR: mode 0: y = A x; 1: y = b - alpha A x; 2: y += A x
 int launch_csr_spmv(alfi_ctx* ctx, const DevCSR& A, const double* x, double* y, const double* b, double alpha, int mode);
 int launch_scale_rows(alfi_ctx* ctx, double* y, const double* x, const double* d, double a, int64_t n);  // y = a d x

@@ -478,9 +478,18 @@ __global__ __launch_bounds__(256) void norm_init_finish_kernel(const double* __r
 
 // column j of the Hessenberg: h[0..j] = the CGS dots, h[j+1] = tt = sqrt(sum of nblocks partials); Givens update
 // (KSPFGMRESUpdateHessenberg [3P]).  Partitioned levels pass the all-reduced values (nblocks = 1).
+// ww != nullptr (partitioned levels, one all-reduce per iteration): |w_new|^2 = |w|^2 - sum_i h_i^2 with the all-reduced
+// *ww = |w|^2 (w before the projection) and h; V is orthonormal, so this is the same number up to O(eps |w|^2).
+__device__ __forceinline__ double pythagoras_norm2(const double* ww, const double* h, int j) {
+  double s = *ww;
+  for (int i = 0; i <= j; ++i) s -= h[i] * h[i];
+  return s > 0.0 ? s : 0.0;
+}
+
 __global__ __launch_bounds__(256) void hessenberg_update_kernel(const double* __restrict__ partial, int nblocks,
                                                                  const double* __restrict__ h,
-                                                                 double* __restrict__ hs, int j, int K) {
+                                                                 double* __restrict__ hs, int j, int K,
+                                                                 const double* __restrict__ ww) {
   __shared__ double red[256];
   double s = 0.0;
   for (int b = threadIdx.x; b < nblocks; b += 256) s += partial[(int64_t)b * RED_MAXV];
@@ -492,7 +501,7 @@ __global__ __launch_bounds__(256) void hessenberg_update_kernel(const double* __
   }
   if (threadIdx.x == 0) {
     HsLayout L(K);
-    const double tt = sqrt(red[0]);
+    const double tt = sqrt(ww ? pythagoras_norm2(ww, h, j) : red[0]);
     hs[L.tt] = tt;
     double* hcol = hs + L.H(j);
     for (int i = 0; i <= j; ++i) hcol[i] = h[i];
@@ -581,7 +590,8 @@ int launch_multi_axpy_norm(alfi_ctx* ctx, const double* V, int64_t stride, int n
 __global__ __launch_bounds__(256) void hessenberg_scale_kernel(const double* __restrict__ partial, int nblocks,
                                                                 const double* __restrict__ h, double* __restrict__ hs,
                                                                 int j, int K, double* __restrict__ vnext,
-                                                                const double* __restrict__ w, int64_t n) {
+                                                                const double* __restrict__ w, int64_t n,
+                                                                const double* __restrict__ ww) {
   __shared__ double red[256];
   double s = 0.0;
   for (int b = threadIdx.x; b < nblocks; b += 256) s += partial[(int64_t)b * RED_MAXV];
@@ -591,7 +601,7 @@ __global__ __launch_bounds__(256) void hessenberg_scale_kernel(const double* __r
     if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
     __syncthreads();
   }
-  const double tt = sqrt(red[0]);
+  const double tt = sqrt(ww ? pythagoras_norm2(ww, h, j) : red[0]);
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     HsLayout L(K);
     hs[L.tt] = tt;
@@ -624,16 +634,16 @@ __global__ __launch_bounds__(256) void hessenberg_scale_kernel(const double* __r
 }
 
 int launch_hessenberg_scale(alfi_ctx* ctx, const double* partial, int nblocks, const double* h, double* hs, int j, int K,
-                            double* vnext, const double* w, int64_t n) {
+                            double* vnext, const double* w, int64_t n, const double* ww) {
   hipLaunchKernelGGL(hessenberg_scale_kernel, ew_grid(n), dim3(256), 0, ctx->stream, partial, nblocks, h, hs, j, K, vnext,
-                     w, n);
+                     w, n, ww);
   ALFI_HIP_CHECK(ctx, hipGetLastError());
   return 0;
 }
 
 int launch_hessenberg_update(alfi_ctx* ctx, const double* partial, int nblocks, const double* h, double* hs, int j,
-                             int K) {
-  hipLaunchKernelGGL(hessenberg_update_kernel, dim3(1), dim3(256), 0, ctx->stream, partial, nblocks, h, hs, j, K);
+                             int K, const double* ww) {
+  hipLaunchKernelGGL(hessenberg_update_kernel, dim3(1), dim3(256), 0, ctx->stream, partial, nblocks, h, hs, j, K, ww);
   ALFI_HIP_CHECK(ctx, hipGetLastError());
   return 0;
 }

@@ -64,11 +64,13 @@ def test_partitioned_cycles_match_single_gpu(case, world, robust, tmp_path):
     assert np.abs(dv - ov).max() / np.abs(ov).max() < CYCLE_TOL
 
 
-def test_rccl_code_path_with_a_one_rank_group(tmp_path):
+@pytest.mark.parametrize("exact_norm,tol", [("1", 1e-12), ("0", CYCLE_TOL)])
+def test_rccl_code_path_with_a_one_rank_group(tmp_path, exact_norm, tol):
     """The NCCL (= RCCL) transport of alfi_amd.dist on the one GPU of the box: a 1-rank process group with the exchange
     points forced on (empty halos, 1-rank all-reduces issued on the library's stream from inside the callbacks).  Checks
     that torch's RCCL backend accepts exactly the calls the 8-GPU run makes and that the cycle still matches the
-    single-GPU result."""
+    single-GPU result (to rounding with the exact-norm variant; with the one-all-reduce-per-iteration default the 1e-14-level difference in
+    |w| is amplified by the chained FGMRES least-squares problems like any other rounding difference: CYCLE_TOL)."""
     import textwrap
     script = tmp_path / "one_rank.py"
     script.write_text(textwrap.dedent('''
@@ -99,11 +101,13 @@ def test_rccl_code_path_with_a_one_rank_group(tmp_path):
             sv = sx.get()
             mg.fcycle(sb, sx)
             sf = sx.get()
-        assert np.abs(xv - sv).max() <= 1e-12 * np.abs(sv).max(), np.abs(xv - sv).max()
-        assert np.abs(xf - sf).max() <= 1e-12 * np.abs(sf).max()
+        assert np.abs(xv - sv).max() <= %g * np.abs(sv).max(), np.abs(xv - sv).max()
+        assert np.abs(xf - sf).max() <= %g * np.abs(sf).max()
         dist.destroy_process_group()
         print("ONE-RANK-RCCL-OK")
-    ''' % ROOT))
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    ''' % (ROOT, tol, tol)))
+    # ALFI_DIST_EXACT_NORM=1: |w| by its own all-reduce (PETSc's VecNorm) -> the partitioned path reproduces the serial one
+    # to rounding; default: |w|^2 = |w_old|^2 - |h|^2 from the single all-reduce of the iteration
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), ALFI_DIST_EXACT_NORM=exact_norm)
     out = subprocess.run([sys.executable, str(script)], env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "ONE-RANK-RCCL-OK" in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]
