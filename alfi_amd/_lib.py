@@ -39,6 +39,7 @@ SIGNATURES = {
     "alfi_ctx_set_comm": (ctypes.c_int, [vp, vp, vp, vp, ctypes.c_int64]),
     "alfi_level_set_partition": (ctypes.c_int, [vp, ctypes.c_int64, ctypes.c_int, ctypes.c_int64, vp, vp, vp,
                                                 ctypes.c_int64]),
+    "alfi_level_set_overlap": (ctypes.c_int, [vp, ctypes.c_int64, ctypes.c_int64]),
     "alfi_level_id": (ctypes.c_int, [vp, ctypes.POINTER(ctypes.c_int)]),
     "alfi_level_create": (ctypes.c_int, [vp, ctypes.c_int64, ctypes.c_int, vp, vp, vp, vp, ctypes.c_int64,
                                          ctypes.POINTER(vp)]),

@@ -141,6 +141,26 @@ static int halo_fwd(alfi_level* L, double* v) {
   return 0;
 }
 
+// the same in two halves: pack + start the exchange | (caller launches work that needs no ghost value) | wait + unpack
+static int halo_fwd_begin(alfi_level* L, const double* v) {
+  alfi_ctx* ctx = L->ctx;
+  int t = alfi_prof_begin(ctx, ALFI_EV_COMM);
+  ALFI_CHECK(launch_halo_pack(ctx, L->halo_sendbuf, v, L->halo_send_nodes, L->halo_nsend, L->bs));
+  ALFI_CHECK(comm_call(ctx, ALFI_COMM_HALO_FWD_BEGIN, L->id, 0, 0));
+  alfi_prof_end(ctx, t);
+  return 0;
+}
+static int halo_fwd_end(alfi_level* L, double* v) {
+  alfi_ctx* ctx = L->ctx;
+  int t = alfi_prof_begin(ctx, ALFI_EV_COMM);
+  ALFI_CHECK(comm_call(ctx, ALFI_COMM_HALO_FWD_END, L->id, 0, 0));
+  if (L->halo_nghost > 0)
+    ALFI_HIP_CHECK(ctx, hipMemcpyAsync(v + L->n_own, L->halo_recvbuf, sizeof(double) * L->halo_nghost * L->bs,
+                                       hipMemcpyDeviceToDevice, ctx->stream));
+  alfi_prof_end(ctx, t);
+  return 0;
+}
+
 // ghost contributions of v added onto their owners (ghost slots of v keep their local values)
 static int halo_rev(alfi_level* L, double* v) {
   alfi_ctx* ctx = L->ctx;
@@ -359,9 +379,77 @@ int alfi_level_set_partition(alfi_level* L, int64_t nb_owned, int distributed, i
   return 0;
 }
 
+// block-row range [r0, r1) of the flat upload as a view with its own chunk table and carry arrays
+static int make_row_view(alfi_ctx* ctx, const DevBSR& A, const std::vector<int32_t>& rowptr, int64_t r0, int64_t r1,
+                         DevBSR* V) {
+  *V = A;
+  V->view = true;
+  V->nbrows = r1;                       // rows are addressed absolutely; nbrows only has to cover the range
+  V->kbase = rowptr[r0];
+  V->nnzb = rowptr[r1] - rowptr[r0];
+  V->nchunks = (V->nnzb + SPMV_CHUNK - 1) / SPMV_CHUNK;
+  V->chunk_row = nullptr;
+  V->carry = nullptr;
+  V->carry_row = nullptr;
+  std::vector<int32_t> chunk_row((size_t)std::max<int64_t>(V->nchunks, 1));
+  int64_t row = r0;
+  for (int64_t c = 0; c < V->nchunks; ++c) {
+    const int64_t k = V->kbase + c * SPMV_CHUNK;
+    while (rowptr[row + 1] <= k) ++row;
+    chunk_row[c] = (int32_t)row;
+  }
+  ALFI_CHECK(dev_upload(ctx, &V->chunk_row, chunk_row.data(), V->nchunks));
+  ALFI_CHECK(dev_alloc(ctx, &V->carry, V->nchunks * A.bs));
+  ALFI_CHECK(dev_alloc(ctx, &V->carry_row, V->nchunks));
+  return 0;
+}
+static void free_row_view(DevBSR* V) {
+  dev_free(V->chunk_row);
+  dev_free(V->carry);
+  dev_free(V->carry_row);
+  *V = DevBSR();
+}
+
+int alfi_level_set_overlap(alfi_level* L, int64_t nb_interior, int64_t npatch_interior) {
+  alfi_ctx* ctx = L->ctx;
+  const int64_t nb_own = L->n_own / L->bs;
+  if (!L->has_halo || !L->distributed)
+    return alfi_set_error(ctx, ALFI_E_STATE, "alfi_level_set_overlap needs a distributed level (alfi_level_set_partition)");
+  if (nb_interior < 0 || nb_interior > nb_own || npatch_interior < 0 || npatch_interior > L->npatch)
+    return alfi_set_error(ctx, ALFI_E_ARG, "interior counts out of range");
+  if (!L->A.flat) return 0;   // row-per-lane-group layout: no row-range views; keep the plain exchange
+  ALFI_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  ALFI_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  // verify the claims: interior rows hold owned columns only, interior patches hold owned dofs only
+  const int64_t nb = L->A.nbrows;
+  std::vector<int32_t> rowptr(nb + 1);
+  ALFI_HIP_CHECK(ctx, hipMemcpy(rowptr.data(), L->A.rowptr, sizeof(int32_t) * (nb + 1), hipMemcpyDeviceToHost));
+  const int64_t kint = rowptr[nb_interior];
+  if (kint > 0) {
+    std::vector<int32_t> col((size_t)kint);
+    ALFI_HIP_CHECK(ctx, hipMemcpy(col.data(), L->A.colidx, sizeof(int32_t) * kint, hipMemcpyDeviceToHost));
+    for (int64_t k = 0; k < kint; ++k)
+      if ((col[k] & 0x7fffffff) >= nb_own)
+        return alfi_set_error(ctx, ALFI_E_ARG, "an operator row declared interior holds a ghost column");
+  }
+  for (int64_t p = 0; p < npatch_interior; ++p)
+    for (int64_t q = L->h_patch_ptr[p]; q < L->h_patch_ptr[p + 1]; ++q)
+      if (L->h_patch_dofs[q] >= L->n_own)
+        return alfi_set_error(ctx, ALFI_E_ARG, "patch %lld declared interior holds a ghost dof", (long long)p);
+  free_row_view(&L->A_int);
+  free_row_view(&L->A_bnd);
+  ALFI_CHECK(make_row_view(ctx, L->A, rowptr, 0, nb_interior, &L->A_int));
+  ALFI_CHECK(make_row_view(ctx, L->A, rowptr, nb_interior, nb_own, &L->A_bnd));
+  L->npatch_int = npatch_interior;
+  L->overlap = true;
+  return 0;
+}
+
 int alfi_level_destroy(alfi_level* L) {
   if (!L) return 0;
   (void)hipStreamSynchronize(L->ctx->stream);
+  free_row_view(&L->A_int);
+  free_row_view(&L->A_bnd);
   free_bsr(&L->A);
   dev_free(L->bc_dofs);
   dev_free(L->bc_mask);
@@ -396,6 +484,7 @@ int alfi_level_update_values(alfi_level* L, const double* bvals) {
   ALFI_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
   ALFI_CHECK(upload_bsr_values(ctx, &L->A, bvals));
   L->A_own.vals = L->A.vals;
+  L->A_int.vals = L->A_bnd.vals = L->A.vals;
   L->factored = false;
   return 0;
 }
@@ -411,23 +500,33 @@ int alfi_level_id(alfi_level* L, int* id) {
 
 // Partitioned levels: x's ghost slots are refreshed from their owners first (they are scratch: see alfi_hip.h), the
 // product is formed on the owned rows.
-int alfi_spmv(alfi_level* L, const double* dx, double* dy) {
-  L->ctx->cur_tag = L->id;
+// y = A x (mode 0) or y = b - A x (mode 1) on the owned rows of a level.  With alfi_level_set_overlap the rows without
+// ghost columns are multiplied while the forward halo of x is in flight.
+static int level_spmv(alfi_level* L, const double* dx, double* dy, const double* db, int mode) {
+  alfi_ctx* ctx = L->ctx;
+  ctx->cur_tag = L->id;
+  int t;
+  if (L->distributed && L->overlap) {
+    ALFI_CHECK(halo_fwd_begin(L, dx));
+    t = alfi_prof_begin(ctx, ALFI_EV_MATMULT);
+    ALFI_CHECK(launch_bsr_spmv(ctx, L->A_int, dx, dy, db, 1.0, mode));
+    alfi_prof_end(ctx, t);
+    ALFI_CHECK(halo_fwd_end(L, const_cast<double*>(dx)));
+    t = alfi_prof_begin(ctx, ALFI_EV_MATMULT);
+    ALFI_CHECK(launch_bsr_spmv(ctx, L->A_bnd, dx, dy, db, 1.0, mode));
+    alfi_prof_end(ctx, t);
+    return 0;
+  }
   if (L->distributed) ALFI_CHECK(halo_fwd(L, const_cast<double*>(dx)));
-  int t = alfi_prof_begin(L->ctx, ALFI_EV_MATMULT);
-  ALFI_CHECK(launch_bsr_spmv(L->ctx, L->A_own, dx, dy, nullptr, 0.0, 0));
-  alfi_prof_end(L->ctx, t);
+  t = alfi_prof_begin(ctx, ALFI_EV_MATMULT);
+  ALFI_CHECK(launch_bsr_spmv(ctx, L->A_own, dx, dy, db, 1.0, mode));
+  alfi_prof_end(ctx, t);
   return 0;
 }
 
-int alfi_residual(alfi_level* L, const double* db, const double* dx, double* dr) {
-  L->ctx->cur_tag = L->id;
-  if (L->distributed) ALFI_CHECK(halo_fwd(L, const_cast<double*>(dx)));
-  int t = alfi_prof_begin(L->ctx, ALFI_EV_MATMULT);
-  ALFI_CHECK(launch_bsr_spmv(L->ctx, L->A_own, dx, dr, db, 1.0, 1));
-  alfi_prof_end(L->ctx, t);
-  return 0;
-}
+int alfi_spmv(alfi_level* L, const double* dx, double* dy) { return level_spmv(L, dx, dy, nullptr, 0); }
+
+int alfi_residual(alfi_level* L, const double* db, const double* dx, double* dr) { return level_spmv(L, dx, dr, db, 1); }
 
 // PCApply_PATCH on a (possibly partitioned) level: ghost values in, local patch solves, ghost contributions back to
 // their owners, Dirichlet dofs copied
@@ -453,6 +552,15 @@ static int level_patch_apply(alfi_level* L, const double* dx, double* dy) {
       alfi_prof_end(ctx, t);
     }
     return 0;
+  }
+  if (L->distributed && L->overlap) {
+    // patches without ghost dofs while the forward halo of x is in flight, the others after it landed
+    ALFI_CHECK(halo_fwd_begin(L, dx));
+    ALFI_CHECK(launch_patch_apply_range(L, 0, L->npatch_int, dx));
+    ALFI_CHECK(halo_fwd_end(L, const_cast<double*>(dx)));
+    ALFI_CHECK(launch_patch_apply_range(L, L->npatch_int, L->npatch, dx));
+    ALFI_CHECK(launch_patch_sum(L, dx, dy));
+    return halo_rev(L, dy);
   }
   if (L->distributed) ALFI_CHECK(halo_fwd(L, const_cast<double*>(dx)));
   ALFI_CHECK(launch_patch_apply(L, dx, dy));    // includes y[bc] = x[bc] (no patch holds a Dirichlet dof, so the

@@ -96,6 +96,8 @@ struct DevBSR {
   int32_t* colidx = nullptr;
   double* vals = nullptr;
   int flat = 0;
+  int64_t kbase = 0;            // first block of a block-row-range view (flat layout; 0 for the upload itself)
+  bool view = false;            // a row-range view: rows outside the range are not touched
   int64_t nchunks = 0;
   int32_t* chunk_row = nullptr;
   double* carry = nullptr;      // (nchunks, bs): partial sums of block rows that continue into the next chunk
@@ -118,6 +120,10 @@ struct alfi_level {
   // partition: owned prefix [0, n_own) of the local numbering, then ghosts (serial: n_own == n)
   int64_t n_own = 0;
   DevBSR A_own;             // view of A restricted to the owned block rows
+  // overlap of the forward halo with work that needs no ghost value (alfi_level_set_overlap)
+  bool overlap = false;
+  DevBSR A_int, A_bnd;       // owned rows without / with ghost columns (own chunk tables)
+  int64_t npatch_int = 0;    // leading patches without ghost dofs
   bool distributed = false;  // smoother / SpMV exchange halos and all-reduce
   bool has_halo = false;
   int64_t halo_nsend = 0, halo_nghost = 0;  // nodes
@@ -217,7 +223,9 @@ int launch_bsr_spmv(alfi_ctx* ctx, const DevBSR& A, const double* x, double* y, 
 int upload_bsr_values(alfi_ctx* ctx, DevBSR* d, const double* host_vals);
 int launch_patch_gather_dense(alfi_level* lvl);
 int launch_patch_invert(alfi_level* lvl);
-int launch_patch_apply(alfi_level* lvl, const double* x, double* y);
+int launch_patch_apply(alfi_level* lvl, const double* x, double* y);          // both stages, all patches
+int launch_patch_apply_range(alfi_level* lvl, int64_t p0, int64_t p1, const double* x);   // stage 1, patches [p0, p1)
+int launch_patch_sum(alfi_level* lvl, const double* x, double* y);             // stage 2
 // one dependency wavefront of a multiplicative sweep: patches seq[0..count): y_p += inv(A_p) (x - A y)_p
 int launch_patch_mult_wave(alfi_level* lvl, const int32_t* seq, int64_t count, const double* x, double* y);
 int launch_invert_small_any(alfi_ctx* ctx, int nmax, int64_t nmat, const int64_t* ptr, const int64_t* inv_ptr,

@@ -253,7 +253,8 @@ __device__ __forceinline__ void apply_piece(const double* __restrict__ T, int n,
 }
 
 template <bool NT>
-__global__ __launch_bounds__(256) void patch_apply_kernel(int64_t npatch, const int64_t* __restrict__ patch_ptr,
+__global__ __launch_bounds__(256) void patch_apply_kernel(int64_t p0, int64_t npatch,
+                                                           const int64_t* __restrict__ patch_ptr,
                                                            const int32_t* __restrict__ patch_dofs,
                                                            const int64_t* __restrict__ inv_ptr,
                                                            const int64_t* __restrict__ stage_ptr,
@@ -261,7 +262,7 @@ __global__ __launch_bounds__(256) void patch_apply_kernel(int64_t npatch, const 
                                                            const double* __restrict__ x, double* __restrict__ stage) {
   __shared__ double xs_all[4][MAX_NP];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int64_t p = (int64_t)blockIdx.x * 4 + wave;
+  const int64_t p = p0 + (int64_t)blockIdx.x * 4 + wave;   // patches [p0, npatch)
   double* xs = xs_all[wave];
   int n = 0;
   if (p < npatch) {
@@ -298,14 +299,15 @@ __global__ __launch_bounds__(256) void patch_apply_kernel(int64_t npatch, const 
 //     16-byte load per column, x_p broadcast within the lane group by shuffles.  Same storage, same staging as section 3.
 // ---------------------------------------------------------------------------------------------------------------------
 template <int G, bool NT>
-__global__ __launch_bounds__(256) void patch_apply_small_kernel(int64_t npatch, const int64_t* __restrict__ patch_ptr,
+__global__ __launch_bounds__(256) void patch_apply_small_kernel(int64_t p0, int64_t npatch,
+                                                                 const int64_t* __restrict__ patch_ptr,
                                                                  const int32_t* __restrict__ patch_dofs,
                                                                  const int64_t* __restrict__ inv_ptr,
                                                                  const int64_t* __restrict__ stage_ptr,
                                                                  const double* __restrict__ inv,
                                                                  const double* __restrict__ x,
                                                                  double* __restrict__ stage) {
-  const int64_t p = ((int64_t)blockIdx.x * 256 + threadIdx.x) / G;
+  const int64_t p = p0 + ((int64_t)blockIdx.x * 256 + threadIdx.x) / G;   // patches [p0, npatch)
   const int l = threadIdx.x % G;
   const bool live = p < npatch;
   int n = 0;
@@ -599,36 +601,43 @@ int launch_patch_mult_wave(alfi_level* L, const int32_t* seq, int64_t count, con
   return 0;
 }
 
-int launch_patch_apply(alfi_level* L, const double* x, double* y) {
+// stage 1 for the patches [p0, p1) of the level
+int launch_patch_apply_range(alfi_level* L, int64_t p0, int64_t p1, const double* x) {
   alfi_ctx* ctx = L->ctx;
-  if (L->npatch > 0) {
-    int t = alfi_prof_begin(ctx, ALFI_EV_PATCH_APPLY);
-    dim3 grid((unsigned)((L->npatch + 3) / 4)), block(256);
-    // the inverses are read once per apply: nontemporal loads keep x, the staging buffer and the index arrays in cache
-    static const bool nt = !(getenv("ALFI_NT") && atoi(getenv("ALFI_NT")) == 0);
-    static const bool small_ok = !(getenv("ALFI_SMALL_PATCH") && atoi(getenv("ALFI_SMALL_PATCH")) == 0);
-    if (small_ok && L->max_np <= 32) {
-      // small patches: G lanes per patch, 64 / G patches per wave
-      const int G = L->max_np <= 16 ? 8 : 16;
-      dim3 sgrid((unsigned)((L->npatch * G + 255) / 256));
+  if (p1 <= p0) return 0;
+  int t = alfi_prof_begin(ctx, ALFI_EV_PATCH_APPLY);
+  const int64_t cnt = p1 - p0;
+  dim3 grid((unsigned)((cnt + 3) / 4)), block(256);
+  // the inverses are read once per apply: nontemporal loads keep x, the staging buffer and the index arrays in cache
+  static const bool nt = !(getenv("ALFI_NT") && atoi(getenv("ALFI_NT")) == 0);
+  static const bool small_ok = !(getenv("ALFI_SMALL_PATCH") && atoi(getenv("ALFI_SMALL_PATCH")) == 0);
+  if (small_ok && L->max_np <= 32) {
+    // small patches: G lanes per patch, 64 / G patches per wave
+    const int G = L->max_np <= 16 ? 8 : 16;
+    dim3 sgrid((unsigned)((cnt * G + 255) / 256));
 #define ALFI_SMALL(GV, NTV)                                                                                            \
-  hipLaunchKernelGGL((patch_apply_small_kernel<GV, NTV>), sgrid, block, 0, ctx->stream, L->npatch, L->patch_ptr,       \
+  hipLaunchKernelGGL((patch_apply_small_kernel<GV, NTV>), sgrid, block, 0, ctx->stream, p0, p1, L->patch_ptr,          \
                      L->patch_dofs, L->inv_ptr, L->stage_ptr, L->inv, x, L->stage)
-      if (G == 8) {
-        if (nt) ALFI_SMALL(8, true); else ALFI_SMALL(8, false);
-      } else {
-        if (nt) ALFI_SMALL(16, true); else ALFI_SMALL(16, false);
-      }
+    if (G == 8) {
+      if (nt) ALFI_SMALL(8, true); else ALFI_SMALL(8, false);
+    } else {
+      if (nt) ALFI_SMALL(16, true); else ALFI_SMALL(16, false);
+    }
 #undef ALFI_SMALL
-    } else if (nt)
-      hipLaunchKernelGGL(patch_apply_kernel<true>, grid, block, 0, ctx->stream, L->npatch, L->patch_ptr, L->patch_dofs,
-                         L->inv_ptr, L->stage_ptr, L->inv, x, L->stage);
-    else
-      hipLaunchKernelGGL(patch_apply_kernel<false>, grid, block, 0, ctx->stream, L->npatch, L->patch_ptr, L->patch_dofs,
-                         L->inv_ptr, L->stage_ptr, L->inv, x, L->stage);
-    ALFI_HIP_CHECK(ctx, hipGetLastError());
-    alfi_prof_end(ctx, t);
-  }
+  } else if (nt)
+    hipLaunchKernelGGL(patch_apply_kernel<true>, grid, block, 0, ctx->stream, p0, p1, L->patch_ptr, L->patch_dofs,
+                       L->inv_ptr, L->stage_ptr, L->inv, x, L->stage);
+  else
+    hipLaunchKernelGGL(patch_apply_kernel<false>, grid, block, 0, ctx->stream, p0, p1, L->patch_ptr, L->patch_dofs,
+                       L->inv_ptr, L->stage_ptr, L->inv, x, L->stage);
+  ALFI_HIP_CHECK(ctx, hipGetLastError());
+  alfi_prof_end(ctx, t);
+  return 0;
+}
+
+// stage 2: dof-wise sum of the staged results (+ Dirichlet copy)
+int launch_patch_sum(alfi_level* L, const double* x, double* y) {
+  alfi_ctx* ctx = L->ctx;
   int t = alfi_prof_begin(ctx, ALFI_EV_PATCH_SCATTER);
   dim3 grid((unsigned)((L->n + 255) / 256)), block(256);
   hipLaunchKernelGGL(patch_sum_kernel, grid, block, 0, ctx->stream, L->n, L->dof_ptr, L->dof_pos, L->stage, L->bc_mask, x,
@@ -636,4 +645,9 @@ int launch_patch_apply(alfi_level* L, const double* x, double* y) {
   ALFI_HIP_CHECK(ctx, hipGetLastError());
   alfi_prof_end(ctx, t);
   return 0;
+}
+
+int launch_patch_apply(alfi_level* L, const double* x, double* y) {
+  ALFI_CHECK(launch_patch_apply_range(L, 0, L->npatch, x));
+  return launch_patch_sum(L, x, y);
 }

@@ -58,7 +58,7 @@ __global__ __launch_bounds__(256) void bsr_spmv_kernel(int64_t nbrows, const int
 // ---------------------------------------------------------------------------------------------------------------------
 typedef double spmv_d2 __attribute__((ext_vector_type(2)));
 template <int BS, bool NT>
-__global__ __launch_bounds__(256) void bsr_spmv_flat_kernel(int64_t nnzb, int64_t nchunks,
+__global__ __launch_bounds__(256) void bsr_spmv_flat_kernel(int64_t kbase, int64_t nnzb, int64_t nchunks,
                                                              const int32_t* __restrict__ colflag,
                                                              const double* __restrict__ vals,
                                                              const int32_t* __restrict__ chunk_row,
@@ -80,7 +80,10 @@ __global__ __launch_bounds__(256) void bsr_spmv_flat_kernel(int64_t nnzb, int64_
   }
   const int64_t chunk = blk * 4 + (threadIdx.x >> 6);
   if (chunk >= nchunks) return;
-  const int64_t base = chunk * SPMV_CHUNK;
+  // blocks [kbase, kbase + nnzb) of the upload: a block-row range (the whole matrix, the owned rows, or the owned rows
+  // with / without ghost columns of a partitioned level); the value / index layout is addressed by the absolute block
+  const int64_t kend_all = kbase + nnzb;
+  const int64_t base = kbase + chunk * SPMV_CHUNK;
   int R = chunk_row[chunk];  // block row of lane 0's block
   int Rlast = R;
   double carry[BS];
@@ -96,7 +99,7 @@ __global__ __launch_bounds__(256) void bsr_spmv_flat_kernel(int64_t nnzb, int64_
 #pragma unroll
   for (int u = 0; u < SPMV_U; ++u) {
     const int64_t k = base + u * 64 + lane;
-    const bool valid = k < nnzb;
+    const bool valid = k < kend_all;
     const int32_t cf = valid ? (NT ? __builtin_nontemporal_load(colflag + k) : colflag[k]) : 0;
     const bool head = cf < 0;
     const int64_t col = cf & 0x7fffffff;
@@ -105,16 +108,17 @@ __global__ __launch_bounds__(256) void bsr_spmv_flat_kernel(int64_t nnzb, int64_
     for (int r = 0; r < BS; ++r) p[r] = 0.0;
     if (valid) {
       const double* v = vals + (k >> 6) * (64 * BB);
+      const int kl = (int)(k & 63);        // position inside the 64-block group (== lane unless the view starts mid-group)
       double a[BB], xv[BS];
 #pragma unroll
       for (int q = 0; q < BB / 2; ++q) {   // pair planes: one aligned 16-byte load per lane
-        const spmv_d2* pq = reinterpret_cast<const spmv_d2*>(v + q * 128) + lane;
+        const spmv_d2* pq = reinterpret_cast<const spmv_d2*>(v + q * 128) + kl;
         const spmv_d2 t = NT ? __builtin_nontemporal_load(pq) : *pq;
         a[2 * q] = t.x;
         a[2 * q + 1] = t.y;
       }
       if (BB & 1) {
-        const double* pl = v + (BB / 2) * 128 + lane;
+        const double* pl = v + (BB / 2) * 128 + kl;
         a[BB - 1] = NT ? __builtin_nontemporal_load(pl) : *pl;
       }
 #pragma unroll
@@ -157,7 +161,7 @@ __global__ __launch_bounds__(256) void bsr_spmv_flat_kernel(int64_t nnzb, int64_
   }
   const int64_t kend = base + SPMV_CHUNK;
   if (lane == 0) {
-    const bool closed = kend >= nnzb || colflag[kend] < 0;
+    const bool closed = kend >= kend_all || colflag[kend] < 0;
     if (closed) {
       store_row(Rlast, carry);
       carry_row[chunk] = -1;
@@ -233,19 +237,20 @@ template <int BS>
 static int launch_bsr_spmv_bs(alfi_ctx* ctx, const DevBSR& A, const double* x, double* y, const double* b, double alpha,
                               int mode) {
   if (A.flat) {
-    const int64_t nchunks = (A.nnzb + SPMV_CHUNK - 1) / SPMV_CHUNK;   // A may be a row-prefix view of the upload
+    if (A.nnzb == 0) return 0;
+    const int64_t nchunks = (A.nnzb + SPMV_CHUNK - 1) / SPMV_CHUNK;   // A may be a block-row-range view of the upload
     // operator values and indices are used once per product: stream them past the caches (nontemporal) so that x and y
     // keep the L2 / Infinity Cache.  ALFI_NT=0 switches to plain loads (A/B measurements).
     static const bool nt = !(getenv("ALFI_NT") && atoi(getenv("ALFI_NT")) == 0);
     static const int xcd = (getenv("ALFI_XCD_MAP") && atoi(getenv("ALFI_XCD_MAP")) == 1) ? 1 : 0;
     if (nt)
       hipLaunchKernelGGL((bsr_spmv_flat_kernel<BS, true>), dim3((unsigned)((nchunks + 3) / 4)), dim3(256), 0,
-                         ctx->stream, A.nnzb, nchunks, A.colidx, A.vals, A.chunk_row, x, y, b, alpha, mode, A.carry,
-                         A.carry_row, xcd);
+                         ctx->stream, A.kbase, A.nnzb, nchunks, A.colidx, A.vals, A.chunk_row, x, y, b, alpha, mode,
+                         A.carry, A.carry_row, xcd);
     else
       hipLaunchKernelGGL((bsr_spmv_flat_kernel<BS, false>), dim3((unsigned)((nchunks + 3) / 4)), dim3(256), 0,
-                         ctx->stream, A.nnzb, nchunks, A.colidx, A.vals, A.chunk_row, x, y, b, alpha, mode, A.carry,
-                         A.carry_row, xcd);
+                         ctx->stream, A.kbase, A.nnzb, nchunks, A.colidx, A.vals, A.chunk_row, x, y, b, alpha, mode,
+                         A.carry, A.carry_row, xcd);
     ALFI_HIP_CHECK(ctx, hipGetLastError());
     hipLaunchKernelGGL((bsr_spmv_fixup_kernel<BS>), dim3((unsigned)((nchunks + 255) / 256)), dim3(256), 0, ctx->stream,
                        nchunks, A.carry, A.carry_row, y, alpha, mode);
@@ -276,6 +281,7 @@ static int launch_bsr_spmv_bs(alfi_ctx* ctx, const DevBSR& A, const double* x, d
 
 int launch_bsr_spmv(alfi_ctx* ctx, const DevBSR& A, const double* x, double* y, const double* b, double alpha,
                     int mode) {
+  if (A.view && A.nnzb == 0) return 0;   // an empty row range of a partitioned level: nothing to write
   if (A.nbrows == 0 || A.nnzb == 0) {
     // no entries: y = 0 or y = b on the rows of A
     if (A.nbrows > 0) {

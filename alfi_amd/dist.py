@@ -27,7 +27,7 @@ import numpy as np
 
 from .problem import BSR
 
-COMM_ALLREDUCE, COMM_HALO_FWD, COMM_HALO_REV = 0, 1, 2
+COMM_ALLREDUCE, COMM_HALO_FWD, COMM_HALO_REV, COMM_HALO_FWD_BEGIN, COMM_HALO_FWD_END = 0, 1, 2, 3, 4
 RED_LEN = 64
 
 
@@ -70,10 +70,20 @@ def choose_splits(levels, world, min_dofs=400000):
 class LevelPart(object):
     """One rank's view of one level: owned range, ghosts, local numbering, halo plan."""
 
-    def __init__(self, level, bs, splits, rank, ghosts, force_distributed=False):
+    def __init__(self, level, bs, splits, rank, ghosts, force_distributed=False, boundary_mask=None):
+        """boundary_mask: (nb_own,) bool over the owned global range, True for owned nodes whose operator row reaches a
+        ghost.  Local numbering = owned interior nodes, owned boundary nodes, ghosts: the rows / patches that need no
+        ghost value come first, so the library can work on them while the forward halo is in flight."""
         self.level, self.bs, self.splits, self.rank = level, bs, np.asarray(splits, dtype=np.int64), rank
         self.lo, self.hi = int(splits[rank]), int(splits[rank + 1])
         self.nb_own = self.hi - self.lo
+        if boundary_mask is None:
+            boundary_mask = np.zeros(self.nb_own, dtype=bool)
+        own = np.arange(self.lo, self.hi, dtype=np.int64)
+        self.own_nodes = np.concatenate([own[~boundary_mask], own[boundary_mask]])     # global ids in local order
+        self.nb_int = int(np.count_nonzero(~boundary_mask))
+        self.own_perm = np.empty(self.nb_own, dtype=np.int64)                           # global - lo -> local index
+        self.own_perm[self.own_nodes - self.lo] = np.arange(self.nb_own)
         self.ghosts = np.asarray(ghosts, dtype=np.int64)              # global ids, ascending => grouped by owner
         self.nb_ghost = self.ghosts.shape[0]
         self.nb_loc = self.nb_own + self.nb_ghost
@@ -88,7 +98,11 @@ class LevelPart(object):
 
     @property
     def nodes(self):
-        return np.concatenate([np.arange(self.lo, self.hi, dtype=np.int64), self.ghosts])
+        return np.concatenate([self.own_nodes, self.ghosts])
+
+    def own_dofs(self):
+        """Global dof numbers of the owned entries of a local vector, in local order."""
+        return (self.own_nodes[:, None] * self.bs + np.arange(self.bs)).ravel()
 
     def ghosts_by_owner(self):
         off = np.concatenate([[0], np.cumsum(self.recv_counts)])
@@ -96,9 +110,10 @@ class LevelPart(object):
 
     def set_send_lists(self, wanted):
         """wanted[q]: global node ids rank q holds as ghosts of mine (ascending, q's ghost order)."""
-        self.send_nodes = [np.asarray(w, dtype=np.int64) - self.lo for w in wanted]
-        for q, s in enumerate(self.send_nodes):
-            assert s.size == 0 or (s.min() >= 0 and s.max() < self.nb_own), "rank %d asked for nodes I do not own" % q
+        for q, w in enumerate(wanted):
+            w = np.asarray(w, dtype=np.int64)
+            assert w.size == 0 or (w.min() >= self.lo and w.max() < self.hi), "rank %d asked for nodes I do not own" % q
+        self.send_nodes = [self.own_perm[np.asarray(w, dtype=np.int64) - self.lo] for w in wanted]
         self.send_counts = np.array([s.shape[0] for s in self.send_nodes], dtype=np.int64)
 
     @property
@@ -110,7 +125,7 @@ class LevelPart(object):
         g = np.asarray(g, dtype=np.int64)
         out = np.full(g.shape, -1, dtype=np.int64)
         own = (g >= self.lo) & (g < self.hi)
-        out[own] = g[own] - self.lo
+        out[own] = self.own_perm[g[own] - self.lo]
         if self.nb_ghost:
             pos = np.searchsorted(self.ghosts, g)
             pos[pos >= self.nb_ghost] = self.nb_ghost - 1
@@ -147,6 +162,19 @@ def transfer_blocks(T, bs, lo, hi):
     reach exactly the fine nodes of the coarse cell's closure."""
     mb = T.blk_dofs.shape[1] // bs
     return np.flatnonzero(_rows_with_cols_in(T.D_I, lo, hi).reshape(-1, mb).any(axis=1))
+
+
+def owned_boundary_mask(A, lo, hi):
+    """Over the owned rows [lo, hi) of BSR A: True where the row holds a column outside the owned range."""
+    if hi <= lo:
+        return np.zeros(0, dtype=bool)
+    k0, k1 = int(A.rowptr[lo]), int(A.rowptr[hi])
+    col = A.colidx[k0:k1]
+    out_of_range = (col < lo) | (col >= hi)
+    rows = np.repeat(np.arange(hi - lo, dtype=np.int64), np.diff(A.rowptr[lo:hi + 1]))[out_of_range]
+    mask = np.zeros(hi - lo, dtype=bool)
+    mask[rows] = True
+    return mask
 
 
 def compute_ghosts(levels, transfers, splits, l, rank):
@@ -188,7 +216,9 @@ def build_parts(levels, transfers, splits, rank, exchange_lists=None, force_dist
     mine = []
     for l, L in enumerate(levels):
         force = force_distributed_above is not None and l > 0 and L.n >= force_distributed_above
-        p = LevelPart(l, L.bs, splits[l], rank, compute_ghosts(levels, transfers, splits, l, rank), force)
+        lo, hi = int(splits[l][rank]), int(splits[l][rank + 1])
+        p = LevelPart(l, L.bs, splits[l], rank, compute_ghosts(levels, transfers, splits, l, rank), force,
+                      boundary_mask=owned_boundary_mask(L.A, lo, hi))
         parts.append(p)
         mine.append(p.ghosts_by_owner())
     if exchange_lists is not None:
@@ -253,7 +283,7 @@ def localize_level(L, part):
             np.concatenate([own.colidx, gh.colidx]), np.concatenate([own.vals, gh.vals]))
     out.A = A
     bcn = np.asarray(L.bc_dofs, dtype=np.int64)[::bs] // bs
-    bcn = bcn[(bcn >= part.lo) & (bcn < part.hi)] - part.lo
+    bcn = np.sort(part.g2l(bcn[(bcn >= part.lo) & (bcn < part.hi)]))
     out.bc_dofs = (bcn[:, None] * bs + np.arange(bs)).ravel().astype(np.int32)
     if L.level > 0 and part.nb_own > 0:
         sel = owned_patches(L, part.lo, part.hi)
@@ -262,12 +292,23 @@ def localize_level(L, part):
         ld = part.g2l(gd // bs) * bs + gd % bs
         assert (ld >= 0).all()
         pid = np.repeat(np.arange(len(sel)), np.diff(nptr))
-        order = np.lexsort((ld, pid))                                          # ascending within each patch
-        out.patch_ptr, out.patch_dofs = nptr.astype(np.int64), ld[order].astype(np.int32)
-        out.patch_ids = sel
+        # patches without a ghost dof first (the library applies them while the forward halo is in flight); inside a
+        # patch ascending local dofs
+        has_ghost = np.zeros(len(sel), dtype=bool)
+        has_ghost[pid[ld >= part.nb_own * bs]] = True
+        porder = np.concatenate([np.flatnonzero(~has_ghost), np.flatnonzero(has_ghost)])
+        rank_of = np.empty(len(sel), dtype=np.int64)
+        rank_of[porder] = np.arange(len(sel))
+        order = np.lexsort((ld, rank_of[pid]))
+        cnt = np.diff(nptr)[porder]
+        out.patch_ptr = np.concatenate([[0], np.cumsum(cnt)]).astype(np.int64)
+        out.patch_dofs = ld[order].astype(np.int32)
+        out.patch_ids = sel[porder]
+        out.npatch_int = int(np.count_nonzero(~has_ghost))
     else:
         out.patch_ptr, out.patch_dofs = np.zeros(1, dtype=np.int64), np.zeros(0, dtype=np.int32)
         out.patch_ids = np.zeros(0, dtype=np.int64)
+        out.npatch_int = 0
     return out
 
 
@@ -287,11 +328,11 @@ def localize_transfer(T, Lf, pc, pf):
     out.D_I = _map_cols(T.D_I.select_rows(rows), pf, pf.nb_loc)
     # rows of D_I^T for the owned fine nodes only: s = r - gamma D_I^T t is formed on owned rows
     out.D_IT = out.D_I.transpose().select_rows(np.arange(pf.nb_own))
-    P = _map_cols(T.P.select_rows(np.arange(pf.lo, pf.hi)), pc, pc.nb_loc)
+    P = _map_cols(T.P.select_rows(pf.own_nodes), pc, pc.nb_loc)
     out.P = P
     out.PT = P.transpose()                                  # (coarse local) x (fine owned): partial sums, reverse-added
     if T.PT_plain is not T.PT:
-        Pp = T.PT_plain.transpose().select_rows(np.arange(pf.lo, pf.hi))
+        Pp = T.PT_plain.transpose().select_rows(pf.own_nodes)
         out.PT_plain = _map_cols(Pp, pc, pc.nb_loc).transpose()
     else:
         out.PT_plain = out.PT
@@ -346,6 +387,20 @@ class Comm(object):
         else:
             self.dist.all_reduce(t, group=self.group)
 
+    def exchange_begin(self, send, recv, send_counts, recv_counts):
+        """Start the exchange without making the current stream wait for it; returns a handle for exchange_end.  The
+        collective runs on the backend's own stream after everything enqueued so far on the current stream (RCCL); with
+        a host-staged backend the whole exchange happens here."""
+        if self._staged(send):
+            self.exchange(send, recv, send_counts, recv_counts)
+            return None
+        return self.dist.all_to_all_single(recv, send, recv_counts, send_counts, group=self.group, async_op=True)
+
+    @staticmethod
+    def exchange_end(work):
+        if work is not None:
+            work.wait()          # stream-level wait (no host block) for the RCCL backend
+
     def exchange(self, send, recv, send_counts, recv_counts):
         """recv[segment q] <- rank q's send[segment me]; counts in elements of the tensors."""
         sc, rc = send_counts, recv_counts
@@ -376,9 +431,17 @@ class HaloBuffers(object):
         # the callbacks run ~200 times per cycle: keep the per-call host work to the collective itself
         self._send, self._recv = self.sendbuf[:self.nsend], self.recvbuf[:self.nrecv]
         self._sc, self._rc = [int(c) for c in self.send_counts], [int(c) for c in self.recv_counts]
+        self._work = None
 
     def forward(self, comm):
         comm.exchange(self._send, self._recv, self._sc, self._rc)
+
+    def forward_begin(self, comm):
+        self._work = comm.exchange_begin(self._send, self._recv, self._sc, self._rc)
+
+    def forward_end(self, comm):
+        comm.exchange_end(self._work)
+        self._work = None
 
     def reverse(self, comm):
         comm.exchange(self._recv, self._send, self._rc, self._sc)
@@ -394,11 +457,15 @@ class DistMultigrid(object):
     only the rank's rows are uploaded)."""
 
     def __init__(self, levels, transfers, k, robust_restriction=False, group=None, device=None, min_dofs=400000,
-                 coarse_inverse=None, verbose=False, force_distributed=False):
+                 coarse_inverse=None, verbose=False, force_distributed=False, overlap=None):
         import torch
         from . import hip
         self.comm = Comm(group)
         rank = self.comm.rank
+        if overlap is None:
+            import os
+            overlap = os.environ.get("ALFI_DIST_OVERLAP", "1") != "0"
+        self.overlap = overlap
         if device is None:
             device = torch.device("cuda", torch.cuda.current_device())
         self.device = device
@@ -428,6 +495,9 @@ class DistMultigrid(object):
                 if LL.level > 0:
                     dl.set_patches(LL.patch_ptr, LL.patch_dofs)
                     dl.factor()
+                    if p.distributed and overlap:
+                        # interior rows / patches are worked on while the forward halo is in flight
+                        dl.set_overlap(p.nb_int, LL.npatch_int)
                 elif p.nb_own > 0:
                     inv = coarse_inverse(levels[0].A) if coarse_inverse is not None else hip.coarse_inverse(levels[0].A)
                     if isinstance(inv, tuple):
@@ -453,6 +523,10 @@ class DistMultigrid(object):
                 self.halos[level_id].forward(self.comm)
             elif op == COMM_HALO_REV:
                 self.halos[level_id].reverse(self.comm)
+            elif op == COMM_HALO_FWD_BEGIN:
+                self.halos[level_id].forward_begin(self.comm)
+            elif op == COMM_HALO_FWD_END:
+                self.halos[level_id].forward_end(self.comm)
             else:
                 return -2
             return 0
@@ -467,7 +541,7 @@ class DistMultigrid(object):
         if global_array is not None:
             p, bs = self.fine.part, self.fine.bs
             loc = np.zeros(self.n_loc)
-            loc[:self.n_own] = np.asarray(global_array)[p.lo * bs:p.hi * bs]
+            loc[:self.n_own] = np.asarray(global_array)[p.own_dofs()]
             v.set(loc)
         return v
 

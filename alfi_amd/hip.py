@@ -135,6 +135,9 @@ class Level(object):
                                                              int(nb_ghost)))
         self.n_own = int(nb_owned) * self.bs
 
+    def set_overlap(self, nb_interior, npatch_interior):
+        self.ctx.check(self.ctx.lib.alfi_level_set_overlap(self.h, int(nb_interior), int(npatch_interior)))
+
     def update_values(self, vals):
         vals = np.ascontiguousarray(vals, dtype=np.float64)
         self.ctx.check(self.ctx.lib.alfi_level_update_values(self.h, _ptr(vals)))

@@ -75,9 +75,13 @@ int alfi_prof_get_level(alfi_ctx* ctx, int ev, int level_id, double* total_ms, i
  * alfi_amd/dist.py) stream-ordered on the ctx's stream and returns 0.  ops:
  *   ALFI_COMM_ALLREDUCE: sum dred[offset .. offset+count) over all ranks, in place;
  *   ALFI_COMM_HALO_FWD : level `level_id`: every owner's send buffer -> the ghosts' receive buffers;
- *   ALFI_COMM_HALO_REV : the reverse route: receive buffers (ghost contributions) -> owners' send buffers.
+ *   ALFI_COMM_HALO_REV : the reverse route: receive buffers (ghost contributions) -> owners' send buffers;
+ *   ALFI_COMM_HALO_FWD_BEGIN / _END: the forward exchange split in two, so that the library can launch work that needs
+ *                        no ghost value in between (only used on levels prepared with alfi_level_set_overlap): BEGIN
+ *                        starts the exchange without making the ctx stream wait for it, END makes the stream wait.
  * Every rank of the group reaches every call (the exchanges are collective). */
-enum { ALFI_COMM_ALLREDUCE = 0, ALFI_COMM_HALO_FWD = 1, ALFI_COMM_HALO_REV = 2 };
+enum { ALFI_COMM_ALLREDUCE = 0, ALFI_COMM_HALO_FWD = 1, ALFI_COMM_HALO_REV = 2, ALFI_COMM_HALO_FWD_BEGIN = 3,
+       ALFI_COMM_HALO_FWD_END = 4 };
 typedef int (*alfi_comm_fn)(void* user, int op, int level_id, int64_t offset, int64_t count);
 /* dred: device buffer of dred_len >= 64 doubles owned by the caller (reduction scratch the callback all-reduces). */
 int alfi_ctx_set_comm(alfi_ctx* ctx, alfi_comm_fn fn, void* user, double* dred, int64_t dred_len);
@@ -97,6 +101,11 @@ int alfi_level_destroy(alfi_level* lvl);
  * doubles in ghost order.  Both buffers are device memory owned by the caller. */
 int alfi_level_set_partition(alfi_level* lvl, int64_t nb_owned, int distributed, int64_t nsend,
                              const int32_t* send_nodes_host, double* d_sendbuf, double* d_recvbuf, int64_t nb_ghost);
+/* Communication / computation overlap on a distributed level (after alfi_level_set_partition and alfi_patches_set): the
+ * caller numbered the owned nodes so that the first nb_interior have operator rows without ghost columns, and ordered the
+ * patches so that the first npatch_interior hold no ghost dof.  SpMV and patch apply then run those parts between
+ * ALFI_COMM_HALO_FWD_BEGIN and _END.  Both claims are verified. */
+int alfi_level_set_overlap(alfi_level* lvl, int64_t nb_interior, int64_t npatch_interior);
 /* new Newton step / new Reynolds number: same sparsity, new values (PatchPC.update -> PCSetUp_PATCH [3P]). */
 int alfi_level_update_values(alfi_level* lvl, const double* bvals_host);
 int alfi_level_size(alfi_level* lvl, int64_t* n);

@@ -30,7 +30,7 @@ def main():
     dmg.fcycle(db, dx)
     xf = dmg.owned(dx)
     p, bs = dmg.fine.part, dmg.fine.bs
-    np.savez(os.path.join(out, "rank%d.npz" % rank), lo=p.lo * bs, hi=p.hi * bs, xv=xv, xf=xf)
+    np.savez(os.path.join(out, "rank%d.npz" % rank), dofs=p.own_dofs(), xv=xv, xf=xf)
     dmg.close()
     dist.barrier()
     dist.destroy_process_group()

@@ -49,11 +49,11 @@ def _worker(rank, world, port, case, robust, q):
         b = np.random.default_rng(0).standard_normal(lv[-1].n)
         b[lv[-1].bc_dofs] = 0.0
         bl = np.zeros(F.n)
-        bl[:F.n_own] = b[p.lo * bs:p.hi * bs]
+        bl[:F.n_own] = b[p.own_dofs()]
         xv = mg.vcycle(len(llev) - 1, bl, np.zeros(F.n))
         xv = mg.vcycle(len(llev) - 1, bl, xv)
         xf = mg.fcycle(bl)
-        q.put((rank, p.lo * bs, p.hi * bs, xv[:F.n_own], xf[:F.n_own]))
+        q.put((rank, p.own_dofs(), xv[:F.n_own], xf[:F.n_own]))
     finally:
         dist.destroy_process_group()
 
@@ -91,8 +91,8 @@ def test_spmd_oracle_matches_serial(case, world, robust):
         p.join(timeout=60)
         assert p.exitcode == 0
     dv, df = np.full_like(b, np.nan), np.full_like(b, np.nan)
-    for rank, lo, hi, v, f in got:
-        dv[lo:hi], df[lo:hi] = v, f
+    for rank, dofs, v, f in got:
+        dv[dofs], df[dofs] = v, f
     assert not np.isnan(dv).any()
     # 2-D: 1e-8.  3-D (patch condition numbers ~1e7 at Re 1000): LAPACK inverts the same patch operators with the dofs in
     # local instead of global order, a cond*eps ~ 1e-9 difference per apply that the chained FGMRES least-squares problems
@@ -117,7 +117,7 @@ def test_partition_covers_and_plans_are_consistent():
             gb = pr.ghosts_by_owner()
             for q in range(world):
                 pq = allparts[q][l]
-                assert np.array_equal(gb[q], pq.send_nodes[r] + pq.lo)
+                assert np.array_equal(gb[q], pq.own_nodes[pq.send_nodes[r]])
             # owned rows see all their columns locally; owned patches are complete
             LL = D.localize_level(lv[l], pr)
             assert LL.A.nbrows == pr.nb_loc and LL.A.colidx.max(initial=0) < pr.nb_loc
