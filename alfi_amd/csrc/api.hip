@@ -175,6 +175,26 @@ static int halo_rev(alfi_level* L, double* v) {
   return 0;
 }
 
+// reverse route in two halves (see halo_rev): ghost slots -> buffer, start | ... | wait, add onto the owners
+static int halo_rev_begin(alfi_level* L, const double* v) {
+  alfi_ctx* ctx = L->ctx;
+  int t = alfi_prof_begin(ctx, ALFI_EV_COMM);
+  if (L->halo_nghost > 0)
+    ALFI_HIP_CHECK(ctx, hipMemcpyAsync(L->halo_recvbuf, v + L->n_own, sizeof(double) * L->halo_nghost * L->bs,
+                                       hipMemcpyDeviceToDevice, ctx->stream));
+  ALFI_CHECK(comm_call(ctx, ALFI_COMM_HALO_REV_BEGIN, L->id, 0, 0));
+  alfi_prof_end(ctx, t);
+  return 0;
+}
+static int halo_rev_end(alfi_level* L, double* v) {
+  alfi_ctx* ctx = L->ctx;
+  int t = alfi_prof_begin(ctx, ALFI_EV_COMM);
+  ALFI_CHECK(comm_call(ctx, ALFI_COMM_HALO_REV_END, L->id, 0, 0));
+  ALFI_CHECK(launch_halo_add(ctx, v, L->halo_sendbuf, L->rev_nodes, L->rev_ptr, L->rev_pos, L->rev_nuniq, L->bs));
+  alfi_prof_end(ctx, t);
+  return 0;
+}
+
 extern "C" {
 
 // ---- context -------------------------------------------------------------------------------------------------------------
@@ -554,13 +574,20 @@ static int level_patch_apply(alfi_level* L, const double* dx, double* dy) {
     return 0;
   }
   if (L->distributed && L->overlap) {
-    // patches without ghost dofs while the forward halo of x is in flight, the others after it landed
+    // Both exchanges hidden behind the patches that hold no ghost dof: half of them run while the forward halo of x is
+    // in flight; then the patches with ghost dofs (the only ones contributing to ghost slots), the sums on the ghost
+    // slots, and the reverse exchange starts; the other half of the interior patches and the sums on the owned dofs run
+    // while it is in flight.
+    const int64_t half = L->npatch_int / 2;
     ALFI_CHECK(halo_fwd_begin(L, dx));
-    ALFI_CHECK(launch_patch_apply_range(L, 0, L->npatch_int, dx));
+    ALFI_CHECK(launch_patch_apply_range(L, 0, half, dx));
     ALFI_CHECK(halo_fwd_end(L, const_cast<double*>(dx)));
     ALFI_CHECK(launch_patch_apply_range(L, L->npatch_int, L->npatch, dx));
-    ALFI_CHECK(launch_patch_sum(L, dx, dy));
-    return halo_rev(L, dy);
+    ALFI_CHECK(launch_patch_sum_range(L, L->n_own, L->n, dx, dy));
+    ALFI_CHECK(halo_rev_begin(L, dy));
+    ALFI_CHECK(launch_patch_apply_range(L, half, L->npatch_int, dx));
+    ALFI_CHECK(launch_patch_sum_range(L, 0, L->n_own, dx, dy));
+    return halo_rev_end(L, dy);
   }
   if (L->distributed) ALFI_CHECK(halo_fwd(L, const_cast<double*>(dx)));
   ALFI_CHECK(launch_patch_apply(L, dx, dy));    // includes y[bc] = x[bc] (no patch holds a Dirichlet dof, so the

@@ -226,6 +226,7 @@ int launch_patch_invert(alfi_level* lvl);
 int launch_patch_apply(alfi_level* lvl, const double* x, double* y);          // both stages, all patches
 int launch_patch_apply_range(alfi_level* lvl, int64_t p0, int64_t p1, const double* x);   // stage 1, patches [p0, p1)
 int launch_patch_sum(alfi_level* lvl, const double* x, double* y);             // stage 2
+int launch_patch_sum_range(alfi_level* lvl, int64_t i0, int64_t i1, const double* x, double* y);   // stage 2, dofs [i0, i1)
 // one dependency wavefront of a multiplicative sweep: patches seq[0..count): y_p += inv(A_p) (x - A y)_p
 int launch_patch_mult_wave(alfi_level* lvl, const int32_t* seq, int64_t count, const double* x, double* y);
 int launch_invert_small_any(alfi_ctx* ctx, int nmax, int64_t nmat, const int64_t* ptr, const int64_t* inv_ptr,

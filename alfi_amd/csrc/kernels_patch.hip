@@ -508,12 +508,12 @@ __global__ __launch_bounds__(256) void patch_mult_kernel(int64_t count, const in
 }
 
 // stage 2: dof-wise sum of the staged patch results in a fixed order (deterministic; replaces PETSc's scatter-add)
-__global__ __launch_bounds__(256) void patch_sum_kernel(int64_t n, const int32_t* __restrict__ dof_ptr,
+__global__ __launch_bounds__(256) void patch_sum_kernel(int64_t i0, int64_t n, const int32_t* __restrict__ dof_ptr,
                                                          const int32_t* __restrict__ dof_pos,
                                                          const double* __restrict__ stage,
                                                          const uint8_t* __restrict__ bc_mask,
                                                          const double* __restrict__ x, double* __restrict__ y) {
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t i = i0 + (int64_t)blockIdx.x * 256 + threadIdx.x;   // dofs [i0, n)
   if (i >= n) return;
   double s = 0.0;
   for (int32_t q = dof_ptr[i]; q < dof_ptr[i + 1]; ++q) s += stage[dof_pos[q]];
@@ -635,17 +635,20 @@ int launch_patch_apply_range(alfi_level* L, int64_t p0, int64_t p1, const double
   return 0;
 }
 
-// stage 2: dof-wise sum of the staged results (+ Dirichlet copy)
-int launch_patch_sum(alfi_level* L, const double* x, double* y) {
+// stage 2: dof-wise sum of the staged results (+ Dirichlet copy) for the dofs [i0, i1)
+int launch_patch_sum_range(alfi_level* L, int64_t i0, int64_t i1, const double* x, double* y) {
   alfi_ctx* ctx = L->ctx;
+  if (i1 <= i0) return 0;
   int t = alfi_prof_begin(ctx, ALFI_EV_PATCH_SCATTER);
-  dim3 grid((unsigned)((L->n + 255) / 256)), block(256);
-  hipLaunchKernelGGL(patch_sum_kernel, grid, block, 0, ctx->stream, L->n, L->dof_ptr, L->dof_pos, L->stage, L->bc_mask, x,
-                     y);
+  dim3 grid((unsigned)((i1 - i0 + 255) / 256)), block(256);
+  hipLaunchKernelGGL(patch_sum_kernel, grid, block, 0, ctx->stream, i0, i1, L->dof_ptr, L->dof_pos, L->stage, L->bc_mask,
+                     x, y);
   ALFI_HIP_CHECK(ctx, hipGetLastError());
   alfi_prof_end(ctx, t);
   return 0;
 }
+
+int launch_patch_sum(alfi_level* L, const double* x, double* y) { return launch_patch_sum_range(L, 0, L->n, x, y); }
 
 int launch_patch_apply(alfi_level* L, const double* x, double* y) {
   ALFI_CHECK(launch_patch_apply_range(L, 0, L->npatch, x));

@@ -28,6 +28,7 @@ import numpy as np
 from .problem import BSR
 
 COMM_ALLREDUCE, COMM_HALO_FWD, COMM_HALO_REV, COMM_HALO_FWD_BEGIN, COMM_HALO_FWD_END = 0, 1, 2, 3, 4
+COMM_HALO_REV_BEGIN, COMM_HALO_REV_END = 5, 6
 RED_LEN = 64
 
 
@@ -443,6 +444,11 @@ class HaloBuffers(object):
         comm.exchange_end(self._work)
         self._work = None
 
+    def reverse_begin(self, comm):
+        self._work = comm.exchange_begin(self._recv, self._send, self._rc, self._sc)
+
+    reverse_end = forward_end
+
     def reverse(self, comm):
         comm.exchange(self._recv, self._send, self._rc, self._sc)
 
@@ -527,6 +533,10 @@ class DistMultigrid(object):
                 self.halos[level_id].forward_begin(self.comm)
             elif op == COMM_HALO_FWD_END:
                 self.halos[level_id].forward_end(self.comm)
+            elif op == COMM_HALO_REV_BEGIN:
+                self.halos[level_id].reverse_begin(self.comm)
+            elif op == COMM_HALO_REV_END:
+                self.halos[level_id].reverse_end(self.comm)
             else:
                 return -2
             return 0

@@ -78,10 +78,11 @@ int alfi_prof_get_level(alfi_ctx* ctx, int ev, int level_id, double* total_ms, i
  *   ALFI_COMM_HALO_REV : the reverse route: receive buffers (ghost contributions) -> owners' send buffers;
  *   ALFI_COMM_HALO_FWD_BEGIN / _END: the forward exchange split in two, so that the library can launch work that needs
  *                        no ghost value in between (only used on levels prepared with alfi_level_set_overlap): BEGIN
- *                        starts the exchange without making the ctx stream wait for it, END makes the stream wait.
+ *                        starts the exchange without making the ctx stream wait for it, END makes the stream wait;
+ *   ALFI_COMM_HALO_REV_BEGIN / _END: the same for the reverse route.
  * Every rank of the group reaches every call (the exchanges are collective). */
 enum { ALFI_COMM_ALLREDUCE = 0, ALFI_COMM_HALO_FWD = 1, ALFI_COMM_HALO_REV = 2, ALFI_COMM_HALO_FWD_BEGIN = 3,
-       ALFI_COMM_HALO_FWD_END = 4 };
+       ALFI_COMM_HALO_FWD_END = 4, ALFI_COMM_HALO_REV_BEGIN = 5, ALFI_COMM_HALO_REV_END = 6 };
 typedef int (*alfi_comm_fn)(void* user, int op, int level_id, int64_t offset, int64_t count);
 /* dred: device buffer of dred_len >= 64 doubles owned by the caller (reduction scratch the callback all-reduces). */
 int alfi_ctx_set_comm(alfi_ctx* ctx, alfi_comm_fn fn, void* user, double* dred, int64_t dred_len);
