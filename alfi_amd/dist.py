@@ -523,22 +523,23 @@ class DistMultigrid(object):
     # the library calls this at every exchange point of the cycle (alfi_ctx_set_comm)
     def _callback(self, user, op, level_id, offset, count):
         try:
-            if op == COMM_ALLREDUCE:
-                self.comm.allreduce(self.red[offset:offset + count])
-            elif op == COMM_HALO_FWD:
-                self.halos[level_id].forward(self.comm)
-            elif op == COMM_HALO_REV:
-                self.halos[level_id].reverse(self.comm)
-            elif op == COMM_HALO_FWD_BEGIN:
-                self.halos[level_id].forward_begin(self.comm)
-            elif op == COMM_HALO_FWD_END:
-                self.halos[level_id].forward_end(self.comm)
-            elif op == COMM_HALO_REV_BEGIN:
-                self.halos[level_id].reverse_begin(self.comm)
-            elif op == COMM_HALO_REV_END:
-                self.halos[level_id].reverse_end(self.comm)
-            else:
-                return -2
+            import torch
+            # the collectives must be ordered against the library's stream whatever stream the caller had current
+            with torch.cuda.stream(self.stream):
+                if op == COMM_ALLREDUCE:
+                    self.comm.allreduce(self.red[offset:offset + count])
+                elif op == COMM_HALO_FWD:
+                    self.halos[level_id].forward(self.comm)
+                elif op == COMM_HALO_REV:
+                    self.halos[level_id].reverse(self.comm)
+                elif op == COMM_HALO_FWD_BEGIN:
+                    self.halos[level_id].forward_begin(self.comm)
+                elif op == COMM_HALO_REV_BEGIN:
+                    self.halos[level_id].reverse_begin(self.comm)
+                elif op in (COMM_HALO_FWD_END, COMM_HALO_REV_END):
+                    self.halos[level_id].forward_end(self.comm)
+                else:
+                    return -2
             return 0
         except Exception:                                   # never let an exception cross the C boundary
             import traceback
