@@ -27,6 +27,7 @@ int alfi_set_error(alfi_ctx* ctx, int code, const char* fmt, ...) {
 // ---- profiling ---------------------------------------------------------------------------------------------------------
 int alfi_prof_begin(alfi_ctx* ctx, int kind) {
   if (!ctx->prof) return -1;
+  if (ctx->prof == 2 && kind != ALFI_EV_PATCH_APPLY && kind != ALFI_EV_COMM) return -1;
   if (ctx->ev_used == ctx->ev_pool.size()) {
     alfi_ctx::EvPair p;
     if (hipEventCreate(&p.a) != hipSuccess || hipEventCreate(&p.b) != hipSuccess) return -1;
@@ -284,7 +285,7 @@ int alfi_ctx_set_comm(alfi_ctx* ctx, alfi_comm_fn fn, void* user, double* dred, 
 }
 
 int alfi_prof_enable(alfi_ctx* ctx, int on) {
-  ctx->prof = on != 0;
+  ctx->prof = on;
   return 0;
 }
 int alfi_prof_reset(alfi_ctx* ctx) {

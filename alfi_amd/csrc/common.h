@@ -13,7 +13,7 @@ struct alfi_ctx {
   bool own_stream = false;
   std::string err;
   // profiling
-  bool prof = false;
+  int prof = 0;   // 0 off, 1 every class, 2 PATCH_APPLY and COMM only (alfi_prof_enable)
   struct EvPair {
     hipEvent_t a, b;
     int kind;

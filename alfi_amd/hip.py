@@ -58,7 +58,8 @@ class Context(object):
 
     # profiling (PETSc-event style report, driver.py:77-92) ----------------------------------------------------------------
     def prof_enable(self, on=True):
-        self.check(self.lib.alfi_prof_enable(self.h, 1 if on else 0))
+        """True / 1: every event class; 2: PATCH_APPLY and COMM only; False / 0: off."""
+        self.check(self.lib.alfi_prof_enable(self.h, int(on)))
 
     def prof_reset(self):
         self.check(self.lib.alfi_prof_reset(self.h))

@@ -61,7 +61,9 @@ enum {
   ALFI_EV_COMM = 8,          /* halo pack/exchange/unpack and all-reduces (VecScatter / MPI_Allreduce in the reference) */
   ALFI_EV_COUNT = 9
 };
-int alfi_prof_enable(alfi_ctx* ctx, int on); /* records a hipEvent pair around every launch of the classes above */
+/* on = 1: a hipEvent pair around every launch of the classes above; on = 2: PATCH_APPLY and COMM only (fewer event
+ * records on launch-bound levels); 0: off */
+int alfi_prof_enable(alfi_ctx* ctx, int on);
 int alfi_prof_reset(alfi_ctx* ctx);
 /* synchronises, then returns summed device time (ms) and launch count of one class since the last reset */
 int alfi_prof_get(alfi_ctx* ctx, int ev, double* total_ms, int64_t* count);
