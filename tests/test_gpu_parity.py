@@ -338,3 +338,50 @@ def test_small_patch_kernel_ragged_sizes(ctx, bs, max_n):
     lvl.patch_apply(dx, dy)
     assert np.abs(dy.get() - ref).max() < 1e-12 * np.abs(ref).max()
     lvl.close()
+
+
+def test_uncommon_paths(ctx):
+    """k = 20 smoothing iterations (Gram-Schmidt passes of more than 16 vectors), k = 1, a one-level hierarchy (coarse
+    solve only), repeated operator updates with refactorisation."""
+    from alfi_amd import hip
+    from oracle import alfi_oracle as O
+    lv, tr = build_hierarchy(TwoDimLidDrivenCavityProblem(4), 1, 2, Re=10.0)
+    L = lv[-1]
+    b = rhs(L.n, L.bc_dofs, 3)
+    for k in (1, 20):
+        omg = O.build_oracle_mg(lv, tr, k)
+        dmg = hip.Multigrid(ctx, lv, tr, k)
+        db, dx = ctx.vec(b), ctx.vec(L.n)
+        dmg.vcycle(db, dx)
+        ref = omg.vcycle(len(lv) - 1, b, np.zeros(L.n))
+        assert relerr(dx.get(), ref) < 1e-7, k
+        x0 = rhs(L.n, L.bc_dofs, 4)
+        dx0 = ctx.vec(x0)
+        dmg.levels[-1].smooth(k, db, dx0, nonzero_guess=True)
+        assert relerr(dx0.get(), omg.smooth(len(lv) - 1, b, x0)) < 1e-7, k
+        dmg.close()
+    # one level: the cycle is the coarse solve
+    one = hip.Multigrid(ctx, lv[:1], [], 3)
+    b0 = rhs(lv[0].n, lv[0].bc_dofs, 5)
+    d0, x0 = ctx.vec(b0), ctx.vec(lv[0].n)
+    one.vcycle(d0, x0)
+    sol = np.linalg.solve(lv[0].A.to_scipy().toarray(), b0)
+    assert relerr(x0.get(), sol) < 1e-10
+    one.fcycle(d0, x0)
+    assert relerr(x0.get(), sol) < 1e-10
+    one.close()
+    # update -> factor -> apply, twice, tracks the new operator each time
+    dl = hip.Level(ctx, L.A, L.bc_dofs)
+    dl.set_patches(L.patch_ptr, L.patch_dofs)
+    x = rhs(L.n, [], 6)
+    dxx, dyy = ctx.vec(x), ctx.vec(L.n)
+    for scale in (1.0, 3.0, 0.5):
+        dl.update_values(scale * L.A.vals)
+        dl.factor()
+        dl.patch_apply(dxx, dyy)
+        A = (scale * L.A.to_scipy()).tocsr()
+        ref = O.PatchSmoother(A, L.patch_ptr, L.patch_dofs, L.bc_dofs).apply(x)
+        assert relerr(dyy.get(), ref) < 1e-9
+        dl.spmv(dxx, dyy)
+        assert relerr(dyy.get(), A @ x) < 1e-13
+    dl.close()
