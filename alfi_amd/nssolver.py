@@ -153,3 +153,21 @@ def run_solver(solver, res):
     for re in res:
         _, results[re] = solver.solve(re)
     return results
+
+
+# PETSc event names the reference's report prints (driver.py:80) -> the library's profiling classes
+_EVENT_NAMES = [("PCPATCHApply", "PATCH_APPLY"), ("PCPATCHScatter", "PATCH_SCATTER"), ("PCPatchComputeOp", "PATCH_FACTOR"),
+                ("MatMult", "MATMULT"), ("KSPGMRESOrthog", "BLAS1"), ("SchoeberlProlong", "PROLONG"),
+                ("SchoeberlRestrict", "RESTRICT"), ("MatSolve", "COARSE")]
+
+
+def performance_info(solver, out=print):
+    """alfi.driver.performance_info (driver.py:77-92): device time per event class since profiling was switched on
+    (``solver.ctx.prof_enable(True)`` before the solves), sorted, with time per 1k dofs."""
+    prof = solver.ctx.prof_get()
+    ndofs = solver.n_u + solver.n_p
+    rows = sorted(((name, prof[key][0] * 1e-3, prof[key][1]) for name, key in _EVENT_NAMES), key=lambda r: -r[1])
+    out("Some performance info:")
+    for name, t, cnt in rows:
+        out(("%s:" % name).ljust(30) + "Time = % 6.2fs, Time/1kdofs = %.2fs  (%d launches)" % (t, 1000 * t / ndofs, cnt))
+    return rows
