@@ -8,11 +8,21 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from alfi_amd.problem import TwoDimLidDrivenCavityProblem, ThreeDimLidDrivenCavityProblem, build_hierarchy  # noqa: E402
+from alfi_amd.problem import build_pressure_coupling  # noqa: E402
+from alfi_amd.relaxation import OrderedRelaxation, Options  # noqa: E402
 from oracle import alfi_oracle as O  # noqa: E402
 
 CASES = {"ldc2d_p2_N4": (lambda: TwoDimLidDrivenCavityProblem(2), 2, 1, 10.0, 6),
          "ldc3d_p1fb_N2": (lambda: ThreeDimLidDrivenCavityProblem(1), 1, 1, 100.0, 4),
          "ldc3d_p2fb_N2": (lambda: ThreeDimLidDrivenCavityProblem(1), 2, 1, 100.0, 4)}
+
+
+def sweep_order(L):
+    """Iteration set of the Star constructor with the problems' relaxation_direction "0+:1-" (relaxation.py:139-150)."""
+    orl = OrderedRelaxation()
+    orl.name = "Star"
+    orl.opts = Options("", {"pc_patch_construction_Star_sort_order": "0+:1-"})
+    return orl.iteration_order(L.V.mesh.coords[L.patch_seeds])
 
 
 def make(name):
@@ -32,6 +42,15 @@ def make(name):
                prolong_uc=mg.prolong(len(lv) - 1, uc), restrict_b=mg.restrict(len(lv) - 1, x),
                vcycle_b=mg.vcycle(len(lv) - 1, b, np.zeros(L.n)), fcycle_b=mg.fcycle(b),
                inv_patch0=mg.levels[-1]["smoother"].inv[0])
+    # multiplicative symmetrised sweep in the problems' relaxation order; inject; one outer (saddle-point) solve
+    order = sweep_order(L)
+    sm = O.PatchSmoother(mg.levels[-1]["A"], L.patch_ptr, L.patch_dofs, L.bc_dofs, "multiplicative", order, True)
+    B, vol = build_pressure_coupling(L)
+    mgp = O.build_oracle_mg(lv, tr, ks)
+    rhs = np.concatenate([b, np.zeros(B.shape[0])])
+    xs, its, hist = O.saddle_solve(mgp, mg.levels[-1]["A"], B, vol, L.nu, L.gamma, rhs, rtol=1e-9, atol=1e-10)
+    out.update(mult_order=order, mult_apply_x=sm.apply(x), inject_x=x.reshape(-1, L.bs)[tr[-1].inject_map].ravel(),
+               saddle_x=xs, saddle_its=its, saddle_hist=np.array(hist))
     np.savez_compressed(os.path.join(os.path.dirname(os.path.abspath(__file__)), name + ".npz"), **out)
 
 

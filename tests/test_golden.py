@@ -38,6 +38,9 @@ def test_oracles_reproduce_golden(name):
     assert rel(mg.levels[-1]["A"] @ g["x"], g["A_x"]) < 1e-14
     assert rel(mg.levels[-1]["smoother"].apply(g["x"]), g["patch_apply_x"]) < 1e-10
     assert rel(mg.vcycle(len(lv) - 1, g["b"], np.zeros(L.n)), g["vcycle_b"]) < 1e-8
+    sm = O.PatchSmoother(mg.levels[-1]["A"], L.patch_ptr, L.patch_dofs, L.bc_dofs, "multiplicative", g["mult_order"], True)
+    assert rel(sm.apply(g["x"]), g["mult_apply_x"]) < 1e-10
+    assert np.array_equal(g["x"].reshape(-1, L.bs)[tr[-1].inject_map].ravel(), g["inject_x"])
     cmg = C.CMultigrid(lv, tr, ks, robust_restriction=True)
     assert rel(cmg.levels[-1].patch_apply(g["x"]), g["patch_apply_x"]) < 1e-8
     assert rel(cmg.vcycle(len(lv) - 1, g["b"], np.zeros(L.n)), g["vcycle_b"]) < 1e-6
@@ -72,5 +75,25 @@ def test_hip_matches_golden(name):
     assert rel(dv.get(), g["vcycle_b"]) < 1e-5
     mg.fcycle(db, dv)
     assert rel(dv.get(), g["fcycle_b"]) < 1e-5
+    # inject, multiplicative symmetrised sweep, outer solve (fixtures added with those features)
+    dxc = ctx.vec(lv[0].n)
+    mg.transfers[-1].inject(dx, dxc)
+    assert np.array_equal(dxc.get(), g["inject_x"])
+    nw = fin.set_multiplicative(g["mult_order"], True)
+    assert nw >= 1
+    fin.patch_apply(dx, dy)
+    assert rel(dy.get(), g["mult_apply_x"]) < 1e-7
+    fin.set_multiplicative(None, False)
+    from alfi_amd.problem import build_pressure_coupling
+    B, vol = build_pressure_coupling(L)
+    mgp = hip.Multigrid(ctx, lv, tr, ks)                      # non-robust restriction, as for the fixture
+    sad = hip.Saddle(mgp, B, vol, L.nu, L.gamma)
+    dbb, dxx = ctx.vec(np.concatenate([g["b"], np.zeros(B.shape[0])])), ctx.vec(L.n + B.shape[0])
+    its, rn = sad.solve(dbb, dxx, 1e-9, 1e-10, 500, 30)
+    assert abs(its - int(g["saddle_its"])) <= 1
+    xs = dxx.get()
+    assert rel(xs[:L.n], g["saddle_x"][:L.n]) < 1e-5
+    sad.close()
+    mgp.close()
     mg.close()
     ctx.close()
