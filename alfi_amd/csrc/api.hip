@@ -556,6 +556,7 @@ static int level_patch_apply(alfi_level* L, const double* dx, double* dy) {
   if (L->mult) {
     // multiplicative sweep (PCApply_PATCH, local_type multiplicative [3P]): y = 0, then wavefront by wavefront in
     // iteration order and, with symmetrise_sweep, back again in reverse order
+    if (L->distributed) ALFI_CHECK(halo_fwd(L, const_cast<double*>(dx)));
     ALFI_HIP_CHECK(ctx, hipMemsetAsync(dy, 0, sizeof(double) * L->n, ctx->stream));
     int t = alfi_prof_begin(ctx, ALFI_EV_PATCH_APPLY);
     const int64_t nw = (int64_t)L->mult_wave_ptr.size() - 1;
@@ -567,6 +568,7 @@ static int level_patch_apply(alfi_level* L, const double* dx, double* dy) {
         ALFI_CHECK(launch_patch_mult_wave(L, L->mult_seq + L->mult_wave_ptr[w],
                                           L->mult_wave_ptr[w + 1] - L->mult_wave_ptr[w], dx, dy));
     alfi_prof_end(ctx, t);
+    if (L->distributed) ALFI_CHECK(halo_rev(L, dy));
     if (L->nbc > 0) {
       t = alfi_prof_begin(ctx, ALFI_EV_PATCH_SCATTER);
       ALFI_CHECK(launch_copy_dofs(ctx, dy, dx, L->bc_dofs, L->nbc));
@@ -686,8 +688,9 @@ int alfi_patches_set_multiplicative(alfi_level* L, int64_t nit, const int64_t* i
   L->mult_wave_ptr.clear();
   if (nit == 0) return 0;
   if (nit < 0 || !iterset) return alfi_set_error(ctx, ALFI_E_ARG, "bad iteration set");
-  if (L->has_halo && L->distributed)
-    return alfi_set_error(ctx, ALFI_E_ARG, "multiplicative sweeps are not available on partitioned levels");
+  // partitioned levels: every rank sweeps over its own patches with the residual of its local vector (ghost slots hold
+  // the rank's own contributions only) and the ghost contributions are added onto their owners at the end -- what
+  // PCPATCH does under MPI: local Gauss-Seidel, additive between ranks [3P]
   if (nit > INT32_MAX) return alfi_set_error(ctx, ALFI_E_ARG, "iteration set too long");
   const int bs = L->bs;
   // patches must be unions of whole nodes (the sweep works on block rows)

@@ -132,7 +132,8 @@ int alfi_patch_apply(alfi_level* lvl, const double* dx, double* dy);
  * the positions into dependency wavefronts (two patches are independent when no operator entry couples them), which
  * reproduces the sequential sweep exactly.  Afterwards alfi_patch_apply and alfi_smooth_fgmres on this level use the
  * multiplicative sweep; nit == 0 switches back to additive.  Patches must consist of whole nodes (all bs components),
- * at most 64 nodes per patch; not available on partitioned levels. */
+ * at most 64 nodes per patch.  On a partitioned level every rank sweeps over its own patches (local Gauss-Seidel,
+ * additive between ranks, ghost contributions reverse-added at the end), as PCPATCH does under MPI. */
 int alfi_patches_set_multiplicative(alfi_level* lvl, int64_t nit, const int64_t* iterset_host, int symmetrise);
 /* number of dependency wavefronts of one sweep (0 = additive) */
 int alfi_patches_multiplicative_levels(alfi_level* lvl, int64_t* nwave);

@@ -17,8 +17,12 @@ import torch
 
 
 class DistOracle(object):
-    def __init__(self, llev, ltr, lmin, k, comm, robust=False):
+    def __init__(self, llev, ltr, lmin, k, comm, robust=False, mult_orders=None, symmetrise=False):
+        """mult_orders[i]: iteration set (local patch indices) of local level i for multiplicative sweeps, or None for the
+        additive smoother.  Under MPI PCPATCH sweeps over the rank's own patches with its local vectors and combines
+        ranks additively [3P]."""
         self.lev, self.tr, self.lmin, self.k, self.comm, self.robust = llev, ltr, lmin, k, comm, robust
+        self.mult_orders, self.symmetrise = mult_orders, symmetrise
         self.A = [L.A.to_scipy().tocsr() for L in llev]
         self.inv = []
         for L, A in zip(llev, self.A):
@@ -75,9 +79,16 @@ class DistOracle(object):
         if L.part.distributed:
             self.halo_fwd(i, x)
         y = np.zeros(L.n)
-        for p, Ainv in enumerate(self.inv[i]):
-            d = L.patch_dofs[L.patch_ptr[p]:L.patch_ptr[p + 1]]
-            y[d] += Ainv @ x[d]
+        order = None if self.mult_orders is None else self.mult_orders[i]
+        if order is None:
+            for p, Ainv in enumerate(self.inv[i]):
+                d = L.patch_dofs[L.patch_ptr[p]:L.patch_ptr[p + 1]]
+                y[d] += Ainv @ x[d]
+        else:
+            seq = list(order) + (list(order[::-1]) if self.symmetrise else [])
+            for p in seq:                                     # local Gauss-Seidel: r_p = (x - A_loc y)_p
+                d = L.patch_dofs[L.patch_ptr[p]:L.patch_ptr[p + 1]]
+                y[d] += self.inv[i][p] @ (x[d] - (self.A[i][d] @ y))
         if L.part.distributed:
             self.halo_rev(i, y)
         y[L.bc_dofs] = x[L.bc_dofs]

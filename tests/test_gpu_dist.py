@@ -112,3 +112,20 @@ def test_rccl_code_path_with_a_one_rank_group(tmp_path, exact_norm, tol):
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), ALFI_DIST_EXACT_NORM=exact_norm)
     out = subprocess.run([sys.executable, str(script)], env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "ONE-RANK-RCCL-OK" in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]
+
+
+@pytest.mark.parametrize("case,world", [("2d-all-distributed", 2), ("3d-P2FB", 3)])
+def test_partitioned_multiplicative(case, world, tmp_path):
+    """Multiplicative sweeps on partitioned levels (local Gauss-Seidel per rank, additive between ranks -- PCPATCH's MPI
+    semantics [3P]): the HIP path against the SPMD oracle on the same rank-local data."""
+    port = _free_port()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), OMP_NUM_THREADS="4")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dist_gpu_mult_worker.py"), case,
+                                       str(tmp_path)], env=env, cwd=ROOT))
+    for p in procs:
+        assert p.wait(timeout=600) == 0
+    for r in range(world):
+        assert os.path.exists(os.path.join(str(tmp_path), "rank%d.ok" % r))
