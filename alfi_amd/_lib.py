@@ -4,7 +4,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libalfi_hip.so")
+# ALFI_HIP_LIB: an alternative build of the same library (kernel tuning experiments)
+LIB_PATH = os.environ.get("ALFI_HIP_LIB") or os.path.join(_HERE, "libalfi_hip.so")
 
 c_i32p = ctypes.POINTER(ctypes.c_int32)
 c_i64p = ctypes.POINTER(ctypes.c_int64)

@@ -87,7 +87,10 @@ __host__ __device__ inline int64_t patch_inv_index(int r, int c, int n, int ld) 
 //              16 B per lane (bs = 3: four of those plus one 512-B request); the sign bit of colidx[k]
 //              marks the first block of a block row; chunk_row[c] = block row of block c * SPMV_CHUNK.  Used by the
 //              nnz-balanced segmented SpMV (bsr_spmv_flat_kernel) whenever every block row is non-empty.
-constexpr int SPMV_U = 4;                 // wave iterations of 64 blocks
+#ifndef ALFI_SPMV_U
+#define ALFI_SPMV_U 4                     // tuning builds: -DALFI_SPMV_U=2 / 8 (4 measured best)
+#endif
+constexpr int SPMV_U = ALFI_SPMV_U;       // wave iterations of 64 blocks
 constexpr int SPMV_CHUNK = 64 * SPMV_U;   // blocks per wave
 struct DevBSR {
   int64_t nbrows = 0, nbcols = 0, nnzb = 0;
