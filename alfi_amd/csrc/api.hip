@@ -623,9 +623,9 @@ int alfi_patches_set(alfi_level* L, int64_t npatch, const int64_t* pptr, const i
   int max_np = 0;
   for (int64_t p = 0; p < npatch; ++p) {
     const int64_t n = pptr[p + 1] - pptr[p];
-    if (n <= 0 || n > 160)
-      return alfi_set_error(ctx, ALFI_E_ARG, "patch %lld has %lld dofs; supported range is 1..160", (long long)p,
-                            (long long)n);
+    if (n <= 0 || n > PATCH_MAX)
+      return alfi_set_error(ctx, ALFI_E_ARG, "patch %lld has %lld dofs; supported range is 1..%d", (long long)p,
+                            (long long)n, PATCH_MAX);
     for (int64_t q = pptr[p]; q < pptr[p + 1]; ++q) {
       if (pdofs[q] < 0 || pdofs[q] >= L->n)
         return alfi_set_error(ctx, ALFI_E_ARG, "patch %lld: dof %d out of range", (long long)p, pdofs[q]);
@@ -755,8 +755,12 @@ int alfi_patches_factor(alfi_level* L) {
   if (!L->patch_ptr) return alfi_set_error(ctx, ALFI_E_STATE, "alfi_patches_factor before alfi_patches_set");
   int t = alfi_prof_begin(ctx, ALFI_EV_PATCH_FACTOR);
   ALFI_HIP_CHECK(ctx, hipMemsetAsync(L->status, 0, sizeof(int), ctx->stream));
-  ALFI_CHECK(launch_patch_gather_dense(L));
-  ALFI_CHECK(launch_patch_invert(L));
+  if (L->max_np > SMALL_PATCH_MAX) {
+    ALFI_CHECK(launch_big_factor(L));             // macro-star sized patches: blocked Gauss-Jordan on the matrix cores
+  } else {
+    ALFI_CHECK(launch_patch_gather_dense(L));
+    ALFI_CHECK(launch_patch_invert(L));
+  }
   alfi_prof_end(ctx, t);
   int st = 0;
   ALFI_HIP_CHECK(ctx, hipMemcpyAsync(&st, L->status, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));

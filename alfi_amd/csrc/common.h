@@ -55,6 +55,9 @@ int alfi_set_error(alfi_ctx* ctx, int code, const char* fmt, ...);
 int alfi_prof_begin(alfi_ctx* ctx, int kind);
 int alfi_prof_end(alfi_ctx* ctx, int token);
 
+constexpr int SMALL_PATCH_MAX = 160;   // register-resident inversion / one wave per patch up to here (kernels_patch.hip)
+constexpr int PATCH_MAX = 2048;        // blocked MFMA inversion / one workgroup per patch beyond (kernels_bigpatch.hip)
+
 // ---- storage of one dense patch inverse (n x n, rows padded to ld = n rounded up to even) --------------------------------
 // Row pieces: as many 128-row pieces as fit, then the binary digits of the remainder (64, 32, ..., 2).  A piece of R rows
 // is stored [column][R] contiguously, pieces follow each other, so the whole inverse is ld * n contiguous doubles that
@@ -228,6 +231,8 @@ int launch_patch_gather_dense(alfi_level* lvl);
 int launch_patch_invert(alfi_level* lvl);
 int launch_patch_apply(alfi_level* lvl, const double* x, double* y);          // both stages, all patches
 int launch_patch_apply_range(alfi_level* lvl, int64_t p0, int64_t p1, const double* x);   // stage 1, patches [p0, p1)
+int launch_big_apply_range(alfi_level* lvl, int64_t p0, int64_t p1, const double* x);     // the same for levels with n_p > 160
+int launch_big_factor(alfi_level* lvl);                                                    // gather + blocked MFMA inversion
 int launch_patch_sum(alfi_level* lvl, const double* x, double* y);             // stage 2
 int launch_patch_sum_range(alfi_level* lvl, int64_t i0, int64_t i1, const double* x, double* y);   // stage 2, dofs [i0, i1)
 // one dependency wavefront of a multiplicative sweep: patches seq[0..count): y_p += inv(A_p) (x - A y)_p

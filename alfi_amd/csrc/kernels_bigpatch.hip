@@ -1,0 +1,408 @@
+// Large patches (160 < n_p <= 2048): the macro-star patches of the reference's high-order discretisations
+// (alfi/relaxation.py:163-177; 405 / 1275 dofs for Scott-Vogelius P2 / P3) need a different setup
+// and a different work split than the vertex stars of kernels_patch.hip:
+//
+//  * setup (PCSetUp_PATCH with dense_inverse): 2 n^3 flops per patch are now a GEMM-shaped problem -- 4.1 GFLOP for
+//    n = 1275, against 13 MB of matrix -- so the inversion is a BLOCKED Gauss-Jordan on a row-major scratch copy
+//    (identity-padded to a multiple of 64): per 64-column step a panel kernel (one workgroup per patch: inverse of the
+//    64 x 64 pivot block in LDS, the scaled pivot row panel R = D^-1 S[K,:], the saved column panel F = S[:,K] and
+//    S[:,K] <- -F D^-1) and the rank-64 trailing update S -= F R on the FP64 matrix cores
+//    (v_mfma_f64_16x16x4_f64: 95 % of the flops).  No pivoting across blocks, like the register kernel for small patches.
+//  * apply: one WORKGROUP per patch; the row pieces of the inverse (same storage as for small patches,
+//    patch_inv_index) are dealt round-robin to the four waves, x_p sits in LDS.
+#include <cstdlib>
+#include "common.h"
+
+constexpr int BIG_NB = 64;          // pivot block / GEMM k-extent
+constexpr int BIG_MAX_NP = 2048;
+
+// ---------------------------------------------------------------------------------------------------------------------
+// 1. gather A_p = A[dofs_p, dofs_p] into the row-major scratch (N x N, N = n rounded up to 64, identity padding)
+// ---------------------------------------------------------------------------------------------------------------------
+template <int BS>
+__global__ __launch_bounds__(256) void big_gather_kernel(int64_t p0, const int32_t* __restrict__ rowptr,
+                                                          const int32_t* __restrict__ colidx,
+                                                          const double* __restrict__ vals, int flat,
+                                                          const int64_t* __restrict__ patch_ptr,
+                                                          const int32_t* __restrict__ patch_dofs,
+                                                          const int64_t* __restrict__ scr_ptr, double* __restrict__ scr) {
+  __shared__ int32_t dofs_s[BIG_MAX_NP];
+  const int64_t p = p0 + blockIdx.x;
+  const int64_t off = patch_ptr[p];
+  const int n = (int)(patch_ptr[p + 1] - off);
+  const int N = (n + BIG_NB - 1) / BIG_NB * BIG_NB;
+  double* S = scr + scr_ptr[blockIdx.x];
+  for (int i = threadIdx.x; i < n; i += 256) dofs_s[i] = patch_dofs[off + i];
+  // zero + identity padding
+  for (int64_t e = threadIdx.x; e < (int64_t)N * N; e += 256) {
+    const int r = (int)(e / N), c = (int)(e % N);
+    S[e] = (r == c && r >= n) ? 1.0 : 0.0;
+  }
+  __syncthreads();
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  for (int r = wave; r < n; r += 4) {
+    const int gr = dofs_s[r];
+    const int brow = gr / BS, rr = gr % BS;
+    const int32_t lo = rowptr[brow], hi = rowptr[brow + 1];
+    const int nent = (hi - lo) * BS;
+    for (int e = lane; e < nent; e += 64) {
+      const int blk = e / BS, cc = e % BS;
+      const int gcol = (colidx[lo + blk] & 0x7fffffff) * BS + cc;
+      int a = 0, b = n;
+      while (a < b) {
+        const int mid = (a + b) >> 1;
+        if (dofs_s[mid] < gcol) a = mid + 1; else b = mid;
+      }
+      if (a < n && dofs_s[a] == gcol) S[(int64_t)r * N + a] = vals[bsr_val_index(flat, lo + blk, rr * BS + cc, BS * BS)];
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// 2a. panel step for pivot block K = [k0, k0 + 64): one workgroup per patch.
+//       D^-1 = inv(S[K,K])  (Gauss-Jordan in LDS);  F = S[:,K] saved (rows K zeroed);  R = D^-1 S[K,:] saved (columns K zeroed);
+//       S[K,:] <- R with S[K,K] <- D^-1;  S[I,K] <- -F[I] D^-1 for I != K.
+//     After the trailing update S[I,J] -= F[I] R[J] (2b) the scratch holds the state of block Gauss-Jordan after step K.
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void big_panel_kernel(int k0, const int64_t* __restrict__ patch_ptr, int64_t p0,
+                                                         const int64_t* __restrict__ scr_ptr, double* __restrict__ scr,
+                                                         const int64_t* __restrict__ pan_ptr, double* __restrict__ panF,
+                                                         double* __restrict__ panR, int* __restrict__ status) {
+  __shared__ double D[BIG_NB][BIG_NB + 1];     // pivot block, becomes its inverse
+  __shared__ double T[BIG_NB][BIG_NB + 1];     // a 64 x 64 tile of S
+  const int64_t p = p0 + blockIdx.x;
+  const int n = (int)(patch_ptr[p + 1] - patch_ptr[p]);
+  const int N = (n + BIG_NB - 1) / BIG_NB * BIG_NB;
+  if (k0 >= N) return;                          // smaller patch of the batch: already done
+  double* S = scr + scr_ptr[blockIdx.x];
+  double* F = panF + pan_ptr[blockIdx.x];       // (N, 64) row-major
+  double* R = panR + pan_ptr[blockIdx.x];       // (64, N) row-major
+  const int t = threadIdx.x;
+  // load the pivot block
+  for (int e = t; e < BIG_NB * BIG_NB; e += 256) D[e / BIG_NB][e % BIG_NB] = S[(int64_t)(k0 + e / BIG_NB) * N + k0 + e % BIG_NB];
+  __syncthreads();
+  // in-place Gauss-Jordan, thread (i, jq) owns row i, columns jq, jq + 4, ...
+  const int gi = t >> 2, gq = t & 3;
+  bool bad = false;
+  for (int k = 0; k < BIG_NB; ++k) {
+    const double piv = D[k][k];
+    if (piv == 0.0) bad = true;
+    const double ip = 1.0 / piv;
+    const double f = D[gi][k];
+    __syncthreads();
+    if (gi == k) {
+      for (int j = gq; j < BIG_NB; j += 4) D[k][j] = (j == k) ? ip : D[k][j] * ip;
+    }
+    __syncthreads();
+    if (gi != k) {
+      for (int j = gq; j < BIG_NB; j += 4) D[gi][j] = (j == k) ? -f * ip : __builtin_fma(-f, D[k][j], D[gi][j]);
+    }
+    __syncthreads();
+  }
+  if (bad && t == 0) atomicExch(status, 1);
+  // column tiles J: R[:, J] = D^-1 S[K, J]
+  const int ti = t >> 4, tj = t & 15;           // thread computes the 4 x 4 sub-block (4 ti .., 4 tj ..) of a 64 x 64 product
+  for (int j0 = 0; j0 < N; j0 += BIG_NB) {
+    for (int e = t; e < BIG_NB * BIG_NB; e += 256) T[e / BIG_NB][e % BIG_NB] = S[(int64_t)(k0 + e / BIG_NB) * N + j0 + e % BIG_NB];
+    __syncthreads();
+    double acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) acc[a][b] = 0.0;
+    for (int k = 0; k < BIG_NB; ++k) {
+      double dv[4], tv[4];
+#pragma unroll
+      for (int a = 0; a < 4; ++a) dv[a] = D[4 * ti + a][k];
+#pragma unroll
+      for (int b = 0; b < 4; ++b) tv[b] = T[k][4 * tj + b];
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_fma(dv[a], tv[b], acc[a][b]);
+    }
+    const bool diag = j0 == k0;
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        const int r = 4 * ti + a, c = 4 * tj + b;
+        // row panel of S: R, with D^-1 itself on the pivot block; saved R has its pivot columns zeroed
+        S[(int64_t)(k0 + r) * N + j0 + c] = diag ? D[r][c] : acc[a][b];
+        R[(int64_t)r * N + j0 + c] = diag ? 0.0 : acc[a][b];
+      }
+    __syncthreads();
+  }
+  // row tiles I: F[I] = S[I, K] saved (pivot rows zeroed); S[I, K] = -F[I] D^-1 for I != K
+  for (int i0 = 0; i0 < N; i0 += BIG_NB) {
+    if (i0 == k0) {
+      for (int e = t; e < BIG_NB * BIG_NB; e += 256) F[(int64_t)(i0 + e / BIG_NB) * BIG_NB + e % BIG_NB] = 0.0;
+      continue;                                   // uniform branch: no barrier skipped inside
+    }
+    for (int e = t; e < BIG_NB * BIG_NB; e += 256) {
+      const double v = S[(int64_t)(i0 + e / BIG_NB) * N + k0 + e % BIG_NB];
+      T[e / BIG_NB][e % BIG_NB] = v;
+      F[(int64_t)(i0 + e / BIG_NB) * BIG_NB + e % BIG_NB] = v;
+    }
+    __syncthreads();
+    double acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) acc[a][b] = 0.0;
+    for (int k = 0; k < BIG_NB; ++k) {
+      double tv[4], dv[4];
+#pragma unroll
+      for (int a = 0; a < 4; ++a) tv[a] = T[4 * ti + a][k];
+#pragma unroll
+      for (int b = 0; b < 4; ++b) dv[b] = D[k][4 * tj + b];
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_fma(tv[a], dv[b], acc[a][b]);
+    }
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) S[(int64_t)(i0 + 4 * ti + a) * N + k0 + 4 * tj + b] = -acc[a][b];
+    __syncthreads();
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// 2b. trailing update S[I,J] -= F[I] R[J] on the FP64 matrix cores: workgroup = one 64 x 64 tile of one patch, wave =
+//     32 x 32 quarter = 2 x 2 MFMA blocks, K = 64 in 16 steps of v_mfma_f64_16x16x4_f64.
+//     Operand maps (cdna_hip_programming.md): A[m = lane & 15][k = lane >> 4], B[k = lane >> 4][n = lane & 15],
+//     C/D: col = lane & 15, row = (lane >> 4) + 4 reg.  The panels are small (1.3 MB per patch) and L2-resident, so the
+//     operands are read straight from global memory.
+// ---------------------------------------------------------------------------------------------------------------------
+typedef double big_d4 __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(256) void big_update_kernel(int k0, const int64_t* __restrict__ patch_ptr, int64_t p0,
+                                                          const int64_t* __restrict__ scr_ptr, double* __restrict__ scr,
+                                                          const int64_t* __restrict__ pan_ptr,
+                                                          const double* __restrict__ panF,
+                                                          const double* __restrict__ panR, int tiles_max) {
+  const int64_t p = p0 + blockIdx.y;
+  const int n = (int)(patch_ptr[p + 1] - patch_ptr[p]);
+  const int N = (n + BIG_NB - 1) / BIG_NB * BIG_NB;
+  const int nt = N / BIG_NB;
+  if (k0 >= N) return;
+  const int ti = blockIdx.x / tiles_max, tj = blockIdx.x % tiles_max;
+  if (ti >= nt || tj >= nt) return;
+  if (ti * BIG_NB == k0 || tj * BIG_NB == k0) return;      // F rows / R columns of the pivot block are zero: nothing to do
+  double* S = scr + scr_ptr[blockIdx.y];
+  const double* F = panF + pan_ptr[blockIdx.y];
+  const double* R = panR + pan_ptr[blockIdx.y];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int r0 = ti * BIG_NB + (wave >> 1) * 32, c0 = tj * BIG_NB + (wave & 1) * 32;
+  const int lm = lane & 15, lk = lane >> 4;
+  big_d4 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) acc[a][b] = (big_d4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll 4
+  for (int kk = 0; kk < BIG_NB; kk += 4) {
+    const double a0 = F[(int64_t)(r0 + lm) * BIG_NB + kk + lk];
+    const double a1 = F[(int64_t)(r0 + 16 + lm) * BIG_NB + kk + lk];
+    const double b0 = R[(int64_t)(kk + lk) * N + c0 + lm];
+    const double b1 = R[(int64_t)(kk + lk) * N + c0 + 16 + lm];
+    acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
+    acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
+    acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
+    acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+  }
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int64_t at = (int64_t)(r0 + 16 * a + lk + 4 * g) * N + c0 + 16 * b + lm;
+        S[at] -= acc[a][b][g];
+      }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// 2c. scratch (row-major inverse) -> the level's inverse storage (row pieces, patch_inv_index), incl. the zero pad row
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void big_store_kernel(int64_t p0, const int64_t* __restrict__ patch_ptr,
+                                                         const int64_t* __restrict__ inv_ptr,
+                                                         const int64_t* __restrict__ scr_ptr,
+                                                         const double* __restrict__ scr, double* __restrict__ inv) {
+  const int64_t p = p0 + blockIdx.y;
+  const int n = (int)(patch_ptr[p + 1] - patch_ptr[p]);
+  const int N = (n + BIG_NB - 1) / BIG_NB * BIG_NB;
+  const int ld = (n + 1) & ~1;
+  const double* S = scr + scr_ptr[blockIdx.y];
+  double* T = inv + inv_ptr[p];
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < (int64_t)ld * n; e += (int64_t)gridDim.x * 256) {
+    const int r = (int)(e / n), c = (int)(e % n);
+    T[patch_inv_index(r, c, n, ld)] = r < n ? S[(int64_t)r * N + c] : 0.0;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// 3. additive apply, stage 1: one workgroup per patch, row pieces dealt to the four waves
+// ---------------------------------------------------------------------------------------------------------------------
+typedef double big_d2 __attribute__((ext_vector_type(2)));
+template <int G, bool NT>
+__device__ __forceinline__ void big_piece(const double* __restrict__ T, int n, const double* __restrict__ xs, int lane,
+                                          double* __restrict__ out) {
+  constexpr int C = 64 / G, U = 8;
+  const int cg = lane / G, l = lane % G;
+  const double* base = T + 2 * l;
+  double acc0 = 0.0, acc1 = 0.0;
+  int j = cg;
+  for (; j + (U - 1) * C < n; j += U * C) {
+    big_d2 v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const big_d2* q = reinterpret_cast<const big_d2*>(base + (int64_t)(j + u * C) * (2 * G));
+      v[u] = NT ? __builtin_nontemporal_load(q) : *q;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const double xj = xs[j + u * C];
+      acc0 = __builtin_fma(v[u].x, xj, acc0);
+      acc1 = __builtin_fma(v[u].y, xj, acc1);
+    }
+  }
+  for (; j < n; j += C) {
+    const big_d2* q = reinterpret_cast<const big_d2*>(base + (int64_t)j * (2 * G));
+    const big_d2 v = NT ? __builtin_nontemporal_load(q) : *q;
+    const double xj = xs[j];
+    acc0 = __builtin_fma(v.x, xj, acc0);
+    acc1 = __builtin_fma(v.y, xj, acc1);
+  }
+  if (C > 1) {
+#pragma unroll
+    for (int o = G; o < 64; o <<= 1) {
+      acc0 += __shfl_xor(acc0, o);
+      acc1 += __shfl_xor(acc1, o);
+    }
+  }
+  if (cg == 0) *reinterpret_cast<double2*>(out + 2 * l) = make_double2(acc0, acc1);
+}
+
+template <bool NT>
+__global__ __launch_bounds__(256) void big_apply_kernel(int64_t p0, int64_t npatch, const int64_t* __restrict__ patch_ptr,
+                                                         const int32_t* __restrict__ patch_dofs,
+                                                         const int64_t* __restrict__ inv_ptr,
+                                                         const int64_t* __restrict__ stage_ptr,
+                                                         const double* __restrict__ inv, const double* __restrict__ x,
+                                                         double* __restrict__ stage) {
+  __shared__ double xs[BIG_MAX_NP];
+  const int64_t p = p0 + blockIdx.x;
+  if (p >= npatch) return;
+  const int64_t off = patch_ptr[p];
+  const int n = (int)(patch_ptr[p + 1] - off);
+  for (int i = threadIdx.x; i < n; i += 256) xs[i] = x[patch_dofs[off + i]];
+  __syncthreads();
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int ld = (n + 1) & ~1;
+  const double* T = inv + inv_ptr[p];
+  double* out = stage + stage_ptr[p];
+  int piece = 0, row0 = 0;
+  for (; row0 + 128 <= ld; row0 += 128, ++piece)
+    if ((piece & 3) == wave) big_piece<64, NT>(T + (int64_t)row0 * n, n, xs, lane, out + row0);
+  const int rem = ld - row0;
+#define ALFI_BIG_PIECE(R)                                                                   \
+  if (rem & R) {                                                                            \
+    if ((piece & 3) == wave) big_piece<R / 2, NT>(T + (int64_t)row0 * n, n, xs, lane, out + row0); \
+    row0 += R;                                                                              \
+    ++piece;                                                                                \
+  }
+  ALFI_BIG_PIECE(64)
+  ALFI_BIG_PIECE(32)
+  ALFI_BIG_PIECE(16)
+  ALFI_BIG_PIECE(8)
+  ALFI_BIG_PIECE(4)
+  ALFI_BIG_PIECE(2)
+#undef ALFI_BIG_PIECE
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// launch wrappers
+// ---------------------------------------------------------------------------------------------------------------------
+int launch_big_apply_range(alfi_level* L, int64_t p0, int64_t p1, const double* x) {
+  alfi_ctx* ctx = L->ctx;
+  if (p1 <= p0) return 0;
+  static const bool nt = !(getenv("ALFI_NT") && atoi(getenv("ALFI_NT")) == 0);
+  dim3 grid((unsigned)(p1 - p0)), block(256);
+  if (nt)
+    hipLaunchKernelGGL(big_apply_kernel<true>, grid, block, 0, ctx->stream, p0, p1, L->patch_ptr, L->patch_dofs, L->inv_ptr,
+                       L->stage_ptr, L->inv, x, L->stage);
+  else
+    hipLaunchKernelGGL(big_apply_kernel<false>, grid, block, 0, ctx->stream, p0, p1, L->patch_ptr, L->patch_dofs, L->inv_ptr,
+                       L->stage_ptr, L->inv, x, L->stage);
+  ALFI_HIP_CHECK(ctx, hipGetLastError());
+  return 0;
+}
+
+// gather + blocked inversion of all patches of the level, in batches bounded by the scratch budget
+int launch_big_factor(alfi_level* L) {
+  alfi_ctx* ctx = L->ctx;
+  if (L->npatch == 0) return 0;
+  const int64_t budget = (int64_t)6 << 30;          // bytes of scratch (matrices + panels) per batch
+  const char* env = getenv("ALFI_BIG_SCRATCH_MB");
+  const int64_t limit = env ? (int64_t)atoll(env) << 20 : budget;
+  int64_t p0 = 0;
+  while (p0 < L->npatch) {
+    // batch [p0, p1)
+    std::vector<int64_t> scr_ptr, pan_ptr;
+    int64_t sdoubles = 0, pdoubles = 0, p1 = p0;
+    int Nmax = 0;
+    while (p1 < L->npatch) {
+      const int n = (int)(L->h_patch_ptr[p1 + 1] - L->h_patch_ptr[p1]);
+      const int N = (n + BIG_NB - 1) / BIG_NB * BIG_NB;
+      const int64_t need = ((int64_t)N * N + 2 * (int64_t)N * BIG_NB) * 8;
+      if (p1 > p0 && (sdoubles + 2 * pdoubles) * 8 + need > limit) break;
+      scr_ptr.push_back(sdoubles);
+      pan_ptr.push_back(pdoubles);
+      sdoubles += (int64_t)N * N;
+      pdoubles += (int64_t)N * BIG_NB;
+      if (N > Nmax) Nmax = N;
+      ++p1;
+    }
+    const int64_t nb = p1 - p0;
+    double *scr = nullptr, *panF = nullptr, *panR = nullptr;
+    int64_t *d_scr_ptr = nullptr, *d_pan_ptr = nullptr;
+    hipError_t e = hipMalloc((void**)&scr, (size_t)sdoubles * 8);
+    if (e == hipSuccess) e = hipMalloc((void**)&panF, (size_t)pdoubles * 8);
+    if (e == hipSuccess) e = hipMalloc((void**)&panR, (size_t)pdoubles * 8);
+    if (e == hipSuccess) e = hipMalloc((void**)&d_scr_ptr, (size_t)nb * 8);
+    if (e == hipSuccess) e = hipMalloc((void**)&d_pan_ptr, (size_t)nb * 8);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_scr_ptr, scr_ptr.data(), (size_t)nb * 8, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_pan_ptr, pan_ptr.data(), (size_t)nb * 8, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) {
+      dim3 block(256);
+      if (L->bs == 2)
+        hipLaunchKernelGGL(big_gather_kernel<2>, dim3((unsigned)nb), block, 0, ctx->stream, p0, L->A.rowptr, L->A.colidx,
+                           L->A.vals, L->A.flat, L->patch_ptr, L->patch_dofs, d_scr_ptr, scr);
+      else
+        hipLaunchKernelGGL(big_gather_kernel<3>, dim3((unsigned)nb), block, 0, ctx->stream, p0, L->A.rowptr, L->A.colidx,
+                           L->A.vals, L->A.flat, L->patch_ptr, L->patch_dofs, d_scr_ptr, scr);
+      const int tiles = Nmax / BIG_NB;
+      for (int k0 = 0; k0 < Nmax; k0 += BIG_NB) {
+        hipLaunchKernelGGL(big_panel_kernel, dim3((unsigned)nb), block, 0, ctx->stream, k0, L->patch_ptr, p0, d_scr_ptr, scr,
+                           d_pan_ptr, panF, panR, L->status);
+        hipLaunchKernelGGL(big_update_kernel, dim3((unsigned)(tiles * tiles), (unsigned)nb), block, 0, ctx->stream, k0,
+                           L->patch_ptr, p0, d_scr_ptr, scr, d_pan_ptr, panF, panR, tiles);
+      }
+      hipLaunchKernelGGL(big_store_kernel, dim3(64, (unsigned)nb), block, 0, ctx->stream, p0, L->patch_ptr, L->inv_ptr,
+                         d_scr_ptr, scr, L->inv);
+      e = hipGetLastError();
+      if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    }
+    (void)hipFree(scr);
+    (void)hipFree(panF);
+    (void)hipFree(panR);
+    (void)hipFree(d_scr_ptr);
+    (void)hipFree(d_pan_ptr);
+    if (e != hipSuccess) return alfi_set_error(ctx, ALFI_E_HIP, "large-patch factorisation failed: %s", hipGetErrorString(e));
+    p0 = p1;
+  }
+  return 0;
+}

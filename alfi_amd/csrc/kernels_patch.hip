@@ -606,6 +606,11 @@ int launch_patch_apply_range(alfi_level* L, int64_t p0, int64_t p1, const double
   alfi_ctx* ctx = L->ctx;
   if (p1 <= p0) return 0;
   int t = alfi_prof_begin(ctx, ALFI_EV_PATCH_APPLY);
+  if (L->max_np > SMALL_PATCH_MAX) {            // one workgroup per patch (kernels_bigpatch.hip)
+    ALFI_CHECK(launch_big_apply_range(L, p0, p1, x));
+    alfi_prof_end(ctx, t);
+    return 0;
+  }
   const int64_t cnt = p1 - p0;
   dim3 grid((unsigned)((cnt + 3) / 4)), block(256);
   // the inverses are read once per apply: nontemporal loads keep x, the staging buffer and the index arrays in cache

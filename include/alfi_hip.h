@@ -118,7 +118,9 @@ int alfi_residual(alfi_level* lvl, const double* db, const double* dx, double* d
 
 /* ---- patch smoother: firedrake.PatchPC -> PETSc PCPATCH [3P], alfi/solver.py:318-328, 599-602 -------------------- */
 /* Patches as produced by a patch-construction callable (alfi/relaxation.py:110-150) after PCPATCH's dof mapping:
- * patch p owns dofs patch_dofs[patch_ptr[p] .. patch_ptr[p+1]), ascending, Dirichlet dofs excluded, sizes <= 160. */
+ * patch p owns dofs patch_dofs[patch_ptr[p] .. patch_ptr[p+1]), ascending, Dirichlet dofs excluded, sizes <= 2048
+ * (levels whose largest patch exceeds 160 dofs -- macro stars -- use the blocked matrix-core inversion and one workgroup
+ * per patch in the apply). */
 int alfi_patches_set(alfi_level* lvl, int64_t npatch, const int64_t* patch_ptr_host, const int32_t* patch_dofs_host);
 /* PCSetUp_PATCH with save_operators + dense_inverse (solver.py:320, 602): A_p = A[dofs_p, dofs_p], store inv(A_p). */
 int alfi_patches_factor(alfi_level* lvl);

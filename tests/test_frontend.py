@@ -222,3 +222,43 @@ def test_macro_star_patches_through_the_option_dictionary():
     assert np.abs(y - ref).max() < 1e-8 * np.abs(ref).max()
     obj.level.close()
     ctx.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("k,nmax", [(1, 1053), (2, 1533)])
+def test_macro_star_patches_3d_use_the_large_patch_path(k, nmax):
+    """3-D macro stars (solver.py:339-343 / relaxation.py:163-177) hold 60 .. 1533 dofs on a once-refined ldc3d mesh -- the
+    size class of the reference's Scott-Vogelius macro patches (405 / 1275): blocked matrix-core
+    inversion + workgroup-per-patch apply behind the same PCPython class; apply and a whole multigrid cycle with that
+    smoother against the oracle."""
+    import alfi_amd
+    from alfi_amd import hip
+    from oracle import alfi_oracle as O
+    lv, tr = build_hierarchy(ThreeDimLidDrivenCavityProblem(2), 1, k, Re=100.0)
+    L = lv[-1]
+    ctx = hip.Context(0)
+    opts = alfi_amd.mg_levels_solver(3, patch="macro", smoothing=3)
+    pc = alfi_amd.PC(ctx, L, options=opts)
+    obj = alfi_amd.HipPatchPC()
+    obj.initialize(pc)
+    sizes = np.diff(obj.patch_ptr)
+    assert len(sizes) == 27 and sizes.max() == nmax
+    x = np.random.default_rng(7).standard_normal(L.n)
+    y = np.zeros(L.n)
+    obj.apply(pc, x, y)
+    sm = O.PatchSmoother(L.A.to_scipy().tocsr(), obj.patch_ptr, obj.patch_dofs, L.bc_dofs)
+    ref = sm.apply(x)
+    # 1e-6: the macro patches are worse conditioned than vertex stars (cond ~ 1e8), two backward-stable inversions agree
+    # to cond * eps
+    assert np.abs(y - ref).max() < 1e-6 * np.abs(ref).max()
+    obj.level.close()
+    mg = alfi_amd.HipMG(ctx, lv, tr, alfi_amd.fieldsplit_0_mg(opts))
+    b = np.random.default_rng(8).standard_normal(L.n)
+    b[L.bc_dofs] = 0.0
+    out = np.zeros(L.n)
+    mg.apply(b, out)
+    lv[-1].patch_ptr, lv[-1].patch_dofs = mg.pc_objs[-1].patch_ptr, mg.pc_objs[-1].patch_dofs
+    ref = O.build_oracle_mg(lv, tr, 3).fcycle(b)
+    assert np.abs(out - ref).max() < 1e-5 * np.abs(ref).max()
+    mg.mg.close()
+    ctx.close()

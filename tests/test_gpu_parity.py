@@ -298,8 +298,8 @@ def test_patch_sizes_1_to_160_all_row_piece_combinations(ctx, bs):
     e = np.zeros_like(x)
     e[bc] = x[bc]
     assert np.array_equal(dy.get(), e)
-    # one patch too large
-    big = (np.arange(max_nodes + 1)[:, None] * bs + np.arange(bs)).ravel().astype(np.int32)
+    # one patch too large (the limit is 2048 dofs, tests/test_gpu_parity.py::test_large_patches covers 161 .. 2048)
+    big = (np.arange(2048 // bs + 1)[:, None] * bs + np.arange(bs)).ravel().astype(np.int32) % (nb * bs)
     with pytest.raises(hip.AlfiHipError):
         lvl.set_patches(np.array([0, len(big)], dtype=np.int64), big)
     lvl.close()
@@ -385,3 +385,52 @@ def test_uncommon_paths(ctx):
         dl.spmv(dxx, dyy)
         assert relerr(dyy.get(), A @ x) < 1e-13
     dl.close()
+
+
+@pytest.mark.parametrize("bs", [2, 3])
+def test_large_patches(ctx, bs):
+    """Patches beyond the register-resident path (161 .. ~1300 dofs; the macro-star sizes of SURVEY.md section 8: 405,
+    1275): gather, blocked Gauss-Jordan inversion with the FP64 matrix cores, one-workgroup-per-patch apply -- against
+    NumPy on a random diagonally dominant block operator.  Sizes straddle the 64-column blocks and the 128-row pieces."""
+    import scipy.sparse as sp
+    from alfi_amd import hip
+    from alfi_amd.problem import BSR
+    rng = np.random.default_rng(50 + bs)
+    nb = 900
+    M = sp.random(nb * bs, nb * bs, density=0.01, random_state=11, format="csr")
+    M = M + M.T + sp.identity(nb * bs) * 30.0
+    A = BSR.from_scipy(sp.csr_matrix(M), bs)
+    S = A.to_scipy().tocsr()
+    sizes = [(161 + bs - 1) // bs, 200 // bs, 64, 405 // bs, 640 // bs, 1275 // bs, 1300 // bs, 10]   # nodes per patch
+    ptr, dofs = [0], []
+    for sz in sizes:
+        nodes = np.sort(rng.choice(nb, sz, replace=False))
+        d = (nodes[:, None] * bs + np.arange(bs)).ravel()
+        dofs.append(d)
+        ptr.append(ptr[-1] + len(d))
+    ptr, dofs = np.array(ptr, dtype=np.int64), np.concatenate(dofs).astype(np.int32)
+    lvl = hip.Level(ctx, A, np.array([0], dtype=np.int32))
+    lvl.set_patches(ptr, dofs)
+    lvl.factor()
+    x = rng.standard_normal(nb * bs)
+    ref = np.zeros_like(x)
+    for p in range(len(sizes)):
+        d = dofs[ptr[p]:ptr[p + 1]]
+        Ainv = np.linalg.inv(S[d][:, d].toarray())
+        got = lvl.patch_inverse(p, len(d))
+        assert np.abs(got - Ainv).max() < 1e-10 * np.abs(Ainv).max(), (p, len(d))
+        ref[d] += Ainv @ x[d]
+    ref[0] = x[0]
+    dx, dy = ctx.vec(x), ctx.vec(nb * bs)
+    lvl.patch_apply(dx, dy)
+    assert np.abs(dy.get() - ref).max() < 1e-11 * np.abs(ref).max()
+    # as smoother of FGMRES
+    b = rng.standard_normal(nb * bs)
+    b[0] = 0.0
+    db, dz = ctx.vec(b), ctx.vec(nb * bs)
+    lvl.smooth(3, db, dz, nonzero_guess=False)
+    from oracle import alfi_oracle as O
+    sm = O.PatchSmoother(S, ptr, dofs, np.array([0]))
+    zref = O.fgmres(lambda v: S @ v, sm.apply, b, np.zeros_like(b), 3, nonzero_guess=False)
+    assert np.abs(dz.get() - zref).max() < 1e-8 * np.abs(zref).max()
+    lvl.close()
