@@ -177,7 +177,9 @@ __global__ __launch_bounds__(256) void big_panel_kernel(int k0, const int64_t* _
 //     operands are read straight from global memory: 15.9 TFLOP/s over the whole factorisation, 27 % MFMA-busy
 //     (SQ_VALU_MFMA_BUSY_CYCLES).  A variant staging both 64 x 64 operand tiles through LDS in MFMA lane order was
 //     measured SLOWER (10.8 TFLOP/s: 64 KB of LDS per workgroup leave 2 waves per SIMD, too few to cover the fill and the
-//     read-modify-write of S); larger register tiles per wave are the next step.
+//     read-modify-write of S), and so was a 64 x 64 register tile per wave (9.5 TFLOP/s: 128 accumulator VGPRs, occupancy).
+//     The rank-64 update re-streams S once per step: 20 steps x 26 MB per 1275-dof patch = 0.26 s of HBM time for 3000
+//     patches, a third of the measured 0.78 s -- a 128-wide pivot block halves that and is the next step.
 // ---------------------------------------------------------------------------------------------------------------------
 typedef double big_d4 __attribute__((ext_vector_type(4)));
 
