@@ -187,7 +187,7 @@ def test_bad_arguments_are_reported(ctx, setup):
     with pytest.raises(hip.AlfiHipError):
         dl.set_patches(np.array([0, 1]), np.array([L.n]))             # out of range
     with pytest.raises(hip.AlfiHipError):
-        dl.set_patches(np.array([0, 161]), np.arange(161))            # too large
+        dl.set_patches(np.array([0, 2049]), np.arange(2049) % L.n)    # too large (limit: 2048 dofs per patch)
     dl.close()
 
 
