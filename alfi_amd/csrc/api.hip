@@ -674,6 +674,10 @@ int alfi_patches_set(alfi_level* L, int64_t npatch, const int64_t* pptr, const i
   L->mult_seq = nullptr;
   L->mult = false;
   L->mult_wave_ptr.clear();
+  // a new patch set invalidates the interior-patch count of alfi_level_set_overlap: back to the plain exchange until the
+  // caller declares the new one
+  L->overlap = false;
+  L->npatch_int = 0;
   return 0;
 }
 
