@@ -759,7 +759,8 @@ int alfi_patches_factor(alfi_level* L) {
   if (!L->patch_ptr) return alfi_set_error(ctx, ALFI_E_STATE, "alfi_patches_factor before alfi_patches_set");
   int t = alfi_prof_begin(ctx, ALFI_EV_PATCH_FACTOR);
   ALFI_HIP_CHECK(ctx, hipMemsetAsync(L->status, 0, sizeof(int), ctx->stream));
-  if (L->max_np > SMALL_PATCH_MAX) {
+  static const bool force_big = getenv("ALFI_FORCE_BIG_FACTOR") && atoi(getenv("ALFI_FORCE_BIG_FACTOR")) == 1;
+  if (L->max_np > SMALL_PATCH_MAX || force_big) {
     ALFI_CHECK(launch_big_factor(L));             // macro-star sized patches: blocked Gauss-Jordan on the matrix cores
   } else {
     ALFI_CHECK(launch_patch_gather_dense(L));

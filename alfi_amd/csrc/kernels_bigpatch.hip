@@ -230,6 +230,57 @@ __global__ __launch_bounds__(256) void big_update_kernel(int k0, const int64_t* 
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// 2b'. Newton-Schulz polish X <- X + X (I - A X) (two N x N x N products on the matrix cores).  Block Gauss-Jordan forms
+//      the inverses of its 64 x 64 pivot blocks explicitly; with patch condition numbers of 1e7 that costs accuracy
+//      (relative difference to LAPACK's inverse 2e-5 against 1e-10 for the scalar register kernel of the small patches,
+//      measured).  One polish step squares the error (measured afterwards: see DESIGN.md).
+//        mode 0: C = I - A B        mode 1: C = A0 + A B   (A0 = the left operand itself)
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void big_gemm_kernel(int mode, const int64_t* __restrict__ patch_ptr, int64_t p0,
+                                                        const int64_t* __restrict__ scr_ptr,
+                                                        const double* __restrict__ Aall, const double* __restrict__ Ball,
+                                                        double* __restrict__ Call, int tiles_max) {
+  const int64_t p = p0 + blockIdx.y;
+  const int n = (int)(patch_ptr[p + 1] - patch_ptr[p]);
+  const int N = (n + BIG_NB - 1) / BIG_NB * BIG_NB;
+  const int nt = N / BIG_NB;
+  const int ti = blockIdx.x / tiles_max, tj = blockIdx.x % tiles_max;
+  if (ti >= nt || tj >= nt) return;
+  const double* A = Aall + scr_ptr[blockIdx.y];
+  const double* B = Ball + scr_ptr[blockIdx.y];
+  double* C = Call + scr_ptr[blockIdx.y];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int r0 = ti * BIG_NB + (wave >> 1) * 32, c0 = tj * BIG_NB + (wave & 1) * 32;
+  const int lm = lane & 15, lk = lane >> 4;
+  big_d4 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) acc[a][b] = (big_d4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll 4
+  for (int kk = 0; kk < N; kk += 4) {
+    const double a0 = A[(int64_t)(r0 + lm) * N + kk + lk];
+    const double a1 = A[(int64_t)(r0 + 16 + lm) * N + kk + lk];
+    const double b0 = B[(int64_t)(kk + lk) * N + c0 + lm];
+    const double b1 = B[(int64_t)(kk + lk) * N + c0 + 16 + lm];
+    acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
+    acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
+    acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
+    acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+  }
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int row = r0 + 16 * a + lk + 4 * g, col = c0 + 16 * b + lm;
+        const int64_t at = (int64_t)row * N + col;
+        C[at] = mode == 0 ? (row == col ? 1.0 : 0.0) - acc[a][b][g] : A[at] + acc[a][b][g];
+      }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // 2c. scratch (row-major inverse) -> the level's inverse storage (row pieces, patch_inv_index), incl. the zero pad row
 // ---------------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void big_store_kernel(int64_t p0, const int64_t* __restrict__ patch_ptr,
@@ -353,6 +404,8 @@ int launch_big_factor(alfi_level* L) {
   const int64_t budget = (int64_t)6 << 30;          // bytes of scratch (matrices + panels) per batch
   const char* env = getenv("ALFI_BIG_SCRATCH_MB");
   const int64_t limit = env ? (int64_t)atoll(env) << 20 : budget;
+  const bool polish = !(getenv("ALFI_BIG_POLISH") && atoi(getenv("ALFI_BIG_POLISH")) == 0);
+  const int64_t nscr = polish ? 3 : 1;            // X | a second copy of A_p | I - A X
   int64_t p0 = 0;
   while (p0 < L->npatch) {
     // batch [p0, p1)
@@ -362,8 +415,8 @@ int launch_big_factor(alfi_level* L) {
     while (p1 < L->npatch) {
       const int n = (int)(L->h_patch_ptr[p1 + 1] - L->h_patch_ptr[p1]);
       const int N = (n + BIG_NB - 1) / BIG_NB * BIG_NB;
-      const int64_t need = ((int64_t)N * N + 2 * (int64_t)N * BIG_NB) * 8;
-      if (p1 > p0 && (sdoubles + 2 * pdoubles) * 8 + need > limit) break;
+      const int64_t need = ((int64_t)nscr * N * N + 2 * (int64_t)N * BIG_NB) * 8;
+      if (p1 > p0 && (nscr * sdoubles + 2 * pdoubles) * 8 + need > limit) break;
       scr_ptr.push_back(sdoubles);
       pan_ptr.push_back(pdoubles);
       sdoubles += (int64_t)N * N;
@@ -372,9 +425,11 @@ int launch_big_factor(alfi_level* L) {
       ++p1;
     }
     const int64_t nb = p1 - p0;
-    double *scr = nullptr, *panF = nullptr, *panR = nullptr;
+    double *scr = nullptr, *scrA = nullptr, *scrR = nullptr, *panF = nullptr, *panR = nullptr;
     int64_t *d_scr_ptr = nullptr, *d_pan_ptr = nullptr;
     hipError_t e = hipMalloc((void**)&scr, (size_t)sdoubles * 8);
+    if (e == hipSuccess && polish) e = hipMalloc((void**)&scrA, (size_t)sdoubles * 8);
+    if (e == hipSuccess && polish) e = hipMalloc((void**)&scrR, (size_t)sdoubles * 8);
     if (e == hipSuccess) e = hipMalloc((void**)&panF, (size_t)pdoubles * 8);
     if (e == hipSuccess) e = hipMalloc((void**)&panR, (size_t)pdoubles * 8);
     if (e == hipSuccess) e = hipMalloc((void**)&d_scr_ptr, (size_t)nb * 8);
@@ -396,12 +451,29 @@ int launch_big_factor(alfi_level* L) {
         hipLaunchKernelGGL(big_update_kernel, dim3((unsigned)(tiles * tiles), (unsigned)nb), block, 0, ctx->stream, k0,
                            L->patch_ptr, p0, d_scr_ptr, scr, d_pan_ptr, panF, panR, tiles);
       }
+      const double* result = scr;
+      if (polish) {
+        // A_p once more (the inversion overwrote its copy), R = I - A X, X <- X + X R (into the buffer that held A_p)
+        if (L->bs == 2)
+          hipLaunchKernelGGL(big_gather_kernel<2>, dim3((unsigned)nb), block, 0, ctx->stream, p0, L->A.rowptr, L->A.colidx,
+                             L->A.vals, L->A.flat, L->patch_ptr, L->patch_dofs, d_scr_ptr, scrA);
+        else
+          hipLaunchKernelGGL(big_gather_kernel<3>, dim3((unsigned)nb), block, 0, ctx->stream, p0, L->A.rowptr, L->A.colidx,
+                             L->A.vals, L->A.flat, L->patch_ptr, L->patch_dofs, d_scr_ptr, scrA);
+        hipLaunchKernelGGL(big_gemm_kernel, dim3((unsigned)(tiles * tiles), (unsigned)nb), block, 0, ctx->stream, 0,
+                           L->patch_ptr, p0, d_scr_ptr, scrA, scr, scrR, tiles);
+        hipLaunchKernelGGL(big_gemm_kernel, dim3((unsigned)(tiles * tiles), (unsigned)nb), block, 0, ctx->stream, 1,
+                           L->patch_ptr, p0, d_scr_ptr, scr, scrR, scrA, tiles);
+        result = scrA;
+      }
       hipLaunchKernelGGL(big_store_kernel, dim3(64, (unsigned)nb), block, 0, ctx->stream, p0, L->patch_ptr, L->inv_ptr,
-                         d_scr_ptr, scr, L->inv);
+                         d_scr_ptr, result, L->inv);
       e = hipGetLastError();
       if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     }
     (void)hipFree(scr);
+    (void)hipFree(scrA);
+    (void)hipFree(scrR);
     (void)hipFree(panF);
     (void)hipFree(panR);
     (void)hipFree(d_scr_ptr);

@@ -248,9 +248,8 @@ def test_macro_star_patches_3d_use_the_large_patch_path(k, nmax):
     obj.apply(pc, x, y)
     sm = O.PatchSmoother(L.A.to_scipy().tocsr(), obj.patch_ptr, obj.patch_dofs, L.bc_dofs)
     ref = sm.apply(x)
-    # 1e-6: the macro patches are worse conditioned than vertex stars (cond ~ 1e8), two backward-stable inversions agree
-    # to cond * eps
-    assert np.abs(y - ref).max() < 1e-6 * np.abs(ref).max()
+    # the blocked inversion is followed by a Newton-Schulz polish, so the macro patches meet the tolerance of the stars
+    assert np.abs(y - ref).max() < 1e-7 * np.abs(ref).max()
     obj.level.close()
     mg = alfi_amd.HipMG(ctx, lv, tr, alfi_amd.fieldsplit_0_mg(opts))
     b = np.random.default_rng(8).standard_normal(L.n)
