@@ -228,3 +228,44 @@ def coarse_support_size(mesh, entity_vertices):
     par = mesh.vertex_parents[entity_vertices].reshape(entity_vertices.shape[0], -1)   # (m, 2k)
     par = np.sort(par, axis=1)
     return 1 + (np.diff(par, axis=1) != 0).sum(axis=1)
+
+
+# -- barycentric (Alfeld) refinement: the meshes of the reference's Scott-Vogelius discretisation ------------------------
+def bary_refine(mesh):
+    """Alfeld split (PETSc DMPlexTransform REFINEALFELD, alfi/bary.py:16-27): every cell gets its barycentre as a new
+    vertex and is replaced by dim+1 cells, child i = the parent with vertex i moved to the barycentre; fine cell
+    c*(dim+1)+i is child i of cell c (the numbering bary.py:148-151 relies on).  The vertices of the mesh that is split
+    are the macro vertices (``MacroVertices`` label = 1, bary.py:18-19): ``macro_vertex_mask`` on the result."""
+    dim, nv, nc = mesh.dim, mesh.num_vertices, mesh.num_cells
+    centres = mesh.coords[mesh.cells].mean(axis=1)
+    coords = np.concatenate([mesh.coords, centres])
+    cells = np.repeat(mesh.cells.astype(np.int64)[:, None, :], dim + 1, axis=1)          # (nc, dim+1, dim+1)
+    for i in range(dim + 1):
+        cells[:, i, i] = nv + np.arange(nc)
+    out = SimplexMesh(coords, cells.reshape(-1, dim + 1),
+                      parent_cell=np.repeat(np.arange(nc, dtype=np.int32), dim + 1),
+                      child_index=np.tile(np.arange(dim + 1, dtype=np.int32), nc))
+    out.macro_vertex_mask = np.concatenate([np.ones(nv, dtype=bool), np.zeros(nc, dtype=bool)])
+    out.macro_mesh = mesh
+    return out
+
+
+def bary_mesh_hierarchy(base, nref):
+    """alfi.bary.BaryMeshHierarchy (bary.py:29-194): level l = Alfeld split of the l-times uniformly refined base mesh.
+    The levels are NOT nested in one another (only their macro meshes are); ``macro_mesh`` on every level gives the
+    nested skeleton the reference's coarse_to_fine maps are built from (bary.py:137-160)."""
+    return [bary_refine(m) for m in mesh_hierarchy(base, nref)]
+
+
+def bfs3d_mesh(n):
+    """Structured stand-in for the reference's gmsh backward-facing-step channel (examples/bfs3d/
+    backwards-facing-step-3d.geo:1-6: a 10 x 2 x 1 channel with a 1 x 1 step under the inlet): Kuhn tets on n cubes per
+    unit length, the cubes of the step [0, 1] x [0, 1] x [0, 1] removed."""
+    full = box_mesh(10 * n, 2 * n, n, 10.0, 2.0, 1.0)
+    centre = full.coords[full.cells].mean(axis=1)
+    keep = ~((centre[:, 0] < 1.0) & (centre[:, 1] < 1.0))
+    cells = full.cells[keep]
+    used = np.unique(cells)
+    renum = np.full(full.num_vertices, -1, dtype=np.int64)
+    renum[used] = np.arange(used.shape[0])
+    return SimplexMesh(full.coords[used], renum[cells])

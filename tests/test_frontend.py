@@ -261,3 +261,41 @@ def test_macro_star_patches_3d_use_the_large_patch_path(k, nmax):
     assert np.abs(out - ref).max() < 1e-5 * np.abs(ref).max()
     mg.mg.close()
     ctx.close()
+
+
+def test_macro_star_on_an_alfeld_split_mesh():
+    """The reference's macro-star patches live on barycentrically refined meshes (bary.py:16-27; MacroVertices = the
+    vertices of the mesh that is split).  For a fully interior macro vertex of a Kuhn box and [P2]^3:
+      * 24 macro tets -> 96 cells; the interior of the macro patch holds 25 vertices + 110 edges = 135 nodes = 405 dofs --
+        the figure of SURVEY.md section 8 (and 425 nodes = 1275 dofs for P3);
+      * the LITERAL callback (relaxation.py:168-177) tests the MacroVertices label on every point of the closures, not only
+        on vertices, so the 36 outer edges of the macro star bring their own stars -- and their dofs -- along: 513 dofs.
+        alfi_amd.MacroStar follows the literal code; both sizes are within the library's 2048-dof limit."""
+    from alfi_amd.mesh import box_mesh, bary_refine, bary_mesh_hierarchy, bfs3d_mesh
+    from alfi_amd.elements import NodalElement
+    from alfi_amd.fespace import VectorFunctionSpace
+    from alfi_amd.relaxation import MacroStar
+    m = box_mesh(4, 4, 4, 2.0, 2.0, 2.0)
+    b = bary_refine(m)
+    assert b.num_cells == 4 * m.num_cells and b.num_vertices == m.num_vertices + m.num_cells
+    assert np.isclose(b.cell_geometry()[1].sum(), 8.0) and b.macro_vertex_mask.sum() == m.num_vertices
+    assert np.array_equal(b.parent_cell, np.repeat(np.arange(m.num_cells), 4))
+    V = VectorFunctionSpace(b, NodalElement(3, 2, False))
+    dm = PlexLike(b, labels={"MacroVertices": {int(b.num_cells + v): 1 for v in np.flatnonzero(b.macro_vertex_mask)}})
+    vid = int(np.flatnonzero((np.abs(m.coords - 1.0) < 1e-12).all(axis=1))[0])        # the centre vertex
+    ms = MacroStar()
+    assert ms.callback(dm, dm.vStart + m.num_vertices) is None                          # a barycentre is no seed
+    pts = ms.callback(dm, dm.vStart + vid)
+    ptr, dofs, _ = patch_points_to_dofs(V, dm, [np.asarray(pts)])
+    assert np.diff(ptr)[0] == 513
+    s = list(ms.star(dm, dm.vStart + vid))
+    clos = sum((list(ms.closure(dm, e)) for e in s), [])
+    vs = [p for p in set(clos) if dm.vStart <= p < dm.eStart and dm.getLabelValue("MacroVertices", p) != 1]
+    assert len(vs) == 24                                                                # the 24 barycentres
+    ptr2, _, _ = patch_points_to_dofs(V, dm, [np.asarray(s + sum((list(ms.star(dm, v)) for v in vs), []))])
+    assert np.diff(ptr2)[0] == 405
+    # hierarchy and the step channel of config 5
+    mh = bary_mesh_hierarchy(box_mesh(1, 1, 1, 1.0, 1.0, 1.0), 1)
+    assert [x.num_cells for x in mh] == [24, 192] and mh[1].macro_mesh.num_cells == 48
+    step = bfs3d_mesh(2)
+    assert np.isclose(step.cell_geometry()[1].sum(), 10 * 2 * 1 - 1.0)
