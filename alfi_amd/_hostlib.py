@@ -66,7 +66,8 @@ def node_graph(cell_nodes, nnode):
 
 
 def assemble_bsr(cell_nodes, g, vol, tensors, d, rowptr, colidx, nu=0.0, gamma=0.0, adv=0.0, wind=None, out=None,
-                 row_map=None):
+                 row_map=None, gamma_full=0.0):
+    """gamma: coefficient of (cell_avg div u, div v) (PkP0 forms); gamma_full: of (div u, div v) (Scott-Vogelius forms)."""
     cn = np.ascontiguousarray(cell_nodes, dtype=np.int32)
     ncell, nloc = cn.shape
     g = np.ascontiguousarray(g, dtype=np.float64)
@@ -81,7 +82,7 @@ def assemble_bsr(cell_nodes, g, vol, tensors, d, rowptr, colidx, nu=0.0, gamma=0
     rc = lib().alfi_host_assemble_bsr(ctypes.c_int64(ncell), ctypes.c_int(nloc), ctypes.c_int(d), _p(cn), _p(g),
                                       _p(vol), _p(S), _p(bI), _p(T1), _p(wind), ctypes.c_double(nu),
                                       ctypes.c_double(gamma), ctypes.c_double(adv), _p(row_map), _p(rowptr), _p(colidx),
-                                      _p(out))
+                                      _p(out), ctypes.c_double(gamma_full))
     if rc != 0:
         raise RuntimeError("assemble_bsr failed (%d): sparsity pattern does not cover the mesh" % rc)
     return out
@@ -104,7 +105,7 @@ def extract_blocks(d, rowptr, colidx, vals, blk_ptr, blk_dofs):
     return out_ptr, out
 
 
-def interior_blocks(cell_nodes, g, vol, tensors, d, blk_nodes, num_nodes, nch):
+def interior_blocks(cell_nodes, g, vol, tensors, d, blk_nodes, num_nodes, nch, full_div=False):
     """K_II, D_II (nblk, m, m) of the coarse-cell interior dofs; children of block b are cells b*nch .. b*nch+nch-1."""
     cn = np.ascontiguousarray(cell_nodes, dtype=np.int32)
     nloc = cn.shape[1]
@@ -118,7 +119,8 @@ def interior_blocks(cell_nodes, g, vol, tensors, d, blk_nodes, num_nodes, nch):
     K = np.empty((nblk, m, m))
     D = np.empty((nblk, m, m))
     lib().alfi_host_interior_blocks(ctypes.c_int64(nblk), ctypes.c_int(nch), ctypes.c_int(nloc), ctypes.c_int(d),
-                                    _p(cn), _p(g), _p(vol), _p(S), _p(bI), _p(blk_local), ctypes.c_int(m), _p(K), _p(D))
+                                    _p(cn), _p(g), _p(vol), _p(S), _p(bI), _p(blk_local), ctypes.c_int(m), _p(K), _p(D),
+                                    ctypes.c_int(1 if full_div else 0))
     return K, D
 
 

@@ -932,7 +932,10 @@ int alfi_transfer_create(alfi_ctx* ctx, alfi_level* coarse, alfi_level* fine, co
     return alfi_set_error(ctx, ALFI_E_ARG, "NULL argument");
   const int bs = fine->bs;
   if (coarse->bs != bs) return alfi_set_error(ctx, ALFI_E_ARG, "block size mismatch");
-  if (m < 1 || m > 32) return alfi_set_error(ctx, ALFI_E_ARG, "interior block size %d not in 1..32", m);
+  if (m < 1 || m > SMALL_PATCH_MAX)
+    return alfi_set_error(ctx, ALFI_E_ARG, "interior block size %d not in 1..%d", m, SMALL_PATCH_MAX);
+  if (m > 32 && (m & 1))
+    return alfi_set_error(ctx, ALFI_E_ARG, "interior blocks of more than 32 dofs must have an even size, got %d", m);
   // partitioned fine level: P and D_I^T hold the owned fine rows, P^T the owned fine columns (its rows are partial sums
   // over the local coarse numbering, reverse-added to their owners); serial: n_own == n
   if (P->nbrows * bs != fine->n_own || P->nbcols * bs != coarse->n || PT->nbrows * bs != coarse->n ||
@@ -969,7 +972,27 @@ int alfi_transfer_create(alfi_ctx* ctx, alfi_level* coarse, alfi_level* fine, co
   if (rc == 0) rc = dev_upload(ctx, &T->blk_dofs, blk_dofs, nblk * m);
   if (rc == 0) rc = dev_upload(ctx, &T->KII, K_II, nblk * m * m);
   if (rc == 0) rc = dev_upload(ctx, &T->DII, D_II, nblk * m * m);
-  if (rc == 0) rc = dev_alloc(ctx, &T->binv, nblk * m * T->ld);
+  if (m > 32) {
+    // macro-cell blocks (Scott-Vogelius transfer, transfer.py:49-88): inverses in the row-piece layout, solved with the
+    // patch smoother's kernels; compact vectors keep stride m (= ld: m is even)
+    T->patch_mode = true;
+    T->bstride = ((int64_t)m * T->ld + 15) & ~(int64_t)15;
+    std::vector<int64_t> ptr(nblk + 1), iptr(nblk + 1), sptr(nblk + 1);
+    std::vector<int32_t> iota((size_t)nblk * m);
+    for (int64_t b = 0; b <= nblk; ++b) {
+      ptr[b] = b * m;
+      iptr[b] = b * T->bstride;
+      sptr[b] = b * T->ld;
+    }
+    for (int64_t i = 0; i < nblk * m; ++i) iota[i] = (int32_t)i;
+    if (rc == 0) rc = dev_upload(ctx, &T->pm_ptr, ptr.data(), nblk + 1);
+    if (rc == 0) rc = dev_upload(ctx, &T->pm_inv_ptr, iptr.data(), nblk + 1);
+    if (rc == 0) rc = dev_upload(ctx, &T->pm_stage_ptr, sptr.data(), nblk + 1);
+    if (rc == 0) rc = dev_upload(ctx, &T->pm_iota, iota.data(), nblk * m);
+    if (rc == 0) rc = dev_alloc(ctx, &T->binv, nblk * T->bstride);
+  } else if (rc == 0) {
+    rc = dev_alloc(ctx, &T->binv, nblk * m * T->ld);
+  }
   if (rc == 0) rc = dev_alloc(ctx, &T->tI, nblk * m);
   if (rc == 0) rc = dev_alloc(ctx, &T->bI, nblk * m);
   if (rc == 0) rc = dev_alloc(ctx, &T->tmp_f, fine->n);
@@ -994,6 +1017,10 @@ int alfi_transfer_destroy(alfi_transfer* T) {
   dev_free(T->KII);
   dev_free(T->DII);
   dev_free(T->binv);
+  dev_free(T->pm_ptr);
+  dev_free(T->pm_inv_ptr);
+  dev_free(T->pm_stage_ptr);
+  dev_free(T->pm_iota);
   dev_free(T->tI);
   dev_free(T->bI);
   dev_free(T->tmp_f);

@@ -184,7 +184,12 @@ struct alfi_transfer {
   int m = 0, ld = 0;
   int32_t* blk_dofs = nullptr;  // (nblk*m)
   double *KII = nullptr, *DII = nullptr;
-  double* binv = nullptr;  // (nblk, m cols, ld) column-major padded inverses
+  double* binv = nullptr;  // (nblk, m cols, ld) column-major padded inverses (m <= 32) or row-piece layout (m > 32)
+  // m > 32 (macro-cell blocks of the Scott-Vogelius transfer): the blocks go through the patch kernels
+  bool patch_mode = false;
+  int64_t bstride = 0;                  // doubles between consecutive block inverses
+  int64_t *pm_ptr = nullptr, *pm_inv_ptr = nullptr, *pm_stage_ptr = nullptr;   // (nblk+1) each
+  int32_t* pm_iota = nullptr;           // (nblk*m) identity index list: compact input vectors
   double *tI = nullptr, *bI = nullptr;  // compact interior vectors (nblk*m)
   double* tmp_f = nullptr;              // fine work vector
   int32_t* inj = nullptr;               // (coarse nodes) fine node coinciding with each coarse node
@@ -229,6 +234,11 @@ int launch_bsr_spmv(alfi_ctx* ctx, const DevBSR& A, const double* x, double* y, 
 int upload_bsr_values(alfi_ctx* ctx, DevBSR* d, const double* host_vals);
 int launch_patch_gather_dense(alfi_level* lvl);
 int launch_patch_invert(alfi_level* lvl);
+int launch_patch_invert_arrays(alfi_ctx* ctx, int64_t npatch, int max_np, const int64_t* patch_ptr,
+                               const int64_t* inv_ptr, double* inv, int* status);
+int launch_patch_apply_arrays(alfi_ctx* ctx, int64_t npatch, const int64_t* patch_ptr, const int32_t* patch_dofs,
+                              const int64_t* inv_ptr, const int64_t* stage_ptr, const double* inv, const double* x,
+                              double* stage);
 int launch_patch_apply(alfi_level* lvl, const double* x, double* y);          // both stages, all patches
 int launch_patch_apply_range(alfi_level* lvl, int64_t p0, int64_t p1, const double* x);   // stage 1, patches [p0, p1)
 int launch_big_apply_range(alfi_level* lvl, int64_t p0, int64_t p1, const double* x);     // the same for levels with n_p > 160

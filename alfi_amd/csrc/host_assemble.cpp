@@ -80,9 +80,11 @@ struct ElemWork {
                                cki((size_t)nloc * (d + 1)) {}
 };
 
+// gfull: coefficient of the FULL grad-div term (div u, div v) of the Scott-Vogelius forms (alfi/solver.py:609-619,
+// alfi/transfer.py:295-309), as opposed to gamma, the coefficient of the cell-averaged one of the PkP0 forms.
 static void element_matrix(int nloc, int d, const double* gc, double vc, const double* S, const double* bI,
                            const double* T1, const double* wk, double nu, double gamma, double adv, ElemWork& W,
-                           double* Ae) {
+                           double* Ae, double gfull = 0.0) {
   const int nv = d + 1;
   const int ndof = nloc * d;
   double* G = W.G.data();
@@ -90,7 +92,7 @@ static void element_matrix(int nloc, int d, const double* gc, double vc, const d
   double* bvec = W.bvec.data();
   double* cki = W.cki.data();
   std::fill(Ae, Ae + (size_t)ndof * ndof, 0.0);
-  if (nu != 0.0) {
+  if (nu != 0.0 || gfull != 0.0) {
     for (int i = 0; i < nv; ++i)
       for (int j = 0; j < nv; ++j) {
         double s = 0;
@@ -112,12 +114,12 @@ static void element_matrix(int nloc, int d, const double* gc, double vc, const d
             const double* hh = &Hij[((i * nv + j) * d) * d];
             for (int q = 0; q < d * d; ++q) h[q] += s * hh[q];
           }
-        // K_(a,c),(b,dd) = delta_{c,dd} G_ab + int d_dd phi_a d_c phi_b
+        // K_(a,c),(b,dd) = delta_{c,dd} G_ab + int d_dd phi_a d_c phi_b ;  (div, div)_(a,c),(b,dd) = int d_c phi_a d_dd phi_b
         for (int cc = 0; cc < d; ++cc)
           for (int dd = 0; dd < d; ++dd) {
             double v = h[dd * d + cc];
             if (cc == dd) v += gab;
-            Ae[(size_t)(a * d + cc) * ndof + b * d + dd] += nu * vc * v;
+            Ae[(size_t)(a * d + cc) * ndof + b * d + dd] += nu * vc * v + gfull * vc * h[cc * d + dd];
           }
       }
   }
@@ -177,7 +179,7 @@ static void element_matrix(int nloc, int d, const double* gc, double vc, const d
 int alfi_host_assemble_bsr(int64_t ncell, int nloc, int d, const int32_t* cell_nodes, const double* g,
                            const double* vol, const double* S, const double* bI, const double* T1, const double* w,
                            double nu, double gamma, double adv, const int32_t* row_map, const int32_t* rowptr,
-                           const int32_t* colidx, double* vals) {
+                           const int32_t* colidx, double* vals, double gamma_full) {
   const int nv = d + 1;
   const int ndof = nloc * d;
   const bool do_adv = (adv != 0.0) && (w != nullptr);
@@ -198,7 +200,7 @@ int alfi_host_assemble_bsr(int64_t ncell, int nloc, int d, const int32_t* cell_n
         for (int k = 0; k < nloc; ++k)
           for (int x = 0; x < d; ++x) wk[k * d + x] = w[(int64_t)cn[k] * d + x];
       element_matrix(nloc, d, g + c * nv * d, vol[c], S, bI, T1, wk.data(), nu, gamma, do_adv ? adv : 0.0, W,
-                     Ae.data());
+                     Ae.data(), gamma_full);
       for (int a = 0; a < nloc; ++a) {
         const int32_t ra = row_map ? row_map[cn[a]] : cn[a];
         if (ra < 0) continue;
@@ -228,7 +230,7 @@ int alfi_host_assemble_bsr(int64_t ncell, int nloc, int d, const int32_t* cell_n
 // blk_local[node] = position of the node inside its block (0..m/d-1) or -1.  KII, DII: (nblk, m, m) row-major.
 int alfi_host_interior_blocks(int64_t nblk, int nch, int nloc, int d, const int32_t* cell_nodes, const double* g,
                               const double* vol, const double* S, const double* bI, const int32_t* blk_local, int m,
-                              double* KII, double* DII) {
+                              double* KII, double* DII, int full_div) {
   const int nv = d + 1;
   const int ndof = nloc * d;
 #pragma omp parallel
@@ -245,7 +247,8 @@ int alfi_host_interior_blocks(int64_t nblk, int nch, int nloc, int d, const int3
         const int64_t c = blk * nch + ch;
         const int32_t* cn = cell_nodes + c * nloc;
         element_matrix(nloc, d, g + c * nv * d, vol[c], S, bI, nullptr, nullptr, 1.0, 0.0, 0.0, W, Ke.data());
-        element_matrix(nloc, d, g + c * nv * d, vol[c], S, bI, nullptr, nullptr, 0.0, 1.0, 0.0, W, De.data());
+        element_matrix(nloc, d, g + c * nv * d, vol[c], S, bI, nullptr, nullptr, 0.0, full_div ? 0.0 : 1.0, 0.0, W,
+                       De.data(), full_div ? 1.0 : 0.0);
         for (int a = 0; a < nloc; ++a) {
           const int la = blk_local[cn[a]];
           if (la < 0) continue;

@@ -563,20 +563,41 @@ int launch_invert_small_any(alfi_ctx* ctx, int nmax, int64_t nmat, const int64_t
   return alfi_set_error(ctx, ALFI_E_ARG, "small inversion supports n <= 32, got %d", nmax);
 }
 
-int launch_patch_invert(alfi_level* L) {
-  alfi_ctx* ctx = L->ctx;
-  if (L->npatch == 0) return 0;
-  if (L->max_np <= 32)
-    return launch_invert_small_any(ctx, L->max_np, L->npatch, L->patch_ptr, L->inv_ptr, 0, 0, L->inv, L->status);
-  dim3 grid((unsigned)L->npatch), block(256);
-  if (L->max_np <= 112)
-    hipLaunchKernelGGL(patch_invert_big_kernel<7>, grid, block, 0, ctx->stream, L->patch_ptr, L->inv_ptr, L->inv,
-                       L->status);
-  else if (L->max_np <= 160)
-    hipLaunchKernelGGL(patch_invert_big_kernel<10>, grid, block, 0, ctx->stream, L->patch_ptr, L->inv_ptr, L->inv,
-                       L->status);
+// in-place inversion of npatch dense matrices (row-major n x ld at inv + inv_ptr[p], n = patch_ptr[p+1] - patch_ptr[p] <=
+// max_np <= 160) into the row-piece layout: the level's patches, and the interior blocks of a Schoeberl transfer whose
+// block size exceeds 32
+int launch_patch_invert_arrays(alfi_ctx* ctx, int64_t npatch, int max_np, const int64_t* patch_ptr,
+                               const int64_t* inv_ptr, double* inv, int* status) {
+  if (npatch == 0) return 0;
+  if (max_np <= 32) return launch_invert_small_any(ctx, max_np, npatch, patch_ptr, inv_ptr, 0, 0, inv, status);
+  dim3 grid((unsigned)npatch), block(256);
+  if (max_np <= 112)
+    hipLaunchKernelGGL(patch_invert_big_kernel<7>, grid, block, 0, ctx->stream, patch_ptr, inv_ptr, inv, status);
+  else if (max_np <= SMALL_PATCH_MAX)
+    hipLaunchKernelGGL(patch_invert_big_kernel<10>, grid, block, 0, ctx->stream, patch_ptr, inv_ptr, inv, status);
   else
-    return alfi_set_error(ctx, ALFI_E_ARG, "patch size %d > 160 not supported (macro-star: SURVEY.md 8(f))", L->max_np);
+    return alfi_set_error(ctx, ALFI_E_ARG, "register inversion handles sizes <= %d, got %d", SMALL_PATCH_MAX, max_np);
+  ALFI_HIP_CHECK(ctx, hipGetLastError());
+  return 0;
+}
+
+int launch_patch_invert(alfi_level* L) {
+  return launch_patch_invert_arrays(L->ctx, L->npatch, L->max_np, L->patch_ptr, L->inv_ptr, L->inv, L->status);
+}
+
+// stage[stage_ptr[p] + r] = sum_c inv_p[r][c] x[patch_dofs[patch_ptr[p] + c]] for npatch row-piece inverses of size <= 160
+int launch_patch_apply_arrays(alfi_ctx* ctx, int64_t npatch, const int64_t* patch_ptr, const int32_t* patch_dofs,
+                              const int64_t* inv_ptr, const int64_t* stage_ptr, const double* inv, const double* x,
+                              double* stage) {
+  if (npatch == 0) return 0;
+  static const bool nt = !(getenv("ALFI_NT") && atoi(getenv("ALFI_NT")) == 0);
+  dim3 grid((unsigned)((npatch + 3) / 4)), block(256);
+  if (nt)
+    hipLaunchKernelGGL(patch_apply_kernel<true>, grid, block, 0, ctx->stream, (int64_t)0, npatch, patch_ptr, patch_dofs,
+                       inv_ptr, stage_ptr, inv, x, stage);
+  else
+    hipLaunchKernelGGL(patch_apply_kernel<false>, grid, block, 0, ctx->stream, (int64_t)0, npatch, patch_ptr, patch_dofs,
+                       inv_ptr, stage_ptr, inv, x, stage);
   ALFI_HIP_CHECK(ctx, hipGetLastError());
   return 0;
 }

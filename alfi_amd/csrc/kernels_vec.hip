@@ -734,21 +734,26 @@ int launch_update_solution(alfi_ctx* ctx, double* x, const double* Z, int64_t st
 // Schoeberl transfer: interior blocks.  binv holds nblk inverses, column-major, leading dimension ld (m rounded up to
 // even), stride m_cols * ld per block -- the same convention as the patch inverses.
 // ---------------------------------------------------------------------------------------------------------------------
-// S = nu K_II + gamma D_II in row-major padded form (input of invert_small_kernel)
-__global__ void block_build_kernel(int64_t nblk, int m, int ld, const double* __restrict__ K,
+// S = nu K_II + gamma D_II in row-major padded form (input of the inversion kernels); block b at S + b * stride
+__global__ void block_build_kernel(int64_t nblk, int m, int ld, int64_t stride, const double* __restrict__ K,
                                    const double* __restrict__ D, double nu, double gamma, double* __restrict__ S) {
   const int64_t total = nblk * m * ld;
   for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
     const int64_t blk = e / (m * ld);
-    const int r = (int)((e / ld) % m), c = (int)(e % ld);
-    S[e] = c < m ? nu * K[(blk * m + r) * m + c] + gamma * D[(blk * m + r) * m + c] : 0.0;
+    const int64_t in = e - blk * m * ld;
+    const int r = (int)(in / ld), c = (int)(in % ld);
+    S[blk * stride + in] = c < m ? nu * K[(blk * m + r) * m + c] + gamma * D[(blk * m + r) * m + c] : 0.0;
   }
 }
 
 int launch_block_build_invert(alfi_transfer* tr) {
   alfi_ctx* ctx = tr->ctx;
   const int64_t total = tr->nblk * tr->m * tr->ld;
-  ALFI_LAUNCH_EW(block_build_kernel, total, tr->nblk, tr->m, tr->ld, tr->KII, tr->DII, tr->nu, tr->gamma, tr->binv);
+  const int64_t stride = tr->patch_mode ? tr->bstride : (int64_t)tr->m * tr->ld;
+  ALFI_LAUNCH_EW(block_build_kernel, total, tr->nblk, tr->m, tr->ld, stride, tr->KII, tr->DII, tr->nu, tr->gamma,
+                 tr->binv);
+  if (tr->patch_mode)   // m > 32: register Gauss-Jordan of the patch smoother, result in the row-piece layout
+    return launch_patch_invert_arrays(ctx, tr->nblk, tr->m, tr->pm_ptr, tr->pm_inv_ptr, tr->binv, tr->status);
   return launch_invert_small_any(ctx, tr->m, tr->nblk, nullptr, nullptr, tr->m, (int64_t)tr->m * tr->ld, tr->binv,
                                  tr->status);
 }
@@ -777,6 +782,9 @@ __global__ __launch_bounds__(256) void block_gemv_kernel(int64_t nblk, int m, in
 int launch_block_gemv(alfi_transfer* tr, const double* in, double* out, bool gather_in) {
   alfi_ctx* ctx = tr->ctx;
   if (tr->nblk == 0) return 0;
+  if (tr->patch_mode)
+    return launch_patch_apply_arrays(ctx, tr->nblk, tr->pm_ptr, gather_in ? tr->blk_dofs : tr->pm_iota, tr->pm_inv_ptr,
+                                     tr->pm_stage_ptr, tr->binv, in, out);
   const int m = tr->m;
   const int G = m <= 8 ? 8 : (m <= 16 ? 16 : 32);
   const int64_t threads = tr->nblk * G;

@@ -1,0 +1,204 @@
+"""Scott-Vogelius side of the reference (towards BASELINE.json config 5): [P_k]^d velocities on barycentrically refined
+meshes with the FULL grad-div term, macro-star patches and the macro-cell Schoeberl transfer.
+
+Reference: ``ScottVogeliusSolver`` (alfi/solver.py:604-662: forms with ``gamma * inner(div(u), div(v))``, no cell_avg;
+``patch = macro``), ``BaryMeshHierarchy`` (alfi/bary.py:29-194: level l = Alfeld split of the l-times refined base mesh;
+the levels are not nested, only their macro meshes are), ``SVSchoeberlTransfer`` (alfi/transfer.py:293-309) with
+``CoarseCellMacroPatches`` (transfer.py:49-88: one interior block per coarse MACRO cell) and Firedrake's non-nested
+``prolong`` as the standard transfer (transfer.py:284-290).
+
+Everything here is host-side input generation (the role Firedrake plays for the reference); the arithmetic of smoother,
+transfers and cycles is the same libalfi_hip.so entry points as for the PkP0 discretisation.  Implemented for k = 2 (the
+element tables of ``elements.NodalElement`` stop at degree 2; the inf-sup stable 3-D pair needs k = 3).
+"""
+import numpy as np
+import scipy.sparse as sp
+
+from . import _hostlib
+from .elements import NodalElement
+from .fespace import VectorFunctionSpace
+from .mesh import bary_refine, mesh_hierarchy
+from .problem import BSR, LevelData, TransferData
+from .relaxation import MacroStar, PlexLike, patch_points_to_dofs
+
+
+def macro_labels(mesh):
+    """``MacroVertices`` = 1 on the vertices of the mesh that was split (bary.py:18-19), in PlexLike point numbering."""
+    return {"MacroVertices": {int(mesh.num_cells + v): 1 for v in np.flatnonzero(mesh.macro_vertex_mask)}}
+
+
+def macro_star_patches(V):
+    """The reference's MacroStar constructor (relaxation.py:163-177), literally, on the Alfeld-split mesh of V."""
+    dm = PlexLike(V.mesh, labels=macro_labels(V.mesh))
+
+    class _PC(object):
+        options = {}
+
+        def getDM(self):
+            return dm
+
+        def getOptionsPrefix(self):
+            return ""
+    patches, iterset = MacroStar()(_PC())
+    ptr, dofs, kept = patch_points_to_dofs(V, dm, patches)
+    return ptr, dofs
+
+
+def _coarse_macro_cell_of_nodes(Vf):
+    """For every fine node one fine cell holding it, and the coarse MACRO cell that cell lies in."""
+    mf = Vf.mesh
+    d = mf.dim
+    flat = Vf.cell_nodes.ravel()
+    _, first = np.unique(flat, return_index=True)
+    cell = first // Vf.cell_nodes.shape[1]
+    fine_macro = cell // (d + 1)                                  # bary cell c*(d+1)+i is a child of macro cell c
+    return mf.macro_mesh.parent_cell[fine_macro].astype(np.int64)
+
+
+def _barycentric(mesh, cells, x):
+    """Barycentric coordinates of the points x (m, dim) with respect to the cells ``cells`` (m,) of mesh."""
+    g, _ = mesh.cell_geometry()
+    v0 = mesh.coords[mesh.cells[cells, 0]]
+    lam = np.einsum("mix,mx->mi", g[cells], x - v0)
+    lam[:, 0] += 1.0
+    return lam
+
+
+def bary_prolongation(Vc, Vf):
+    """Nodal interpolation between the (non-nested) Alfeld levels: every fine node is located in one of the d+1 sub-cells
+    of the coarse macro cell it lies in, and the coarse basis is evaluated there -- what firedrake.prolong does on a
+    non-nested hierarchy with the coarse_to_fine maps of bary.py:137-160.  Scalar CSR (fine nodes x coarse nodes)."""
+    mc = Vc.mesh
+    d = mc.dim
+    C = _coarse_macro_cell_of_nodes(Vf)
+    x = Vf.node_coords
+    best, bestlam = None, None
+    for i in range(d + 1):
+        cand = C * (d + 1) + i
+        lam = _barycentric(mc, cand, x)
+        score = lam.min(axis=1)
+        if best is None:
+            best, bestlam, bestscore = cand.copy(), lam, score
+        else:
+            better = score > bestscore
+            best[better], bestlam[better], bestscore[better] = cand[better], lam[better], score[better]
+    assert bestscore.min() > -1e-9, "a fine node was not located in its coarse macro cell"
+    phi = Vc.element.tabulate(np.clip(bestlam, 0.0, 1.0))[0]        # (nfine, nloc)
+    phi[np.abs(phi) < 1e-13] = 0.0
+    rows = np.repeat(np.arange(Vf.num_nodes), phi.shape[1])
+    cols = Vc.cell_nodes[best].ravel()
+    P = sp.csr_matrix((phi.ravel(), (rows, cols)), shape=(Vf.num_nodes, Vc.num_nodes))
+    P.sum_duplicates()
+    P.eliminate_zeros()
+    P.sort_indices()
+    return P
+
+
+def macro_skeleton_mask(Vf):
+    """True for fine nodes on the closure of a coarse MACRO facet: the Dirichlet set of fix_coarse_boundaries
+    (transfer.py:121-158) on a bary hierarchy, where the ``prolongation`` label marks the facets of the coarse macro mesh."""
+    coarse_macro = Vf.mesh.macro_mesh                                  # refined macro mesh; its parent is the coarse macro mesh
+    C = _coarse_macro_cell_of_nodes(Vf)
+    # barycentric coordinates with respect to the coarse macro cell: reconstruct that mesh's geometry from the parents
+    cm_cells = _coarse_macro_cells(coarse_macro)
+    x = Vf.node_coords
+    v = coarse_macro.coords[cm_cells[C]]                               # (m, d+1, d) vertices of the coarse macro cell
+    T = (v[:, 1:, :] - v[:, :1, :]).transpose(0, 2, 1)
+    rhs = x - v[:, 0, :]
+    lam_rest = np.linalg.solve(T, rhs[:, :, None])[:, :, 0]
+    lam = np.concatenate([1.0 - lam_rest.sum(axis=1, keepdims=True), lam_rest], axis=1)
+    return lam.min(axis=1) < 1e-9
+
+
+def _coarse_macro_cells(refined_macro):
+    """Vertex tuples of the cells of the mesh ``refined_macro`` was refined from (child 0..d keep one parent vertex each)."""
+    d = refined_macro.dim
+    nch = 2 ** d
+    ncoarse = refined_macro.num_cells // nch
+    out = np.empty((ncoarse, d + 1), dtype=np.int64)
+    for i in range(d + 1):
+        # child i of coarse cell c is fine cell c*nch + i and its local vertex i is the coarse vertex i (mesh.children_table)
+        out[:, i] = refined_macro.cells[np.arange(ncoarse) * nch + i, i]
+    return out
+
+
+def macro_cell_blocks(Vf):
+    """transfer.py:49-88 (CoarseCellMacroPatches): one block per coarse macro cell with the fine nodes strictly inside it.
+    (num coarse macro cells, m / dim) node numbers, ascending."""
+    C = _coarse_macro_cell_of_nodes(Vf)
+    interior = ~macro_skeleton_mask(Vf)
+    nodes = np.flatnonzero(interior)
+    order = np.lexsort((nodes, C[nodes]))
+    counts = np.bincount(C[nodes])
+    assert counts.min() == counts.max(), "non-uniform macro interior blocks"
+    return nodes[order].reshape(-1, counts[0]).astype(np.int32)
+
+
+def build_sv_transfer_data(Vc, Vf, nu, gamma, graph):
+    mesh, d = Vf.mesh, Vf.dim
+    el = Vf.element
+    rowptr, colidx = graph
+    g, vol = mesh.cell_geometry()
+    tens = el.reference_tensors()
+    T = TransferData()
+    blk_nodes = macro_cell_blocks(Vf)
+    T.blk_dofs = np.ascontiguousarray(Vf.node_dofs(blk_nodes), dtype=np.int32)
+    nch = (2 ** d) * (d + 1)                                         # fine bary cells per coarse macro cell, contiguous
+    T.K_II, T.D_II = _hostlib.interior_blocks(Vf.cell_nodes, g, vol, tens, d, blk_nodes, Vf.num_nodes, nch,
+                                              full_div=True)
+    rows = blk_nodes.ravel().astype(np.int64)
+    cnt = (rowptr[rows + 1] - rowptr[rows]).astype(np.int64)
+    ptr = np.concatenate([[0], np.cumsum(cnt)])
+    idx = np.repeat(rowptr[rows].astype(np.int64) - ptr[:-1], cnt) + np.arange(ptr[-1])
+    di_rowptr, di_colidx = ptr.astype(np.int32), colidx[idx]
+    row_map = np.full(Vf.num_nodes, -1, dtype=np.int32)
+    row_map[rows] = np.arange(rows.shape[0], dtype=np.int32)
+    di_vals = _hostlib.assemble_bsr(Vf.cell_nodes, g, vol, tens, d, di_rowptr, di_colidx, gamma_full=1.0,
+                                    row_map=row_map)
+    T.D_I = BSR(rows.shape[0], Vf.num_nodes, d, di_rowptr, di_colidx, di_vals)
+    T.D_IT = T.D_I.transpose()
+    Pv = sp.kron(bary_prolongation(Vc, Vf), sp.identity(d, format="csr"), format="csr")
+    T.P = BSR.from_scipy(Pv, d)
+    T.PT = T.P.transpose()
+    T.PT_plain = T.PT
+    T.inject_map = None
+    T.nu, T.gamma = nu, gamma
+    T.n_f, T.n_c = Vf.num_dofs, Vc.num_dofs
+    T.bc_dofs_f, T.bc_dofs_c = Vf.bc_dofs, Vc.bc_dofs
+    T.skeleton_dofs = np.flatnonzero(np.repeat(macro_skeleton_mask(Vf), d))
+    return T
+
+
+def build_sv_hierarchy(problem, nref, k, Re, gamma=1e4, advect=True, patches=True):
+    """The Scott-Vogelius analogue of ``problem.build_hierarchy``: levels 0..nref on the bary hierarchy."""
+    dim = problem.dim
+    if k != 2:
+        raise NotImplementedError("element tables stop at degree 2 (the 3-D SV pair of config 5 needs P3)")
+    element = NodalElement(dim, k, False)
+    mh = [bary_refine(m) for m in mesh_hierarchy(problem.mesh(), nref)]
+    nu = problem.char_length() * problem.char_velocity() / Re if Re > 0 else problem.char_length() * problem.char_velocity()
+    adv = 1.0 if (advect and Re > 0) else 0.0
+    levels, transfers, Vprev = [], [], None
+    for l, mesh in enumerate(mh):
+        V = VectorFunctionSpace(mesh, element)
+        d = V.dim
+        L = LevelData()
+        L.V, L.level, L.n, L.bs = V, l, V.num_dofs, d
+        rowptr, colidx = _hostlib.node_graph(V.cell_nodes, V.num_nodes)
+        g, vol = mesh.cell_geometry()
+        tens = element.reference_tensors()
+        wind = problem.driver(V.node_coords)
+        A = _hostlib.assemble_bsr(V.cell_nodes, g, vol, tens, d, rowptr, colidx, nu=nu, adv=adv,
+                                  wind=wind if adv else None, gamma_full=gamma)
+        _hostlib.apply_bc_bsr(V.num_nodes, d, rowptr, colidx, A, np.repeat(V.bc_node_mask, d))
+        L.A = BSR(V.num_nodes, V.num_nodes, d, rowptr, colidx, A)
+        L.bc_dofs = V.bc_dofs
+        L.nu, L.gamma = nu, gamma
+        if patches and l > 0:
+            L.patch_ptr, L.patch_dofs = macro_star_patches(V)
+            L.patch_seeds = None
+        if l > 0:
+            transfers.append(build_sv_transfer_data(Vprev, V, nu, gamma, (rowptr, colidx)))
+        levels.append(L)
+        Vprev = V
+    return levels, transfers

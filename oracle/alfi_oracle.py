@@ -51,8 +51,10 @@ def star_patches_literal(V):
 # operator: independent quadrature-based assembly of the velocity-block form (alfi/solver.py:565-568 linearised;
 # alfi/transfer.py:319-324 for the symmetric transfer form)
 # ---------------------------------------------------------------------------------------------------------------------
-def assemble_form(V, nu=0.0, gamma=0.0, adv=0.0, wind=None, nq=6):
-    """CSR of nu (2 sym grad u, grad v) + gamma (cell_avg div u, div v) + adv ((w.grad)u + (u.grad)w, v), no BCs."""
+def assemble_form(V, nu=0.0, gamma=0.0, adv=0.0, wind=None, nq=6, gamma_full=0.0):
+    """CSR of nu (2 sym grad u, grad v) + gamma (cell_avg div u, div v) + gamma_full (div u, div v)
+    + adv ((w.grad)u + (u.grad)w, v), no BCs.  gamma: PkP0 forms (solver.py:565-568, transfer.py:319-332); gamma_full:
+    Scott-Vogelius forms (solver.py:609-619, transfer.py:295-309)."""
     from alfi_amd.elements import simplex_quadrature
     m, d, el = V.mesh, V.dim, V.element
     lam, wq = simplex_quadrature(d, nq)
@@ -70,6 +72,8 @@ def assemble_form(V, nu=0.0, gamma=0.0, adv=0.0, wind=None, nq=6):
     if gamma:
         bdiv = np.einsum("q,cqax->cax", wq, gradphi)                 # cell average of d_x phi_a
         Ae += gamma * vol[:, None, None, None, None] * np.einsum("cax,cby->caxby", bdiv, bdiv)
+    if gamma_full:
+        Ae += gamma_full * vol[:, None, None, None, None] * np.einsum("q,cqax,cqby->caxby", wq, gradphi, gradphi)
     if adv:
         wloc = wind[V.cell_nodes]                                    # (c, k, x)
         wq_ = np.einsum("qk,ckx->cqx", phi, wloc)                    # w at quadrature points
@@ -382,8 +386,13 @@ def oracle_transfer(T, L, schoeberl_restriction=False):
     from alfi_amd.fespace import skeleton_node_mask
     V = L.V
     K = assemble_form(V, nu=1.0)
-    D = assemble_form(V, gamma=1.0)
-    skel = np.flatnonzero(np.repeat(skeleton_node_mask(V), V.dim))
+    if getattr(T, "skeleton_dofs", None) is not None:
+        # Scott-Vogelius transfer on a bary hierarchy: full grad-div form, Dirichlet set = coarse MACRO facets
+        D = assemble_form(V, gamma_full=1.0)
+        skel = T.skeleton_dofs
+    else:
+        D = assemble_form(V, gamma=1.0)
+        skel = np.flatnonzero(np.repeat(skeleton_node_mask(V), V.dim))
     st = SchoeberlTransfer(T.P.to_scipy(), T.nu * K + T.gamma * D, T.gamma * D, T.blk_dofs, skel)
     return _TransferPair(st, T.PT_plain.to_scipy().tocsr(), schoeberl_restriction)
 

@@ -1,0 +1,72 @@
+"""Scott-Vogelius hierarchy on the GPU (-m gpu): macro-star patches (62 dofs) in the patch smoother, macro-cell blocks
+(38 dofs > 32: solved with the patch kernels) in the Schoeberl transfer, full grad-div operators -- same library entry
+points as PkP0.  Transfers, cycles and the gamma-robustness experiment against the oracle."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from alfi_amd.problem import TwoDimLidDrivenCavityProblem
+from alfi_amd.sv import build_sv_hierarchy
+from tests.test_graddiv import fgmres_solve
+from tests.test_sv import run as run_oracle
+
+
+def test_sv_transfers_and_cycles_match_oracle():
+    from alfi_amd import hip
+    from oracle import alfi_oracle as O
+    lv, tr = build_sv_hierarchy(TwoDimLidDrivenCavityProblem(2), 2, 2, Re=100.0, gamma=1e4)
+    ctx = hip.Context(0)
+    k = 3
+    rng = np.random.default_rng(0)
+    for robust in (True, False):
+        mg = hip.Multigrid(ctx, lv, tr, k, robust_restriction=robust)
+        omg = O.build_oracle_mg(lv, tr, k, schoeberl_restriction=robust)
+        for l in (1, 2):
+            uc = rng.standard_normal(lv[l - 1].n)
+            uc[lv[l - 1].bc_dofs] = 0
+            rf = rng.standard_normal(lv[l].n)
+            duc, dxf, drf, drc = ctx.vec(uc), ctx.vec(lv[l].n), ctx.vec(rf), ctx.vec(lv[l - 1].n)
+            mg.transfers[l - 1].prolong(duc, dxf)
+            ref = omg.prolong(l, uc)
+            assert np.abs(dxf.get() - ref).max() < 1e-7 * np.abs(ref).max()
+            mg.transfers[l - 1].restrict(drf, drc, robust=robust)
+            ref = omg.restrict(l, rf)
+            assert np.abs(drc.get() - ref).max() < 1e-7 * np.abs(ref).max()
+        L = lv[-1]
+        b = rng.standard_normal(L.n)
+        b[L.bc_dofs] = 0
+        db, dx = ctx.vec(b), ctx.vec(L.n)
+        mg.vcycle(db, dx)
+        ref = omg.vcycle(len(lv) - 1, b, np.zeros(L.n))
+        assert np.abs(dx.get() - ref).max() < 1e-5 * np.abs(ref).max()
+        mg.fcycle(db, dx)
+        ref = omg.fcycle(b)
+        assert np.abs(dx.get() - ref).max() < 1e-5 * np.abs(ref).max()
+        mg.close()
+    ctx.close()
+
+
+def test_sv_gamma_robustness_on_the_gpu():
+    from alfi_amd import hip
+    ctx = hip.Context(0)
+    its = {}
+    for gamma in (0.0, 1e2, 1e4, 1e6):
+        lv, tr = build_sv_hierarchy(TwoDimLidDrivenCavityProblem(2), 2, 2, Re=0, gamma=gamma, advect=False)
+        mg = hip.Multigrid(ctx, lv, tr, 3, robust_restriction=True)
+        L = lv[-1]
+        A = L.A.to_scipy().tocsr()
+        b = np.ones(L.n)
+        b[L.bc_dofs] = 0
+        dr, dz = ctx.vec(L.n), ctx.vec(L.n)
+
+        def M(r):
+            dr.set(r)
+            dz.zero()
+            mg.vcycle(dr, dz)
+            return dz.get()
+        its[gamma] = fgmres_solve(A, M, b)
+        mg.close()
+    assert max(its.values()) <= 12 and its[1e6] - its[1e2] <= 2, its
+    assert abs(its[1e4] - run_oracle(1e4, True)) <= 1
+    ctx.close()

@@ -1,0 +1,54 @@
+"""Scott-Vogelius side (towards BASELINE config 5): [P2]^d on Alfeld-split meshes with the full grad-div term, macro-star
+patches, the macro-cell Schoeberl transfer (alfi/solver.py:604-662, alfi/transfer.py:49-88, 293-309, alfi/bary.py).
+CPU: generator against the oracle's quadrature assembly, polynomial reproduction of the non-nested prolongation, and the
+reference's gamma-robustness experiment (examples/graddiv/graddiv.py with --discretisation sv) on the oracle."""
+import numpy as np
+import pytest
+
+from alfi_amd.problem import TwoDimLidDrivenCavityProblem
+from alfi_amd.sv import build_sv_hierarchy
+from oracle import alfi_oracle as O
+from tests.test_graddiv import fgmres_solve
+
+
+def test_sv_generator_against_quadrature_and_polynomials():
+    lv, tr = build_sv_hierarchy(TwoDimLidDrivenCavityProblem(2), 2, 2, Re=0, gamma=100.0, advect=False)
+    assert [L.n for L in lv] == [114, 418, 1602]
+    assert all(np.diff(L.patch_ptr).max() == 62 for L in lv[1:])           # interior macro vertex, literal MacroStar
+    assert tr[0].blk_dofs.shape == (8, 38) and tr[1].blk_dofs.shape == (32, 38)
+    L, T = lv[1], tr[0]
+    A = O.apply_bcs_matrix(O.assemble_form(L.V, nu=L.nu, gamma_full=100.0), L.bc_dofs)
+    assert abs(A - L.A.to_scipy()).max() < 1e-11
+    Ks, Ds = O.assemble_form(L.V, nu=1.0).tocsr(), O.assemble_form(L.V, gamma_full=1.0).tocsr()
+    for b in (0, 5):
+        d = T.blk_dofs[b]
+        assert np.abs(Ks[d][:, d].toarray() - T.K_II[b]).max() < 1e-12
+        assert np.abs(Ds[d][:, d].toarray() - T.D_II[b]).max() < 1e-12
+    assert abs(Ds[T.blk_dofs.ravel()] - T.D_I.to_scipy()).max() < 1e-12
+    # the blocks are the interiors of the coarse macro cells: disjoint, and together with the skeleton they cover everything
+    assert len(np.unique(T.blk_dofs)) == T.blk_dofs.size
+    assert len(np.unique(T.blk_dofs)) + len(T.skeleton_dofs) == L.n
+    # non-nested prolongation reproduces P2 exactly
+    def f(X):
+        return np.stack([X[:, 0] ** 2 - X[:, 1], X[:, 0] * X[:, 1] + 1.0], axis=1).ravel()
+    P = T.P.to_scipy()
+    assert np.abs(P @ f(lv[0].V.node_coords) - f(L.V.node_coords)).max() < 1e-13
+    # robust prolongation keeps a divergence-free coarse field (discretely) divergence-free up to O(nu / gamma)
+    ot = O.oracle_transfer(T, L, True).st
+    uc = np.stack([lv[0].V.node_coords[:, 1] ** 2, lv[0].V.node_coords[:, 0] ** 2], axis=1).ravel()   # div = 0, in P2
+    uf = ot.prolong(uc)
+    assert uf @ (Ds @ uf) < 1e-6 * (uf @ (Ks @ uf))
+
+
+def run(gamma, schoeberl):
+    lv, tr = build_sv_hierarchy(TwoDimLidDrivenCavityProblem(2), 2, 2, Re=0, gamma=gamma, advect=False)
+    mg = O.build_oracle_mg(lv, tr, k=3, schoeberl_restriction=schoeberl)
+    A = mg.levels[-1]["A"]
+    b = np.ones(A.shape[0])
+    b[lv[-1].bc_dofs] = 0
+    return fgmres_solve(A, lambda r: mg.vcycle(len(lv) - 1, r, np.zeros_like(r)), b)
+
+
+def test_sv_gamma_robustness():
+    its = {g: run(g, True) for g in (0.0, 1e2, 1e4, 1e6)}
+    assert max(its.values()) <= 12 and its[1e6] - its[1e2] <= 2, its
