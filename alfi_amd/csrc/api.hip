@@ -934,8 +934,6 @@ int alfi_transfer_create(alfi_ctx* ctx, alfi_level* coarse, alfi_level* fine, co
   if (coarse->bs != bs) return alfi_set_error(ctx, ALFI_E_ARG, "block size mismatch");
   if (m < 1 || m > SMALL_PATCH_MAX)
     return alfi_set_error(ctx, ALFI_E_ARG, "interior block size %d not in 1..%d", m, SMALL_PATCH_MAX);
-  if (m > 32 && (m & 1))
-    return alfi_set_error(ctx, ALFI_E_ARG, "interior blocks of more than 32 dofs must have an even size, got %d", m);
   // partitioned fine level: P and D_I^T hold the owned fine rows, P^T the owned fine columns (its rows are partial sums
   // over the local coarse numbering, reverse-added to their owners); serial: n_own == n
   if (P->nbrows * bs != fine->n_own || P->nbcols * bs != coarse->n || PT->nbrows * bs != coarse->n ||
@@ -974,7 +972,8 @@ int alfi_transfer_create(alfi_ctx* ctx, alfi_level* coarse, alfi_level* fine, co
   if (rc == 0) rc = dev_upload(ctx, &T->DII, D_II, nblk * m * m);
   if (m > 32) {
     // macro-cell blocks (Scott-Vogelius transfer, transfer.py:49-88): inverses in the row-piece layout, solved with the
-    // patch smoother's kernels; compact vectors keep stride m (= ld: m is even)
+    // patch smoother's kernels; compact vectors keep stride m, the kernels write row pairs with stride ld (for odd m the
+    // result passes through pm_tmp)
     T->patch_mode = true;
     T->bstride = ((int64_t)m * T->ld + 15) & ~(int64_t)15;
     std::vector<int64_t> ptr(nblk + 1), iptr(nblk + 1), sptr(nblk + 1);
@@ -990,6 +989,7 @@ int alfi_transfer_create(alfi_ctx* ctx, alfi_level* coarse, alfi_level* fine, co
     if (rc == 0) rc = dev_upload(ctx, &T->pm_stage_ptr, sptr.data(), nblk + 1);
     if (rc == 0) rc = dev_upload(ctx, &T->pm_iota, iota.data(), nblk * m);
     if (rc == 0) rc = dev_alloc(ctx, &T->binv, nblk * T->bstride);
+    if (rc == 0 && T->ld != m) rc = dev_alloc(ctx, &T->pm_tmp, nblk * T->ld);
   } else if (rc == 0) {
     rc = dev_alloc(ctx, &T->binv, nblk * m * T->ld);
   }
@@ -1021,6 +1021,7 @@ int alfi_transfer_destroy(alfi_transfer* T) {
   dev_free(T->pm_inv_ptr);
   dev_free(T->pm_stage_ptr);
   dev_free(T->pm_iota);
+  dev_free(T->pm_tmp);
   dev_free(T->tI);
   dev_free(T->bI);
   dev_free(T->tmp_f);

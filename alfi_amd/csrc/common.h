@@ -190,6 +190,7 @@ struct alfi_transfer {
   int64_t bstride = 0;                  // doubles between consecutive block inverses
   int64_t *pm_ptr = nullptr, *pm_inv_ptr = nullptr, *pm_stage_ptr = nullptr;   // (nblk+1) each
   int32_t* pm_iota = nullptr;           // (nblk*m) identity index list: compact input vectors
+  double* pm_tmp = nullptr;             // (nblk*ld) only for odd m: output of the patch kernel before compaction
   double *tI = nullptr, *bI = nullptr;  // compact interior vectors (nblk*m)
   double* tmp_f = nullptr;              // fine work vector
   int32_t* inj = nullptr;               // (coarse nodes) fine node coinciding with each coarse node

@@ -779,12 +779,25 @@ __global__ __launch_bounds__(256) void block_gemv_kernel(int64_t nblk, int m, in
   if (valid) out[blk * m + i] = acc;
 }
 
+__global__ void compact_rows_kernel(double* __restrict__ out, const double* __restrict__ in, int64_t total, int m,
+                                    int ld) {
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x)
+    out[e] = in[(e / m) * ld + e % m];
+}
+
 int launch_block_gemv(alfi_transfer* tr, const double* in, double* out, bool gather_in) {
   alfi_ctx* ctx = tr->ctx;
   if (tr->nblk == 0) return 0;
-  if (tr->patch_mode)
-    return launch_patch_apply_arrays(ctx, tr->nblk, tr->pm_ptr, gather_in ? tr->blk_dofs : tr->pm_iota, tr->pm_inv_ptr,
-                                     tr->pm_stage_ptr, tr->binv, in, out);
+  if (tr->patch_mode) {
+    double* dst = tr->pm_tmp ? tr->pm_tmp : out;
+    ALFI_CHECK(launch_patch_apply_arrays(ctx, tr->nblk, tr->pm_ptr, gather_in ? tr->blk_dofs : tr->pm_iota,
+                                         tr->pm_inv_ptr, tr->pm_stage_ptr, tr->binv, in, dst));
+    if (tr->pm_tmp) {   // odd m: rows were written with stride ld = m + 1
+      const int64_t total = tr->nblk * tr->m;
+      ALFI_LAUNCH_EW(compact_rows_kernel, total, out, tr->pm_tmp, total, tr->m, tr->ld);
+    }
+    return 0;
+  }
   const int m = tr->m;
   const int G = m <= 8 ? 8 : (m <= 16 ? 16 : 32);
   const int64_t threads = tr->nblk * G;

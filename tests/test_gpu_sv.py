@@ -12,17 +12,25 @@ from tests.test_graddiv import fgmres_solve
 from tests.test_sv import run as run_oracle
 
 
-def test_sv_transfers_and_cycles_match_oracle():
+@pytest.mark.parametrize("dim", [2, 3])
+def test_sv_transfers_and_cycles_match_oracle(dim):
+    """2-D: macro stars of 62 dofs, macro-cell blocks of 38.  3-D ([P2]^3: the smoother / transfer machinery, not an
+    inf-sup stable pair): macro stars of up to 513 dofs (blocked matrix-core inversion), macro-cell blocks of 123 (odd)."""
     from alfi_amd import hip
+    from alfi_amd.problem import ThreeDimLidDrivenCavityProblem
     from oracle import alfi_oracle as O
-    lv, tr = build_sv_hierarchy(TwoDimLidDrivenCavityProblem(2), 2, 2, Re=100.0, gamma=1e4)
+    if dim == 2:
+        lv, tr = build_sv_hierarchy(TwoDimLidDrivenCavityProblem(2), 2, 2, Re=100.0, gamma=1e4)
+    else:
+        lv, tr = build_sv_hierarchy(ThreeDimLidDrivenCavityProblem(1), 2, 2, Re=100.0, gamma=1e4)
+        assert tr[0].blk_dofs.shape[1] == 123 and max(np.diff(L.patch_ptr).max() for L in lv[1:]) > 160
     ctx = hip.Context(0)
     k = 3
     rng = np.random.default_rng(0)
     for robust in (True, False):
         mg = hip.Multigrid(ctx, lv, tr, k, robust_restriction=robust)
         omg = O.build_oracle_mg(lv, tr, k, schoeberl_restriction=robust)
-        for l in (1, 2):
+        for l in range(1, len(lv)):
             uc = rng.standard_normal(lv[l - 1].n)
             uc[lv[l - 1].bc_dofs] = 0
             rf = rng.standard_normal(lv[l].n)
