@@ -932,8 +932,8 @@ int alfi_transfer_create(alfi_ctx* ctx, alfi_level* coarse, alfi_level* fine, co
     return alfi_set_error(ctx, ALFI_E_ARG, "NULL argument");
   const int bs = fine->bs;
   if (coarse->bs != bs) return alfi_set_error(ctx, ALFI_E_ARG, "block size mismatch");
-  if (m < 1 || m > SMALL_PATCH_MAX)
-    return alfi_set_error(ctx, ALFI_E_ARG, "interior block size %d not in 1..%d", m, SMALL_PATCH_MAX);
+  if (m < 1 || m > PATCH_MAX)
+    return alfi_set_error(ctx, ALFI_E_ARG, "interior block size %d not in 1..%d", m, PATCH_MAX);
   // partitioned fine level: P and D_I^T hold the owned fine rows, P^T the owned fine columns (its rows are partial sums
   // over the local coarse numbering, reverse-added to their owners); serial: n_own == n
   if (P->nbrows * bs != fine->n_own || P->nbcols * bs != coarse->n || PT->nbrows * bs != coarse->n ||
@@ -990,6 +990,10 @@ int alfi_transfer_create(alfi_ctx* ctx, alfi_level* coarse, alfi_level* fine, co
     if (rc == 0) rc = dev_upload(ctx, &T->pm_iota, iota.data(), nblk * m);
     if (rc == 0) rc = dev_alloc(ctx, &T->binv, nblk * T->bstride);
     if (rc == 0 && T->ld != m) rc = dev_alloc(ctx, &T->pm_tmp, nblk * T->ld);
+    if (!(getenv("ALFI_TRANSFER_REFINE") && atoi(getenv("ALFI_TRANSFER_REFINE")) == 0)) {
+      if (rc == 0) rc = dev_alloc(ctx, &T->pm_res, nblk * m);
+      if (rc == 0) rc = dev_alloc(ctx, &T->pm_cor, nblk * m);
+    }
   } else if (rc == 0) {
     rc = dev_alloc(ctx, &T->binv, nblk * m * T->ld);
   }
@@ -1022,6 +1026,8 @@ int alfi_transfer_destroy(alfi_transfer* T) {
   dev_free(T->pm_stage_ptr);
   dev_free(T->pm_iota);
   dev_free(T->pm_tmp);
+  dev_free(T->pm_res);
+  dev_free(T->pm_cor);
   dev_free(T->tI);
   dev_free(T->bI);
   dev_free(T->tmp_f);

@@ -191,6 +191,8 @@ struct alfi_transfer {
   int64_t *pm_ptr = nullptr, *pm_inv_ptr = nullptr, *pm_stage_ptr = nullptr;   // (nblk+1) each
   int32_t* pm_iota = nullptr;           // (nblk*m) identity index list: compact input vectors
   double* pm_tmp = nullptr;             // (nblk*ld) only for odd m: output of the patch kernel before compaction
+  double* pm_res = nullptr;             // (nblk*m) residual b - A t of the refinement step (NULL: ALFI_TRANSFER_REFINE=0)
+  double* pm_cor = nullptr;             // (nblk*m) its correction X r
   double *tI = nullptr, *bI = nullptr;  // compact interior vectors (nblk*m)
   double* tmp_f = nullptr;              // fine work vector
   int32_t* inj = nullptr;               // (coarse nodes) fine node coinciding with each coarse node
@@ -243,6 +245,10 @@ int launch_patch_apply_arrays(alfi_ctx* ctx, int64_t npatch, const int64_t* patc
 int launch_patch_apply(alfi_level* lvl, const double* x, double* y);          // both stages, all patches
 int launch_patch_apply_range(alfi_level* lvl, int64_t p0, int64_t p1, const double* x);   // stage 1, patches [p0, p1)
 int launch_big_apply_range(alfi_level* lvl, int64_t p0, int64_t p1, const double* x);     // the same for levels with n_p > 160
+int launch_big_factor_transfer(alfi_transfer* tr);                                            // dense nu K + gamma D blocks, m > 160
+int launch_big_apply_arrays(alfi_ctx* ctx, int64_t npatch, const int64_t* patch_ptr, const int32_t* patch_dofs,
+                            const int64_t* inv_ptr, const int64_t* stage_ptr, const double* inv, const double* x,
+                            double* stage);
 int launch_big_factor(alfi_level* lvl);                                                    // gather + blocked MFMA inversion
 int launch_patch_sum(alfi_level* lvl, const double* x, double* y);             // stage 2
 int launch_patch_sum_range(alfi_level* lvl, int64_t i0, int64_t i1, const double* x, double* y);   // stage 2, dofs [i0, i1)

@@ -397,23 +397,73 @@ int launch_big_apply_range(alfi_level* L, int64_t p0, int64_t p1, const double* 
   return 0;
 }
 
-// gather + blocked inversion of all patches of the level, in batches bounded by the scratch budget
-int launch_big_factor(alfi_level* L) {
-  alfi_ctx* ctx = L->ctx;
-  if (L->npatch == 0) return 0;
+// nu K + gamma D of the interior blocks of a Schoeberl transfer (dense m x m inputs, transfer.py:186-232) into the scratch
+__global__ __launch_bounds__(256) void big_dense_fill_kernel(int64_t p0, int m, const double* __restrict__ K,
+                                                              const double* __restrict__ D, double nu, double gamma,
+                                                              const int64_t* __restrict__ scr_ptr, double* __restrict__ scr) {
+  const int64_t p = p0 + blockIdx.y;
+  const int N = (m + BIG_NB - 1) / BIG_NB * BIG_NB;
+  double* S = scr + scr_ptr[blockIdx.y];
+  const double* Kp = K + p * (int64_t)m * m;
+  const double* Dp = D + p * (int64_t)m * m;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < (int64_t)N * N; e += (int64_t)gridDim.x * 256) {
+    const int r = (int)(e / N), c = (int)(e % N);
+    S[e] = (r < m && c < m) ? nu * Kp[(int64_t)r * m + c] + gamma * Dp[(int64_t)r * m + c] : (r == c ? 1.0 : 0.0);
+  }
+}
+
+int launch_big_apply_arrays(alfi_ctx* ctx, int64_t npatch, const int64_t* patch_ptr, const int32_t* patch_dofs,
+                            const int64_t* inv_ptr, const int64_t* stage_ptr, const double* inv, const double* x,
+                            double* stage) {
+  if (npatch == 0) return 0;
+  static const bool nt = !(getenv("ALFI_NT") && atoi(getenv("ALFI_NT")) == 0);
+  dim3 grid((unsigned)npatch), block(256);
+  if (nt)
+    hipLaunchKernelGGL(big_apply_kernel<true>, grid, block, 0, ctx->stream, (int64_t)0, npatch, patch_ptr, patch_dofs,
+                       inv_ptr, stage_ptr, inv, x, stage);
+  else
+    hipLaunchKernelGGL(big_apply_kernel<false>, grid, block, 0, ctx->stream, (int64_t)0, npatch, patch_ptr, patch_dofs,
+                       inv_ptr, stage_ptr, inv, x, stage);
+  ALFI_HIP_CHECK(ctx, hipGetLastError());
+  return 0;
+}
+
+// Where the matrices of a batch come from: the level's operator (patch smoother) or the dense blocks of a transfer.
+struct BigSource {
+  alfi_level* L = nullptr;
+  alfi_transfer* T = nullptr;
+  void fill(alfi_ctx* ctx, int64_t p0, int64_t nb, const int64_t* d_scr_ptr, double* dst) const {
+    dim3 block(256);
+    if (T) {
+      hipLaunchKernelGGL(big_dense_fill_kernel, dim3(64, (unsigned)nb), block, 0, ctx->stream, p0, T->m, T->KII, T->DII,
+                         T->nu, T->gamma, d_scr_ptr, dst);
+    } else if (L->bs == 2) {
+      hipLaunchKernelGGL(big_gather_kernel<2>, dim3((unsigned)nb), block, 0, ctx->stream, p0, L->A.rowptr, L->A.colidx,
+                         L->A.vals, L->A.flat, L->patch_ptr, L->patch_dofs, d_scr_ptr, dst);
+    } else {
+      hipLaunchKernelGGL(big_gather_kernel<3>, dim3((unsigned)nb), block, 0, ctx->stream, p0, L->A.rowptr, L->A.colidx,
+                         L->A.vals, L->A.flat, L->patch_ptr, L->patch_dofs, d_scr_ptr, dst);
+    }
+  }
+};
+
+// fill + blocked inversion of npatch matrices, in batches bounded by the scratch budget
+static int big_factor_core(alfi_ctx* ctx, const BigSource& src, int64_t npatch, const int64_t* h_patch_ptr,
+                           const int64_t* d_patch_ptr, const int64_t* d_inv_ptr, double* inv, int* status) {
+  if (npatch == 0) return 0;
   const int64_t budget = (int64_t)6 << 30;          // bytes of scratch (matrices + panels) per batch
   const char* env = getenv("ALFI_BIG_SCRATCH_MB");
   const int64_t limit = env ? (int64_t)atoll(env) << 20 : budget;
   const bool polish = !(getenv("ALFI_BIG_POLISH") && atoi(getenv("ALFI_BIG_POLISH")) == 0);
   const int64_t nscr = polish ? 3 : 1;            // X | a second copy of A_p | I - A X
   int64_t p0 = 0;
-  while (p0 < L->npatch) {
+  while (p0 < npatch) {
     // batch [p0, p1)
     std::vector<int64_t> scr_ptr, pan_ptr;
     int64_t sdoubles = 0, pdoubles = 0, p1 = p0;
     int Nmax = 0;
-    while (p1 < L->npatch) {
-      const int n = (int)(L->h_patch_ptr[p1 + 1] - L->h_patch_ptr[p1]);
+    while (p1 < npatch) {
+      const int n = (int)(h_patch_ptr[p1 + 1] - h_patch_ptr[p1]);
       const int N = (n + BIG_NB - 1) / BIG_NB * BIG_NB;
       const int64_t need = ((int64_t)nscr * N * N + 2 * (int64_t)N * BIG_NB) * 8;
       if (p1 > p0 && (nscr * sdoubles + 2 * pdoubles) * 8 + need > limit) break;
@@ -438,36 +488,26 @@ int launch_big_factor(alfi_level* L) {
     if (e == hipSuccess) e = hipMemcpyAsync(d_pan_ptr, pan_ptr.data(), (size_t)nb * 8, hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess) {
       dim3 block(256);
-      if (L->bs == 2)
-        hipLaunchKernelGGL(big_gather_kernel<2>, dim3((unsigned)nb), block, 0, ctx->stream, p0, L->A.rowptr, L->A.colidx,
-                           L->A.vals, L->A.flat, L->patch_ptr, L->patch_dofs, d_scr_ptr, scr);
-      else
-        hipLaunchKernelGGL(big_gather_kernel<3>, dim3((unsigned)nb), block, 0, ctx->stream, p0, L->A.rowptr, L->A.colidx,
-                           L->A.vals, L->A.flat, L->patch_ptr, L->patch_dofs, d_scr_ptr, scr);
+      src.fill(ctx, p0, nb, d_scr_ptr, scr);
       const int tiles = Nmax / BIG_NB;
       for (int k0 = 0; k0 < Nmax; k0 += BIG_NB) {
-        hipLaunchKernelGGL(big_panel_kernel, dim3((unsigned)nb), block, 0, ctx->stream, k0, L->patch_ptr, p0, d_scr_ptr, scr,
-                           d_pan_ptr, panF, panR, L->status);
+        hipLaunchKernelGGL(big_panel_kernel, dim3((unsigned)nb), block, 0, ctx->stream, k0, d_patch_ptr, p0, d_scr_ptr, scr,
+                           d_pan_ptr, panF, panR, status);
         hipLaunchKernelGGL(big_update_kernel, dim3((unsigned)(tiles * tiles), (unsigned)nb), block, 0, ctx->stream, k0,
-                           L->patch_ptr, p0, d_scr_ptr, scr, d_pan_ptr, panF, panR, tiles);
+                           d_patch_ptr, p0, d_scr_ptr, scr, d_pan_ptr, panF, panR, tiles);
       }
       const double* result = scr;
       if (polish) {
         // A_p once more (the inversion overwrote its copy), R = I - A X, X <- X + X R (into the buffer that held A_p)
-        if (L->bs == 2)
-          hipLaunchKernelGGL(big_gather_kernel<2>, dim3((unsigned)nb), block, 0, ctx->stream, p0, L->A.rowptr, L->A.colidx,
-                             L->A.vals, L->A.flat, L->patch_ptr, L->patch_dofs, d_scr_ptr, scrA);
-        else
-          hipLaunchKernelGGL(big_gather_kernel<3>, dim3((unsigned)nb), block, 0, ctx->stream, p0, L->A.rowptr, L->A.colidx,
-                             L->A.vals, L->A.flat, L->patch_ptr, L->patch_dofs, d_scr_ptr, scrA);
+        src.fill(ctx, p0, nb, d_scr_ptr, scrA);
         hipLaunchKernelGGL(big_gemm_kernel, dim3((unsigned)(tiles * tiles), (unsigned)nb), block, 0, ctx->stream, 0,
-                           L->patch_ptr, p0, d_scr_ptr, scrA, scr, scrR, tiles);
+                           d_patch_ptr, p0, d_scr_ptr, scrA, scr, scrR, tiles);
         hipLaunchKernelGGL(big_gemm_kernel, dim3((unsigned)(tiles * tiles), (unsigned)nb), block, 0, ctx->stream, 1,
-                           L->patch_ptr, p0, d_scr_ptr, scr, scrR, scrA, tiles);
+                           d_patch_ptr, p0, d_scr_ptr, scr, scrR, scrA, tiles);
         result = scrA;
       }
-      hipLaunchKernelGGL(big_store_kernel, dim3(64, (unsigned)nb), block, 0, ctx->stream, p0, L->patch_ptr, L->inv_ptr,
-                         d_scr_ptr, result, L->inv);
+      hipLaunchKernelGGL(big_store_kernel, dim3(64, (unsigned)nb), block, 0, ctx->stream, p0, d_patch_ptr, d_inv_ptr,
+                         d_scr_ptr, result, inv);
       e = hipGetLastError();
       if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     }
@@ -478,8 +518,23 @@ int launch_big_factor(alfi_level* L) {
     (void)hipFree(panR);
     (void)hipFree(d_scr_ptr);
     (void)hipFree(d_pan_ptr);
-    if (e != hipSuccess) return alfi_set_error(ctx, ALFI_E_HIP, "large-patch factorisation failed: %s", hipGetErrorString(e));
+    if (e != hipSuccess) return alfi_set_error(ctx, ALFI_E_HIP, "large-block factorisation failed: %s", hipGetErrorString(e));
     p0 = p1;
   }
   return 0;
+}
+
+int launch_big_factor(alfi_level* L) {
+  BigSource src;
+  src.L = L;
+  return big_factor_core(L->ctx, src, L->npatch, L->h_patch_ptr.data(), L->patch_ptr, L->inv_ptr, L->inv, L->status);
+}
+
+// interior blocks of a transfer with 160 < m <= 2048 (macro-cell blocks of the 3-D Scott-Vogelius transfer, m = 390 for P3)
+int launch_big_factor_transfer(alfi_transfer* T) {
+  BigSource src;
+  src.T = T;
+  std::vector<int64_t> hptr(T->nblk + 1);
+  for (int64_t b = 0; b <= T->nblk; ++b) hptr[b] = b * T->m;
+  return big_factor_core(T->ctx, src, T->nblk, hptr.data(), T->pm_ptr, T->pm_inv_ptr, T->binv, T->status);
 }

@@ -748,6 +748,7 @@ __global__ void block_build_kernel(int64_t nblk, int m, int ld, int64_t stride, 
 
 int launch_block_build_invert(alfi_transfer* tr) {
   alfi_ctx* ctx = tr->ctx;
+  if (tr->m > SMALL_PATCH_MAX) return launch_big_factor_transfer(tr);   // blocked MFMA inversion (kernels_bigpatch.hip)
   const int64_t total = tr->nblk * tr->m * tr->ld;
   const int64_t stride = tr->patch_mode ? tr->bstride : (int64_t)tr->m * tr->ld;
   ALFI_LAUNCH_EW(block_build_kernel, total, tr->nblk, tr->m, tr->ld, stride, tr->KII, tr->DII, tr->nu, tr->gamma,
@@ -785,16 +786,58 @@ __global__ void compact_rows_kernel(double* __restrict__ out, const double* __re
     out[e] = in[(e / m) * ld + e % m];
 }
 
+// r = b - (nu K + gamma D) t per interior block (one workgroup per block, t in LDS, a wave per row).  One step of
+// iterative refinement around the explicit inverse: the reference solves these blocks by LU (patch_sub_pc_type lu,
+// transfer.py:100-113), and nu K + gamma D of a macro cell has condition number ~gamma / nu, which an explicit inverse
+// alone turns into a relative error of cond * eps in the transferred vector.
+__global__ __launch_bounds__(256) void block_residual_kernel(int m, const double* __restrict__ K, const double* __restrict__ D,
+                                                              double nu, double gamma, const int32_t* __restrict__ idx,
+                                                              const double* __restrict__ in, const double* __restrict__ t,
+                                                              double* __restrict__ r) {
+  __shared__ double ts[PATCH_MAX];
+  const int64_t blk = blockIdx.x;
+  for (int i = threadIdx.x; i < m; i += 256) ts[i] = t[blk * m + i];
+  __syncthreads();
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const double* Kb = K + blk * (int64_t)m * m;
+  const double* Db = D + blk * (int64_t)m * m;
+  for (int row = wave; row < m; row += 4) {
+    double acc = 0.0;
+    for (int j = lane; j < m; j += 64)
+      acc = __builtin_fma(nu * Kb[(int64_t)row * m + j] + gamma * Db[(int64_t)row * m + j], ts[j], acc);
+    acc = wave_sum(acc);
+    if (lane == 0) r[blk * m + row] = in[idx[blk * m + row]] - acc;
+  }
+}
+
+// out (compact, stride m) = X in[idx] with the row-piece inverses of a patch-mode transfer
+static int pm_apply(alfi_transfer* tr, const int32_t* idx, const double* in, double* out) {
+  alfi_ctx* ctx = tr->ctx;
+  double* dst = tr->pm_tmp ? tr->pm_tmp : out;
+  if (tr->m > SMALL_PATCH_MAX)
+    ALFI_CHECK(launch_big_apply_arrays(ctx, tr->nblk, tr->pm_ptr, idx, tr->pm_inv_ptr, tr->pm_stage_ptr, tr->binv, in, dst));
+  else
+    ALFI_CHECK(launch_patch_apply_arrays(ctx, tr->nblk, tr->pm_ptr, idx, tr->pm_inv_ptr, tr->pm_stage_ptr, tr->binv, in,
+                                         dst));
+  if (tr->pm_tmp) {   // odd m: rows were written with stride ld = m + 1
+    const int64_t total = tr->nblk * tr->m;
+    ALFI_LAUNCH_EW(compact_rows_kernel, total, out, tr->pm_tmp, total, tr->m, tr->ld);
+  }
+  return 0;
+}
+
 int launch_block_gemv(alfi_transfer* tr, const double* in, double* out, bool gather_in) {
   alfi_ctx* ctx = tr->ctx;
   if (tr->nblk == 0) return 0;
   if (tr->patch_mode) {
-    double* dst = tr->pm_tmp ? tr->pm_tmp : out;
-    ALFI_CHECK(launch_patch_apply_arrays(ctx, tr->nblk, tr->pm_ptr, gather_in ? tr->blk_dofs : tr->pm_iota,
-                                         tr->pm_inv_ptr, tr->pm_stage_ptr, tr->binv, in, dst));
-    if (tr->pm_tmp) {   // odd m: rows were written with stride ld = m + 1
-      const int64_t total = tr->nblk * tr->m;
-      ALFI_LAUNCH_EW(compact_rows_kernel, total, out, tr->pm_tmp, total, tr->m, tr->ld);
+    const int32_t* idx = gather_in ? tr->blk_dofs : tr->pm_iota;
+    ALFI_CHECK(pm_apply(tr, idx, in, out));
+    if (tr->pm_res) {   // t += X (b - A t)
+      hipLaunchKernelGGL(block_residual_kernel, dim3((unsigned)tr->nblk), dim3(256), 0, ctx->stream, tr->m, tr->KII,
+                         tr->DII, tr->nu, tr->gamma, idx, in, out, tr->pm_res);
+      ALFI_HIP_CHECK(ctx, hipGetLastError());
+      ALFI_CHECK(pm_apply(tr, tr->pm_iota, tr->pm_res, tr->pm_cor));
+      ALFI_CHECK(launch_axpy(ctx, out, tr->pm_cor, 1.0, tr->nblk * tr->m));
     }
     return 0;
   }

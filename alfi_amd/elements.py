@@ -50,32 +50,38 @@ class NodalElement(object):
     bubble.py:86)."""
 
     def __init__(self, dim, degree, bubble):
-        assert dim in (2, 3) and degree in (1, 2)
+        assert dim in (2, 3) and degree in (1, 2, 3)
         if bubble:
             assert dim == 3, "FacetBubble enrichment is only needed for k < tdim in 3-D here"
+        if degree == 3:
+            # the velocity element of the reference's 3-D Scott-Vogelius pair (solver.py:625-630, config 5): 4 vertex,
+            # 12 edge (two per edge, at 1/3 and 2/3) and 4 face nodes; no cell-interior node in 3-D
+            assert dim == 3 and not bubble, "P3 is provided for tetrahedra (the 2-D pairs of the reference use k = 2)"
         self.dim, self.degree, self.bubble = dim, degree, bubble
         self.name = "P%d%s" % (degree, "+FB" if bubble else "")
         nv = dim + 1
         self.local_edges = TRI_EDGES if dim == 2 else TET_EDGES
-        ent = [(0, i) for i in range(nv)]
+        self.nodes_per_edge = {1: 0, 2: 1, 3: 2}[degree]
+        ent = [(0, i, 0) for i in range(nv)]
         bary = [np.eye(nv)[i] for i in range(nv)]
-        if degree == 2:
-            for j, (a, b) in enumerate(self.local_edges):
-                ent.append((1, j))
+        for j, (a, b) in enumerate(self.local_edges):
+            for sub in range(self.nodes_per_edge):
+                ent.append((1, j, sub))             # sub counts from local vertex a towards b
                 p = np.zeros(nv)
-                p[a] = p[b] = 0.5
+                t = (sub + 1.0) / (self.nodes_per_edge + 1.0)
+                p[a], p[b] = 1.0 - t, t
                 bary.append(p)
-        if bubble:
+        if bubble or degree == 3:
             for i in range(4):
-                ent.append((2, i))
+                ent.append((2, i, 0))
                 p = np.full(4, 1.0 / 3.0)
                 p[i] = 0.0
                 bary.append(p)
-        self.entity_nodes = ent                     # (entity dim, local entity number) per local node
+        self.entity_nodes = ent                     # (entity dim, local entity number, sub-index on the entity) per node
         self.node_bary = np.array(bary)             # (nloc, dim+1)
         self.nloc = len(ent)
-        self.has_edge_nodes = degree == 2
-        self.has_face_nodes = bubble
+        self.has_edge_nodes = degree >= 2
+        self.has_face_nodes = bubble or degree == 3
         if bubble:
             fb = self.node_bary[-4:]
             phi, _ = self._primal(fb)               # (4 faces, nprimal)
@@ -84,6 +90,8 @@ class NodalElement(object):
     # plain Lagrange part --------------------------------------------------------------------------------------
     def _primal(self, lam):
         npts, nv = lam.shape
+        if self.degree == 3:
+            return self._p3(lam)
         if self.degree == 1:
             phi = lam.copy()
             dphi = np.broadcast_to(np.eye(nv), (npts, nv, nv)).copy()
@@ -98,6 +106,32 @@ class NodalElement(object):
             phi[:, nv + j] = 4 * lam[:, a] * lam[:, b]
             dphi[:, nv + j, a] = 4 * lam[:, b]
             dphi[:, nv + j, b] = 4 * lam[:, a]
+        return phi, dphi
+
+    def _p3(self, lam):
+        """Cubic Lagrange basis on equispaced nodes: vertices 1/2 l (3l - 1)(3l - 2); edge (a, b) node nearer a:
+        9/2 la lb (3 la - 1), nearer b: 9/2 la lb (3 lb - 1); face (i, j, k): 27 li lj lk."""
+        npts, nv = lam.shape
+        ne = self.local_edges.shape[0]
+        n = nv + 2 * ne + 4
+        phi = np.empty((npts, n))
+        dphi = np.zeros((npts, n, nv))
+        for i in range(nv):
+            l = lam[:, i]
+            phi[:, i] = 0.5 * l * (3 * l - 1) * (3 * l - 2)
+            dphi[:, i, i] = 0.5 * (27 * l * l - 18 * l + 2)
+        for j, (a, b) in enumerate(self.local_edges):
+            la, lb = lam[:, a], lam[:, b]
+            k0, k1 = nv + 2 * j, nv + 2 * j + 1
+            phi[:, k0] = 4.5 * la * lb * (3 * la - 1)
+            dphi[:, k0, a] = 4.5 * lb * (6 * la - 1)
+            dphi[:, k0, b] = 4.5 * la * (3 * la - 1)
+            phi[:, k1] = 4.5 * la * lb * (3 * lb - 1)
+            dphi[:, k1, a] = 4.5 * lb * (3 * lb - 1)
+            dphi[:, k1, b] = 4.5 * la * (6 * lb - 1)
+        beta, dbeta = self._bubbles(lam)
+        phi[:, nv + 2 * ne:] = beta
+        dphi[:, nv + 2 * ne:, :] = dbeta
         return phi, dphi
 
     @staticmethod

@@ -58,12 +58,17 @@ class VectorFunctionSpace(object):
         self.mesh, self.element = mesh, element
         self.dim = mesh.dim
         nv, ne, nf = mesh.num_vertices, mesh.num_edges, mesh.num_faces
-        sizes = [nv, ne if element.has_edge_nodes else 0, nf if element.has_face_nodes else 0]
+        npe = getattr(element, "nodes_per_edge", 1 if element.has_edge_nodes else 0)
+        self.nodes_per_edge = npe
+        sizes = [nv, ne * npe, nf if element.has_face_nodes else 0]
         self.raw_offsets = np.concatenate([[0], np.cumsum(sizes)])
         self.num_nodes = int(self.raw_offsets[-1])
         pos = [mesh.coords]
         if element.has_edge_nodes:
-            pos.append(mesh.coords[mesh.edges].mean(axis=1))
+            # node s of a global edge (v0 < v1) sits at v0 + (s + 1) / (npe + 1) (v1 - v0); raw number edge * npe + s
+            x0, x1 = mesh.coords[mesh.edges[:, 0]], mesh.coords[mesh.edges[:, 1]]
+            t = (np.arange(npe) + 1.0) / (npe + 1.0)
+            pos.append((x0[:, None, :] + t[None, :, None] * (x1 - x0)[:, None, :]).reshape(-1, mesh.dim))
         if element.has_face_nodes:
             pos.append(mesh.coords[mesh.faces].mean(axis=1))
         pos = np.concatenate(pos)
@@ -77,22 +82,30 @@ class VectorFunctionSpace(object):
             self.node_coords = pos
         # cell -> node map
         cols = []
-        for (edim, loc) in element.entity_nodes:
+        for (edim, loc, sub) in element.entity_nodes:
             if edim == 0:
                 cols.append(mesh.cells[:, loc])
             elif edim == 1:
-                cols.append(self.raw_offsets[1] + mesh.cell_edges[:, loc])
+                # the element counts sub from local vertex a to b, the space from the smaller to the larger global vertex
+                a, b = element.local_edges[loc]
+                same = mesh.cells[:, a] < mesh.cells[:, b]
+                s_glob = np.where(same, sub, npe - 1 - sub)
+                cols.append(self.raw_offsets[1] + mesh.cell_edges[:, loc].astype(np.int64) * npe + s_glob)
             else:
                 cols.append(self.raw_offsets[2] + mesh.cell_faces[:, loc])
         self.cell_nodes = np.ascontiguousarray(self.raw2new[np.stack(cols, axis=1)], dtype=np.int32)
         self.vertex_nodes = self.raw2new[:nv]
-        self.edge_nodes = self.raw2new[self.raw_offsets[1]:self.raw_offsets[2]] if element.has_edge_nodes else None
+        # edge_nodes: (ne,) for one node per edge, (ne, npe) otherwise
+        self.edge_nodes = None
+        if element.has_edge_nodes:
+            en = self.raw2new[self.raw_offsets[1]:self.raw_offsets[2]]
+            self.edge_nodes = en if npe == 1 else en.reshape(ne, npe)
         self.face_nodes = self.raw2new[self.raw_offsets[2]:self.raw_offsets[3]] if element.has_face_nodes else None
         # all-Dirichlet boundary (ldc2d.py:22-25, ldc3d.py:17-20)
         vm, em, fm = mesh.boundary_entities()
         bc = [self.vertex_nodes[vm]]
         if element.has_edge_nodes:
-            bc.append(self.edge_nodes[em])
+            bc.append(np.asarray(self.edge_nodes[em]).ravel())
         if element.has_face_nodes:
             bc.append(self.face_nodes[fm])
         self.bc_nodes = np.unique(np.concatenate(bc)).astype(np.int32)
@@ -121,9 +134,11 @@ class VectorFunctionSpace(object):
         nv = m.num_vertices
         seed, node = [np.arange(nv, dtype=np.int64)], [self.vertex_nodes.astype(np.int64)]
         if self.element.has_edge_nodes:
+            en = np.asarray(self.edge_nodes, dtype=np.int64).reshape(m.num_edges, -1)
             for j in range(2):
-                seed.append(m.edges[:, j].astype(np.int64))
-                node.append(self.edge_nodes.astype(np.int64))
+                for s_ in range(en.shape[1]):
+                    seed.append(m.edges[:, j].astype(np.int64))
+                    node.append(en[:, s_])
         if self.element.has_face_nodes:
             for j in range(3):
                 seed.append(m.faces[:, j].astype(np.int64))

@@ -270,7 +270,7 @@ def patch_points_to_dofs(V, dm, patches):
             if dm.vStart <= p < dm.eStart:
                 nodes.append(int(V.vertex_nodes[p - dm.vStart]))
             elif dm.eStart <= p < dm.fStart and V.element.has_edge_nodes:
-                nodes.append(int(V.edge_nodes[p - dm.eStart]))
+                nodes.extend(int(q) for q in np.atleast_1d(V.edge_nodes[p - dm.eStart]))
             elif p >= dm.fStart and V.element.has_face_nodes:
                 nodes.append(int(V.face_nodes[p - dm.fStart]))
         nodes = sorted(n for n in set(nodes) if not V.bc_node_mask[n])

@@ -8,8 +8,8 @@ the levels are not nested, only their macro meshes are), ``SVSchoeberlTransfer``
 ``prolong`` as the standard transfer (transfer.py:284-290).
 
 Everything here is host-side input generation (the role Firedrake plays for the reference); the arithmetic of smoother,
-transfers and cycles is the same libalfi_hip.so entry points as for the PkP0 discretisation.  Implemented for k = 2 (the
-element tables of ``elements.NodalElement`` stop at degree 2; the inf-sup stable 3-D pair needs k = 3).
+transfers and cycles is the same libalfi_hip.so entry points as for the PkP0 discretisation.  Implemented for k = 2 and,
+in 3-D, k = 3 (the inf-sup stable pair of config 5: macro stars of up to ~1600 dofs, macro-cell transfer blocks of 390).
 """
 import numpy as np
 import scipy.sparse as sp
@@ -172,8 +172,8 @@ def build_sv_transfer_data(Vc, Vf, nu, gamma, graph):
 def build_sv_hierarchy(problem, nref, k, Re, gamma=1e4, advect=True, patches=True):
     """The Scott-Vogelius analogue of ``problem.build_hierarchy``: levels 0..nref on the bary hierarchy."""
     dim = problem.dim
-    if k != 2:
-        raise NotImplementedError("element tables stop at degree 2 (the 3-D SV pair of config 5 needs P3)")
+    if k not in (2, 3) or (k == 3 and dim != 3):
+        raise NotImplementedError("Scott-Vogelius velocities: [P2]^d, and [P3]^3 (the inf-sup stable 3-D pair of config 5)")
     element = NodalElement(dim, k, False)
     mh = [bary_refine(m) for m in mesh_hierarchy(problem.mesh(), nref)]
     nu = problem.char_length() * problem.char_velocity() / Re if Re > 0 else problem.char_length() * problem.char_velocity()

@@ -164,8 +164,9 @@ typedef struct {
 /* P: standard prolongation (fine x coarse; bubble-corrected for 3-D P1+FB, transfer.py:334-356), PT its transpose,
  * PT_plain: transpose of the plain nodal interpolation used when restriction is not robust (solver.py:595; may be
  * NULL = same as PT).  D_I: rows of the cell-averaged grad-div matrix (gamma = 1) for the coarse-cell interior dofs
- * in block order; D_IT its transpose.  blk_dofs: (nblk, m) interior dofs per coarse cell (transfer.py:13-46; m <= 160: beyond 32 -- the coarse
- * MACRO cells of the Scott-Vogelius transfer, transfer.py:49-88 -- the blocks are solved with the patch kernels);
+ * in block order; D_IT its transpose.  blk_dofs: (nblk, m) interior dofs per coarse cell (transfer.py:13-46; m <= 2048: beyond 32 -- the coarse
+ * MACRO cells of the Scott-Vogelius transfer, transfer.py:49-88 -- the blocks are solved with the patch kernels, beyond
+ * 160 with the large-patch ones);
  * K_II, D_II: (nblk, m, m) dense interior blocks of (2 sym grad u, grad v) and (cell_avg div u, div v). */
 int alfi_transfer_create(alfi_ctx* ctx, alfi_level* coarse, alfi_level* fine, const alfi_bsr_host* P,
                          const alfi_bsr_host* PT, const alfi_bsr_host* PT_plain, const alfi_bsr_host* D_I,

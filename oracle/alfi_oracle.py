@@ -12,6 +12,7 @@ Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import 
 (alfi_amd/) never does.
 """
 import numpy as np
+import scipy.linalg
 import scipy.sparse as sp
 import scipy.sparse.linalg as spla
 
@@ -38,7 +39,7 @@ def star_patches_literal(V):
     for v in range(m.num_vertices):
         nodes = [int(V.vertex_nodes[v])]
         if V.element.has_edge_nodes:
-            nodes += [int(V.edge_nodes[e]) for e in edges_of_v[v]]
+            nodes += [int(q) for e in edges_of_v[v] for q in np.atleast_1d(V.edge_nodes[e])]
         if V.element.has_face_nodes:
             nodes += [int(V.face_nodes[f]) for f in faces_of_v[v]]
         nodes = sorted(n for n in set(nodes) if not V.bc_node_mask[n])
@@ -228,13 +229,13 @@ class SchoeberlTransfer(object):
         self.blk_dofs, self.skel = blk_dofs, skeleton_dofs
         A = sp.csr_matrix(A_sym)
         # patch_sub_pc_type lu on each coarse-cell patch (transfer.py:100-113)
-        self.lu = [np.linalg.inv(A[d][:, d].toarray()) for d in blk_dofs]
+        self.lu = [scipy.linalg.lu_factor(A[d][:, d].toarray()) for d in blk_dofs]
 
     def _patch_apply(self, x):
         """PatchPC.apply with the coarse-cell patches: additive, disjoint; y[bc] = x[bc]."""
         y = np.zeros_like(x)
-        for d, Ainv in zip(self.blk_dofs, self.lu):
-            y[d] = Ainv @ x[d]
+        for d, lu in zip(self.blk_dofs, self.lu):
+            y[d] = scipy.linalg.lu_solve(lu, x[d])
         y[self.skel] = x[self.skel]
         return y
 

@@ -12,18 +12,23 @@ from tests.test_graddiv import fgmres_solve
 from tests.test_sv import run as run_oracle
 
 
-@pytest.mark.parametrize("dim", [2, 3])
-def test_sv_transfers_and_cycles_match_oracle(dim):
-    """2-D: macro stars of 62 dofs, macro-cell blocks of 38.  3-D ([P2]^3: the smoother / transfer machinery, not an
-    inf-sup stable pair): macro stars of up to 513 dofs (blocked matrix-core inversion), macro-cell blocks of 123 (odd)."""
+@pytest.mark.parametrize("case", ["2d-p2", "3d-p2", "3d-p3"])
+def test_sv_transfers_and_cycles_match_oracle(case):
+    """2-D: macro stars of 62 dofs, macro-cell blocks of 38.  3-D [P2]^3 (the smoother / transfer machinery, not an
+    inf-sup stable pair): macro stars of up to 513 dofs (blocked matrix-core inversion), macro-cell blocks of 123 (odd).
+    3-D [P3]^3 (the velocity space of BASELINE config 5): macro stars of up to 1599 dofs, macro-cell blocks of 390 --
+    both through the blocked matrix-core inversion and the workgroup-per-patch apply."""
     from alfi_amd import hip
     from alfi_amd.problem import ThreeDimLidDrivenCavityProblem
     from oracle import alfi_oracle as O
-    if dim == 2:
+    if case == "2d-p2":
         lv, tr = build_sv_hierarchy(TwoDimLidDrivenCavityProblem(2), 2, 2, Re=100.0, gamma=1e4)
-    else:
+    elif case == "3d-p2":
         lv, tr = build_sv_hierarchy(ThreeDimLidDrivenCavityProblem(1), 2, 2, Re=100.0, gamma=1e4)
         assert tr[0].blk_dofs.shape[1] == 123 and max(np.diff(L.patch_ptr).max() for L in lv[1:]) > 160
+    else:
+        lv, tr = build_sv_hierarchy(ThreeDimLidDrivenCavityProblem(1), 1, 3, Re=100.0, gamma=1e4)
+        assert tr[0].blk_dofs.shape[1] == 390 and np.diff(lv[1].patch_ptr).max() == 1599
     ctx = hip.Context(0)
     k = 3
     rng = np.random.default_rng(0)

@@ -40,6 +40,31 @@ def test_sv_generator_against_quadrature_and_polynomials():
     assert uf @ (Ds @ uf) < 1e-6 * (uf @ (Ks @ uf))
 
 
+def test_sv_p3_generator_3d():
+    """[P3]^3 on Alfeld-split tetrahedra, the velocity space of BASELINE config 5 (solver.py:604-662 with k = 3)."""
+    from alfi_amd.problem import ThreeDimLidDrivenCavityProblem
+    lv, tr = build_sv_hierarchy(ThreeDimLidDrivenCavityProblem(1), 1, 3, Re=0, gamma=100.0, advect=False)
+    assert [L.n for L in lv] == [462, 3189]
+    L, T = lv[1], tr[0]
+    assert np.diff(L.patch_ptr).max() == 1599 and T.blk_dofs.shape == (6, 390)
+    A = O.apply_bcs_matrix(O.assemble_form(L.V, nu=L.nu, gamma_full=100.0), L.bc_dofs)
+    assert abs(A - L.A.to_scipy()).max() < 1e-10
+    Ks, Ds = O.assemble_form(L.V, nu=1.0).tocsr(), O.assemble_form(L.V, gamma_full=1.0).tocsr()
+    d = T.blk_dofs[3]
+    assert np.abs(Ks[d][:, d].toarray() - T.K_II[3]).max() < 1e-12
+    assert np.abs(Ds[d][:, d].toarray() - T.D_II[3]).max() < 1e-12
+
+    def f(X):
+        return np.stack([X[:, 0] ** 3 - X[:, 1] * X[:, 2], X[:, 0] * X[:, 1] ** 2 + 1.0, X[:, 2] ** 3 - X[:, 0]], axis=1).ravel()
+    P = T.P.to_scipy()
+    assert np.abs(P @ f(lv[0].V.node_coords) - f(L.V.node_coords)).max() < 1e-12
+    ot = O.oracle_transfer(T, L, True).st
+    X = lv[0].V.node_coords
+    uc = np.stack([X[:, 1] ** 3, X[:, 2] ** 3, X[:, 0] ** 3], axis=1).ravel()             # div = 0, in P3
+    uf = ot.prolong(uc)
+    assert abs(uf @ (Ds @ uf)) < 1e-8 * (uf @ (Ks @ uf))
+
+
 def run(gamma, schoeberl):
     lv, tr = build_sv_hierarchy(TwoDimLidDrivenCavityProblem(2), 2, 2, Re=0, gamma=gamma, advect=False)
     mg = O.build_oracle_mg(lv, tr, k=3, schoeberl_restriction=schoeberl)
