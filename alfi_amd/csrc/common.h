@@ -56,7 +56,7 @@ int alfi_prof_begin(alfi_ctx* ctx, int kind);
 int alfi_prof_end(alfi_ctx* ctx, int token);
 
 constexpr int SMALL_PATCH_MAX = 160;   // register-resident inversion / one wave per patch up to here (kernels_patch.hip)
-constexpr int PATCH_MAX = 2048;        // blocked MFMA inversion / one workgroup per patch beyond (kernels_bigpatch.hip)
+constexpr int PATCH_MAX = 4096;        // blocked MFMA inversion / one workgroup per patch beyond (kernels_bigpatch.hip)
 
 // ---- storage of one dense patch inverse (n x n, rows padded to ld = n rounded up to even) --------------------------------
 // Row pieces: as many 128-row pieces as fit, then the binary digits of the remainder (64, 32, ..., 2).  A piece of R rows
@@ -246,9 +246,9 @@ int launch_patch_apply(alfi_level* lvl, const double* x, double* y);          //
 int launch_patch_apply_range(alfi_level* lvl, int64_t p0, int64_t p1, const double* x);   // stage 1, patches [p0, p1)
 int launch_big_apply_range(alfi_level* lvl, int64_t p0, int64_t p1, const double* x);     // the same for levels with n_p > 160
 int launch_big_factor_transfer(alfi_transfer* tr);                                            // dense nu K + gamma D blocks, m > 160
-int launch_big_apply_arrays(alfi_ctx* ctx, int64_t npatch, const int64_t* patch_ptr, const int32_t* patch_dofs,
-                            const int64_t* inv_ptr, const int64_t* stage_ptr, const double* inv, const double* x,
-                            double* stage);
+int launch_big_apply_arrays(alfi_ctx* ctx, int64_t npatch, int max_np, const int64_t* patch_ptr,
+                            const int32_t* patch_dofs, const int64_t* inv_ptr, const int64_t* stage_ptr, const double* inv,
+                            const double* x, double* stage);
 int launch_big_factor(alfi_level* lvl);                                                    // gather + blocked MFMA inversion
 int launch_patch_sum(alfi_level* lvl, const double* x, double* y);             // stage 2
 int launch_patch_sum_range(alfi_level* lvl, int64_t i0, int64_t i1, const double* x, double* y);   // stage 2, dofs [i0, i1)

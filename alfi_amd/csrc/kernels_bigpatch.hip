@@ -1,4 +1,4 @@
-// Large patches (160 < n_p <= 2048): the macro-star patches of the reference's high-order discretisations
+// Large patches (160 < n_p <= 4096): the macro-star patches of the reference's high-order discretisations
 // (alfi/relaxation.py:163-177; 405 / 1275 dofs for Scott-Vogelius P2 / P3) need a different setup
 // and a different work split than the vertex stars of kernels_patch.hip:
 //
@@ -14,7 +14,7 @@
 #include "common.h"
 
 constexpr int BIG_NB = 64;          // pivot block / GEMM k-extent
-constexpr int BIG_MAX_NP = 2048;
+constexpr int BIG_MAX_NP = PATCH_MAX;
 
 // ---------------------------------------------------------------------------------------------------------------------
 // 1. gather A_p = A[dofs_p, dofs_p] into the row-major scratch (N x N, N = n rounded up to 64, identity padding)
@@ -348,25 +348,27 @@ __global__ __launch_bounds__(256) void big_apply_kernel(int64_t p0, int64_t npat
                                                          const int64_t* __restrict__ inv_ptr,
                                                          const int64_t* __restrict__ stage_ptr,
                                                          const double* __restrict__ inv, const double* __restrict__ x,
-                                                         double* __restrict__ stage) {
+                                                         double* __restrict__ stage, int split) {
   __shared__ double xs[BIG_MAX_NP];
-  const int64_t p = p0 + blockIdx.x;
+  // ``split`` consecutive workgroups share a patch (levels with few patches: 303 macro stars would leave half the CUs idle)
+  const int64_t p = p0 + blockIdx.x / split;
+  const int part = blockIdx.x % split, nwave = 4 * split;
   if (p >= npatch) return;
   const int64_t off = patch_ptr[p];
   const int n = (int)(patch_ptr[p + 1] - off);
   for (int i = threadIdx.x; i < n; i += 256) xs[i] = x[patch_dofs[off + i]];
   __syncthreads();
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int wave = part * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int ld = (n + 1) & ~1;
   const double* T = inv + inv_ptr[p];
   double* out = stage + stage_ptr[p];
   int piece = 0, row0 = 0;
   for (; row0 + 128 <= ld; row0 += 128, ++piece)
-    if ((piece & 3) == wave) big_piece<64, NT>(T + (int64_t)row0 * n, n, xs, lane, out + row0);
+    if (piece % nwave == wave) big_piece<64, NT>(T + (int64_t)row0 * n, n, xs, lane, out + row0);
   const int rem = ld - row0;
 #define ALFI_BIG_PIECE(R)                                                                   \
   if (rem & R) {                                                                            \
-    if ((piece & 3) == wave) big_piece<R / 2, NT>(T + (int64_t)row0 * n, n, xs, lane, out + row0); \
+    if (piece % nwave == wave) big_piece<R / 2, NT>(T + (int64_t)row0 * n, n, xs, lane, out + row0); \
     row0 += R;                                                                              \
     ++piece;                                                                                \
   }
@@ -382,17 +384,28 @@ __global__ __launch_bounds__(256) void big_apply_kernel(int64_t p0, int64_t npat
 // ---------------------------------------------------------------------------------------------------------------------
 // launch wrappers
 // ---------------------------------------------------------------------------------------------------------------------
+// workgroups per patch: enough of them to fill 256 CUs several times over, but no more waves than 128-row pieces
+static int big_split(int64_t npatch, int max_np) {
+  static const int forced = getenv("ALFI_BIG_SPLIT") ? atoi(getenv("ALFI_BIG_SPLIT")) : 0;
+  if (forced > 0) return forced;
+  const int64_t want = (2048 + npatch - 1) / npatch;
+  const int pieces = (max_np + 127) / 128;
+  const int cap = (pieces + 3) / 4;
+  return (int)(want < 1 ? 1 : (want > cap ? cap : want));
+}
+
 int launch_big_apply_range(alfi_level* L, int64_t p0, int64_t p1, const double* x) {
   alfi_ctx* ctx = L->ctx;
   if (p1 <= p0) return 0;
   static const bool nt = !(getenv("ALFI_NT") && atoi(getenv("ALFI_NT")) == 0);
-  dim3 grid((unsigned)(p1 - p0)), block(256);
+  const int split = big_split(p1 - p0, L->max_np);
+  dim3 grid((unsigned)((p1 - p0) * split)), block(256);
   if (nt)
     hipLaunchKernelGGL(big_apply_kernel<true>, grid, block, 0, ctx->stream, p0, p1, L->patch_ptr, L->patch_dofs, L->inv_ptr,
-                       L->stage_ptr, L->inv, x, L->stage);
+                       L->stage_ptr, L->inv, x, L->stage, split);
   else
     hipLaunchKernelGGL(big_apply_kernel<false>, grid, block, 0, ctx->stream, p0, p1, L->patch_ptr, L->patch_dofs, L->inv_ptr,
-                       L->stage_ptr, L->inv, x, L->stage);
+                       L->stage_ptr, L->inv, x, L->stage, split);
   ALFI_HIP_CHECK(ctx, hipGetLastError());
   return 0;
 }
@@ -412,18 +425,19 @@ __global__ __launch_bounds__(256) void big_dense_fill_kernel(int64_t p0, int m, 
   }
 }
 
-int launch_big_apply_arrays(alfi_ctx* ctx, int64_t npatch, const int64_t* patch_ptr, const int32_t* patch_dofs,
-                            const int64_t* inv_ptr, const int64_t* stage_ptr, const double* inv, const double* x,
-                            double* stage) {
+int launch_big_apply_arrays(alfi_ctx* ctx, int64_t npatch, int max_np, const int64_t* patch_ptr,
+                            const int32_t* patch_dofs, const int64_t* inv_ptr, const int64_t* stage_ptr, const double* inv,
+                            const double* x, double* stage) {
   if (npatch == 0) return 0;
   static const bool nt = !(getenv("ALFI_NT") && atoi(getenv("ALFI_NT")) == 0);
-  dim3 grid((unsigned)npatch), block(256);
+  const int split = big_split(npatch, max_np);
+  dim3 grid((unsigned)(npatch * split)), block(256);
   if (nt)
     hipLaunchKernelGGL(big_apply_kernel<true>, grid, block, 0, ctx->stream, (int64_t)0, npatch, patch_ptr, patch_dofs,
-                       inv_ptr, stage_ptr, inv, x, stage);
+                       inv_ptr, stage_ptr, inv, x, stage, split);
   else
     hipLaunchKernelGGL(big_apply_kernel<false>, grid, block, 0, ctx->stream, (int64_t)0, npatch, patch_ptr, patch_dofs,
-                       inv_ptr, stage_ptr, inv, x, stage);
+                       inv_ptr, stage_ptr, inv, x, stage, split);
   ALFI_HIP_CHECK(ctx, hipGetLastError());
   return 0;
 }
@@ -530,7 +544,7 @@ int launch_big_factor(alfi_level* L) {
   return big_factor_core(L->ctx, src, L->npatch, L->h_patch_ptr.data(), L->patch_ptr, L->inv_ptr, L->inv, L->status);
 }
 
-// interior blocks of a transfer with 160 < m <= 2048 (macro-cell blocks of the 3-D Scott-Vogelius transfer, m = 390 for P3)
+// interior blocks of a transfer with 160 < m <= 4096 (macro-cell blocks of the 3-D Scott-Vogelius transfer, m = 390 for P3)
 int launch_big_factor_transfer(alfi_transfer* T) {
   BigSource src;
   src.T = T;

@@ -815,7 +815,7 @@ static int pm_apply(alfi_transfer* tr, const int32_t* idx, const double* in, dou
   alfi_ctx* ctx = tr->ctx;
   double* dst = tr->pm_tmp ? tr->pm_tmp : out;
   if (tr->m > SMALL_PATCH_MAX)
-    ALFI_CHECK(launch_big_apply_arrays(ctx, tr->nblk, tr->pm_ptr, idx, tr->pm_inv_ptr, tr->pm_stage_ptr, tr->binv, in, dst));
+    ALFI_CHECK(launch_big_apply_arrays(ctx, tr->nblk, tr->m, tr->pm_ptr, idx, tr->pm_inv_ptr, tr->pm_stage_ptr, tr->binv, in, dst));
   else
     ALFI_CHECK(launch_patch_apply_arrays(ctx, tr->nblk, tr->pm_ptr, idx, tr->pm_inv_ptr, tr->pm_stage_ptr, tr->binv, in,
                                          dst));

@@ -54,7 +54,7 @@ class VectorFunctionSpace(object):
     that patches, matrix rows and mesh partitions are contiguous-ish in memory (an MI355X choice: x-gathers of the
     patch smoother and the SpMV then hit L2 / Infinity Cache instead of HBM)."""
 
-    def __init__(self, mesh, element, reorder=True):
+    def __init__(self, mesh, element, reorder=True, dirichlet=None):
         self.mesh, self.element = mesh, element
         self.dim = mesh.dim
         nv, ne, nf = mesh.num_vertices, mesh.num_edges, mesh.num_faces
@@ -101,8 +101,9 @@ class VectorFunctionSpace(object):
             en = self.raw2new[self.raw_offsets[1]:self.raw_offsets[2]]
             self.edge_nodes = en if npe == 1 else en.reshape(ne, npe)
         self.face_nodes = self.raw2new[self.raw_offsets[2]:self.raw_offsets[3]] if element.has_face_nodes else None
-        # all-Dirichlet boundary (ldc2d.py:22-25, ldc3d.py:17-20)
-        vm, em, fm = mesh.boundary_entities()
+        # Dirichlet nodes: the whole boundary (ldc2d.py:22-25, ldc3d.py:17-20) unless ``dirichlet`` (a callable on the
+        # boundary facet centroids) selects a part of it (bfs3d.py:23-26: inflow and walls, the outflow stays natural)
+        vm, em, fm = mesh.boundary_entities(dirichlet)
         bc = [self.vertex_nodes[vm]]
         if element.has_edge_nodes:
             bc.append(np.asarray(self.edge_nodes[em]).ravel())

@@ -79,12 +79,15 @@ class SimplexMesh(object):
     def num_faces(self):
         return 0 if self.faces is None else self.faces.shape[0]
 
-    def boundary_entities(self):
-        """(vertex mask, edge mask, face mask) of entities in the closure of exterior facets."""
+    def boundary_entities(self, select=None):
+        """(vertex mask, edge mask, face mask) of entities in the closure of exterior facets; ``select``: callable on the
+        facet centroids (nbf, dim) -> bool mask, restricts to a part of the boundary (DirichletBC on some labels only)."""
         vm = np.zeros(self.num_vertices, dtype=bool)
         em = np.zeros(self.num_edges, dtype=bool)
         fm = np.zeros(self.num_faces, dtype=bool)
         bf = self.boundary_facets
+        if select is not None:
+            bf = bf[np.asarray(select(self.coords[self.facets[bf]].mean(axis=1)), dtype=bool)]
         vm[self.facets[bf].ravel()] = True
         if self.dim == 2:
             em[bf] = True

@@ -47,6 +47,11 @@ class NavierStokesProblem(object):
     def relaxation_direction(self):
         return None
 
+    def dirichlet_facets(self, centroids):
+        """Which boundary facets carry the velocity Dirichlet condition (``bcs``, problem.py:27): all of them unless a
+        problem overrides this."""
+        return np.ones(centroids.shape[0], dtype=bool)
+
 
 class TwoDimLidDrivenCavityProblem(NavierStokesProblem):
     """examples/ldc2d/ldc2d.py:7-39."""
@@ -92,6 +97,35 @@ class ThreeDimLidDrivenCavityProblem(NavierStokesProblem):
 
     def char_length(self):
         return 2.0
+
+    def relaxation_direction(self):
+        return "0+:1-"
+
+
+class ThreeDimBackwardsFacingStepProblem(NavierStokesProblem):
+    """examples/bfs3d/bfs3d.py:8-33 on the structured stand-in for the gmsh channel (``mesh.bfs3d_mesh``): Poiseuille
+    inflow at x = 0 (label 1), no-slip walls (label 3), natural outflow at x = 10 (label 2)."""
+
+    def __init__(self, baseN=1):
+        self.baseN = baseN
+        self.dim = 3
+
+    def mesh(self, distribution_parameters=None):
+        from .mesh import bfs3d_mesh
+        return bfs3d_mesh(self.baseN)
+
+    def driver(self, x):
+        """poiseuille_flow (bfs3d.py:19-21): the inflow profile, extended along the channel as the linearisation state."""
+        w = np.zeros_like(x)
+        y, z = x[:, 1], x[:, 2]
+        w[:, 0] = 16.0 * (2 - y) * (y - 1) * z * (1 - z) * (y > 1)
+        return w
+
+    def dirichlet_facets(self, centroids):
+        return centroids[:, 0] < 10.0 - 1e-9
+
+    def has_nullspace(self):
+        return False
 
     def relaxation_direction(self):
         return "0+:1-"
@@ -223,7 +257,7 @@ def build_hierarchy(problem, nref, k, Re, gamma=1e4, advect=True, patches=True, 
     levels, transfers = [], []
     Vprev = None
     for l, mesh in enumerate(mh):
-        V = VectorFunctionSpace(mesh, element)
+        V = VectorFunctionSpace(mesh, element, dirichlet=getattr(problem, "dirichlet_facets", None))
         d = V.dim
         L = LevelData()
         L.V, L.level, L.n, L.bs = V, l, V.num_dofs, d

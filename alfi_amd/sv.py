@@ -180,7 +180,7 @@ def build_sv_hierarchy(problem, nref, k, Re, gamma=1e4, advect=True, patches=Tru
     adv = 1.0 if (advect and Re > 0) else 0.0
     levels, transfers, Vprev = [], [], None
     for l, mesh in enumerate(mh):
-        V = VectorFunctionSpace(mesh, element)
+        V = VectorFunctionSpace(mesh, element, dirichlet=getattr(problem, "dirichlet_facets", None))
         d = V.dim
         L = LevelData()
         L.V, L.level, L.n, L.bs = V, l, V.num_dofs, d

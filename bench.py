@@ -33,12 +33,19 @@ CONFIGS = {
     "cfg4": (3, 7, 3, 2, 1000.0, 10),
     "cfg4s": (3, 7, 2, 2, 1000.0, 10),   # config 4 truncated by one level (N = 28), for quick tuning runs
     "tiny": (3, 2, 1, 2, 1000.0, 4),
+    # config 5 on ONE GPU: bfs3d channel, Scott-Vogelius [P3]^3 on Alfeld-split meshes, macro-star patches (up to 2175 dofs),
+    # macro-cell transfer blocks of 390; baseN 1 (114 tets), nref 2 -> 441 k velocity dofs, 33 GB of patch inverses
+    "cfg5": ("sv", 1, 2, 3, 500.0, 10),
+    "cfg5s": ("sv", 1, 1, 3, 500.0, 10),
 }
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 TB/s achievable)
 
 
 def describe(cfg):
     dim, baseN, nref, ke, Re, k = CONFIGS[cfg]
+    if dim == "sv":
+        return ("bfs3d Scott-Vogelius [P%d]^3 on Alfeld-split meshes (structured 10x2x1 channel with step, baseN %d, nref %d), "
+                "Re=%g, gamma=1e4, FGMRES(%d)+macro-star patches" % (ke, baseN, nref, Re, k))
     el = "[P2]^2" if dim == 2 else ("[P1+FB]^3" if ke == 1 else "[P2+FB]^3")
     return "ldc%dd %s-P0, N=%d (baseN %d, nref %d), Re=%g, gamma=1e4, FGMRES(%d)+star patches" % (
         dim, el, baseN * 2 ** nref, baseN, nref, Re, k)
@@ -47,6 +54,11 @@ def describe(cfg):
 def build_problem(cfg, verbose):
     from alfi_amd.problem import TwoDimLidDrivenCavityProblem, ThreeDimLidDrivenCavityProblem, build_hierarchy
     dim, baseN, nref, ke, Re, k = CONFIGS[cfg]
+    if dim == "sv":
+        from alfi_amd.problem import ThreeDimBackwardsFacingStepProblem
+        from alfi_amd.sv import build_sv_hierarchy
+        lv, tr = build_sv_hierarchy(ThreeDimBackwardsFacingStepProblem(baseN), nref, ke, Re=Re)
+        return lv, tr, k
     prob = TwoDimLidDrivenCavityProblem(baseN) if dim == 2 else ThreeDimLidDrivenCavityProblem(baseN)
     lv, tr = build_hierarchy(prob, nref, ke, Re=Re, verbose=verbose)
     return lv, tr, k
@@ -184,7 +196,8 @@ def main_distributed(args, rank, world, local_rank):
         vps = args.steps / elapsed
         per_rank = [[float(v) for v in t.tolist()] for t in allstats]
         out = {
-            "metric": "V-cycles/sec on ldc%dd P2-P0 (DoF*smooths/sec in dof_smooths_per_s)" % CONFIGS[args.config][0],
+            "metric": ("V-cycles/sec on bfs3d SV P3-P2dg (DoF*smooths/sec in dof_smooths_per_s)" if CONFIGS[args.config][0] == "sv"
+                   else "V-cycles/sec on ldc%dd P2-P0 (DoF*smooths/sec in dof_smooths_per_s)" % CONFIGS[args.config][0]),
             "value": vps, "unit": "V-cycles/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
@@ -195,7 +208,7 @@ def main_distributed(args, rank, world, local_rank):
                        "backend": backend,
                        "distributed_levels": [int(p.level) for p in dmg.parts if p.distributed]},
             "dof_smooths_per_s": L.n * 2 * k * vps,
-            "roofline": {"kernel": "patch_apply_kernel", "bound": "hbm", "achieved": local_gbs, "peak": HBM_PEAK_GBS,
+            "roofline": {"kernel": "big_apply_kernel" if np.diff(L.patch_ptr).max() > 160 else "patch_apply_kernel", "bound": "hbm", "achieved": local_gbs, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": local_gbs / HBM_PEAK_GBS, "traffic": None,
                          "note": "rank 0's finest-level applies (its share of the patches; one apply = up to three "
                                  "launches around the halo exchanges), HIP events",
@@ -337,7 +350,8 @@ def main():
         traffic = json.load(open(pmc_file)).get("hbm_bytes_per_launch")
 
     out = {
-        "metric": "V-cycles/sec on ldc%dd P2-P0 (DoF*smooths/sec in dof_smooths_per_s)" % CONFIGS[args.config][0],
+        "metric": ("V-cycles/sec on bfs3d SV P3-P2dg (DoF*smooths/sec in dof_smooths_per_s)" if CONFIGS[args.config][0] == "sv"
+                   else "V-cycles/sec on ldc%dd P2-P0 (DoF*smooths/sec in dof_smooths_per_s)" % CONFIGS[args.config][0]),
         "value": vps,
         "unit": "V-cycles/s",
         "n_gpus": 1,
@@ -357,7 +371,7 @@ def main():
         "fcycle_ms": fcycle_ms,
         "vcycle_algorithmic_GB": total_bytes / 1e9,
         "vcycle_hbm_frac_of_peak": total_bytes / 1e9 / (elapsed / args.steps) / HBM_PEAK_GBS,
-        "roofline": {"kernel": "patch_apply_kernel", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
+        "roofline": {"kernel": "big_apply_kernel" if np.diff(L.patch_ptr).max() > 160 else "patch_apply_kernel", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "avg_launch_us": 1e3 * t_apply_ms / max(n_apply, 1), "launches": int(n_apply),
                      "bytes_per_launch_avg": bytes_apply_total / max(n_apply, 1),

@@ -118,7 +118,7 @@ int alfi_residual(alfi_level* lvl, const double* db, const double* dx, double* d
 
 /* ---- patch smoother: firedrake.PatchPC -> PETSc PCPATCH [3P], alfi/solver.py:318-328, 599-602 -------------------- */
 /* Patches as produced by a patch-construction callable (alfi/relaxation.py:110-150) after PCPATCH's dof mapping:
- * patch p owns dofs patch_dofs[patch_ptr[p] .. patch_ptr[p+1]), ascending, Dirichlet dofs excluded, sizes <= 2048
+ * patch p owns dofs patch_dofs[patch_ptr[p] .. patch_ptr[p+1]), ascending, Dirichlet dofs excluded, sizes <= 4096
  * (levels whose largest patch exceeds 160 dofs -- macro stars -- use the blocked matrix-core inversion and one workgroup
  * per patch in the apply). */
 int alfi_patches_set(alfi_level* lvl, int64_t npatch, const int64_t* patch_ptr_host, const int32_t* patch_dofs_host);
@@ -164,7 +164,7 @@ typedef struct {
 /* P: standard prolongation (fine x coarse; bubble-corrected for 3-D P1+FB, transfer.py:334-356), PT its transpose,
  * PT_plain: transpose of the plain nodal interpolation used when restriction is not robust (solver.py:595; may be
  * NULL = same as PT).  D_I: rows of the cell-averaged grad-div matrix (gamma = 1) for the coarse-cell interior dofs
- * in block order; D_IT its transpose.  blk_dofs: (nblk, m) interior dofs per coarse cell (transfer.py:13-46; m <= 2048: beyond 32 -- the coarse
+ * in block order; D_IT its transpose.  blk_dofs: (nblk, m) interior dofs per coarse cell (transfer.py:13-46; m <= 4096: beyond 32 -- the coarse
  * MACRO cells of the Scott-Vogelius transfer, transfer.py:49-88 -- the blocks are solved with the patch kernels, beyond
  * 160 with the large-patch ones);
  * K_II, D_II: (nblk, m, m) dense interior blocks of (2 sym grad u, grad v) and (cell_avg div u, div v). */

@@ -99,15 +99,18 @@ int oracle_invert_patches(int64_t npatch, const int64_t* patch_ptr, const int32_
                           const int32_t* rowptr, const int32_t* colidx, const double* vals, const int64_t* inv_ptr,
                           double* inv) {
   int err = 0;
+  int max_n = 1;
+  for (int64_t p = 0; p < npatch; ++p)
+    if (patch_ptr[p + 1] - patch_ptr[p] > max_n) max_n = (int)(patch_ptr[p + 1] - patch_ptr[p]);
 #pragma omp parallel
   {
-    int piv[256];
-#pragma omp for schedule(dynamic, 16)
+    int* piv = (int*)malloc(sizeof(int) * max_n);
+#pragma omp for schedule(dynamic, 1)
     for (int64_t p = 0; p < npatch; ++p) {
       const int32_t* dofs = patch_dofs + patch_ptr[p];
       const int n = (int)(patch_ptr[p + 1] - patch_ptr[p]);
       double* a = inv + inv_ptr[p];
-      memset(a, 0, sizeof(double) * n * n);
+      memset(a, 0, sizeof(double) * (size_t)n * n);
       for (int i = 0; i < n; ++i) {
         const int64_t r = dofs[i] / bs, rc = dofs[i] % bs;
         for (int32_t k = rowptr[r]; k < rowptr[r + 1]; ++k) {
@@ -117,8 +120,9 @@ int oracle_invert_patches(int64_t npatch, const int64_t* patch_ptr, const int32_
           for (; lo < n && dofs[lo] < c0 + bs; ++lo) a[i * n + lo] = vals[(int64_t)k * bs * bs + rc * bs + (dofs[lo] - c0)];
         }
       }
-      if (n > 256 || dense_inverse(n, a, piv) != 0) err = 1;
+      if (dense_inverse(n, a, piv) != 0) err = 1;
     }
+    free(piv);
   }
   return err ? -1 : 0;
 }
@@ -128,10 +132,14 @@ int oracle_invert_patches(int64_t npatch, const int64_t* patch_ptr, const int32_
 void oracle_patch_apply(int64_t npatch, const int64_t* patch_ptr, const int32_t* patch_dofs, const int64_t* inv_ptr,
                         const double* inv, int64_t n, const int32_t* dof_ptr, const int32_t* dof_pos,
                         const int32_t* bc_dofs, int64_t nbc, const double* x, double* y, double* stage) {
+  int max_n = 1;
+  for (int64_t p = 0; p < npatch; ++p)
+    if (patch_ptr[p + 1] - patch_ptr[p] > max_n) max_n = (int)(patch_ptr[p + 1] - patch_ptr[p]);
+  const int chunk = max_n > 256 ? 1 : 16;
 #pragma omp parallel
   {
-    double xp[256];
-#pragma omp for schedule(dynamic, 16)
+    double* xp = (double*)malloc(sizeof(double) * max_n);
+#pragma omp for schedule(dynamic, chunk)
     for (int64_t p = 0; p < npatch; ++p) {
       const int32_t* dofs = patch_dofs + patch_ptr[p];
       const int np = (int)(patch_ptr[p + 1] - patch_ptr[p]);
@@ -146,6 +154,7 @@ void oracle_patch_apply(int64_t npatch, const int64_t* patch_ptr, const int32_t*
         out[i] = s;
       }
     }
+    free(xp);
 #pragma omp for schedule(static)
     for (int64_t i = 0; i < n; ++i) {
       double s = 0.0;
@@ -242,15 +251,19 @@ void oracle_fgmres(const oracle_level* L, int k, const double* b, double* x, int
 /* out[blk*m + i] = sum_j binv[blk][i][j] * in[...]; binv row-major (nblk, m, m); gather: in indexed by blk_dofs */
 void oracle_block_gemv(int64_t nblk, int m, const double* binv, const int32_t* blk_dofs, const double* in, double* out,
                        int gather) {
-#pragma omp parallel for schedule(static)
-  for (int64_t b = 0; b < nblk; ++b) {
-    double xb[64];
-    for (int j = 0; j < m; ++j) xb[j] = gather ? in[blk_dofs[b * m + j]] : in[b * m + j];
-    for (int i = 0; i < m; ++i) {
-      double s = 0.0;
-      for (int j = 0; j < m; ++j) s += binv[(b * m + i) * m + j] * xb[j];
-      out[b * m + i] = s;
+#pragma omp parallel
+  {
+    double* xb = (double*)malloc(sizeof(double) * m);
+#pragma omp for schedule(static)
+    for (int64_t b = 0; b < nblk; ++b) {
+      for (int j = 0; j < m; ++j) xb[j] = gather ? in[blk_dofs[b * m + j]] : in[b * m + j];
+      for (int i = 0; i < m; ++i) {
+        double s = 0.0;
+        for (int j = 0; j < m; ++j) s += binv[(b * m + i) * m + j] * xb[j];
+        out[b * m + i] = s;
+      }
     }
+    free(xb);
   }
 }
 
@@ -259,13 +272,14 @@ int oracle_block_invert(int64_t nblk, int m, const double* K, const double* D, d
   int err = 0;
 #pragma omp parallel
   {
-    int piv[64];
+    int* piv = (int*)malloc(sizeof(int) * m);
 #pragma omp for schedule(static)
     for (int64_t b = 0; b < nblk; ++b) {
       double* a = binv + b * m * m;
       for (int e = 0; e < m * m; ++e) a[e] = nu * K[b * m * m + e] + gamma * D[b * m * m + e];
       if (dense_inverse(m, a, piv) != 0) err = 1;
     }
+    free(piv);
   }
   return err ? -1 : 0;
 }

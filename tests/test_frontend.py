@@ -270,7 +270,7 @@ def test_macro_star_on_an_alfeld_split_mesh():
         the figure of SURVEY.md section 8 (and 425 nodes = 1275 dofs for P3);
       * the LITERAL callback (relaxation.py:168-177) tests the MacroVertices label on every point of the closures, not only
         on vertices, so the 36 outer edges of the macro star bring their own stars -- and their dofs -- along: 513 dofs.
-        alfi_amd.MacroStar follows the literal code; both sizes are within the library's 2048-dof limit."""
+        alfi_amd.MacroStar follows the literal code; both sizes are within the library's 4096-dof limit."""
     from alfi_amd.mesh import box_mesh, bary_refine, bary_mesh_hierarchy, bfs3d_mesh
     from alfi_amd.elements import NodalElement
     from alfi_amd.fespace import VectorFunctionSpace

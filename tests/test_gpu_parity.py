@@ -187,7 +187,7 @@ def test_bad_arguments_are_reported(ctx, setup):
     with pytest.raises(hip.AlfiHipError):
         dl.set_patches(np.array([0, 1]), np.array([L.n]))             # out of range
     with pytest.raises(hip.AlfiHipError):
-        dl.set_patches(np.array([0, 2049]), np.arange(2049) % L.n)    # too large (limit: 2048 dofs per patch)
+        dl.set_patches(np.array([0, 4097]), np.arange(4097) % L.n)    # too large (limit: 4096 dofs per patch)
     dl.close()
 
 
@@ -298,8 +298,8 @@ def test_patch_sizes_1_to_160_all_row_piece_combinations(ctx, bs):
     e = np.zeros_like(x)
     e[bc] = x[bc]
     assert np.array_equal(dy.get(), e)
-    # one patch too large (the limit is 2048 dofs, tests/test_gpu_parity.py::test_large_patches covers 161 .. 2048)
-    big = (np.arange(2048 // bs + 1)[:, None] * bs + np.arange(bs)).ravel().astype(np.int32) % (nb * bs)
+    # one patch too large (the limit is 4096 dofs, tests/test_gpu_parity.py::test_large_patches covers 161 .. 2048)
+    big = (np.arange(4096 // bs + 1)[:, None] * bs + np.arange(bs)).ravel().astype(np.int32) % (nb * bs)
     with pytest.raises(hip.AlfiHipError):
         lvl.set_patches(np.array([0, len(big)], dtype=np.int64), big)
     lvl.close()

@@ -12,12 +12,14 @@ from tests.test_graddiv import fgmres_solve
 from tests.test_sv import run as run_oracle
 
 
-@pytest.mark.parametrize("case", ["2d-p2", "3d-p2", "3d-p3"])
+@pytest.mark.parametrize("case", ["2d-p2", "3d-p2", "3d-p3", "bfs3d-p3"])
 def test_sv_transfers_and_cycles_match_oracle(case):
     """2-D: macro stars of 62 dofs, macro-cell blocks of 38.  3-D [P2]^3 (the smoother / transfer machinery, not an
     inf-sup stable pair): macro stars of up to 513 dofs (blocked matrix-core inversion), macro-cell blocks of 123 (odd).
     3-D [P3]^3 (the velocity space of BASELINE config 5): macro stars of up to 1599 dofs, macro-cell blocks of 390 --
-    both through the blocked matrix-core inversion and the workgroup-per-patch apply."""
+    both through the blocked matrix-core inversion and the workgroup-per-patch apply.  bfs3d-p3: BASELINE config 5 at its
+    smallest (bench.py --config cfg5s): backward-facing-step channel with a natural outflow, Re = 500, 57 k velocity dofs,
+    303 macro stars of up to 1941 dofs."""
     from alfi_amd import hip
     from alfi_amd.problem import ThreeDimLidDrivenCavityProblem
     from oracle import alfi_oracle as O
@@ -26,9 +28,13 @@ def test_sv_transfers_and_cycles_match_oracle(case):
     elif case == "3d-p2":
         lv, tr = build_sv_hierarchy(ThreeDimLidDrivenCavityProblem(1), 2, 2, Re=100.0, gamma=1e4)
         assert tr[0].blk_dofs.shape[1] == 123 and max(np.diff(L.patch_ptr).max() for L in lv[1:]) > 160
-    else:
+    elif case == "3d-p3":
         lv, tr = build_sv_hierarchy(ThreeDimLidDrivenCavityProblem(1), 1, 3, Re=100.0, gamma=1e4)
         assert tr[0].blk_dofs.shape[1] == 390 and np.diff(lv[1].patch_ptr).max() == 1599
+    else:
+        from alfi_amd.problem import ThreeDimBackwardsFacingStepProblem
+        lv, tr = build_sv_hierarchy(ThreeDimBackwardsFacingStepProblem(1), 1, 3, Re=500.0, gamma=1e4)
+        assert lv[1].n == 56937 and np.diff(lv[1].patch_ptr).max() == 1941
     ctx = hip.Context(0)
     k = 3
     rng = np.random.default_rng(0)

@@ -65,6 +65,28 @@ def test_sv_p3_generator_3d():
     assert abs(uf @ (Ds @ uf)) < 1e-8 * (uf @ (Ks @ uf))
 
 
+def test_bfs3d_problem_has_a_natural_outflow():
+    """examples/bfs3d/bfs3d.py:23-26: Dirichlet data on the inflow and the walls only; the nodes strictly inside the outflow
+    face x = 10 stay free, get matrix rows and sit in patches."""
+    from alfi_amd.problem import ThreeDimBackwardsFacingStepProblem
+    lv, tr = build_sv_hierarchy(ThreeDimBackwardsFacingStepProblem(1), 1, 2, Re=500.0, gamma=1e4)
+    L = lv[1]
+    X = L.V.node_coords
+    out = np.abs(X[:, 0] - 10.0) < 1e-12
+    wall = (np.abs(X[:, 1] - 2.0) < 1e-12) | (np.abs(X[:, 2]) < 1e-12) | (np.abs(X[:, 2] - 1.0) < 1e-12) | \
+        (np.abs(X[:, 1]) < 1e-12) | (np.abs(X[:, 0]) < 1e-12) | \
+        ((np.abs(X[:, 1] - 1.0) < 1e-12) & (X[:, 0] < 1 + 1e-12)) | ((np.abs(X[:, 0] - 1.0) < 1e-12) & (X[:, 1] < 1 + 1e-12))
+    assert np.array_equal(L.V.bc_node_mask, wall)
+    assert (out & ~wall).sum() > 0
+    in_patch = np.zeros(L.n, dtype=bool)
+    in_patch[L.patch_dofs] = True
+    assert np.array_equal(in_patch.reshape(-1, 3)[:, 0], ~wall)
+    assert L.nu == 1.0 / 500.0                                       # char_length = char_velocity = 1, problem.py:40-44
+    A = O.apply_bcs_matrix(O.assemble_form(L.V, nu=L.nu, gamma_full=1e4, adv=1.0, wind=ThreeDimBackwardsFacingStepProblem(1).driver(X)),
+                           L.bc_dofs)
+    assert abs(A - L.A.to_scipy()).max() < 1e-8 * abs(A).max()
+
+
 def run(gamma, schoeberl):
     lv, tr = build_sv_hierarchy(TwoDimLidDrivenCavityProblem(2), 2, 2, Re=0, gamma=gamma, advect=False)
     mg = O.build_oracle_mg(lv, tr, k=3, schoeberl_restriction=schoeberl)
