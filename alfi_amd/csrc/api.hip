@@ -237,6 +237,7 @@ int alfi_ctx_destroy(alfi_ctx* ctx) {
     (void)hipEventDestroy(p.b);
   }
   dev_free(ctx->red_partial);
+  (void)hipFree(ctx->big_arena);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
   return 0;

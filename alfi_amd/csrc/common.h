@@ -10,6 +10,8 @@
 struct alfi_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
+  void* big_arena = nullptr;        // scratch of the large-block factorisation (kernels_bigpatch.hip), kept between calls
+  size_t big_arena_bytes = 0;
   bool own_stream = false;
   std::string err;
   // profiling

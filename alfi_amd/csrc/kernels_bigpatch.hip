@@ -10,7 +10,9 @@
 //    (v_mfma_f64_16x16x4_f64: 95 % of the flops).  No pivoting across blocks, like the register kernel for small patches.
 //  * apply: one WORKGROUP per patch; the row pieces of the inverse (same storage as for small patches,
 //    patch_inv_index) are dealt round-robin to the four waves, x_p sits in LDS.
+#include <algorithm>
 #include <cstdlib>
+#include <vector>
 #include "common.h"
 
 constexpr int BIG_NB = 64;          // pivot block / GEMM k-extent
@@ -27,20 +29,22 @@ __global__ __launch_bounds__(256) void big_gather_kernel(int64_t p0, const int32
                                                           const int32_t* __restrict__ patch_dofs,
                                                           const int64_t* __restrict__ scr_ptr, double* __restrict__ scr) {
   __shared__ int32_t dofs_s[BIG_MAX_NP];
-  const int64_t p = p0 + blockIdx.x;
+  const int64_t p = p0 + blockIdx.y;
   const int64_t off = patch_ptr[p];
   const int n = (int)(patch_ptr[p + 1] - off);
   const int N = (n + BIG_NB - 1) / BIG_NB * BIG_NB;
-  double* S = scr + scr_ptr[blockIdx.x];
+  double* S = scr + scr_ptr[blockIdx.y];
   for (int i = threadIdx.x; i < n; i += 256) dofs_s[i] = patch_dofs[off + i];
-  // zero + identity padding
-  for (int64_t e = threadIdx.x; e < (int64_t)N * N; e += 256) {
+  // this workgroup's rows: zero + identity padding, then the matrix entries
+  const int chunk = (N + gridDim.x - 1) / gridDim.x;
+  const int ra = blockIdx.x * chunk, rb = min(N, ra + chunk);
+  for (int64_t e = (int64_t)ra * N + threadIdx.x; e < (int64_t)rb * N; e += 256) {
     const int r = (int)(e / N), c = (int)(e % N);
     S[e] = (r == c && r >= n) ? 1.0 : 0.0;
   }
   __syncthreads();
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  for (int r = wave; r < n; r += 4) {
+  for (int r = ra + wave; r < min(rb, n); r += 4) {
     const int gr = dofs_s[r];
     const int brow = gr / BS, rr = gr % BS;
     const int32_t lo = rowptr[brow], hi = rowptr[brow + 1];
@@ -59,26 +63,24 @@ __global__ __launch_bounds__(256) void big_gather_kernel(int64_t p0, const int32
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// 2a. panel step for pivot block K = [k0, k0 + 64): one workgroup per patch.
-//       D^-1 = inv(S[K,K])  (Gauss-Jordan in LDS);  F = S[:,K] saved (rows K zeroed);  R = D^-1 S[K,:] saved (columns K zeroed);
-//       S[K,:] <- R with S[K,K] <- D^-1;  S[I,K] <- -F[I] D^-1 for I != K.
+// 2a. panel step for pivot block K = [k0, k0 + 64), two launches:
+//       big_pivot_kernel (one workgroup per patch):  D^-1 = inv(S[K,K]) by Gauss-Jordan in LDS, written to dinv;
+//       big_panel_kernel (2 N/64 workgroups per patch, one 64 x 64 x 64 product each on the matrix cores):
+//         column tile J:  R[:,J] = D^-1 S[K,J] saved (columns K zeroed);  S[K,J] <- R[:,J],  S[K,K] <- D^-1;
+//         row tile I:     F[I] = S[I,K] saved (rows K zeroed);            S[I,K] <- -F[I] D^-1  (I != K).
 //     After the trailing update S[I,J] -= F[I] R[J] (2b) the scratch holds the state of block Gauss-Jordan after step K.
+//     (First version: everything in one workgroup per patch with FMA products -- 0.69 s of the 3.0 s setup of config 5.)
 // ---------------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void big_panel_kernel(int k0, const int64_t* __restrict__ patch_ptr, int64_t p0,
-                                                         const int64_t* __restrict__ scr_ptr, double* __restrict__ scr,
-                                                         const int64_t* __restrict__ pan_ptr, double* __restrict__ panF,
-                                                         double* __restrict__ panR, int* __restrict__ status) {
+__global__ __launch_bounds__(256) void big_pivot_kernel(int k0, const int64_t* __restrict__ patch_ptr, int64_t p0,
+                                                         const int64_t* __restrict__ scr_ptr, const double* __restrict__ scr,
+                                                         double* __restrict__ dinv, int* __restrict__ status) {
   __shared__ double D[BIG_NB][BIG_NB + 1];     // pivot block, becomes its inverse
-  __shared__ double T[BIG_NB][BIG_NB + 1];     // a 64 x 64 tile of S
   const int64_t p = p0 + blockIdx.x;
   const int n = (int)(patch_ptr[p + 1] - patch_ptr[p]);
   const int N = (n + BIG_NB - 1) / BIG_NB * BIG_NB;
   if (k0 >= N) return;                          // smaller patch of the batch: already done
-  double* S = scr + scr_ptr[blockIdx.x];
-  double* F = panF + pan_ptr[blockIdx.x];       // (N, 64) row-major
-  double* R = panR + pan_ptr[blockIdx.x];       // (64, N) row-major
+  const double* S = scr + scr_ptr[blockIdx.x];
   const int t = threadIdx.x;
-  // load the pivot block
   for (int e = t; e < BIG_NB * BIG_NB; e += 256) D[e / BIG_NB][e % BIG_NB] = S[(int64_t)(k0 + e / BIG_NB) * N + k0 + e % BIG_NB];
   __syncthreads();
   // in-place Gauss-Jordan, thread (i, jq) owns row i, columns jq, jq + 4, ...
@@ -100,94 +102,153 @@ __global__ __launch_bounds__(256) void big_panel_kernel(int k0, const int64_t* _
     __syncthreads();
   }
   if (bad && t == 0) atomicExch(status, 1);
-  // column tiles J: R[:, J] = D^-1 S[K, J]
-  const int ti = t >> 4, tj = t & 15;           // thread computes the 4 x 4 sub-block (4 ti .., 4 tj ..) of a 64 x 64 product
-  for (int j0 = 0; j0 < N; j0 += BIG_NB) {
-    for (int e = t; e < BIG_NB * BIG_NB; e += 256) T[e / BIG_NB][e % BIG_NB] = S[(int64_t)(k0 + e / BIG_NB) * N + j0 + e % BIG_NB];
-    __syncthreads();
-    double acc[4][4];
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-      for (int b = 0; b < 4; ++b) acc[a][b] = 0.0;
-    for (int k = 0; k < BIG_NB; ++k) {
-      double dv[4], tv[4];
-#pragma unroll
-      for (int a = 0; a < 4; ++a) dv[a] = D[4 * ti + a][k];
-#pragma unroll
-      for (int b = 0; b < 4; ++b) tv[b] = T[k][4 * tj + b];
-#pragma unroll
-      for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_fma(dv[a], tv[b], acc[a][b]);
-    }
-    const bool diag = j0 == k0;
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-      for (int b = 0; b < 4; ++b) {
-        const int r = 4 * ti + a, c = 4 * tj + b;
-        // row panel of S: R, with D^-1 itself on the pivot block; saved R has its pivot columns zeroed
-        S[(int64_t)(k0 + r) * N + j0 + c] = diag ? D[r][c] : acc[a][b];
-        R[(int64_t)r * N + j0 + c] = diag ? 0.0 : acc[a][b];
+  double* Dg = dinv + (int64_t)blockIdx.x * BIG_NB * BIG_NB;
+  for (int e = t; e < BIG_NB * BIG_NB; e += 256) Dg[e] = D[e / BIG_NB][e % BIG_NB];
+}
+
+typedef double big_d4 __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(256) void big_panel_kernel(int k0, const int64_t* __restrict__ patch_ptr, int64_t p0,
+                                                         const int64_t* __restrict__ scr_ptr, double* __restrict__ scr,
+                                                         const int64_t* __restrict__ pan_ptr, double* __restrict__ panF,
+                                                         double* __restrict__ panR, const double* __restrict__ dinv,
+                                                         int tiles_max) {
+  const int64_t p = p0 + blockIdx.y;
+  const int n = (int)(patch_ptr[p + 1] - patch_ptr[p]);
+  const int N = (n + BIG_NB - 1) / BIG_NB * BIG_NB;
+  const int nt = N / BIG_NB;
+  if (k0 >= N) return;
+  const bool col = (int)blockIdx.x < tiles_max;                 // column tile of the pivot row panel / row tile of the pivot column panel
+  const int tile = col ? blockIdx.x : blockIdx.x - tiles_max;
+  if (tile >= nt) return;
+  double* S = scr + scr_ptr[blockIdx.y];
+  double* F = panF + pan_ptr[blockIdx.y];       // (N, 64) row-major
+  double* R = panR + pan_ptr[blockIdx.y];       // (64, N) row-major
+  const double* Dg = dinv + (int64_t)blockIdx.y * BIG_NB * BIG_NB;
+  const int t = threadIdx.x;
+  const int e0 = tile * BIG_NB;
+  if (e0 == k0) {                                // the pivot block itself (uniform per workgroup)
+    if (col) {
+      for (int e = t; e < BIG_NB * BIG_NB; e += 256) {
+        S[(int64_t)(k0 + e / BIG_NB) * N + k0 + e % BIG_NB] = Dg[e];
+        R[(int64_t)(e / BIG_NB) * N + k0 + e % BIG_NB] = 0.0;
       }
-    __syncthreads();
+    } else {
+      for (int e = t; e < BIG_NB * BIG_NB; e += 256) F[(int64_t)(k0 + e / BIG_NB) * BIG_NB + e % BIG_NB] = 0.0;
+    }
+    return;
   }
-  // row tiles I: F[I] = S[I, K] saved (pivot rows zeroed); S[I, K] = -F[I] D^-1 for I != K
-  for (int i0 = 0; i0 < N; i0 += BIG_NB) {
-    if (i0 == k0) {
-      for (int e = t; e < BIG_NB * BIG_NB; e += 256) F[(int64_t)(i0 + e / BIG_NB) * BIG_NB + e % BIG_NB] = 0.0;
-      continue;                                   // uniform branch: no barrier skipped inside
-    }
-    for (int e = t; e < BIG_NB * BIG_NB; e += 256) {
-      const double v = S[(int64_t)(i0 + e / BIG_NB) * N + k0 + e % BIG_NB];
-      T[e / BIG_NB][e % BIG_NB] = v;
-      F[(int64_t)(i0 + e / BIG_NB) * BIG_NB + e % BIG_NB] = v;
-    }
-    __syncthreads();
-    double acc[4][4];
+  // operands: column tile  A = D^-1 (ld 64),  B = S[K, J] (ld N);   row tile  A = S[I, K] (ld N),  B = D^-1 (ld 64)
+  const double* A = col ? Dg : S + (int64_t)e0 * N + k0;
+  const double* B = col ? S + (int64_t)k0 * N + e0 : Dg;
+  const int lda = col ? BIG_NB : N, ldb = col ? N : BIG_NB;
+  const int wave = t >> 6, lane = t & 63;
+  const int r0 = (wave >> 1) * 32, c0 = (wave & 1) * 32;
+  const int lm = lane & 15, lk = lane >> 4;
+  if (!col)                                       // save F[I] = S[I, K] before it is overwritten
+    for (int e = t; e < BIG_NB * BIG_NB; e += 256)
+      F[(int64_t)(e0 + e / BIG_NB) * BIG_NB + e % BIG_NB] = S[(int64_t)(e0 + e / BIG_NB) * N + k0 + e % BIG_NB];
+  big_d4 acc[2][2];
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
+  for (int a = 0; a < 2; ++a)
 #pragma unroll
-      for (int b = 0; b < 4; ++b) acc[a][b] = 0.0;
-    for (int k = 0; k < BIG_NB; ++k) {
-      double tv[4], dv[4];
-#pragma unroll
-      for (int a = 0; a < 4; ++a) tv[a] = T[4 * ti + a][k];
-#pragma unroll
-      for (int b = 0; b < 4; ++b) dv[b] = D[k][4 * tj + b];
-#pragma unroll
-      for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_fma(tv[a], dv[b], acc[a][b]);
-    }
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-      for (int b = 0; b < 4; ++b) S[(int64_t)(i0 + 4 * ti + a) * N + k0 + 4 * tj + b] = -acc[a][b];
-    __syncthreads();
+    for (int b = 0; b < 2; ++b) acc[a][b] = (big_d4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll 4
+  for (int kk = 0; kk < BIG_NB; kk += 4) {
+    const double a0 = A[(int64_t)(r0 + lm) * lda + kk + lk];
+    const double a1 = A[(int64_t)(r0 + 16 + lm) * lda + kk + lk];
+    const double b0 = B[(int64_t)(kk + lk) * ldb + c0 + lm];
+    const double b1 = B[(int64_t)(kk + lk) * ldb + c0 + 16 + lm];
+    acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
+    acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
+    acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
+    acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
   }
+  __syncthreads();                                // the product overwrites one of its operands: all reads first
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int r = r0 + 16 * a + lk + 4 * g, c = c0 + 16 * b + lm;
+        if (col) {
+          S[(int64_t)(k0 + r) * N + e0 + c] = acc[a][b][g];
+          R[(int64_t)r * N + e0 + c] = acc[a][b][g];
+        } else {
+          S[(int64_t)(e0 + r) * N + k0 + c] = -acc[a][b][g];
+        }
+      }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// 2b. trailing update S[I,J] -= F[I] R[J] on the FP64 matrix cores: workgroup = one 64 x 64 tile of one patch, wave =
-//     32 x 32 quarter = 2 x 2 MFMA blocks, K = 64 in 16 steps of v_mfma_f64_16x16x4_f64.
-//     Operand maps (cdna_hip_programming.md): A[m = lane & 15][k = lane >> 4], B[k = lane >> 4][n = lane & 15],
-//     C/D: col = lane & 15, row = (lane >> 4) + 4 reg.  The panels are small (1.3 MB per patch) and L2-resident, so the
-//     operands are read straight from global memory: 15.9 TFLOP/s over the whole factorisation, 27 % MFMA-busy
-//     (SQ_VALU_MFMA_BUSY_CYCLES).  A variant staging both 64 x 64 operand tiles through LDS in MFMA lane order was
-//     measured SLOWER (10.8 TFLOP/s: 64 KB of LDS per workgroup leave 2 waves per SIMD, too few to cover the fill and the
-//     read-modify-write of S), and so was a 64 x 64 register tile per wave (9.5 TFLOP/s: 128 accumulator VGPRs, occupancy).
-//     The rank-64 update re-streams S once per step: 20 steps x 26 MB per 1275-dof patch = 0.26 s of HBM time for 3000
-//     patches, a third of the measured 0.78 s -- a 128-wide pivot block halves that and is the next step.
+// 2b. trailing update S[I,J] -= F[I] R[J] on the FP64 matrix cores: workgroup = one 64 x 64 tile of one patch, K = 64.
+//     History (config-5 setup, 1765 + 303 patches): fragments read straight from global memory 0.75 s (16 TFLOP/s, 24 %
+//     MFMA-busy); staging BOTH whole 64 x 64 operand tiles through LDS (64 KB per workgroup, 2 waves per SIMD) was slower,
+//     and so was a 64 x 64 register tile per wave (128 accumulator VGPRs); the 16-deep double-buffered slices of
+//     big_tile_product (32 KB) are faster: 0.62 s.  The rank-64 update re-streams S once per step -- (n/64) 16 n^2 bytes
+//     per patch, 0.24 s of HBM time here -- so a 128-wide pivot block is what would help next.
 // ---------------------------------------------------------------------------------------------------------------------
-typedef double big_d4 __attribute__((ext_vector_type(4)));
+// 64 x 64 tile product on the matrix cores, shared by the trailing update (K = 64) and the polish products (K = N):
+// acc += A[0:64, 0:K] B[0:K, 0:64], A row-major with leading dimension lda, B row-major with ldb.  Both operands pass
+// through LDS in 16-deep k slices, double-buffered (one barrier per slice); the left operand is transposed on the way in
+// (k-major, so that the 16 lanes of an MFMA A fragment read consecutive doubles); global loads are 32 B per lane along the
+// rows.  Wave w owns the 32 x 32 quarter (w >> 1, w & 1) = 2 x 2 MFMA blocks.
+// Operand maps (cdna_hip_programming.md): A[m = lane & 15][k = lane >> 4], B[k = lane >> 4][n = lane & 15],
+// C/D: col = lane & 15, row = (lane >> 4) + 4 reg.
+constexpr int BIG_BK = 16;
+__device__ __forceinline__ void big_tile_product(const double* __restrict__ A, int lda, const double* __restrict__ B, int ldb,
+                                                 int K, double (*As)[BIG_BK][BIG_NB], double (*Bs)[BIG_BK][BIG_NB],
+                                                 big_d4 (&acc)[2][2]) {
+  const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
+  const int wr0 = (wave >> 1) * 32, wc0 = (wave & 1) * 32;
+  const int lm = lane & 15, lk = lane >> 4;
+  // staging roles: A slice 64 rows x 16 k (thread: row t / 4, 4 k's), B slice 16 k x 64 columns (thread: k t / 16, 4 columns)
+  const int arow = t >> 2, akq = (t & 3) * 4;
+  const int bk = t >> 4, bnq = (t & 15) * 4;
+  const double* Ag = A + (int64_t)arow * lda + akq;
+  const double* Bg = B + (int64_t)bk * ldb + bnq;
+  big_d4 ra = *reinterpret_cast<const big_d4*>(Ag);
+  big_d4 rb = *reinterpret_cast<const big_d4*>(Bg);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) As[0][akq + i][arow] = ra[i];
+  *reinterpret_cast<big_d4*>(&Bs[0][bk][bnq]) = rb;
+  __syncthreads();
+  int cur = 0;
+  for (int kk = 0; kk < K; kk += BIG_BK) {
+    const bool more = kk + BIG_BK < K;
+    if (more) {
+      ra = *reinterpret_cast<const big_d4*>(Ag + kk + BIG_BK);
+      rb = *reinterpret_cast<const big_d4*>(Bg + (int64_t)(kk + BIG_BK) * ldb);
+    }
+#pragma unroll
+    for (int s4 = 0; s4 < BIG_BK; s4 += 4) {
+      const double a0 = As[cur][s4 + lk][wr0 + lm];
+      const double a1 = As[cur][s4 + lk][wr0 + 16 + lm];
+      const double b0 = Bs[cur][s4 + lk][wc0 + lm];
+      const double b1 = Bs[cur][s4 + lk][wc0 + 16 + lm];
+      acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+    }
+    if (more) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) As[cur ^ 1][akq + i][arow] = ra[i];
+      *reinterpret_cast<big_d4*>(&Bs[cur ^ 1][bk][bnq]) = rb;
+    }
+    __syncthreads();
+    cur ^= 1;
+  }
+}
 
 __global__ __launch_bounds__(256) void big_update_kernel(int k0, const int64_t* __restrict__ patch_ptr, int64_t p0,
                                                           const int64_t* __restrict__ scr_ptr, double* __restrict__ scr,
                                                           const int64_t* __restrict__ pan_ptr,
                                                           const double* __restrict__ panF,
                                                           const double* __restrict__ panR, int tiles_max) {
+  __shared__ double As[2][BIG_BK][BIG_NB];
+  __shared__ double Bs[2][BIG_BK][BIG_NB];
   const int64_t p = p0 + blockIdx.y;
   const int n = (int)(patch_ptr[p + 1] - patch_ptr[p]);
   const int N = (n + BIG_NB - 1) / BIG_NB * BIG_NB;
@@ -207,17 +268,7 @@ __global__ __launch_bounds__(256) void big_update_kernel(int k0, const int64_t* 
   for (int a = 0; a < 2; ++a)
 #pragma unroll
     for (int b = 0; b < 2; ++b) acc[a][b] = (big_d4){0.0, 0.0, 0.0, 0.0};
-#pragma unroll 4
-  for (int kk = 0; kk < BIG_NB; kk += 4) {
-    const double a0 = F[(int64_t)(r0 + lm) * BIG_NB + kk + lk];
-    const double a1 = F[(int64_t)(r0 + 16 + lm) * BIG_NB + kk + lk];
-    const double b0 = R[(int64_t)(kk + lk) * N + c0 + lm];
-    const double b1 = R[(int64_t)(kk + lk) * N + c0 + 16 + lm];
-    acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
-    acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
-    acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
-    acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
-  }
+  big_tile_product(F + (int64_t)ti * BIG_NB * BIG_NB, BIG_NB, R + tj * BIG_NB, N, BIG_NB, As, Bs, acc);
 #pragma unroll
   for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -235,11 +286,14 @@ __global__ __launch_bounds__(256) void big_update_kernel(int k0, const int64_t* 
 //      (relative difference to LAPACK's inverse 2e-5 against 1e-10 for the scalar register kernel of the small patches,
 //      measured).  One polish step squares the error (measured afterwards: see DESIGN.md).
 //        mode 0: C = I - A B        mode 1: C = A0 + A B   (A0 = the left operand itself)
+//      big_tile_product with K = N: 35 TFLOP/s (the first version, fragments straight from global memory: 19.5).
 // ---------------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void big_gemm_kernel(int mode, const int64_t* __restrict__ patch_ptr, int64_t p0,
                                                         const int64_t* __restrict__ scr_ptr,
                                                         const double* __restrict__ Aall, const double* __restrict__ Ball,
                                                         double* __restrict__ Call, int tiles_max) {
+  __shared__ double As[2][BIG_BK][BIG_NB];            // [k][m]
+  __shared__ double Bs[2][BIG_BK][BIG_NB];            // [k][n]
   const int64_t p = p0 + blockIdx.y;
   const int n = (int)(patch_ptr[p + 1] - patch_ptr[p]);
   const int N = (n + BIG_NB - 1) / BIG_NB * BIG_NB;
@@ -250,24 +304,15 @@ __global__ __launch_bounds__(256) void big_gemm_kernel(int mode, const int64_t* 
   const double* B = Ball + scr_ptr[blockIdx.y];
   double* C = Call + scr_ptr[blockIdx.y];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int r0 = ti * BIG_NB + (wave >> 1) * 32, c0 = tj * BIG_NB + (wave & 1) * 32;
+  const int wr0 = (wave >> 1) * 32, wc0 = (wave & 1) * 32;
   const int lm = lane & 15, lk = lane >> 4;
   big_d4 acc[2][2];
 #pragma unroll
   for (int a = 0; a < 2; ++a)
 #pragma unroll
     for (int b = 0; b < 2; ++b) acc[a][b] = (big_d4){0.0, 0.0, 0.0, 0.0};
-#pragma unroll 4
-  for (int kk = 0; kk < N; kk += 4) {
-    const double a0 = A[(int64_t)(r0 + lm) * N + kk + lk];
-    const double a1 = A[(int64_t)(r0 + 16 + lm) * N + kk + lk];
-    const double b0 = B[(int64_t)(kk + lk) * N + c0 + lm];
-    const double b1 = B[(int64_t)(kk + lk) * N + c0 + 16 + lm];
-    acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
-    acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
-    acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
-    acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
-  }
+  big_tile_product(A + (int64_t)ti * BIG_NB * N, N, B + tj * BIG_NB, N, N, As, Bs, acc);
+  const int r0 = ti * BIG_NB + wr0, c0 = tj * BIG_NB + wc0;
 #pragma unroll
   for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -452,10 +497,10 @@ struct BigSource {
       hipLaunchKernelGGL(big_dense_fill_kernel, dim3(64, (unsigned)nb), block, 0, ctx->stream, p0, T->m, T->KII, T->DII,
                          T->nu, T->gamma, d_scr_ptr, dst);
     } else if (L->bs == 2) {
-      hipLaunchKernelGGL(big_gather_kernel<2>, dim3((unsigned)nb), block, 0, ctx->stream, p0, L->A.rowptr, L->A.colidx,
+      hipLaunchKernelGGL(big_gather_kernel<2>, dim3(16, (unsigned)nb), block, 0, ctx->stream, p0, L->A.rowptr, L->A.colidx,
                          L->A.vals, L->A.flat, L->patch_ptr, L->patch_dofs, d_scr_ptr, dst);
     } else {
-      hipLaunchKernelGGL(big_gather_kernel<3>, dim3((unsigned)nb), block, 0, ctx->stream, p0, L->A.rowptr, L->A.colidx,
+      hipLaunchKernelGGL(big_gather_kernel<3>, dim3(16, (unsigned)nb), block, 0, ctx->stream, p0, L->A.rowptr, L->A.colidx,
                          L->A.vals, L->A.flat, L->patch_ptr, L->patch_dofs, d_scr_ptr, dst);
     }
   }
@@ -470,71 +515,100 @@ static int big_factor_core(alfi_ctx* ctx, const BigSource& src, int64_t npatch, 
   const int64_t limit = env ? (int64_t)atoll(env) << 20 : budget;
   const bool polish = !(getenv("ALFI_BIG_POLISH") && atoi(getenv("ALFI_BIG_POLISH")) == 0);
   const int64_t nscr = polish ? 3 : 1;            // X | a second copy of A_p | I - A X
-  int64_t p0 = 0;
-  while (p0 < npatch) {
-    // batch [p0, p1)
+  // batches [p0, p1) within the scratch budget
+  struct Batch {
+    int64_t p0, p1, sdoubles, pdoubles;
+    int Nmax;
     std::vector<int64_t> scr_ptr, pan_ptr;
-    int64_t sdoubles = 0, pdoubles = 0, p1 = p0;
-    int Nmax = 0;
+  };
+  std::vector<Batch> batches;
+  int64_t smax = 0, pmax = 0, nbmax = 0;
+  for (int64_t p0 = 0; p0 < npatch;) {
+    Batch B;
+    B.p0 = p0;
+    B.sdoubles = B.pdoubles = 0;
+    B.Nmax = 0;
+    int64_t p1 = p0;
     while (p1 < npatch) {
       const int n = (int)(h_patch_ptr[p1 + 1] - h_patch_ptr[p1]);
       const int N = (n + BIG_NB - 1) / BIG_NB * BIG_NB;
       const int64_t need = ((int64_t)nscr * N * N + 2 * (int64_t)N * BIG_NB) * 8;
-      if (p1 > p0 && (nscr * sdoubles + 2 * pdoubles) * 8 + need > limit) break;
-      scr_ptr.push_back(sdoubles);
-      pan_ptr.push_back(pdoubles);
-      sdoubles += (int64_t)N * N;
-      pdoubles += (int64_t)N * BIG_NB;
-      if (N > Nmax) Nmax = N;
+      if (p1 > p0 && (nscr * B.sdoubles + 2 * B.pdoubles) * 8 + need > limit) break;
+      B.scr_ptr.push_back(B.sdoubles);
+      B.pan_ptr.push_back(B.pdoubles);
+      B.sdoubles += (int64_t)N * N;
+      B.pdoubles += (int64_t)N * BIG_NB;
+      if (N > B.Nmax) B.Nmax = N;
       ++p1;
     }
-    const int64_t nb = p1 - p0;
-    double *scr = nullptr, *scrA = nullptr, *scrR = nullptr, *panF = nullptr, *panR = nullptr;
-    int64_t *d_scr_ptr = nullptr, *d_pan_ptr = nullptr;
-    hipError_t e = hipMalloc((void**)&scr, (size_t)sdoubles * 8);
-    if (e == hipSuccess && polish) e = hipMalloc((void**)&scrA, (size_t)sdoubles * 8);
-    if (e == hipSuccess && polish) e = hipMalloc((void**)&scrR, (size_t)sdoubles * 8);
-    if (e == hipSuccess) e = hipMalloc((void**)&panF, (size_t)pdoubles * 8);
-    if (e == hipSuccess) e = hipMalloc((void**)&panR, (size_t)pdoubles * 8);
-    if (e == hipSuccess) e = hipMalloc((void**)&d_scr_ptr, (size_t)nb * 8);
-    if (e == hipSuccess) e = hipMalloc((void**)&d_pan_ptr, (size_t)nb * 8);
-    if (e == hipSuccess) e = hipMemcpyAsync(d_scr_ptr, scr_ptr.data(), (size_t)nb * 8, hipMemcpyHostToDevice, ctx->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(d_pan_ptr, pan_ptr.data(), (size_t)nb * 8, hipMemcpyHostToDevice, ctx->stream);
-    if (e == hipSuccess) {
-      dim3 block(256);
-      src.fill(ctx, p0, nb, d_scr_ptr, scr);
-      const int tiles = Nmax / BIG_NB;
-      for (int k0 = 0; k0 < Nmax; k0 += BIG_NB) {
-        hipLaunchKernelGGL(big_panel_kernel, dim3((unsigned)nb), block, 0, ctx->stream, k0, d_patch_ptr, p0, d_scr_ptr, scr,
-                           d_pan_ptr, panF, panR, status);
-        hipLaunchKernelGGL(big_update_kernel, dim3((unsigned)(tiles * tiles), (unsigned)nb), block, 0, ctx->stream, k0,
-                           d_patch_ptr, p0, d_scr_ptr, scr, d_pan_ptr, panF, panR, tiles);
-      }
-      const double* result = scr;
-      if (polish) {
-        // A_p once more (the inversion overwrote its copy), R = I - A X, X <- X + X R (into the buffer that held A_p)
-        src.fill(ctx, p0, nb, d_scr_ptr, scrA);
-        hipLaunchKernelGGL(big_gemm_kernel, dim3((unsigned)(tiles * tiles), (unsigned)nb), block, 0, ctx->stream, 0,
-                           d_patch_ptr, p0, d_scr_ptr, scrA, scr, scrR, tiles);
-        hipLaunchKernelGGL(big_gemm_kernel, dim3((unsigned)(tiles * tiles), (unsigned)nb), block, 0, ctx->stream, 1,
-                           d_patch_ptr, p0, d_scr_ptr, scr, scrR, scrA, tiles);
-        result = scrA;
-      }
-      hipLaunchKernelGGL(big_store_kernel, dim3(64, (unsigned)nb), block, 0, ctx->stream, p0, d_patch_ptr, d_inv_ptr,
-                         d_scr_ptr, result, inv);
-      e = hipGetLastError();
-      if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-    }
-    (void)hipFree(scr);
-    (void)hipFree(scrA);
-    (void)hipFree(scrR);
-    (void)hipFree(panF);
-    (void)hipFree(panR);
-    (void)hipFree(d_scr_ptr);
-    (void)hipFree(d_pan_ptr);
-    if (e != hipSuccess) return alfi_set_error(ctx, ALFI_E_HIP, "large-block factorisation failed: %s", hipGetErrorString(e));
+    B.p1 = p1;
+    smax = std::max(smax, B.sdoubles);
+    pmax = std::max(pmax, B.pdoubles);
+    nbmax = std::max(nbmax, p1 - p0);
     p0 = p1;
+    batches.push_back(std::move(B));
   }
+  // one arena for all batches, kept by the context (patches are re-factored every Newton step; hipMalloc / hipFree of
+  // gigabytes per batch cost more wall time than the kernels)
+  auto up = [](int64_t b) { return (size_t)((b + 255) & ~(int64_t)255); };
+  const size_t need = nscr * up(smax * 8) + 2 * up(pmax * 8) + up(nbmax * BIG_NB * BIG_NB * 8) + 2 * up(nbmax * 8);
+  if (ctx->big_arena_bytes < need) {
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipFree(ctx->big_arena);
+    ctx->big_arena = nullptr;
+    ctx->big_arena_bytes = 0;
+    hipError_t e = hipMalloc(&ctx->big_arena, need);
+    if (e != hipSuccess)
+      return alfi_set_error(ctx, ALFI_E_HIP, "large-block scratch of %zu bytes: %s", need, hipGetErrorString(e));
+    ctx->big_arena_bytes = need;
+  }
+  char* cur = static_cast<char*>(ctx->big_arena);
+  auto carve = [&](size_t bytes) { char* q = cur; cur += bytes; return q; };
+  double* scr = reinterpret_cast<double*>(carve(up(smax * 8)));
+  double* scrA = polish ? reinterpret_cast<double*>(carve(up(smax * 8))) : nullptr;
+  double* scrR = polish ? reinterpret_cast<double*>(carve(up(smax * 8))) : nullptr;
+  double* panF = reinterpret_cast<double*>(carve(up(pmax * 8)));
+  double* panR = reinterpret_cast<double*>(carve(up(pmax * 8)));
+  double* dinv = reinterpret_cast<double*>(carve(up(nbmax * BIG_NB * BIG_NB * 8)));
+  int64_t* d_scr_ptr = reinterpret_cast<int64_t*>(carve(up(nbmax * 8)));
+  int64_t* d_pan_ptr = reinterpret_cast<int64_t*>(carve(up(nbmax * 8)));
+  hipError_t e = hipSuccess;
+  const dim3 block(256);
+  for (const Batch& B : batches) {
+    const int64_t p0 = B.p0, nb = B.p1 - B.p0;
+    // (pageable host source: the copy has left the host buffer when the call returns; the stream orders it after the
+    // previous batch's kernels)
+    e = hipMemcpyAsync(d_scr_ptr, B.scr_ptr.data(), (size_t)nb * 8, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_pan_ptr, B.pan_ptr.data(), (size_t)nb * 8, hipMemcpyHostToDevice, ctx->stream);
+    if (e != hipSuccess) break;
+    src.fill(ctx, p0, nb, d_scr_ptr, scr);
+    if (polish)   // the elimination overwrites its copy of A_p; the polish needs A_p again
+      (void)hipMemcpyAsync(scrA, scr, (size_t)B.sdoubles * 8, hipMemcpyDeviceToDevice, ctx->stream);
+    const int tiles = B.Nmax / BIG_NB;
+    for (int k0 = 0; k0 < B.Nmax; k0 += BIG_NB) {
+      hipLaunchKernelGGL(big_pivot_kernel, dim3((unsigned)nb), block, 0, ctx->stream, k0, d_patch_ptr, p0, d_scr_ptr, scr,
+                         dinv, status);
+      hipLaunchKernelGGL(big_panel_kernel, dim3((unsigned)(2 * tiles), (unsigned)nb), block, 0, ctx->stream, k0,
+                         d_patch_ptr, p0, d_scr_ptr, scr, d_pan_ptr, panF, panR, dinv, tiles);
+      hipLaunchKernelGGL(big_update_kernel, dim3((unsigned)(tiles * tiles), (unsigned)nb), block, 0, ctx->stream, k0,
+                         d_patch_ptr, p0, d_scr_ptr, scr, d_pan_ptr, panF, panR, tiles);
+    }
+    const double* result = scr;
+    if (polish) {
+      // R = I - A X, X <- X + X R (into the buffer that held the copy of A_p)
+      hipLaunchKernelGGL(big_gemm_kernel, dim3((unsigned)(tiles * tiles), (unsigned)nb), block, 0, ctx->stream, 0,
+                         d_patch_ptr, p0, d_scr_ptr, scrA, scr, scrR, tiles);
+      hipLaunchKernelGGL(big_gemm_kernel, dim3((unsigned)(tiles * tiles), (unsigned)nb), block, 0, ctx->stream, 1,
+                         d_patch_ptr, p0, d_scr_ptr, scr, scrR, scrA, tiles);
+      result = scrA;
+    }
+    hipLaunchKernelGGL(big_store_kernel, dim3(64, (unsigned)nb), block, 0, ctx->stream, p0, d_patch_ptr, d_inv_ptr,
+                       d_scr_ptr, result, inv);
+    e = hipGetLastError();
+    if (e != hipSuccess) break;
+  }
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  if (e != hipSuccess) return alfi_set_error(ctx, ALFI_E_HIP, "large-block factorisation failed: %s", hipGetErrorString(e));
   return 0;
 }
 
