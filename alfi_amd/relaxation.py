@@ -225,6 +225,7 @@ class OrderedRelaxation(object):
             patches.append(np.asarray(points, dtype=np.int64))
             seeds.append(entity)
         centroids = [self.coords(dm, p) for p in seeds]
+        self.seeds = seeds                      # seed entity of every patch (not in the reference; the partitioner wants it)
         return patches, self.iteration_order(centroids)
 
 

@@ -39,9 +39,11 @@ def macro_star_patches(V):
 
         def getOptionsPrefix(self):
             return ""
-    patches, iterset = MacroStar()(_PC())
+    ms = MacroStar()
+    patches, iterset = ms(_PC())
     ptr, dofs, kept = patch_points_to_dofs(V, dm, patches)
-    return ptr, dofs
+    seeds = np.array([ms.seeds[i] - dm.vStart for i in kept], dtype=np.int64)     # the macro vertex of every patch
+    return ptr, dofs, seeds
 
 
 def _coarse_macro_cell_of_nodes(Vf):
@@ -195,8 +197,7 @@ def build_sv_hierarchy(problem, nref, k, Re, gamma=1e4, advect=True, patches=Tru
         L.bc_dofs = V.bc_dofs
         L.nu, L.gamma = nu, gamma
         if patches and l > 0:
-            L.patch_ptr, L.patch_dofs = macro_star_patches(V)
-            L.patch_seeds = None
+            L.patch_ptr, L.patch_dofs, L.patch_seeds = macro_star_patches(V)
         if l > 0:
             transfers.append(build_sv_transfer_data(Vprev, V, nu, gamma, (rowptr, colidx)))
         levels.append(L)

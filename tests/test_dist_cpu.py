@@ -19,12 +19,20 @@ CASES = {
     "3d-P1FB": (3, 2, 1, 1, 100.0, 2, 1),
     # three 3-D levels, the middle one owned by rank 0 alone, the finest split (the shape of the config-4 run)
     "3d-P2FB-3lev": (3, 1, 2, 2, 100.0, 2, 3000),
+    # Scott-Vogelius: macro-star patches (wider ghost layer: solver.py:661-662 asks for overlap 2), macro-cell transfer blocks
+    "2d-SV": ("sv2", 2, 2, 2, 100.0, 3, 1),
+    "3d-SV-P3": ("sv3", 1, 1, 3, 100.0, 2, 1),
 }
 
 
 def _hier(case):
     from alfi_amd.problem import TwoDimLidDrivenCavityProblem, ThreeDimLidDrivenCavityProblem, build_hierarchy
     dim, baseN, nref, ke, Re, k, min_dofs = CASES[case]
+    if dim in ("sv2", "sv3"):
+        from alfi_amd.sv import build_sv_hierarchy
+        prob = TwoDimLidDrivenCavityProblem(baseN) if dim == "sv2" else ThreeDimLidDrivenCavityProblem(baseN)
+        lv, tr = build_sv_hierarchy(prob, nref, ke, Re=Re)
+        return lv, tr, k, min_dofs
     prob = TwoDimLidDrivenCavityProblem(baseN) if dim == 2 else ThreeDimLidDrivenCavityProblem(baseN)
     lv, tr = build_hierarchy(prob, nref, ke, Re=Re)
     return lv, tr, k, min_dofs
@@ -68,7 +76,8 @@ def _free_port():
 
 @pytest.mark.parametrize("case,world,robust", [("2d-all-distributed", 2, False), ("2d-all-distributed", 3, True),
                                                ("2d-coarse-on-rank0", 2, True), ("3d-P2FB", 2, False),
-                                               ("3d-P1FB", 2, True), ("3d-P2FB-3lev", 4, True)])
+                                               ("3d-P1FB", 2, True), ("3d-P2FB-3lev", 4, True),
+                                               ("2d-SV", 3, True), ("3d-SV-P3", 2, True)])
 def test_spmd_oracle_matches_serial(case, world, robust):
     import torch.multiprocessing as mp
     from oracle import alfi_oracle as O

@@ -24,7 +24,8 @@ def _free_port():
 
 @pytest.mark.parametrize("case,world,robust,overlap", [("2d-all-distributed", 2, 0, "1"), ("2d-coarse-on-rank0", 3, 1, "1"),
                                                        ("3d-P2FB", 2, 0, "1"), ("3d-P1FB", 3, 1, "1"),
-                                                       ("3d-P2FB-3lev", 4, 1, "1"), ("3d-P2FB", 2, 1, "0")])
+                                                       ("3d-P2FB-3lev", 4, 1, "1"), ("3d-P2FB", 2, 1, "0"),
+                                                       ("2d-SV", 3, 1, "1"), ("3d-SV-P3", 2, 1, "1")])
 def test_partitioned_cycles_match_single_gpu(case, world, robust, overlap, tmp_path):
     from alfi_amd import hip
     from oracle import alfi_oracle as O
