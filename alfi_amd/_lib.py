@@ -77,6 +77,7 @@ SIGNATURES = {
     "alfi_saddle_create": (ctypes.c_int, [vp, ctypes.POINTER(CsrHost), ctypes.POINTER(CsrHost), vp, ctypes.c_double,
                                           ctypes.c_double, ctypes.c_int, ctypes.POINTER(vp)]),
     "alfi_saddle_destroy": (ctypes.c_int, [vp]),
+    "alfi_saddle_set_mass_inverse": (ctypes.c_int, [vp, ctypes.POINTER(CsrHost)]),
     "alfi_saddle_update": (ctypes.c_int, [vp, ctypes.c_double, ctypes.c_double]),
     "alfi_saddle_solve": (ctypes.c_int, [vp, vp, vp, ctypes.c_double, ctypes.c_double, ctypes.c_int, ctypes.c_int,
                                          ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_double)]),

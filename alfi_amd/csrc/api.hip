@@ -1262,6 +1262,7 @@ int alfi_saddle_destroy(alfi_saddle* S) {
   (void)hipStreamSynchronize(S->ctx->stream);
   free_csr(&S->B);
   free_csr(&S->BT);
+  if (S->has_Minv) free_csr(&S->Minv);
   dev_free(S->minv);
   dev_free(S->V);
   dev_free(S->Z);
@@ -1290,12 +1291,27 @@ int alfi_saddle_mult(alfi_saddle* S, const double* dx, double* dy) {
 }
 
 // PCFIELDSPLIT, Schur, full factorisation [3P] with the sub-solvers of solver.py:359-391
+int alfi_saddle_set_mass_inverse(alfi_saddle* S, const alfi_csr_host* Minv) {
+  alfi_ctx* ctx = S->ctx;
+  if (!Minv || Minv->nrows != S->np_dofs || Minv->ncols != S->np_dofs)
+    return alfi_set_error(ctx, ALFI_E_ARG, "mass inverse must be %lld x %lld", (long long)S->np_dofs, (long long)S->np_dofs);
+  ALFI_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  if (S->has_Minv) free_csr(&S->Minv);
+  S->has_Minv = false;
+  ALFI_CHECK(upload_csr(ctx, &S->Minv, Minv));
+  S->has_Minv = true;
+  return 0;
+}
+
 int alfi_saddle_precond(alfi_saddle* S, const double* dx, double* dy) {
   alfi_ctx* ctx = S->ctx;
   const int64_t nu = S->nu_dofs, np = S->np_dofs;
   ALFI_CHECK(alfi_mg_fcycle(S->mg, dx, dy));                                    // y_u = MG(b_u)
   ALFI_CHECK(launch_csr_spmv(ctx, S->B, dy, S->tmp_p, dx + nu, 1.0, 1));        // q = b_p - B y_u
-  ALFI_CHECK(launch_scale_rows(ctx, dy + nu, S->tmp_p, S->minv, -(S->nu + S->gamma), np));   // y_p = -(nu+gamma) M^-1 q
+  if (S->has_Minv)                                                                // y_p = -(nu+gamma) M^-1 q
+    ALFI_CHECK(launch_csr_spmv(ctx, S->Minv, S->tmp_p, dy + nu, nullptr, -(S->nu + S->gamma), 3));
+  else
+    ALFI_CHECK(launch_scale_rows(ctx, dy + nu, S->tmp_p, S->minv, -(S->nu + S->gamma), np));
   ALFI_CHECK(launch_csr_spmv(ctx, S->BT, dy + nu, S->tmp_u, dx, 1.0, 1));       // t = b_u - B^T y_p
   ALFI_CHECK(alfi_mg_fcycle(S->mg, S->tmp_u, dy));                              // y_u = MG(t)
   if (S->remove_nullspace) ALFI_CHECK(launch_remove_mean(ctx, dy + nu, np));

@@ -225,6 +225,8 @@ struct alfi_saddle {
   int64_t nu_dofs = 0, np_dofs = 0;
   DevCSR B, BT;
   double* minv = nullptr;  // 1 / diag(M_p)
+  DevCSR Minv;             // block-diagonal inverse mass matrix of a discontinuous P_k pressure (alfi_saddle_set_mass_inverse)
+  bool has_Minv = false;
   double nu = 0, gamma = 0;
   bool remove_nullspace = false;
   // outer FGMRES workspace

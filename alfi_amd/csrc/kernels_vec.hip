@@ -898,7 +898,8 @@ __global__ __launch_bounds__(256) void csr_spmv_kernel(int64_t nrows, const int3
     for (int32_t k = rowptr[row] + l; k < rowptr[row + 1]; k += LPR) acc = __builtin_fma(vals[k], x[colidx[k]], acc);
 #pragma unroll
   for (int o = LPR / 2; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
-  if (row < nrows && l == 0) y[row] = mode == 0 ? acc : (mode == 1 ? b[row] - alpha * acc : y[row] + acc);
+  if (row < nrows && l == 0)
+    y[row] = mode == 0 ? acc : (mode == 1 ? b[row] - alpha * acc : (mode == 3 ? alpha * acc : y[row] + acc));
 }
 
 int launch_csr_spmv(alfi_ctx* ctx, const DevCSR& A, const double* x, double* y, const double* b, double alpha,

@@ -333,8 +333,9 @@ class Saddle(object):
     """Outer solve of one Newton step (alfi/solver.py:386-422): FGMRES around PCFIELDSPLIT-Schur-full with the device
     multigrid as fieldsplit_0 and DGMassInv (solver.py:15-38) as fieldsplit_1."""
 
-    def __init__(self, mg, B, mass_diag, nu, gamma, remove_constant_nullspace=True):
-        """mg: hip.Multigrid; B: scipy CSR (pressure dofs x velocity dofs); mass_diag: diagonal of the P0 mass matrix."""
+    def __init__(self, mg, B, mass_diag, nu, gamma, remove_constant_nullspace=True, mass_inv=None):
+        """mg: hip.Multigrid; B: scipy CSR (pressure dofs x velocity dofs); mass_diag: diagonal of the P0 mass matrix;
+        mass_inv: scipy sparse inverse of a block-diagonal (discontinuous P_k) pressure mass matrix, replaces mass_diag."""
         import scipy.sparse as sp
         self.mg, self.ctx = mg, mg.ctx
         B = sp.csr_matrix(B)
@@ -350,6 +351,8 @@ class Saddle(object):
             keep.extend([rp, ci, va])
             return CsrHost(M.shape[0], M.shape[1], _ptr(rp), _ptr(ci), _ptr(va))
         sB, sBT = st(B), st(BT)
+        if mass_diag is None:
+            mass_diag = np.ones(B.shape[0])
         md = np.ascontiguousarray(mass_diag, dtype=np.float64)
         h = vp()
         self.ctx.check(self.ctx.lib.alfi_saddle_create(mg.h, ctypes.byref(sB), ctypes.byref(sBT), _ptr(md), float(nu),
@@ -358,6 +361,11 @@ class Saddle(object):
         self.h = h
         self.n_u, self.n_p = B.shape[1], B.shape[0]
         self.n = self.n_u + self.n_p
+        if mass_inv is not None:
+            Mi = sp.csr_matrix(mass_inv)
+            Mi.sort_indices()
+            sM = st(Mi)
+            self.ctx.check(self.ctx.lib.alfi_saddle_set_mass_inverse(self.h, ctypes.byref(sM)))
 
     def update(self, nu, gamma):
         self.ctx.check(self.ctx.lib.alfi_saddle_update(self.h, float(nu), float(gamma)))

@@ -171,6 +171,38 @@ def build_sv_transfer_data(Vc, Vf, nu, gamma, graph):
     return T
 
 
+def build_sv_pressure_coupling(L, zero_bc_columns=True):
+    """The discontinuous P_{k-1} pressure space of ScottVogeliusSolver.function_space (solver.py:624-629) on the level's
+    (Alfeld-split) mesh, nodal basis psi per cell: the discrete divergence B[(c, j), (a, x)] = -int_c psi_j d_x phi_a
+    (``- div(u) * q * dx``, solver.py:619; Dirichlet velocity columns zeroed for the Jacobian) and the block-diagonal
+    pressure mass matrix with its inverse (what DGMassInv applies, solver.py:15-38).  With these the full grad-div term of
+    the level operator is gamma B^T M^-1 B (div [P_k]^d is contained in P_{k-1}^dg).  Returns scipy CSR (B, M, Minv)."""
+    from .elements import simplex_quadrature
+    V = L.V
+    mesh, d, el = V.mesh, V.dim, V.element
+    pel = NodalElement(d, el.degree - 1, False)
+    lam, wq = simplex_quadrature(d, 6)
+    phi, dphi = el.tabulate(lam)                                    # (q, a), (q, a, i)
+    psi = pel.tabulate(lam)[0]                                      # (q, j)
+    g, vol = mesh.cell_geometry()
+    nc, nloc, npl = mesh.num_cells, el.nloc, pel.nloc
+    ref = np.einsum("q,qj,qai->jai", wq, psi, dphi)                 # reference integrals of psi_j d_i phi_a
+    Bc = -np.einsum("c,jai,cix->cjax", vol, ref, g)                 # (c, j, a, x)
+    rows = np.repeat(np.arange(nc * npl), nloc * d)
+    cols = np.broadcast_to((V.cell_nodes[:, None, :, None] * d + np.arange(d)), (nc, npl, nloc, d)).ravel()
+    B = sp.csr_matrix((Bc.ravel(), (rows, cols)), shape=(nc * npl, V.num_dofs))
+    if zero_bc_columns:
+        keep = np.ones(V.num_dofs)
+        keep[V.bc_dofs] = 0.0
+        B = (B @ sp.diags(keep)).tocsr()
+    B.eliminate_zeros()
+    B.sort_indices()
+    mref = np.einsum("q,qj,ql->jl", wq, psi, psi)                   # reference mass matrix (unit volume)
+    M = sp.block_diag([mref], format="csr") if nc == 0 else sp.kron(sp.diags(vol), mref, format="csr")
+    Minv = sp.kron(sp.diags(1.0 / vol), np.linalg.inv(mref), format="csr")
+    return B, M, Minv
+
+
 def build_sv_hierarchy(problem, nref, k, Re, gamma=1e4, advect=True, patches=True):
     """The Scott-Vogelius analogue of ``problem.build_hierarchy``: levels 0..nref on the bary hierarchy."""
     dim = problem.dim

@@ -384,10 +384,15 @@ def main():
                     "host_peak_rss_GB": round(resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 1e6, 1)},
     }
     if args.outer:
-        from alfi_amd.problem import build_pressure_coupling
         t0 = time.time()
-        Bm, vol = build_pressure_coupling(L)
-        sad = hip.Saddle(dmg, Bm, vol, L.nu, L.gamma, remove_constant_nullspace=True)
+        if CONFIGS[args.config][0] == "sv":      # discontinuous P2 pressure, block DGMassInv; bfs3d has an outflow: no nullspace
+            from alfi_amd.sv import build_sv_pressure_coupling
+            Bm, _, Minv = build_sv_pressure_coupling(L)
+            sad = hip.Saddle(dmg, Bm, None, L.nu, L.gamma, remove_constant_nullspace=False, mass_inv=Minv)
+        else:
+            from alfi_amd.problem import build_pressure_coupling
+            Bm, vol = build_pressure_coupling(L)
+            sad = hip.Saddle(dmg, Bm, vol, L.nu, L.gamma, remove_constant_nullspace=True)
         t_b = time.time() - t0
         rtol, atol = (1e-9, 1e-10) if L.bs == 2 else (1e-8, 1e-8)          # solver.py:484-499
         dbb, dxx = ctx.vec(np.concatenate([b, np.zeros(Bm.shape[0])])), ctx.vec(L.n + Bm.shape[0])

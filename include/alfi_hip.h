@@ -218,6 +218,9 @@ typedef struct {
 int alfi_saddle_create(alfi_mg* mg, const alfi_csr_host* B, const alfi_csr_host* BT, const double* mass_diag_host,
                        double nu, double gamma, int remove_constant_nullspace, alfi_saddle** out);
 int alfi_saddle_destroy(alfi_saddle* s);
+/* Discontinuous P_k pressure (Scott-Vogelius, solver.py:624-629): DGMassInv's ``Tensor(inner(u, v)*dx).inv`` (solver.py:24) is
+ * block diagonal, one (k+1)(k+2)(k+3)/6 block per cell; pass it as scalar CSR (n_p x n_p).  Replaces mass_diag. */
+int alfi_saddle_set_mass_inverse(alfi_saddle* s, const alfi_csr_host* Minv);
 int alfi_saddle_update(alfi_saddle* s, double nu, double gamma);
 /* db, dx: device vectors of n_u + n_p doubles (velocity dofs first).  Zero initial guess.  Convergence as KSP's default
  * test on the (recurrence) residual norm: ||r|| <= max(rtol ||b||, atol); max_it iterations at most (solver.py:404,

@@ -403,21 +403,22 @@ def oracle_transfer(T, L, schoeberl_restriction=False):
 # and fieldsplit_1 = DGMassInv (alfi/solver.py:15-38, 386-422, 463-499)
 # ---------------------------------------------------------------------------------------------------------------------
 def saddle_solve(mg, A, B, mass_diag, nu, gamma, b, rtol=1e-8, atol=1e-8, max_it=500, restart=30,
-                 remove_constant_nullspace=True):
+                 remove_constant_nullspace=True, mass_inv=None):
     """[A B^T; B 0] x = b by right-preconditioned FGMRES(restart), classical Gram-Schmidt, zero initial guess, KSP's
     default convergence test on the recurrence residual.  Preconditioner (PCApply_FieldSplit_Schur, FULL [3P]):
     y_u = MG(b_u); y_p = -(nu + gamma) M_p^-1 (b_p - B y_u)  (DGMassInv.apply, solver.py:26-35); y_u = MG(b_u - B^T y_p);
     constants removed from y_p (the nullspace attached for enclosed flows).  Returns (x, iterations, residual history)."""
     nu_ = A.shape[0]
     n = nu_ + B.shape[0]
-    minv = 1.0 / np.asarray(mass_diag)
+    # mass_inv: sparse inverse of a block-diagonal (discontinuous P_k) pressure mass matrix, replaces mass_diag
+    minv = sp.diags(1.0 / np.asarray(mass_diag)) if mass_inv is None else sp.csr_matrix(mass_inv)
 
     def K(x):
         return np.concatenate([A @ x[:nu_] + B.T @ x[nu_:], B @ x[:nu_]])
 
     def P(v):
         yu = mg.fcycle(v[:nu_])
-        yp = -(nu + gamma) * minv * (v[nu_:] - B @ yu)
+        yp = -(nu + gamma) * (minv @ (v[nu_:] - B @ yu))
         yu = mg.fcycle(v[:nu_] - B.T @ yp)
         if remove_constant_nullspace:
             yp = yp - yp.mean()

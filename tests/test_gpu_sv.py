@@ -89,3 +89,40 @@ def test_sv_gamma_robustness_on_the_gpu():
     assert max(its.values()) <= 12 and its[1e6] - its[1e2] <= 2, its
     assert abs(its[1e4] - run_oracle(1e4, True)) <= 1
     ctx.close()
+
+
+@pytest.mark.parametrize("case", ["2d-p2", "3d-p3"])
+def test_sv_outer_solve_matches_oracle(case):
+    """One Newton-step linear solve with the discontinuous P_{k-1} pressure (alfi_saddle_set_mass_inverse: DGMassInv with
+    the cell-block mass inverse, solver.py:15-38, 624-629): iteration count and solution against the oracle."""
+    from alfi_amd import hip
+    from alfi_amd.problem import ThreeDimLidDrivenCavityProblem
+    from alfi_amd.sv import build_sv_pressure_coupling
+    from oracle import alfi_oracle as O
+    if case == "2d-p2":
+        lv, tr = build_sv_hierarchy(TwoDimLidDrivenCavityProblem(2), 2, 2, Re=10.0, gamma=1e4)
+        k = 6
+    else:
+        lv, tr = build_sv_hierarchy(ThreeDimLidDrivenCavityProblem(1), 1, 3, Re=10.0, gamma=1e4)
+        k = 4
+    L = lv[-1]
+    B, M, Minv = build_sv_pressure_coupling(L)
+    rng = np.random.default_rng(1)
+    b = rng.standard_normal(L.n)
+    b[L.bc_dofs] = 0
+    rhs = np.concatenate([b, np.zeros(B.shape[0])])
+    omg = O.build_oracle_mg(lv, tr, k, schoeberl_restriction=False)
+    xo, its_o, hist = O.saddle_solve(omg, omg.levels[-1]["A"], B, None, L.nu, L.gamma, rhs, rtol=1e-9, atol=1e-12,
+                                     mass_inv=Minv)
+    ctx = hip.Context(0)
+    mg = hip.Multigrid(ctx, lv, tr, k, robust_restriction=False)
+    sad = hip.Saddle(mg, B, None, L.nu, L.gamma, remove_constant_nullspace=True, mass_inv=Minv)
+    db, dx = ctx.vec(rhs), ctx.vec(L.n + B.shape[0])
+    its, rn = sad.solve(db, dx, 1e-9, 1e-12, 500, 30)
+    x = dx.get()
+    assert abs(its - its_o) <= 1 and its <= 12, (its, its_o)
+    assert rn <= 2e-9 * np.linalg.norm(rhs)
+    assert np.abs(x[:L.n] - xo[:L.n]).max() < 1e-6 * np.abs(xo[:L.n]).max()
+    sad.close()
+    mg.close()
+    ctx.close()

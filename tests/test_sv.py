@@ -99,3 +99,48 @@ def run(gamma, schoeberl):
 def test_sv_gamma_robustness():
     its = {g: run(g, True) for g in (0.0, 1e2, 1e4, 1e6)}
     assert max(its.values()) <= 12 and its[1e6] - its[1e2] <= 2, its
+
+
+@pytest.mark.parametrize("dim,k", [(2, 2), (3, 3)])
+def test_sv_pressure_coupling(dim, k):
+    """Discontinuous P_{k-1} pressure of the Scott-Vogelius pair (solver.py:624-629): div [P_k]^d lies in it, so the full
+    grad-div term is gamma B^T M^-1 B exactly, and M^-1 is the cell-wise inverse DGMassInv applies (solver.py:24)."""
+    from alfi_amd.problem import ThreeDimLidDrivenCavityProblem
+    from alfi_amd.sv import build_sv_pressure_coupling
+    prob = TwoDimLidDrivenCavityProblem(2) if dim == 2 else ThreeDimLidDrivenCavityProblem(1)
+    lv, tr = build_sv_hierarchy(prob, 1, k, Re=0, gamma=1.0, advect=False, patches=False)
+    L = lv[1]
+    B, M, Minv = build_sv_pressure_coupling(L, zero_bc_columns=False)
+    npl = {1: dim + 1, 2: (dim + 1) * (dim + 2) // 2}[k - 1]
+    assert B.shape == (L.V.mesh.num_cells * npl, L.n)
+    assert abs((M @ Minv) - np.eye(M.shape[0])).max() < 1e-10
+    D = O.assemble_form(L.V, gamma_full=1.0)
+    assert abs(D - B.T @ Minv @ B).max() < 1e-10 * abs(D).max()
+    # constants: B^T 1 = -int div(phi) = boundary flux only -> zero on interior velocity dofs
+    flux = B.T @ np.ones(B.shape[0])
+    interior = np.setdiff1d(np.arange(L.n), L.bc_dofs)
+    assert abs(flux[interior]).max() < 1e-12
+
+
+def test_sv_outer_solve_on_the_oracle():
+    """One Newton-step linear solve of the Scott-Vogelius discretisation (2-D, [P2]^2-P1dg, Re 10): FGMRES + fieldsplit
+    Schur full with the block DGMassInv converges in a handful of iterations (the reference's point, README.md:3)."""
+    from alfi_amd.sv import build_sv_pressure_coupling
+    lv, tr = build_sv_hierarchy(TwoDimLidDrivenCavityProblem(2), 2, 2, Re=10.0, gamma=1e4)
+    L = lv[-1]
+    B, M, Minv = build_sv_pressure_coupling(L)
+    mg = O.build_oracle_mg(lv, tr, 6, schoeberl_restriction=False)            # 6 smoothing steps in 2-D, solver.py:309
+    rng = np.random.default_rng(1)
+    b = rng.standard_normal(L.n)
+    b[L.bc_dofs] = 0
+    rhs = np.concatenate([b, np.zeros(B.shape[0])])
+    A = mg.levels[-1]["A"]
+    x, its, hist = O.saddle_solve(mg, A, B, None, L.nu, L.gamma, rhs, rtol=1e-9, atol=1e-12, mass_inv=Minv)
+    assert its <= 8, (its, hist)
+    K = sp_bmat(A, B)
+    assert np.linalg.norm(K @ x - rhs) <= 2e-9 * np.linalg.norm(rhs)
+
+
+def sp_bmat(A, B):
+    import scipy.sparse as sp
+    return sp.bmat([[A, B.T], [B, None]], format="csr")
