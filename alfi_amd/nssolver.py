@@ -22,11 +22,13 @@ from .problem import BSR, build_hierarchy, build_pressure_coupling
 from .solver import HipMG, mg_levels_solver, fieldsplit_0_mg, outer_solver
 
 
-def _assemble(L, nu, gamma, adv, wind, with_bc):
+def _assemble(L, nu, gamma, adv, wind, with_bc, full_div=False):
+    """full_div: the Scott-Vogelius grad-div term gamma (div u, div v) (solver.py:616) instead of the cell-averaged one."""
     V = L.V
     g, vol = V.mesh.cell_geometry()
     tens = V.element.reference_tensors()
-    A = _hostlib.assemble_bsr(V.cell_nodes, g, vol, tens, V.dim, L.A.rowptr, L.A.colidx, nu=nu, gamma=gamma, adv=adv,
+    A = _hostlib.assemble_bsr(V.cell_nodes, g, vol, tens, V.dim, L.A.rowptr, L.A.colidx, nu=nu,
+                              gamma=0.0 if full_div else gamma, gamma_full=gamma if full_div else 0.0, adv=adv,
                               wind=wind if adv else None)
     if with_bc:
         _hostlib.apply_bc_bsr(V.num_nodes, V.dim, L.A.rowptr, L.A.colidx, A, np.repeat(V.bc_node_mask, V.dim))
@@ -38,20 +40,42 @@ class HipNavierStokesSolver(object):
     keys Re, nu, linear_iter, nonlinear_iter, time."""
 
     def __init__(self, problem, nref, k, gamma=1e4, smoothing=None, restriction=False, ctx=None, verbose=False,
-                 snes_rtol=None, snes_atol=None, snes_max_it=20):
+                 snes_rtol=None, snes_atol=None, snes_max_it=20, discretisation="pkp0"):
+        """discretisation: "pkp0" ([P_k(+FB)]^d - P0 on the uniform hierarchy, ConstantPressureSolver solver.py:561-602) or
+        "sv" ([P_k]^d - P_{k-1}^dg on the barycentric hierarchy with macro-star patches, ScottVogeliusSolver :604-662)."""
         self.problem, self.gamma, self.verbose = problem, float(gamma), verbose
         self.ctx = ctx or hip.Context(0)
         dim = problem.dim
+        self.sv = discretisation == "sv"
         self.char_L, self.char_U = problem.char_length(), problem.char_velocity()
+        self.nullspace = bool(problem.has_nullspace())
         # hierarchy and device objects are created once (Stokes operator); values are replaced per Newton step
-        self.levels, self.transfers = build_hierarchy(problem, nref, k, Re=0.0, gamma=gamma)
-        self.params = outer_solver(dim, fieldsplit_0_mg(mg_levels_solver(dim, smoothing=smoothing)))
+        if self.sv:
+            from .sv import build_sv_hierarchy, build_sv_pressure_coupling
+            self.levels, self.transfers = build_sv_hierarchy(problem, nref, k, Re=0.0, gamma=gamma)
+        else:
+            self.levels, self.transfers = build_hierarchy(problem, nref, k, Re=0.0, gamma=gamma)
+        if self.sv:      # patch = macro with the problem's relaxation direction (solver.py:339-342), sparse-LU patch options
+            from .solver import configure_patch_solver_sv
+            mgl = configure_patch_solver_sv(mg_levels_solver(dim, patch="macro", smoothing=smoothing,
+                                                             relaxation_direction=problem.relaxation_direction()), dim)
+        else:
+            mgl = mg_levels_solver(dim, smoothing=smoothing)
+        self.params = outer_solver(dim, fieldsplit_0_mg(mgl))
         self.hmg = HipMG(self.ctx, self.levels, self.transfers, self.params["fieldsplit_0"], restriction=restriction)
         L = self.levels[-1]
-        self.B, self.vol = build_pressure_coupling(L)                     # Dirichlet columns zeroed: the Jacobian's B
-        self.B_raw, _ = build_pressure_coupling(L, zero_bc_columns=False)  # all columns: the residual's B
         self.nu = self.char_L * self.char_U
-        self.saddle = hip.Saddle(self.hmg.mg, self.B, self.vol, self.nu, self.gamma, remove_constant_nullspace=True)
+        if self.sv:
+            self.B, M, Minv = build_sv_pressure_coupling(L)                  # Dirichlet columns zeroed: the Jacobian's B
+            self.B_raw, _, _ = build_sv_pressure_coupling(L, zero_bc_columns=False)
+            self.vol = np.asarray(M.sum(axis=1)).ravel()                    # int psi_j: weights of the pressure integral
+            self.saddle = hip.Saddle(self.hmg.mg, self.B, None, self.nu, self.gamma,
+                                     remove_constant_nullspace=self.nullspace, mass_inv=Minv)
+        else:
+            self.B, self.vol = build_pressure_coupling(L)                     # Dirichlet columns zeroed: the Jacobian's B
+            self.B_raw, _ = build_pressure_coupling(L, zero_bc_columns=False)  # all columns: the residual's B
+            self.saddle = hip.Saddle(self.hmg.mg, self.B, self.vol, self.nu, self.gamma,
+                                     remove_constant_nullspace=self.nullspace)
         self.rtol, self.atol = self.params["ksp_rtol"], self.params["ksp_atol"]
         tol2, tol3 = (1e-9, 1e-8), (1e-8, 1e-8)                            # snes_rtol / snes_atol, solver.py:484-499
         self.snes_rtol = snes_rtol if snes_rtol is not None else (tol2 if dim == 2 else tol3)[0]
@@ -72,14 +96,16 @@ class HipNavierStokesSolver(object):
         w = [None] * len(self.levels)
         w[-1] = u.reshape(-1, d)
         for l in range(len(self.levels) - 1, 0, -1):
-            w[l - 1] = w[l][self.transfers[l - 1].inject_map]
+            T = self.transfers[l - 1]
+            # nested uniform hierarchy: every coarse node is a fine node; bary hierarchy: point evaluation (sv.bary_injection)
+            w[l - 1] = w[l][T.inject_map] if T.inject_map is not None else T.inject_matrix @ w[l]
         return w
 
     def _rediscretise(self, u, adv):
         winds = self._winds(u)
         for L, w in zip(self.levels, winds):
             L.A = BSR(L.A.nbrows, L.A.nbcols, L.bs, L.A.rowptr, L.A.colidx,
-                      _assemble(L, self.nu, self.gamma, adv, np.ascontiguousarray(w), True))
+                      _assemble(L, self.nu, self.gamma, adv, np.ascontiguousarray(w), True, self.sv))
             L.nu = self.nu
         self.hmg.update(self.levels)
         self.hmg.mg.levels[0].update_values(self.levels[0].A.vals)
@@ -91,11 +117,11 @@ class HipNavierStokesSolver(object):
         d = self.problem.dim
         wind = np.ascontiguousarray(u.reshape(-1, d))
         A0 = BSR(L.A.nbrows, L.A.nbcols, L.bs, L.A.rowptr, L.A.colidx,
-                 _assemble(L, self.nu, self.gamma, 0.0, None, False)).to_scipy()
+                 _assemble(L, self.nu, self.gamma, 0.0, None, False, self.sv)).to_scipy()
         Fu = A0 @ u
         if adv:
             J = BSR(L.A.nbrows, L.A.nbcols, L.bs, L.A.rowptr, L.A.colidx,
-                    _assemble(L, self.nu, self.gamma, 1.0, wind, False)).to_scipy()
+                    _assemble(L, self.nu, self.gamma, 1.0, wind, False, self.sv)).to_scipy()
             Fu = 0.5 * (Fu + J @ u)                  # A0 u + 1/2 N(u) u with N = J - A0
         Fu = Fu + self.B_raw.T @ p
         Fu[L.bc_dofs] = 0.0
@@ -135,7 +161,8 @@ class HipNavierStokesSolver(object):
             if self.verbose:
                 print("[alfi_amd] Re %g  Newton %d  |F| %.3e  (%d Krylov its, linear residual %.2e)"
                       % (re, newton_its, fnorm, its, rn), flush=True)
-        p -= (self.vol @ p) / self.area                                      # zero pressure integral, solver.py:273-277
+        if self.nullspace:
+            p -= (self.vol @ p) / self.area                                  # zero pressure integral, solver.py:273-277
         self.u, self.p = u, p
         info = {"Re": re, "nu": self.nu, "linear_iter": lin_its, "nonlinear_iter": newton_its,
                 "time": (time.time() - t0) / 60.0, "residual_history": hist,

@@ -75,6 +75,15 @@ def mg_levels_solver(tdim, patch="star", patch_composition="additive", smoothing
     return opts
 
 
+def configure_patch_solver_sv(opts, tdim, use_mkl=False):
+    """ScottVogeliusSolver.configure_patch_solver (solver.py:655-659)."""
+    opts = dict(opts)
+    opts["patch_pc_patch_sub_mat_type"] = "seqaij"
+    opts["patch_sub_pc_factor_mat_solver_type"] = ("mkl_pardiso" if use_mkl else "umfpack") if tdim > 2 else "petsc"
+    opts.pop("patch_pc_patch_dense_inverse", None)
+    return opts
+
+
 def fieldsplit_0_mg(mg_levels):
     """alfi/solver.py:359-379 (the coarse solve is a dense inverse applied on the GPU instead of telescoped
     SuperLU_DIST; the keys are accepted and ignored)."""
@@ -103,6 +112,8 @@ def macro_vertex_labels(mesh):
     """``MacroVertices`` label (alfi/bary.py:18-19 sets it to 1 on the vertices of the mesh that is then split).  For a
     uniformly refined mesh the analogous macro vertices are the vertices inherited from the parent mesh; a mesh without
     parent information carries no label."""
+    if getattr(mesh, "macro_vertex_mask", None) is not None:          # Alfeld split (mesh.bary_refine): the split mesh's vertices
+        return {"MacroVertices": {int(mesh.num_cells + v): 1 for v in np.flatnonzero(mesh.macro_vertex_mask)}}
     if getattr(mesh, "vertex_parents", None) is None:
         return {}
     vp_ = np.asarray(mesh.vertex_parents)
@@ -169,9 +180,11 @@ class HipPatchPC(object):
         if _truthy(opts.getString("patch_pc_patch_partition_of_unity", "false")):
             raise NotImplementedError("partition_of_unity weighting (the reference always sets it False, solver.py:321)")
         sub_mat = opts.getString("patch_pc_patch_sub_mat_type", "seqdense")
-        if sub_mat not in ("seqdense", "dense"):
-            raise NotImplementedError("patch sub_mat_type %r: only dense patch solves (ConstantPressureSolver, "
-                                      "solver.py:599-602) are implemented" % sub_mat)
+        if sub_mat not in ("seqdense", "dense", "seqaij", "aij"):
+            raise NotImplementedError("patch sub_mat_type %r" % sub_mat)
+        # seqaij (ScottVogeliusSolver.configure_patch_solver, solver.py:655-659: sparse patch matrices factored by
+        # UMFPACK / PARDISO) asks for the same operator A_p^-1 as seqdense + dense_inverse (solver.py:599-602); here both
+        # are the explicit dense inverse -- macro-star patches are inverted on the FP64 matrix cores
         ctype = opts.getString("patch_pc_patch_construct_type", "star")
         if ctype == "star":
             if opts.getInt("patch_pc_patch_construct_dim", 0) != 0:

@@ -96,6 +96,39 @@ def bary_prolongation(Vc, Vf):
     return P
 
 
+def bary_injection(Vc, Vf):
+    """firedrake ``inject`` on the non-nested bary hierarchy for the nodal velocity spaces (solver.py:641-644): the fine
+    function evaluated at the coarse nodes.  Every coarse node is located in one of the 2^d (d+1) fine cells of the coarse
+    macro cell it belongs to.  Scalar CSR (coarse nodes x fine nodes); used to move the Newton state to the coarse levels."""
+    mf = Vf.mesh
+    d = mf.dim
+    nch = 2 ** d
+    flat = Vc.cell_nodes.ravel()
+    _, first = np.unique(flat, return_index=True)
+    C = (first // Vc.cell_nodes.shape[1]) // (d + 1)                # coarse macro cell of every coarse node
+    x = Vc.node_coords
+    best = bestlam = bestscore = None
+    for j in range(nch):
+        for i in range(d + 1):
+            cand = (C * nch + j) * (d + 1) + i
+            lam = _barycentric(mf, cand, x)
+            score = lam.min(axis=1)
+            if best is None:
+                best, bestlam, bestscore = cand.copy(), lam, score
+            else:
+                better = score > bestscore
+                best[better], bestlam[better], bestscore[better] = cand[better], lam[better], score[better]
+    assert bestscore.min() > -1e-9, "a coarse node was not located in the fine cells of its macro cell"
+    phi = Vf.element.tabulate(np.clip(bestlam, 0.0, 1.0))[0]
+    phi[np.abs(phi) < 1e-13] = 0.0
+    rows = np.repeat(np.arange(Vc.num_nodes), phi.shape[1])
+    J = sp.csr_matrix((phi.ravel(), (rows, Vf.cell_nodes[best].ravel())), shape=(Vc.num_nodes, Vf.num_nodes))
+    J.sum_duplicates()
+    J.eliminate_zeros()
+    J.sort_indices()
+    return J
+
+
 def macro_skeleton_mask(Vf):
     """True for fine nodes on the closure of a coarse MACRO facet: the Dirichlet set of fix_coarse_boundaries
     (transfer.py:121-158) on a bary hierarchy, where the ``prolongation`` label marks the facets of the coarse macro mesh."""
@@ -164,6 +197,7 @@ def build_sv_transfer_data(Vc, Vf, nu, gamma, graph):
     T.PT = T.P.transpose()
     T.PT_plain = T.PT
     T.inject_map = None
+    T.inject_matrix = bary_injection(Vc, Vf)
     T.nu, T.gamma = nu, gamma
     T.n_f, T.n_c = Vf.num_dofs, Vc.num_dofs
     T.bc_dofs_f, T.bc_dofs_c = Vf.bc_dofs, Vc.bc_dofs

@@ -24,7 +24,8 @@ def host_newton(solver, re, u, p, tol):
         if np.sqrt(Fu @ Fu + Fp @ Fp) < tol:
             break
         J = BSR(L.A.nbrows, L.A.nbcols, L.bs, L.A.rowptr, L.A.colidx,
-                _assemble(L, nu, solver.gamma, 1.0, np.ascontiguousarray(u.reshape(-1, L.bs)), True)).to_scipy().tocsr()
+                _assemble(L, nu, solver.gamma, 1.0, np.ascontiguousarray(u.reshape(-1, L.bs)), True,
+                          solver.sv)).to_scipy().tocsr()
         K = sp.bmat([[J, solver.B.T, None], [solver.B, None, sp.csr_matrix(vol[:, None])],
                      [None, sp.csr_matrix(vol[None, :]), None]], format="csc")
         d = spla.spsolve(K, -np.concatenate([Fu, Fp, [0.0]]))
@@ -33,12 +34,15 @@ def host_newton(solver, re, u, p, tol):
     return u, p - (vol @ p) / vol.sum(), it
 
 
-@pytest.mark.parametrize("mk,ke,nref", [(lambda: TwoDimLidDrivenCavityProblem(8), 2, 1),
-                                        (lambda: ThreeDimLidDrivenCavityProblem(2), 2, 1)])
-def test_newton_continuation_matches_direct_solver(mk, ke, nref):
+@pytest.mark.parametrize("mk,ke,nref,disc", [(lambda: TwoDimLidDrivenCavityProblem(8), 2, 1, "pkp0"),
+                                             (lambda: ThreeDimLidDrivenCavityProblem(2), 2, 1, "pkp0"),
+                                             # Scott-Vogelius [P2]^2 - P1dg on the barycentric hierarchy, macro-star patches,
+                                             # block DGMassInv, state moved to the coarse levels by point evaluation
+                                             (lambda: TwoDimLidDrivenCavityProblem(4), 2, 1, "sv")])
+def test_newton_continuation_matches_direct_solver(mk, ke, nref, disc):
     from alfi_amd.nssolver import HipNavierStokesSolver, run_solver
     prob = mk()
-    s = HipNavierStokesSolver(prob, nref, ke)
+    s = HipNavierStokesSolver(prob, nref, ke, discretisation=disc)
     u0, p0 = s.u.copy(), s.p.copy()
     res = run_solver(s, [10, 100])
     for re in (10, 100):
