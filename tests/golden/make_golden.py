@@ -54,7 +54,44 @@ def make(name):
     np.savez_compressed(os.path.join(os.path.dirname(os.path.abspath(__file__)), name + ".npz"), **out)
 
 
+# Scott-Vogelius side (alfi_amd/sv.py): name -> (problem, nref, element degree, Re, smoothing steps)
+SV_CASES = {"sv2d_p2_N2": (lambda: TwoDimLidDrivenCavityProblem(2), 2, 2, 10.0, 6),
+            "sv3d_p3_N1": (lambda: ThreeDimLidDrivenCavityProblem(1), 1, 3, 100.0, 4)}
+
+
+def sv_hierarchy(name):
+    from alfi_amd.sv import build_sv_hierarchy
+    mk, nref, k, Re, ks = SV_CASES[name]
+    lv, tr = build_sv_hierarchy(mk(), nref, k, Re=Re)
+    return lv, tr, ks
+
+
+def make_sv(name):
+    from alfi_amd.sv import build_sv_pressure_coupling
+    lv, tr, ks = sv_hierarchy(name)
+    mg = O.build_oracle_mg(lv, tr, ks, schoeberl_restriction=True)
+    L = lv[-1]
+    top = len(lv) - 1
+    rng = np.random.default_rng(7)
+    x = rng.standard_normal(L.n)
+    b = rng.standard_normal(L.n)
+    b[L.bc_dofs] = 0
+    uc = rng.standard_normal(lv[-2].n)
+    uc[lv[-2].bc_dofs] = 0
+    B, M, Minv = build_sv_pressure_coupling(L)
+    mgp = O.build_oracle_mg(lv, tr, ks)
+    rhs = np.concatenate([b, np.zeros(B.shape[0])])
+    xs, its, hist = O.saddle_solve(mgp, mg.levels[-1]["A"], B, None, L.nu, L.gamma, rhs, rtol=1e-9, atol=1e-12, mass_inv=Minv)
+    out = dict(x=x, b=b, uc=uc, n=L.n, patch_ptr=L.patch_ptr, patch_dofs=L.patch_dofs, blk_dofs=tr[-1].blk_dofs,
+               A_x=mg.levels[-1]["A"] @ x, patch_apply_x=mg.levels[-1]["smoother"].apply(x),
+               prolong_uc=mg.prolong(top, uc), restrict_x=mg.restrict(top, x), vcycle_b=mg.vcycle(top, b, np.zeros(L.n)),
+               fcycle_b=mg.fcycle(b), inject_x=tr[-1].inject_matrix @ x.reshape(-1, L.bs), saddle_x=xs, saddle_its=its,
+               B_x=B @ x, Minv_diag=Minv.diagonal())
+    np.savez_compressed(os.path.join(os.path.dirname(os.path.abspath(__file__)), name + ".npz"), **out)
+
+
 if __name__ == "__main__":
-    for name in CASES:
-        make(name)
+    which = sys.argv[1:] or list(CASES) + list(SV_CASES)
+    for name in which:
+        (make if name in CASES else make_sv)(name)
         print("wrote", name)

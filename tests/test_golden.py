@@ -97,3 +97,78 @@ def test_hip_matches_golden(name):
     mgp.close()
     mg.close()
     ctx.close()
+
+
+# ---- Scott-Vogelius fixtures (macro-star patches, macro-cell transfer blocks, discontinuous pressure) ---------------------
+SV_NAMES = ["sv2d_p2_N2", "sv3d_p3_N1"]
+
+
+def load_sv(name):
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_golden", os.path.join(HERE, "golden", "make_golden.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    lv, tr, ks = mod.sv_hierarchy(name)
+    return lv, tr, ks, np.load(os.path.join(HERE, "golden", name + ".npz"))
+
+
+@pytest.mark.parametrize("name", SV_NAMES)
+def test_oracles_reproduce_sv_golden(name):
+    from alfi_amd.sv import build_sv_pressure_coupling
+    from oracle import alfi_oracle as O
+    from oracle import c_oracle as C
+    lv, tr, ks, g = load_sv(name)
+    L, top = lv[-1], len(lv) - 1
+    assert np.array_equal(L.patch_ptr, g["patch_ptr"]) and np.array_equal(L.patch_dofs, g["patch_dofs"])
+    assert np.array_equal(tr[-1].blk_dofs, g["blk_dofs"])
+    mg = O.build_oracle_mg(lv, tr, ks, schoeberl_restriction=True)
+    assert rel(mg.levels[-1]["A"] @ g["x"], g["A_x"]) < 1e-14
+    assert rel(mg.levels[-1]["smoother"].apply(g["x"]), g["patch_apply_x"]) < 1e-9
+    assert rel(mg.prolong(top, g["uc"]), g["prolong_uc"]) < 1e-10
+    assert rel(mg.restrict(top, g["x"]), g["restrict_x"]) < 1e-10
+    assert rel(mg.vcycle(top, g["b"], np.zeros(L.n)), g["vcycle_b"]) < 1e-8
+    B, M, Minv = build_sv_pressure_coupling(L)
+    assert rel(B @ g["x"], g["B_x"]) < 1e-13 and rel(Minv.diagonal(), g["Minv_diag"]) < 1e-13
+    assert rel(tr[-1].inject_matrix @ g["x"].reshape(-1, L.bs), g["inject_x"]) < 1e-13
+    cmg = C.CMultigrid(lv, tr, ks, robust_restriction=True)
+    assert rel(cmg.vcycle(top, g["b"], np.zeros(L.n)), g["vcycle_b"]) < 1e-5
+    assert rel(cmg.transfers[-1].prolong(g["uc"]), g["prolong_uc"]) < 1e-4      # explicit block inverse, cond ~ gamma / nu
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", SV_NAMES)
+def test_hip_matches_sv_golden(name):
+    from alfi_amd import hip
+    from alfi_amd.sv import build_sv_pressure_coupling
+    lv, tr, ks, g = load_sv(name)
+    L = lv[-1]
+    ctx = hip.Context(0)
+    mg = hip.Multigrid(ctx, lv, tr, ks, robust_restriction=True)
+    fin = mg.levels[-1]
+    dx, dy, db = ctx.vec(g["x"]), ctx.vec(L.n), ctx.vec(g["b"])
+    fin.spmv(dx, dy)
+    assert rel(dy.get(), g["A_x"]) < 1e-13
+    fin.patch_apply(dx, dy)
+    assert rel(dy.get(), g["patch_apply_x"]) < 1e-7
+    duc, dxf, drc = ctx.vec(g["uc"]), ctx.vec(L.n), ctx.vec(lv[-2].n)
+    mg.transfers[-1].prolong(duc, dxf)
+    assert rel(dxf.get(), g["prolong_uc"]) < 1e-7
+    mg.transfers[-1].restrict(dx, drc, robust=True)
+    assert rel(drc.get(), g["restrict_x"]) < 1e-7
+    dv = ctx.vec(L.n)
+    mg.vcycle(db, dv)
+    assert rel(dv.get(), g["vcycle_b"]) < 1e-5
+    mg.fcycle(db, dv)
+    assert rel(dv.get(), g["fcycle_b"]) < 1e-5
+    mg.close()
+    B, M, Minv = build_sv_pressure_coupling(L)
+    mgp = hip.Multigrid(ctx, lv, tr, ks, robust_restriction=False)
+    sad = hip.Saddle(mgp, B, None, L.nu, L.gamma, remove_constant_nullspace=True, mass_inv=Minv)
+    rhs = np.concatenate([g["b"], np.zeros(B.shape[0])])
+    dr, ds = ctx.vec(rhs), ctx.vec(L.n + B.shape[0])
+    its, rn = sad.solve(dr, ds, 1e-9, 1e-12, 500, 30)
+    assert abs(its - int(g["saddle_its"])) <= 1
+    assert rel(ds.get()[:L.n], g["saddle_x"][:L.n]) < 1e-6
+    sad.close()
+    mgp.close()
+    ctx.close()
