@@ -463,7 +463,7 @@ class DistMultigrid(object):
     only the rank's rows are uploaded)."""
 
     def __init__(self, levels, transfers, k, robust_restriction=False, group=None, device=None, min_dofs=400000,
-                 coarse_inverse=None, verbose=False, force_distributed=False, overlap=None):
+                 coarse_inverse=None, verbose=False, force_distributed=False, overlap=None, overlap_min_dofs=None):
         import torch
         from . import hip
         self.comm = Comm(group)
@@ -472,6 +472,11 @@ class DistMultigrid(object):
             import os
             overlap = os.environ.get("ALFI_DIST_OVERLAP", "1") != "0"
         self.overlap = overlap
+        self._in_cycle = False
+        self._red_views = {}
+        if overlap_min_dofs is None:
+            import os
+            overlap_min_dofs = int(os.environ.get("ALFI_DIST_OVERLAP_MIN_DOFS", "2000000"))
         if device is None:
             device = torch.device("cuda", torch.cuda.current_device())
         self.device = device
@@ -501,8 +506,13 @@ class DistMultigrid(object):
                 if LL.level > 0:
                     dl.set_patches(LL.patch_ptr, LL.patch_dofs)
                     dl.factor()
-                    if p.distributed and overlap:
-                        # interior rows / patches are worked on while the forward halo is in flight
+                    if p.distributed and overlap and p.nb_own * p.bs >= overlap_min_dofs:
+                        # interior rows / patches are worked on while the forward halo is in flight.  Only where a rank
+                        # owns enough for that to pay: the split launches and the asynchronous begin/end pairs (RCCL's
+                        # own stream, two cross-stream waits each) have a fixed cost -- measured with a 1-rank RCCL group
+                        # and all exchange points on: 173 k dofs 8.9 ms per cycle with, 7.0 ms without (plain path 5.2);
+                        # 1.35 M dofs +7.4 ms with, +3.3 ms without -- more than the ~3 ms of wire time the overlap can
+                        # hide at 8 ranks, so the default keeps it for shares above 2 M dofs (2 and 4 ranks on config 4)
                         dl.set_overlap(p.nb_int, LL.npatch_int)
                 elif p.nb_own > 0:
                     inv = coarse_inverse(levels[0].A) if coarse_inverse is not None else hip.coarse_inverse(levels[0].A)
@@ -520,31 +530,42 @@ class DistMultigrid(object):
                   % (rank, self.lmin, len(levels) - 1, self.n_own, levels[-1].n, self.n_loc - self.n_own,
                      len(self.fine.patch_ptr) - 1), flush=True)
 
-    # the library calls this at every exchange point of the cycle (alfi_ctx_set_comm)
+    # the library calls this at every exchange point of the cycle (alfi_ctx_set_comm): ~200 times per V-cycle, so the host
+    # work per call is kept to the collective itself (on small levels the cycle is bound by exactly this host time)
     def _callback(self, user, op, level_id, offset, count):
         try:
-            import torch
-            # the collectives must be ordered against the library's stream whatever stream the caller had current
-            with torch.cuda.stream(self.stream):
-                if op == COMM_ALLREDUCE:
-                    self.comm.allreduce(self.red[offset:offset + count])
-                elif op == COMM_HALO_FWD:
-                    self.halos[level_id].forward(self.comm)
-                elif op == COMM_HALO_REV:
-                    self.halos[level_id].reverse(self.comm)
-                elif op == COMM_HALO_FWD_BEGIN:
-                    self.halos[level_id].forward_begin(self.comm)
-                elif op == COMM_HALO_REV_BEGIN:
-                    self.halos[level_id].reverse_begin(self.comm)
-                elif op in (COMM_HALO_FWD_END, COMM_HALO_REV_END):
-                    self.halos[level_id].forward_end(self.comm)
-                else:
-                    return -2
+            if self._in_cycle:            # vcycle()/fcycle() made the library's stream current: nothing to switch
+                self._dispatch(op, level_id, offset, count)
+            else:
+                import torch
+                # the collectives must be ordered against the library's stream whatever stream the caller had current
+                with torch.cuda.stream(self.stream):
+                    self._dispatch(op, level_id, offset, count)
             return 0
         except Exception:                                   # never let an exception cross the C boundary
             import traceback
             traceback.print_exc()
             return -1
+
+    def _dispatch(self, op, level_id, offset, count):
+        if op == COMM_ALLREDUCE:
+            key = (offset, count)
+            view = self._red_views.get(key)
+            if view is None:
+                view = self._red_views[key] = self.red[offset:offset + count]
+            self.comm.allreduce(view)
+        elif op == COMM_HALO_FWD:
+            self.halos[level_id].forward(self.comm)
+        elif op == COMM_HALO_REV:
+            self.halos[level_id].reverse(self.comm)
+        elif op == COMM_HALO_FWD_BEGIN:
+            self.halos[level_id].forward_begin(self.comm)
+        elif op == COMM_HALO_REV_BEGIN:
+            self.halos[level_id].reverse_begin(self.comm)
+        elif op == COMM_HALO_FWD_END or op == COMM_HALO_REV_END:
+            self.halos[level_id].forward_end(self.comm)
+        else:
+            raise ValueError("unknown exchange op %d" % op)
 
     def local_vec(self, global_array=None):
         """Device vector of the finest level in local numbering (owned + ghost slots), filled from a global array."""
@@ -562,12 +583,20 @@ class DistMultigrid(object):
     def vcycle(self, b, x):
         import torch
         with torch.cuda.stream(self.stream):
-            self.mg.vcycle(b, x)
+            self._in_cycle = True
+            try:
+                self.mg.vcycle(b, x)
+            finally:
+                self._in_cycle = False
 
     def fcycle(self, b, x):
         import torch
         with torch.cuda.stream(self.stream):
-            self.mg.fcycle(b, x)
+            self._in_cycle = True
+            try:
+                self.mg.fcycle(b, x)
+            finally:
+                self._in_cycle = False
 
     def sync(self):
         self.ctx.sync()

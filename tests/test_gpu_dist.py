@@ -37,7 +37,8 @@ def test_partitioned_cycles_match_single_gpu(case, world, robust, overlap, tmp_p
     procs = []
     for r in range(world):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=str(port), OMP_NUM_THREADS="4", ALFI_DIST_OVERLAP=overlap)
+                   MASTER_PORT=str(port), OMP_NUM_THREADS="4", ALFI_DIST_OVERLAP=overlap,
+                   ALFI_DIST_OVERLAP_MIN_DOFS="0")       # exercise the overlapped sequence on these small levels too
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dist_gpu_worker.py"), case,
                                        str(robust), str(tmp_path)], env=env, cwd=ROOT))
     # the single-GPU references while the ranks run
