@@ -41,6 +41,7 @@ def lib():
         _lib.alfi_host_extract_blocks.restype = ctypes.c_int
         _lib.alfi_host_interior_blocks.restype = ctypes.c_int
         _lib.alfi_host_bsr_transpose.restype = ctypes.c_int
+        _lib.alfi_host_supg.restype = ctypes.c_int
         # ALFI_HOST_THREADS overrides OMP_NUM_THREADS (torch.distributed.run exports OMP_NUM_THREADS=1 to every rank)
         nthr = int(os.environ.get("ALFI_HOST_THREADS", "0")) or cpu_share()
         _lib.alfi_host_set_num_threads(ctypes.c_int(nthr))
@@ -86,6 +87,44 @@ def assemble_bsr(cell_nodes, g, vol, tensors, d, rowptr, colidx, nu=0.0, gamma=0
     if rc != 0:
         raise RuntimeError("assemble_bsr failed (%d): sparsity pattern does not cover the mesh" % rc)
     return out
+
+
+def cell_size(mesh):
+    """Firedrake's ``CellSize`` = 2 * circumradius [3P] (problem.mesh_size(u, "cell"), alfi/problem.py:46-52)."""
+    x = mesh.coords[mesh.cells]
+    if mesh.dim == 2:
+        a = np.linalg.norm(x[:, 1] - x[:, 2], axis=1)
+        b = np.linalg.norm(x[:, 0] - x[:, 2], axis=1)
+        c = np.linalg.norm(x[:, 0] - x[:, 1], axis=1)
+        area = mesh.cell_geometry()[1]
+        return 2.0 * a * b * c / (4.0 * area)
+    e = lambda i, j: np.linalg.norm(x[:, i] - x[:, j], axis=1)
+    aA, bB, cC = e(0, 1) * e(2, 3), e(0, 2) * e(1, 3), e(0, 3) * e(1, 2)         # products of opposite edges
+    vol = mesh.cell_geometry()[1]
+    rad = np.sqrt((aA + bB + cC) * (aA + bB - cC) * (aA - bB + cC) * (-aA + bB + cC)) / (24.0 * vol)
+    return 2.0 * rad
+
+
+def supg(V, U, nu, weight, magic, rowptr=None, colidx=None, vals=None, F=None, nq=None):
+    """SUPG stabilisation (stabilisation.py:47-97, solver.py:204-234) about the state U (num_nodes, dim): adds the residual
+    contribution to F (num_dofs) and / or the Newton linearisation to the BSR values ``vals``.  Quadrature degree 2k."""
+    from .elements import simplex_quadrature
+    mesh, el, d = V.mesh, V.element, V.dim
+    deg = 3 if (el.bubble or el.degree == 3) else el.degree                  # ufl degree of the (enriched) element
+    lam, wq = simplex_quadrature(d, nq or (deg + 1))                          # n points per direction: exact to 2n - 1 >= 2k
+    phi, dphi = el.tabulate(lam)
+    d2phi = el.tabulate_hessian(lam)
+    g, vol = mesh.cell_geometry()
+    h = cell_size(mesh)
+    cn = np.ascontiguousarray(V.cell_nodes, dtype=np.int32)
+    U = np.ascontiguousarray(U, dtype=np.float64)
+    arrs = [np.ascontiguousarray(a, dtype=np.float64) for a in (g, vol, h, wq, phi, dphi, d2phi)]
+    rc = lib().alfi_host_supg(ctypes.c_int64(cn.shape[0]), ctypes.c_int(cn.shape[1]), ctypes.c_int(d), _p(cn), _p(arrs[0]),
+                              _p(arrs[1]), _p(arrs[2]), ctypes.c_int(len(wq)), _p(arrs[3]), _p(arrs[4]), _p(arrs[5]),
+                              _p(arrs[6]), _p(U), ctypes.c_double(nu), ctypes.c_double(weight), ctypes.c_double(magic),
+                              _p(rowptr), _p(colidx), _p(vals), _p(F))
+    if rc != 0:
+        raise RuntimeError("supg failed (%d): sparsity pattern does not cover the mesh" % rc)
 
 
 def apply_bc_bsr(nnode, d, rowptr, colidx, vals, bcmask):

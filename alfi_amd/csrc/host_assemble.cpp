@@ -11,6 +11,7 @@
 //
 // C ABI, plain pointers; called through ctypes from alfi_amd/_hostlib.py.
 #include <algorithm>
+#include <cmath>
 #include <cstdint>
 #include <cstring>
 #include <vector>
@@ -341,6 +342,129 @@ int alfi_host_num_threads() { return omp_get_max_threads(); }
 int alfi_host_set_num_threads(int n) {
   if (n > 0) omp_set_num_threads(n);
   return omp_get_max_threads();
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------
+// SUPG stabilisation of the momentum equation (alfi/stabilisation.py:47-97 with the Shakib-Hughes-Johan coefficient,
+// alfi/solver.py:204-234: stabilisation_form = weight * beta * inner(Lu, dot(grad(v), u)) * dx(degree = 2k), state = u):
+//   Lu   = -nu div(2 sym grad u) + (grad u) u   (+ grad p, zero for the piecewise constant pressure)
+//   beta = (4 u.u / h^2 + magic (4 nu / h^2)^2)^(-1/2)
+// by quadrature (beta is not polynomial).  F (n dofs, may be NULL) += the residual contribution; vals (BSR, may be NULL)
+// += its Newton linearisation about u:
+//   dF[a,i; b,j] = int wgt [ dbeta_j (Lu)_i s_a + beta (dLu)_ij s_a + beta (Lu)_i phi_b d_j phi_a ],
+//   s_a = u.grad phi_a,  dbeta_j = -4 beta^3 u_j phi_b / h^2,
+//   (dLu)_ij = -nu (delta_ij Lap phi_b + d_i d_j phi_b) + delta_ij s_b + phi_b d_j u_i.
+// phi (nq, nloc), dphi (nq, nloc, d+1), d2phi (nq, nloc, d+1, d+1): basis and its derivatives w.r.t. the barycentric
+// coordinates at the quadrature points; wq (nq) sums to 1; h (ncell): cell size; U (nnode, d): state.
+// ---------------------------------------------------------------------------------------------------------------------
+int alfi_host_supg(int64_t ncell, int nloc, int d, const int32_t* cell_nodes, const double* g, const double* vol,
+                   const double* h, int nq, const double* wq, const double* phi, const double* dphi, const double* d2phi,
+                   const double* U, double nu, double weight, double magic, const int32_t* rowptr, const int32_t* colidx,
+                   double* vals, double* F) {
+  const int nv = d + 1;
+  const int ndof = nloc * d;
+  int err = 0;
+#pragma omp parallel
+  {
+    std::vector<double> Ae((size_t)ndof * ndof), Fe(ndof), Uk((size_t)nloc * d), gp((size_t)nloc * d),
+        hs((size_t)nloc * d * d), lap(nloc), s(nloc);
+#pragma omp for schedule(dynamic, 64)
+    for (int64_t c = 0; c < ncell; ++c) {
+      const int32_t* cn = cell_nodes + c * nloc;
+      const double* gc = g + c * nv * d;
+      for (int a = 0; a < nloc; ++a)
+        for (int x = 0; x < d; ++x) Uk[a * d + x] = U[(int64_t)cn[a] * d + x];
+      std::fill(Ae.begin(), Ae.end(), 0.0);
+      std::fill(Fe.begin(), Fe.end(), 0.0);
+      const double h2 = h[c] * h[c];
+      for (int q = 0; q < nq; ++q) {
+        const double* ph = phi + (size_t)q * nloc;
+        // physical gradients and Hessians of the basis at this point
+        for (int a = 0; a < nloc; ++a) {
+          const double* da = dphi + ((size_t)q * nloc + a) * nv;
+          const double* ha = d2phi + ((size_t)q * nloc + a) * nv * nv;
+          for (int x = 0; x < d; ++x) {
+            double t = 0.0;
+            for (int i = 0; i < nv; ++i) t += da[i] * gc[i * d + x];
+            gp[a * d + x] = t;
+          }
+          double l = 0.0;
+          for (int x = 0; x < d; ++x)
+            for (int y = 0; y < d; ++y) {
+              double t = 0.0;
+              for (int i = 0; i < nv; ++i)
+                for (int k = 0; k < nv; ++k) t += ha[i * nv + k] * gc[i * d + x] * gc[k * d + y];
+              hs[((size_t)a * d + x) * d + y] = t;
+              if (x == y) l += t;
+            }
+          lap[a] = l;
+        }
+        // state at the point
+        double u[3] = {0, 0, 0}, Gu[3][3] = {{0}}, Lu[3] = {0, 0, 0};
+        for (int a = 0; a < nloc; ++a)
+          for (int i = 0; i < d; ++i) {
+            const double ui = Uk[a * d + i];
+            u[i] += ph[a] * ui;
+            for (int x = 0; x < d; ++x) Gu[i][x] += gp[a * d + x] * ui;
+            Lu[i] -= nu * lap[a] * ui;                                             // -nu Lap u_i
+            for (int j = 0; j < d; ++j) Lu[j] -= nu * hs[((size_t)a * d + j) * d + i] * ui;   // -nu d_j div u
+          }
+        for (int i = 0; i < d; ++i)
+          for (int x = 0; x < d; ++x) Lu[i] += u[x] * Gu[i][x];
+        double uu = 0.0;
+        for (int i = 0; i < d; ++i) uu += u[i] * u[i];
+        const double vis = 4.0 * nu / h2;
+        const double beta = 1.0 / std::sqrt(4.0 * uu / h2 + magic * vis * vis);
+        for (int a = 0; a < nloc; ++a) {
+          double t = 0.0;
+          for (int x = 0; x < d; ++x) t += u[x] * gp[a * d + x];
+          s[a] = t;
+        }
+        const double wt = wq[q] * vol[c] * weight;
+        for (int a = 0; a < nloc; ++a)
+          for (int i = 0; i < d; ++i) Fe[a * d + i] += wt * beta * Lu[i] * s[a];
+        if (vals) {
+          const double b3 = -4.0 * beta * beta * beta / h2;
+          for (int a = 0; a < nloc; ++a)
+            for (int i = 0; i < d; ++i) {
+              double* row = Ae.data() + (size_t)(a * d + i) * ndof;
+              for (int b = 0; b < nloc; ++b)
+                for (int j = 0; j < d; ++j) {
+                  double dL = -nu * hs[((size_t)b * d + i) * d + j] + ph[b] * Gu[i][j];
+                  if (i == j) dL += -nu * lap[b] + s[b];
+                  row[b * d + j] += wt * (b3 * u[j] * ph[b] * Lu[i] * s[a] + beta * dL * s[a] +
+                                          beta * Lu[i] * ph[b] * gp[a * d + j]);
+                }
+            }
+        }
+      }
+      if (F)
+        for (int a = 0; a < nloc; ++a)
+          for (int i = 0; i < d; ++i) {
+#pragma omp atomic
+            F[(int64_t)cn[a] * d + i] += Fe[a * d + i];
+          }
+      if (vals)
+        for (int a = 0; a < nloc; ++a) {
+          const int64_t lo = rowptr[cn[a]], hi = rowptr[cn[a] + 1];
+          for (int b = 0; b < nloc; ++b) {
+            const int64_t pos = find_col(colidx, lo, hi, cn[b]);
+            if (pos >= hi || colidx[pos] != cn[b]) {
+              err = 1;
+              continue;
+            }
+            double* dst = vals + pos * d * d;
+            for (int cc = 0; cc < d; ++cc)
+              for (int dd = 0; dd < d; ++dd) {
+#pragma omp atomic
+                dst[cc * d + dd] += Ae[(size_t)(a * d + cc) * ndof + b * d + dd];
+              }
+          }
+        }
+    }
+  }
+  return err ? -2 : 0;
 }
 
 }  // extern "C"

@@ -159,6 +159,20 @@ class NodalElement(object):
         dphi = dphi - np.einsum("pmi,am->pai", dbeta, self._bub_coef)
         return np.concatenate([phi, beta], axis=1), np.concatenate([dphi, dbeta], axis=1)
 
+    def tabulate_hessian(self, lam):
+        """d2phi (npts, nloc, dim+1, dim+1): second partial derivatives w.r.t. the barycentric coordinates (independent
+        variables, as in ``tabulate``).  The first derivatives are polynomials of degree <= 2 in every coordinate, so
+        their central differences are exact."""
+        lam = np.atleast_2d(np.asarray(lam, dtype=np.float64))
+        nv = lam.shape[1]
+        step = 0.5
+        out = np.empty((lam.shape[0], self.nloc, nv, nv))
+        for k in range(nv):
+            e = np.zeros(nv)
+            e[k] = step
+            out[:, :, :, k] = (self.tabulate(lam + e)[1] - self.tabulate(lam - e)[1]) / (2 * step)
+        return out
+
     # reference tensors (averages over the reference cell: multiply by the cell volume) -----------------------------
     def reference_tensors(self):
         if hasattr(self, "_tensors"):

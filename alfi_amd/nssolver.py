@@ -40,13 +40,25 @@ class HipNavierStokesSolver(object):
     keys Re, nu, linear_iter, nonlinear_iter, time."""
 
     def __init__(self, problem, nref, k, gamma=1e4, smoothing=None, restriction=False, ctx=None, verbose=False,
-                 snes_rtol=None, snes_atol=None, snes_max_it=20, discretisation="pkp0"):
+                 snes_rtol=None, snes_atol=None, snes_max_it=20, discretisation="pkp0", stabilisation_type=None,
+                 stabilisation_weight=None, supg_magic=9.0):
         """discretisation: "pkp0" ([P_k(+FB)]^d - P0 on the uniform hierarchy, ConstantPressureSolver solver.py:561-602) or
         "sv" ([P_k]^d - P_{k-1}^dg on the barycentric hierarchy with macro-star patches, ScottVogeliusSolver :604-662)."""
         self.problem, self.gamma, self.verbose = problem, float(gamma), verbose
         self.ctx = ctx or hip.Context(0)
         dim = problem.dim
         self.sv = discretisation == "sv"
+        # stabilisation (solver.py:56-58, 66-68, 204-234): SUPG with the Shakib-Hughes-Johan coefficient (supg_method
+        # "shakib", the default), default weight 0.1 in 3-D and 1 in 2-D (stabilisation.py:52-54), supg_magic 9
+        if stabilisation_type in ("none", None):
+            stabilisation_type = None
+        if stabilisation_type not in (None, "supg"):
+            raise NotImplementedError("stabilisation type %r (built: supg for the P0-pressure pairs)" % stabilisation_type)
+        if stabilisation_type == "supg" and self.sv:
+            raise NotImplementedError("supg with a discontinuous P_k pressure couples grad p into the momentum block")
+        self.supg = stabilisation_type == "supg"
+        self.supg_weight = float(stabilisation_weight) if stabilisation_weight is not None else (0.1 if dim == 3 else 1.0)
+        self.supg_magic = float(supg_magic)
         self.char_L, self.char_U = problem.char_length(), problem.char_velocity()
         self.nullspace = bool(problem.has_nullspace())
         # hierarchy and device objects are created once (Stokes operator); values are replaced per Newton step
@@ -101,11 +113,21 @@ class HipNavierStokesSolver(object):
             w[l - 1] = w[l][T.inject_map] if T.inject_map is not None else T.inject_matrix @ w[l]
         return w
 
+    def level_values(self, L, state, adv, with_bc):
+        """BSR values of the linearised momentum block of level L about ``state`` (num_nodes, dim): viscous + grad-div +
+        Newton-linearised advection (+ the linearised SUPG term, ``advect * stabilisation_form``, solver.py:233-234)."""
+        state = np.ascontiguousarray(state)
+        A = _assemble(L, self.nu, self.gamma, adv, state, False, self.sv)
+        if adv and self.supg:
+            _hostlib.supg(L.V, state, self.nu, self.supg_weight, self.supg_magic, L.A.rowptr, L.A.colidx, A)
+        if with_bc:
+            _hostlib.apply_bc_bsr(L.V.num_nodes, L.V.dim, L.A.rowptr, L.A.colidx, A, np.repeat(L.V.bc_node_mask, L.V.dim))
+        return A
+
     def _rediscretise(self, u, adv):
         winds = self._winds(u)
         for L, w in zip(self.levels, winds):
-            L.A = BSR(L.A.nbrows, L.A.nbcols, L.bs, L.A.rowptr, L.A.colidx,
-                      _assemble(L, self.nu, self.gamma, adv, np.ascontiguousarray(w), True, self.sv))
+            L.A = BSR(L.A.nbrows, L.A.nbcols, L.bs, L.A.rowptr, L.A.colidx, self.level_values(L, w, adv, True))
             L.nu = self.nu
         self.hmg.update(self.levels)
         self.hmg.mg.levels[0].update_values(self.levels[0].A.vals)
@@ -123,6 +145,10 @@ class HipNavierStokesSolver(object):
             J = BSR(L.A.nbrows, L.A.nbcols, L.bs, L.A.rowptr, L.A.colidx,
                     _assemble(L, self.nu, self.gamma, 1.0, wind, False, self.sv)).to_scipy()
             Fu = 0.5 * (Fu + J @ u)                  # A0 u + 1/2 N(u) u with N = J - A0
+            if self.supg:
+                Fs = np.zeros_like(Fu)
+                _hostlib.supg(L.V, wind, self.nu, self.supg_weight, self.supg_magic, F=Fs)
+                Fu = Fu + Fs
         Fu = Fu + self.B_raw.T @ p
         Fu[L.bc_dofs] = 0.0
         Fp = self.B_raw @ u

@@ -296,7 +296,8 @@ def main():
     for _ in range(args.warmup):
         dmg.vcycle(db, dx)
     ctx.sync()
-    ctx.prof_enable(True)
+    # ALFI_BENCH_PROF=0/2: tuning runs without (or with only the PATCH_APPLY) events; the roofline block needs the default
+    ctx.prof_enable({"0": False, "2": 2}.get(os.environ.get("ALFI_BENCH_PROF", "1"), True))
     ctx.prof_reset()
     torch.cuda.synchronize()
     t0 = time.perf_counter()

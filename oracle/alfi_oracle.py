@@ -94,6 +94,32 @@ def assemble_form(V, nu=0.0, gamma=0.0, adv=0.0, wind=None, nq=6, gamma_full=0.0
     return A
 
 
+def supg_residual(V, U, nu, weight, magic, h, nq):
+    """SUPG term of the momentum residual (alfi/stabilisation.py:57-60, 83-88; alfi/solver.py:204-223), PkP0 pairs (grad p = 0):
+    F[a, i] = int weight beta (Lu)_i (u . grad phi_a),  Lu = -nu div(2 sym grad u) + (grad u) u,
+    beta = (4 u.u / h^2 + magic (4 nu / h^2)^2)^(-1/2).  U: (num_nodes, dim); h: (ncell,) cell size.  Returns (num_dofs,)."""
+    from alfi_amd.elements import simplex_quadrature
+    m, d, el = V.mesh, V.dim, V.element
+    lam, wq = simplex_quadrature(d, nq)
+    phi, dphi = el.tabulate(lam)
+    d2 = el.tabulate_hessian(lam)
+    g, vol = m.cell_geometry()
+    gphi = np.einsum("qai,cix->cqax", dphi, g)                         # grad phi_a
+    hphi = np.einsum("qaik,cix,cky->cqaxy", d2, g, g)                  # Hessian of phi_a
+    Uc = U[V.cell_nodes]                                               # (c, a, i)
+    u = np.einsum("qa,cai->cqi", phi, Uc)
+    Gu = np.einsum("cqax,cai->cqix", gphi, Uc)                         # d_x u_i
+    lap = np.einsum("cqaxx,cai->cqi", hphi, Uc)
+    gdiv = np.einsum("cqaij,caj->cqi", hphi, Uc)                       # d_i div u
+    Lu = -nu * (lap + gdiv) + np.einsum("cqix,cqx->cqi", Gu, u)
+    beta = (4.0 * np.einsum("cqi,cqi->cq", u, u) / h[:, None] ** 2 + magic * (4.0 * nu / h[:, None] ** 2) ** 2) ** -0.5
+    s = np.einsum("cqx,cqax->cqa", u, gphi)
+    Fe = np.einsum("q,c,cq,cqi,cqa->cai", wq, vol * weight, beta, Lu, s)
+    F = np.zeros((V.num_nodes, d))
+    np.add.at(F, V.cell_nodes, Fe)
+    return F.ravel()
+
+
 def apply_bcs_matrix(A, bc_dofs):
     """Rows and columns of Dirichlet dofs -> identity (firedrake.assemble(a, bcs=bcs) [3P])."""
     n = A.shape[0]

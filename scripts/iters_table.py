@@ -24,6 +24,8 @@ def main():
     ap.add_argument("--nref-end", type=int, default=3)
     ap.add_argument("--re-max", type=int, default=1000)
     ap.add_argument("--gamma", type=float, default=1e4)
+    ap.add_argument("--stabilisation-type", default="none", choices=["none", "supg"])
+    ap.add_argument("--stabilisation-weight", type=float, default=None)
     args = ap.parse_args()
     # continuation as in alfi.driver.get_default_parser / run_solver: 0 (Stokes), 1, 10, 100, then steps of 250
     res = [0, 1, 10, 100] + list(range(250, args.re_max + 1, 250))
@@ -32,7 +34,8 @@ def main():
     rows = []
     for nref in range(args.nref_start, args.nref_end + 1):
         prob = TwoDimLidDrivenCavityProblem(args.baseN) if args.dim == 2 else ThreeDimLidDrivenCavityProblem(args.baseN)
-        s = HipNavierStokesSolver(prob, nref, args.k, gamma=args.gamma)
+        s = HipNavierStokesSolver(prob, nref, args.k, gamma=args.gamma, stabilisation_type=args.stabilisation_type,
+                                  stabilisation_weight=args.stabilisation_weight)
         t0 = time.time()
         results = run_solver(s, res)
         rows.append((nref, s.n_u + s.n_p, results, time.time() - t0))
