@@ -81,6 +81,11 @@ SIGNATURES = {
     "alfi_saddle_update": (ctypes.c_int, [vp, ctypes.c_double, ctypes.c_double]),
     "alfi_saddle_solve": (ctypes.c_int, [vp, vp, vp, ctypes.c_double, ctypes.c_double, ctypes.c_int, ctypes.c_int,
                                          ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_double)]),
+    "alfi_level_halo_forward": (ctypes.c_int, [vp, vp]),
+    "alfi_level_halo_reverse_add": (ctypes.c_int, [vp, vp]),
+    "alfi_csr_create": (ctypes.c_int, [vp, ctypes.POINTER(CsrHost), ctypes.POINTER(vp)]),
+    "alfi_csr_destroy": (ctypes.c_int, [vp]),
+    "alfi_csr_mult": (ctypes.c_int, [vp, vp, vp, vp, ctypes.c_double, ctypes.c_int]),
     "alfi_saddle_mult": (ctypes.c_int, [vp, vp, vp]),
     "alfi_saddle_precond": (ctypes.c_int, [vp, vp, vp]),
 }

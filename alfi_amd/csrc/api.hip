@@ -1222,6 +1222,58 @@ static void free_csr(DevCSR* d) {
   *d = DevCSR();
 }
 
+// ---- building blocks of the outer solve on partitioned levels (alfi_amd/dist.py: DistSaddle drives them from the host) -------
+int alfi_level_halo_forward(alfi_level* L, double* dv) {
+  if (!L->distributed) return 0;
+  L->ctx->cur_tag = L->id;
+  return halo_fwd(L, dv);
+}
+
+int alfi_level_halo_reverse_add(alfi_level* L, double* dv) {
+  if (!L->distributed) return 0;
+  L->ctx->cur_tag = L->id;
+  return halo_rev(L, dv);
+}
+
+struct alfi_csr {
+  alfi_ctx* ctx = nullptr;
+  DevCSR M;
+};
+
+int alfi_csr_create(alfi_ctx* ctx, const alfi_csr_host* h, alfi_csr** out) {
+  if (!ctx || !h || !out) return alfi_set_error(ctx, ALFI_E_ARG, "NULL argument");
+  for (int64_t i = 0; i < h->nrows; ++i)
+    if (h->rowptr[i + 1] < h->rowptr[i]) return alfi_set_error(ctx, ALFI_E_ARG, "row pointer not monotone");
+  const int64_t nnz = h->rowptr[h->nrows];
+  for (int64_t k = 0; k < nnz; ++k)
+    if (h->colidx[k] < 0 || h->colidx[k] >= h->ncols) return alfi_set_error(ctx, ALFI_E_ARG, "column index out of range");
+  ALFI_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  alfi_csr* C = new alfi_csr();
+  C->ctx = ctx;
+  int rc = upload_csr(ctx, &C->M, h);
+  if (rc != 0) {
+    free_csr(&C->M);
+    delete C;
+    return rc;
+  }
+  *out = C;
+  return 0;
+}
+
+int alfi_csr_destroy(alfi_csr* C) {
+  if (!C) return 0;
+  (void)hipStreamSynchronize(C->ctx->stream);
+  free_csr(&C->M);
+  delete C;
+  return 0;
+}
+
+// mode 0: y = M x;  1: y = b - alpha M x;  2: y += M x;  3: y = alpha M x
+int alfi_csr_mult(alfi_csr* C, const double* dx, double* dy, const double* db, double alpha, int mode) {
+  if (mode < 0 || mode > 3 || (mode == 1 && !db)) return alfi_set_error(C->ctx, ALFI_E_ARG, "bad mode / missing b");
+  return launch_csr_spmv(C->ctx, C->M, dx, dy, db, alpha, mode);
+}
+
 int alfi_saddle_create(alfi_mg* mg, const alfi_csr_host* B, const alfi_csr_host* BT, const double* mass_diag,
                        double nu, double gamma, int remove_constant_nullspace, alfi_saddle** out) {
   if (!mg || !B || !BT || !mass_diag || !out) return alfi_set_error(mg ? mg->ctx : nullptr, ALFI_E_ARG, "NULL argument");

@@ -356,6 +356,21 @@ def localize(levels, transfers, parts):
     return llev, ltr, lmin
 
 
+def localize_pressure(B, mass_diag, cell_nodes, part, bs):
+    """The rank's share of the P0 pressure space for the outer solve: a cell belongs to the rank that owns its lowest-numbered
+    node (all its nodes are then local: they are columns of that node's operator row).  Returns (owned cell ids ascending,
+    B_loc = rows of B for those cells with columns in the local dof numbering (scipy CSR, n_p_own x n_loc), mass_diag_loc)."""
+    import scipy.sparse as sp
+    low = np.asarray(cell_nodes).min(axis=1).astype(np.int64)
+    cells = np.flatnonzero((low >= part.lo) & (low < part.hi))
+    Bl = sp.csr_matrix(B)[cells].tocoo()
+    lcol = part.g2l(Bl.col // bs) * bs + Bl.col % bs
+    assert (lcol >= 0).all(), "a velocity dof of an owned cell is not in the local node set"
+    Bloc = sp.csr_matrix((Bl.data, (Bl.row, lcol)), shape=(len(cells), part.nb_loc * bs))
+    Bloc.sort_indices()
+    return cells, Bloc, np.asarray(mass_diag)[cells]
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # communication (torch.distributed)
 # ---------------------------------------------------------------------------------------------------------------------
@@ -604,3 +619,131 @@ class DistMultigrid(object):
     def close(self):
         self.mg.close()
         self.ctx.close()
+
+
+class DistSaddle(object):
+    """The outer solve of one Newton step (alfi/solver.py:386-422: FGMRES around PCFIELDSPLIT-Schur-full, fieldsplit_0 = one
+    PCMG full cycle, fieldsplit_1 = DGMassInv) on partitioned levels.  Same algorithm as ``alfi_saddle_solve``; here the
+    host drives the Krylov loop (a handful of iterations, each two full multigrid cycles) with torch tensors on the
+    library's stream, and the library supplies the cycles, the partitioned SpMV, the halo routes and the products with the
+    rank's rows of the discrete divergence.  Velocity dofs are owned with their nodes, pressure dofs with their cells
+    (``localize_pressure``); every reduction is one all-reduce."""
+
+    def __init__(self, dmg, B, mass_diag, cell_nodes, nu, gamma, remove_constant_nullspace=True):
+        import torch
+        from . import hip
+        self.dmg, self.nu, self.gamma, self.remove_nullspace = dmg, float(nu), float(gamma), remove_constant_nullspace
+        F = dmg.fine
+        self.part, self.bs = F.part, F.bs
+        self.cells, Bloc, md = localize_pressure(B, mass_diag, cell_nodes, self.part, self.bs)
+        self.n_own, self.n_loc, self.np_own = dmg.n_own, dmg.n_loc, len(self.cells)
+        self.n = self.n_own + self.np_own
+        self.np_global = int(B.shape[0])
+        dev = dmg.device
+        with torch.cuda.stream(dmg.stream):
+            self.B = hip.Csr(dmg.ctx, Bloc)
+            self.BT = hip.Csr(dmg.ctx, Bloc.T.tocsr())
+            self.minv = torch.tensor(1.0 / md, dtype=torch.float64, device=dev)
+            self.wa, self.wb, self.wc = (torch.zeros(max(self.n_loc, 1), dtype=torch.float64, device=dev) for _ in range(3))
+            self.wq = torch.zeros(max(self.np_own, 1), dtype=torch.float64, device=dev)
+        self.level = dmg.levels[-1]
+
+    def _raw(self, t):
+        from .hip import RawVec
+        return RawVec(t.data_ptr(), t.numel())
+
+    def _allsum(self, t):
+        self.dmg.comm.allreduce(t)
+        return t
+
+    def mult(self, x, y):
+        """y = [A B^T; B 0] x on (owned velocity dofs | owned pressure dofs)."""
+        n_own = self.n_own
+        self.wa[:n_own] = x[:n_own]
+        self.level.spmv(self._raw(self.wa), self._raw(self.wb))                   # ghosts of wa filled, owned rows of A
+        self.B.mult(self._raw(self.wa), self._raw(y[n_own:]))                     # y_p = B u (needs the ghosts)
+        self.BT.mult(self._raw(x[n_own:]), self._raw(self.wc))                    # partial B^T p on all local dofs
+        self.level.halo_reverse_add(self._raw(self.wc))
+        y[:n_own] = self.wb[:n_own] + self.wc[:n_own]
+
+    def precond(self, v, z):
+        """z = P^-1 v: y_u = MG(b_u); y_p = -(nu + gamma) M^-1 (b_p - B y_u); y_u = MG(b_u - B^T y_p)."""
+        import torch
+        n_own = self.n_own
+        mg = self.dmg.mg
+        self.wa[:n_own] = v[:n_own]
+        mg.fcycle(self._raw(self.wa), self._raw(self.wb))
+        self.level.halo_forward(self._raw(self.wb))
+        self.B.mult(self._raw(self.wb), self._raw(self.wq), b=self._raw(v[n_own:]), alpha=1.0, mode=1)
+        yp = z[n_own:]
+        torch.mul(self.wq[:self.np_own], self.minv, out=yp)
+        yp.mul_(-(self.nu + self.gamma))
+        self.BT.mult(self._raw(yp), self._raw(self.wc))
+        self.level.halo_reverse_add(self._raw(self.wc))
+        self.wa[:n_own] = v[:n_own] - self.wc[:n_own]
+        mg.fcycle(self._raw(self.wa), self._raw(self.wb))
+        z[:n_own] = self.wb[:n_own]
+        if self.remove_nullspace:
+            tot = self._allsum(yp.sum().reshape(1))
+            yp.sub_(tot[0] / self.np_global)
+
+    def solve(self, b, rtol=1e-8, atol=1e-8, max_it=500, restart=30):
+        """b: torch tensor (n_own + np_own) on the device, owned entries.  Zero initial guess, KSP's default convergence test
+        on the recurrence residual.  Returns (x, iterations, true residual norm)."""
+        import torch
+        dmg = self.dmg
+        dev = dmg.device
+        n = self.n
+        with torch.cuda.stream(dmg.stream):
+            dmg._in_cycle = True
+            try:
+                x = torch.zeros(n, dtype=torch.float64, device=dev)
+                r = b.clone()
+                bnorm = float(self._allsum((r @ r).reshape(1)).sqrt())
+                tol = max(rtol * bnorm, atol)
+                its, rnorm = 0, bnorm
+                V = torch.zeros((restart + 1, n), dtype=torch.float64, device=dev)
+                Z = torch.zeros((restart, n), dtype=torch.float64, device=dev)
+                w = torch.zeros(n, dtype=torch.float64, device=dev)
+                while rnorm > tol and its < max_it:
+                    beta = rnorm
+                    V[0] = r / beta
+                    H = np.zeros((restart + 1, restart))
+                    cs, sn, grs = np.zeros(restart), np.zeros(restart), np.zeros(restart + 1)
+                    grs[0] = beta
+                    j = 0
+                    while j < restart and its < max_it:
+                        self.precond(V[j], Z[j])
+                        self.mult(Z[j], w)
+                        h = self._allsum(V[:j + 1] @ w)
+                        w -= h @ V[:j + 1]
+                        tt = float(self._allsum((w @ w).reshape(1)).sqrt())
+                        hcol = np.concatenate([h.cpu().numpy(), [tt]])
+                        for i in range(j):
+                            t = hcol[i]
+                            hcol[i] = cs[i] * t + sn[i] * hcol[i + 1]
+                            hcol[i + 1] = -sn[i] * t + cs[i] * hcol[i + 1]
+                        den = np.hypot(hcol[j], hcol[j + 1])
+                        cs[j], sn[j] = hcol[j] / den, hcol[j + 1] / den
+                        grs[j + 1] = -sn[j] * grs[j]
+                        grs[j] = cs[j] * grs[j]
+                        hcol[j], hcol[j + 1] = den, 0.0
+                        H[:j + 2, j] = hcol[:j + 2]
+                        its += 1
+                        rnorm = abs(grs[j + 1])
+                        j += 1
+                        if rnorm <= tol or tt == 0.0:
+                            break
+                        V[j] = w / tt
+                    y = np.linalg.solve(np.triu(H[:j, :j]), grs[:j])
+                    x += torch.as_tensor(y, dtype=torch.float64, device=dev) @ Z[:j]
+                    self.mult(x, w)
+                    r = b - w
+                    rnorm = float(self._allsum((r @ r).reshape(1)).sqrt())
+                return x, its, rnorm
+            finally:
+                dmg._in_cycle = False
+
+    def close(self):
+        self.B.close()
+        self.BT.close()

@@ -176,6 +176,14 @@ class Level(object):
     def spmv(self, x, y):
         self.ctx.check(self.ctx.lib.alfi_spmv(self.h, x.ptr, y.ptr))
 
+    def halo_forward(self, v):
+        """Partitioned level: ghost slots of v <- their owners' values (no-op otherwise)."""
+        self.ctx.check(self.ctx.lib.alfi_level_halo_forward(self.h, v.ptr))
+
+    def halo_reverse_add(self, v):
+        """Partitioned level: ghost slots of v added onto their owners' entries (no-op otherwise)."""
+        self.ctx.check(self.ctx.lib.alfi_level_halo_reverse_add(self.h, v.ptr))
+
     def residual(self, b, x, r):
         self.ctx.check(self.ctx.lib.alfi_residual(self.h, b.ptr, x.ptr, r.ptr))
 
@@ -327,6 +335,40 @@ class Multigrid(object):
             t.close()
         for l in self.levels:
             l.close()
+
+
+class RawVec(object):
+    """A device buffer owned by someone else (a torch tensor) in the shape the wrappers expect (``.ptr``)."""
+
+    def __init__(self, ptr, n):
+        self.ptr, self.n = vp(int(ptr)), int(n)
+
+
+class Csr(object):
+    """Scalar CSR matrix on the device (alfi_csr_*): the rank's rows of the discrete divergence and its transpose."""
+
+    def __init__(self, ctx, M):
+        import scipy.sparse as sp
+        M = sp.csr_matrix(M)
+        M.sort_indices()
+        rp = np.ascontiguousarray(M.indptr, dtype=np.int32)
+        ci = np.ascontiguousarray(M.indices, dtype=np.int32)
+        va = np.ascontiguousarray(M.data, dtype=np.float64)
+        st = CsrHost(M.shape[0], M.shape[1], _ptr(rp), _ptr(ci), _ptr(va))
+        self.ctx, self.shape = ctx, M.shape
+        h = vp()
+        ctx.check(ctx.lib.alfi_csr_create(ctx.h, ctypes.byref(st), ctypes.byref(h)))
+        self.h = h
+
+    def mult(self, x, y, b=None, alpha=1.0, mode=0):
+        """mode 0: y = M x;  1: y = b - alpha M x;  2: y += M x;  3: y = alpha M x"""
+        self.ctx.check(self.ctx.lib.alfi_csr_mult(self.h, x.ptr, y.ptr, b.ptr if b is not None else None, float(alpha),
+                                                  int(mode)))
+
+    def close(self):
+        if self.h:
+            self.ctx.lib.alfi_csr_destroy(self.h)
+            self.h = None
 
 
 class Saddle(object):

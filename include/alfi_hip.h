@@ -227,6 +227,18 @@ int alfi_saddle_update(alfi_saddle* s, double nu, double gamma);
  * 463-499).  Returns the iteration count and the final true residual norm. */
 int alfi_saddle_solve(alfi_saddle* s, const double* db, double* dx, double rtol, double atol, int max_it, int restart,
                       int* iterations, double* residual_norm);
+/* Building blocks of the same solve on PARTITIONED levels (the host drives the outer Krylov loop: 2 full cycles per
+ * iteration dwarf its few vector operations; alfi_amd/dist.py: DistSaddle).  Halo routes of a level set up with
+ * alfi_level_set_partition: forward = owner -> ghost copies, reverse_add = ghost contributions summed onto their owners
+ * (PETSc's VecScatter forward / reverse-add on the velocity DM).  No-ops on levels that are not distributed. */
+int alfi_level_halo_forward(alfi_level* lvl, double* dv);
+int alfi_level_halo_reverse_add(alfi_level* lvl, double* dv);
+/* a scalar CSR matrix on the device (the rank's rows of the discrete divergence and its transpose) */
+typedef struct alfi_csr alfi_csr;
+int alfi_csr_create(alfi_ctx* ctx, const alfi_csr_host* M, alfi_csr** out);
+int alfi_csr_destroy(alfi_csr* m);
+/* mode 0: y = M x;  1: y = b - alpha M x;  2: y += M x;  3: y = alpha M x */
+int alfi_csr_mult(alfi_csr* m, const double* dx, double* dy, const double* db, double alpha, int mode);
 /* y = [A B^T; B 0] x and y = P^-1 x on device vectors (tests, monitors) */
 int alfi_saddle_mult(alfi_saddle* s, const double* dx, double* dy);
 int alfi_saddle_precond(alfi_saddle* s, const double* dx, double* dy);

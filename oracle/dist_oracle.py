@@ -204,3 +204,82 @@ class DistOracle(object):
             x = self.vcycle(i, bs[i], x)
             x = self.prolong(i, x)
         return self.vcycle(top, bs[top], x)
+
+
+def dist_saddle_solve(mg, Bloc, mass_diag_loc, np_global, nu, gamma, b, rtol=1e-8, atol=1e-8, max_it=500, restart=30,
+                      remove_constant_nullspace=True):
+    """SPMD restatement of oracle.alfi_oracle.saddle_solve on the rank-local data of alfi_amd.dist.localize_pressure: owned
+    velocity dofs | owned pressure dofs, every dot product all-reduced.  mg: DistOracle.  b: (n_own + np_own,)."""
+    i = len(mg.lev) - 1
+    L = mg.lev[i]
+    n_own, n_loc = L.n_own, L.n
+    np_own = Bloc.shape[0]
+    n = n_own + np_own
+    minv = 1.0 / np.asarray(mass_diag_loc)
+
+    def allsum(a):
+        return mg.allsum(i, np.atleast_1d(np.asarray(a, dtype=np.float64)))
+
+    def K(x):
+        u = np.zeros(n_loc)
+        u[:n_own] = x[:n_own]
+        Au = mg.spmv(i, u)                                  # fills the ghosts of u
+        t = Bloc.T @ x[n_own:]
+        mg.halo_rev(i, t)
+        return np.concatenate([Au[:n_own] + t[:n_own], Bloc @ u])
+
+    def P(v):
+        bu = np.zeros(n_loc)
+        bu[:n_own] = v[:n_own]
+        yu = mg.fcycle(bu)
+        mg.halo_fwd(i, yu)
+        yp = -(nu + gamma) * minv * (v[n_own:] - Bloc @ yu)
+        t = Bloc.T @ yp
+        mg.halo_rev(i, t)
+        bu2 = np.zeros(n_loc)
+        bu2[:n_own] = v[:n_own] - t[:n_own]
+        yu = mg.fcycle(bu2)
+        if remove_constant_nullspace:
+            yp = yp - allsum(yp.sum())[0] / np_global
+        return np.concatenate([yu[:n_own], yp])
+
+    x = np.zeros(n)
+    r = b.copy()
+    bnorm = float(np.sqrt(allsum(r @ r)[0]))
+    tol = max(rtol * bnorm, atol)
+    its, rnorm = 0, bnorm
+    while rnorm > tol and its < max_it:
+        V = np.zeros((restart + 1, n))
+        Z = np.zeros((restart, n))
+        H = np.zeros((restart + 1, restart))
+        cs, sn, grs = np.zeros(restart), np.zeros(restart), np.zeros(restart + 1)
+        V[0], grs[0] = r / rnorm, rnorm
+        j = 0
+        while j < restart and its < max_it:
+            Z[j] = P(V[j])
+            w = K(Z[j])
+            h = allsum(V[:j + 1] @ w)
+            w = w - h @ V[:j + 1]
+            tt = float(np.sqrt(allsum(w @ w)[0]))
+            hcol = np.concatenate([h, [tt]])
+            for q in range(j):
+                t = hcol[q]
+                hcol[q] = cs[q] * t + sn[q] * hcol[q + 1]
+                hcol[q + 1] = -sn[q] * t + cs[q] * hcol[q + 1]
+            den = np.hypot(hcol[j], hcol[j + 1])
+            cs[j], sn[j] = hcol[j] / den, hcol[j + 1] / den
+            grs[j + 1] = -sn[j] * grs[j]
+            grs[j] = cs[j] * grs[j]
+            hcol[j], hcol[j + 1] = den, 0.0
+            H[:j + 2, j] = hcol[:j + 2]
+            its += 1
+            rnorm = abs(grs[j + 1])
+            j += 1
+            if rnorm <= tol or tt == 0.0:
+                break
+            V[j] = w / tt
+        y = np.linalg.solve(np.triu(H[:j, :j]), grs[:j])
+        x = x + y @ Z[:j]
+        r = b - K(x)
+        rnorm = float(np.sqrt(allsum(r @ r)[0]))
+    return x, its, rnorm

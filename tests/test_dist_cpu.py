@@ -133,3 +133,65 @@ def test_partition_covers_and_plans_are_consistent():
             if l > 0:
                 assert sum(len(D.owned_patches(lv[l], allparts[q][l].lo, allparts[q][l].hi)) for q in range(world)) \
                     == len(lv[l].patch_ptr) - 1
+
+
+def _saddle_worker(rank, world, port, case, q):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from alfi_amd import dist as D
+        from alfi_amd.problem import build_pressure_coupling
+        from oracle.dist_oracle import DistOracle, dist_saddle_solve
+        lv, tr, k, min_dofs = _hier(case)
+        L = lv[-1]
+        comm = D.Comm()
+        splits = D.choose_splits(lv, world, min_dofs)
+        parts = D.build_parts(lv, tr, splits, rank, comm.all_gather_object)
+        llev, ltr, lmin = D.localize(lv, tr, parts)
+        mg = DistOracle(llev, ltr, lmin, k, comm, robust=False)
+        B, vol = build_pressure_coupling(L)
+        p = llev[-1].part
+        cells, Bloc, md = D.localize_pressure(B, vol, L.V.cell_nodes, p, L.bs)
+        b = np.random.default_rng(0).standard_normal(L.n)
+        b[L.bc_dofs] = 0.0
+        rhs = np.concatenate([b[p.own_dofs()], np.zeros(len(cells))])
+        x, its, rn = dist_saddle_solve(mg, Bloc, md, B.shape[0], L.nu, L.gamma, rhs, rtol=1e-9, atol=1e-12)
+        q.put((rank, p.own_dofs(), cells, x[:llev[-1].n_own], x[llev[-1].n_own:], its))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("case,world", [("2d-all-distributed", 2), ("3d-P2FB", 3)])
+def test_spmd_outer_solve_matches_serial(case, world):
+    """The outer FGMRES / fieldsplit-Schur solve on partitioned levels (velocity dofs owned with their nodes, pressure dofs
+    with their cells): same iteration count and solution as the serial oracle."""
+    import torch.multiprocessing as mp
+    from alfi_amd.problem import build_pressure_coupling
+    from oracle import alfi_oracle as O
+    lv, tr, k, _ = _hier(case)
+    L = lv[-1]
+    ser = O.build_oracle_mg(lv, tr, k, schoeberl_restriction=False)
+    B, vol = build_pressure_coupling(L)
+    b = np.random.default_rng(0).standard_normal(L.n)
+    b[L.bc_dofs] = 0.0
+    xs, its_s, _ = O.saddle_solve(ser, ser.levels[-1]["A"], B, vol, L.nu, L.gamma, np.concatenate([b, np.zeros(B.shape[0])]),
+                                  rtol=1e-9, atol=1e-12)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_saddle_worker, args=(r, world, port, case, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=300) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    xu, xp = np.full(L.n, np.nan), np.full(B.shape[0], np.nan)
+    for rank, dofs, cells, u, pp, its in got:
+        xu[dofs], xp[cells] = u, pp
+        assert abs(its - its_s) <= 1
+    assert not np.isnan(xu).any() and not np.isnan(xp).any()             # every velocity dof and every cell has one owner
+    assert np.abs(xu - xs[:L.n]).max() < 1e-6 * np.abs(xs[:L.n]).max()
+    assert np.abs(xp - xs[L.n:]).max() < 1e-5 * np.abs(xs[L.n:]).max()

@@ -131,3 +131,44 @@ def test_partitioned_multiplicative(case, world, tmp_path):
         assert p.wait(timeout=600) == 0
     for r in range(world):
         assert os.path.exists(os.path.join(str(tmp_path), "rank%d.ok" % r))
+
+
+@pytest.mark.parametrize("case,world", [("2d-all-distributed", 2), ("3d-P2FB", 3)])
+def test_partitioned_outer_solve(case, world, tmp_path):
+    """alfi_amd.dist.DistSaddle (host-driven FGMRES around the library's partitioned cycles, halo routes and divergence
+    products) against the single-GPU alfi_saddle_solve: same iteration count, same solution."""
+    from alfi_amd import hip
+    from alfi_amd.problem import build_pressure_coupling
+    from tests.test_dist_cpu import _hier
+    lv, tr, k, _ = _hier(case)
+    L = lv[-1]
+    b = np.random.default_rng(0).standard_normal(L.n)
+    b[L.bc_dofs] = 0.0
+    port = _free_port()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), OMP_NUM_THREADS="4")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dist_gpu_saddle_worker.py"), case,
+                                       str(tmp_path)], env=env, cwd=ROOT))
+    ctx = hip.Context(0)
+    mg = hip.Multigrid(ctx, lv, tr, k, robust_restriction=False)
+    B, vol = build_pressure_coupling(L)
+    sad = hip.Saddle(mg, B, vol, L.nu, L.gamma, remove_constant_nullspace=True)
+    db, dx = ctx.vec(np.concatenate([b, np.zeros(B.shape[0])])), ctx.vec(L.n + B.shape[0])
+    its_s, rn = sad.solve(db, dx, 1e-9, 1e-12, 500, 30)
+    xs = dx.get()
+    sad.close()
+    mg.close()
+    ctx.close()
+    for p in procs:
+        assert p.wait(timeout=600) == 0
+    xu, xp = np.full(L.n, np.nan), np.full(B.shape[0], np.nan)
+    for r in range(world):
+        z = np.load(os.path.join(str(tmp_path), "rank%d.npz" % r))
+        xu[z["dofs"]], xp[z["cells"]] = z["xu"], z["xp"]
+        assert abs(int(z["its"]) - its_s) <= 1
+        assert float(z["rn"]) <= 2e-9 * np.linalg.norm(b)
+    assert not np.isnan(xu).any() and not np.isnan(xp).any()
+    assert np.abs(xu - xs[:L.n]).max() < 1e-6 * np.abs(xs[:L.n]).max()
+    assert np.abs(xp - xs[L.n:]).max() < 1e-5 * np.abs(xs[L.n:]).max()
