@@ -582,6 +582,24 @@ class DistMultigrid(object):
         else:
             raise ValueError("unknown exchange op %d" % op)
 
+    def update(self, levels, coarse_inverse=None):
+        """New operator values on every level (a Newton step): the rank's rows are cut out of the global operators again,
+        patches re-gathered and re-inverted, the coarse inverse rebuilt by its owner."""
+        import torch
+        from . import hip
+        with torch.cuda.stream(self.stream):
+            for dl, LL in zip(self.levels, self.local_levels):
+                new = localize_level(levels[LL.level], LL.part)
+                LL.A = new.A
+                dl.update_values(new.A.vals)
+                if LL.level > 0:
+                    dl.factor()
+                elif LL.part.nb_own > 0:
+                    inv = coarse_inverse(levels[0].A) if coarse_inverse is not None else hip.coarse_inverse(levels[0].A)
+                    if isinstance(inv, tuple):
+                        inv, self._keep_inv = inv
+                    dl.set_coarse_inverse(inv)
+
     def local_vec(self, global_array=None):
         """Device vector of the finest level in local numbering (owned + ghost slots), filled from a global array."""
         v = self.ctx.vec(self.n_loc)
@@ -747,3 +765,71 @@ class DistSaddle(object):
     def close(self):
         self.B.close()
         self.BT.close()
+
+
+def _dist_ns_solver_class():
+    from .nssolver import HipNavierStokesSolver
+
+    class DistNavierStokesSolver(HipNavierStokesSolver):
+        """HipNavierStokesSolver with the device side on partitioned levels (one process per GPU): DistMultigrid + DistSaddle.
+        Every rank rediscretises the global operators on its host cores (as every rank generates the global hierarchy) and
+        uploads its own rows; the Newton state is replicated, the update of each linear solve gathered from its owners."""
+
+        def __init__(self, *args, min_dofs=400000, group=None, **kwargs):
+            self._min_dofs, self._group = min_dofs, group
+            super().__init__(*args, **kwargs)
+
+        def _create_device(self, restriction):
+            if self.sv:
+                raise NotImplementedError("partitioned outer solve: P0 pressure pairs")
+            self.dmg = DistMultigrid(self.levels, self.transfers, self.params["fieldsplit_0"]["mg_levels"]["ksp_max_it"],
+                                     robust_restriction=restriction, group=self._group, min_dofs=self._min_dofs)
+            self.ctx = self.dmg.ctx
+            L = self.levels[-1]
+            self.saddle = DistSaddle(self.dmg, self.B, self.vol, L.V.cell_nodes, self.nu, self.gamma,
+                                     remove_constant_nullspace=self.nullspace)
+
+        def _push_operators(self):
+            self.dmg.update(self.levels)
+
+        def _set_parameters(self):
+            # transfers present on this rank link local levels lmin.. ; their (nu, gamma) follow the solver's
+            ltr = self.dmg.local_transfers
+            for T, dt in zip(ltr, self.dmg.mg.transfers):
+                if T.nu != self.nu:
+                    T.nu = self.nu
+                    with self._on_stream():
+                        dt.update(self.nu, self.gamma)
+            for T in self.transfers:
+                T.nu = self.nu
+            self.saddle.nu, self.saddle.gamma = self.nu, self.gamma
+
+        def _on_stream(self):
+            import torch
+            return torch.cuda.stream(self.dmg.stream)
+
+        def _linear_solve(self, rhs):
+            import torch
+            sad, part = self.saddle, self.dmg.fine.part
+            loc = np.concatenate([rhs[:self.n_u][part.own_dofs()], rhs[self.n_u:][sad.cells]])
+            x, its, rn = sad.solve(torch.tensor(loc, dtype=torch.float64, device=self.dmg.device), self.rtol, self.atol,
+                                   self.params["ksp_max_it"], 30)
+            self.dmg.sync()
+            x = x.cpu().numpy()
+            pieces = self.dmg.comm.all_gather_object((part.own_dofs(), sad.cells, x[:sad.n_own], x[sad.n_own:]))
+            delta = np.zeros(self.n_u + self.n_p)
+            for dofs, cells, xu, xp in pieces:
+                delta[dofs] = xu
+                delta[self.n_u + np.asarray(cells)] = xp
+            return delta, its, rn
+
+        def close(self):
+            self.saddle.close()
+            self.dmg.close()
+
+    return DistNavierStokesSolver
+
+
+def DistNavierStokesSolver(*args, **kwargs):
+    """Factory (the class derives from alfi_amd.nssolver.HipNavierStokesSolver, imported lazily)."""
+    return _dist_ns_solver_class()(*args, **kwargs)

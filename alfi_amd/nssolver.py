@@ -45,7 +45,7 @@ class HipNavierStokesSolver(object):
         """discretisation: "pkp0" ([P_k(+FB)]^d - P0 on the uniform hierarchy, ConstantPressureSolver solver.py:561-602) or
         "sv" ([P_k]^d - P_{k-1}^dg on the barycentric hierarchy with macro-star patches, ScottVogeliusSolver :604-662)."""
         self.problem, self.gamma, self.verbose = problem, float(gamma), verbose
-        self.ctx = ctx or hip.Context(0)
+        self._ctx_arg = ctx
         dim = problem.dim
         self.sv = discretisation == "sv"
         # stabilisation (solver.py:56-58, 66-68, 204-234): SUPG with the Shakib-Hughes-Johan coefficient (supg_method
@@ -74,20 +74,17 @@ class HipNavierStokesSolver(object):
         else:
             mgl = mg_levels_solver(dim, smoothing=smoothing)
         self.params = outer_solver(dim, fieldsplit_0_mg(mgl))
-        self.hmg = HipMG(self.ctx, self.levels, self.transfers, self.params["fieldsplit_0"], restriction=restriction)
         L = self.levels[-1]
         self.nu = self.char_L * self.char_U
+        self.Minv = None
         if self.sv:
-            self.B, M, Minv = build_sv_pressure_coupling(L)                  # Dirichlet columns zeroed: the Jacobian's B
+            self.B, M, self.Minv = build_sv_pressure_coupling(L)             # Dirichlet columns zeroed: the Jacobian's B
             self.B_raw, _, _ = build_sv_pressure_coupling(L, zero_bc_columns=False)
             self.vol = np.asarray(M.sum(axis=1)).ravel()                    # int psi_j: weights of the pressure integral
-            self.saddle = hip.Saddle(self.hmg.mg, self.B, None, self.nu, self.gamma,
-                                     remove_constant_nullspace=self.nullspace, mass_inv=Minv)
         else:
             self.B, self.vol = build_pressure_coupling(L)                     # Dirichlet columns zeroed: the Jacobian's B
             self.B_raw, _ = build_pressure_coupling(L, zero_bc_columns=False)  # all columns: the residual's B
-            self.saddle = hip.Saddle(self.hmg.mg, self.B, self.vol, self.nu, self.gamma,
-                                     remove_constant_nullspace=self.nullspace)
+        self._create_device(restriction)
         self.rtol, self.atol = self.params["ksp_rtol"], self.params["ksp_atol"]
         tol2, tol3 = (1e-9, 1e-8), (1e-8, 1e-8)                            # snes_rtol / snes_atol, solver.py:484-499
         self.snes_rtol = snes_rtol if snes_rtol is not None else (tol2 if dim == 2 else tol3)[0]
@@ -100,6 +97,36 @@ class HipNavierStokesSolver(object):
         self.u.reshape(-1, dim)[bc_nodes] = problem.driver(L.V.node_coords[bc_nodes])
         self.p = np.zeros(self.n_p)
         self.area = float(self.vol.sum())
+
+    # -- device side (overridden by alfi_amd.dist.DistNavierStokesSolver for partitioned levels) -------------------------
+    def _create_device(self, restriction):
+        self.ctx = self._ctx_arg or hip.Context(0)
+        self.hmg = HipMG(self.ctx, self.levels, self.transfers, self.params["fieldsplit_0"], restriction=restriction)
+        self.saddle = hip.Saddle(self.hmg.mg, self.B, None if self.sv else self.vol, self.nu, self.gamma,
+                                 remove_constant_nullspace=self.nullspace, mass_inv=self.Minv)
+
+    def _push_operators(self):
+        """New operator values on every level: re-gather and re-invert the patches, new coarse inverse."""
+        self.hmg.update(self.levels)
+        self.hmg.mg.levels[0].update_values(self.levels[0].A.vals)
+        self.hmg.mg.levels[0].set_coarse_inverse(hip.coarse_inverse(self.levels[0].A))
+
+    def _set_parameters(self):
+        for T, dt in zip(self.transfers, self.hmg.mg.transfers):            # AutoSchoeberlTransfer.rebuild, transfer.py:173-184
+            if T.nu != self.nu:
+                T.nu = self.nu
+                dt.update(self.nu, self.gamma)
+        self.saddle.update(self.nu, self.gamma)
+
+    def _linear_solve(self, rhs):
+        """J d = rhs for the current operators: (d, Krylov iterations, true residual norm)."""
+        db, dx = self.ctx.vec(rhs), self.ctx.vec(self.n_u + self.n_p)
+        its, rn = self.saddle.solve(db, dx, self.rtol, self.atol, self.params["ksp_max_it"], 30)
+        return dx.get(), its, rn
+
+    def close(self):
+        self.saddle.close()
+        self.hmg.mg.close()
 
     # -- host side: state on all levels, operators, residual -------------------------------------------------------------
     def _winds(self, u):
@@ -129,9 +156,7 @@ class HipNavierStokesSolver(object):
         for L, w in zip(self.levels, winds):
             L.A = BSR(L.A.nbrows, L.A.nbcols, L.bs, L.A.rowptr, L.A.colidx, self.level_values(L, w, adv, True))
             L.nu = self.nu
-        self.hmg.update(self.levels)
-        self.hmg.mg.levels[0].update_values(self.levels[0].A.vals)
-        self.hmg.mg.levels[0].set_coarse_inverse(hip.coarse_inverse(self.levels[0].A))
+        self._push_operators()
 
     def residual(self, u, p, adv):
         """F(u, p) of solver.py:565-568 (rhs = 0), Dirichlet rows zeroed (``bc.zero(F)``, solver.py:282-286)."""
@@ -161,11 +186,7 @@ class HipNavierStokesSolver(object):
             adv, self.nu = 0.0, self.char_L * self.char_U                   # Stokes, solver.py:261-264
         else:
             adv, self.nu = 1.0, self.char_L * self.char_U / re
-        for T, dt in zip(self.transfers, self.hmg.mg.transfers):            # AutoSchoeberlTransfer.rebuild, transfer.py:173-184
-            if T.nu != self.nu:
-                T.nu = self.nu
-                dt.update(self.nu, self.gamma)
-        self.saddle.update(self.nu, self.gamma)
+        self._set_parameters()
         u, p = self.u.copy(), self.p.copy()
         lin_its, newton_its = 0, 0
         Fu, Fp = self.residual(u, p, adv)
@@ -174,9 +195,7 @@ class HipNavierStokesSolver(object):
         while fnorm > max(self.snes_rtol * f0, self.snes_atol) and newton_its < self.snes_max_it:
             self._rediscretise(u, adv)
             rhs = -np.concatenate([Fu, Fp])
-            db, dx = self.ctx.vec(rhs), self.ctx.vec(self.n_u + self.n_p)
-            its, rn = self.saddle.solve(db, dx, self.rtol, self.atol, self.params["ksp_max_it"], 30)
-            delta = dx.get()
+            delta, its, rn = self._linear_solve(rhs)
             u += delta[:self.n_u]
             p += delta[self.n_u:]
             lin_its += its
@@ -194,10 +213,6 @@ class HipNavierStokesSolver(object):
                 "time": (time.time() - t0) / 60.0, "residual_history": hist,
                 "converged": fnorm <= max(self.snes_rtol * f0, self.snes_atol)}
         return (u, p), info
-
-    def close(self):
-        self.saddle.close()
-        self.hmg.mg.close()
 
 
 def run_solver(solver, res):

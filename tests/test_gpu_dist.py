@@ -172,3 +172,29 @@ def test_partitioned_outer_solve(case, world, tmp_path):
     assert not np.isnan(xu).any() and not np.isnan(xp).any()
     assert np.abs(xu - xs[:L.n]).max() < 1e-6 * np.abs(xs[:L.n]).max()
     assert np.abs(xp - xs[L.n:]).max() < 1e-5 * np.abs(xs[L.n:]).max()
+
+
+def test_partitioned_newton(tmp_path):
+    """Newton + Reynolds continuation with every linear solve on partitioned levels (2 ranks): same Newton / Krylov counts
+    and the same solution as the single-GPU solver."""
+    from alfi_amd.nssolver import HipNavierStokesSolver, run_solver
+    from alfi_amd.problem import TwoDimLidDrivenCavityProblem
+    world = 2
+    port = _free_port()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), OMP_NUM_THREADS="4")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dist_gpu_newton_worker.py"),
+                                       str(tmp_path)], env=env, cwd=ROOT))
+    s = HipNavierStokesSolver(TwoDimLidDrivenCavityProblem(8), 1, 2)
+    res = run_solver(s, [10, 100])
+    for p in procs:
+        assert p.wait(timeout=600) == 0
+    z = np.load(os.path.join(str(tmp_path), "newton.npz"))
+    assert all(z["conv"]) and all(res[r]["converged"] for r in (10, 100))
+    assert list(z["newton"]) == [res[r]["nonlinear_iter"] for r in (10, 100)]
+    assert all(abs(int(a) - res[r]["linear_iter"]) <= 2 for a, r in zip(z["its"], (10, 100)))
+    assert np.abs(z["u"] - s.u).max() < 1e-7 * np.abs(s.u).max()
+    assert np.abs(z["p"] - s.p).max() < 1e-6 * np.abs(s.p).max()
+    s.close()
