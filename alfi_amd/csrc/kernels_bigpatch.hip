@@ -74,36 +74,50 @@ __global__ __launch_bounds__(256) void big_gather_kernel(int64_t p0, const int32
 __global__ __launch_bounds__(256) void big_pivot_kernel(int k0, const int64_t* __restrict__ patch_ptr, int64_t p0,
                                                          const int64_t* __restrict__ scr_ptr, const double* __restrict__ scr,
                                                          double* __restrict__ dinv, int* __restrict__ status) {
-  __shared__ double D[BIG_NB][BIG_NB + 1];     // pivot block, becomes its inverse
+  // Gauss-Jordan on the 64 x 64 pivot block held in REGISTERS: thread (row i = t / 4, q = t % 4) owns D[i][q + 4 m],
+  // m = 0..15.  Per elimination step the four threads of a row get their multiplier D[i][k] by a shuffle inside their
+  // lane quad, the pivot row travels through a double-buffered LDS line, and there is ONE barrier (the first version
+  // kept D in LDS with three barriers per step: 184 us per launch).  The k loop is fully unrolled so that every register
+  // index is a compile-time constant.
+  __shared__ double rowbuf[2][BIG_NB];
   const int64_t p = p0 + blockIdx.x;
   const int n = (int)(patch_ptr[p + 1] - patch_ptr[p]);
   const int N = (n + BIG_NB - 1) / BIG_NB * BIG_NB;
   if (k0 >= N) return;                          // smaller patch of the batch: already done
   const double* S = scr + scr_ptr[blockIdx.x];
   const int t = threadIdx.x;
-  for (int e = t; e < BIG_NB * BIG_NB; e += 256) D[e / BIG_NB][e % BIG_NB] = S[(int64_t)(k0 + e / BIG_NB) * N + k0 + e % BIG_NB];
-  __syncthreads();
-  // in-place Gauss-Jordan, thread (i, jq) owns row i, columns jq, jq + 4, ...
-  const int gi = t >> 2, gq = t & 3;
+  const int gi = t >> 2, gq = t & 3, lane = t & 63;
+  double a[16];
+#pragma unroll
+  for (int m = 0; m < 16; ++m) a[m] = S[(int64_t)(k0 + gi) * N + k0 + gq + 4 * m];
   bool bad = false;
+#pragma unroll
   for (int k = 0; k < BIG_NB; ++k) {
-    const double piv = D[k][k];
-    if (piv == 0.0) bad = true;
-    const double ip = 1.0 / piv;
-    const double f = D[gi][k];
-    __syncthreads();
-    if (gi == k) {
-      for (int j = gq; j < BIG_NB; j += 4) D[k][j] = (j == k) ? ip : D[k][j] * ip;
+    const int kq = k & 3, km = k >> 2;
+    const double f = __shfl(a[km], (lane & ~3) | kq, 64);     // D[gi][k]
+    double* rb = rowbuf[k & 1];
+    if (gi == k) {                                            // wave-uniform for 63 of 64 rows' waves: one quad diverges
+      if (f == 0.0) bad = true;
+      const double ip = 1.0 / f;
+#pragma unroll
+      for (int m = 0; m < 16; ++m) {
+        a[m] = (m == km && gq == kq) ? ip : a[m] * ip;
+        rb[gq + 4 * m] = a[m];
+      }
     }
     __syncthreads();
     if (gi != k) {
-      for (int j = gq; j < BIG_NB; j += 4) D[gi][j] = (j == k) ? -f * ip : __builtin_fma(-f, D[k][j], D[gi][j]);
+#pragma unroll
+      for (int m = 0; m < 16; ++m) {
+        const double rk = rb[gq + 4 * m];
+        a[m] = (m == km && gq == kq) ? -f * rk : __builtin_fma(-f, rk, a[m]);
+      }
     }
-    __syncthreads();
   }
-  if (bad && t == 0) atomicExch(status, 1);
+  if (bad) atomicExch(status, 1);
   double* Dg = dinv + (int64_t)blockIdx.x * BIG_NB * BIG_NB;
-  for (int e = t; e < BIG_NB * BIG_NB; e += 256) Dg[e] = D[e / BIG_NB][e % BIG_NB];
+#pragma unroll
+  for (int m = 0; m < 16; ++m) Dg[gi * BIG_NB + gq + 4 * m] = a[m];
 }
 
 typedef double big_d4 __attribute__((ext_vector_type(4)));
@@ -268,6 +282,14 @@ __global__ __launch_bounds__(256) void big_update_kernel(int k0, const int64_t* 
   for (int a = 0; a < 2; ++a)
 #pragma unroll
     for (int b = 0; b < 2; ++b) acc[a][b] = (big_d4){0.0, 0.0, 0.0, 0.0};
+  // the tile of S is fetched before the product so that its latency hides behind the matrix-core work
+  double sold[2][2][4];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) sold[a][b][g] = S[(int64_t)(r0 + 16 * a + lk + 4 * g) * N + c0 + 16 * b + lm];
   big_tile_product(F + (int64_t)ti * BIG_NB * BIG_NB, BIG_NB, R + tj * BIG_NB, N, BIG_NB, As, Bs, acc);
 #pragma unroll
   for (int a = 0; a < 2; ++a)
@@ -276,7 +298,7 @@ __global__ __launch_bounds__(256) void big_update_kernel(int k0, const int64_t* 
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const int64_t at = (int64_t)(r0 + 16 * a + lk + 4 * g) * N + c0 + 16 * b + lm;
-        S[at] -= acc[a][b][g];
+        S[at] = sold[a][b][g] - acc[a][b][g];
       }
 }
 
