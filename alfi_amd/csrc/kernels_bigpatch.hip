@@ -308,7 +308,8 @@ __global__ __launch_bounds__(256) void big_update_kernel(int k0, const int64_t* 
 //      (relative difference to LAPACK's inverse 2e-5 against 1e-10 for the scalar register kernel of the small patches,
 //      measured).  One polish step squares the error (measured afterwards: see DESIGN.md).
 //        mode 0: C = I - A B        mode 1: C = A0 + A B   (A0 = the left operand itself)
-//      big_tile_product with K = N: 35 TFLOP/s (the first version, fragments straight from global memory: 19.5).
+//      big_tile_product with K = N: 36 TFLOP/s, 62 % MFMA-busy (the first version, fragments straight from global memory:
+//      19.5; a 64 x 128 workgroup tile with 2 x 4 MFMA blocks per wave and 48 KB of LDS: 33 -- two waves per SIMD).
 // ---------------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void big_gemm_kernel(int mode, const int64_t* __restrict__ patch_ptr, int64_t p0,
                                                         const int64_t* __restrict__ scr_ptr,
