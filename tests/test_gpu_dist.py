@@ -111,7 +111,8 @@ def test_rccl_code_path_with_a_one_rank_group(tmp_path, exact_norm, tol):
     ''' % (ROOT, tol, tol)))
     # ALFI_DIST_EXACT_NORM=1: |w| by its own all-reduce (PETSc's VecNorm) -> the partitioned path reproduces the serial one
     # to rounding; default: |w|^2 = |w_old|^2 - |h|^2 from the single all-reduce of the iteration
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), ALFI_DIST_EXACT_NORM=exact_norm)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), ALFI_DIST_EXACT_NORM=exact_norm,
+               ALFI_DIST_OVERLAP_MIN_DOFS="0")      # the asynchronous (overlapped) exchanges too, on these small levels
     out = subprocess.run([sys.executable, str(script)], env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "ONE-RANK-RCCL-OK" in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]
 
