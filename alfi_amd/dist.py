@@ -491,7 +491,7 @@ class DistMultigrid(object):
         self._red_views = {}
         if overlap_min_dofs is None:
             import os
-            overlap_min_dofs = int(os.environ.get("ALFI_DIST_OVERLAP_MIN_DOFS", "2000000"))
+            overlap_min_dofs = int(os.environ.get("ALFI_DIST_OVERLAP_MIN_DOFS", str(1 << 62)))
         if device is None:
             device = torch.device("cuda", torch.cuda.current_device())
         self.device = device
@@ -522,12 +522,12 @@ class DistMultigrid(object):
                     dl.set_patches(LL.patch_ptr, LL.patch_dofs)
                     dl.factor()
                     if p.distributed and overlap and p.nb_own * p.bs >= overlap_min_dofs:
-                        # interior rows / patches are worked on while the forward halo is in flight.  Only where a rank
-                        # owns enough for that to pay: the split launches and the asynchronous begin/end pairs (RCCL's
-                        # own stream, two cross-stream waits each) have a fixed cost -- measured with a 1-rank RCCL group
-                        # and all exchange points on: 173 k dofs 8.9 ms per cycle with, 7.0 ms without (plain path 5.2);
-                        # 1.35 M dofs +7.4 ms with, +3.3 ms without -- more than the ~3 ms of wire time the overlap can
-                        # hide at 8 ranks, so the default keeps it for shares above 2 M dofs (2 and 4 ranks on config 4)
+                        # interior rows / patches are worked on while the forward halo is in flight.  Opt-in
+                        # (ALFI_DIST_OVERLAP_MIN_DOFS = smallest per-rank share that overlaps): the split launches and the
+                        # asynchronous begin/end pairs (RCCL's own stream, two cross-stream waits each) have a fixed cost
+                        # -- measured with a 1-rank RCCL group and all exchange points on: 173 k dofs 8.9 ms per cycle
+                        # with, 7.0 ms without (plain path 5.2); 1.35 M dofs +7.4 ms with, +3.3 ms without -- which is
+                        # more than the ~3 ms of wire time per cycle the overlap can hide on config 4 at 2 to 8 ranks
                         dl.set_overlap(p.nb_int, LL.npatch_int)
                 elif p.nb_own > 0:
                     inv = coarse_inverse(levels[0].A) if coarse_inverse is not None else hip.coarse_inverse(levels[0].A)
