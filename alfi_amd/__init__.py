@@ -3,7 +3,7 @@ Schoeberl transfers, PCMG cycles) behind alfi's plug-in surface.  Module paths f
 like ``"alfi_amd.Star"`` resolve the way ``"alfi.Star"`` does (alfi/__init__.py:1-6)."""
 from .relaxation import OrderedRelaxation, Star, MacroStar, Options, PlexLike      # noqa: F401
 from .problem import (NavierStokesProblem, TwoDimLidDrivenCavityProblem,            # noqa: F401
-                      ThreeDimLidDrivenCavityProblem, build_hierarchy)
+                      ThreeDimLidDrivenCavityProblem, ThreeDimBackwardsFacingStepProblem, build_hierarchy)
 
 
 def __getattr__(name):
@@ -12,8 +12,8 @@ def __getattr__(name):
                 "HipOuterSolver"):
         from . import solver
         return getattr(solver, name)
-    if name in ("PkP0SchoeberlTransfer", "AutoSchoeberlTransfer", "CoarseCellPatches", "NullTransfer", "Constant",
-                "Function"):
+    if name in ("PkP0SchoeberlTransfer", "SVSchoeberlTransfer", "AutoSchoeberlTransfer", "CoarseCellPatches",
+                "CoarseCellMacroPatches", "NullTransfer", "Constant", "Function"):
         from . import transfer
         return getattr(transfer, name)
     raise AttributeError(name)

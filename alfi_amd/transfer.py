@@ -62,10 +62,23 @@ class CoarseCellPatches(object):
         return [b for b in blocks], np.arange(blocks.shape[0], dtype=np.int64)
 
 
+class CoarseCellMacroPatches(object):
+    """transfer.py:49-88: on a barycentric hierarchy one patch per coarse MACRO cell = the fine points strictly inside it
+    (``sv.macro_cell_blocks``)."""
+
+    def __call__(self, pc):
+        from .sv import macro_cell_blocks
+        blocks = macro_cell_blocks(pc.level_data.V)
+        return [b for b in blocks], np.arange(blocks.shape[0], dtype=np.int64)
+
+
 class AutoSchoeberlTransfer(object):
+    hierarchies = ("uniform",)
+
     def __init__(self, parameters, tdim, hierarchy, ctx=None):
-        if hierarchy != "uniform":
-            raise NotImplementedError("hierarchy %r: only uniform refinement (bary: SURVEY.md section 8(f))" % hierarchy)
+        if hierarchy not in self.hierarchies:
+            raise NotImplementedError("%s on a %r hierarchy (PkP0SchoeberlTransfer: uniform; SVSchoeberlTransfer: bary)"
+                                      % (type(self).__name__, hierarchy))
         self.parameters = parameters
         self.tdim = tdim
         self.ctx = ctx
@@ -100,7 +113,9 @@ class AutoSchoeberlTransfer(object):
         if self.ctx is None:
             self.ctx = hip.Context(0)
         nu, gamma = (float(p) for p in self.parameters)
-        T = build_transfer_data(Vc, Vf, nu, gamma)
+        T = self._transfer_data(Vc, Vf, nu, gamma)
+        self._inject_matrix = getattr(self, "_inject_matrix", {})
+        self._inject_matrix[Vf.num_dofs] = getattr(T, "inject_matrix", None) if T.inject_map is None else None
 
         def shell(V):       # a level without operator: only sizes and Dirichlet dofs are needed by the transfer
             empty = BSR(V.num_nodes, V.num_nodes, V.dim, np.zeros(V.num_nodes + 1, dtype=np.int32),
@@ -110,6 +125,9 @@ class AutoSchoeberlTransfer(object):
         dev = hip.Transfer(self.ctx, lc, lf, T)
         dev.update(nu, gamma)
         return dev, (lc, lf)
+
+    def _transfer_data(self, Vc, Vf, nu, gamma):
+        return build_transfer_data(Vc, Vf, nu, gamma)
 
     def restrict_or_prolong(self, source, target, mode):
         coarse, fine = (source, target) if mode == "prolong" else (target, source)
@@ -141,6 +159,10 @@ class AutoSchoeberlTransfer(object):
             self.solver[key] = self._setup(Vc, Vf)
             self.prev_parameters[key] = [float(p) for p in self.parameters]
         dev, ctx = self.solver[key][0], self.ctx
+        J = self._inject_matrix.get(key)
+        if J is not None:          # non-nested (bary) hierarchy: point evaluation at the coarse nodes, a host matrix
+            coarse.dat.data[:] = J @ fine.dat.data
+            return
         dxf, dxc = ctx.vec(fine.dat.data.ravel()), ctx.vec(Vc.num_dofs)
         dev.inject(dxf, dxc)
         coarse.dat.data[:] = dxc.get().reshape(coarse.dat.data.shape)
@@ -149,6 +171,18 @@ class AutoSchoeberlTransfer(object):
 class PkP0SchoeberlTransfer(AutoSchoeberlTransfer):
     """transfer.py:312-356: forms nu (2 sym grad u, grad v) + gamma (cell_avg div u, div v); the standard transfer is
     the bubble transfer for 3-D P1+FB and nodal interpolation otherwise (decided in fespace.vector_prolongation)."""
+
+
+class SVSchoeberlTransfer(AutoSchoeberlTransfer):
+    """transfer.py:293-309: Scott-Vogelius forms nu (2 sym grad u, grad v) + gamma (div u, div v) on a barycentric hierarchy;
+    interior blocks = coarse macro cells (CoarseCellMacroPatches), standard transfer = firedrake's non-nested prolong
+    (``sv.bary_prolongation``)."""
+    hierarchies = ("bary",)
+
+    def _transfer_data(self, Vc, Vf, nu, gamma):
+        from . import _hostlib
+        from .sv import build_sv_transfer_data
+        return build_sv_transfer_data(Vc, Vf, nu, gamma, _hostlib.node_graph(Vf.cell_nodes, Vf.num_nodes))
 
 
 class NullTransfer(object):

@@ -197,6 +197,50 @@ def test_schoeberl_transfer_object_protocol():
 
 
 @pytest.mark.gpu
+def test_sv_schoeberl_transfer_object_protocol():
+    """SVSchoeberlTransfer((nu, gamma), tdim, "bary") (transfer.py:293-309) with the reference's prolong / restrict / inject
+    protocol on a barycentric hierarchy; PkP0SchoeberlTransfer refuses that hierarchy and vice versa."""
+    from alfi_amd import Constant, Function, PkP0SchoeberlTransfer, SVSchoeberlTransfer, CoarseCellMacroPatches
+    from alfi_amd.sv import build_sv_hierarchy
+    from oracle import alfi_oracle as O
+    lv, tr = build_sv_hierarchy(TwoDimLidDrivenCavityProblem(2), 1, 2, Re=100.0)
+    nu, gamma = Constant(lv[-1].nu), Constant(lv[-1].gamma)
+    with pytest.raises(NotImplementedError):
+        PkP0SchoeberlTransfer((nu, gamma), 2, "bary")
+    with pytest.raises(NotImplementedError):
+        SVSchoeberlTransfer((nu, gamma), 2, "uniform")
+    vt = SVSchoeberlTransfer((nu, gamma), 2, "bary")
+    Vc, Vf = lv[0].V, lv[1].V
+    rng = np.random.default_rng(1)
+    uc = rng.standard_normal(Vc.num_dofs)
+    uc[lv[0].bc_dofs] = 0
+    coarse, fine = Function(Vc, uc), Function(Vf)
+    vt.prolong(coarse, fine)
+    ot = O.oracle_transfer(tr[-1], lv[-1], True).st
+    ref = ot.prolong(uc)
+    ref[lv[1].bc_dofs] = 0
+    assert np.abs(fine.dat.data.ravel() - ref).max() < 1e-8 * np.abs(ref).max()
+    r = rng.standard_normal(Vf.num_dofs)
+    fr, cr = Function(Vf, r), Function(Vc)
+    vt.restrict(fr, cr)
+    ref = ot.restrict(r)
+    ref[lv[0].bc_dofs] = 0
+    assert np.abs(cr.dat.data.ravel() - ref).max() < 1e-8 * np.abs(ref).max()
+    # inject on the non-nested hierarchy: point evaluation; inject(prolong(P2 field)) is the identity
+    X = Vc.node_coords
+    q = np.stack([X[:, 0] ** 2 - X[:, 1], X[:, 0] * X[:, 1]], axis=1)
+    fi, ci = Function(Vf, tr[-1].P.to_scipy() @ q.ravel()), Function(Vc)
+    vt.inject(fi, ci)
+    assert np.abs(ci.dat.data - q).max() < 1e-12
+
+    class _PC(object):
+        level_data = lv[1]
+    blocks, it = CoarseCellMacroPatches()(_PC())
+    assert np.array_equal(np.asarray(blocks), tr[-1].blk_dofs[:, ::2] // 2)
+    vt.break_ref_cycles()
+
+
+@pytest.mark.gpu
 def test_macro_star_patches_through_the_option_dictionary():
     """``patch="macro"`` (solver.py:339-343): python-constructed ``MacroStar`` patches (relaxation.py:163-177) -- one per
     MacroVertices-labelled vertex, the union of the stars of every vertex of its macro neighbourhood; 74 dofs for an
