@@ -74,6 +74,7 @@ SIGNATURES = {
     "alfi_mg_destroy": (ctypes.c_int, [vp]),
     "alfi_mg_vcycle": (ctypes.c_int, [vp, vp, vp]),
     "alfi_mg_fcycle": (ctypes.c_int, [vp, vp, vp]),
+    "alfi_ctx_set_graph": (ctypes.c_int, [vp, ctypes.c_int]),
     "alfi_saddle_create": (ctypes.c_int, [vp, ctypes.POINTER(CsrHost), ctypes.POINTER(CsrHost), vp, ctypes.c_double,
                                           ctypes.c_double, ctypes.c_int, ctypes.POINTER(vp)]),
     "alfi_saddle_destroy": (ctypes.c_int, [vp]),

@@ -10,6 +10,7 @@
 struct alfi_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
+  bool use_graph = false;           // alfi_ctx_set_graph: replay whole cycles as hipGraphs (not while profiling / partitioned)
   void* big_arena = nullptr;        // scratch of the large-block factorisation (kernels_bigpatch.hip), kept between calls
   size_t big_arena_bytes = 0;
   bool own_stream = false;
@@ -203,12 +204,23 @@ struct alfi_transfer {
   int* status = nullptr;
 };
 
+// one captured cycle (alfi_ctx_set_graph): the whole V- or full cycle for a given (b, x) pair replayed as a hipGraph
+struct CycleGraph {
+  int kind = 0;                 // 0 V-cycle, 1 full cycle
+  const double* b = nullptr;
+  double* x = nullptr;
+  std::vector<uint64_t> sig;    // everything a captured kernel argument depends on (pointers, nu, gamma, k, ...)
+  hipGraphExec_t exec = nullptr;
+  bool failed = false;          // capture was refused once: run this cycle eagerly from then on
+};
+
 struct alfi_mg {
   alfi_ctx* ctx = nullptr;
   std::vector<alfi_level*> levels;
   std::vector<alfi_transfer*> transfers;
   int k = 0;
   int robust = 0;
+  std::vector<CycleGraph> graphs;
 };
 
 struct DevCSR {

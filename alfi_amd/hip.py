@@ -57,6 +57,10 @@ class Context(object):
         return v
 
     # profiling (PETSc-event style report, driver.py:77-92) ----------------------------------------------------------------
+    def set_graph(self, on=True):
+        """Replay whole multigrid cycles as hipGraphs (alfi_ctx_set_graph)."""
+        self.check(self.lib.alfi_ctx_set_graph(self.h, 1 if on else 0))
+
     def prof_enable(self, on=True):
         """True / 1: every event class; 2: PATCH_APPLY and COMM only; False / 0: off."""
         self.check(self.lib.alfi_prof_enable(self.h, int(on)))

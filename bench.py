@@ -265,6 +265,9 @@ def main():
     ap.add_argument("--outer", action="store_true",
                     help="also time one outer linear solve (FGMRES + fieldsplit Schur, alfi/solver.py:386-422) and "
                          "report it as `outer_solve`; not part of the headline metric")
+    ap.add_argument("--graph", action="store_true",
+                    help="after the timed (eager, event-instrumented) cycles also time the same cycles replayed as a "
+                         "hipGraph (alfi_ctx_set_graph) and report them as `graph_replay`; single GPU only")
     ap.add_argument("--verbose", action="store_true")
     args = ap.parse_args()
 
@@ -345,6 +348,30 @@ def main():
     ctx.sync()
     fcycle_ms = 1e3 * (time.perf_counter() - t0) / 2
 
+    graph_replay = None
+    if args.graph:
+        ctx.set_graph(True)
+        dxg = ctx.vec(L.n)
+        for _ in range(3):                      # eager, capture, first replay
+            dmg.vcycle(db, dxg)
+        ctx.sync()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            dmg.vcycle(db, dxg)
+        ctx.sync()
+        tg = (time.perf_counter() - t0) / args.steps
+        ctx.set_graph(False)
+        ctx.prof_enable(False)
+        dxe = ctx.vec(L.n)
+        dmg.vcycle(db, dxe)
+        ctx.sync()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            dmg.vcycle(db, dxe)
+        ctx.sync()
+        te = (time.perf_counter() - t0) / args.steps
+        graph_replay = {"ms_per_step": 1e3 * tg, "v_cycles_per_s": 1.0 / tg, "eager_without_events_ms_per_step": 1e3 * te,
+                        "note": "same V-cycles replayed as one hipGraph; `value` above is the eager run with HIP events"}
     ms_per_step = 1e3 * elapsed / args.steps
     vps = args.steps / elapsed
     nlev = len(lv)
@@ -407,6 +434,8 @@ def main():
         "setup_s": {"host_generation": round(t_gen, 1), "device_setup_incl_patch_inversion": round(t_setup, 1),
                     "host_peak_rss_GB": round(resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 1e6, 1)},
     }
+    if graph_replay is not None:
+        out["graph_replay"] = graph_replay
     if args.outer:
         t0 = time.time()
         if CONFIGS[args.config][0] == "sv":      # discontinuous P2 pressure, block DGMassInv; bfs3d has an outflow: no nullspace

@@ -197,6 +197,11 @@ int alfi_mg_destroy(alfi_mg* mg);
 int alfi_mg_vcycle(alfi_mg* mg, const double* db, double* dx);
 /* pc_mg_type full (solver.py:366): x <- F(b), x need not be initialised (PCMGFCycle_Private) */
 int alfi_mg_fcycle(alfi_mg* mg, const double* db, double* dx);
+/* on != 0: alfi_mg_vcycle / alfi_mg_fcycle replay their launch sequence as a hipGraph from the second call with the same
+ * (db, dx) pair on (the small levels of a hierarchy are launch-bound).  New operator values in place need no new capture;
+ * new (nu, gamma), patches, coarse inverse or smoother length re-capture.  Runs with profiling on or on partitioned
+ * levels stay eager. */
+int alfi_ctx_set_graph(alfi_ctx* ctx, int on);
 
 /* ---- outer solve around the path: alfi/solver.py:386-422, 463-499 ------------------------------------------------------- */
 /* The linear system of one Newton step, [A B^T; B 0] [u; p] = [f; g], solved as the reference configures PETSc:

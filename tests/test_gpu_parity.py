@@ -434,3 +434,57 @@ def test_large_patches(ctx, bs):
     zref = O.fgmres(lambda v: S @ v, sm.apply, b, np.zeros_like(b), 3, nonzero_guess=False)
     assert np.abs(dz.get() - zref).max() < 1e-8 * np.abs(zref).max()
     lvl.close()
+
+
+@pytest.mark.parametrize("composition", ["additive", "multiplicative"])
+def test_cycles_replayed_as_hip_graphs(ctx, composition):
+    """alfi_ctx_set_graph: the captured V- and full cycles give bit-identical results to the eager ones, pick up new
+    operator values written in place, and re-capture when (nu, gamma) of a transfer change."""
+    from alfi_amd import hip
+    from alfi_amd.problem import TwoDimLidDrivenCavityProblem, build_hierarchy
+    from alfi_amd.relaxation import OrderedRelaxation, Options
+    lv, tr = build_hierarchy(TwoDimLidDrivenCavityProblem(4), 2, 2, Re=100.0)
+    mg = hip.Multigrid(ctx, lv, tr, 3, robust_restriction=True)
+    if composition == "multiplicative":
+        for Lh, dl in zip(lv[1:], mg.levels[1:]):
+            orl = OrderedRelaxation()
+            orl.name = "Star"
+            orl.opts = Options("", {"pc_patch_construction_Star_sort_order": "0+:1-"})
+            dl.set_multiplicative(orl.iteration_order(Lh.V.mesh.coords[Lh.patch_seeds]), True)
+    L = lv[-1]
+    rng = np.random.default_rng(5)
+    b = rng.standard_normal(L.n)
+    b[L.bc_dofs] = 0
+    db, dx = ctx.vec(b), ctx.vec(L.n)
+
+    def run(cycle, reps):
+        outs = []
+        for _ in range(reps):
+            dx.zero()
+            cycle(db, dx)
+            outs.append(dx.get())
+        return outs
+    ev, ef = run(mg.vcycle, 1)[0], run(mg.fcycle, 1)[0]
+    ctx.set_graph(True)
+    try:
+        gv = run(mg.vcycle, 4)          # eager, capture + replay, replay, replay
+        gf = run(mg.fcycle, 3)
+        assert all(np.array_equal(g, ev) for g in gv) and all(np.array_equal(g, ef) for g in gf)
+        # new operator values in place: the replay must see them
+        vals = L.A.vals * 1.5
+        mg.levels[-1].update_values(vals)
+        mg.levels[-1].factor()
+        g2 = run(mg.vcycle, 2)
+        ctx.set_graph(False)
+        e2 = run(mg.vcycle, 1)[0]
+        assert np.array_equal(g2[0], e2) and np.array_equal(g2[1], e2) and not np.array_equal(e2, ev)
+        # new transfer parameters: signature changes, the cycle is captured again
+        ctx.set_graph(True)
+        mg.transfers[-1].update(L.nu * 2, L.gamma)
+        g3 = run(mg.vcycle, 3)
+        ctx.set_graph(False)
+        e3 = run(mg.vcycle, 1)[0]
+        assert all(np.array_equal(g, e3) for g in g3) and not np.array_equal(e3, e2)
+    finally:
+        ctx.set_graph(False)
+        mg.close()
