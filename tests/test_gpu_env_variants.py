@@ -1,0 +1,27 @@
+"""The library's tuning switches (environment variables read once per process) select alternative kernels or skip
+refinement steps; each must still give the cycle -- exactly where it only changes the memory path, to the stated accuracy
+where it drops a refinement.  -m gpu; one subprocess per switch."""
+import os
+import re
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("env,tol", [({}, 1e-5),
+                                     ({"ALFI_NT": "0"}, 1e-5),                    # plain instead of nontemporal loads
+                                     ({"ALFI_SPMV": "legacy"}, 1e-5),             # row-per-wave SpMV, (nnzb, bs, bs) values
+                                     ({"ALFI_BIG_SPLIT": "1"}, 1e-5),             # one workgroup per large patch
+                                     ({"ALFI_BIG_SCRATCH_MB": "64"}, 1e-5),       # many small factorisation batches
+                                     ({"ALFI_BIG_POLISH": "0"}, 5e-2),            # block elimination without Newton-Schulz
+                                     ({"ALFI_TRANSFER_REFINE": "0"}, 1e-3)])      # explicit block inverses without refinement
+def test_switch(env, tol):
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "gpu_env_variant_worker.py")],
+                         env=dict(os.environ, **env), cwd=ROOT, capture_output=True, text=True, timeout=600)
+    m = re.search(r"RELERR (\S+)", out.stdout)
+    assert out.returncode == 0 and m, out.stdout[-2000:] + out.stderr[-3000:]
+    assert float(m.group(1)) < tol, (env, m.group(1))
