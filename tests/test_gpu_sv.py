@@ -38,7 +38,7 @@ def test_sv_transfers_and_cycles_match_oracle(case):
     ctx = hip.Context(0)
     k = 3
     rng = np.random.default_rng(0)
-    for robust in (True, False):
+    for robust in ((True,) if case == "bfs3d-p3" else (True, False)):      # (the oracle needs ~1.5 min per pass on bfs3d)
         mg = hip.Multigrid(ctx, lv, tr, k, robust_restriction=robust)
         omg = O.build_oracle_mg(lv, tr, k, schoeberl_restriction=robust)
         for l in range(1, len(lv)):
