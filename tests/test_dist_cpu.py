@@ -39,6 +39,7 @@ def _hier(case):
 
 
 def _worker(rank, world, port, case, robust, q):
+    os.environ["OMP_NUM_THREADS"] = "1"          # up to 8 ranks on the container's 8 cores
     sys.path.insert(0, ROOT)
     import torch.distributed as dist
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
@@ -77,7 +78,9 @@ def _free_port():
 @pytest.mark.parametrize("case,world,robust", [("2d-all-distributed", 2, False), ("2d-all-distributed", 3, True),
                                                ("2d-coarse-on-rank0", 2, True), ("3d-P2FB", 2, False),
                                                ("3d-P1FB", 2, True), ("3d-P2FB-3lev", 4, True),
-                                               ("2d-SV", 3, True), ("3d-SV-P3", 2, True)])
+                                               ("2d-SV", 3, True), ("3d-SV-P3", 2, True),
+                                               # the driver's widest launch: finest level split eight ways, the rest on rank 0
+                                               ("3d-P2FB-3lev", 8, False)])
 def test_spmd_oracle_matches_serial(case, world, robust):
     import torch.multiprocessing as mp
     from oracle import alfi_oracle as O
