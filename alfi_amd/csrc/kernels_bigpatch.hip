@@ -205,7 +205,8 @@ __global__ __launch_bounds__(256) void big_panel_kernel(int k0, const int64_t* _
 //     XCD-aware placement was tried for this kernel and the polish products (all tiles of a patch on one XCD so that the
 //     shared operand panels stay in one L2): handing each XCD a contiguous eighth of the batch 0.64 s / 0.99 s, dealing
 //     patches round-robin to the XCDs 0.52 s / 0.79 s, against 0.45 s / 0.66 s with the hardware's own round-robin of
-//     workgroups -- which stays.
+//     workgroups -- which stays.  Storing F k-major like R (so that both fragments load coalesced) and dropping the LDS
+//     stage again: 0.54 s, and the transposing panel writes cost another 0.05 s.
 // ---------------------------------------------------------------------------------------------------------------------
 // 64 x 64 tile product on the matrix cores, shared by the trailing update (K = 64) and the polish products (K = N):
 // acc += A[0:64, 0:K] B[0:K, 0:64], A row-major with leading dimension lda, B row-major with ldb.  Both operands pass
