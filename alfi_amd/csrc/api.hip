@@ -135,9 +135,8 @@ static int halo_fwd(alfi_level* L, double* v) {
   int t = alfi_prof_begin(ctx, ALFI_EV_COMM);
   ALFI_CHECK(launch_halo_pack(ctx, L->halo_sendbuf, v, L->halo_send_nodes, L->halo_nsend, L->bs));
   ALFI_CHECK(comm_call(ctx, ALFI_COMM_HALO_FWD, L->id, 0, 0));
-  if (L->halo_nghost > 0)
-    ALFI_HIP_CHECK(ctx, hipMemcpyAsync(v + L->n_own, L->halo_recvbuf, sizeof(double) * L->halo_nghost * L->bs,
-                                       hipMemcpyDeviceToDevice, ctx->stream));
+  // (an own copy kernel: the runtime's device-to-device copy costs more per call than these surface-sized buffers take)
+  ALFI_CHECK(launch_copy(ctx, v + L->n_own, L->halo_recvbuf, L->halo_nghost * L->bs));
   alfi_prof_end(ctx, t);
   return 0;
 }
@@ -155,9 +154,8 @@ static int halo_fwd_end(alfi_level* L, double* v) {
   alfi_ctx* ctx = L->ctx;
   int t = alfi_prof_begin(ctx, ALFI_EV_COMM);
   ALFI_CHECK(comm_call(ctx, ALFI_COMM_HALO_FWD_END, L->id, 0, 0));
-  if (L->halo_nghost > 0)
-    ALFI_HIP_CHECK(ctx, hipMemcpyAsync(v + L->n_own, L->halo_recvbuf, sizeof(double) * L->halo_nghost * L->bs,
-                                       hipMemcpyDeviceToDevice, ctx->stream));
+  // (an own copy kernel: the runtime's device-to-device copy costs more per call than these surface-sized buffers take)
+  ALFI_CHECK(launch_copy(ctx, v + L->n_own, L->halo_recvbuf, L->halo_nghost * L->bs));
   alfi_prof_end(ctx, t);
   return 0;
 }
@@ -167,9 +165,7 @@ static int halo_rev(alfi_level* L, double* v) {
   alfi_ctx* ctx = L->ctx;
   if (!L->has_halo) return alfi_set_error(ctx, ALFI_E_STATE, "halo exchange on a level without alfi_level_set_partition");
   int t = alfi_prof_begin(ctx, ALFI_EV_COMM);
-  if (L->halo_nghost > 0)
-    ALFI_HIP_CHECK(ctx, hipMemcpyAsync(L->halo_recvbuf, v + L->n_own, sizeof(double) * L->halo_nghost * L->bs,
-                                       hipMemcpyDeviceToDevice, ctx->stream));
+  ALFI_CHECK(launch_copy(ctx, L->halo_recvbuf, v + L->n_own, L->halo_nghost * L->bs));
   ALFI_CHECK(comm_call(ctx, ALFI_COMM_HALO_REV, L->id, 0, 0));
   ALFI_CHECK(launch_halo_add(ctx, v, L->halo_sendbuf, L->rev_nodes, L->rev_ptr, L->rev_pos, L->rev_nuniq, L->bs));
   alfi_prof_end(ctx, t);
@@ -180,9 +176,7 @@ static int halo_rev(alfi_level* L, double* v) {
 static int halo_rev_begin(alfi_level* L, const double* v) {
   alfi_ctx* ctx = L->ctx;
   int t = alfi_prof_begin(ctx, ALFI_EV_COMM);
-  if (L->halo_nghost > 0)
-    ALFI_HIP_CHECK(ctx, hipMemcpyAsync(L->halo_recvbuf, v + L->n_own, sizeof(double) * L->halo_nghost * L->bs,
-                                       hipMemcpyDeviceToDevice, ctx->stream));
+  ALFI_CHECK(launch_copy(ctx, L->halo_recvbuf, v + L->n_own, L->halo_nghost * L->bs));
   ALFI_CHECK(comm_call(ctx, ALFI_COMM_HALO_REV_BEGIN, L->id, 0, 0));
   alfi_prof_end(ctx, t);
   return 0;
