@@ -4,10 +4,12 @@
 gfx950 corrections (MI355X_MICROARCH.md, HBM section): FETCH_SIZE is reported in KiB and tallies the 128-B requests of a
 wide streaming read at 64 B => bytes = 2 * 1024 * FETCH_SIZE; WRITE_SIZE (KiB) is exact for streaming stores.
 
-usage: pmc_summary.py <fetch_dir> <write_dir> <kernel-name-prefix> <out.json> [tag] [first]
+usage: pmc_summary.py <fetch_dir> <write_dir> <kernel-name-prefix> <out.json> [tag] [first] [grids]
 
 ``first``: only the first N launches of the kernel -- the V-cycle of ``bench.py --steps 1 --warmup 0`` (60 patch applies, 79
 SpMVs on config 4); the full cycles bench.py runs afterwards for ``fcycle_ms`` have a different mix of levels.
+``grids``: comma-separated Grid_Size values -- only launches of those sizes (config 5: the smoother's big_apply_kernel launches,
+903680 and 310272 threads; the transfers' interior solves use the same kernel on smaller grids).
 """
 import glob
 import json
@@ -16,10 +18,12 @@ import sys
 import pandas as pd
 
 
-def per_kernel(d, counter, prefix, first=None):
+def per_kernel(d, counter, prefix, first=None, grids=None):
     f = glob.glob(d + "/**/*_counter_collection.csv", recursive=True)[0]
     t = pd.read_csv(f)
     t = t[(t["Counter_Name"] == counter) & t["Kernel_Name"].str.startswith(prefix)]
+    if grids:
+        t = t[t["Grid_Size"].isin(grids)]
     # one row per dispatch and counter instance: sum the instances, keep dispatch order
     v = t.groupby("Dispatch_Id", sort=True)["Counter_Value"].sum().to_numpy()
     return v[:first] if first else v
@@ -29,7 +33,9 @@ def main():
     fetch_dir, write_dir, prefix, out = sys.argv[1:5]
     tag = sys.argv[5] if len(sys.argv) > 5 else ""
     first = int(sys.argv[6]) if len(sys.argv) > 6 else None
-    f, w = per_kernel(fetch_dir, "FETCH_SIZE", prefix, first), per_kernel(write_dir, "WRITE_SIZE", prefix, first)
+    grids = [int(g) for g in sys.argv[7].split(",")] if len(sys.argv) > 7 else None
+    f, w = (per_kernel(fetch_dir, "FETCH_SIZE", prefix, first, grids),
+            per_kernel(write_dir, "WRITE_SIZE", prefix, first, grids))
     fb, wb = 2.0 * 1024.0 * f.mean(), 1024.0 * w.mean()
     res = {"kernel": prefix, "tag": tag, "launches": int(len(f)),
            "fetch_size_KiB_avg_raw": float(f.mean()), "write_size_KiB_avg_raw": float(w.mean()),
