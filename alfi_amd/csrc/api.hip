@@ -28,6 +28,7 @@ int alfi_set_error(alfi_ctx* ctx, int code, const char* fmt, ...) {
 int alfi_prof_begin(alfi_ctx* ctx, int kind) {
   if (!ctx->prof) return -1;
   if (ctx->prof == 2 && kind != ALFI_EV_PATCH_APPLY && kind != ALFI_EV_COMM) return -1;
+  if (ctx->prof == 3 && kind != ALFI_EV_PATCH_APPLY) return -1;
   if (ctx->ev_used == ctx->ev_pool.size()) {
     alfi_ctx::EvPair p;
     if (hipEventCreate(&p.a) != hipSuccess || hipEventCreate(&p.b) != hipSuccess) return -1;

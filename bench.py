@@ -153,9 +153,9 @@ def main_distributed(args, rank, world, local_rank):
     for _ in range(args.warmup):
         dmg.vcycle(db, dx)
     dmg.sync()
-    # events around the dominant kernel and the exchanges only: the small distributed levels are launch-bound and every
-    # event record costs host time there
-    ctx.prof_enable(2 if world > 1 else True)
+    # events around the dominant kernel only (the roofline block needs them): the small distributed levels are bound by
+    # per-launch latency and every event record adds to it; the exchanges are timed in one extra cycle afterwards
+    ctx.prof_enable(3 if world > 1 else True)
     ctx.prof_reset()
     dist.barrier()
     torch.cuda.synchronize()
@@ -184,6 +184,15 @@ def main_distributed(args, rank, world, local_rank):
     npatch, sum_n, sum_n2 = fin.patch_stats()
     prof = ctx.prof_get()
     ms_f, cnt_f = ctx.prof_get(fin.id)["PATCH_APPLY"]
+    comm_ms = prof["COMM"][0] / args.steps
+    if world > 1:                                    # device time of the exchange points: one extra, untimed cycle
+        ctx.prof_enable(2)
+        ctx.prof_reset()
+        dmg.vcycle(db, dx)
+        dmg.sync()
+        comm_ms = ctx.prof_get()["COMM"][0]
+        ctx.prof_enable(False)
+        prof = dict(prof, COMM=(comm_ms * args.steps, prof["COMM"][1]))
     outer = None
     if args.outer and CONFIGS[args.config][0] != "sv":
         # one Newton-step linear solve on the partitioned levels (alfi_amd.dist.DistSaddle), outside the timed region
@@ -209,8 +218,8 @@ def main_distributed(args, rank, world, local_rank):
     # account per apply, not per launch
     applies = args.steps * 2 * k
     local_gbs = bytes_apply * applies / (ms_f * 1e-3) / 1e9 if ms_f > 0 else 0.0
-    stats = torch.tensor([float(npatch), float(dmg.n_own), float(dmg.n_loc - dmg.n_own), local_gbs,
-                          prof["COMM"][0] / args.steps], dtype=torch.float64, device="cuda")
+    stats = torch.tensor([float(npatch), float(dmg.n_own), float(dmg.n_loc - dmg.n_own), local_gbs, comm_ms],
+                         dtype=torch.float64, device="cuda")
     allstats = [torch.zeros_like(stats) for _ in range(world)]
     dist.all_gather(allstats, stats)
     if rank == 0:

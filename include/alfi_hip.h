@@ -62,7 +62,7 @@ enum {
   ALFI_EV_COUNT = 9
 };
 /* on = 1: a hipEvent pair around every launch of the classes above; on = 2: PATCH_APPLY and COMM only (fewer event
- * records on launch-bound levels); 0: off */
+ * records on launch-bound levels); on = 3: PATCH_APPLY only; 0: off */
 int alfi_prof_enable(alfi_ctx* ctx, int on);
 int alfi_prof_reset(alfi_ctx* ctx);
 /* synchronises, then returns summed device time (ms) and launch count of one class since the last reset */
