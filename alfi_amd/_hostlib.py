@@ -127,9 +127,13 @@ def supg(V, U, nu, weight, magic, rowptr=None, colidx=None, vals=None, F=None, n
         raise RuntimeError("supg failed (%d): sparsity pattern does not cover the mesh" % rc)
 
 
-def apply_bc_bsr(nnode, d, rowptr, colidx, vals, bcmask):
+def apply_bc_bsr(nrow, d, rowptr, colidx, vals, bcmask, row_ids=None):
+    """Dirichlet rows / columns -> identity.  row_ids: the node of each block row when the rows are a subset."""
     bcmask = np.ascontiguousarray(bcmask, dtype=np.uint8)
-    lib().alfi_host_apply_bc_bsr(ctypes.c_int64(nnode), ctypes.c_int(d), _p(rowptr), _p(colidx), _p(vals), _p(bcmask))
+    if row_ids is not None:
+        row_ids = np.ascontiguousarray(row_ids, dtype=np.int32)
+    lib().alfi_host_apply_bc_bsr(ctypes.c_int64(nrow), ctypes.c_int(d), _p(rowptr), _p(colidx), _p(vals), _p(bcmask),
+                                 _p(row_ids))
 
 
 def extract_blocks(d, rowptr, colidx, vals, blk_ptr, blk_dofs):

@@ -38,6 +38,11 @@ SIGNATURES = {
     "alfi_prof_get_level": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_double),
                                            ctypes.POINTER(ctypes.c_int64)]),
     "alfi_ctx_set_comm": (ctypes.c_int, [vp, vp, vp, vp, ctypes.c_int64]),
+    "alfi_comm_unique_id": (ctypes.c_int, [vp, ctypes.c_int64]),
+    "alfi_ctx_comm_init": (ctypes.c_int, [vp, vp, ctypes.c_int, ctypes.c_int]),
+    "alfi_ctx_comm_size": (ctypes.c_int, [vp, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]),
+    "alfi_ctx_comm_destroy": (ctypes.c_int, [vp]),
+    "alfi_level_set_neighbours": (ctypes.c_int, [vp, ctypes.c_int, vp, vp, vp]),
     "alfi_level_set_partition": (ctypes.c_int, [vp, ctypes.c_int64, ctypes.c_int, ctypes.c_int64, vp, vp, vp,
                                                 ctypes.c_int64]),
     "alfi_level_set_overlap": (ctypes.c_int, [vp, ctypes.c_int64, ctypes.c_int64]),
@@ -91,9 +96,21 @@ SIGNATURES = {
     "alfi_saddle_precond": (ctypes.c_int, [vp, vp, vp]),
 }
 
+COMM_ID_BYTES = 128      # ALFI_COMM_ID_BYTES
+
 EVENTS = ["PATCH_APPLY", "PATCH_SCATTER", "PATCH_FACTOR", "MATMULT", "BLAS1", "PROLONG", "RESTRICT", "COARSE", "COMM"]
 
 _lib = None
+
+
+def comm_unique_id():
+    """128-byte id for alfi_ctx_comm_init; call on ONE rank and distribute the bytes."""
+    buf = ctypes.create_string_buffer(COMM_ID_BYTES)
+    lib = load()
+    rc = lib.alfi_comm_unique_id(ctypes.cast(buf, vp), COMM_ID_BYTES)
+    if rc != 0:
+        raise RuntimeError("alfi_comm_unique_id failed (%d): %s" % (rc, lib.alfi_last_error(None).decode()))
+    return buf.raw
 
 
 def load():

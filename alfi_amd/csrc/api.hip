@@ -112,10 +112,22 @@ static void free_bsr(DevBSR* d) {
   *d = DevBSR();
 }
 
-// ---- mesh-partition exchanges (alfi_ctx_set_comm) ------------------------------------------------------------------------
-static int comm_call(alfi_ctx* ctx, int op, int level_id, int64_t offset, int64_t count) {
-  if (!ctx->comm) return alfi_set_error(ctx, ALFI_E_STATE, "partitioned level used before alfi_ctx_set_comm");
-  const int rc = ctx->comm(ctx->comm_user, op, level_id, offset, count);
+// ---- mesh-partition exchanges: the ctx's own RCCL communicator (alfi_ctx_comm_init, comm.hip) or, as the test transport,
+// a host callback (alfi_ctx_set_comm) ----------------------------------------------------------------------------------
+static int comm_call(alfi_level* L, int op, int64_t offset, int64_t count) {
+  alfi_ctx* ctx = L->ctx;
+  if (ctx->nat) {
+    switch (op) {
+      case ALFI_COMM_ALLREDUCE: return native_allreduce(ctx, offset, count);
+      case ALFI_COMM_HALO_FWD: return native_exchange(L, 0, false);
+      case ALFI_COMM_HALO_REV: return native_exchange(L, 1, false);
+      case ALFI_COMM_HALO_FWD_BEGIN: return native_exchange(L, 0, true);
+      case ALFI_COMM_HALO_REV_BEGIN: return native_exchange(L, 1, true);
+      default: return native_wait(ctx);                      // ALFI_COMM_HALO_FWD_END / _REV_END
+    }
+  }
+  if (!ctx->comm) return alfi_set_error(ctx, ALFI_E_STATE, "partitioned level used before alfi_ctx_comm_init / alfi_ctx_set_comm");
+  const int rc = ctx->comm(ctx->comm_user, op, L->id, offset, count);
   if (rc != 0) return alfi_set_error(ctx, ALFI_E_STATE, "communication callback failed (op %d, rc %d)", op, rc);
   return 0;
 }
@@ -124,7 +136,7 @@ static int comm_call(alfi_ctx* ctx, int op, int level_id, int64_t offset, int64_
 static int comm_allreduce(alfi_level* L, int64_t offset, int64_t count) {
   alfi_ctx* ctx = L->ctx;
   int t = alfi_prof_begin(ctx, ALFI_EV_COMM);
-  ALFI_CHECK(comm_call(ctx, ALFI_COMM_ALLREDUCE, L->id, offset, count));
+  ALFI_CHECK(comm_call(L, ALFI_COMM_ALLREDUCE, offset, count));
   alfi_prof_end(ctx, t);
   return 0;
 }
@@ -135,7 +147,7 @@ static int halo_fwd(alfi_level* L, double* v) {
   if (!L->has_halo) return alfi_set_error(ctx, ALFI_E_STATE, "halo exchange on a level without alfi_level_set_partition");
   int t = alfi_prof_begin(ctx, ALFI_EV_COMM);
   ALFI_CHECK(launch_halo_pack(ctx, L->halo_sendbuf, v, L->halo_send_nodes, L->halo_nsend, L->bs));
-  ALFI_CHECK(comm_call(ctx, ALFI_COMM_HALO_FWD, L->id, 0, 0));
+  ALFI_CHECK(comm_call(L, ALFI_COMM_HALO_FWD, 0, 0));
   // (an own copy kernel: the runtime's device-to-device copy costs more per call than these surface-sized buffers take)
   ALFI_CHECK(launch_copy(ctx, v + L->n_own, L->halo_recvbuf, L->halo_nghost * L->bs));
   alfi_prof_end(ctx, t);
@@ -147,14 +159,14 @@ static int halo_fwd_begin(alfi_level* L, const double* v) {
   alfi_ctx* ctx = L->ctx;
   int t = alfi_prof_begin(ctx, ALFI_EV_COMM);
   ALFI_CHECK(launch_halo_pack(ctx, L->halo_sendbuf, v, L->halo_send_nodes, L->halo_nsend, L->bs));
-  ALFI_CHECK(comm_call(ctx, ALFI_COMM_HALO_FWD_BEGIN, L->id, 0, 0));
+  ALFI_CHECK(comm_call(L, ALFI_COMM_HALO_FWD_BEGIN, 0, 0));
   alfi_prof_end(ctx, t);
   return 0;
 }
 static int halo_fwd_end(alfi_level* L, double* v) {
   alfi_ctx* ctx = L->ctx;
   int t = alfi_prof_begin(ctx, ALFI_EV_COMM);
-  ALFI_CHECK(comm_call(ctx, ALFI_COMM_HALO_FWD_END, L->id, 0, 0));
+  ALFI_CHECK(comm_call(L, ALFI_COMM_HALO_FWD_END, 0, 0));
   // (an own copy kernel: the runtime's device-to-device copy costs more per call than these surface-sized buffers take)
   ALFI_CHECK(launch_copy(ctx, v + L->n_own, L->halo_recvbuf, L->halo_nghost * L->bs));
   alfi_prof_end(ctx, t);
@@ -167,7 +179,7 @@ static int halo_rev(alfi_level* L, double* v) {
   if (!L->has_halo) return alfi_set_error(ctx, ALFI_E_STATE, "halo exchange on a level without alfi_level_set_partition");
   int t = alfi_prof_begin(ctx, ALFI_EV_COMM);
   ALFI_CHECK(launch_copy(ctx, L->halo_recvbuf, v + L->n_own, L->halo_nghost * L->bs));
-  ALFI_CHECK(comm_call(ctx, ALFI_COMM_HALO_REV, L->id, 0, 0));
+  ALFI_CHECK(comm_call(L, ALFI_COMM_HALO_REV, 0, 0));
   ALFI_CHECK(launch_halo_add(ctx, v, L->halo_sendbuf, L->rev_nodes, L->rev_ptr, L->rev_pos, L->rev_nuniq, L->bs));
   alfi_prof_end(ctx, t);
   return 0;
@@ -178,14 +190,14 @@ static int halo_rev_begin(alfi_level* L, const double* v) {
   alfi_ctx* ctx = L->ctx;
   int t = alfi_prof_begin(ctx, ALFI_EV_COMM);
   ALFI_CHECK(launch_copy(ctx, L->halo_recvbuf, v + L->n_own, L->halo_nghost * L->bs));
-  ALFI_CHECK(comm_call(ctx, ALFI_COMM_HALO_REV_BEGIN, L->id, 0, 0));
+  ALFI_CHECK(comm_call(L, ALFI_COMM_HALO_REV_BEGIN, 0, 0));
   alfi_prof_end(ctx, t);
   return 0;
 }
 static int halo_rev_end(alfi_level* L, double* v) {
   alfi_ctx* ctx = L->ctx;
   int t = alfi_prof_begin(ctx, ALFI_EV_COMM);
-  ALFI_CHECK(comm_call(ctx, ALFI_COMM_HALO_REV_END, L->id, 0, 0));
+  ALFI_CHECK(comm_call(L, ALFI_COMM_HALO_REV_END, 0, 0));
   ALFI_CHECK(launch_halo_add(ctx, v, L->halo_sendbuf, L->rev_nodes, L->rev_ptr, L->rev_pos, L->rev_nuniq, L->bs));
   alfi_prof_end(ctx, t);
   return 0;
@@ -227,6 +239,7 @@ int alfi_ctx_create(int device, void* stream, alfi_ctx** out) {
 int alfi_ctx_destroy(alfi_ctx* ctx) {
   if (!ctx) return 0;
   (void)hipStreamSynchronize(ctx->stream);
+  native_destroy(ctx);
   for (auto& p : ctx->ev_pool) {
     (void)hipEventDestroy(p.a);
     (void)hipEventDestroy(p.b);
@@ -272,6 +285,7 @@ int alfi_memset0(alfi_ctx* ctx, void* dst, int64_t bytes) {
 int alfi_ctx_set_comm(alfi_ctx* ctx, alfi_comm_fn fn, void* user, double* dred, int64_t dred_len) {
   if (fn && (!dred || dred_len < 2 * RED_MAXV))
     return alfi_set_error(ctx, ALFI_E_ARG, "alfi_ctx_set_comm needs a device buffer of >= %d doubles", 2 * RED_MAXV);
+  if (ctx->nat) return alfi_set_error(ctx, ALFI_E_STATE, "the ctx already owns a communicator (alfi_ctx_comm_init)");
   ctx->comm = fn;
   ctx->comm_user = user;
   ctx->dred = dred;
@@ -351,8 +365,8 @@ int alfi_level_set_partition(alfi_level* L, int64_t nb_owned, int distributed, i
   if (nb_owned < 0 || nb_ghost < 0 || nb_owned + nb_ghost != L->A.nbrows)
     return alfi_set_error(ctx, ALFI_E_ARG, "owned (%lld) + ghost (%lld) nodes != %lld block rows", (long long)nb_owned,
                           (long long)nb_ghost, (long long)L->A.nbrows);
-  if (nsend < 0 || (nsend > 0 && (!send_nodes || !d_sendbuf)) || (nb_ghost > 0 && !d_recvbuf))
-    return alfi_set_error(ctx, ALFI_E_ARG, "NULL halo buffers");
+  if (nsend < 0 || (nsend > 0 && !send_nodes) || (!d_sendbuf) != (!d_recvbuf))
+    return alfi_set_error(ctx, ALFI_E_ARG, "bad halo arguments (pass both buffers or neither)");
   for (int64_t i = 0; i < nsend; ++i)
     if (send_nodes[i] < 0 || send_nodes[i] >= nb_owned)
       return alfi_set_error(ctx, ALFI_E_ARG, "send node %d is not an owned node", send_nodes[i]);
@@ -364,6 +378,18 @@ int alfi_level_set_partition(alfi_level* L, int64_t nb_owned, int distributed, i
   dev_free(L->rev_ptr);
   dev_free(L->rev_pos);
   L->halo_send_nodes = L->rev_nodes = L->rev_ptr = L->rev_pos = nullptr;
+  if (L->own_halo_bufs) {
+    dev_free(L->halo_sendbuf);
+    dev_free(L->halo_recvbuf);
+  }
+  L->halo_sendbuf = L->halo_recvbuf = nullptr;
+  L->own_halo_bufs = false;
+  L->nbr_rank.clear();
+  if (!d_sendbuf) {                       // the library's own buffers (native transport)
+    ALFI_CHECK(dev_alloc(ctx, &d_sendbuf, nsend * L->bs));
+    ALFI_CHECK(dev_alloc(ctx, &d_recvbuf, nb_ghost * L->bs));
+    L->own_halo_bufs = true;
+  }
   // reverse-add plan: positions of the send buffer grouped by node, in buffer order (fixed summation order)
   std::vector<int32_t> order(nsend);
   for (int64_t i = 0; i < nsend; ++i) order[i] = (int32_t)i;
@@ -471,6 +497,10 @@ int alfi_level_destroy(alfi_level* L) {
   dev_free(L->bc_dofs);
   dev_free(L->bc_mask);
   dev_free(L->halo_send_nodes);
+  if (L->own_halo_bufs) {
+    dev_free(L->halo_sendbuf);
+    dev_free(L->halo_recvbuf);
+  }
   dev_free(L->rev_nodes);
   dev_free(L->rev_ptr);
   dev_free(L->rev_pos);
@@ -1153,8 +1183,10 @@ int alfi_mg_destroy(alfi_mg* mg) {
   return 0;
 }
 
-// PCMGMCycle_Private [3P]: x_l <- V(b_l, x_l)
-static int vcycle(alfi_mg* mg, int l, const double* b, double* x) {
+// PCMGMCycle_Private [3P]: x_l <- V(b_l, x_l).  x_zero: the incoming x is known to be zero (every level below the one the
+// cycle starts on): the pre-smoother then runs with a zero initial guess -- r0 = b, no residual SpMV -- as PCMG does by
+// switching KSPSetInitialGuessNonzero off for the down-smoother of those levels; the result is the same bit for bit.
+static int vcycle(alfi_mg* mg, int l, const double* b, double* x, bool x_zero) {
   alfi_ctx* ctx = mg->ctx;
   alfi_level* L = mg->levels[l];
   // partitioned hierarchies: a rank's lowest level is either the coarse grid it owns or ghost copies of a level another
@@ -1162,11 +1194,11 @@ static int vcycle(alfi_mg* mg, int l, const double* b, double* x) {
   if (l == 0) return L->n_own > 0 ? alfi_coarse_solve(L, b, x) : 0;
   alfi_level* C = mg->levels[l - 1];
   alfi_transfer* T = mg->transfers[l - 1];
-  ALFI_CHECK(alfi_smooth_fgmres(L, mg->k, b, x, 1));                 // pre-smooth
+  ALFI_CHECK(alfi_smooth_fgmres(L, mg->k, b, x, x_zero ? 0 : 1));    // pre-smooth
   ALFI_CHECK(alfi_residual(L, b, x, L->mg_r));                       // r = b - A x
   ALFI_CHECK(alfi_restrict(T, L->mg_r, C->mg_b, mg->robust));        // b_{l-1} = R r
-  ALFI_HIP_CHECK(ctx, hipMemsetAsync(C->mg_x, 0, sizeof(double) * C->n, ctx->stream));
-  ALFI_CHECK(vcycle(mg, l - 1, C->mg_b, C->mg_x));
+  // x_{l-1} = 0: the coarse solve overwrites it, a smoother with a zero initial guess zeroes it itself
+  ALFI_CHECK(vcycle(mg, l - 1, C->mg_b, C->mg_x, true));
   ALFI_CHECK(alfi_prolong(T, C->mg_x, L->mg_r));                     // x += P x_{l-1}
   ctx->cur_tag = L->id;
   int t = alfi_prof_begin(ctx, ALFI_EV_BLAS1);
@@ -1178,7 +1210,6 @@ static int vcycle(alfi_mg* mg, int l, const double* b, double* x) {
 
 // PCMGFCycle_Private [3P]
 static int fcycle(alfi_mg* mg, const double* db, double* dx) {
-  alfi_ctx* ctx = mg->ctx;
   const int Lmax = (int)mg->levels.size() - 1;
   if (Lmax == 0) return mg->levels[0]->n_own > 0 ? alfi_coarse_solve(mg->levels[0], db, dx) : 0;
   // restrict the right-hand side through all levels
@@ -1187,17 +1218,16 @@ static int fcycle(alfi_mg* mg, const double* db, double* dx) {
     ALFI_CHECK(alfi_restrict(mg->transfers[l - 1], bf, mg->levels[l - 1]->mg_b, mg->robust));
     bf = mg->levels[l - 1]->mg_b;
   }
-  ALFI_HIP_CHECK(ctx, hipMemsetAsync(mg->levels[0]->mg_x, 0, sizeof(double) * mg->levels[0]->n, ctx->stream));
   for (int l = 0; l < Lmax; ++l) {
     alfi_level* L = mg->levels[l];
     // note: inside vcycle(l) the coarser levels' mg_b / mg_x are overwritten; level l's own b must survive, and it
     // does: vcycle(l) only writes mg_b of levels < l.  But the restricted rhs of levels < l is then gone -- it is
     // not needed any more at that point (levels are visited in increasing order).
-    ALFI_CHECK(vcycle(mg, l, L->mg_b, L->mg_x));
+    ALFI_CHECK(vcycle(mg, l, L->mg_b, L->mg_x, l == 0));    // l >= 1: x_l is the prolonged coarser solution
     double* xnext = (l + 1 == Lmax) ? dx : mg->levels[l + 1]->mg_x;
     ALFI_CHECK(alfi_prolong(mg->transfers[l], L->mg_x, xnext));
   }
-  return vcycle(mg, Lmax, db, dx);
+  return vcycle(mg, Lmax, db, dx, false);
 }
 
 // ---- whole cycles as hipGraphs (alfi_ctx_set_graph) -----------------------------------------------------------------------
@@ -1239,7 +1269,7 @@ static void cycle_signature(alfi_mg* mg, std::vector<uint64_t>* sig) {
 
 static int run_cycle(alfi_mg* mg, int kind, const double* db, double* dx) {
   alfi_ctx* ctx = mg->ctx;
-  auto eager = [&]() { return kind ? fcycle(mg, db, dx) : vcycle(mg, (int)mg->levels.size() - 1, db, dx); };
+  auto eager = [&]() { return kind ? fcycle(mg, db, dx) : vcycle(mg, (int)mg->levels.size() - 1, db, dx, false); };
   bool ok = ctx->use_graph && ctx->prof == 0;
   for (alfi_level* L : mg->levels) ok = ok && !L->has_halo;
   if (!ok) return eager();

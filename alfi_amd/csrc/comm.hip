@@ -1,0 +1,247 @@
+// Native transport of the mesh-partition exchanges: the ctx owns an RCCL communicator (created from a unique id the host
+// program distributes once) and performs the halo exchanges and reductions of a cycle by itself, stream-ordered on its own
+// stream -- no host callback, no Python between the kernels of a smoother iteration.
+//
+// What it replaces in the reference: PETSc's VecScatter (PetscSF) forward / reverse-add around PCApply_PATCH and MatMult and
+// the MPI_Allreduce of KSPFGMRES's Gram-Schmidt step [3P], reached through alfi/solver.py:604-605 (distribution parameters)
+// and alfi/relaxation.py:120-121 (patches of owned vertices only).
+//
+// MI355X: xGMI is point to point, every GPU has a direct link to each of its 7 peers.  A halo exchange is ONE group of
+// ncclSend / ncclRecv pairs with the level's actual neighbours (a box partition of the mesh has at most 7 of them on a
+// node), so each message travels over its own link; the reductions are one small ncclAllReduce (<= 33 doubles) each.
+// librccl is resolved at run time (dlopen): the library itself has no link-time dependency on it and loads on hosts
+// without RCCL; whichever copy the process already holds (PyTorch ships one with the same SONAME) is reused.
+#include <dlfcn.h>
+#include <cstdlib>
+#include <cstring>
+#include <rccl/rccl.h>
+#include "common.h"
+
+namespace {
+
+struct RcclApi {
+  void* handle = nullptr;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*GroupStart)() = nullptr;
+  ncclResult_t (*GroupEnd)() = nullptr;
+  ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+  const char* (*GetErrorString)(ncclResult_t) = nullptr;
+};
+
+RcclApi g_api;
+std::string g_api_error;
+
+template <typename F>
+bool resolve(void* h, const char* name, F* out) {
+  *out = reinterpret_cast<F>(dlsym(h, name));
+  if (!*out) g_api_error = std::string("librccl lacks ") + name;
+  return *out != nullptr;
+}
+
+// nullptr + g_api_error on failure
+RcclApi* rccl() {
+  if (g_api.handle) return &g_api;
+  const char* names[] = {getenv("ALFI_RCCL_LIB"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+  void* h = nullptr;
+  for (const char* n : names) {
+    if (!n || !*n) continue;
+    h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+    if (h) break;
+  }
+  if (!h) {
+    g_api_error = std::string("cannot load librccl: ") + (dlerror() ? dlerror() : "not found");
+    return nullptr;
+  }
+  RcclApi a;
+  a.handle = h;
+  if (!(resolve(h, "ncclGetUniqueId", &a.GetUniqueId) && resolve(h, "ncclCommInitRank", &a.CommInitRank) &&
+        resolve(h, "ncclCommDestroy", &a.CommDestroy) && resolve(h, "ncclGroupStart", &a.GroupStart) &&
+        resolve(h, "ncclGroupEnd", &a.GroupEnd) && resolve(h, "ncclSend", &a.Send) && resolve(h, "ncclRecv", &a.Recv) &&
+        resolve(h, "ncclAllReduce", &a.AllReduce) && resolve(h, "ncclGetErrorString", &a.GetErrorString)))
+    return nullptr;
+  g_api = a;
+  return &g_api;
+}
+
+}  // namespace
+
+struct NativeComm {
+  ncclComm_t comm = nullptr;
+  int rank = 0, nranks = 1;
+  bool own_dred = false;
+  hipStream_t side = nullptr;      // asynchronous exchanges (overlap with interior work) run here
+  hipEvent_t ev_ready = nullptr;   // ctx stream -> side stream: buffers packed
+  hipEvent_t ev_done = nullptr;    // side stream -> ctx stream: exchange finished
+};
+
+#define ALFI_NCCL_CHECK(ctx, api, call)                                                                      \
+  do {                                                                                                       \
+    ncclResult_t r_ = (call);                                                                                \
+    if (r_ != ncclSuccess)                                                                                   \
+      return alfi_set_error(ctx, ALFI_E_COMM, "%s failed: %s (%s:%d)", #call, (api)->GetErrorString(r_), __FILE__, \
+                            __LINE__);                                                                       \
+  } while (0)
+
+void native_destroy(alfi_ctx* ctx) {
+  NativeComm* N = ctx->nat;
+  if (!N) return;
+  (void)hipStreamSynchronize(ctx->stream);
+  if (N->side) (void)hipStreamSynchronize(N->side);
+  if (N->comm && g_api.handle) (void)g_api.CommDestroy(N->comm);
+  if (N->ev_ready) (void)hipEventDestroy(N->ev_ready);
+  if (N->ev_done) (void)hipEventDestroy(N->ev_done);
+  if (N->side) (void)hipStreamDestroy(N->side);
+  if (N->own_dred && ctx->dred) {
+    (void)hipFree(ctx->dred);
+    ctx->dred = nullptr;
+  }
+  delete N;
+  ctx->nat = nullptr;
+}
+
+int native_allreduce(alfi_ctx* ctx, int64_t offset, int64_t count) {
+  NativeComm* N = ctx->nat;
+  RcclApi* api = &g_api;
+  if (N->nranks == 1) return 0;      // the sum over one rank
+  double* p = ctx->dred + offset;
+  ALFI_NCCL_CHECK(ctx, api, api->AllReduce(p, p, (size_t)count, ncclDouble, ncclSum, N->comm, ctx->stream));
+  return 0;
+}
+
+int native_exchange(alfi_level* L, int dir, bool async) {
+  alfi_ctx* ctx = L->ctx;
+  NativeComm* N = ctx->nat;
+  RcclApi* api = &g_api;
+  hipStream_t s = ctx->stream;
+  if (async) {
+    ALFI_HIP_CHECK(ctx, hipEventRecord(N->ev_ready, ctx->stream));
+    ALFI_HIP_CHECK(ctx, hipStreamWaitEvent(N->side, N->ev_ready, 0));
+    s = N->side;
+  }
+  const size_t nn = L->nbr_rank.size();
+  if (nn > 0) {
+    // forward: my send-buffer segments go out, my receive-buffer segments come in; reverse: the other way round
+    const double* out = dir == 0 ? L->halo_sendbuf : L->halo_recvbuf;
+    double* in = dir == 0 ? L->halo_recvbuf : L->halo_sendbuf;
+    const std::vector<int64_t>& ooff = dir == 0 ? L->nbr_send_off : L->nbr_recv_off;
+    const std::vector<int64_t>& ocnt = dir == 0 ? L->nbr_send_cnt : L->nbr_recv_cnt;
+    const std::vector<int64_t>& ioff = dir == 0 ? L->nbr_recv_off : L->nbr_send_off;
+    const std::vector<int64_t>& icnt = dir == 0 ? L->nbr_recv_cnt : L->nbr_send_cnt;
+    ALFI_NCCL_CHECK(ctx, api, api->GroupStart());
+    for (size_t i = 0; i < nn; ++i) {
+      if (ocnt[i] > 0)
+        ALFI_NCCL_CHECK(ctx, api, api->Send(out + ooff[i], (size_t)ocnt[i], ncclDouble, L->nbr_rank[i], N->comm, s));
+      if (icnt[i] > 0)
+        ALFI_NCCL_CHECK(ctx, api, api->Recv(in + ioff[i], (size_t)icnt[i], ncclDouble, L->nbr_rank[i], N->comm, s));
+    }
+    ALFI_NCCL_CHECK(ctx, api, api->GroupEnd());
+  }
+  if (async) ALFI_HIP_CHECK(ctx, hipEventRecord(N->ev_done, N->side));
+  return 0;
+}
+
+int native_wait(alfi_ctx* ctx) {
+  ALFI_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->stream, ctx->nat->ev_done, 0));
+  return 0;
+}
+
+extern "C" {
+
+int alfi_comm_unique_id(void* id_out, int64_t len) {
+  if (!id_out || len < ALFI_COMM_ID_BYTES) return alfi_set_error(nullptr, ALFI_E_ARG, "id buffer must hold %d bytes", ALFI_COMM_ID_BYTES);
+  RcclApi* api = rccl();
+  if (!api) return alfi_set_error(nullptr, ALFI_E_COMM, "%s", g_api_error.c_str());
+  static_assert(sizeof(ncclUniqueId) == ALFI_COMM_ID_BYTES, "unique id size");
+  ncclUniqueId id;
+  ncclResult_t r = api->GetUniqueId(&id);
+  if (r != ncclSuccess) return alfi_set_error(nullptr, ALFI_E_COMM, "ncclGetUniqueId failed: %s", api->GetErrorString(r));
+  memcpy(id_out, &id, sizeof(id));
+  return 0;
+}
+
+int alfi_ctx_comm_init(alfi_ctx* ctx, const void* id, int rank, int nranks) {
+  if (!ctx || !id) return alfi_set_error(ctx, ALFI_E_ARG, "NULL argument");
+  if (nranks < 1 || rank < 0 || rank >= nranks) return alfi_set_error(ctx, ALFI_E_ARG, "rank %d of %d", rank, nranks);
+  if (ctx->nat) return alfi_set_error(ctx, ALFI_E_STATE, "the ctx already has a communicator");
+  if (ctx->comm) return alfi_set_error(ctx, ALFI_E_STATE, "the ctx already exchanges through a callback (alfi_ctx_set_comm)");
+  RcclApi* api = rccl();
+  if (!api) return alfi_set_error(ctx, ALFI_E_COMM, "%s", g_api_error.c_str());
+  ALFI_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  NativeComm* N = new NativeComm();
+  N->rank = rank;
+  N->nranks = nranks;
+  ctx->nat = N;
+  ncclUniqueId uid;
+  memcpy(&uid, id, sizeof(uid));
+  ncclResult_t r = api->CommInitRank(&N->comm, nranks, uid, rank);
+  if (r != ncclSuccess) {
+    N->comm = nullptr;
+    native_destroy(ctx);
+    return alfi_set_error(ctx, ALFI_E_COMM, "ncclCommInitRank(rank %d of %d) failed: %s", rank, nranks, api->GetErrorString(r));
+  }
+  hipError_t e = hipStreamCreateWithFlags(&N->side, hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&N->ev_ready, hipEventDisableTiming);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&N->ev_done, hipEventDisableTiming);
+  if (e == hipSuccess) e = hipMalloc((void**)&ctx->dred, sizeof(double) * 2 * RED_MAXV);
+  if (e == hipSuccess) {
+    N->own_dred = true;
+    e = hipMemsetAsync(ctx->dred, 0, sizeof(double) * 2 * RED_MAXV, ctx->stream);
+  }
+  if (e != hipSuccess) {
+    native_destroy(ctx);
+    return alfi_set_error(ctx, ALFI_E_HIP, "communicator resources: %s", hipGetErrorString(e));
+  }
+  const char* en = getenv("ALFI_DIST_EXACT_NORM");   // 1: |w| by its own all-reduce, as PETSc's VecNorm (A/B, parity checks)
+  ctx->exact_norm = en && atoi(en) == 1;
+  return 0;
+}
+
+int alfi_ctx_comm_size(alfi_ctx* ctx, int* rank, int* nranks) {
+  if (!ctx->nat) return alfi_set_error(ctx, ALFI_E_STATE, "no communicator (alfi_ctx_comm_init)");
+  if (rank) *rank = ctx->nat->rank;
+  if (nranks) *nranks = ctx->nat->nranks;
+  return 0;
+}
+
+int alfi_ctx_comm_destroy(alfi_ctx* ctx) {
+  native_destroy(ctx);
+  return 0;
+}
+
+int alfi_level_set_neighbours(alfi_level* L, int nnbr, const int32_t* ranks, const int64_t* send_nodes,
+                              const int64_t* recv_nodes) {
+  alfi_ctx* ctx = L->ctx;
+  if (!L->has_halo) return alfi_set_error(ctx, ALFI_E_STATE, "alfi_level_set_neighbours before alfi_level_set_partition");
+  if (nnbr < 0 || (nnbr > 0 && (!ranks || !send_nodes || !recv_nodes))) return alfi_set_error(ctx, ALFI_E_ARG, "NULL neighbour arrays");
+  const int me = ctx->nat ? ctx->nat->rank : -1, world = ctx->nat ? ctx->nat->nranks : INT32_MAX;
+  int64_t so = 0, ro = 0;
+  std::vector<int> nr;
+  std::vector<int64_t> soff, scnt, roff, rcnt;
+  for (int i = 0; i < nnbr; ++i) {
+    if (ranks[i] < 0 || ranks[i] >= world || ranks[i] == me || (i > 0 && ranks[i] <= ranks[i - 1]))
+      return alfi_set_error(ctx, ALFI_E_ARG, "neighbour ranks must be ascending, distinct from this rank and inside the group");
+    if (send_nodes[i] < 0 || recv_nodes[i] < 0) return alfi_set_error(ctx, ALFI_E_ARG, "negative neighbour count");
+    nr.push_back(ranks[i]);
+    soff.push_back(so * L->bs);
+    scnt.push_back(send_nodes[i] * L->bs);
+    roff.push_back(ro * L->bs);
+    rcnt.push_back(recv_nodes[i] * L->bs);
+    so += send_nodes[i];
+    ro += recv_nodes[i];
+  }
+  if (so != L->halo_nsend || ro != L->halo_nghost)
+    return alfi_set_error(ctx, ALFI_E_ARG, "neighbour counts (%lld send, %lld receive nodes) do not add up to the level's halo "
+                          "(%lld, %lld)", (long long)so, (long long)ro, (long long)L->halo_nsend, (long long)L->halo_nghost);
+  L->nbr_rank = nr;
+  L->nbr_send_off = soff;
+  L->nbr_send_cnt = scnt;
+  L->nbr_recv_off = roff;
+  L->nbr_recv_cnt = rcnt;
+  return 0;
+}
+
+}  // extern "C"

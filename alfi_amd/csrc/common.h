@@ -32,8 +32,20 @@ struct alfi_ctx {
   alfi_comm_fn comm = nullptr;
   void* comm_user = nullptr;
   bool exact_norm = false;  // partitioned FGMRES: second all-reduce for |w| instead of the Pythagorean identity
-  double* dred = nullptr;  // caller-owned device buffer the callback all-reduces: [0, RED_MAXV) dots, [RED_MAXV] norm^2
+  double* dred = nullptr;  // device buffer that is all-reduced: [0, RED_MAXV) dots, [RED_MAXV] norm^2 (caller-owned with
+                           // alfi_ctx_set_comm, owned by the ctx with alfi_ctx_comm_init)
+  // native transport (alfi_ctx_comm_init, comm.hip): the ctx owns an RCCL communicator and exchanges by itself
+  struct NativeComm* nat = nullptr;
 };
+
+// comm.hip: the library's own exchanges over RCCL (no host callback)
+struct alfi_level;
+int native_allreduce(alfi_ctx* ctx, int64_t offset, int64_t count);
+// dir 0: forward (send buffer segments -> the neighbours' receive buffers), 1: reverse (receive buffer segments back to
+// the owners' send buffers); async: on the transport's own stream between an event pair (..._BEGIN), finished by native_wait
+int native_exchange(alfi_level* L, int dir, bool async);
+int native_wait(alfi_ctx* ctx);
+void native_destroy(alfi_ctx* ctx);
 
 constexpr int RED_BLOCKS = 1024;  // blocks used by the two-stage dot/norm reductions
 constexpr int RED_MAXV = 32;      // max simultaneous dot products
@@ -137,7 +149,12 @@ struct alfi_level {
   bool has_halo = false;
   int64_t halo_nsend = 0, halo_nghost = 0;  // nodes
   int32_t* halo_send_nodes = nullptr;       // (nsend) owned nodes, grouped by destination
-  double *halo_sendbuf = nullptr, *halo_recvbuf = nullptr;  // caller-owned
+  double *halo_sendbuf = nullptr, *halo_recvbuf = nullptr;  // caller-owned unless own_halo_bufs
+  bool own_halo_bufs = false;
+  // alfi_level_set_neighbours: the ranks this level exchanges with and the segment of the send / receive buffer that
+  // belongs to each (offsets and counts in doubles)
+  std::vector<int> nbr_rank;
+  std::vector<int64_t> nbr_send_off, nbr_send_cnt, nbr_recv_off, nbr_recv_cnt;
   int64_t rev_nuniq = 0;                    // reverse-add: unique owned nodes receiving contributions
   int32_t *rev_nodes = nullptr, *rev_ptr = nullptr, *rev_pos = nullptr;
   int32_t* bc_dofs = nullptr;

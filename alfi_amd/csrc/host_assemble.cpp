@@ -297,20 +297,23 @@ int alfi_host_bsr_transpose(int64_t nbrows, int64_t nbcols, int bs, const int32_
   return 0;
 }
 
-// Dirichlet rows and columns -> identity (what firedrake.assemble(a, bcs=...) produces).  bcmask: (nnode*d) bytes.
-int alfi_host_apply_bc_bsr(int64_t nnode, int d, const int32_t* rowptr, const int32_t* colidx, double* vals,
-                           const uint8_t* bcmask) {
+// Dirichlet rows and columns -> identity (what firedrake.assemble(a, bcs=...) produces).  bcmask: (all nodes * d) bytes.
+// row_ids: node of each of the nrow block rows (a row subset, rank-local generation), or nullptr: row r is node r.
+int alfi_host_apply_bc_bsr(int64_t nrow, int d, const int32_t* rowptr, const int32_t* colidx, double* vals,
+                           const uint8_t* bcmask, const int32_t* row_ids) {
 #pragma omp parallel for schedule(static)
-  for (int64_t r = 0; r < nnode; ++r)
+  for (int64_t r = 0; r < nrow; ++r) {
+    const int64_t rnode = row_ids ? row_ids[r] : r;
     for (int64_t p = rowptr[r]; p < rowptr[r + 1]; ++p) {
       const int64_t cnode = colidx[p];
       double* blk = vals + p * d * d;
       for (int cc = 0; cc < d; ++cc)
         for (int dd = 0; dd < d; ++dd) {
-          const bool rb = bcmask[r * d + cc], cb = bcmask[cnode * d + dd];
-          if (rb || cb) blk[cc * d + dd] = (rb && cb && r == cnode && cc == dd) ? 1.0 : 0.0;
+          const bool rb = bcmask[rnode * d + cc], cb = bcmask[cnode * d + dd];
+          if (rb || cb) blk[cc * d + dd] = (rb && cb && rnode == cnode && cc == dd) ? 1.0 : 0.0;
         }
     }
+  }
   return 0;
 }
 

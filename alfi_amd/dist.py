@@ -124,6 +124,14 @@ class LevelPart(object):
     def g2l(self, g):
         """Local index of global nodes (-1 where absent)."""
         g = np.asarray(g, dtype=np.int64)
+        if g.size > 4096 and g.size * 8 > self.splits[-1]:
+            # many lookups: one dense global -> local table (int32 per global node) beats the binary searches
+            if getattr(self, "_g2l_table", None) is None:
+                t = np.full(int(self.splits[-1]), -1, dtype=np.int32)
+                t[self.own_nodes] = np.arange(self.nb_own, dtype=np.int32)
+                t[self.ghosts] = self.nb_own + np.arange(self.nb_ghost, dtype=np.int32)
+                self._g2l_table = t
+            return self._g2l_table[g].astype(np.int64)
         out = np.full(g.shape, -1, dtype=np.int64)
         own = (g >= self.lo) & (g < self.hi)
         out[own] = self.own_perm[g[own] - self.lo]
@@ -161,8 +169,24 @@ def owned_patches(L, lo, hi):
 def transfer_blocks(T, bs, lo, hi):
     """Coarse-cell blocks (transfer.py:13-46) whose closure holds a fine node in [lo, hi): the rows of D_I of a block
     reach exactly the fine nodes of the coarse cell's closure."""
+    if hasattr(T.D_I, "blocks_with_cols_in"):                      # rank-local generation (alfi_amd.lazy)
+        return np.flatnonzero(T.D_I.blocks_with_cols_in(lo, hi))
     mb = T.blk_dofs.shape[1] // bs
     return np.flatnonzero(_rows_with_cols_in(T.D_I, lo, hi).reshape(-1, mb).any(axis=1))
+
+
+def _cols_of_rows(B, rows):
+    """Concatenated column indices of the block rows ``rows`` of a BSR (or lazy) matrix."""
+    if hasattr(B, "cols_of_rows"):
+        return B.cols_of_rows(rows)
+    idx, _ = _ragged_take(B.rowptr, rows)
+    return B.colidx[idx]
+
+
+def _cols_of_row_range(B, lo, hi):
+    if hasattr(B, "cols_of_row_range"):
+        return B.cols_of_row_range(lo, hi)
+    return B.colidx[B.rowptr[lo]:B.rowptr[hi]]
 
 
 def owned_boundary_mask(A, lo, hi):
@@ -194,15 +218,17 @@ def compute_ghosts(levels, transfers, splits, l, rank):
             mb = T.blk_dofs.shape[1] // L.bs
             blocks = transfer_blocks(T, L.bs, lo, hi)
             rows = (blocks[:, None] * mb + np.arange(mb)).ravel()
-            idx, _ = _ragged_take(T.D_I.rowptr, rows)
-            need.append(T.D_I.colidx[idx])                                        # closures of those coarse cells
+            need.append(_cols_of_rows(T.D_I, rows))                               # closures of those coarse cells
     if l + 1 < len(levels):
         T = transfers[l]
         flo, fhi = int(splits[l + 1][rank]), int(splits[l + 1][rank + 1])
         if fhi > flo:
-            need.append(T.P.colidx[T.P.rowptr[flo]:T.P.rowptr[fhi]])              # prolongation stencils
+            need.append(_cols_of_row_range(T.P, flo, fhi))                        # prolongation stencils
             if T.PT_plain is not T.PT:
-                need.append(np.flatnonzero(_rows_with_cols_in(T.PT_plain, flo, fhi)))
+                if getattr(T.PT_plain, "is_lazy", False):
+                    need.append(_cols_of_row_range(T.PT_plain.transpose(), flo, fhi))
+                else:
+                    need.append(np.flatnonzero(_rows_with_cols_in(T.PT_plain, flo, fhi)))
     if not need:
         return np.zeros(0, dtype=np.int64)
     g = np.unique(np.concatenate([np.asarray(x, dtype=np.int64) for x in need]))
@@ -324,7 +350,10 @@ def localize_transfer(T, Lf, pc, pf):
     assert (ld >= 0).all()
     out.blocks = blocks
     out.blk_dofs = ld.astype(np.int32)
-    out.K_II, out.D_II = np.ascontiguousarray(T.K_II[blocks]), np.ascontiguousarray(T.D_II[blocks])
+    if hasattr(T, "interior_mats"):                                  # rank-local generation: assembled for these blocks only
+        out.K_II, out.D_II = T.interior_mats(blocks)
+    else:
+        out.K_II, out.D_II = np.ascontiguousarray(T.K_II[blocks]), np.ascontiguousarray(T.D_II[blocks])
     rows = (blocks[:, None] * mb + np.arange(mb)).ravel()
     out.D_I = _map_cols(T.D_I.select_rows(rows), pf, pf.nb_loc)
     # rows of D_I^T for the owned fine nodes only: s = r - gamma D_I^T t is formed on owned rows
@@ -478,11 +507,22 @@ class DistMultigrid(object):
     only the rank's rows are uploaded)."""
 
     def __init__(self, levels, transfers, k, robust_restriction=False, group=None, device=None, min_dofs=400000,
-                 coarse_inverse=None, verbose=False, force_distributed=False, overlap=None, overlap_min_dofs=None):
+                 coarse_inverse=None, verbose=False, force_distributed=False, overlap=None, overlap_min_dofs=None,
+                 transport=None):
+        """transport: "rccl" -- the library's own RCCL communicator serves every exchange point of a cycle (no Python
+        between the kernels; the default whenever the process group's backend is nccl) -- or "callback": the library
+        calls back into this module, which exchanges through torch.distributed (the test transport: gloo, ranks sharing
+        a GPU).  ALFI_DIST_TRANSPORT overrides."""
+        import os
         import torch
         from . import hip
         self.comm = Comm(group)
         rank = self.comm.rank
+        if transport is None:
+            transport = os.environ.get("ALFI_DIST_TRANSPORT") or ("rccl" if self.comm.backend == "nccl" else "callback")
+        if transport not in ("rccl", "callback"):
+            raise ValueError("transport must be 'rccl' or 'callback'")
+        self.transport = transport
         if overlap is None:
             import os
             overlap = os.environ.get("ALFI_DIST_OVERLAP", "1") != "0"
@@ -504,20 +544,32 @@ class DistMultigrid(object):
         self.k = k
         with torch.cuda.stream(self.stream):
             self.ctx = ctx = hip.Context(device.index or 0, stream=self.stream.cuda_stream)
-            self.red = torch.zeros(RED_LEN, dtype=torch.float64, device=device)
-            self._cb = CommFn(self._callback)
-            ctx.set_comm(self._cb, self.red.data_ptr(), RED_LEN)
+            if transport == "rccl":
+                from . import _lib
+                box = [_lib.comm_unique_id() if rank == 0 else None]
+                self.comm.dist.broadcast_object_list(box, src=self.comm.dist.get_global_rank(group, 0) if group else 0,
+                                                     group=group)
+                ctx.comm_init(box[0], rank, self.comm.world)          # collective: ncclCommInitRank
+            else:
+                self.red = torch.zeros(RED_LEN, dtype=torch.float64, device=device)
+                self._cb = CommFn(self._callback)
+                ctx.set_comm(self._cb, self.red.data_ptr(), RED_LEN)
             self.halos = {}
             self.levels = []
             for LL in llev:
                 p = LL.part
                 dl = hip.Level(ctx, LL.A, LL.bc_dofs)
-                hb = HaloBuffers(p, device)
                 send_nodes = np.concatenate(p.send_nodes).astype(np.int32) if p.send_counts.sum() else \
                     np.zeros(0, dtype=np.int32)
-                dl.set_partition(p.nb_own, p.distributed, send_nodes, hb.sendbuf.data_ptr(), hb.recvbuf.data_ptr(),
-                                 p.nb_ghost)
-                self.halos[dl.id] = hb
+                if transport == "rccl":
+                    dl.set_partition(p.nb_own, p.distributed, send_nodes, None, None, p.nb_ghost)
+                    nbr = np.flatnonzero((p.send_counts > 0) | (p.recv_counts > 0))
+                    dl.set_neighbours(nbr, p.send_counts[nbr], p.recv_counts[nbr])
+                else:
+                    hb = HaloBuffers(p, device)
+                    dl.set_partition(p.nb_own, p.distributed, send_nodes, hb.sendbuf.data_ptr(), hb.recvbuf.data_ptr(),
+                                     p.nb_ghost)
+                    self.halos[dl.id] = hb
                 if LL.level > 0:
                     dl.set_patches(LL.patch_ptr, LL.patch_dofs)
                     dl.factor()

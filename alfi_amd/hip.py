@@ -45,6 +45,11 @@ class Context(object):
         """callback: a ctypes function pointer of type alfi_amd.dist.CommFn (kept alive by the caller)."""
         self.check(self.lib.alfi_ctx_set_comm(self.h, ctypes.cast(callback, vp), None, vp(int(dred_ptr)), int(dred_len)))
 
+    def comm_init(self, unique_id, rank, nranks):
+        """Native transport: the ctx creates its own RCCL communicator from the 128-byte id (collective over the ranks)."""
+        buf = ctypes.create_string_buffer(bytes(unique_id), _lib.COMM_ID_BYTES)
+        self.check(self.lib.alfi_ctx_comm_init(self.h, ctypes.cast(buf, vp), int(rank), int(nranks)))
+
     # vectors ----------------------------------------------------------------------------------------------------------
     def vec(self, n_or_array):
         if isinstance(n_or_array, (int, np.integer)):
@@ -134,11 +139,19 @@ class Level(object):
         self.id = i.value
 
     def set_partition(self, nb_owned, distributed, send_nodes, sendbuf_ptr, recvbuf_ptr, nb_ghost):
+        """sendbuf_ptr / recvbuf_ptr: device buffers the callback transport exchanges, or None: library-owned."""
         sn = np.ascontiguousarray(send_nodes, dtype=np.int32)
+        sp_, rp_ = (vp(int(sendbuf_ptr)), vp(int(recvbuf_ptr))) if sendbuf_ptr is not None else (None, None)
         self.ctx.check(self.ctx.lib.alfi_level_set_partition(self.h, int(nb_owned), 1 if distributed else 0, len(sn),
-                                                             _ptr(sn), vp(int(sendbuf_ptr)), vp(int(recvbuf_ptr)),
-                                                             int(nb_ghost)))
+                                                             _ptr(sn), sp_, rp_, int(nb_ghost)))
         self.n_own = int(nb_owned) * self.bs
+
+    def set_neighbours(self, ranks, send_nodes, recv_nodes):
+        """Native transport: neighbour ranks (ascending) and the nodes sent to / received from each."""
+        r = np.ascontiguousarray(ranks, dtype=np.int32)
+        sc = np.ascontiguousarray(send_nodes, dtype=np.int64)
+        rc = np.ascontiguousarray(recv_nodes, dtype=np.int64)
+        self.ctx.check(self.ctx.lib.alfi_level_set_neighbours(self.h, len(r), _ptr(r), _ptr(sc), _ptr(rc)))
 
     def set_overlap(self, nb_interior, npatch_interior):
         self.ctx.check(self.ctx.lib.alfi_level_set_overlap(self.h, int(nb_interior), int(npatch_interior)))

@@ -205,13 +205,16 @@ def build_transfer_data(Vc, Vf, nu, gamma, graph=None):
     di_vals = _hostlib.assemble_bsr(Vf.cell_nodes, g, vol, tens, d, di_rowptr, di_colidx, gamma=1.0, row_map=row_map)
     T.D_I = BSR(rows.shape[0], Vf.num_nodes, d, di_rowptr, di_colidx, di_vals)
     T.D_IT = T.D_I.transpose()                            # (fine nodes) x (interior nodes)
-    Pv = vector_prolongation(Vc, Vf)
-    T.P = BSR.from_scipy(Pv, d)
-    T.PT = T.P.transpose()
+    def scalar_blocks(Ps):       # kron(Ps, I_d) as BSR without forming the d^2-times larger scalar matrix
+        return BSR(Ps.shape[0], Ps.shape[1], d, Ps.indptr, Ps.indices, Ps.data[:, None, None] * np.eye(d)[None])
+
     if dim == 3 and element.bubble and element.degree == 1:
-        Pn = sp.kron(nodal_prolongation(Vc, Vf), sp.identity(d, format="csr"), format="csr")
-        T.PT_plain = BSR.from_scipy(Pn, d).transpose()
+        T.P = BSR.from_scipy(vector_prolongation(Vc, Vf), d)
+        T.PT = T.P.transpose()
+        T.PT_plain = scalar_blocks(nodal_prolongation(Vc, Vf)).transpose()
     else:
+        T.P = scalar_blocks(nodal_prolongation(Vc, Vf))
+        T.PT = T.P.transpose()
         T.PT_plain = T.PT
     T.inject_map = injection_map(Vc, Vf)
     T.nu, T.gamma = nu, gamma
@@ -244,10 +247,14 @@ def build_pressure_coupling(L, zero_bc_columns=True):
     return B, vol
 
 
-def build_hierarchy(problem, nref, k, Re, gamma=1e4, advect=True, patches=True, verbose=False):
+def build_hierarchy(problem, nref, k, Re, gamma=1e4, advect=True, patches=True, verbose=False, lazy=False):
     """Levels 0..nref of the velocity block for ``problem`` at Reynolds number Re.
 
-    nu = char_length * char_velocity / Re (alfi/solver.py:261-267); gamma default 1e4 (alfi/driver.py:30)."""
+    nu = char_length * char_velocity / Re (alfi/solver.py:261-267); gamma default 1e4 (alfi/driver.py:30).
+
+    lazy: rank-local generation (alfi_amd.lazy): meshes, numbering, graphs, patches and coarse-cell blocks as usual --
+    what the mesh partitioner needs -- but operators and transfers as recipes that assemble the rows a rank asks for
+    (``alfi_amd.dist.DistMultigrid`` then never holds global values)."""
     t0 = time.time()
     dim = problem.dim
     element = velocity_element(dim, k)
@@ -266,16 +273,22 @@ def build_hierarchy(problem, nref, k, Re, gamma=1e4, advect=True, patches=True, 
         tens = element.reference_tensors()
         bcmask = np.repeat(V.bc_node_mask, d)
         wind = problem.driver(V.node_coords)
-        # level operator in one pass over the cells
-        A = _hostlib.assemble_bsr(V.cell_nodes, g, vol, tens, d, rowptr, colidx, nu=nu, gamma=gamma, adv=adv,
-                                  wind=wind if adv else None)
-        _hostlib.apply_bc_bsr(V.num_nodes, d, rowptr, colidx, A, bcmask)
-        L.A = BSR(V.num_nodes, V.num_nodes, d, rowptr, colidx, A)
+        if lazy:
+            from .lazy import LazyOperator, LazyTransfer
+            L.A = LazyOperator(V, rowptr, colidx, (g, vol), tens, nu, gamma, adv, wind)
+        else:
+            # level operator in one pass over the cells
+            A = _hostlib.assemble_bsr(V.cell_nodes, g, vol, tens, d, rowptr, colidx, nu=nu, gamma=gamma, adv=adv,
+                                      wind=wind if adv else None)
+            _hostlib.apply_bc_bsr(V.num_nodes, d, rowptr, colidx, A, bcmask)
+            L.A = BSR(V.num_nodes, V.num_nodes, d, rowptr, colidx, A)
         L.bc_dofs = V.bc_dofs
         L.nu, L.gamma = nu, gamma
         if patches and l > 0:
             L.patch_ptr, L.patch_dofs, L.patch_seeds = V.star_patches()
-        if l > 0:
+        if l > 0 and lazy:
+            transfers.append(LazyTransfer(Vprev, V, nu, gamma, (rowptr, colidx), (g, vol), tens))
+        elif l > 0:
             transfers.append(build_transfer_data(Vprev, V, nu, gamma, graph=(rowptr, colidx)))
         levels.append(L)
         Vprev = V

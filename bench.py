@@ -52,7 +52,9 @@ def describe(cfg):
         dim, el, baseN * 2 ** nref, baseN, nref, Re, k)
 
 
-def build_problem(cfg, verbose):
+def build_problem(cfg, verbose, lazy=False):
+    """lazy: rank-local generation (alfi_amd.lazy) -- integers (meshes, numbering, graphs, patches) now, operator and
+    transfer values only for the rows a rank's partition asks for; used by the multi-GPU leg."""
     from alfi_amd.problem import TwoDimLidDrivenCavityProblem, ThreeDimLidDrivenCavityProblem, build_hierarchy
     dim, baseN, nref, ke, Re, k = CONFIGS[cfg]
     if dim == "sv":
@@ -61,7 +63,7 @@ def build_problem(cfg, verbose):
         lv, tr = build_sv_hierarchy(ThreeDimBackwardsFacingStepProblem(baseN), nref, ke, Re=Re)
         return lv, tr, k
     prob = TwoDimLidDrivenCavityProblem(baseN) if dim == 2 else ThreeDimLidDrivenCavityProblem(baseN)
-    lv, tr = build_hierarchy(prob, nref, ke, Re=Re, verbose=verbose)
+    lv, tr = build_hierarchy(prob, nref, ke, Re=Re, verbose=verbose, lazy=lazy)
     return lv, tr, k
 
 
@@ -113,7 +115,8 @@ def claim_stdout():
 
 def main_distributed(args, rank, world, local_rank):
     """One process per GPU: the fixed config-4 mesh partitioned over the ranks (strong scaling), halos and reductions over
-    RCCL.  Every rank generates the same global hierarchy on its host cores and uploads its own share."""
+    RCCL issued by the library itself.  Every rank builds the integer side of the hierarchy (meshes, numbering, graphs,
+    patches: what the partitioner needs) and assembles operator / transfer values for its own rows only."""
     import torch
     import torch.distributed as dist
     emit = claim_stdout()
@@ -132,7 +135,8 @@ def main_distributed(args, rank, world, local_rank):
     os.environ.setdefault("ALFI_HOST_THREADS", str(max(1, cpu_share() // world)))    # host generator threads of this rank
     from alfi_amd.dist import DistMultigrid
     t0 = time.time()
-    lv, tr, k = build_problem(args.config, args.verbose and rank == 0)
+    lazy = CONFIGS[args.config][0] != "sv" and os.environ.get("ALFI_DIST_GLOBAL_GENERATION") != "1"
+    lv, tr, k = build_problem(args.config, args.verbose and rank == 0, lazy=lazy)
     t_gen = time.time() - t0
 
     def coarse_inv(A_bsr):
@@ -155,7 +159,8 @@ def main_distributed(args, rank, world, local_rank):
     dmg.sync()
     # events around the dominant kernel only (the roofline block needs them): the small distributed levels are bound by
     # per-launch latency and every event record adds to it; the exchanges are timed in one extra cycle afterwards
-    ctx.prof_enable(3 if world > 1 else True)
+    prof_mode = {"0": False, "1": True}.get(os.environ.get("ALFI_BENCH_PROF", "3"), 3)
+    ctx.prof_enable(prof_mode)
     ctx.prof_reset()
     dist.barrier()
     torch.cuda.synchronize()
@@ -185,7 +190,7 @@ def main_distributed(args, rank, world, local_rank):
     prof = ctx.prof_get()
     ms_f, cnt_f = ctx.prof_get(fin.id)["PATCH_APPLY"]
     comm_ms = prof["COMM"][0] / args.steps
-    if world > 1:                                    # device time of the exchange points: one extra, untimed cycle
+    if True:                                         # device time of the exchange points: one extra, untimed cycle
         ctx.prof_enable(2)
         ctx.prof_reset()
         dmg.vcycle(db, dx)
@@ -218,8 +223,9 @@ def main_distributed(args, rank, world, local_rank):
     # account per apply, not per launch
     applies = args.steps * 2 * k
     local_gbs = bytes_apply * applies / (ms_f * 1e-3) / 1e9 if ms_f > 0 else 0.0
-    stats = torch.tensor([float(npatch), float(dmg.n_own), float(dmg.n_loc - dmg.n_own), local_gbs, comm_ms],
-                         dtype=torch.float64, device="cuda")
+    rss_gb = resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 1e6
+    stats = torch.tensor([float(npatch), float(dmg.n_own), float(dmg.n_loc - dmg.n_own), local_gbs, comm_ms, rss_gb,
+                          t_gen, t_setup], dtype=torch.float64, device="cuda")
     allstats = [torch.zeros_like(stats) for _ in range(world)]
     dist.all_gather(allstats, stats)
     if rank == 0:
@@ -228,14 +234,16 @@ def main_distributed(args, rank, world, local_rank):
         out = {
             "metric": ("V-cycles/sec on bfs3d SV P3-P2dg (DoF*smooths/sec in dof_smooths_per_s)" if CONFIGS[args.config][0] == "sv"
                    else "V-cycles/sec on ldc%dd P2-P0 (DoF*smooths/sec in dof_smooths_per_s)" % CONFIGS[args.config][0]),
-            "value": vps, "unit": "V-cycles/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "value": vps, "unit": "V-cycles/s", "n_gpus": world, "n_ranks_seen": int(dist.get_world_size()),
+            "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": describe(args.config), "name": args.config, "velocity_dofs": int(L.n),
                        "levels": len(lv), "patches_finest": int(len(L.patch_ptr) - 1),
                        "cycle": "V(k,k), 1 cycle per step",
                        "parallelism": "mesh partition over %d GPUs (Morton boxes, RCCL halos + all-reduce)" % world,
-                       "backend": backend,
+                       "backend": backend, "transport": dmg.transport,
+                       "generation": "rank-local (alfi_amd.lazy)" if lazy else "global on every rank",
                        "distributed_levels": [int(p.level) for p in dmg.parts if p.distributed]},
             "dof_smooths_per_s": L.n * 2 * k * vps,
             "roofline": {"kernel": "big_apply_kernel" if np.diff(L.patch_ptr).max() > 160 else "patch_apply_kernel", "bound": "hbm", "achieved": local_gbs, "peak": HBM_PEAK_GBS,
@@ -248,8 +256,11 @@ def main_distributed(args, rank, world, local_rank):
                          "ghost_dofs": [r[2] for r in per_rank], "patch_apply_GBps": [round(r[3], 1) for r in per_rank],
                          "comm_ms_per_cycle": [round(r[4], 3) for r in per_rank]},
             "rel_residual_after_timed_cycles": res,
-            "setup_s": {"host_generation": round(t_gen, 1), "partition_and_device_setup": round(t_setup, 1),
-                        "host_peak_rss_GB_rank0": round(resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 1e6, 1)},
+            "setup_s": {"host_generation": round(max(r[6] for r in per_rank), 1),
+                        "partition_and_device_setup": round(max(r[7] for r in per_rank), 1),
+                        "host_peak_rss_GB_per_rank": [round(r[5], 1) for r in per_rank],
+                        "note": "max over ranks; generation = meshes, numbering, graphs, patches (every rank); setup = "
+                                "partition, assembly of the rank's own rows, upload, patch inversion"},
             "cpu_baseline": {"value": None, "unit": "V-cycles/s", "cores": 0, "kind": "port",
                              "sample": "reported at N=1 only"},
         }
@@ -259,6 +270,76 @@ def main_distributed(args, rank, world, local_rank):
     dist.barrier()
     dmg.close()
     dist.destroy_process_group()
+
+
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start the N rank processes as children -- one per GPU, the same
+    command line, the rank environment torch.distributed.run would export -- relay rank 0's JSON line and exit non-zero
+    if any rank fails.  Nothing in this (parent) process touches a GPU: `device_count()` reads the topology without
+    creating a context, and the children are new processes, not an exec of an initialised one."""
+    import signal
+    import socket
+    import subprocess
+    import torch
+    ndev = torch.cuda.device_count()
+    shared = os.environ.get("ALFI_DIST_BACKEND", "nccl") != "nccl"     # gloo: functional runs with ranks sharing a GPU
+    if ndev < n and not shared:
+        raise SystemExit("bench.py --gpus %d: only %d GPU(s) visible (RCCL needs one GPU per rank; ALFI_DIST_BACKEND=gloo "
+                         "runs the ranks on a shared GPU as a functional check)" % (n, ndev))
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: the only mode the host driver supports
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, cwd=os.getcwd()))
+    line = None
+    failed = None
+    import selectors
+    sel = selectors.DefaultSelector()
+    sel.register(procs[0].stdout, selectors.EVENT_READ)
+    buf = b""
+    open_out = True
+    while True:
+        if open_out:
+            for _ in sel.select(timeout=0.5):
+                chunk = os.read(procs[0].stdout.fileno(), 65536)
+                if not chunk:
+                    open_out = False
+                    sel.unregister(procs[0].stdout)
+                buf += chunk
+        else:
+            time.sleep(0.2)
+        codes = [p.poll() for p in procs]
+        bad = [(r, c) for r, c in enumerate(codes) if c not in (None, 0)]
+        if bad:
+            failed = bad[0]
+            break
+        if all(c == 0 for c in codes) and not open_out:
+            break
+    if failed is not None:
+        for p in procs:                                            # exactly the children started above, by PID
+            if p.poll() is None:
+                p.send_signal(signal.SIGTERM)
+        for p in procs:
+            try:
+                p.wait(timeout=20)
+            except subprocess.TimeoutExpired:
+                p.kill()
+        sys.stderr.write("bench.py: rank %d exited with code %d\n" % failed)
+        raise SystemExit(1)
+    for cand in buf.decode(errors="replace").splitlines():
+        if cand.startswith("{"):
+            line = cand
+    if line is None:
+        sys.stderr.write("bench.py: rank 0 printed no JSON line\n")
+        raise SystemExit(1)
+    print(line, flush=True)
+    return 0
 
 
 def main():
@@ -280,6 +361,10 @@ def main():
     ap.add_argument("--verbose", action="store_true")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: this process only starts the N rank processes (before anything here touches a
+        # GPU) and relays rank 0's JSON line; under torch.distributed.run the rank environment is already there
+        return spawn_ranks(args.gpus)
     import torch
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -292,9 +377,7 @@ def main():
         os.environ.setdefault("WORLD_SIZE", "1")
     if world > 1 or args.gpus > 1 or force_dist:
         if world != args.gpus:
-            raise SystemExit("--gpus %d needs %d ranks: launch with python -m torch.distributed.run --nnodes=1 "
-                             "--nproc-per-node %d --master-addr 127.0.0.1 bench.py --gpus %d ..."
-                             % (args.gpus, args.gpus, args.gpus, args.gpus))
+            raise SystemExit("--gpus %d but the launcher started %d ranks (WORLD_SIZE)" % (args.gpus, world))
         return main_distributed(args, rank, world, local_rank)
 
     emit = claim_stdout()

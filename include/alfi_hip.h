@@ -30,6 +30,7 @@ extern "C" {
 #define ALFI_E_ARG -2      /* invalid argument / unsupported size */
 #define ALFI_E_STATE -3    /* call sequence error (e.g. apply before factor) */
 #define ALFI_E_SINGULAR -4 /* zero pivot met while inverting a patch or transfer block */
+#define ALFI_E_COMM -5     /* an RCCL call failed / librccl could not be loaded */
 
 typedef struct alfi_ctx alfi_ctx;
 typedef struct alfi_level alfi_level;
@@ -70,11 +71,26 @@ int alfi_prof_get(alfi_ctx* ctx, int ev, double* total_ms, int64_t* count);
 /* same, restricted to launches issued on behalf of one level (level_id from alfi_level_id; -1 = all levels) */
 int alfi_prof_get_level(alfi_ctx* ctx, int ev, int level_id, double* total_ms, int64_t* count);
 
-/* ---- mesh-partition parallelism: one ctx per GPU / process, exchanges delegated to the host program ---------------- */
+/* ---- mesh-partition parallelism: one ctx per GPU / process --------------------------------------------------------- */
 /* The reference runs one MPI rank per mesh partition (alfi/solver.py:604-605, alfi/relaxation.py:120-121) and PETSc
- * performs the ghost exchanges [3P].  Here the library packs / unpacks halo buffers and calls `fn` at every exchange
- * point of a smoother, transfer or cycle; the host program performs the exchange (torch.distributed over RCCL in
- * alfi_amd/dist.py) stream-ordered on the ctx's stream and returns 0.  ops:
+ * performs the ghost exchanges (VecScatter forward / reverse-add around PCApply_PATCH and MatMult) and the reductions of
+ * the Gram-Schmidt step (MPI_Allreduce) [3P].  Here every exchange point of a smoother, transfer or cycle is served by
+ * one of two transports:
+ *
+ * (1) NATIVE (the product path): the ctx owns an RCCL communicator and exchanges by itself, stream-ordered on its own
+ *     stream: one group of ncclSend / ncclRecv pairs with the level's actual neighbours (alfi_level_set_neighbours; a box
+ *     partition has <= 7 of them on a node = one xGMI link each) per halo exchange, one ncclAllReduce of <= 33 doubles
+ *     per reduction.  The host program only distributes the 128-byte id once (any channel: MPI_Bcast in the reference's
+ *     world, torch.distributed / a file here): alfi_comm_unique_id on one rank, alfi_ctx_comm_init on every rank
+ *     (collective).  librccl is resolved at run time (dlopen). */
+#define ALFI_COMM_ID_BYTES 128
+int alfi_comm_unique_id(void* id_out, int64_t len);                                  /* ncclGetUniqueId */
+int alfi_ctx_comm_init(alfi_ctx* ctx, const void* id, int rank, int nranks);        /* ncclCommInitRank on the ctx's device */
+int alfi_ctx_comm_size(alfi_ctx* ctx, int* rank, int* nranks);
+int alfi_ctx_comm_destroy(alfi_ctx* ctx);                                            /* also done by alfi_ctx_destroy */
+/* (2) CALLBACK (test transport: CPU-staged exchanges between ranks sharing one GPU, gloo): the library packs / unpacks
+ *     halo buffers and calls `fn` at every exchange point; the host program performs the exchange stream-ordered on the
+ *     ctx's stream and returns 0.  ops:
  *   ALFI_COMM_ALLREDUCE: sum dred[offset .. offset+count) over all ranks, in place;
  *   ALFI_COMM_HALO_FWD : level `level_id`: every owner's send buffer -> the ghosts' receive buffers;
  *   ALFI_COMM_HALO_REV : the reverse route: receive buffers (ghost contributions) -> owners' send buffers;
@@ -101,9 +117,15 @@ int alfi_level_destroy(alfi_level* lvl);
  * smoother and SpMV exchange halos and all-reduce (needs alfi_ctx_set_comm); distributed == 0: a level owned by one
  * rank whose halo is only used by the transfer to a distributed finer level.  send_nodes_host: owned nodes other ranks
  * hold as ghosts, grouped by destination rank (the layout of d_sendbuf: nsend * bs doubles); d_recvbuf: nb_ghost * bs
- * doubles in ghost order.  Both buffers are device memory owned by the caller. */
+ * doubles in ghost order (ghosts grouped by owner).  Both buffers are device memory owned by the caller (callback
+ * transport, which exchanges them), or both NULL: the library allocates them (native transport). */
 int alfi_level_set_partition(alfi_level* lvl, int64_t nb_owned, int distributed, int64_t nsend,
                              const int32_t* send_nodes_host, double* d_sendbuf, double* d_recvbuf, int64_t nb_ghost);
+/* Native transport: the ranks this level exchanges with (ascending, without this rank) and how many nodes of the send
+ * list go to / how many ghost nodes come from each; the counts must add up to nsend and nb_ghost.  A rank with no
+ * neighbour on a level passes nnbr = 0. */
+int alfi_level_set_neighbours(alfi_level* lvl, int nnbr, const int32_t* ranks_host, const int64_t* send_nodes_host,
+                              const int64_t* recv_nodes_host);
 /* Communication / computation overlap on a distributed level (after alfi_level_set_partition and alfi_patches_set): the
  * caller numbered the owned nodes so that the first nb_interior have operator rows without ghost columns, and ordered the
  * patches so that the first npatch_interior hold no ghost dof.  SpMV and patch apply then run those parts between

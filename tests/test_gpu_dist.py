@@ -67,11 +67,14 @@ def test_partitioned_cycles_match_single_gpu(case, world, robust, overlap, tmp_p
     assert np.abs(dv - ov).max() / np.abs(ov).max() < CYCLE_TOL
 
 
-@pytest.mark.parametrize("exact_norm,tol", [("1", 1e-12), ("0", CYCLE_TOL)])
-def test_rccl_code_path_with_a_one_rank_group(tmp_path, exact_norm, tol):
-    """The NCCL (= RCCL) transport of alfi_amd.dist on the one GPU of the box: a 1-rank process group with the exchange
-    points forced on (empty halos, 1-rank all-reduces issued on the library's stream from inside the callbacks).  Checks
-    that torch's RCCL backend accepts exactly the calls the 8-GPU run makes and that the cycle still matches the
+@pytest.mark.parametrize("exact_norm,tol,transport", [("1", 1e-12, "rccl"), ("0", CYCLE_TOL, "rccl"),
+                                                      ("1", 1e-12, "callback")])
+def test_rccl_code_path_with_a_one_rank_group(tmp_path, exact_norm, tol, transport):
+    """The RCCL transports of alfi_amd.dist on the one GPU of the box: a 1-rank process group with the exchange points
+    forced on (empty halos, 1-rank all-reduces).  "rccl": the library's own communicator (alfi_ctx_comm_init from a unique
+    id, the exchanges issued by the library on its stream -- the product path of bench.py --gpus N); "callback": the
+    library calls back into alfi_amd.dist, which issues torch.distributed collectives on the library's stream.  Checks
+    that RCCL accepts exactly the calls the 8-GPU run makes and that the cycle still matches the
     single-GPU result (to rounding with the exact-norm variant; with the one-all-reduce-per-iteration default the 1e-14-level difference in
     |w| is amplified by the chained FGMRES least-squares problems like any other rounding difference: CYCLE_TOL)."""
     import textwrap
@@ -89,6 +92,7 @@ def test_rccl_code_path_with_a_one_rank_group(tmp_path, exact_norm, tol):
         lv, tr, k, _ = _hier("3d-P2FB")
         dmg = DistMultigrid(lv, tr, k, robust_restriction=True, min_dofs=1, force_distributed=True)
         assert dmg.comm.backend == "nccl" and all(p.distributed for p in dmg.parts[1:])
+        assert dmg.transport == os.environ["ALFI_DIST_TRANSPORT"]
         b = np.random.default_rng(0).standard_normal(lv[-1].n)
         b[lv[-1].bc_dofs] = 0.0
         db, dx = dmg.local_vec(b), dmg.local_vec()
@@ -112,7 +116,7 @@ def test_rccl_code_path_with_a_one_rank_group(tmp_path, exact_norm, tol):
     # ALFI_DIST_EXACT_NORM=1: |w| by its own all-reduce (PETSc's VecNorm) -> the partitioned path reproduces the serial one
     # to rounding; default: |w|^2 = |w_old|^2 - |h|^2 from the single all-reduce of the iteration
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), ALFI_DIST_EXACT_NORM=exact_norm,
-               ALFI_DIST_OVERLAP_MIN_DOFS="0")      # the asynchronous (overlapped) exchanges too, on these small levels
+               ALFI_DIST_TRANSPORT=transport, ALFI_DIST_OVERLAP_MIN_DOFS="0")      # the asynchronous (overlapped) exchanges too, on these small levels
     out = subprocess.run([sys.executable, str(script)], env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "ONE-RANK-RCCL-OK" in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]
 
