@@ -56,6 +56,8 @@ SIGNATURES = {
     "alfi_residual": (ctypes.c_int, [vp, vp, vp, vp]),
     "alfi_patches_set": (ctypes.c_int, [vp, ctypes.c_int64, vp, vp]),
     "alfi_patches_factor": (ctypes.c_int, [vp]),
+    "alfi_patches_check": (ctypes.c_int, [vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int64),
+                                          ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_double)]),
     "alfi_patches_set_multiplicative": (ctypes.c_int, [vp, ctypes.c_int64, vp, ctypes.c_int]),
     "alfi_patches_multiplicative_levels": (ctypes.c_int, [vp, ctypes.POINTER(ctypes.c_int64)]),
     "alfi_patch_apply": (ctypes.c_int, [vp, vp, vp]),
@@ -70,6 +72,7 @@ SIGNATURES = {
                                             ctypes.c_int64, ctypes.c_int, vp, vp, vp, ctypes.POINTER(vp)]),
     "alfi_transfer_destroy": (ctypes.c_int, [vp]),
     "alfi_transfer_update": (ctypes.c_int, [vp, ctypes.c_double, ctypes.c_double]),
+    "alfi_transfer_get_block_inverse": (ctypes.c_int, [vp, ctypes.c_int64, vp]),
     "alfi_prolong": (ctypes.c_int, [vp, vp, vp]),
     "alfi_transfer_set_injection": (ctypes.c_int, [vp, vp]),
     "alfi_inject": (ctypes.c_int, [vp, vp, vp]),

@@ -42,12 +42,31 @@ def hip_deps():
 
 
 def build_hip(force=False):
+    """One object per .hip file (compiled in parallel, only when the file or a header changed), then one link."""
+    from concurrent.futures import ThreadPoolExecutor
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
         raise RuntimeError("hipcc not found: cannot build libalfi_hip.so")
-    if force or _newer(HIP_LIB, hip_deps()):
-        _run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fno-gpu-rdc",
-              "-I", os.path.join(ROOT, "include"), "-I", CSRC, "-o", HIP_LIB] + hip_sources())
+    inc = os.path.join(ROOT, "include")
+    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    headers += [os.path.join(inc, f) for f in os.listdir(inc) if f.endswith(".h")]
+    objdir = os.path.join(CSRC, ".obj")
+    os.makedirs(objdir, exist_ok=True)
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-I", inc, "-I", CSRC]
+    jobs, objs = [], []
+    for src in hip_sources():
+        obj = os.path.join(objdir, os.path.basename(src)[:-4] + ".o")
+        objs.append(obj)
+        if force or _newer(obj, [src] + headers):
+            jobs.append([hipcc] + flags + ["-c", src, "-o", obj])
+    stale = set(os.listdir(objdir)) - set(os.path.basename(o) for o in objs)
+    for f in stale:
+        os.remove(os.path.join(objdir, f))
+    if jobs:
+        with ThreadPoolExecutor(max_workers=min(4, len(jobs))) as ex:
+            list(ex.map(_run, jobs))
+    if jobs or stale or force or _newer(HIP_LIB, objs):
+        _run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-fno-gpu-rdc", "-o", HIP_LIB] + objs)
     return HIP_LIB
 
 

@@ -514,6 +514,8 @@ int alfi_level_destroy(alfi_level* L) {
   dev_free(L->dof_pos);
   dev_free(L->mult_seq);
   dev_free(L->status);
+  dev_free(L->chk);
+  dev_free(L->chk_list);
   dev_free(L->V);
   dev_free(L->Z);
   dev_free(L->w);
@@ -796,8 +798,19 @@ int alfi_patches_factor(alfi_level* L) {
   int st = 0;
   ALFI_HIP_CHECK(ctx, hipMemcpyAsync(&st, L->status, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
   ALFI_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-  if (st != 0) return alfi_set_error(ctx, ALFI_E_SINGULAR, "zero pivot while inverting a patch operator");
+  // every stored inverse is probed (|| A_p X_p e - e ||); the ones that fail -- an unpivoted elimination met a zero or
+  // tiny pivot -- are re-inverted with partial pivoting, as the reference's LAPACK / UMFPACK factorisations would
+  ALFI_CHECK(patch_verify_and_repair(L, st));
   L->factored = true;
+  return 0;
+}
+
+int alfi_patches_check(alfi_level* L, double* worst_residual, int64_t* flagged, int64_t* repaired, double* worst_after) {
+  if (!L->factored) return alfi_set_error(L->ctx, ALFI_E_STATE, "alfi_patches_check before alfi_patches_factor");
+  if (worst_residual) *worst_residual = L->chk_worst;
+  if (flagged) *flagged = L->chk_flagged;
+  if (repaired) *repaired = L->chk_repaired;
+  if (worst_after) *worst_after = L->chk_flagged > 0 ? L->chk_worst_after : L->chk_worst;
   return 0;
 }
 
@@ -1093,6 +1106,21 @@ int alfi_transfer_update(alfi_transfer* T, double nu, double gamma) {
   ALFI_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
   if (st != 0) return alfi_set_error(ctx, ALFI_E_SINGULAR, "zero pivot while inverting a coarse-cell interior block");
   T->ready = true;
+  return 0;
+}
+
+int alfi_transfer_get_block_inverse(alfi_transfer* T, int64_t blk, double* out) {
+  alfi_ctx* ctx = T->ctx;
+  if (!T->ready) return alfi_set_error(ctx, ALFI_E_STATE, "alfi_transfer_get_block_inverse before alfi_transfer_update");
+  if (blk < 0 || blk >= T->nblk) return alfi_set_error(ctx, ALFI_E_ARG, "block index out of range");
+  const int m = T->m, ld = T->ld;
+  const int64_t stride = T->patch_mode ? T->bstride : (int64_t)m * ld;
+  std::vector<double> tmp((size_t)m * ld);
+  ALFI_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  ALFI_HIP_CHECK(ctx, hipMemcpy(tmp.data(), T->binv + blk * stride, tmp.size() * sizeof(double), hipMemcpyDeviceToHost));
+  for (int i = 0; i < m; ++i)
+    for (int j = 0; j < m; ++j)
+      out[(int64_t)i * m + j] = T->patch_mode ? tmp[patch_inv_index(i, j, m, ld)] : tmp[(int64_t)j * ld + i];
   return 0;
 }
 

@@ -174,6 +174,12 @@ struct alfi_level {
   int32_t* dof_pos = nullptr;     // (sum_n)
   bool factored = false;
   int* status = nullptr;          // device flag: nonzero if a zero pivot was met
+  // residual probe of the stored inverses + pivoted repair (kernels_check.hip)
+  double* chk = nullptr;          // device: [0] worst residual (as ordered bits), [1] number of flagged patches (int)
+  int32_t* chk_list = nullptr;    // device: flagged patch ids
+  int chk_cap = 0;
+  double chk_worst = -1.0, chk_worst_after = -1.0;   // of the last factorisation: before / after the repair (-1: not run)
+  int64_t chk_flagged = 0, chk_repaired = 0;
   // multiplicative sweeps: positions of the iteration sequence grouped into dependency wavefronts
   bool mult = false, mult_symmetrise = false;
   int32_t* mult_seq = nullptr;          // (nit) patch ids, wavefront-major
@@ -270,6 +276,8 @@ int launch_bsr_spmv(alfi_ctx* ctx, const DevBSR& A, const double* x, double* y, 
 int upload_bsr_values(alfi_ctx* ctx, DevBSR* d, const double* host_vals);
 int launch_patch_gather_dense(alfi_level* lvl);
 int launch_patch_invert(alfi_level* lvl);
+// kernels_check.hip: probe || A_p X_p e - e || of every stored inverse, pivoted re-inversion of the patches that fail
+int patch_verify_and_repair(alfi_level* lvl, int unpivoted_status);
 int launch_patch_invert_arrays(alfi_ctx* ctx, int64_t npatch, int max_np, const int64_t* patch_ptr,
                                const int64_t* inv_ptr, double* inv, int* status);
 int launch_patch_apply_arrays(alfi_ctx* ctx, int64_t npatch, const int64_t* patch_ptr, const int32_t* patch_dofs,

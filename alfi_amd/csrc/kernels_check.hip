@@ -1,0 +1,327 @@
+// Verification of the stored patch inverses and repair of the ones that fail it.
+//
+// The reference factors its patches with LAPACK's pivoted LU (patch_sub_pc_type lu + patch_pc_patch_dense_inverse,
+// alfi/solver.py:599-602; UMFPACK for Scott-Vogelius, :655-659).  The fast inversion kernels here (kernels_patch.hip,
+// kernels_bigpatch.hip) eliminate WITHOUT pivoting, which is backward stable for the SPD-dominated patch operators of the
+// shipped problems but not for an arbitrary Newton / SUPG Jacobian at high Reynolds number.  So every factorisation is
+// followed by a probe of every patch,
+//
+//     rho_p = || A_p (X_p e_p) - e_p ||_inf,       e_p a fixed vector of +-1,
+//
+// (O(n_p^2): one pass over X_p, one over the patch's operator rows), and every patch with rho_p > tol -- or a non-finite
+// inverse -- is re-gathered and re-inverted by Gauss-Jordan WITH partial pivoting (one workgroup per flagged patch, work
+// matrix in global scratch), then probed again.  alfi_patches_check reports the worst residual and the counts.
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+#include "common.h"
+
+namespace {
+
+__device__ __forceinline__ double probe_entry(int64_t p, int i) {
+  uint32_t h = (uint32_t)i * 2654435761u ^ (uint32_t)p * 40503u;
+  h ^= h >> 15;
+  h *= 2246822519u;
+  h ^= h >> 13;
+  return (h & 1u) ? 1.0 : -1.0;
+}
+
+__device__ __forceinline__ double wave_sum_chk(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+// position of patch dof `gcol` in the ascending list dofs_s[0..n), or -1
+__device__ __forceinline__ int find_dof(const int32_t* dofs_s, int n, int gcol) {
+  int a = 0, b = n;
+  while (a < b) {
+    const int mid = (a + b) >> 1;
+    if (dofs_s[mid] < gcol) a = mid + 1; else b = mid;
+  }
+  return (a < n && dofs_s[a] == gcol) ? a : -1;
+}
+
+// one workgroup per patch (list[blockIdx.x], or blockIdx.x itself).  Dynamic LDS: n int32 + n doubles.
+template <int BS>
+__global__ __launch_bounds__(256) void patch_check_kernel(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colidx,
+                                                           const double* __restrict__ vals, int flat,
+                                                           const int64_t* __restrict__ patch_ptr,
+                                                           const int32_t* __restrict__ patch_dofs,
+                                                           const int64_t* __restrict__ inv_ptr, const double* __restrict__ inv,
+                                                           const int32_t* __restrict__ list, double tol,
+                                                           unsigned long long* __restrict__ worst_bits,
+                                                           int32_t* __restrict__ flagged, int* __restrict__ nflag, int cap) {
+  extern __shared__ unsigned char smem[];
+  const int64_t p = list ? list[blockIdx.x] : blockIdx.x;
+  const int64_t off = patch_ptr[p];
+  const int n = (int)(patch_ptr[p + 1] - off);
+  const int ld = (n + 1) & ~1;
+  double* y_s = reinterpret_cast<double*>(smem);
+  int32_t* dofs_s = reinterpret_cast<int32_t*>(y_s + n);
+  __shared__ double wmax_s[4];
+  const double* X = inv + inv_ptr[p];
+  for (int i = threadIdx.x; i < n; i += 256) dofs_s[i] = patch_dofs[off + i];
+  // y = X e: a thread per row; entry (r, c) of the row-piece layout sits at base_r + c * rows_r
+  for (int r = threadIdx.x; r < n; r += 256) {
+    const int64_t base = patch_inv_index(r, 0, n, ld);
+    const int64_t rows = n > 1 ? patch_inv_index(r, 1, n, ld) - base : 0;
+    double acc = 0.0;
+    for (int c = 0; c < n; ++c) acc = __builtin_fma(X[base + (int64_t)c * rows], probe_entry(p, c), acc);
+    y_s[r] = acc;
+  }
+  __syncthreads();
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  double wmax = 0.0;
+  for (int r = wave; r < n; r += 4) {
+    const int gr = dofs_s[r];
+    const int brow = gr / BS, rr = gr % BS;
+    const int32_t lo = rowptr[brow], hi = rowptr[brow + 1];
+    const int nent = (hi - lo) * BS;
+    double acc = 0.0;
+    for (int e = lane; e < nent; e += 64) {
+      const int blk = e / BS, cc = e % BS;
+      const int a = find_dof(dofs_s, n, (colidx[lo + blk] & 0x7fffffff) * BS + cc);
+      if (a >= 0) acc = __builtin_fma(vals[bsr_val_index(flat, lo + blk, rr * BS + cc, BS * BS)], y_s[a], acc);
+    }
+    acc = wave_sum_chk(acc);
+    const double res = fabs(acc - probe_entry(p, r));
+    if (!(res <= wmax)) wmax = (res == res) ? res : INFINITY;      // NaN -> +inf
+  }
+  if (lane == 0) wmax_s[wave] = wmax;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double m = fmax(fmax(wmax_s[0], wmax_s[1]), fmax(wmax_s[2], wmax_s[3]));
+    atomicMax(worst_bits, (unsigned long long)__double_as_longlong(m));   // m >= 0: the bit patterns order like the values
+    if (!(m <= tol)) {
+      const int slot = atomicAdd(nflag, 1);
+      if (slot < cap) flagged[slot] = (int32_t)p;
+    }
+  }
+}
+
+// Gauss-Jordan with partial pivoting, one workgroup per flagged patch: gather A_p into the n x n row-major scratch W,
+// invert in place (row interchanges, undone as column interchanges at the end), store in the row-piece layout.
+template <int BS>
+__global__ __launch_bounds__(256) void patch_repair_kernel(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colidx,
+                                                            const double* __restrict__ vals, int flat,
+                                                            const int64_t* __restrict__ patch_ptr,
+                                                            const int32_t* __restrict__ patch_dofs,
+                                                            const int64_t* __restrict__ inv_ptr, double* __restrict__ inv,
+                                                            const int32_t* __restrict__ list, double* __restrict__ scratch,
+                                                            int64_t scratch_stride, int* __restrict__ status) {
+  extern __shared__ unsigned char smem[];
+  const int64_t p = list[blockIdx.x];
+  const int64_t off = patch_ptr[p];
+  const int n = (int)(patch_ptr[p + 1] - off);
+  const int ld = (n + 1) & ~1;
+  double* prow = reinterpret_cast<double*>(smem);        // n: scaled pivot row
+  double* mcol = prow + n;                               // n: multipliers of the pivot column
+  int32_t* dofs_s = reinterpret_cast<int32_t*>(mcol + n);   // n
+  int32_t* perm = dofs_s + n;                            // n
+  __shared__ double red_v[256];
+  __shared__ int red_i[256];
+  __shared__ int bad_s;
+  double* W = scratch + (int64_t)blockIdx.x * scratch_stride;
+  const int tid = threadIdx.x;
+  if (tid == 0) bad_s = 0;
+  for (int i = tid; i < n; i += 256) dofs_s[i] = patch_dofs[off + i];
+  for (int64_t e = tid; e < (int64_t)n * n; e += 256) W[e] = 0.0;
+  __syncthreads();
+  const int wave = tid >> 6, lane = tid & 63;
+  for (int r = wave; r < n; r += 4) {
+    const int gr = dofs_s[r];
+    const int brow = gr / BS, rr = gr % BS;
+    const int32_t lo = rowptr[brow], hi = rowptr[brow + 1];
+    const int nent = (hi - lo) * BS;
+    for (int e = lane; e < nent; e += 64) {
+      const int blk = e / BS, cc = e % BS;
+      const int a = find_dof(dofs_s, n, (colidx[lo + blk] & 0x7fffffff) * BS + cc);
+      if (a >= 0) W[(int64_t)r * n + a] = vals[bsr_val_index(flat, lo + blk, rr * BS + cc, BS * BS)];
+    }
+  }
+  __syncthreads();
+  for (int k = 0; k < n; ++k) {
+    // pivot search: largest |W[i][k]|, i >= k (ties: smallest i)
+    double bv = -1.0;
+    int bi = k;
+    for (int i = k + tid; i < n; i += 256) {
+      const double v = fabs(W[(int64_t)i * n + k]);
+      if (v > bv) { bv = v; bi = i; }
+    }
+    red_v[tid] = bv;
+    red_i[tid] = bi;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+      if (tid < s) {
+        const double ov = red_v[tid + s];
+        const int oi = red_i[tid + s];
+        if (ov > red_v[tid] || (ov == red_v[tid] && oi < red_i[tid])) { red_v[tid] = ov; red_i[tid] = oi; }
+      }
+      __syncthreads();
+    }
+    const int pr = red_i[0];
+    const double pv = red_v[0];
+    if (!(pv > 0.0) || pv == INFINITY) {       // zero / NaN / inf pivot column: singular to working precision
+      if (tid == 0) bad_s = 1;
+      __syncthreads();
+      break;
+    }
+    if (tid == 0) perm[k] = pr;
+    if (pr != k)
+      for (int j = tid; j < n; j += 256) {
+        const double t = W[(int64_t)k * n + j];
+        W[(int64_t)k * n + j] = W[(int64_t)pr * n + j];
+        W[(int64_t)pr * n + j] = t;
+      }
+    __syncthreads();
+    const double ip = 1.0 / W[(int64_t)k * n + k];
+    for (int j = tid; j < n; j += 256) {
+      prow[j] = (j == k) ? ip : W[(int64_t)k * n + j] * ip;
+      mcol[j] = (j == k) ? 0.0 : W[(int64_t)j * n + k];
+    }
+    __syncthreads();
+    for (int64_t e = tid; e < (int64_t)n * n; e += 256) {
+      const int i = (int)(e / n), j = (int)(e % n);
+      if (i == k)
+        W[e] = prow[j];
+      else if (j == k)
+        W[e] = -mcol[i] * ip;
+      else
+        W[e] = __builtin_fma(-mcol[i], prow[j], W[e]);
+    }
+    __syncthreads();
+  }
+  if (bad_s) {
+    if (tid == 0) atomicExch(status, 1);
+    return;
+  }
+  // inv(P A) = inv(A) P^T: undo the row interchanges as column interchanges, last first
+  for (int k = n - 1; k >= 0; --k) {
+    const int pr = perm[k];
+    if (pr != k)
+      for (int i = tid; i < n; i += 256) {
+        const double t = W[(int64_t)i * n + k];
+        W[(int64_t)i * n + k] = W[(int64_t)i * n + pr];
+        W[(int64_t)i * n + pr] = t;
+      }
+    __syncthreads();
+  }
+  double* S = inv + inv_ptr[p];
+  for (int64_t e = tid; e < (int64_t)ld * n; e += 256) {
+    const int r = (int)(e / n), c = (int)(e % n);
+    S[patch_inv_index(r, c, n, ld)] = r < n ? W[(int64_t)r * n + c] : 0.0;      // r == n: the zero padding row
+  }
+}
+
+}  // namespace
+
+// probe all patches (list == nullptr) or the listed ones; results accumulate in L->chk (device)
+static int launch_check(alfi_level* L, const int32_t* list, int64_t count, double tol) {
+  alfi_ctx* ctx = L->ctx;
+  if (count == 0) return 0;
+  const size_t lds = (size_t)L->max_np * (sizeof(double) + sizeof(int32_t));
+  unsigned long long* worst = reinterpret_cast<unsigned long long*>(L->chk);
+  int* nflag = reinterpret_cast<int*>(L->chk + 1);
+  dim3 grid((unsigned)count), block(256);
+  if (L->bs == 2)
+    hipLaunchKernelGGL(patch_check_kernel<2>, grid, block, lds, ctx->stream, L->A.rowptr, L->A.colidx, L->A.vals, L->A.flat,
+                       L->patch_ptr, L->patch_dofs, L->inv_ptr, L->inv, list, tol, worst, L->chk_list, nflag, L->chk_cap);
+  else
+    hipLaunchKernelGGL(patch_check_kernel<3>, grid, block, lds, ctx->stream, L->A.rowptr, L->A.colidx, L->A.vals, L->A.flat,
+                       L->patch_ptr, L->patch_dofs, L->inv_ptr, L->inv, list, tol, worst, L->chk_list, nflag, L->chk_cap);
+  ALFI_HIP_CHECK(ctx, hipGetLastError());
+  return 0;
+}
+
+static int read_check(alfi_level* L, double* worst, int* nflag) {
+  alfi_ctx* ctx = L->ctx;
+  double h[2];
+  ALFI_HIP_CHECK(ctx, hipMemcpyAsync(h, L->chk, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+  ALFI_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  *worst = h[0];
+  int nf;
+  memcpy(&nf, &h[1], sizeof(int));
+  *nflag = nf;
+  return 0;
+}
+
+// Called by alfi_patches_factor after the fast inversion.  unpivoted_status: the zero-pivot flag of that inversion (a
+// patch that met one holds non-finite entries and is caught by the probe).
+int patch_verify_and_repair(alfi_level* L, int unpivoted_status) {
+  alfi_ctx* ctx = L->ctx;
+  static const bool enabled = !(getenv("ALFI_PATCH_CHECK") && atoi(getenv("ALFI_PATCH_CHECK")) == 0);
+  static const double tol = getenv("ALFI_PATCH_CHECK_TOL") ? atof(getenv("ALFI_PATCH_CHECK_TOL")) : 1e-6;
+  L->chk_worst = -1.0;
+  L->chk_flagged = L->chk_repaired = 0;
+  if (!enabled || L->npatch == 0) {
+    if (unpivoted_status != 0) return alfi_set_error(ctx, ALFI_E_SINGULAR, "zero pivot while inverting a patch operator");
+    return 0;
+  }
+  if (!L->chk) {
+    ALFI_HIP_CHECK(ctx, hipMalloc((void**)&L->chk, 2 * sizeof(double)));
+    L->chk_cap = (int)std::min<int64_t>(L->npatch, 1 << 20);
+    ALFI_HIP_CHECK(ctx, hipMalloc((void**)&L->chk_list, sizeof(int32_t) * (size_t)L->chk_cap));
+  }
+  ALFI_HIP_CHECK(ctx, hipMemsetAsync(L->chk, 0, 2 * sizeof(double), ctx->stream));
+  ALFI_CHECK(launch_check(L, nullptr, L->npatch, tol));
+  double worst = 0.0;
+  int nflag = 0;
+  ALFI_CHECK(read_check(L, &worst, &nflag));
+  L->chk_worst = worst;
+  L->chk_flagged = nflag;
+  if (nflag == 0) return 0;
+  if (nflag > L->chk_cap)
+    return alfi_set_error(ctx, ALFI_E_SINGULAR, "%d of %lld patch inverses fail the residual probe (worst %.3e)", nflag,
+                          (long long)L->npatch, worst);
+  constexpr int REPAIR_MAX_NP = 1024;
+  if (L->max_np > REPAIR_MAX_NP)
+    return alfi_set_error(ctx, ALFI_E_SINGULAR, "%d patch inverses fail the residual probe (worst %.3e) and the pivoted "
+                          "repair handles patches of at most %d dofs", nflag, worst, REPAIR_MAX_NP);
+  // pivoted re-inversion of the flagged patches, in batches bounded by 1 GiB of scratch
+  const int64_t stride = (int64_t)L->max_np * L->max_np;
+  const int64_t per_batch = std::max<int64_t>(1, ((int64_t)1 << 27) / stride);
+  double* scratch = nullptr;
+  ALFI_HIP_CHECK(ctx, hipMalloc((void**)&scratch, sizeof(double) * (size_t)(std::min<int64_t>(per_batch, nflag) * stride)));
+  ALFI_HIP_CHECK(ctx, hipMemsetAsync(L->status, 0, sizeof(int), ctx->stream));
+  const size_t lds = (size_t)L->max_np * (2 * sizeof(double) + 2 * sizeof(int32_t));
+  int rc = 0;
+  for (int64_t b0 = 0; b0 < nflag && rc == 0; b0 += per_batch) {
+    const int64_t nb = std::min<int64_t>(per_batch, nflag - b0);
+    dim3 grid((unsigned)nb), block(256);
+    if (L->bs == 2)
+      hipLaunchKernelGGL(patch_repair_kernel<2>, grid, block, lds, ctx->stream, L->A.rowptr, L->A.colidx, L->A.vals, L->A.flat,
+                         L->patch_ptr, L->patch_dofs, L->inv_ptr, L->inv, L->chk_list + b0, scratch, stride, L->status);
+    else
+      hipLaunchKernelGGL(patch_repair_kernel<3>, grid, block, lds, ctx->stream, L->A.rowptr, L->A.colidx, L->A.vals, L->A.flat,
+                         L->patch_ptr, L->patch_dofs, L->inv_ptr, L->inv, L->chk_list + b0, scratch, stride, L->status);
+    if (hipGetLastError() != hipSuccess) rc = alfi_set_error(ctx, ALFI_E_HIP, "patch_repair_kernel launch failed");
+  }
+  int st = 0;
+  if (rc == 0 && hipMemcpyAsync(&st, L->status, sizeof(int), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) rc = ALFI_E_HIP;
+  (void)hipStreamSynchronize(ctx->stream);
+  (void)hipFree(scratch);
+  if (rc != 0) return rc;
+  if (st != 0) return alfi_set_error(ctx, ALFI_E_SINGULAR, "a patch operator is singular to working precision (pivoted inversion)");
+  // probe the repaired patches again (the list stays as it is: copy it, the kernel appends to chk_list)
+  std::vector<int32_t> h_list((size_t)nflag);
+  ALFI_HIP_CHECK(ctx, hipMemcpy(h_list.data(), L->chk_list, sizeof(int32_t) * (size_t)nflag, hipMemcpyDeviceToHost));
+  int32_t* d_list = nullptr;
+  ALFI_HIP_CHECK(ctx, hipMalloc((void**)&d_list, sizeof(int32_t) * (size_t)nflag));
+  ALFI_HIP_CHECK(ctx, hipMemcpy(d_list, h_list.data(), sizeof(int32_t) * (size_t)nflag, hipMemcpyHostToDevice));
+  ALFI_HIP_CHECK(ctx, hipMemsetAsync(L->chk, 0, 2 * sizeof(double), ctx->stream));
+  rc = launch_check(L, d_list, nflag, tol);
+  double worst2 = 0.0;
+  int nflag2 = 0;
+  if (rc == 0) rc = read_check(L, &worst2, &nflag2);
+  (void)hipFree(d_list);
+  if (rc != 0) return rc;
+  L->chk_repaired = nflag - nflag2;
+  L->chk_worst_after = worst2;
+  if (nflag2 > 0)
+    return alfi_set_error(ctx, ALFI_E_SINGULAR, "%d patch inverses still fail the residual probe after pivoted re-inversion "
+                          "(worst %.3e): the patch operators are singular to working precision", nflag2, worst2);
+  return 0;
+}

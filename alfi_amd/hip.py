@@ -177,6 +177,15 @@ class Level(object):
     def factor(self):
         self.ctx.check(self.ctx.lib.alfi_patches_factor(self.h))
 
+    def patch_check(self):
+        """(worst residual || A_p X_p e - e || of the fast inversion, patches flagged, patches repaired by the pivoted
+        re-inversion, worst residual afterwards) of the last ``factor()``."""
+        w, wa = ctypes.c_double(), ctypes.c_double()
+        f, r = ctypes.c_int64(), ctypes.c_int64()
+        self.ctx.check(self.ctx.lib.alfi_patches_check(self.h, ctypes.byref(w), ctypes.byref(f), ctypes.byref(r),
+                                                       ctypes.byref(wa)))
+        return w.value, f.value, r.value, wa.value
+
     def patch_stats(self):
         a, b, c = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int64()
         self.ctx.check(self.ctx.lib.alfi_patches_stats(self.h, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)))
@@ -252,6 +261,11 @@ class Transfer(object):
 
     def update(self, nu, gamma):
         self.ctx.check(self.ctx.lib.alfi_transfer_update(self.h, float(nu), float(gamma)))
+
+    def block_inverse(self, blk, m):
+        out = np.empty((m, m))
+        self.ctx.check(self.ctx.lib.alfi_transfer_get_block_inverse(self.h, int(blk), _ptr(out)))
+        return out
 
     def prolong(self, xc, xf):
         self.ctx.check(self.ctx.lib.alfi_prolong(self.h, xc.ptr, xf.ptr))

@@ -499,10 +499,17 @@ def main():
     b_spmv = (8.0 * bsz * bsz + 4.0) * L.A.nnzb + 4.0 * (L.A.nbrows + 1) + 16.0 * L.n
     spmv_gbs = b_spmv * n_spmv / (t_spmv_ms * 1e-3) / 1e9 if t_spmv_ms > 0 else 0.0
 
-    traffic = None
+    # HBM traffic of the dominant kernel comes from rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE in separate runs,
+    # scripts/gpu_check.sh + scripts/pmc_summary.py): hardware counters cannot be read from inside this process, so the
+    # figure is the committed summary of the latest such pass -- NOT a measurement of this run; traffic_source says so.
+    traffic, traffic_source = None, None
     pmc_file = os.path.join(ROOT, "profiles", "pmc_patch_apply_%s.json" % args.config)
     if os.path.exists(pmc_file):
-        traffic = json.load(open(pmc_file)).get("hbm_bytes_per_launch")
+        pmc = json.load(open(pmc_file))
+        traffic = pmc.get("hbm_bytes_per_launch")
+        traffic_source = {"measured_in_this_run": False, "file": os.path.relpath(pmc_file, ROOT),
+                          "collected": pmc.get("collected", "round 1 (2026-10-03), rocprofv3 --pmc, another box"),
+                          "tag": pmc.get("tag")}
 
     out = {
         "metric": ("V-cycles/sec on bfs3d SV P3-P2dg (DoF*smooths/sec in dof_smooths_per_s)" if CONFIGS[args.config][0] == "sv"
@@ -527,7 +534,7 @@ def main():
         "vcycle_algorithmic_GB": total_bytes / 1e9,
         "vcycle_hbm_frac_of_peak": total_bytes / 1e9 / (elapsed / args.steps) / HBM_PEAK_GBS,
         "roofline": {"kernel": "big_apply_kernel" if np.diff(L.patch_ptr).max() > 160 else "patch_apply_kernel", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                      "avg_launch_us": 1e3 * t_apply_ms / max(n_apply, 1), "launches": int(n_apply),
                      "bytes_per_launch_avg": bytes_apply_total / max(n_apply, 1),
                      "finest_level_GBps": finest_gbs, "finest_level_avg_launch_us": 1e3 * ms_f / max(cnt_f, 1)},

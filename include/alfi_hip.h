@@ -146,6 +146,13 @@ int alfi_residual(alfi_level* lvl, const double* db, const double* dx, double* d
 int alfi_patches_set(alfi_level* lvl, int64_t npatch, const int64_t* patch_ptr_host, const int32_t* patch_dofs_host);
 /* PCSetUp_PATCH with save_operators + dense_inverse (solver.py:320, 602): A_p = A[dofs_p, dofs_p], store inv(A_p). */
 int alfi_patches_factor(alfi_level* lvl);
+/* Every alfi_patches_factor ends with a residual probe of every stored inverse, rho_p = || A_p (X_p e) - e ||_inf with a
+ * fixed +-1 vector e, and re-inverts the patches with rho_p > 1e-6 (ALFI_PATCH_CHECK_TOL) -- or with a zero pivot -- by
+ * Gauss-Jordan with partial pivoting (the reference factors with pivoted LAPACK / UMFPACK LU, solver.py:599-602, 655-659;
+ * the fast kernels do not pivot).  ALFI_E_SINGULAR if a patch still fails afterwards.  This reports, for the last
+ * factorisation: the worst residual of the fast inversion, how many patches were flagged and repaired, and the worst
+ * residual after the repair (any pointer may be NULL; -1 = probe disabled with ALFI_PATCH_CHECK=0). */
+int alfi_patches_check(alfi_level* lvl, double* worst_residual, int64_t* flagged, int64_t* repaired, double* worst_after);
 /* PCApply_PATCH, additive, no partition of unity (solver.py:321-322): y = sum_p R_p^T inv(A_p) R_p x; y[bc] = x[bc].
  * x is not modified.  Deterministic (no atomics): patch results are staged and summed dof-wise in a fixed order. */
 int alfi_patch_apply(alfi_level* lvl, const double* dx, double* dy);
@@ -197,6 +204,9 @@ int alfi_transfer_create(alfi_ctx* ctx, alfi_level* coarse, alfi_level* fine, co
 int alfi_transfer_destroy(alfi_transfer* tr);
 /* (re)build the interior solves for new (nu, gamma): AutoSchoeberlTransfer.rebuild, transfer.py:173-184, 238-244 */
 int alfi_transfer_update(alfi_transfer* tr, double nu, double gamma);
+/* debugging / parity tests: the stored inverse of interior block blk (row-major m x m) copied to the host.  (Blocks with
+ * m > 32 are applied with one step of iterative refinement on top of this inverse.) */
+int alfi_transfer_get_block_inverse(alfi_transfer* tr, int64_t blk, double* out_host);
 /* prolong: fine = (I - E_I inv(A_II) E_I^T gamma D) P coarse   (transfer.py:246-259); fine Dirichlet dofs zeroed */
 int alfi_prolong(alfi_transfer* tr, const double* dxc, double* dxf);
 /* restrict: robust = 1: coarse = P^T (I - gamma D E_I inv(A_II) E_I^T) fine (transfer.py:261-275);

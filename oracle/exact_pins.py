@@ -1,0 +1,206 @@
+"""Exact (rational-arithmetic) derivation of the finite-element ingredients of the hot path, independent of alfi_amd.
+
+TEST INFRASTRUCTURE.  Nothing here imports the product (alfi_amd/) or the NumPy oracle: node sets, nodal bases, one
+element matrix and the nodal prolongation rows are re-derived from their definitions with SymPy / ``fractions`` so that a
+wrong basis function, node ordering, quadrature rule or transfer stencil in the product cannot pass both sides.
+
+What is derived, and from which lines of the reference (/root/reference/alfi):
+
+* velocity elements: ``VectorElement(NodalEnrichedElement(P_k, FacetBubble))`` for k < tdim, ``VectorElement(P_k)``
+  otherwise (solver.py:574-586), ``[P_k]^d`` for Scott-Vogelius (solver.py:625-630).  All dofs are point evaluations:
+  vertices, edge points, face barycentres (bubble.py:43-44, 64-80 hard-codes the change of basis this implies).  The nodal
+  basis is the dual basis of those point evaluations on span{P_k} + span{27 l_j l_k l_l}: solved exactly below.
+* the velocity-block form ``nu (2 sym grad u, grad v) + gamma (cell_avg(div u), div v)`` (solver.py:565-568,
+  transfer.py:319-324): one element matrix on a simplex with rational vertex coordinates, integrated exactly with
+  int_K l^alpha = |K| d! alpha! / (|alpha| + d)!.
+* nodal interpolation (firedrake.prolong [3P], transfer.py:284-286): row of a fine node = coarse basis at that node.  For
+  2-D P2 the values are {1, 3/8, 3/4, -1/8, 1/2, 1/4, 0} with at most 6 non-zeros per row.
+
+Consumers: tests/test_exact_pins.py (CPU) compares the product's tabulation, assembled element matrices and prolongation
+matrices -- and the NumPy oracle's quadrature assembly -- with these, matching nodes by POSITION, never by index.
+"""
+import itertools
+from fractions import Fraction
+from math import factorial
+
+import sympy as sp
+
+
+# -- polynomials in the barycentric coordinates: {exponent tuple: Fraction} -------------------------------------------------
+def p_add(a, b, sb=1):
+    out = dict(a)
+    for e, c in b.items():
+        v = out.get(e, 0) + sb * c
+        if v == 0:
+            out.pop(e, None)
+        else:
+            out[e] = v
+    return out
+
+
+def p_scale(a, s):
+    return {e: c * s for e, c in a.items()} if s != 0 else {}
+
+
+def p_mul(a, b):
+    out = {}
+    for ea, ca in a.items():
+        for eb, cb in b.items():
+            e = tuple(x + y for x, y in zip(ea, eb))
+            v = out.get(e, 0) + ca * cb
+            if v == 0:
+                out.pop(e, None)
+            else:
+                out[e] = v
+    return out
+
+
+def p_diff(a, i):
+    out = {}
+    for e, c in a.items():
+        if e[i] > 0:
+            f = list(e)
+            f[i] -= 1
+            out[tuple(f)] = out.get(tuple(f), 0) + c * e[i]
+    return out
+
+
+def p_eval(a, lam):
+    s = 0
+    for e, c in a.items():
+        t = c
+        for x, k in zip(lam, e):
+            if k:
+                t = t * x ** k
+        s = s + t
+    return s
+
+
+def p_average(a):
+    """Average over the simplex: int_K l^alpha / |K| = d! alpha! / (|alpha| + d)!  (d = number of coordinates - 1)."""
+    s = Fraction(0)
+    for e, c in a.items():
+        d = len(e) - 1
+        num = factorial(d)
+        for k in e:
+            num *= factorial(k)
+        s += c * Fraction(num, factorial(sum(e) + d))
+    return s
+
+
+# -- elements ------------------------------------------------------------------------------------------------------------------
+def element_nodes(dim, name):
+    """Barycentric coordinates (tuples of Fractions) of the point-evaluation dofs.  Order: vertices, edge points (edges as
+    sorted vertex pairs, points from the lower to the higher vertex), face barycentres -- consumers must match by position."""
+    nv = dim + 1
+    unit = lambda i: tuple(Fraction(int(j == i)) for j in range(nv))
+    nodes = [unit(i) for i in range(nv)]
+    degree = {"P1+FB": 1, "P2": 2, "P2+FB": 2, "P3": 3}[name]
+    for a, b in itertools.combinations(range(nv), 2):
+        for s in range(1, degree):
+            t = Fraction(s, degree)
+            nodes.append(tuple((1 - t) * x + t * y for x, y in zip(unit(a), unit(b))))
+    if name.endswith("+FB") or (name == "P3" and dim == 3):
+        assert dim == 3
+        for face in itertools.combinations(range(nv), 3):
+            nodes.append(tuple(Fraction(1, 3) if j in face else Fraction(0) for j in range(nv)))
+    if name == "P3" and dim == 2:
+        nodes.append(tuple(Fraction(1, 3) for _ in range(nv)))
+    return nodes
+
+
+def element_span(dim, name):
+    """A spanning set of the scalar space: homogeneous monomials of degree k in the barycentric coordinates (they span P_k on
+    the simplex because sum(l) = 1) plus, for '+FB', the facet bubbles 27 l_j l_k l_l of the four faces."""
+    nv = dim + 1
+    degree = {"P1+FB": 1, "P2": 2, "P2+FB": 2, "P3": 3}[name]
+    span = []
+    for combo in itertools.combinations_with_replacement(range(nv), degree):
+        e = [0] * nv
+        for i in combo:
+            e[i] += 1
+        span.append({tuple(e): Fraction(1)})
+    if name.endswith("+FB"):
+        for face in itertools.combinations(range(nv), 3):
+            span.append({tuple(int(j in face) for j in range(nv)): Fraction(27)})
+    return span
+
+
+def nodal_basis(dim, name):
+    """(nodes, basis): basis[a] is the polynomial with basis[a](nodes[b]) = delta_ab, obtained by inverting the generalised
+    Vandermonde matrix exactly (SymPy rationals)."""
+    nodes, span = element_nodes(dim, name), element_span(dim, name)
+    assert len(nodes) == len(span), (len(nodes), len(span))
+    V = sp.Matrix(len(nodes), len(span), lambda n, s: sp.Rational(*_frac(p_eval(span[s], nodes[n]))))
+    C = V.inv()                                   # C[s, a]: coefficient of span_s in basis_a
+    basis = []
+    for a in range(len(nodes)):
+        poly = {}
+        for s in range(len(span)):
+            c = Fraction(int(C[s, a].p), int(C[s, a].q))
+            poly = p_add(poly, p_scale(span[s], c))
+        basis.append(poly)
+    return nodes, basis
+
+
+def _frac(x):
+    x = Fraction(x)
+    return x.numerator, x.denominator
+
+
+# -- geometry --------------------------------------------------------------------------------------------------------------------
+def barycentric_gradients(vertices):
+    """vertices: (dim+1) points with rational coordinates.  Returns (grad l_i as lists of Fractions, |K|)."""
+    dim = len(vertices) - 1
+    M = sp.Matrix(dim + 1, dim + 1, lambda i, j: 1 if j == 0 else sp.Rational(*_frac(vertices[i][j - 1])))
+    Minv = M.inv()          # l_i(x) = Minv[0, i] + sum_x Minv[x + 1, i] * x_x
+    grads = [[Fraction(int(Minv[x + 1, i].p), int(Minv[x + 1, i].q)) for x in range(dim)] for i in range(dim + 1)]
+    det = M.det()
+    vol = abs(Fraction(int(det.p), int(det.q))) / factorial(dim)
+    return grads, vol
+
+
+def element_matrix(dim, name, vertices, nu, gamma):
+    """Exact element matrix of nu (2 sym grad u, grad v) + gamma (cell_avg(div u), div v) for the vector element [name]^dim
+    on the simplex ``vertices``.  Returns (nodes, A) with A[a][c][b][d] (Fractions): row dof = node a, component c."""
+    nodes, basis = nodal_basis(dim, name)
+    grads, vol = barycentric_gradients(vertices)
+    nu, gamma = Fraction(nu), Fraction(gamma)
+    n = len(nodes)
+    # physical partial derivatives d_x phi_a as polynomials in l
+    dphi = [[None] * dim for _ in range(n)]
+    for a in range(n):
+        dl = [p_diff(basis[a], i) for i in range(dim + 1)]
+        for x in range(dim):
+            acc = {}
+            for i in range(dim + 1):
+                acc = p_add(acc, p_scale(dl[i], grads[i][x]))
+            dphi[a][x] = acc
+    avg = [[p_average(dphi[a][x]) for x in range(dim)] for a in range(n)]
+    A = [[[[Fraction(0) for _ in range(dim)] for _ in range(n)] for _ in range(dim)] for _ in range(n)]
+    for a in range(n):
+        for b in range(n):
+            I = [[p_average(p_mul(dphi[a][x], dphi[b][y])) for y in range(dim)] for x in range(dim)]   # avg d_x phi_a d_y phi_b
+            gg = sum(I[x][x] for x in range(dim))
+            for c in range(dim):
+                for d in range(dim):
+                    v = nu * vol * ((gg if c == d else 0) + I[d][c]) + gamma * vol * avg[a][c] * avg[b][d]
+                    A[a][c][b][d] = v
+    return nodes, A
+
+
+def interpolation_row(dim, name, lam):
+    """Values of the nodal basis of ``name`` at the point with barycentric coordinates ``lam`` (floats or Fractions): the
+    row of the nodal prolongation matrix of a fine node located there.  Returns (nodes, values)."""
+    nodes, basis = nodal_basis(dim, name)
+    return nodes, [p_eval(b, lam) for b in basis]
+
+
+_CACHE = {}
+
+
+def cached_basis(dim, name):
+    key = (dim, name)
+    if key not in _CACHE:
+        _CACHE[key] = nodal_basis(dim, name)
+    return _CACHE[key]

@@ -56,6 +56,10 @@ def test_full_size_properties(name):
     S = L.A.to_scipy().tocsr() if name != "cfg4" else None
 
     # -- patch inverses ------------------------------------------------------------------------------------------------------
+    # ALL patches of every level passed the device-side residual probe || A_p X_p e - e || (alfi_patches_check)
+    for dlev in mg.levels[1:]:
+        worst, flagged, repaired, after = dlev.patch_check()
+        assert 0.0 <= worst < 1e-6 and flagged == repaired, (name, worst, flagged, repaired)
     npatch = len(L.patch_ptr) - 1
     for p in rng.choice(npatch, 6, replace=False):
         dofs = L.patch_dofs[L.patch_ptr[p]:L.patch_ptr[p + 1]]

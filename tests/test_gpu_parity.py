@@ -488,3 +488,70 @@ def test_cycles_replayed_as_hip_graphs(ctx, composition):
     finally:
         ctx.set_graph(False)
         mg.close()
+
+
+def test_cycle_logic_with_the_device_inverses(ctx, setup):
+    """Separates inversion rounding from cycle logic: the oracle gets the DEVICE's patch inverses (alfi_patch_get_inverse)
+    and interior-block inverses (alfi_transfer_get_block_inverse) in place of its LAPACK ones; what is left to differ is
+    the order of floating-point sums.  Smoother, transfers, V- and F-cycle then agree to 1e-10 -- against CYCLE_TOL = 1e-5
+    with independently inverted patches -- so a wrong Givens rotation, Hessenberg column, restriction or coarse correction
+    cannot hide inside the inversion tolerance."""
+    from oracle import alfi_oracle as O
+    lv, k = setup["lv"], setup["k"]
+    dmg = setup["dmg"][True]
+    omg = O.build_oracle_mg(lv, setup["tr"], k, schoeberl_restriction=True)     # a private copy to modify
+    for L, dl, ol in list(zip(lv, dmg.levels, omg.levels))[1:]:
+        n = np.diff(L.patch_ptr)
+        ol["smoother"].inv = [dl.patch_inverse(p, int(n[p])) for p in range(len(n))]
+    for dt, ot in zip(dmg.transfers, omg.transfers):
+        m = ot.st.blk_dofs.shape[1]
+        binv = [dt.block_inverse(b, m) for b in range(ot.st.blk_dofs.shape[0])]
+        # the oracle solves with LU factors; feed it exact "LU factors" of the device inverse's action instead
+        ot.st.lu = None
+        ot.st._binv = binv
+
+        def patch_apply(x, st=ot.st):
+            y = np.zeros_like(x)
+            for d, X in zip(st.blk_dofs, st._binv):
+                y[d] = X @ x[d]
+            y[st.skel] = x[st.skel]
+            return y
+        ot.st._patch_apply = patch_apply
+    # the coarse solve: the explicit inverse the device multiplies with (hip.coarse_inverse), not the oracle's sparse LU
+    from alfi_amd import hip
+    Cinv = hip.coarse_inverse(lv[0].A)
+
+    class _Coarse(object):
+        @staticmethod
+        def solve(v):
+            return Cinv @ v
+    omg.coarse_lu = _Coarse()
+    tol = 1e-10
+    L, dl, ol = lv[-1], dmg.levels[-1], omg.levels[-1]
+    b, x0 = rhs(L.n, L.bc_dofs, 21), rhs(L.n, L.bc_dofs, 22)
+    dx, db = ctx.vec(x0), ctx.vec(b)
+    dl.smooth(k, db, dx, nonzero_guess=True)
+    ref = O.fgmres(lambda v: ol["A"] @ v, ol["smoother"].apply, b, x0, k)
+    assert relerr(dx.get(), ref) < tol
+    for i, (dt, ot) in enumerate(zip(dmg.transfers, omg.transfers)):
+        Lc, Lf = lv[i], lv[i + 1]
+        xc, rf = rhs(Lc.n, Lc.bc_dofs, 23), rhs(Lf.n, [], 24)
+        dxc, dxf, drf, drc = ctx.vec(xc), ctx.vec(Lf.n), ctx.vec(rf), ctx.vec(Lc.n)
+        dt.prolong(dxc, dxf)
+        r = ot.st.prolong(xc)
+        r[Lf.bc_dofs] = 0
+        assert relerr(dxf.get(), r) < tol
+        dt.restrict(drf, drc, robust=True)
+        r = ot.st.restrict(rf)
+        r[Lc.bc_dofs] = 0
+        assert relerr(drc.get(), r) < tol
+    b = rhs(L.n, L.bc_dofs, 25)
+    db, dx = ctx.vec(b), ctx.vec(L.n)
+    dmg.vcycle(db, dx)
+    ref = omg.vcycle(len(lv) - 1, b, np.zeros(L.n))
+    assert relerr(dx.get(), ref) < tol
+    dmg.vcycle(db, dx)
+    ref = omg.vcycle(len(lv) - 1, b, ref)
+    assert relerr(dx.get(), ref) < tol
+    dmg.fcycle(db, dx)
+    assert relerr(dx.get(), omg.fcycle(b)) < tol

@@ -169,3 +169,36 @@ def test_bubble_transfer_through_reference_kernels(ref):
     gotr = restrict_with_reference_kernels(ref, Vc, Vf, rf)
     matr = T.PT.to_scipy() @ rf
     assert np.abs(gotr - matr).max() < 1e-13 * np.abs(gotr).max()
+
+
+@pytest.mark.gpu
+def test_hip_prolong_and_restrict_against_reference_kernels(ref):
+    """The device path directly against the reference's own C kernels: alfi_prolong / alfi_restrict with gamma = 0 (then
+    the Schoeberl correction vanishes, transfer.py:259 / :274, and what is left is BubbleTransfer.prolong / .restrict,
+    bubble.py:204-265) on ldc3d [P1+FB]^3, compared with the cell-by-cell evaluation through the reference kernels."""
+    from alfi_amd import hip
+    lv, tr = build_hierarchy(ThreeDimLidDrivenCavityProblem(2), 1, 1, Re=10.0)
+    Vc, Vf, T = lv[0].V, lv[1].V, tr[0]
+    ctx = hip.Context(0)
+    dc, df = hip.Level(ctx, lv[0].A, lv[0].bc_dofs), hip.Level(ctx, lv[1].A, lv[1].bc_dofs)
+    dt = hip.Transfer(ctx, dc, df, T)
+    dt.update(T.nu, 0.0)
+    rng = np.random.default_rng(2)
+    uc = rng.standard_normal(Vc.num_dofs)
+    want = prolong_with_reference_kernels(ref, Vc, Vf, uc)
+    want[lv[1].bc_dofs] = 0.0                                  # alfi_prolong zeroes the fine Dirichlet dofs
+    xc, xf = ctx.vec(uc), ctx.vec(Vf.num_dofs)
+    dt.prolong(xc, xf)
+    got = xf.get()
+    assert np.abs(got - want).max() < 1e-13 * np.abs(want).max()
+    rf = rng.standard_normal(Vf.num_dofs)
+    wantr = restrict_with_reference_kernels(ref, Vc, Vf, rf.copy())
+    wantr[lv[0].bc_dofs] = 0.0
+    yf, yc = ctx.vec(rf), ctx.vec(Vc.num_dofs)
+    dt.restrict(yf, yc, robust=True)
+    gotr = yc.get()
+    assert np.abs(gotr - wantr).max() < 1e-13 * np.abs(wantr).max()
+    dt.close()
+    dc.close()
+    df.close()
+    ctx.close()
