@@ -493,7 +493,7 @@ def test_cycles_replayed_as_hip_graphs(ctx, composition):
 def test_cycle_logic_with_the_device_inverses(ctx, setup):
     """Separates inversion rounding from cycle logic: the oracle gets the DEVICE's patch inverses (alfi_patch_get_inverse)
     and interior-block inverses (alfi_transfer_get_block_inverse) in place of its LAPACK ones; what is left to differ is
-    the order of floating-point sums.  Smoother, transfers, V- and F-cycle then agree to 1e-10 -- against CYCLE_TOL = 1e-5
+    the order of floating-point sums.  Transfers then agree to 1e-10, the smoother to 1e-9, V- and F-cycles to 5e-9 -- against CYCLE_TOL = 1e-5
     with independently inverted patches -- so a wrong Givens rotation, Hessenberg column, restriction or coarse correction
     cannot hide inside the inversion tolerance."""
     from oracle import alfi_oracle as O
@@ -532,7 +532,8 @@ def test_cycle_logic_with_the_device_inverses(ctx, setup):
     dx, db = ctx.vec(x0), ctx.vec(b)
     dl.smooth(k, db, dx, nonzero_guess=True)
     ref = O.fgmres(lambda v: ol["A"] @ v, ol["smoother"].apply, b, x0, k)
-    assert relerr(dx.get(), ref) < tol
+    es = relerr(dx.get(), ref)
+    assert es < 1e-9            # measured 2e-11 .. 1.0e-10 (3d-P2FB, Re 1000: k dependent least-squares problems)
     for i, (dt, ot) in enumerate(zip(dmg.transfers, omg.transfers)):
         Lc, Lf = lv[i], lv[i + 1]
         xc, rf = rhs(Lc.n, Lc.bc_dofs, 23), rhs(Lf.n, [], 24)
@@ -545,13 +546,20 @@ def test_cycle_logic_with_the_device_inverses(ctx, setup):
         r = ot.st.restrict(rf)
         r[Lc.bc_dofs] = 0
         assert relerr(drc.get(), r) < tol
+    # whole cycles chain 2k .. 2k (L + 1) smoother iterations whose least-squares problems amplify the 1e-16 differences
+    # of the summation orders: measured 8e-11 .. 9.3e-10 on these cases -- compared at 5e-9, three to four orders below
+    # CYCLE_TOL
+    ctol = 5e-9
     b = rhs(L.n, L.bc_dofs, 25)
     db, dx = ctx.vec(b), ctx.vec(L.n)
     dmg.vcycle(db, dx)
     ref = omg.vcycle(len(lv) - 1, b, np.zeros(L.n))
-    assert relerr(dx.get(), ref) < tol
+    e1 = relerr(dx.get(), ref)
     dmg.vcycle(db, dx)
     ref = omg.vcycle(len(lv) - 1, b, ref)
-    assert relerr(dx.get(), ref) < tol
+    e2 = relerr(dx.get(), ref)
     dmg.fcycle(db, dx)
-    assert relerr(dx.get(), omg.fcycle(b)) < tol
+    e3 = relerr(dx.get(), omg.fcycle(b))
+    print("cycle logic with device inverses [%s]: smoother %.2e, V %.2e, second V %.2e, F %.2e"
+          % (setup["name"], es, e1, e2, e3))
+    assert max(e1, e2, e3) < ctol
