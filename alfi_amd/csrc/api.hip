@@ -63,6 +63,53 @@ static void dev_free(void* p) {
   if (p) (void)hipFree(p);
 }
 
+// Chunk tables of the flat layout.  Large matrices: equal chunks of SPMV_CHUNK blocks (rows may continue into the next
+// chunk; the fix-up launch completes them).  Small ones (nnzb <= SPMV_ALIGNED_MAX, no row longer than a chunk, unless
+// ALFI_SPMV_ALIGNED=0): chunks of whole block rows, greedily packed, so the product is ONE launch.  break_row >= 0: a chunk
+// boundary is forced in front of that block row (the owned prefix of a partitioned level); returns the number of chunks
+// before it in *nchunks_before.
+static int build_chunk_tables(alfi_ctx* ctx, DevBSR* d, const int32_t* rowptr, int64_t nbrows, int64_t break_row,
+                              int64_t* nchunks_before = nullptr) {
+  dev_free(d->chunk_row);
+  dev_free(d->chunk_start);
+  d->chunk_row = nullptr;
+  d->chunk_start = nullptr;
+  static const bool allow = !(getenv("ALFI_SPMV_ALIGNED") && atoi(getenv("ALFI_SPMV_ALIGNED")) == 0);
+  bool aligned = allow && d->nnzb <= SPMV_ALIGNED_MAX;
+  for (int64_t i = 0; i < nbrows && aligned; ++i) aligned = rowptr[i + 1] - rowptr[i] <= SPMV_CHUNK;
+  d->aligned = aligned;
+  if (!aligned) {
+    d->nchunks = (d->nnzb + SPMV_CHUNK - 1) / SPMV_CHUNK;
+    std::vector<int32_t> chunk_row(d->nchunks);
+    int64_t row = 0;
+    for (int64_t c = 0; c < d->nchunks; ++c) {
+      const int64_t k = c * SPMV_CHUNK;
+      while (rowptr[row + 1] <= k) ++row;
+      chunk_row[c] = (int32_t)row;
+    }
+    ALFI_CHECK(dev_upload(ctx, &d->chunk_row, chunk_row.data(), d->nchunks));
+    if (nchunks_before) *nchunks_before = -1;
+    return 0;
+  }
+  std::vector<int64_t> start;
+  std::vector<int32_t> chunk_row;
+  int64_t i = 0;
+  while (i < nbrows) {
+    start.push_back(rowptr[i]);
+    chunk_row.push_back((int32_t)i);
+    if (nchunks_before && i == break_row) *nchunks_before = (int64_t)start.size() - 1;
+    int64_t e = i;
+    while (e < nbrows && rowptr[e + 1] - rowptr[i] <= SPMV_CHUNK && (e == i || e != break_row)) ++e;
+    i = e;
+  }
+  if (nchunks_before && break_row >= nbrows) *nchunks_before = (int64_t)start.size();
+  start.push_back(rowptr[nbrows]);
+  d->nchunks = (int64_t)chunk_row.size();
+  ALFI_CHECK(dev_upload(ctx, &d->chunk_row, chunk_row.data(), d->nchunks));
+  ALFI_CHECK(dev_upload(ctx, &d->chunk_start, start.data(), d->nchunks + 1));
+  return 0;
+}
+
 static int upload_bsr(alfi_ctx* ctx, DevBSR* d, const alfi_bsr_host* h, int bs) {
   d->nbrows = h->nbrows;
   d->nbcols = h->nbcols;
@@ -82,16 +129,8 @@ static int upload_bsr(alfi_ctx* ctx, DevBSR* d, const alfi_bsr_host* h, int bs) 
   } else {
     std::vector<int32_t> cf(h->colidx, h->colidx + d->nnzb);
     for (int64_t i = 0; i < h->nbrows; ++i) cf[h->rowptr[i]] |= (int32_t)0x80000000;
-    d->nchunks = (d->nnzb + SPMV_CHUNK - 1) / SPMV_CHUNK;
-    std::vector<int32_t> chunk_row(d->nchunks);
-    int64_t row = 0;
-    for (int64_t c = 0; c < d->nchunks; ++c) {
-      const int64_t k = c * SPMV_CHUNK;
-      while (h->rowptr[row + 1] <= k) ++row;
-      chunk_row[c] = (int32_t)row;
-    }
     ALFI_CHECK(dev_upload(ctx, &d->colidx, cf.data(), d->nnzb));
-    ALFI_CHECK(dev_upload(ctx, &d->chunk_row, chunk_row.data(), d->nchunks));
+    ALFI_CHECK(build_chunk_tables(ctx, d, h->rowptr, h->nbrows, -1));
     ALFI_CHECK(dev_alloc(ctx, &d->carry, d->nchunks * bs));
     ALFI_CHECK(dev_alloc(ctx, &d->carry_row, d->nchunks));
     const int64_t padded = ((d->nnzb + 63) / 64) * 64 * bs * bs;
@@ -107,6 +146,7 @@ static void free_bsr(DevBSR* d) {
   dev_free(d->colidx);
   dev_free(d->vals);
   dev_free(d->chunk_row);
+  dev_free(d->chunk_start);
   dev_free(d->carry);
   dev_free(d->carry_row);
   *d = DevBSR();
@@ -228,7 +268,8 @@ int alfi_ctx_create(int device, void* stream, alfi_ctx** out) {
     }
     ctx->own_stream = true;
   }
-  if (hipMalloc((void**)&ctx->red_partial, sizeof(double) * RED_BLOCKS * RED_MAXV) != hipSuccess) {
+  if (hipMalloc((void**)&ctx->red_partial, sizeof(double) * RED_BLOCKS * RED_MAXV) != hipSuccess ||
+      hipMalloc((void**)&ctx->red_partial2, sizeof(double) * RED_BLOCKS * RED_MAXV) != hipSuccess) {
     delete ctx;
     return alfi_set_error(nullptr, ALFI_E_HIP, "hipMalloc failed");
   }
@@ -245,6 +286,7 @@ int alfi_ctx_destroy(alfi_ctx* ctx) {
     (void)hipEventDestroy(p.b);
   }
   dev_free(ctx->red_partial);
+  dev_free(ctx->red_partial2);
   (void)hipFree(ctx->big_arena);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
@@ -414,11 +456,19 @@ int alfi_level_set_partition(alfi_level* L, int64_t nb_owned, int distributed, i
   L->has_halo = true;
   L->distributed = distributed != 0;
   L->n_own = nb_owned * L->bs;
-  L->A_own = L->A;
-  L->A_own.nbrows = nb_owned;
   int32_t nnz_own = 0;
   ALFI_HIP_CHECK(ctx, hipMemcpy(&nnz_own, L->A.rowptr + nb_owned, sizeof(int32_t), hipMemcpyDeviceToHost));
+  int64_t nchunks_own = -1;
+  if (L->A.aligned) {      // whole-row chunks: a chunk boundary in front of the first ghost row
+    const int64_t nb = L->A.nbrows;
+    std::vector<int32_t> rp(nb + 1);
+    ALFI_HIP_CHECK(ctx, hipMemcpy(rp.data(), L->A.rowptr, sizeof(int32_t) * (nb + 1), hipMemcpyDeviceToHost));
+    ALFI_CHECK(build_chunk_tables(ctx, &L->A, rp.data(), nb, nb_owned, &nchunks_own));
+  }
+  L->A_own = L->A;
+  L->A_own.nbrows = nb_owned;
   L->A_own.nnzb = nnz_own;
+  if (L->A.aligned) L->A_own.nchunks = nchunks_own;
   return 0;
 }
 
@@ -427,6 +477,8 @@ static int make_row_view(alfi_ctx* ctx, const DevBSR& A, const std::vector<int32
                          DevBSR* V) {
   *V = A;
   V->view = true;
+  V->aligned = false;                   // a view brings its own equal-sized chunks (+ fix-up)
+  V->chunk_start = nullptr;
   V->nbrows = r1;                       // rows are addressed absolutely; nbrows only has to cover the range
   V->kbase = rowptr[r0];
   V->nnzb = rowptr[r1] - rowptr[r0];
@@ -725,12 +777,14 @@ int alfi_patches_set_multiplicative(alfi_level* L, int64_t nit, const int64_t* i
   // PCPATCH does under MPI: local Gauss-Seidel, additive between ranks [3P]
   if (nit > INT32_MAX) return alfi_set_error(ctx, ALFI_E_ARG, "iteration set too long");
   const int bs = L->bs;
-  // patches must be unions of whole nodes (the sweep works on block rows)
+  // patches must be unions of whole nodes (the sweep works on block rows); up to 64 nodes and 160 dofs a wave sweeps a
+  // patch, beyond (macro stars) a workgroup does
+  L->mult_big = L->max_np > SMALL_PATCH_MAX;
   for (int64_t p = 0; p < L->npatch; ++p) {
     const int64_t a = L->h_patch_ptr[p], b = L->h_patch_ptr[p + 1];
-    if ((b - a) % bs != 0 || (b - a) / bs > 64)
-      return alfi_set_error(ctx, ALFI_E_ARG, "patch %lld: multiplicative sweeps need whole nodes, at most 64 per patch",
-                            (long long)p);
+    if ((b - a) / bs > 64) L->mult_big = true;
+    if ((b - a) % bs != 0)
+      return alfi_set_error(ctx, ALFI_E_ARG, "patch %lld: multiplicative sweeps need patches of whole nodes", (long long)p);
     for (int64_t q = a; q < b; ++q)
       if (L->h_patch_dofs[q] != (L->h_patch_dofs[a + ((q - a) / bs) * bs] / bs) * bs + (int32_t)((q - a) % bs))
         return alfi_set_error(ctx, ALFI_E_ARG, "patch %lld does not consist of whole nodes", (long long)p);
@@ -893,37 +947,45 @@ int alfi_smooth_fgmres(alfi_level* L, int k, const double* db, double* dx, int n
     ALFI_CHECK(launch_copy(ctx, w, db, n));
     alfi_prof_end(ctx, t);
   }
+  // reductions: red_blocks_for(n) partials per vector.  Up to 256 of them (levels of <= 1 M dofs, where a smoother
+  // iteration is a chain of launches of a few microseconds each) the kernel that needs a reduced value sums the partials
+  // itself -- every block in the same fixed order -- instead of waiting for a one-block reduction launch.
+  const int G = red_blocks_for(n);
+  static const bool allow_fused = !(getenv("ALFI_FUSED_REDUCE") && atoi(getenv("ALFI_FUSED_REDUCE")) == 0);   // A/B switch
+  const bool fused = allow_fused && !par && G <= 256 && k + 1 <= 16;
   t = alfi_prof_begin(ctx, ALFI_EV_BLAS1);
   ALFI_CHECK(launch_norm_partials(ctx, w, n));
-  if (par) ALFI_CHECK(launch_reduce_partials(ctx, 1, nrm2));
+  if (par) ALFI_CHECK(launch_reduce_partials(ctx, ctx->red_partial, G, 1, nrm2));
   alfi_prof_end(ctx, t);
   if (par) ALFI_CHECK(comm_allreduce(L, RED_MAXV, 1));
   t = alfi_prof_begin(ctx, ALFI_EV_BLAS1);
-  ALFI_CHECK(launch_norm_init_finish(ctx, par ? nrm2 : ctx->red_partial, par ? 1 : RED_BLOCKS, hs, K));
+  ALFI_CHECK(launch_norm_init_finish(ctx, par ? nrm2 : ctx->red_partial, par ? 1 : G, hs, K));
   ALFI_CHECK(launch_scale_by_inv(ctx, V, w, hs + hl.beta, n));
   alfi_prof_end(ctx, t);
   for (int j = 0; j < k; ++j) {
     ALFI_CHECK(level_patch_apply(L, V + (int64_t)j * ldv, Z + (int64_t)j * ldv));   // z_j = M^-1 v_j
     ALFI_CHECK(alfi_spmv(L, Z + (int64_t)j * ldv, w));                               // w = A z_j
     t = alfi_prof_begin(ctx, ALFI_EV_BLAS1);
-    ALFI_CHECK(launch_multi_dot(ctx, V, ldv, j + 1, w, hdots, n));                   // h = V^T w (classical GS)
+    // h = V^T w (classical GS); fused: the partials stay in red_partial and the projection kernel sums them
+    ALFI_CHECK(launch_multi_dot(ctx, V, ldv, j + 1, w, fused ? nullptr : hdots, n));
     // partitioned: |w|^2 rides along in the same all-reduce; |w - V h|^2 = |w|^2 - |h|^2 then needs no second one
     const bool pyth = par && !ctx->exact_norm;
     const double* ww = pyth ? hdots + (j + 1) : nullptr;
     if (pyth) {
       ALFI_CHECK(launch_norm_partials(ctx, w, n));
-      ALFI_CHECK(launch_reduce_partials(ctx, 1, hdots + (j + 1)));
+      ALFI_CHECK(launch_reduce_partials(ctx, ctx->red_partial, G, 1, hdots + (j + 1)));
     }
     alfi_prof_end(ctx, t);
     if (par) ALFI_CHECK(comm_allreduce(L, 0, pyth ? j + 2 : j + 1));
     t = alfi_prof_begin(ctx, ALFI_EV_BLAS1);
-    ALFI_CHECK(launch_multi_axpy_norm(ctx, V, ldv, j + 1, hdots, w, n));             // w -= V h, |w|^2 partials
-    if (par && !pyth) ALFI_CHECK(launch_reduce_partials(ctx, 1, nrm2));
+    // w -= V h, |w|^2 partials (into the second partial buffer: the dot partials are still being read)
+    ALFI_CHECK(launch_multi_axpy_norm(ctx, V, ldv, j + 1, hdots, w, n, ctx->red_partial2, fused ? G : 0));
+    if (par && !pyth) ALFI_CHECK(launch_reduce_partials(ctx, ctx->red_partial2, G, 1, nrm2));
     alfi_prof_end(ctx, t);
     if (par && !pyth) ALFI_CHECK(comm_allreduce(L, RED_MAXV, 1));
     t = alfi_prof_begin(ctx, ALFI_EV_BLAS1);
-    const double* part = par ? nrm2 : ctx->red_partial;
-    const int nblk = par ? 1 : RED_BLOCKS;
+    const double* part = par ? nrm2 : ctx->red_partial2;
+    const int nblk = par ? 1 : G;
     if (j + 1 < k)   // Hessenberg column + v_{j+1} = w / |w| in one launch
       ALFI_CHECK(launch_hessenberg_scale(ctx, part, nblk, hdots, hs, j, K, V + (int64_t)(j + 1) * ldv, w, n, ww));
     else
@@ -950,6 +1012,74 @@ int alfi_coarse_set_inverse(alfi_level* L, const double* inv, int inv_is_device)
     ALFI_CHECK(dev_upload(ctx, &L->cinv, inv, L->n * L->n));
     L->cinv_owned = true;
   }
+  return 0;
+}
+
+// +-1 pattern for the residual probe of the coarse inverse
+static void probe_vector(std::vector<double>* e) {
+  uint32_t h = 12345u;
+  for (double& v : *e) {
+    h = h * 1664525u + 1013904223u;
+    v = (h >> 16) & 1u ? 1.0 : -1.0;
+  }
+}
+
+int alfi_coarse_factor(alfi_level* L) {
+  alfi_ctx* ctx = L->ctx;
+  if (L->has_halo && L->n_own != L->n)
+    return alfi_set_error(ctx, ALFI_E_STATE, "alfi_coarse_factor needs a level owned by one rank");
+  if (L->n > ((int64_t)1 << 17)) return alfi_set_error(ctx, ALFI_E_ARG, "coarse level of %lld dofs: the dense inverse would "
+                                                      "take %.0f GB", (long long)L->n, 8e-9 * (double)L->n * (double)L->n);
+  ALFI_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  ALFI_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  if (L->cinv_owned) dev_free(L->cinv);
+  L->cinv = nullptr;
+  L->cinv_owned = false;
+  double* inv = nullptr;
+  ALFI_CHECK(dev_alloc(ctx, &inv, L->n * L->n));
+  ALFI_HIP_CHECK(ctx, hipMemsetAsync(L->status, 0, sizeof(int), ctx->stream));
+  int rc = launch_coarse_factor(L, inv);
+  int st = 0;
+  if (rc == 0 && hipMemcpy(&st, L->status, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) rc = ALFI_E_HIP;
+  if (rc == 0 && st != 0) rc = alfi_set_error(ctx, ALFI_E_SINGULAR, "zero pivot block while inverting the coarse operator");
+  // residual probe: || A (X e) - e ||_inf for a +-1 vector e
+  if (rc == 0) {
+    std::vector<double> e((size_t)L->n), r((size_t)L->n);
+    probe_vector(&e);
+    double *de = nullptr, *dy = nullptr, *dr = nullptr;
+    rc = dev_upload(ctx, &de, e.data(), L->n);
+    if (rc == 0) rc = dev_alloc(ctx, &dy, L->n);
+    if (rc == 0) rc = dev_alloc(ctx, &dr, L->n);
+    if (rc == 0) rc = launch_dense_gemv(ctx, inv, de, dy, L->n);
+    if (rc == 0) rc = launch_bsr_spmv(ctx, L->A, dy, dr, nullptr, 1.0, 0);
+    if (rc == 0 && hipMemcpyAsync(r.data(), dr, sizeof(double) * L->n, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) rc = ALFI_E_HIP;
+    if (rc == 0 && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = ALFI_E_HIP;
+    dev_free(de);
+    dev_free(dy);
+    dev_free(dr);
+    if (rc == 0) {
+      double worst = 0.0;
+      for (int64_t i = 0; i < L->n; ++i) {
+        const double d = std::fabs(r[i] - e[i]);
+        if (!(d <= worst)) worst = d == d ? d : INFINITY;
+      }
+      L->cinv_residual = worst;
+      if (!(worst <= 1e-6))
+        rc = alfi_set_error(ctx, ALFI_E_SINGULAR, "coarse inverse fails the residual probe: || A X e - e || = %.3e", worst);
+    }
+  }
+  if (rc != 0) {
+    dev_free(inv);
+    return rc;
+  }
+  L->cinv = inv;
+  L->cinv_owned = true;
+  return 0;
+}
+
+int alfi_coarse_residual(alfi_level* L, double* worst) {
+  if (!L->cinv) return alfi_set_error(L->ctx, ALFI_E_STATE, "no coarse inverse");
+  *worst = L->cinv_residual;
   return 0;
 }
 
@@ -1563,7 +1693,7 @@ int alfi_saddle_solve(alfi_saddle* S, const double* db, double* dx, double rtol,
   // r = b (zero initial guess)
   ALFI_CHECK(launch_copy(ctx, w, db, n));
   ALFI_CHECK(launch_norm_partials(ctx, w, n));
-  ALFI_CHECK(launch_norm_init_finish(ctx, ctx->red_partial, RED_BLOCKS, hs, K));
+  ALFI_CHECK(launch_norm_init_finish(ctx, ctx->red_partial, red_blocks_for(n), hs, K));
   ALFI_CHECK(read(hs + hl.beta, &bnorm));
   rnorm = bnorm;
   const double tol = std::max(rtol * bnorm, atol);
@@ -1576,8 +1706,8 @@ int alfi_saddle_solve(alfi_saddle* S, const double* db, double* dx, double rtol,
       ALFI_CHECK(alfi_saddle_precond(S, V + (int64_t)j * n, zj));            // z_j = P^-1 v_j
       ALFI_CHECK(alfi_saddle_mult(S, zj, w));                               // w = K z_j
       ALFI_CHECK(launch_multi_dot(ctx, V, n, j + 1, w, hs + hl.hd, n));
-      ALFI_CHECK(launch_multi_axpy_norm(ctx, V, n, j + 1, hs + hl.hd, w, n));
-      ALFI_CHECK(launch_hessenberg_update(ctx, ctx->red_partial, RED_BLOCKS, hs + hl.hd, hs, j, K, nullptr));
+      ALFI_CHECK(launch_multi_axpy_norm(ctx, V, n, j + 1, hs + hl.hd, w, n, ctx->red_partial2, 0));
+      ALFI_CHECK(launch_hessenberg_update(ctx, ctx->red_partial2, red_blocks_for(n), hs + hl.hd, hs, j, K, nullptr));
       ++its;
       double g = 0.0;
       ALFI_CHECK(read(hs + hl.grs + j + 1, &g));                            // |rotated rhs| = residual norm estimate
@@ -1596,7 +1726,7 @@ int alfi_saddle_solve(alfi_saddle* S, const double* db, double* dx, double rtol,
     ALFI_CHECK(alfi_saddle_mult(S, dx, w));
     ALFI_CHECK(launch_xmy(ctx, w, db, n));                                   // w = b - K x
     ALFI_CHECK(launch_norm_partials(ctx, w, n));
-    ALFI_CHECK(launch_norm_init_finish(ctx, ctx->red_partial, RED_BLOCKS, hs, K));
+    ALFI_CHECK(launch_norm_init_finish(ctx, ctx->red_partial, red_blocks_for(n), hs, K));
     ALFI_CHECK(read(hs + hl.beta, &rnorm));
     converged = rnorm <= tol;
   }
@@ -1604,7 +1734,7 @@ int alfi_saddle_solve(alfi_saddle* S, const double* db, double* dx, double rtol,
   ALFI_CHECK(alfi_saddle_mult(S, dx, w));
   ALFI_CHECK(launch_xmy(ctx, w, db, n));
   ALFI_CHECK(launch_norm_partials(ctx, w, n));
-  ALFI_CHECK(launch_norm_init_finish(ctx, ctx->red_partial, RED_BLOCKS, hs, K));
+  ALFI_CHECK(launch_norm_init_finish(ctx, ctx->red_partial, red_blocks_for(n), hs, K));
   double tn = 0.0;
   ALFI_CHECK(read(hs + hl.beta, &tn));
   if (iterations) *iterations = its;

@@ -28,6 +28,7 @@ struct alfi_ctx {
   int next_level_id = 0;
   // scratch for reductions: partial sums [RED_BLOCKS][RED_MAXV]
   double* red_partial = nullptr;
+  double* red_partial2 = nullptr;   // second set (|w|^2 partials written while the dot partials are still being read)
   // mesh-partition parallelism (alfi_ctx_set_comm)
   alfi_comm_fn comm = nullptr;
   void* comm_user = nullptr;
@@ -123,7 +124,12 @@ struct DevBSR {
   int32_t* chunk_row = nullptr;
   double* carry = nullptr;      // (nchunks, bs): partial sums of block rows that continue into the next chunk
   int32_t* carry_row = nullptr;  // (nchunks): that block row, or -1
+  // small matrices (nnzb <= SPMV_ALIGNED_MAX): chunks of whole block rows, chunk c = blocks [chunk_start[c], chunk_start[c+1])
+  bool aligned = false;
+  int64_t* chunk_start = nullptr;   // (nchunks + 1)
 };
+constexpr int64_t SPMV_ALIGNED_MAX = (int64_t)1 << 21;   // blocks; beyond, the product is bandwidth-bound and equal-sized
+                                                          // chunks (+ the fix-up launch) keep every lane busy
 __host__ __device__ inline int64_t bsr_val_index(int flat, int64_t k, int rc, int bb) {
   if (!flat) return k * bb + rc;
   const int64_t g = (k >> 6) * 64 * bb;
@@ -182,6 +188,7 @@ struct alfi_level {
   int64_t chk_flagged = 0, chk_repaired = 0;
   // multiplicative sweeps: positions of the iteration sequence grouped into dependency wavefronts
   bool mult = false, mult_symmetrise = false;
+  bool mult_big = false;                // a patch holds more than 64 nodes: workgroup-per-patch sweep kernel
   int32_t* mult_seq = nullptr;          // (nit) patch ids, wavefront-major
   std::vector<int64_t> mult_wave_ptr;   // (nwave+1) offsets into mult_seq
   std::vector<int32_t> h_patch_dofs;    // host copy of the patch dofs (needed to build the wavefronts)
@@ -194,6 +201,7 @@ struct alfi_level {
   // coarse dense inverse
   double* cinv = nullptr;
   bool cinv_owned = false;
+  double cinv_residual = -1.0;    // || A X e - e ||_inf of the inverse built by alfi_coarse_factor (-1: supplied by the caller)
   // multigrid work vectors (owned by alfi_mg but stored per level)
   double *mg_b = nullptr, *mg_x = nullptr, *mg_r = nullptr;
   std::vector<int64_t> h_patch_ptr;  // host copy (for get_inverse)
@@ -290,11 +298,14 @@ int launch_big_factor_transfer(alfi_transfer* tr);                              
 int launch_big_apply_arrays(alfi_ctx* ctx, int64_t npatch, int max_np, const int64_t* patch_ptr,
                             const int32_t* patch_dofs, const int64_t* inv_ptr, const int64_t* stage_ptr, const double* inv,
                             const double* x, double* stage);
+int launch_coarse_factor(alfi_level* lvl, double* out);                                   // dense inverse of the whole level operator
 int launch_big_factor(alfi_level* lvl);                                                    // gather + blocked MFMA inversion
 int launch_patch_sum(alfi_level* lvl, const double* x, double* y);             // stage 2
 int launch_patch_sum_range(alfi_level* lvl, int64_t i0, int64_t i1, const double* x, double* y);   // stage 2, dofs [i0, i1)
 // one dependency wavefront of a multiplicative sweep: patches seq[0..count): y_p += inv(A_p) (x - A y)_p
 int launch_patch_mult_wave(alfi_level* lvl, const int32_t* seq, int64_t count, const double* x, double* y);
+// the same with a workgroup per patch: patches of more than 64 nodes (macro stars)
+int launch_big_mult_wave(alfi_level* lvl, const int32_t* seq, int64_t count, const double* x, double* y);
 int launch_invert_small_any(alfi_ctx* ctx, int nmax, int64_t nmat, const int64_t* ptr, const int64_t* inv_ptr,
                             int fixed_n, int64_t fixed_stride, double* inv, int* status);
 int launch_block_build_invert(alfi_transfer* tr);
@@ -307,10 +318,11 @@ int launch_dense_gemv(alfi_ctx* ctx, const double* A, const double* x, double* y
 // blas1
 int launch_copy(alfi_ctx* ctx, double* y, const double* x, int64_t n);
 int launch_axpy(alfi_ctx* ctx, double* y, const double* x, double a, int64_t n);                 // y += a x
-// |r|^2 partials (RED_BLOCKS of them) into ctx->red_partial; then beta = sqrt(sum of nblocks partials), grs = beta e_1
+// |r|^2 partials (red_blocks_for(n) of them) into ctx->red_partial; then beta = sqrt(sum of nblocks partials), grs = beta e_1
 int launch_norm_partials(alfi_ctx* ctx, const double* r, int64_t n);
 int launch_norm_init_finish(alfi_ctx* ctx, const double* partial, int nblocks, double* hs, int K);
-int launch_reduce_partials(alfi_ctx* ctx, int nv, double* out);  // out[v] = sum_b red_partial[b][v]
+int launch_reduce_partials(alfi_ctx* ctx, const double* partial, int nblocks, int nv, double* out);  // out[v] = sum_b partial[b][v]
+int red_blocks_for(int64_t n);   // number of partials the two-stage reductions over n entries produce
 // ww: nullptr, or (partitioned levels) the all-reduced |w|^2 before the projection -> |w_new|^2 by Pythagoras
 int launch_hessenberg_update(alfi_ctx* ctx, const double* partial, int nblocks, const double* h, double* hs, int j,
                              int K, const double* ww);
@@ -327,8 +339,9 @@ int launch_halo_add(alfi_ctx* ctx, double* v, const double* buf, const int32_t* 
                     const int32_t* rev_pos, int64_t nuniq, int bs);
 int launch_scale_by_inv(alfi_ctx* ctx, double* v, const double* w, const double* scal, int64_t n);  // v = w / *scal
 int launch_multi_dot(alfi_ctx* ctx, const double* V, int64_t stride, int nv, const double* w, double* out, int64_t n);
-// w -= sum_v h[v] V_v; |w|^2 partials into ctx->red_partial
-int launch_multi_axpy_norm(alfi_ctx* ctx, const double* V, int64_t stride, int nv, const double* h, double* w,
-                           int64_t n);
+// w -= sum_v h[v] V_v; |w|^2 partials (red_blocks_for(n)) into norm_partial.  hblocks > 0: h is first reduced inside the
+// kernel from the hblocks (<= 256) dot partials in ctx->red_partial (launch_multi_dot with out == nullptr) and published in h
+int launch_multi_axpy_norm(alfi_ctx* ctx, const double* V, int64_t stride, int nv, double* h, double* w, int64_t n,
+                           double* norm_partial, int hblocks);
 int launch_fgmres_finish(alfi_ctx* ctx, double* hs, int k, int K);  // back substitution -> y
 int launch_update_solution(alfi_ctx* ctx, double* x, const double* Z, int64_t stride, int k, const double* y, int64_t n);

@@ -455,6 +455,105 @@ __global__ __launch_bounds__(256) void big_apply_kernel(int64_t p0, int64_t npat
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// 3b. multiplicative sweep over large patches (macro stars, alfi/solver.py:322-324 with 339-342: --patch macro
+//     --patch-composition multiplicative): one dependency wavefront per launch as in kernels_patch.hip, but a WORKGROUP per
+//     patch.  r_p = x_p - (A y)_p: a wave per patch node, lanes over the blocks of its operator row (coalesced value
+//     planes), shuffle-reduced; then y_p += inv(A_p) r_p with the row pieces dealt to the four waves as in the additive
+//     apply.  Patches of one wavefront neither read what another one writes nor write the same dofs: plain stores, the
+//     result is that of the sequential sweep.
+// ---------------------------------------------------------------------------------------------------------------------
+template <int BS, bool NT>
+__global__ __launch_bounds__(256) void big_mult_kernel(int64_t count, const int32_t* __restrict__ seq,
+                                                        const int64_t* __restrict__ patch_ptr,
+                                                        const int32_t* __restrict__ patch_dofs,
+                                                        const int64_t* __restrict__ inv_ptr, const double* __restrict__ inv,
+                                                        const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colidx,
+                                                        const double* __restrict__ vals, int flat,
+                                                        const double* __restrict__ x, double* __restrict__ y) {
+  constexpr int BB = BS * BS;
+  __shared__ double rs[BIG_MAX_NP];
+  __shared__ double ys[BIG_MAX_NP];
+  const int64_t p = seq[blockIdx.x];
+  const int64_t off = patch_ptr[p];
+  const int n = (int)(patch_ptr[p + 1] - off);
+  const int nn = n / BS;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  for (int i = wave; i < nn; i += 4) {
+    const int node = patch_dofs[off + (int64_t)i * BS] / BS;
+    const int32_t lo = rowptr[node], hi = rowptr[node + 1];
+    double s[BS];
+#pragma unroll
+    for (int r = 0; r < BS; ++r) s[r] = 0.0;
+    for (int32_t k = lo + lane; k < hi; k += 64) {
+      const int64_t col = colidx[k] & 0x7fffffff;
+      double a[BB], yv[BS];
+#pragma unroll
+      for (int e = 0; e < BB; ++e) {
+        const double* v = vals + bsr_val_index(flat, k, e, BB);
+        a[e] = NT ? __builtin_nontemporal_load(v) : *v;
+      }
+#pragma unroll
+      for (int c = 0; c < BS; ++c) yv[c] = y[col * BS + c];
+#pragma unroll
+      for (int r = 0; r < BS; ++r)
+#pragma unroll
+        for (int c = 0; c < BS; ++c) s[r] = __builtin_fma(a[r * BS + c], yv[c], s[r]);
+    }
+#pragma unroll
+    for (int r = 0; r < BS; ++r) {
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) s[r] += __shfl_xor(s[r], o);
+    }
+    if (lane == 0) {
+#pragma unroll
+      for (int r = 0; r < BS; ++r) rs[i * BS + r] = x[(int64_t)node * BS + r] - s[r];
+    }
+  }
+  __syncthreads();
+  const int ld = (n + 1) & ~1;
+  const double* T = inv + inv_ptr[p];
+  int piece = 0, row0 = 0;
+  for (; row0 + 128 <= ld; row0 += 128, ++piece)
+    if (piece % 4 == wave) big_piece<64, NT>(T + (int64_t)row0 * n, n, rs, lane, ys + row0);
+  const int rem = ld - row0;
+#define ALFI_BIG_PIECE(R)                                                                      \
+  if (rem & R) {                                                                               \
+    if (piece % 4 == wave) big_piece<R / 2, NT>(T + (int64_t)row0 * n, n, rs, lane, ys + row0); \
+    row0 += R;                                                                                 \
+    ++piece;                                                                                   \
+  }
+  ALFI_BIG_PIECE(64)
+  ALFI_BIG_PIECE(32)
+  ALFI_BIG_PIECE(16)
+  ALFI_BIG_PIECE(8)
+  ALFI_BIG_PIECE(4)
+  ALFI_BIG_PIECE(2)
+#undef ALFI_BIG_PIECE
+  __syncthreads();
+  for (int i = threadIdx.x; i < n; i += 256) y[patch_dofs[off + i]] += ys[i];
+}
+
+int launch_big_mult_wave(alfi_level* L, const int32_t* seq, int64_t count, const double* x, double* y) {
+  alfi_ctx* ctx = L->ctx;
+  if (count == 0) return 0;
+  static const bool nt = !(getenv("ALFI_NT") && atoi(getenv("ALFI_NT")) == 0);
+  dim3 grid((unsigned)count), block(256);
+#define ALFI_BMULT(BSV, NTV)                                                                                          \
+  hipLaunchKernelGGL((big_mult_kernel<BSV, NTV>), grid, block, 0, ctx->stream, count, seq, L->patch_ptr, L->patch_dofs, \
+                     L->inv_ptr, L->inv, L->A.rowptr, L->A.colidx, L->A.vals, L->A.flat, x, y)
+  if (L->bs == 2) {
+    if (nt) ALFI_BMULT(2, true); else ALFI_BMULT(2, false);
+  } else if (L->bs == 3) {
+    if (nt) ALFI_BMULT(3, true); else ALFI_BMULT(3, false);
+  } else {
+    return alfi_set_error(ctx, ALFI_E_ARG, "unsupported block size %d", L->bs);
+  }
+#undef ALFI_BMULT
+  ALFI_HIP_CHECK(ctx, hipGetLastError());
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // launch wrappers
 // ---------------------------------------------------------------------------------------------------------------------
 // workgroups per patch: enough of them to fill 256 CUs several times over, but no more waves than 128-row pieces
@@ -515,13 +614,50 @@ int launch_big_apply_arrays(alfi_ctx* ctx, int64_t npatch, int max_np, const int
   return 0;
 }
 
-// Where the matrices of a batch come from: the level's operator (patch smoother) or the dense blocks of a transfer.
+// the whole operator of a (coarse) level as ONE dense N x N matrix (N = n rounded up to 64, identity padding): zero / pad,
+// then scatter the bs x bs blocks
+__global__ void coarse_pad_kernel(int64_t n, int64_t N, double* __restrict__ S) {
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < N * N; e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = e / N, c = e % N;
+    S[e] = (r == c && r >= n) ? 1.0 : 0.0;
+  }
+}
+template <int BS>
+__global__ void coarse_scatter_kernel(int64_t nbrows, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colidx,
+                                      const double* __restrict__ vals, int flat, int64_t N, double* __restrict__ S) {
+  const int64_t total = (int64_t)rowptr[nbrows] * BS * BS;
+  // block row of entry k by binary search in rowptr (setup only)
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t k = e / (BS * BS);
+    const int rc = (int)(e % (BS * BS));
+    int64_t a = 0, b = nbrows;
+    while (b - a > 1) {
+      const int64_t mid = (a + b) >> 1;
+      if (rowptr[mid] <= k) a = mid; else b = mid;
+    }
+    const int64_t col = colidx[k] & 0x7fffffff;
+    S[(a * BS + rc / BS) * N + col * BS + rc % BS] = vals[bsr_val_index(flat, k, rc, BS * BS)];
+  }
+}
+
+// Where the matrices of a batch come from: the level's operator (patch smoother), the dense blocks of a transfer, or the
+// whole operator of a level (C: the coarse grid, one matrix).
 struct BigSource {
   alfi_level* L = nullptr;
   alfi_transfer* T = nullptr;
+  alfi_level* C = nullptr;
   void fill(alfi_ctx* ctx, int64_t p0, int64_t nb, const int64_t* d_scr_ptr, double* dst) const {
     dim3 block(256);
-    if (T) {
+    if (C) {
+      const int64_t n = C->n, N = (n + BIG_NB - 1) / BIG_NB * BIG_NB;
+      hipLaunchKernelGGL(coarse_pad_kernel, dim3(8192), block, 0, ctx->stream, n, N, dst);
+      if (C->bs == 2)
+        hipLaunchKernelGGL(coarse_scatter_kernel<2>, dim3(4096), block, 0, ctx->stream, C->A.nbrows, C->A.rowptr, C->A.colidx,
+                           C->A.vals, C->A.flat, N, dst);
+      else
+        hipLaunchKernelGGL(coarse_scatter_kernel<3>, dim3(4096), block, 0, ctx->stream, C->A.nbrows, C->A.rowptr, C->A.colidx,
+                           C->A.vals, C->A.flat, N, dst);
+    } else if (T) {
       hipLaunchKernelGGL(big_dense_fill_kernel, dim3(64, (unsigned)nb), block, 0, ctx->stream, p0, T->m, T->KII, T->DII,
                          T->nu, T->gamma, d_scr_ptr, dst);
     } else if (L->bs == 2) {
@@ -535,8 +671,10 @@ struct BigSource {
 };
 
 // fill + blocked inversion of npatch matrices, in batches bounded by the scratch budget
+// dense_out != nullptr (one matrix): the inverse is delivered row-major n x n there instead of the row-piece layout
 static int big_factor_core(alfi_ctx* ctx, const BigSource& src, int64_t npatch, const int64_t* h_patch_ptr,
-                           const int64_t* d_patch_ptr, const int64_t* d_inv_ptr, double* inv, int* status) {
+                           const int64_t* d_patch_ptr, const int64_t* d_inv_ptr, double* inv, int* status,
+                           double* dense_out = nullptr) {
   if (npatch == 0) return 0;
   const int64_t budget = (int64_t)6 << 30;          // bytes of scratch (matrices + panels) per batch
   const char* env = getenv("ALFI_BIG_SCRATCH_MB");
@@ -630,8 +768,15 @@ static int big_factor_core(alfi_ctx* ctx, const BigSource& src, int64_t npatch, 
                          d_patch_ptr, p0, d_scr_ptr, scr, scrR, scrA, tiles);
       result = scrA;
     }
-    hipLaunchKernelGGL(big_store_kernel, dim3(64, (unsigned)nb), block, 0, ctx->stream, p0, d_patch_ptr, d_inv_ptr,
-                       d_scr_ptr, result, inv);
+    if (dense_out) {
+      const int64_t n = h_patch_ptr[1] - h_patch_ptr[0];
+      e = hipMemcpy2DAsync(dense_out, (size_t)n * 8, result, (size_t)B.Nmax * 8, (size_t)n * 8, (size_t)n,
+                           hipMemcpyDeviceToDevice, ctx->stream);
+      if (e != hipSuccess) break;
+    } else {
+      hipLaunchKernelGGL(big_store_kernel, dim3(64, (unsigned)nb), block, 0, ctx->stream, p0, d_patch_ptr, d_inv_ptr,
+                         d_scr_ptr, result, inv);
+    }
     e = hipGetLastError();
     if (e != hipSuccess) break;
   }
@@ -653,4 +798,27 @@ int launch_big_factor_transfer(alfi_transfer* T) {
   std::vector<int64_t> hptr(T->nblk + 1);
   for (int64_t b = 0; b <= T->nblk; ++b) hptr[b] = b * T->m;
   return big_factor_core(T->ctx, src, T->nblk, hptr.data(), T->pm_ptr, T->pm_inv_ptr, T->binv, T->status);
+}
+
+// Dense inverse of a whole level operator (the coarse grid: AssembledPC + LU in the reference, alfi/solver.py:369-378) with
+// the same blocked Gauss-Jordan on the FP64 matrix cores + Newton-Schulz polish as the macro-star patches: one N x N
+// matrix, N/64 pivot steps, no library GEMM and no host LAPACK.  out: n x n doubles, row-major, on the device.
+int launch_coarse_factor(alfi_level* L, double* out) {
+  alfi_ctx* ctx = L->ctx;
+  BigSource src;
+  src.C = L;
+  const int64_t hptr[2] = {0, L->n};
+  int64_t* dptr = nullptr;
+  ALFI_HIP_CHECK(ctx, hipMalloc((void**)&dptr, sizeof(hptr)));
+  hipError_t e = hipMemcpy(dptr, hptr, sizeof(hptr), hipMemcpyHostToDevice);
+  int rc = e == hipSuccess ? big_factor_core(ctx, src, 1, hptr, dptr, nullptr, nullptr, L->status, out)
+                           : alfi_set_error(ctx, ALFI_E_HIP, "hipMemcpy: %s", hipGetErrorString(e));
+  (void)hipFree(dptr);
+  // the 3 N^2 scratch arena of a large coarse grid is not needed again (patch re-factorisations are far smaller)
+  if (rc == 0 && ctx->big_arena_bytes > ((size_t)1 << 30)) {
+    (void)hipFree(ctx->big_arena);
+    ctx->big_arena = nullptr;
+    ctx->big_arena_bytes = 0;
+  }
+  return rc;
 }

@@ -605,6 +605,7 @@ int launch_patch_apply_arrays(alfi_ctx* ctx, int64_t npatch, const int64_t* patc
 int launch_patch_mult_wave(alfi_level* L, const int32_t* seq, int64_t count, const double* x, double* y) {
   alfi_ctx* ctx = L->ctx;
   if (count == 0) return 0;
+  if (L->mult_big) return launch_big_mult_wave(L, seq, count, x, y);
   static const bool nt = !(getenv("ALFI_NT") && atoi(getenv("ALFI_NT")) == 0);
   dim3 grid((unsigned)((count + 3) / 4)), block(256);
 #define ALFI_MULT(BSV, NTV)                                                                                           \

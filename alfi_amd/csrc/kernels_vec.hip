@@ -57,8 +57,12 @@ __global__ __launch_bounds__(256) void bsr_spmv_kernel(int64_t nbrows, const int
 // (deterministic, no atomics).  The wave holding a row's LAST block stores y, everything earlier is a carry.
 // ---------------------------------------------------------------------------------------------------------------------
 typedef double spmv_d2 __attribute__((ext_vector_type(2)));
-template <int BS, bool NT>
+// ALIGNED (small matrices, where a cycle is bound by the number of dependent launches rather than by bandwidth): the chunks
+// hold whole block rows -- chunk c = blocks [chunk_start[c], chunk_start[c + 1]), at most SPMV_CHUNK of them -- so no row
+// continues into the next chunk and the fix-up launch disappears.
+template <int BS, bool NT, bool ALIGNED>
 __global__ __launch_bounds__(256) void bsr_spmv_flat_kernel(int64_t kbase, int64_t nnzb, int64_t nchunks,
+                                                             const int64_t* __restrict__ chunk_start,
                                                              const int32_t* __restrict__ colflag,
                                                              const double* __restrict__ vals,
                                                              const int32_t* __restrict__ chunk_row,
@@ -82,8 +86,8 @@ __global__ __launch_bounds__(256) void bsr_spmv_flat_kernel(int64_t kbase, int64
   if (chunk >= nchunks) return;
   // blocks [kbase, kbase + nnzb) of the upload: a block-row range (the whole matrix, the owned rows, or the owned rows
   // with / without ghost columns of a partitioned level); the value / index layout is addressed by the absolute block
-  const int64_t kend_all = kbase + nnzb;
-  const int64_t base = kbase + chunk * SPMV_CHUNK;
+  const int64_t kend_all = ALIGNED ? chunk_start[chunk + 1] : kbase + nnzb;
+  const int64_t base = ALIGNED ? chunk_start[chunk] : kbase + chunk * SPMV_CHUNK;
   int R = chunk_row[chunk];  // block row of lane 0's block
   int Rlast = R;
   double carry[BS];
@@ -98,6 +102,7 @@ __global__ __launch_bounds__(256) void bsr_spmv_flat_kernel(int64_t kbase, int64
   };
 #pragma unroll
   for (int u = 0; u < SPMV_U; ++u) {
+    if (ALIGNED && base + u * 64 >= kend_all) break;     // wave-uniform: the chunk is shorter than SPMV_CHUNK
     const int64_t k = base + u * 64 + lane;
     const bool valid = k < kend_all;
     const int32_t cf = valid ? (NT ? __builtin_nontemporal_load(colflag + k) : colflag[k]) : 0;
@@ -158,6 +163,10 @@ __global__ __launch_bounds__(256) void bsr_spmv_flat_kernel(int64_t kbase, int64
 #pragma unroll
     for (int r = 0; r < BS; ++r) carry[r] = __shfl(p[r], 63);
     Rlast = __shfl(row, 63);
+  }
+  if (ALIGNED) {
+    if (lane == 0 && kend_all > base) store_row(Rlast, carry);
+    return;
   }
   const int64_t kend = base + SPMV_CHUNK;
   if (lane == 0) {
@@ -238,19 +247,32 @@ static int launch_bsr_spmv_bs(alfi_ctx* ctx, const DevBSR& A, const double* x, d
                               int mode) {
   if (A.flat) {
     if (A.nnzb == 0) return 0;
-    const int64_t nchunks = (A.nnzb + SPMV_CHUNK - 1) / SPMV_CHUNK;   // A may be a block-row-range view of the upload
     // operator values and indices are used once per product: stream them past the caches (nontemporal) so that x and y
     // keep the L2 / Infinity Cache.  ALFI_NT=0 switches to plain loads (A/B measurements).
     static const bool nt = !(getenv("ALFI_NT") && atoi(getenv("ALFI_NT")) == 0);
     static const int xcd = (getenv("ALFI_XCD_MAP") && atoi(getenv("ALFI_XCD_MAP")) == 1) ? 1 : 0;
+    if (A.aligned) {          // whole rows per chunk: one launch, no fix-up
+      const int64_t nchunks = A.nchunks;
+      if (nt)
+        hipLaunchKernelGGL((bsr_spmv_flat_kernel<BS, true, true>), dim3((unsigned)((nchunks + 3) / 4)), dim3(256), 0,
+                           ctx->stream, A.kbase, A.nnzb, nchunks, A.chunk_start, A.colidx, A.vals, A.chunk_row, x, y, b,
+                           alpha, mode, A.carry, A.carry_row, 0);
+      else
+        hipLaunchKernelGGL((bsr_spmv_flat_kernel<BS, false, true>), dim3((unsigned)((nchunks + 3) / 4)), dim3(256), 0,
+                           ctx->stream, A.kbase, A.nnzb, nchunks, A.chunk_start, A.colidx, A.vals, A.chunk_row, x, y, b,
+                           alpha, mode, A.carry, A.carry_row, 0);
+      ALFI_HIP_CHECK(ctx, hipGetLastError());
+      return 0;
+    }
+    const int64_t nchunks = (A.nnzb + SPMV_CHUNK - 1) / SPMV_CHUNK;   // A may be a block-row-range view of the upload
     if (nt)
-      hipLaunchKernelGGL((bsr_spmv_flat_kernel<BS, true>), dim3((unsigned)((nchunks + 3) / 4)), dim3(256), 0,
-                         ctx->stream, A.kbase, A.nnzb, nchunks, A.colidx, A.vals, A.chunk_row, x, y, b, alpha, mode,
-                         A.carry, A.carry_row, xcd);
+      hipLaunchKernelGGL((bsr_spmv_flat_kernel<BS, true, false>), dim3((unsigned)((nchunks + 3) / 4)), dim3(256), 0,
+                         ctx->stream, A.kbase, A.nnzb, nchunks, (const int64_t*)nullptr, A.colidx, A.vals, A.chunk_row, x,
+                         y, b, alpha, mode, A.carry, A.carry_row, xcd);
     else
-      hipLaunchKernelGGL((bsr_spmv_flat_kernel<BS, false>), dim3((unsigned)((nchunks + 3) / 4)), dim3(256), 0,
-                         ctx->stream, A.kbase, A.nnzb, nchunks, A.colidx, A.vals, A.chunk_row, x, y, b, alpha, mode,
-                         A.carry, A.carry_row, xcd);
+      hipLaunchKernelGGL((bsr_spmv_flat_kernel<BS, false, false>), dim3((unsigned)((nchunks + 3) / 4)), dim3(256), 0,
+                         ctx->stream, A.kbase, A.nnzb, nchunks, (const int64_t*)nullptr, A.colidx, A.vals, A.chunk_row, x,
+                         y, b, alpha, mode, A.carry, A.carry_row, xcd);
     ALFI_HIP_CHECK(ctx, hipGetLastError());
     hipLaunchKernelGGL((bsr_spmv_fixup_kernel<BS>), dim3((unsigned)((nchunks + 255) / 256)), dim3(256), 0, ctx->stream,
                        nchunks, A.carry, A.carry_row, y, alpha, mode);
@@ -392,7 +414,23 @@ __device__ __forceinline__ void block_store_partials(double (&acc)[NV], double* 
         red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
 }
 
-// partial[b][v] = sum over the block's slice of V_v[i] * w[i]
+// every thread of the block gets out[v] = sum_{b < nblocks <= 256} partial[b][v], summed in one fixed order: all blocks
+// of a launch (and the kernels that follow) see the identical value, and no separate reduction launch is needed
+template <int NV>
+__device__ __forceinline__ void block_reduce_partials(const double* __restrict__ partial, int nblocks, double (&out)[NV]) {
+  __shared__ double red2[4][NV];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+  for (int v = 0; v < NV; ++v) {
+    const double s = wave_sum((int)threadIdx.x < nblocks ? partial[(int64_t)threadIdx.x * RED_MAXV + v] : 0.0);
+    if (lane == 0) red2[wave][v] = s;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int v = 0; v < NV; ++v) out[v] = (red2[0][v] + red2[1][v]) + (red2[2][v] + red2[3][v]);
+}
+
+// partial[b][v] = sum over the block's slice of V_v[i] * w[i]   (gridDim.x blocks: RED_BLOCKS, or fewer on small levels)
 template <int NV>
 __global__ __launch_bounds__(256) void multi_dot_kernel(const double* __restrict__ V, int64_t stride,
                                                          const double* __restrict__ w, double* __restrict__ partial,
@@ -400,7 +438,7 @@ __global__ __launch_bounds__(256) void multi_dot_kernel(const double* __restrict
   double acc[NV];
 #pragma unroll
   for (int v = 0; v < NV; ++v) acc[v] = 0.0;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)RED_BLOCKS * 256) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
     const double wi = w[i];
 #pragma unroll
     for (int v = 0; v < NV; ++v) acc[v] = __builtin_fma(V[v * stride + i], wi, acc[v]);
@@ -409,12 +447,12 @@ __global__ __launch_bounds__(256) void multi_dot_kernel(const double* __restrict
 }
 
 // out[v] = sum_b partial[b][v]   (one block, fixed order)
-__global__ __launch_bounds__(256) void reduce_partials_kernel(const double* __restrict__ partial, int nv,
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const double* __restrict__ partial, int nblocks, int nv,
                                                                double* __restrict__ out) {
   __shared__ double red[256];
   for (int v = 0; v < nv; ++v) {
     double s = 0.0;
-    for (int b = threadIdx.x; b < RED_BLOCKS; b += 256) s += partial[(int64_t)b * RED_MAXV + v];
+    for (int b = threadIdx.x; b < nblocks; b += 256) s += partial[(int64_t)b * RED_MAXV + v];
     red[threadIdx.x] = s;
     __syncthreads();
     for (int o = 128; o > 0; o >>= 1) {
@@ -426,16 +464,26 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const double* __re
   }
 }
 
-// w -= sum_v h[v] V_v ; partial[b][0] = sum of w^2 over the block's slice
+// w -= sum_v h[v] V_v ; partial[b][0] = sum of w^2 over the block's slice.  hblocks > 0: h is not given but reduced here
+// from the hblocks (<= 256) dot partials hpart[b][v] of the preceding multi_dot_kernel; block 0 publishes it in h.
 template <int NV>
 __global__ __launch_bounds__(256) void multi_axpy_norm_kernel(const double* __restrict__ V, int64_t stride,
-                                                               const double* __restrict__ h, double* __restrict__ w,
-                                                               double* __restrict__ partial, int64_t n) {
+                                                               double* __restrict__ h, double* __restrict__ w,
+                                                               double* __restrict__ partial, int64_t n,
+                                                               const double* __restrict__ hpart, int hblocks) {
   double hv[NV];
+  if (hblocks > 0) {
+    block_reduce_partials<NV>(hpart, hblocks, hv);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
 #pragma unroll
-  for (int v = 0; v < NV; ++v) hv[v] = h[v];
+      for (int v = 0; v < NV; ++v) h[v] = hv[v];
+    }
+  } else {
+#pragma unroll
+    for (int v = 0; v < NV; ++v) hv[v] = h[v];
+  }
   double acc[1] = {0.0};
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)RED_BLOCKS * 256) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
     double wi = w[i];
 #pragma unroll
     for (int v = 0; v < NV; ++v) wi = __builtin_fma(-hv[v], V[v * stride + i], wi);
@@ -555,33 +603,46 @@ __global__ void fgmres_finish_kernel(double* __restrict__ hs, int k, int K) {
     MACRO(13) MACRO(14) MACRO(15) MACRO(16)                                                                         \
   }
 
+// blocks of the two-stage reductions over a vector of n entries: RED_BLOCKS for the large levels, one per 4096 entries on
+// the small ones (there every kernel of a smoother iteration is a few microseconds of latency, and 1024 blocks with
+// 1024 x nv partials to sum would dominate it)
+int red_blocks_for(int64_t n) {
+  const int64_t g = (n + 4095) / 4096;
+  return (int)(g < 1 ? 1 : (g > RED_BLOCKS ? RED_BLOCKS : g));
+}
+
 int launch_multi_dot(alfi_ctx* ctx, const double* V, int64_t stride, int nv, const double* w, double* out, int64_t n) {
   // out[0..nv) = V_v . w ; more than 16 vectors: passes of 16
+  const int G = red_blocks_for(n);
   for (int v0 = 0; v0 < nv; v0 += 16) {
     const int cnt = nv - v0 < 16 ? nv - v0 : 16;
 #define ALFI_CASE(N)                                                                                              \
   case N:                                                                                                         \
-    hipLaunchKernelGGL(multi_dot_kernel<N>, dim3(RED_BLOCKS), dim3(256), 0, ctx->stream, V + (int64_t)v0 * stride, \
+    hipLaunchKernelGGL(multi_dot_kernel<N>, dim3(G), dim3(256), 0, ctx->stream, V + (int64_t)v0 * stride,          \
                        stride, w, ctx->red_partial, n);                                                           \
     break;
     ALFI_NV_SWITCH(cnt, ALFI_CASE)
 #undef ALFI_CASE
     ALFI_HIP_CHECK(ctx, hipGetLastError());
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(256), 0, ctx->stream, ctx->red_partial, cnt, out + v0);
-    ALFI_HIP_CHECK(ctx, hipGetLastError());
+    if (out) {
+      hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(256), 0, ctx->stream, ctx->red_partial, G, cnt, out + v0);
+      ALFI_HIP_CHECK(ctx, hipGetLastError());
+    }
   }
   return 0;
 }
 
-int launch_multi_axpy_norm(alfi_ctx* ctx, const double* V, int64_t stride, int nv, const double* h, double* w,
-                           int64_t n) {
-  // w -= sum h_v V_v (passes of 16; the last pass also produces |w|^2 partials)
+// w -= sum h_v V_v (passes of 16; the last pass also produces |w|^2 partials, red_blocks_for(n) of them, in norm_partial).
+// hblocks > 0 (nv <= 16, hblocks <= 256): h is reduced inside the kernel from the dot partials in ctx->red_partial.
+int launch_multi_axpy_norm(alfi_ctx* ctx, const double* V, int64_t stride, int nv, double* h, double* w, int64_t n,
+                           double* norm_partial, int hblocks) {
+  const int G = red_blocks_for(n);
   for (int v0 = 0; v0 < nv; v0 += 16) {
     const int cnt = nv - v0 < 16 ? nv - v0 : 16;
 #define ALFI_CASE(N)                                                                                             \
   case N:                                                                                                        \
-    hipLaunchKernelGGL(multi_axpy_norm_kernel<N>, dim3(RED_BLOCKS), dim3(256), 0, ctx->stream,                   \
-                       V + (int64_t)v0 * stride, stride, h + v0, w, ctx->red_partial, n);                        \
+    hipLaunchKernelGGL(multi_axpy_norm_kernel<N>, dim3(G), dim3(256), 0, ctx->stream,                            \
+                       V + (int64_t)v0 * stride, stride, h + v0, w, norm_partial, n, ctx->red_partial, hblocks); \
     break;
     ALFI_NV_SWITCH(cnt, ALFI_CASE)
 #undef ALFI_CASE
@@ -655,8 +716,8 @@ int launch_hessenberg_update(alfi_ctx* ctx, const double* partial, int nblocks, 
 }
 
 int launch_norm_partials(alfi_ctx* ctx, const double* r, int64_t n) {
-  // |r|^2 partials via the dot kernel with V = w = r
-  hipLaunchKernelGGL(multi_dot_kernel<1>, dim3(RED_BLOCKS), dim3(256), 0, ctx->stream, r, (int64_t)0, r,
+  // |r|^2 partials (red_blocks_for(n) of them) via the dot kernel with V = w = r
+  hipLaunchKernelGGL(multi_dot_kernel<1>, dim3(red_blocks_for(n)), dim3(256), 0, ctx->stream, r, (int64_t)0, r,
                      ctx->red_partial, n);
   ALFI_HIP_CHECK(ctx, hipGetLastError());
   return 0;
@@ -668,8 +729,8 @@ int launch_norm_init_finish(alfi_ctx* ctx, const double* partial, int nblocks, d
   return 0;
 }
 
-int launch_reduce_partials(alfi_ctx* ctx, int nv, double* out) {
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(256), 0, ctx->stream, ctx->red_partial, nv, out);
+int launch_reduce_partials(alfi_ctx* ctx, const double* partial, int nblocks, int nv, double* out) {
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(256), 0, ctx->stream, partial, nblocks, nv, out);
   ALFI_HIP_CHECK(ctx, hipGetLastError());
   return 0;
 }

@@ -582,10 +582,7 @@ class DistMultigrid(object):
                         # more than the ~3 ms of wire time per cycle the overlap can hide on config 4 at 2 to 8 ranks
                         dl.set_overlap(p.nb_int, LL.npatch_int)
                 elif p.nb_own > 0:
-                    inv = coarse_inverse(levels[0].A) if coarse_inverse is not None else hip.coarse_inverse(levels[0].A)
-                    if isinstance(inv, tuple):
-                        inv, self._keep_inv = inv
-                    dl.set_coarse_inverse(inv)
+                    self._coarse(dl, levels[0].A, coarse_inverse)
                 self.levels.append(dl)
             self.mg = hip.Multigrid.__new__(hip.Multigrid)
             self.mg._from_device_levels(ctx, self.levels, ltr, k, robust_restriction)
@@ -596,6 +593,17 @@ class DistMultigrid(object):
             print("[alfi_amd.dist] rank %d: levels %d..%d, finest owns %d of %d dofs (+%d ghost), %d patches"
                   % (rank, self.lmin, len(levels) - 1, self.n_own, levels[-1].n, self.n_loc - self.n_own,
                      len(self.fine.patch_ptr) - 1), flush=True)
+
+    def _coarse(self, dl, A0, coarse_inverse):
+        """Coarse solve of the rank that owns level 0: the library's own dense factorisation of the (complete) local
+        operator, or an inverse the caller computes from the global one."""
+        if coarse_inverse is None:
+            dl.coarse_factor()
+            return
+        inv = coarse_inverse(A0)
+        if isinstance(inv, tuple):
+            inv, self._keep_inv = inv
+        dl.set_coarse_inverse(inv)
 
     # the library calls this at every exchange point of the cycle (alfi_ctx_set_comm): ~200 times per V-cycle, so the host
     # work per call is kept to the collective itself (on small levels the cycle is bound by exactly this host time)
@@ -647,10 +655,7 @@ class DistMultigrid(object):
                 if LL.level > 0:
                     dl.factor()
                 elif LL.part.nb_own > 0:
-                    inv = coarse_inverse(levels[0].A) if coarse_inverse is not None else hip.coarse_inverse(levels[0].A)
-                    if isinstance(inv, tuple):
-                        inv, self._keep_inv = inv
-                    dl.set_coarse_inverse(inv)
+                    self._coarse(dl, levels[0].A, coarse_inverse)
 
     def local_vec(self, global_array=None):
         """Device vector of the finest level in local numbering (owned + ghost slots), filled from a global array."""

@@ -225,6 +225,18 @@ class Level(object):
             assert inv.shape == (self.n, self.n)
             self.ctx.check(self.ctx.lib.alfi_coarse_set_inverse(self.h, _ptr(inv), 0))
 
+    def coarse_factor(self):
+        """Dense inverse of this level's operator built by the library itself (blocked Gauss-Jordan on the FP64 matrix cores +
+        residual probe, alfi_coarse_factor); returns the probe residual || A X e - e ||."""
+        self.ctx.check(self.ctx.lib.alfi_coarse_factor(self.h))
+        return self.coarse_residual()
+
+    def coarse_residual(self):
+        """|| A X e - e ||_inf of the coarse inverse built by ``coarse_factor`` (-1 for a caller-supplied inverse)."""
+        w = ctypes.c_double()
+        self.ctx.check(self.ctx.lib.alfi_coarse_residual(self.h, ctypes.byref(w)))
+        return w.value
+
     def coarse_solve(self, b, x):
         self.ctx.check(self.ctx.lib.alfi_coarse_solve(self.h, b.ptr, x.ptr))
 
@@ -280,40 +292,10 @@ class Transfer(object):
 
 
 def coarse_inverse(A_bsr):
-    """Dense inverse of the coarsest operator (stands in for AssembledPC + LU, solver.py:369-378).  Setup only."""
+    """Dense inverse of the coarsest operator by host LAPACK -- an alternative to ``Level.coarse_factor`` for callers that
+    want to supply their own (``Multigrid(..., coarse_inv=...)``); the default path does not use it."""
     A = A_bsr.to_scipy().toarray()
     return np.linalg.inv(A)
-
-
-def dense_inverse_gpu(A_bsr, nb=256, refine=1):
-    """Dense FP64 inverse of a (coarse) operator as a torch CUDA tensor, by blocked Gauss-Jordan: the rank-nb trailing
-    updates run as plain library GEMMs (torch.addmm -> rocBLAS), the nb x nb pivot blocks are inverted with LAPACK on
-    the host.  No pivoting across blocks (the operator is SPD-dominated, like the patch operators).  Setup only: stands
-    in for the factorisation of the reference's coarse LU (solver.py:369-378); the solve itself is the library's GEMV."""
-    import torch
-    A = torch.from_numpy(A_bsr.to_scipy().toarray()).to("cuda")
-    n = A.shape[0]
-    for k0 in range(0, n, nb):
-        k1 = min(n, k0 + nb)
-        Dinv = torch.from_numpy(np.linalg.inv(A[k0:k1, k0:k1].cpu().numpy())).to("cuda")
-        R = A[k0:k1, :].clone()
-        R[:, k0:k1] = 0.0
-        C = A[:, k0:k1] @ Dinv
-        C[k0:k1, :] = 0.0
-        A.addmm_(C, R, alpha=-1.0)
-        A[k0:k1, :] = Dinv @ R
-        A[:, k0:k1] = -C
-        A[k0:k1, k0:k1] = Dinv
-    if refine:
-        # Newton-Schulz polish X <- X (2I - A X): squares the residual left by the unpivoted block elimination
-        A0 = torch.from_numpy(A_bsr.to_scipy().toarray()).to("cuda")
-        for _ in range(refine):
-            R = A0 @ A
-            R.mul_(-1.0)
-            R.diagonal().add_(2.0)
-            A = A @ R
-        del A0, R
-    return A.contiguous()
 
 
 class Multigrid(object):
@@ -328,8 +310,10 @@ class Multigrid(object):
             if L.level > 0:
                 dl.set_patches(L.patch_ptr, L.patch_dofs)
                 dl.factor()
+            elif coarse_inv is not None:
+                dl.set_coarse_inverse(coarse_inv)          # an inverse supplied by the caller (numpy array / device pointer)
             else:
-                dl.set_coarse_inverse(coarse_inv if coarse_inv is not None else coarse_inverse(L.A))
+                dl.coarse_factor()                         # the library's own factorisation
             dlevels.append(dl)
         self._from_device_levels(ctx, dlevels, transfers, k, robust_restriction)
         if verbose:

@@ -251,7 +251,10 @@ class HipMG(object):
         for L in levels:
             if L.level == 0:
                 dl = hip.Level(ctx, L.A, L.bc_dofs)
-                dl.set_coarse_inverse(coarse_inv if coarse_inv is not None else hip.coarse_inverse(L.A))
+                if coarse_inv is not None:
+                    dl.set_coarse_inverse(coarse_inv)
+                else:
+                    dl.coarse_factor()
                 dlevels.append(dl)
                 self.pcs.append(None)
                 self.pc_objs.append(None)

@@ -67,20 +67,6 @@ def build_problem(cfg, verbose, lazy=False):
     return lv, tr, k
 
 
-def coarse_inverse_device(A_bsr):
-    """Dense inverse of the coarsest operator.  Small: LAPACK on the host.  Large (config 4: 23 355 dofs): FP64
-    blocked Gauss-Jordan on the GPU with library GEMMs (setup only; stands in for the reference's SuperLU_DIST
-    factorisation)."""
-    n = A_bsr.shape[0]
-    if n <= 4096:
-        return np.linalg.inv(A_bsr.to_scipy().toarray()), None
-    import torch
-    from alfi_amd.hip import dense_inverse_gpu
-    Ainv = dense_inverse_gpu(A_bsr)
-    torch.cuda.synchronize()
-    return int(Ainv.data_ptr()), Ainv
-
-
 def vcycle_bytes(levels, dmg, k):
     """Algorithmic HBM bytes of one V-cycle and of one patch_apply_kernel launch per level."""
     total = 0.0
@@ -139,12 +125,8 @@ def main_distributed(args, rank, world, local_rank):
     lv, tr, k = build_problem(args.config, args.verbose and rank == 0, lazy=lazy)
     t_gen = time.time() - t0
 
-    def coarse_inv(A_bsr):
-        inv, keep = coarse_inverse_device(A_bsr)
-        return (inv, keep)
-
     t0 = time.time()
-    dmg = DistMultigrid(lv, tr, k, robust_restriction=False, coarse_inverse=coarse_inv,
+    dmg = DistMultigrid(lv, tr, k, robust_restriction=False,
                         min_dofs=int(os.environ.get("ALFI_DIST_MIN_DOFS", "400000")), verbose=args.verbose,
                         force_distributed=os.environ.get("ALFI_DIST_FORCE") == "1")
     dmg.sync()
@@ -390,9 +372,8 @@ def main():
     lv, tr, k = build_problem(args.config, args.verbose)
     t_gen = time.time() - t0
     ctx = hip.Context(0)
-    inv, keep = coarse_inverse_device(lv[0].A)
     t0 = time.time()
-    dmg = hip.Multigrid(ctx, lv, tr, k, robust_restriction=False, coarse_inv=inv, verbose=args.verbose)
+    dmg = hip.Multigrid(ctx, lv, tr, k, robust_restriction=False, verbose=args.verbose)
     ctx.sync()
     t_setup = time.time() - t0
     L = lv[-1]

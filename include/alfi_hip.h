@@ -162,8 +162,8 @@ int alfi_patch_apply(alfi_level* lvl, const double* dx, double* dy);
  * ones; symmetrise != 0 appends the same sequence reversed (patch_pc_patch_symmetrise_sweep).  The library orders
  * the positions into dependency wavefronts (two patches are independent when no operator entry couples them), which
  * reproduces the sequential sweep exactly.  Afterwards alfi_patch_apply and alfi_smooth_fgmres on this level use the
- * multiplicative sweep; nit == 0 switches back to additive.  Patches must consist of whole nodes (all bs components),
- * at most 64 nodes per patch.  On a partitioned level every rank sweeps over its own patches (local Gauss-Seidel,
+ * multiplicative sweep; nit == 0 switches back to additive.  Patches must consist of whole nodes (all bs components); a
+ * wave sweeps a patch of up to 64 nodes / 160 dofs, a workgroup the larger ones (macro stars, solver.py:339-342).  On a partitioned level every rank sweeps over its own patches (local Gauss-Seidel,
  * additive between ranks, ghost contributions reverse-added at the end), as PCPATCH does under MPI. */
 int alfi_patches_set_multiplicative(alfi_level* lvl, int64_t nit, const int64_t* iterset_host, int symmetrise);
 /* number of dependency wavefronts of one sweep (0 = additive) */
@@ -179,7 +179,14 @@ int alfi_patch_get_inverse(alfi_level* lvl, int64_t p, double* out_host);
 int alfi_smooth_fgmres(alfi_level* lvl, int k, const double* db, double* dx, int nonzero_guess);
 
 /* ---- coarse solve: firedrake.AssembledPC + LU [3P], alfi/solver.py:369-378 ---------------------------------------- */
-/* The coarse operator's dense inverse (row-major n x n), computed by the caller; applied as a device GEMV. */
+/* alfi_coarse_factor: the level operator's dense inverse (n x n doubles on the device, n <= 131072) by the library's own
+ * blocked Gauss-Jordan on the FP64 matrix cores (64-wide pivot blocks, rank-64 trailing updates as v_mfma_f64_16x16x4,
+ * one Newton-Schulz polish step) -- no library GEMM, no host LAPACK -- followed by the residual probe || A X e - e ||
+ * (ALFI_E_SINGULAR above 1e-6; alfi_coarse_residual reports it).  The level must be owned by one rank.
+ * alfi_coarse_set_inverse: an inverse computed by the caller instead (row-major n x n, host or device memory).
+ * The solve is a device GEMV either way. */
+int alfi_coarse_factor(alfi_level* lvl);
+int alfi_coarse_residual(alfi_level* lvl, double* worst);
 int alfi_coarse_set_inverse(alfi_level* lvl, const double* inv, int inv_is_device);
 int alfi_coarse_solve(alfi_level* lvl, const double* db, double* dx);
 

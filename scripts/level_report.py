@@ -10,8 +10,7 @@ cfg = sys.argv[1] if len(sys.argv) > 1 else "cfg4"
 reps = 5
 lv, tr, k = bench.build_problem(cfg, False)
 ctx = hip.Context(0)
-inv, keep = bench.coarse_inverse_device(lv[0].A)
-mg = hip.Multigrid(ctx, lv, tr, k, coarse_inv=inv)
+mg = hip.Multigrid(ctx, lv, tr, k)
 L = lv[-1]
 b = np.random.default_rng(0).standard_normal(L.n); b[L.bc_dofs] = 0
 db, dx = ctx.vec(b), ctx.vec(L.n)

@@ -157,6 +157,51 @@ def test_multiplicative_sweeps_through_the_option_dictionary(dim):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("dim", [2, 3])
+def test_multiplicative_sweeps_over_macro_star_patches(dim):
+    """--patch macro --patch-composition multiplicative (alfi/solver.py:322-324 with 339-342): MacroStar patches (74 dofs =
+    37 nodes in 2-D, up to 1533 dofs = 511 nodes in 3-D, i.e. beyond the 64 nodes a wave sweeps) ordered by the problem's
+    relaxation_direction, symmetrised sweep with the workgroup-per-patch kernel; PatchPC.apply and the whole PCMG against
+    the oracle's sequential sweep."""
+    import alfi_amd
+    from alfi_amd import hip
+    from oracle import alfi_oracle as O
+    prob = TwoDimLidDrivenCavityProblem(4) if dim == 2 else ThreeDimLidDrivenCavityProblem(2)
+    lv, tr = build_hierarchy(prob, 1, 2, Re=100.0)
+    ctx = hip.Context(0)
+    L = lv[-1]
+    opts = alfi_amd.mg_levels_solver(dim, patch="macro", patch_composition="multiplicative", smoothing=2,
+                                     relaxation_direction=prob.relaxation_direction())
+    assert opts["patch_pc_patch_construction_MacroStar_sort_order"] == "0+:1-"
+    pc = alfi_amd.PC(ctx, L, options=opts)
+    obj = alfi_amd.HipPatchPC()
+    obj.initialize(pc)
+    sizes = np.diff(obj.patch_ptr)
+    assert sizes.max() == (74 if dim == 2 else 1533) and obj.wavefronts >= 1
+    x = np.random.default_rng(3).standard_normal(L.n)
+    y = np.zeros(L.n)
+    obj.apply(pc, x, y)
+    sm = O.PatchSmoother(L.A.to_scipy().tocsr(), obj.patch_ptr, obj.patch_dofs, L.bc_dofs, "multiplicative",
+                         obj.iterset, True)
+    ref = sm.apply(x)
+    assert np.abs(y - ref).max() < 1e-7 * np.abs(ref).max()
+    add = O.PatchSmoother(L.A.to_scipy().tocsr(), obj.patch_ptr, obj.patch_dofs, L.bc_dofs).apply(x)
+    assert np.abs(add - ref).max() > 1e-3 * np.abs(ref).max()        # it is not the additive operator
+    mg = alfi_amd.HipMG(ctx, lv, tr, alfi_amd.fieldsplit_0_mg(opts))
+    b = np.random.default_rng(4).standard_normal(L.n)
+    b[L.bc_dofs] = 0.0
+    out = np.zeros(L.n)
+    mg.apply(b, out)
+    itersets = [None] + [o.iterset for o in mg.pc_objs[1:]]
+    for Lv, o in zip(lv[1:], mg.pc_objs[1:]):
+        Lv.patch_ptr, Lv.patch_dofs = o.patch_ptr, o.patch_dofs
+    ref = O.build_oracle_mg(lv, tr, 2, local_type="multiplicative", itersets=itersets, symmetrise=True).fcycle(b)
+    assert np.abs(out - ref).max() < 1e-5 * np.abs(ref).max()
+    mg.mg.close()
+    ctx.close()
+
+
+@pytest.mark.gpu
 def test_schoeberl_transfer_object_protocol():
     from alfi_amd import hip, Constant, Function, PkP0SchoeberlTransfer
     from oracle import alfi_oracle as O

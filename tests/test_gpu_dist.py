@@ -67,15 +67,17 @@ def test_partitioned_cycles_match_single_gpu(case, world, robust, overlap, tmp_p
     assert np.abs(dv - ov).max() / np.abs(ov).max() < CYCLE_TOL
 
 
-@pytest.mark.parametrize("exact_norm,tol,transport", [("1", 1e-12, "rccl"), ("0", CYCLE_TOL, "rccl"),
-                                                      ("1", 1e-12, "callback")])
+@pytest.mark.parametrize("exact_norm,tol,transport", [("1", 1e-6, "rccl"), ("0", CYCLE_TOL, "rccl"),
+                                                      ("1", 1e-6, "callback")])
 def test_rccl_code_path_with_a_one_rank_group(tmp_path, exact_norm, tol, transport):
     """The RCCL transports of alfi_amd.dist on the one GPU of the box: a 1-rank process group with the exchange points
     forced on (empty halos, 1-rank all-reduces).  "rccl": the library's own communicator (alfi_ctx_comm_init from a unique
     id, the exchanges issued by the library on its stream -- the product path of bench.py --gpus N); "callback": the
     library calls back into alfi_amd.dist, which issues torch.distributed collectives on the library's stream.  Checks
     that RCCL accepts exactly the calls the 8-GPU run makes and that the cycle still matches the
-    single-GPU result (to rounding with the exact-norm variant; with the one-all-reduce-per-iteration default the 1e-14-level difference in
+    single-GPU result (exact-norm variant: the same algorithm, but the single-GPU smoother sums its reduction partials
+    inside the consuming kernels and multiplies with whole-row SpMV chunks, i.e. in another order -- measured effect of a
+    pure change of summation order on this case: 2e-8 .. 6e-8, scripts/ab_cycle.py) (to rounding with the exact-norm variant; with the one-all-reduce-per-iteration default the 1e-14-level difference in
     |w| is amplified by the chained FGMRES least-squares problems like any other rounding difference: CYCLE_TOL)."""
     import textwrap
     script = tmp_path / "one_rank.py"

@@ -563,3 +563,24 @@ def test_cycle_logic_with_the_device_inverses(ctx, setup):
     print("cycle logic with device inverses [%s]: smoother %.2e, V %.2e, second V %.2e, F %.2e"
           % (setup["name"], es, e1, e2, e3))
     assert max(e1, e2, e3) < ctol
+
+
+def test_coarse_factorisation_by_the_library(ctx, setup):
+    """alfi_coarse_factor (blocked Gauss-Jordan on the matrix cores + Newton-Schulz polish, no library GEMM, no host LAPACK)
+    against a sparse direct solve (the reference: AssembledPC + LU, alfi/solver.py:369-378)."""
+    import scipy.sparse as sp
+    import scipy.sparse.linalg as spla
+    from alfi_amd import hip
+    L = setup["lv"][0]
+    dl = hip.Level(ctx, L.A, L.bc_dofs)
+    res = dl.coarse_factor()
+    assert 0.0 <= res < 1e-8
+    A = sp.csc_matrix(L.A.to_scipy())
+    lu = spla.splu(A)
+    b = rhs(L.n, L.bc_dofs, 31)
+    db, dx = ctx.vec(b), ctx.vec(L.n)
+    dl.coarse_solve(db, dx)
+    err = relerr(dx.get(), lu.solve(b))
+    print("coarse factorisation [%s]: n = %d, probe %.2e, vs splu %.2e" % (setup["name"], L.n, res, err))
+    assert err < 1e-10
+    dl.close()
