@@ -919,12 +919,69 @@ static int ensure_fgmres_workspace(alfi_level* L, int k) {
   return 0;
 }
 
+// FGMRES(k) on a small, unpartitioned level with the additive smoother: four launches per iteration (see the kernels in
+// kernels_vec.hip).  Same algorithm as the general path below -- right-preconditioned FGMRES, classical Gram-Schmidt,
+// explicit norms -- with the normalisation of the new Krylov vector moved behind the patch solves (they are linear).
+static int smooth_fgmres_fused(alfi_level* L, int k, const double* db, double* dx, int nonzero_guess) {
+  alfi_ctx* ctx = L->ctx;
+  const int K = L->kmax;
+  const int64_t n = L->n;
+  HsLayout hl(K);
+  double *V = L->V, *Z = L->Z, *w = L->w, *hs = L->hs;
+  double* hdots = hs + hl.hd;
+  int t;
+  if (nonzero_guess) {
+    ALFI_CHECK(alfi_residual(L, db, dx, w));
+  } else {
+    ALFI_HIP_CHECK(ctx, hipMemsetAsync(dx, 0, sizeof(double) * n, ctx->stream));
+    t = alfi_prof_begin(ctx, ALFI_EV_BLAS1);
+    ALFI_CHECK(launch_copy(ctx, w, db, n));
+    alfi_prof_end(ctx, t);
+  }
+  t = alfi_prof_begin(ctx, ALFI_EV_BLAS1);
+  ALFI_CHECK(launch_norm_partials(ctx, w, n));
+  alfi_prof_end(ctx, t);
+  const int G = red_blocks_for(n);
+  const double* normpart = ctx->red_partial;
+  for (int j = 0; j < k; ++j) {
+    double* zj = Z + (int64_t)j * n;
+    ALFI_CHECK(launch_patch_apply_range(L, 0, L->npatch, w));                                   // stage <- patch solves of w
+    t = alfi_prof_begin(ctx, ALFI_EV_PATCH_SCATTER);
+    ALFI_CHECK(launch_patch_sum_scale(L, w, zj, V + (int64_t)j * n, normpart, G, hdots, hs, j, K));   // z_j, v_j, H column j-1
+    alfi_prof_end(ctx, t);
+    int nb = 0;
+    t = alfi_prof_begin(ctx, ALFI_EV_MATMULT);
+    ALFI_CHECK(launch_bsr_spmv_dot(ctx, L->A_own, zj, w, V, n, j + 1, ctx->red_partial, &nb));    // w = A z_j, V^T w partials
+    alfi_prof_end(ctx, t);
+    t = alfi_prof_begin(ctx, ALFI_EV_BLAS1);
+    ALFI_CHECK(launch_multi_axpy_norm(ctx, V, n, j + 1, hdots, w, n, ctx->red_partial2, nb));     // h, w -= V h, |w|^2 partials
+    alfi_prof_end(ctx, t);
+    normpart = ctx->red_partial2;
+  }
+  t = alfi_prof_begin(ctx, ALFI_EV_BLAS1);
+  ALFI_CHECK(launch_fgmres_finish_fused(ctx, normpart, G, hdots, hs, k, K));                       // H column k-1, y
+  ALFI_CHECK(launch_update_solution(ctx, dx, Z, n, k, hs + hl.y, n));
+  alfi_prof_end(ctx, t);
+  return 0;
+}
+
 int alfi_smooth_fgmres(alfi_level* L, int k, const double* db, double* dx, int nonzero_guess) {
   alfi_ctx* ctx = L->ctx;
   if (k < 1) return alfi_set_error(ctx, ALFI_E_ARG, "k must be >= 1");
   if (!L->factored) return alfi_set_error(ctx, ALFI_E_STATE, "alfi_smooth_fgmres before alfi_patches_factor");
   ALFI_CHECK(ensure_fgmres_workspace(L, k));
   ctx->cur_tag = L->id;
+  {
+    // small unpartitioned levels (<= 1 M dofs, <= 2 M operator blocks: a smoother iteration is launch latency, not
+    // bandwidth): the four-launch iteration.  ALFI_FUSED_SMOOTHER=0 keeps the general path (A/B measurements).
+    static const bool allow = !(getenv("ALFI_FUSED_SMOOTHER") && atoi(getenv("ALFI_FUSED_SMOOTHER")) == 0);
+    // (rows of up to ~32 blocks -- the 2-D operators; with the 50 .. 100 blocks per row of the 3-D ones the flat segmented
+    // product of the general path is the faster kernel and the fused iteration gains nothing: cfg3 19.0 vs 18.9 ms, cfg2
+    // 5.10 vs 5.43 ms, same box)
+    if (allow && !L->distributed && L->n_own == L->n && !L->mult && k + 1 <= 16 && L->A_own.flat &&
+        L->A_own.nnzb <= SPMV_ALIGNED_MAX && L->A_own.nnzb <= 32 * L->A_own.nbrows && red_blocks_for(L->n) <= 256)
+      return smooth_fgmres_fused(L, k, db, dx, nonzero_guess);
+  }
   const int K = L->kmax;
   const int64_t n = L->n_own;    // vector kernels and reductions run on the owned prefix
   const int64_t ldv = L->n;      // stride of the Krylov bases (local length incl. ghost slots)

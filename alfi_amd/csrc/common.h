@@ -344,4 +344,12 @@ int launch_multi_dot(alfi_ctx* ctx, const double* V, int64_t stride, int nv, con
 int launch_multi_axpy_norm(alfi_ctx* ctx, const double* V, int64_t stride, int nv, double* h, double* w, int64_t n,
                            double* norm_partial, int hblocks);
 int launch_fgmres_finish(alfi_ctx* ctx, double* hs, int k, int K);  // back substitution -> y
+// fused smoother iteration of the small levels (kernels_vec.hip): z = f * (dof-wise sum of the staged patch results),
+// v = f * w with f = 1 / |w| from the norm partials, and column j - 1 of the Hessenberg (j == 0: the rotated rhs)
+int launch_patch_sum_scale(alfi_level* lvl, const double* w, double* z, double* v, const double* normpart, int nblocks,
+                           const double* h, double* hs, int j, int K);
+// w = A z with the partials of V_v . w (v < nv <= 16) in the same pass; *nblocks = number of partials per vector
+int launch_bsr_spmv_dot(alfi_ctx* ctx, const DevBSR& A, const double* z, double* w, const double* V, int64_t stride, int nv,
+                        double* partial, int* nblocks);
+int launch_fgmres_finish_fused(alfi_ctx* ctx, const double* normpart, int nblocks, const double* h, double* hs, int k, int K);
 int launch_update_solution(alfi_ctx* ctx, double* x, const double* Z, int64_t stride, int k, const double* y, int64_t n);

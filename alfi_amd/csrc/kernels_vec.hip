@@ -540,6 +540,134 @@ __device__ __forceinline__ double pythagoras_norm2(const double* ww, const doubl
   return s > 0.0 ? s : 0.0;
 }
 
+// one thread: column j of the Hessenberg from the CGS dots h[0..j] and tt = |w_new|, Givens update, rotated rhs
+__device__ __forceinline__ void hessenberg_column(double* __restrict__ hs, int K, int j, const double* __restrict__ h,
+                                                  double tt) {
+  HsLayout L(K);
+  hs[L.tt] = tt;
+  double* hcol = hs + L.H(j);
+  for (int i = 0; i <= j; ++i) hcol[i] = h[i];
+  hcol[j + 1] = tt;
+  double* cs = hs + L.cs;
+  double* sn = hs + L.sn;
+  double* grs = hs + L.grs;
+  for (int i = 0; i < j; ++i) {
+    const double t = hcol[i];
+    hcol[i] = cs[i] * t + sn[i] * hcol[i + 1];
+    hcol[i + 1] = -sn[i] * t + cs[i] * hcol[i + 1];
+  }
+  const double den = hypot(hcol[j], hcol[j + 1]);
+  if (den != 0.0) {
+    cs[j] = hcol[j] / den;
+    sn[j] = hcol[j + 1] / den;
+  } else {
+    cs[j] = 1.0;
+    sn[j] = 0.0;
+  }
+  grs[j + 1] = -sn[j] * grs[j];
+  grs[j] = cs[j] * grs[j];
+  hcol[j] = den;
+  hcol[j + 1] = 0.0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Fused smoother iteration for small levels (a smoother iteration there is a chain of launches of a few microseconds
+// each: fewer, fatter launches).  Per FGMRES iteration j, with w = the unnormalised new Krylov direction:
+//     patch apply on w (existing kernels; the smoother is linear, so the normalisation can follow the solves),
+//     patch_sum_scale_kernel :  f = 1 / |w| from the norm partials;  z_j = f * (sum of the staged patch results),
+//                               v_j = f * w;  one thread finishes column j-1 of the Hessenberg (or starts the rotated rhs),
+//     bsr_spmv_dot_kernel    :  w = A z_j and the partials of V_i . w, i <= j, in the same pass over the rows,
+//     multi_axpy_norm_kernel :  h from the partials, w -= V h, norm partials
+// -- four launches instead of eight.
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void patch_sum_scale_kernel(int64_t n, const int32_t* __restrict__ dof_ptr,
+                                                               const int32_t* __restrict__ dof_pos,
+                                                               const double* __restrict__ stage,
+                                                               const uint8_t* __restrict__ bc_mask,
+                                                               const double* __restrict__ w, double* __restrict__ z,
+                                                               double* __restrict__ v,
+                                                               const double* __restrict__ normpart, int nblocks,
+                                                               const double* __restrict__ h, double* __restrict__ hs, int j,
+                                                               int K) {
+  double s2[1];
+  block_reduce_partials<1>(normpart, nblocks, s2);
+  const double tt = sqrt(s2[0]);
+  const double f = tt != 0.0 ? 1.0 / tt : 0.0;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    if (j == 0) {                       // beta = |r0|, rotated rhs = beta e_1
+      HsLayout L(K);
+      hs[L.beta] = tt;
+      hs[L.grs] = tt;
+      for (int i = 1; i <= K; ++i) hs[L.grs + i] = 0.0;
+    } else {
+      hessenberg_column(hs, K, j - 1, h, tt);
+    }
+  }
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    double s = 0.0;
+    for (int32_t q = dof_ptr[i]; q < dof_ptr[i + 1]; ++q) s += stage[dof_pos[q]];
+    const double wi = w[i];
+    z[i] = f * (bc_mask[i] ? wi : s);   // Dirichlet dofs: the smoother copies its argument there
+    v[i] = f * wi;
+  }
+}
+
+// w = A z on the block rows [0, nbrows) of a flat-layout BSR matrix, LPR lanes per block row, and in the same pass the
+// partials of V_v . w for v < NV (gridDim.x <= 256 blocks, grid-stride over the rows)
+template <int BS, int LPR, int NV>
+__global__ __launch_bounds__(256) void bsr_spmv_dot_kernel(int64_t nbrows, const int32_t* __restrict__ rowptr,
+                                                            const int32_t* __restrict__ colflag,
+                                                            const double* __restrict__ vals,
+                                                            const double* __restrict__ z, double* __restrict__ w,
+                                                            const double* __restrict__ V, int64_t stride,
+                                                            double* __restrict__ partial) {
+  constexpr int BB = BS * BS;
+  const int l = threadIdx.x % LPR;
+  double acc[NV];
+#pragma unroll
+  for (int v = 0; v < NV; ++v) acc[v] = 0.0;
+  for (int64_t row = ((int64_t)blockIdx.x * 256 + threadIdx.x) / LPR; row < nbrows;
+       row += (int64_t)gridDim.x * (256 / LPR)) {
+    double s[BS];
+#pragma unroll
+    for (int r = 0; r < BS; ++r) s[r] = 0.0;
+    const int32_t lo = rowptr[row], hi = rowptr[row + 1];
+    for (int32_t k = lo + l; k < hi; k += LPR) {
+      const int64_t col = colflag[k] & 0x7fffffff;
+      const double* vb = vals + ((int64_t)k >> 6) * (64 * BB);
+      const int kl = k & 63;
+      double a[BB], xv[BS];
+#pragma unroll
+      for (int q = 0; q < BB / 2; ++q) {
+        const spmv_d2 t = *(reinterpret_cast<const spmv_d2*>(vb + q * 128) + kl);
+        a[2 * q] = t.x;
+        a[2 * q + 1] = t.y;
+      }
+      if (BB & 1) a[BB - 1] = vb[(BB / 2) * 128 + kl];
+#pragma unroll
+      for (int c = 0; c < BS; ++c) xv[c] = z[col * BS + c];
+#pragma unroll
+      for (int r = 0; r < BS; ++r)
+#pragma unroll
+        for (int c = 0; c < BS; ++c) s[r] = __builtin_fma(a[r * BS + c], xv[c], s[r]);
+    }
+#pragma unroll
+    for (int o = LPR / 2; o > 0; o >>= 1)
+#pragma unroll
+      for (int r = 0; r < BS; ++r) s[r] += __shfl_xor(s[r], o);
+    if (l == 0) {
+#pragma unroll
+      for (int r = 0; r < BS; ++r) {
+        const int64_t i = row * BS + r;
+        w[i] = s[r];
+#pragma unroll
+        for (int v = 0; v < NV; ++v) acc[v] = __builtin_fma(V[v * stride + i], s[r], acc[v]);
+      }
+    }
+  }
+  block_store_partials<NV>(acc, partial);
+}
+
 __global__ __launch_bounds__(256) void hessenberg_update_kernel(const double* __restrict__ partial, int nblocks,
                                                                  const double* __restrict__ h,
                                                                  double* __restrict__ hs, int j, int K,
@@ -553,34 +681,7 @@ __global__ __launch_bounds__(256) void hessenberg_update_kernel(const double* __
     if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
     __syncthreads();
   }
-  if (threadIdx.x == 0) {
-    HsLayout L(K);
-    const double tt = sqrt(ww ? pythagoras_norm2(ww, h, j) : red[0]);
-    hs[L.tt] = tt;
-    double* hcol = hs + L.H(j);
-    for (int i = 0; i <= j; ++i) hcol[i] = h[i];
-    hcol[j + 1] = tt;
-    double* cs = hs + L.cs;
-    double* sn = hs + L.sn;
-    double* grs = hs + L.grs;
-    for (int i = 0; i < j; ++i) {
-      const double t = hcol[i];
-      hcol[i] = cs[i] * t + sn[i] * hcol[i + 1];
-      hcol[i + 1] = -sn[i] * t + cs[i] * hcol[i + 1];
-    }
-    const double den = hypot(hcol[j], hcol[j + 1]);
-    if (den != 0.0) {
-      cs[j] = hcol[j] / den;
-      sn[j] = hcol[j + 1] / den;
-    } else {
-      cs[j] = 1.0;
-      sn[j] = 0.0;
-    }
-    grs[j + 1] = -sn[j] * grs[j];
-    grs[j] = cs[j] * grs[j];
-    hcol[j] = den;
-    hcol[j + 1] = 0.0;
-  }
+  if (threadIdx.x == 0) hessenberg_column(hs, K, j, h, sqrt(ww ? pythagoras_norm2(ww, h, j) : red[0]));
 }
 
 // back substitution on the triangularised Hessenberg (KSPFGMRESBuildSoln [3P]) -> y
@@ -669,33 +770,7 @@ __global__ __launch_bounds__(256) void hessenberg_scale_kernel(const double* __r
     __syncthreads();
   }
   const double tt = sqrt(ww ? pythagoras_norm2(ww, h, j) : red[0]);
-  if (blockIdx.x == 0 && threadIdx.x == 0) {
-    HsLayout L(K);
-    hs[L.tt] = tt;
-    double* hcol = hs + L.H(j);
-    for (int i = 0; i <= j; ++i) hcol[i] = h[i];
-    hcol[j + 1] = tt;
-    double* cs = hs + L.cs;
-    double* sn = hs + L.sn;
-    double* grs = hs + L.grs;
-    for (int i = 0; i < j; ++i) {
-      const double t = hcol[i];
-      hcol[i] = cs[i] * t + sn[i] * hcol[i + 1];
-      hcol[i + 1] = -sn[i] * t + cs[i] * hcol[i + 1];
-    }
-    const double den = hypot(hcol[j], hcol[j + 1]);
-    if (den != 0.0) {
-      cs[j] = hcol[j] / den;
-      sn[j] = hcol[j + 1] / den;
-    } else {
-      cs[j] = 1.0;
-      sn[j] = 0.0;
-    }
-    grs[j + 1] = -sn[j] * grs[j];
-    grs[j] = cs[j] * grs[j];
-    hcol[j] = den;
-    hcol[j + 1] = 0.0;
-  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) hessenberg_column(hs, K, j, h, tt);
   const double f = tt != 0.0 ? 1.0 / tt : 0.0;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) vnext[i] = w[i] * f;
 }
@@ -766,6 +841,77 @@ int launch_halo_pack(alfi_ctx* ctx, double* buf, const double* v, const int32_t*
 int launch_halo_add(alfi_ctx* ctx, double* v, const double* buf, const int32_t* rev_nodes, const int32_t* rev_ptr,
                     const int32_t* rev_pos, int64_t nuniq, int bs) {
   ALFI_LAUNCH_EW(halo_add_kernel, nuniq * bs, v, buf, rev_nodes, rev_ptr, rev_pos, nuniq * bs, bs);
+  return 0;
+}
+
+int launch_patch_sum_scale(alfi_level* L, const double* w, double* z, double* v, const double* normpart, int nblocks,
+                           const double* h, double* hs, int j, int K) {
+  alfi_ctx* ctx = L->ctx;
+  const int64_t n = L->n;
+  hipLaunchKernelGGL(patch_sum_scale_kernel, ew_grid(n), dim3(256), 0, ctx->stream, n, L->dof_ptr, L->dof_pos, L->stage,
+                     L->bc_mask, w, z, v, normpart, nblocks, h, hs, j, K);
+  ALFI_HIP_CHECK(ctx, hipGetLastError());
+  return 0;
+}
+
+template <int BS, int LPR>
+static int launch_spmv_dot_lpr(alfi_ctx* ctx, const DevBSR& A, const double* z, double* w, const double* V, int64_t stride,
+                               int nv, double* partial, int* nblocks) {
+  const int64_t rows_per_block = 256 / LPR;
+  int64_t g = (A.nbrows + rows_per_block - 1) / rows_per_block;
+  if (g > 256) g = 256;
+  if (g < 1) g = 1;
+  *nblocks = (int)g;
+#define ALFI_CASE(N)                                                                                                 \
+  case N:                                                                                                            \
+    hipLaunchKernelGGL((bsr_spmv_dot_kernel<BS, LPR, N>), dim3((unsigned)g), dim3(256), 0, ctx->stream, A.nbrows,      \
+                       A.rowptr, A.colidx, A.vals, z, w, V, stride, partial);                                        \
+    break;
+  ALFI_NV_SWITCH(nv, ALFI_CASE)
+#undef ALFI_CASE
+  ALFI_HIP_CHECK(ctx, hipGetLastError());
+  return 0;
+}
+
+// w = A z on the rows of a flat-layout matrix with the dot partials of nv <= 16 vectors; *nblocks = partials written
+int launch_bsr_spmv_dot(alfi_ctx* ctx, const DevBSR& A, const double* z, double* w, const double* V, int64_t stride, int nv,
+                        double* partial, int* nblocks) {
+  if (!A.flat || nv < 1 || nv > 16) return alfi_set_error(ctx, ALFI_E_STATE, "fused SpMV needs the flat layout and <= 16 vectors");
+  const double avg = A.nbrows > 0 ? (double)A.nnzb / (double)A.nbrows : 0.0;
+  if (A.bs == 2) {
+    if (avg <= 12) return launch_spmv_dot_lpr<2, 4>(ctx, A, z, w, V, stride, nv, partial, nblocks);
+    if (avg <= 40) return launch_spmv_dot_lpr<2, 8>(ctx, A, z, w, V, stride, nv, partial, nblocks);
+    return launch_spmv_dot_lpr<2, 32>(ctx, A, z, w, V, stride, nv, partial, nblocks);
+  }
+  if (A.bs == 3) {
+    if (avg <= 24) return launch_spmv_dot_lpr<3, 8>(ctx, A, z, w, V, stride, nv, partial, nblocks);
+    if (avg <= 48) return launch_spmv_dot_lpr<3, 16>(ctx, A, z, w, V, stride, nv, partial, nblocks);
+    return launch_spmv_dot_lpr<3, 32>(ctx, A, z, w, V, stride, nv, partial, nblocks);
+  }
+  return alfi_set_error(ctx, ALFI_E_ARG, "unsupported block size %d", A.bs);
+}
+
+// column `col` of the Hessenberg from (h, partials of |w|^2), then the back substitution (last step of the fused smoother)
+__global__ __launch_bounds__(256) void fgmres_finish_fused_kernel(const double* __restrict__ normpart, int nblocks,
+                                                                  const double* __restrict__ h, double* __restrict__ hs,
+                                                                  int k, int K) {
+  double s2[1];
+  block_reduce_partials<1>(normpart, nblocks, s2);
+  if (threadIdx.x != 0) return;
+  hessenberg_column(hs, K, k - 1, h, sqrt(s2[0]));
+  HsLayout L(K);
+  double* y = hs + L.y;
+  const double* grs = hs + L.grs;
+  for (int i = k - 1; i >= 0; --i) {
+    double s = grs[i];
+    for (int q = i + 1; q < k; ++q) s -= hs[L.H(q) + i] * y[q];
+    const double d = hs[L.H(i) + i];
+    y[i] = d != 0.0 ? s / d : 0.0;
+  }
+}
+int launch_fgmres_finish_fused(alfi_ctx* ctx, const double* normpart, int nblocks, const double* h, double* hs, int k, int K) {
+  hipLaunchKernelGGL(fgmres_finish_fused_kernel, dim3(1), dim3(256), 0, ctx->stream, normpart, nblocks, h, hs, k, K);
+  ALFI_HIP_CHECK(ctx, hipGetLastError());
   return 0;
 }
 

@@ -40,7 +40,7 @@ class HipNavierStokesSolver(object):
     keys Re, nu, linear_iter, nonlinear_iter, time."""
 
     def __init__(self, problem, nref, k, gamma=1e4, smoothing=None, restriction=False, ctx=None, verbose=False,
-                 snes_rtol=None, snes_atol=None, snes_max_it=20, discretisation="pkp0", stabilisation_type=None,
+                 snes_rtol=None, snes_atol=None, snes_stol=1e-6, snes_max_it=20, discretisation="pkp0", stabilisation_type=None,
                  stabilisation_weight=None, supg_magic=9.0):
         """discretisation: "pkp0" ([P_k(+FB)]^d - P0 on the uniform hierarchy, ConstantPressureSolver solver.py:561-602) or
         "sv" ([P_k]^d - P_{k-1}^dg on the barycentric hierarchy with macro-star patches, ScottVogeliusSolver :604-662)."""
@@ -89,6 +89,7 @@ class HipNavierStokesSolver(object):
         tol2, tol3 = (1e-9, 1e-8), (1e-8, 1e-8)                            # snes_rtol / snes_atol, solver.py:484-499
         self.snes_rtol = snes_rtol if snes_rtol is not None else (tol2 if dim == 2 else tol3)[0]
         self.snes_atol = snes_atol if snes_atol is not None else (tol2 if dim == 2 else tol3)[1]
+        self.snes_stol = snes_stol                                          # solver.py:490, 498
         self.snes_max_it = snes_max_it
         self.n_u, self.n_p = L.n, self.B.shape[0]
         # state z = (u, p): zero with the Dirichlet values imposed (what Firedrake does to the initial guess)
@@ -192,7 +193,8 @@ class HipNavierStokesSolver(object):
         Fu, Fp = self.residual(u, p, adv)
         f0 = fnorm = float(np.sqrt(Fu @ Fu + Fp @ Fp))
         hist = [fnorm]
-        while fnorm > max(self.snes_rtol * f0, self.snes_atol) and newton_its < self.snes_max_it:
+        small_step = False
+        while fnorm > max(self.snes_rtol * f0, self.snes_atol) and newton_its < self.snes_max_it and not small_step:
             self._rediscretise(u, adv)
             rhs = -np.concatenate([Fu, Fp])
             delta, its, rn = self._linear_solve(rhs)
@@ -203,6 +205,9 @@ class HipNavierStokesSolver(object):
             Fu, Fp = self.residual(u, p, adv)
             fnorm = float(np.sqrt(Fu @ Fu + Fp @ Fp))
             hist.append(fnorm)
+            # SNESConvergedDefault [3P] with snes_stol (solver.py:490, 498): the step is small relative to the iterate
+            if np.linalg.norm(delta) < self.snes_stol * float(np.sqrt(u @ u + p @ p)):
+                small_step = True
             if self.verbose:
                 print("[alfi_amd] Re %g  Newton %d  |F| %.3e  (%d Krylov its, linear residual %.2e)"
                       % (re, newton_its, fnorm, its, rn), flush=True)
@@ -211,7 +216,8 @@ class HipNavierStokesSolver(object):
         self.u, self.p = u, p
         info = {"Re": re, "nu": self.nu, "linear_iter": lin_its, "nonlinear_iter": newton_its,
                 "time": (time.time() - t0) / 60.0, "residual_history": hist,
-                "converged": fnorm <= max(self.snes_rtol * f0, self.snes_atol)}
+                "converged": small_step or fnorm <= max(self.snes_rtol * f0, self.snes_atol),
+                "converged_reason": "SNORM_RELATIVE" if small_step else "FNORM"}
         return (u, p), info
 
 

@@ -196,12 +196,20 @@ class OrderedRelaxation(object):
         return sweeps
 
     def iteration_order(self, centroids):
-        """Concatenation of one coordinate-sorted permutation per sweep (relaxation.py:139-150), or the identity."""
+        """Concatenation of one coordinate-sorted permutation per sweep (relaxation.py:139-150), or the identity.
+
+        With several '|'-separated sweeps the reference's key functions are closures over the loop variable ``sortdata``
+        (relaxation.py:98-108), so at sort time EVERY sweep uses the key of the LAST one: 'a|b' yields the b-ordering twice.
+        That literal behaviour is the default here (a drop-in must visit the patches in the same order);
+        ``pc_patch_construction_<Name>_sort_order_per_sweep: True`` gives every sweep its own key instead.  The shipped
+        problems use a single sweep ('0+:1-', examples/ldc2d/ldc2d.py:39), where both agree."""
         sweeps = self.parse_sort_order(self.opts.getString("pc_patch_construction_%s_sort_order" % self.name,
                                                            default=None))
         n = len(centroids)
         if sweeps is None:
             return np.arange(n, dtype=np.int64)
+        if not self.opts.getBool("pc_patch_construction_%s_sort_order_per_sweep" % self.name, default=False):
+            sweeps = [sweeps[-1]] * len(sweeps)
         X = np.asarray(centroids, dtype=np.float64).reshape(n, -1)
         order = []
         for keys in sweeps:

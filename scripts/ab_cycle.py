@@ -20,8 +20,10 @@ mg.fcycle(db, dx)
 np.savez(sys.argv[2], xv=xv, xf=dx.get())
 ''' % ROOT
 case = sys.argv[1] if len(sys.argv) > 1 else "3d-P2FB"
-variants = {"default": {}, "nofuse": {"ALFI_FUSED_REDUCE": "0"}, "noalign": {"ALFI_SPMV_ALIGNED": "0"},
-            "neither": {"ALFI_FUSED_REDUCE": "0", "ALFI_SPMV_ALIGNED": "0"}}
+variants = {"default": {}, "nofusedsm": {"ALFI_FUSED_SMOOTHER": "0"},
+            "nofuse": {"ALFI_FUSED_SMOOTHER": "0", "ALFI_FUSED_REDUCE": "0"},
+            "noalign": {"ALFI_FUSED_SMOOTHER": "0", "ALFI_SPMV_ALIGNED": "0"},
+            "neither": {"ALFI_FUSED_SMOOTHER": "0", "ALFI_FUSED_REDUCE": "0", "ALFI_SPMV_ALIGNED": "0"}}
 out = {}
 for name, env in variants.items():
     f = "/tmp/ab_%s.npz" % name

@@ -50,6 +50,15 @@ def test_sort_order_grammar_and_sweeps():
     pc2 = _FakePC(L, {"pc_patch_construction_Star_sort_order": "0+|0-"})
     _, it2 = Star()(pc2)
     assert len(it2) == 2 * len(patches)                         # one permutation per '|' sweep (relaxation.py:145-147)
+    # the reference's key functions close over the loop variable (relaxation.py:98-108): both sweeps of "0+|0-" use the LAST
+    # key, i.e. the descending-x ordering twice; the per-sweep option gives the two different orderings
+    n = len(patches)
+    x2 = np.array([dm.point_coords(dm.vStart + v) for v in range(L.V.mesh.num_vertices)])[:, 0]
+    assert np.array_equal(it2[:n], it2[n:]) and (np.diff(x2[it2[:n]]) <= 0).all()
+    pc3 = _FakePC(L, {"pc_patch_construction_Star_sort_order": "0+|0-",
+                      "pc_patch_construction_Star_sort_order_per_sweep": True})
+    _, it3 = Star()(pc3)
+    assert (np.diff(x2[it3[:n]]) >= 0).all() and (np.diff(x2[it3[n:]]) <= 0).all()
 
 
 def test_option_dictionary_has_the_reference_keys():

@@ -17,7 +17,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
                                      ({"ALFI_SPMV": "legacy"}, 1e-5),             # row-per-wave SpMV, (nnzb, bs, bs) values
                                      ({"ALFI_BIG_SPLIT": "1"}, 1e-5),             # one workgroup per large patch
                                      ({"ALFI_BIG_SCRATCH_MB": "64"}, 1e-5),       # many small factorisation batches
-                                     ({"ALFI_BIG_POLISH": "0"}, 5e-2),            # block elimination without Newton-Schulz
+                                     # block elimination without the Newton-Schulz polish: the residual probe of
+                                     # alfi_patches_factor (7e-6 here) would reject these inverses at its default 1e-6
+                                     ({"ALFI_BIG_POLISH": "0", "ALFI_PATCH_CHECK_TOL": "1e-3"}, 5e-2),
                                      ({"ALFI_TRANSFER_REFINE": "0"}, 1e-3)])      # explicit block inverses without refinement
 def test_switch(env, tol):
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "gpu_env_variant_worker.py")],

@@ -493,7 +493,7 @@ def test_cycles_replayed_as_hip_graphs(ctx, composition):
 def test_cycle_logic_with_the_device_inverses(ctx, setup):
     """Separates inversion rounding from cycle logic: the oracle gets the DEVICE's patch inverses (alfi_patch_get_inverse)
     and interior-block inverses (alfi_transfer_get_block_inverse) in place of its LAPACK ones; what is left to differ is
-    the order of floating-point sums.  Transfers then agree to 1e-10, the smoother to 1e-9, V- and F-cycles to 5e-9 -- against CYCLE_TOL = 1e-5
+    the order of floating-point sums.  Smoother then agrees to 1e-9, transfers, V- and F-cycles to 5e-9 -- against CYCLE_TOL = 1e-5
     with independently inverted patches -- so a wrong Givens rotation, Hessenberg column, restriction or coarse correction
     cannot hide inside the inversion tolerance."""
     from oracle import alfi_oracle as O
@@ -538,14 +538,16 @@ def test_cycle_logic_with_the_device_inverses(ctx, setup):
         Lc, Lf = lv[i], lv[i + 1]
         xc, rf = rhs(Lc.n, Lc.bc_dofs, 23), rhs(Lf.n, [], 24)
         dxc, dxf, drf, drc = ctx.vec(xc), ctx.vec(Lf.n), ctx.vec(rf), ctx.vec(Lc.n)
+        # interior blocks nu K + gamma D have condition numbers ~ gamma / nu (1e7 at Re 1000): the order of the 24 .. 27
+        # terms of X b alone moves the result by cond * eps ~ 1e-9 (measured 8e-10 on 3d-P2FB)
         dt.prolong(dxc, dxf)
         r = ot.st.prolong(xc)
         r[Lf.bc_dofs] = 0
-        assert relerr(dxf.get(), r) < tol
+        assert relerr(dxf.get(), r) < 5e-9
         dt.restrict(drf, drc, robust=True)
         r = ot.st.restrict(rf)
         r[Lc.bc_dofs] = 0
-        assert relerr(drc.get(), r) < tol
+        assert relerr(drc.get(), r) < 5e-9
     # whole cycles chain 2k .. 2k (L + 1) smoother iterations whose least-squares problems amplify the 1e-16 differences
     # of the summation orders: measured 8e-11 .. 9.3e-10 on these cases -- compared at 5e-9, three to four orders below
     # CYCLE_TOL
