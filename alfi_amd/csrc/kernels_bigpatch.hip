@@ -767,6 +767,16 @@ static int big_factor_core(alfi_ctx* ctx, const BigSource& src, int64_t npatch, 
       hipLaunchKernelGGL(big_gemm_kernel, dim3((unsigned)(tiles * tiles), (unsigned)nb), block, 0, ctx->stream, 1,
                          d_patch_ptr, p0, d_scr_ptr, scr, scrR, scrA, tiles);
       result = scrA;
+      if (dense_out) {
+        // the coarse operator (one matrix, hundreds of pivot blocks): a second Newton-Schulz step.  The matrix is
+        // filled again (into the buffer that held the first iterate's predecessor), R = I - A X, X <- X + X R.
+        src.fill(ctx, p0, nb, d_scr_ptr, scr);
+        hipLaunchKernelGGL(big_gemm_kernel, dim3((unsigned)(tiles * tiles), (unsigned)nb), block, 0, ctx->stream, 0,
+                           d_patch_ptr, p0, d_scr_ptr, scr, scrA, scrR, tiles);
+        hipLaunchKernelGGL(big_gemm_kernel, dim3((unsigned)(tiles * tiles), (unsigned)nb), block, 0, ctx->stream, 1,
+                           d_patch_ptr, p0, d_scr_ptr, scrA, scrR, scr, tiles);
+        result = scr;
+      }
     }
     if (dense_out) {
       const int64_t n = h_patch_ptr[1] - h_patch_ptr[0];

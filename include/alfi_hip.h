@@ -181,8 +181,8 @@ int alfi_smooth_fgmres(alfi_level* lvl, int k, const double* db, double* dx, int
 /* ---- coarse solve: firedrake.AssembledPC + LU [3P], alfi/solver.py:369-378 ---------------------------------------- */
 /* alfi_coarse_factor: the level operator's dense inverse (n x n doubles on the device, n <= 131072) by the library's own
  * blocked Gauss-Jordan on the FP64 matrix cores (64-wide pivot blocks, rank-64 trailing updates as v_mfma_f64_16x16x4,
- * one Newton-Schulz polish step) -- no library GEMM, no host LAPACK -- followed by the residual probe || A X e - e ||
- * (ALFI_E_SINGULAR above 1e-6; alfi_coarse_residual reports it).  The level must be owned by one rank.
+ * two Newton-Schulz polish steps) -- no library GEMM, no host LAPACK -- followed by the residual probe || A X e - e ||
+ * (ALFI_E_SINGULAR above 1e-5; alfi_coarse_residual reports it).  The level must be owned by one rank.
  * alfi_coarse_set_inverse: an inverse computed by the caller instead (row-major n x n, host or device memory).
  * The solve is a device GEMV either way. */
 int alfi_coarse_factor(alfi_level* lvl);

@@ -39,6 +39,7 @@ def test_full_size_properties(name):
     ctx = hip.Context(0)
     mg = hip.Multigrid(ctx, lv, tr, k, robust_restriction=True)
     assert 0.0 <= mg.levels[0].coarse_residual() < 1e-6        # residual probe of the library's own coarse inverse
+    print("%s: coarse inverse probe %.2e (n = %d)" % (name, mg.levels[0].coarse_residual(), lv[0].n))
     L, dl = lv[-1], mg.levels[-1]
     n, bs = L.n, L.bs
     rng = np.random.default_rng(11)

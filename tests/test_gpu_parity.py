@@ -266,10 +266,25 @@ def test_patch_sizes_1_to_160_all_row_piece_combinations(ctx, bs):
     dx, dy = ctx.vec(x), ctx.vec(nb * bs)
     lvl.patch_apply(dx, dy)
     assert np.abs(dy.get() - ref).max() < 1e-12 * np.abs(ref).max()
-    # multiplicative sweep in a scrambled order, symmetrised (patches of at most 64 nodes: larger ones are refused)
+    # multiplicative sweep in a scrambled order, symmetrised: first with every patch (patches of more than 64 nodes switch the
+    # level to the workgroup-per-patch sweep kernel), then with the patches of at most 64 nodes (a wave per patch)
+    Sc = S.tocsc()
+
+    def sweep_check():
+        order = rng.permutation(len(sizes))
+        nw = lvl.set_multiplicative(order, True)
+        assert 1 <= nw <= len(sizes)
+        y, r = np.zeros_like(x), x.copy()
+        for p in list(order) + list(order[::-1]):
+            d = dofs[ptr[p]:ptr[p + 1]]
+            dyp = invs[p] @ r[d]
+            y[d] += dyp
+            r -= Sc[:, d] @ dyp
+        y[bc] = x[bc]
+        lvl.patch_apply(dx, dy)
+        assert np.abs(dy.get() - y).max() < 1e-11 * np.abs(y).max()
+    sweep_check()
     if max(sizes) > 64:
-        with pytest.raises(hip.AlfiHipError):
-            lvl.set_multiplicative(np.arange(len(sizes)), True)
         keep = [p for p, sz in enumerate(sizes) if sz <= 64]
         dofs = np.concatenate([dofs[ptr[p]:ptr[p + 1]] for p in keep]).astype(np.int32)
         invs = [invs[p] for p in keep]
@@ -277,19 +292,7 @@ def test_patch_sizes_1_to_160_all_row_piece_combinations(ctx, bs):
         ptr = np.concatenate([[0], np.cumsum([s_ * bs for s_ in sizes])]).astype(np.int64)
         lvl.set_patches(ptr, dofs)
         lvl.factor()
-    order = rng.permutation(len(sizes))
-    nw = lvl.set_multiplicative(order, True)
-    assert 1 <= nw <= len(sizes)
-    y, r = np.zeros_like(x), x.copy()
-    Sc = S.tocsc()
-    for p in list(order) + list(order[::-1]):
-        d = dofs[ptr[p]:ptr[p + 1]]
-        dyp = invs[p] @ r[d]
-        y[d] += dyp
-        r -= Sc[:, d] @ dyp
-    y[bc] = x[bc]
-    lvl.patch_apply(dx, dy)
-    assert np.abs(dy.get() - y).max() < 1e-11 * np.abs(y).max()
+        sweep_check()
     lvl.set_multiplicative(None, False)
     # empty patch set: the smoother reduces to the Dirichlet copy
     lvl.set_patches(np.zeros(1, dtype=np.int64), np.zeros(0, dtype=np.int32))
@@ -549,9 +552,10 @@ def test_cycle_logic_with_the_device_inverses(ctx, setup):
         r[Lc.bc_dofs] = 0
         assert relerr(drc.get(), r) < 5e-9
     # whole cycles chain 2k .. 2k (L + 1) smoother iterations whose least-squares problems amplify the 1e-16 differences
-    # of the summation orders: measured 8e-11 .. 9.3e-10 on these cases -- compared at 5e-9, three to four orders below
-    # CYCLE_TOL
-    ctol = 5e-9
+    # of the summation orders: measured 8e-11 .. 9.3e-10 at Re 100 and 3e-9 .. 5.6e-8 at Re 1000 (3d-P2FB; a pure change
+    # of summation order moves that case by 2e-8 .. 8e-8, scripts/ab_cycle.py) -- compared at 5e-9 / 5e-7, against
+    # CYCLE_TOL = 1e-5 for independently inverted patches
+    ctol = 5e-9 if setup["name"] != "3d-P2FB" else 5e-7      # Re 1000: measured up to 5.6e-8 (F-cycle)
     b = rhs(L.n, L.bc_dofs, 25)
     db, dx = ctx.vec(b), ctx.vec(L.n)
     dmg.vcycle(db, dx)
@@ -584,5 +588,6 @@ def test_coarse_factorisation_by_the_library(ctx, setup):
     dl.coarse_solve(db, dx)
     err = relerr(dx.get(), lu.solve(b))
     print("coarse factorisation [%s]: n = %d, probe %.2e, vs splu %.2e" % (setup["name"], L.n, res, err))
-    assert err < 1e-10
+    # two backward-stable solvers of a system with condition number ~1e7 agree to cond * eps ~ 1e-9 (measured 7e-10)
+    assert err < 1e-8
     dl.close()
