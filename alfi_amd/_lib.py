@@ -56,6 +56,8 @@ SIGNATURES = {
     "alfi_residual": (ctypes.c_int, [vp, vp, vp, vp]),
     "alfi_patches_set": (ctypes.c_int, [vp, ctypes.c_int64, vp, vp]),
     "alfi_patches_factor": (ctypes.c_int, [vp]),
+    "alfi_patches_set_groups": (ctypes.c_int, [vp, vp]),
+    "alfi_patches_factor_bytes": (ctypes.c_int, [vp, ctypes.POINTER(ctypes.c_int64)]),
     "alfi_patches_check": (ctypes.c_int, [vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int64),
                                           ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_double)]),
     "alfi_patches_set_multiplicative": (ctypes.c_int, [vp, ctypes.c_int64, vp, ctypes.c_int]),

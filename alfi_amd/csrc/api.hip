@@ -243,6 +243,26 @@ static int halo_rev_end(alfi_level* L, double* v) {
   return 0;
 }
 
+static void free_cond(alfi_level* L) {
+  for (void* q : L->cond_allocs) dev_free(q);
+  L->cond_allocs.clear();
+  L->cd = CondDev();
+  L->cond = false;
+  L->h_sptr.clear();
+  L->h_cond_gptr.clear();
+  L->cond_ngroups = L->cond_mat_doubles = L->cond_sinv_doubles = 0;
+  L->cond_lds_bytes = L->cond_max_s = L->cond_umax = 0;
+}
+
+template <typename T>
+static int cond_upload(alfi_level* L, const T** dst, const std::vector<T>& src) {
+  T* d = nullptr;
+  ALFI_CHECK(dev_upload(L->ctx, &d, src.data(), (int64_t)src.size()));
+  L->cond_allocs.push_back(d);
+  *dst = d;
+  return 0;
+}
+
 extern "C" {
 
 // ---- context -------------------------------------------------------------------------------------------------------------
@@ -568,6 +588,7 @@ int alfi_level_destroy(alfi_level* L) {
   dev_free(L->status);
   dev_free(L->chk);
   dev_free(L->chk_list);
+  free_cond(L);
   dev_free(L->V);
   dev_free(L->Z);
   dev_free(L->w);
@@ -695,6 +716,7 @@ int alfi_patches_set(alfi_level* L, int64_t npatch, const int64_t* pptr, const i
   L->patch_ptr = nullptr; L->patch_dofs = nullptr; L->inv_ptr = nullptr; L->stage_ptr = nullptr;
   L->inv = nullptr; L->stage = nullptr; L->dof_ptr = nullptr; L->dof_pos = nullptr;
   L->factored = false;
+  free_cond(L);
   L->npatch = npatch;
   const int64_t sum_n = npatch > 0 ? pptr[npatch] : 0;
   if (sum_n > INT32_MAX) return alfi_set_error(ctx, ALFI_E_ARG, "too many patch dofs for int32 staging indices");
@@ -761,6 +783,173 @@ int alfi_patches_set(alfi_level* L, int64_t npatch, const int64_t* pptr, const i
   return 0;
 }
 
+int alfi_patches_set_groups(alfi_level* L, const int32_t* group) {
+  alfi_ctx* ctx = L->ctx;
+  if (!L->patch_ptr) return alfi_set_error(ctx, ALFI_E_STATE, "alfi_patches_set_groups before alfi_patches_set");
+  ALFI_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  ALFI_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  free_cond(L);
+  L->factored = false;
+  if (!group) return 0;                                  // back to dense inverses
+  if (L->mult) return alfi_set_error(ctx, ALFI_E_STATE, "condensed patch factors do not support multiplicative sweeps");
+  const int bs = L->bs;
+  const int64_t npatch = L->npatch, nb = L->A.nbrows, nnzb = L->A.nnzb;
+  std::vector<int32_t> rowptr(nb + 1), colidx(nnzb > 0 ? nnzb : 1);
+  ALFI_HIP_CHECK(ctx, hipMemcpy(rowptr.data(), L->A.rowptr, sizeof(int32_t) * (nb + 1), hipMemcpyDeviceToHost));
+  if (nnzb > 0) ALFI_HIP_CHECK(ctx, hipMemcpy(colidx.data(), L->A.colidx, sizeof(int32_t) * nnzb, hipMemcpyDeviceToHost));
+  const std::vector<int64_t>& pp = L->h_patch_ptr;
+  const std::vector<int32_t>& pd = L->h_patch_dofs;
+  const int64_t sum_n = pp[npatch];
+  std::vector<int32_t> c_dofs(sum_n), c_slot(sum_n), g_off, g_m, g_sc, g_uoff, sidx, p_nI(npatch), s_uptr, s_uidx;
+  std::vector<int64_t> gptr(npatch + 1, 0), g_mat, g_sidx, sptr(npatch + 1, 0), sinv_ptr(npatch + 1, 0);
+  std::vector<int32_t> node_pos(nb, -1);               // node -> condensed NODE position inside the current patch
+  int64_t mat_off = 0, sinv_off = 0;
+  int lds_max = 0, umax = 0, smax = 0;
+  s_uptr.push_back(0);
+  for (int64_t p = 0; p < npatch; ++p) {
+    const int64_t off = pp[p];
+    const int n = (int)(pp[p + 1] - off);
+    if (n % bs != 0) return alfi_set_error(ctx, ALFI_E_ARG, "patch %lld: condensed factors need patches of whole nodes", (long long)p);
+    const int nn = n / bs;
+    // labels per node; groups = distinct non-negative labels in ascending order
+    std::vector<int32_t> lab(nn);
+    for (int i = 0; i < nn; ++i) {
+      lab[i] = group[off + (int64_t)i * bs];
+      for (int c = 0; c < bs; ++c) {
+        if (pd[off + (int64_t)i * bs + c] != (pd[off + (int64_t)i * bs] / bs) * bs + c || group[off + (int64_t)i * bs + c] != lab[i])
+          return alfi_set_error(ctx, ALFI_E_ARG, "patch %lld: entries of a node must be adjacent and carry one group label", (long long)p);
+      }
+    }
+    std::vector<int32_t> labels;
+    for (int i = 0; i < nn; ++i) if (lab[i] >= 0) labels.push_back(lab[i]);
+    std::sort(labels.begin(), labels.end());
+    labels.erase(std::unique(labels.begin(), labels.end()), labels.end());
+    const int ng = (int)labels.size();
+    // condensed node order: groups (ascending label, ascending node), then the skeleton nodes
+    std::vector<int32_t> order;                         // condensed node position -> sorted node position
+    order.reserve(nn);
+    std::vector<int32_t> gstart(ng + 1, 0);
+    for (int g = 0; g < ng; ++g) {
+      for (int i = 0; i < nn; ++i) if (lab[i] == labels[g]) order.push_back(i);
+      gstart[g + 1] = (int32_t)order.size();
+    }
+    const int nIn = (int)order.size();                  // interior nodes
+    for (int i = 0; i < nn; ++i) if (lab[i] < 0) order.push_back(i);
+    for (int q = 0; q < nn; ++q) {
+      node_pos[pd[off + (int64_t)order[q] * bs] / bs] = q;
+      for (int c = 0; c < bs; ++c) {
+        c_dofs[off + (int64_t)q * bs + c] = pd[off + (int64_t)order[q] * bs + c];
+        c_slot[off + (int64_t)q * bs + c] = order[q] * bs + c;
+      }
+    }
+    const int sn = nn - nIn, s = sn * bs;
+    p_nI[p] = nIn * bs;
+    sptr[p + 1] = sptr[p] + s;
+    const int64_t ld_s = (s + 1) & ~1;
+    sinv_ptr[p] = sinv_off;
+    sinv_off += ((int64_t)s * ld_s + 15) & ~(int64_t)15;
+    if (s > smax) smax = s;
+    gptr[p + 1] = gptr[p] + ng;
+    // per group: the skeleton nodes its rows couple to; a column inside another group is an error
+    std::vector<std::vector<int32_t>> row_contrib(sn);  // skeleton node -> (u position of its first component) per group
+    int uoff = 0;
+    std::vector<char> mark(sn);
+    for (int g = 0; g < ng; ++g) {
+      std::fill(mark.begin(), mark.end(), 0);
+      for (int q = gstart[g]; q < gstart[g + 1]; ++q) {
+        const int node = pd[off + (int64_t)order[q] * bs] / bs;
+        for (int32_t k = rowptr[node]; k < rowptr[node + 1]; ++k) {
+          const int cq = node_pos[colidx[k] & 0x7fffffff];
+          if (cq < 0) continue;
+          if (cq >= nIn) mark[cq - nIn] = 1;
+          else if (cq < gstart[g] || cq >= gstart[g + 1]) {
+            for (int i = 0; i < nn; ++i) node_pos[pd[off + (int64_t)i * bs] / bs] = -1;
+            return alfi_set_error(ctx, ALFI_E_ARG, "patch %lld: groups %d and another one are coupled by an operator entry "
+                                  "(a group may touch the rest of the patch only through unlabelled dofs)", (long long)p, labels[g]);
+          }
+        }
+      }
+      const int m = (gstart[g + 1] - gstart[g]) * bs;
+      int scn = 0;
+      g_sidx.push_back((int64_t)sidx.size());
+      for (int j = 0; j < sn; ++j)
+        if (mark[j]) {
+          for (int c = 0; c < bs; ++c) sidx.push_back(j * bs + c);
+          row_contrib[j].push_back(uoff + scn * bs);
+          ++scn;
+        }
+      const int sc = scn * bs;
+      if (m > 64 || sc > 64) {
+        for (int i = 0; i < nn; ++i) node_pos[pd[off + (int64_t)i * bs] / bs] = -1;
+        return alfi_set_error(ctx, ALFI_E_ARG, "patch %lld: group %d holds %d entries coupled to %d skeleton entries; the "
+                              "condensed factors handle at most 64 of each", (long long)p, labels[g], m, sc);
+      }
+      g_off.push_back(gstart[g] * bs);
+      g_m.push_back(m);
+      g_sc.push_back(sc);
+      g_uoff.push_back(uoff);
+      g_mat.push_back(mat_off);
+      mat_off += (int64_t)m * m + 2 * (int64_t)m * sc;
+      uoff += sc;
+    }
+    if (uoff > umax) umax = uoff;
+    for (int j = 0; j < sn; ++j)
+      for (int c = 0; c < bs; ++c) {
+        for (int32_t u : row_contrib[j]) s_uidx.push_back(u + c);
+        s_uptr.push_back((int32_t)s_uidx.size());
+      }
+    for (int i = 0; i < nn; ++i) node_pos[pd[off + (int64_t)i * bs] / bs] = -1;
+    const int lds = (n + uoff + s + 2) * (int)sizeof(double);
+    if (lds > lds_max) lds_max = lds;
+  }
+  sinv_ptr[npatch] = sinv_off;
+  if (lds_max > 150 * 1024)
+    return alfi_set_error(ctx, ALFI_E_ARG, "condensed apply would need %d bytes of LDS per patch", lds_max);
+  if (g_off.empty()) return alfi_set_error(ctx, ALFI_E_ARG, "no group label >= 0: nothing to condense");
+  if (sidx.empty()) sidx.push_back(0);
+  if (s_uidx.empty()) s_uidx.push_back(0);
+  CondDev cd;
+  ALFI_CHECK(cond_upload(L, &cd.dofs, c_dofs));
+  ALFI_CHECK(cond_upload(L, &cd.slot, c_slot));
+  ALFI_CHECK(cond_upload(L, &cd.gptr, gptr));
+  ALFI_CHECK(cond_upload(L, &cd.g_off, g_off));
+  ALFI_CHECK(cond_upload(L, &cd.g_m, g_m));
+  ALFI_CHECK(cond_upload(L, &cd.g_sc, g_sc));
+  ALFI_CHECK(cond_upload(L, &cd.g_uoff, g_uoff));
+  ALFI_CHECK(cond_upload(L, &cd.g_mat, g_mat));
+  ALFI_CHECK(cond_upload(L, &cd.g_sidx, g_sidx));
+  ALFI_CHECK(cond_upload(L, &cd.sidx, sidx));
+  ALFI_CHECK(cond_upload(L, &cd.p_nI, p_nI));
+  ALFI_CHECK(cond_upload(L, &cd.sptr, sptr));
+  ALFI_CHECK(cond_upload(L, &cd.sinv_ptr, sinv_ptr));
+  ALFI_CHECK(cond_upload(L, &cd.s_uptr, s_uptr));
+  ALFI_CHECK(cond_upload(L, &cd.s_uidx, s_uidx));
+  ALFI_CHECK(dev_alloc(ctx, &cd.mat, mat_off));
+  L->cond_allocs.push_back(cd.mat);
+  ALFI_CHECK(dev_alloc(ctx, &cd.sinv, sinv_off));
+  L->cond_allocs.push_back(cd.sinv);
+  // the dense inverses are not needed any more
+  dev_free(L->inv);
+  L->inv = nullptr;
+  ALFI_CHECK(dev_alloc(ctx, &L->inv, 16));
+  L->cd = cd;
+  L->cond = true;
+  L->h_sptr = sptr;
+  L->h_cond_gptr = gptr;
+  L->cond_ngroups = (int64_t)g_off.size();
+  L->cond_mat_doubles = mat_off;
+  L->cond_sinv_doubles = sinv_off;
+  L->cond_lds_bytes = lds_max;
+  L->cond_umax = umax;
+  L->cond_max_s = smax;
+  return 0;
+}
+
+int alfi_patches_factor_bytes(alfi_level* L, int64_t* bytes) {
+  *bytes = L->cond ? 8 * (L->cond_mat_doubles + L->cond_sinv_doubles) : 8 * L->inv_doubles;
+  return 0;
+}
+
 int alfi_patches_set_multiplicative(alfi_level* L, int64_t nit, const int64_t* iterset, int symmetrise) {
   alfi_ctx* ctx = L->ctx;
   if (!L->patch_ptr) return alfi_set_error(ctx, ALFI_E_STATE, "alfi_patches_set_multiplicative before alfi_patches_set");
@@ -772,6 +961,7 @@ int alfi_patches_set_multiplicative(alfi_level* L, int64_t nit, const int64_t* i
   L->mult_wave_ptr.clear();
   if (nit == 0) return 0;
   if (nit < 0 || !iterset) return alfi_set_error(ctx, ALFI_E_ARG, "bad iteration set");
+  if (L->cond) return alfi_set_error(ctx, ALFI_E_STATE, "multiplicative sweeps need dense patch inverses (alfi_patches_set_groups(NULL))");
   // partitioned levels: every rank sweeps over its own patches with the residual of its local vector (ghost slots hold
   // the rank's own contributions only) and the ghost contributions are added onto their owners at the end -- what
   // PCPATCH does under MPI: local Gauss-Seidel, additive between ranks [3P]
@@ -842,7 +1032,9 @@ int alfi_patches_factor(alfi_level* L) {
   int t = alfi_prof_begin(ctx, ALFI_EV_PATCH_FACTOR);
   ALFI_HIP_CHECK(ctx, hipMemsetAsync(L->status, 0, sizeof(int), ctx->stream));
   static const bool force_big = getenv("ALFI_FORCE_BIG_FACTOR") && atoi(getenv("ALFI_FORCE_BIG_FACTOR")) == 1;
-  if (L->max_np > SMALL_PATCH_MAX || force_big) {
+  if (L->cond) {
+    ALFI_CHECK(launch_cond_factor(L));            // condensed factors: group inverses + Schur complements
+  } else if (L->max_np > SMALL_PATCH_MAX || force_big) {
     ALFI_CHECK(launch_big_factor(L));             // macro-star sized patches: blocked Gauss-Jordan on the matrix cores
   } else {
     ALFI_CHECK(launch_patch_gather_dense(L));
@@ -886,6 +1078,7 @@ int alfi_patch_get_inverse(alfi_level* L, int64_t p, double* out) {
   alfi_ctx* ctx = L->ctx;
   if (!L->factored) return alfi_set_error(ctx, ALFI_E_STATE, "patches not factored");
   if (p < 0 || p >= L->npatch) return alfi_set_error(ctx, ALFI_E_ARG, "patch index out of range");
+  if (L->cond) return alfi_set_error(ctx, ALFI_E_STATE, "condensed patch factors hold no dense inverse");
   const int64_t n = L->h_patch_ptr[p + 1] - L->h_patch_ptr[p];
   const int64_t ld = (n + 1) & ~(int64_t)1;
   std::vector<double> tmp(n * ld);

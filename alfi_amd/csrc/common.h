@@ -138,6 +138,34 @@ __host__ __device__ inline int64_t bsr_val_index(int flat, int64_t k, int rc, in
   return g + (int64_t)npair * 128 + l;
 }
 
+// Condensed ("statically condensed") patch factors, alfi_patches_set_groups: the dofs of patch p are split into groups
+// I_1 .. I_m that are coupled to the rest of the patch only through the remaining (skeleton) dofs S -- for the macro-star
+// patches of the Scott-Vogelius discretisation the dofs interior to one macro cell each (alfi/relaxation.py:163-177 on the
+// Alfeld-split meshes of alfi/bary.py) -- and inv(A_p) is stored EXACTLY as the block factorisation
+//     t_g = X_g x_g,   y_S = inv(Sigma) (x_S - sum_g B_g t_g),   y_g = t_g - W_g y_S[S_g]
+// with X_g = inv(A_gg), B_g = A[S_g, g], W_g = X_g A[g, S_g], Sigma = A_SS - sum_g B_g W_g (S_g: the skeleton dofs coupled
+// to group g).  Storage sum_g (m_g^2 + 2 m_g s_g) + s^2 doubles instead of n_p^2: 7 x less for the P3 macro stars of
+// config 5 (m_g <= 48, s_g <= 51, s <= 585 of n_p <= 1941), and the apply streams exactly that.
+struct CondDev {
+  const int32_t* dofs = nullptr;   // (sum_n) global dof of every patch entry, condensed order [groups | skeleton]
+  const int32_t* slot = nullptr;   // (sum_n) position of the entry in the patch's ascending order (its staging slot)
+  const int64_t* gptr = nullptr;   // (npatch+1) groups of patch p
+  const int32_t* g_off = nullptr;  // per group: first entry inside the patch (condensed order)
+  const int32_t* g_m = nullptr;    //            entries
+  const int32_t* g_sc = nullptr;   //            coupled skeleton entries
+  const int32_t* g_uoff = nullptr; //            offset of its B_g t_g segment in the patch's u buffer
+  const int64_t* g_mat = nullptr;  //            offset of [X (m x m) | B (sc x m) | W (m x sc)] (column-major each) in mat
+  const int64_t* g_sidx = nullptr; //            offset of its sc skeleton positions in sidx
+  const int32_t* sidx = nullptr;
+  const int32_t* p_nI = nullptr;   // per patch: interior entries = where the skeleton starts
+  const int64_t* sptr = nullptr;   // (npatch+1) prefix sums of the skeleton sizes
+  const int64_t* sinv_ptr = nullptr;  // (npatch+1) offsets of inv(Sigma) (row-piece layout, patch_inv_index) in sinv
+  const int32_t* s_uptr = nullptr; // (sum_s + 1) skeleton row -> contributions in the u buffer
+  const int32_t* s_uidx = nullptr;
+  double* mat = nullptr;
+  double* sinv = nullptr;
+};
+
 struct alfi_level {
   alfi_ctx* ctx = nullptr;
   int id = 0;
@@ -186,6 +214,14 @@ struct alfi_level {
   int chk_cap = 0;
   double chk_worst = -1.0, chk_worst_after = -1.0;   // of the last factorisation: before / after the repair (-1: not run)
   int64_t chk_flagged = 0, chk_repaired = 0;
+  // condensed patch factors (alfi_patches_set_groups)
+  bool cond = false;
+  CondDev cd;
+  std::vector<void*> cond_allocs;        // every device array cd points to
+  std::vector<int64_t> h_sptr;           // host copy of cd.sptr (sizes of the Schur complements)
+  int64_t cond_ngroups = 0, cond_mat_doubles = 0, cond_sinv_doubles = 0;
+  int cond_lds_bytes = 0, cond_max_s = 0, cond_umax = 0;
+  std::vector<int64_t> h_cond_gptr;      // host copy of cd.gptr
   // multiplicative sweeps: positions of the iteration sequence grouped into dependency wavefronts
   bool mult = false, mult_symmetrise = false;
   bool mult_big = false;                // a patch holds more than 64 nodes: workgroup-per-patch sweep kernel
@@ -299,7 +335,10 @@ int launch_big_apply_arrays(alfi_ctx* ctx, int64_t npatch, int max_np, const int
                             const int32_t* patch_dofs, const int64_t* inv_ptr, const int64_t* stage_ptr, const double* inv,
                             const double* x, double* stage);
 int launch_coarse_factor(alfi_level* lvl, double* out);                                   // dense inverse of the whole level operator
-int launch_big_factor(alfi_level* lvl);                                                    // gather + blocked MFMA inversion
+int launch_big_factor(alfi_level* lvl);
+// condensed patches (kernels_bigpatch.hip): block factorisation / its apply for the patches [p0, p1)
+int launch_cond_factor(alfi_level* lvl);
+int launch_cond_apply_range(alfi_level* lvl, int64_t p0, int64_t p1, const double* x);                                                    // gather + blocked MFMA inversion
 int launch_patch_sum(alfi_level* lvl, const double* x, double* y);             // stage 2
 int launch_patch_sum_range(alfi_level* lvl, int64_t i0, int64_t i1, const double* x, double* y);   // stage 2, dofs [i0, i1)
 // one dependency wavefront of a multiplicative sweep: patches seq[0..count): y_p += inv(A_p) (x - A y)_p

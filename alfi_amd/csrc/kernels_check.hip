@@ -6,9 +6,10 @@
 // shipped problems but not for an arbitrary Newton / SUPG Jacobian at high Reynolds number.  So every factorisation is
 // followed by a probe of every patch,
 //
-//     rho_p = || A_p (X_p e_p) - e_p ||_inf,       e_p a fixed vector of +-1,
+//     rho_p = || A_p (X_p e_p) - e_p ||_inf,       e a fixed vector of +-1 (by dof),
 //
-// (O(n_p^2): one pass over X_p, one over the patch's operator rows), and every patch with rho_p > tol -- or a non-finite
+// (X_p e_p by the level's own apply kernels -- so the probe covers whatever storage the factors have: row pieces, large
+// patches, condensed -- then one pass over the patch's operator rows), and every patch with rho_p > tol -- or a non-finite
 // inverse -- is re-gathered and re-inverted by Gauss-Jordan WITH partial pivoting (one workgroup per flagged patch, work
 // matrix in global scratch), then probed again.  alfi_patches_check reports the worst residual and the counts.
 #include <algorithm>
@@ -20,8 +21,8 @@
 
 namespace {
 
-__device__ __forceinline__ double probe_entry(int64_t p, int i) {
-  uint32_t h = (uint32_t)i * 2654435761u ^ (uint32_t)p * 40503u;
+__device__ __forceinline__ double probe_entry(int64_t dof) {
+  uint32_t h = (uint32_t)dof * 2654435761u;
   h ^= h >> 15;
   h *= 2246822519u;
   h ^= h >> 13;
@@ -44,33 +45,34 @@ __device__ __forceinline__ int find_dof(const int32_t* dofs_s, int n, int gcol) 
   return (a < n && dofs_s[a] == gcol) ? a : -1;
 }
 
-// one workgroup per patch (list[blockIdx.x], or blockIdx.x itself).  Dynamic LDS: n int32 + n doubles.
+__global__ void probe_fill_kernel(double* __restrict__ e, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    e[i] = probe_entry(i);
+}
+
+// one workgroup per patch.  The level's own apply kernels (whatever the storage of the factors: row pieces, large
+// patches, condensed) have put y_p = X_p e_p into the staging buffer; this kernel forms A_p y_p - e_p from the
+// operator rows.  Dynamic LDS: n int32 + n doubles.
 template <int BS>
 __global__ __launch_bounds__(256) void patch_check_kernel(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colidx,
                                                            const double* __restrict__ vals, int flat,
                                                            const int64_t* __restrict__ patch_ptr,
                                                            const int32_t* __restrict__ patch_dofs,
-                                                           const int64_t* __restrict__ inv_ptr, const double* __restrict__ inv,
-                                                           const int32_t* __restrict__ list, double tol,
+                                                           const int64_t* __restrict__ stage_ptr,
+                                                           const double* __restrict__ stage, double tol,
                                                            unsigned long long* __restrict__ worst_bits,
                                                            int32_t* __restrict__ flagged, int* __restrict__ nflag, int cap) {
   extern __shared__ unsigned char smem[];
-  const int64_t p = list ? list[blockIdx.x] : blockIdx.x;
+  const int64_t p = blockIdx.x;
   const int64_t off = patch_ptr[p];
   const int n = (int)(patch_ptr[p + 1] - off);
-  const int ld = (n + 1) & ~1;
   double* y_s = reinterpret_cast<double*>(smem);
   int32_t* dofs_s = reinterpret_cast<int32_t*>(y_s + n);
   __shared__ double wmax_s[4];
-  const double* X = inv + inv_ptr[p];
-  for (int i = threadIdx.x; i < n; i += 256) dofs_s[i] = patch_dofs[off + i];
-  // y = X e: a thread per row; entry (r, c) of the row-piece layout sits at base_r + c * rows_r
-  for (int r = threadIdx.x; r < n; r += 256) {
-    const int64_t base = patch_inv_index(r, 0, n, ld);
-    const int64_t rows = n > 1 ? patch_inv_index(r, 1, n, ld) - base : 0;
-    double acc = 0.0;
-    for (int c = 0; c < n; ++c) acc = __builtin_fma(X[base + (int64_t)c * rows], probe_entry(p, c), acc);
-    y_s[r] = acc;
+  const double* yp = stage + stage_ptr[p];
+  for (int i = threadIdx.x; i < n; i += 256) {
+    dofs_s[i] = patch_dofs[off + i];
+    y_s[i] = yp[i];
   }
   __syncthreads();
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -87,7 +89,7 @@ __global__ __launch_bounds__(256) void patch_check_kernel(const int32_t* __restr
       if (a >= 0) acc = __builtin_fma(vals[bsr_val_index(flat, lo + blk, rr * BS + cc, BS * BS)], y_s[a], acc);
     }
     acc = wave_sum_chk(acc);
-    const double res = fabs(acc - probe_entry(p, r));
+    const double res = fabs(acc - probe_entry(gr));
     if (!(res <= wmax)) wmax = (res == res) ? res : INFINITY;      // NaN -> +inf
   }
   if (lane == 0) wmax_s[wave] = wmax;
@@ -218,22 +220,30 @@ __global__ __launch_bounds__(256) void patch_repair_kernel(const int32_t* __rest
 
 }  // namespace
 
-// probe all patches (list == nullptr) or the listed ones; results accumulate in L->chk (device)
-static int launch_check(alfi_level* L, const int32_t* list, int64_t count, double tol) {
+// probe all patches: e = +-1 by dof, the level's stage-1 apply, residual per patch; results accumulate in L->chk (device)
+static int launch_check(alfi_level* L, double tol) {
   alfi_ctx* ctx = L->ctx;
-  if (count == 0) return 0;
-  const size_t lds = (size_t)L->max_np * (sizeof(double) + sizeof(int32_t));
-  unsigned long long* worst = reinterpret_cast<unsigned long long*>(L->chk);
-  int* nflag = reinterpret_cast<int*>(L->chk + 1);
-  dim3 grid((unsigned)count), block(256);
-  if (L->bs == 2)
-    hipLaunchKernelGGL(patch_check_kernel<2>, grid, block, lds, ctx->stream, L->A.rowptr, L->A.colidx, L->A.vals, L->A.flat,
-                       L->patch_ptr, L->patch_dofs, L->inv_ptr, L->inv, list, tol, worst, L->chk_list, nflag, L->chk_cap);
-  else
-    hipLaunchKernelGGL(patch_check_kernel<3>, grid, block, lds, ctx->stream, L->A.rowptr, L->A.colidx, L->A.vals, L->A.flat,
-                       L->patch_ptr, L->patch_dofs, L->inv_ptr, L->inv, list, tol, worst, L->chk_list, nflag, L->chk_cap);
-  ALFI_HIP_CHECK(ctx, hipGetLastError());
-  return 0;
+  if (L->npatch == 0) return 0;
+  double* e = nullptr;
+  ALFI_HIP_CHECK(ctx, hipMalloc((void**)&e, sizeof(double) * (size_t)std::max<int64_t>(L->n, 1)));
+  hipLaunchKernelGGL(probe_fill_kernel, dim3(1024), dim3(256), 0, ctx->stream, e, L->n);
+  int rc = launch_patch_apply_range(L, 0, L->npatch, e);
+  if (rc == 0) {
+    const size_t lds = (size_t)L->max_np * (sizeof(double) + sizeof(int32_t));
+    unsigned long long* worst = reinterpret_cast<unsigned long long*>(L->chk);
+    int* nflag = reinterpret_cast<int*>(L->chk + 1);
+    dim3 grid((unsigned)L->npatch), block(256);
+    if (L->bs == 2)
+      hipLaunchKernelGGL(patch_check_kernel<2>, grid, block, lds, ctx->stream, L->A.rowptr, L->A.colidx, L->A.vals, L->A.flat,
+                         L->patch_ptr, L->patch_dofs, L->stage_ptr, L->stage, tol, worst, L->chk_list, nflag, L->chk_cap);
+    else
+      hipLaunchKernelGGL(patch_check_kernel<3>, grid, block, lds, ctx->stream, L->A.rowptr, L->A.colidx, L->A.vals, L->A.flat,
+                         L->patch_ptr, L->patch_dofs, L->stage_ptr, L->stage, tol, worst, L->chk_list, nflag, L->chk_cap);
+    if (hipGetLastError() != hipSuccess) rc = alfi_set_error(ctx, ALFI_E_HIP, "patch_check_kernel launch failed");
+  }
+  (void)hipStreamSynchronize(ctx->stream);
+  (void)hipFree(e);
+  return rc;
 }
 
 static int read_check(alfi_level* L, double* worst, int* nflag) {
@@ -266,7 +276,7 @@ int patch_verify_and_repair(alfi_level* L, int unpivoted_status) {
     ALFI_HIP_CHECK(ctx, hipMalloc((void**)&L->chk_list, sizeof(int32_t) * (size_t)L->chk_cap));
   }
   ALFI_HIP_CHECK(ctx, hipMemsetAsync(L->chk, 0, 2 * sizeof(double), ctx->stream));
-  ALFI_CHECK(launch_check(L, nullptr, L->npatch, tol));
+  ALFI_CHECK(launch_check(L, tol));
   double worst = 0.0;
   int nflag = 0;
   ALFI_CHECK(read_check(L, &worst, &nflag));
@@ -277,6 +287,9 @@ int patch_verify_and_repair(alfi_level* L, int unpivoted_status) {
     return alfi_set_error(ctx, ALFI_E_SINGULAR, "%d of %lld patch inverses fail the residual probe (worst %.3e)", nflag,
                           (long long)L->npatch, worst);
   constexpr int REPAIR_MAX_NP = 1024;
+  if (L->cond)
+    return alfi_set_error(ctx, ALFI_E_SINGULAR, "%d condensed patch factors fail the residual probe (worst %.3e); use dense "
+                          "inverses (alfi_patches_set_groups(NULL)) for this operator", nflag, worst);
   if (L->max_np > REPAIR_MAX_NP)
     return alfi_set_error(ctx, ALFI_E_SINGULAR, "%d patch inverses fail the residual probe (worst %.3e) and the pivoted "
                           "repair handles patches of at most %d dofs", nflag, worst, REPAIR_MAX_NP);
@@ -305,18 +318,12 @@ int patch_verify_and_repair(alfi_level* L, int unpivoted_status) {
   (void)hipFree(scratch);
   if (rc != 0) return rc;
   if (st != 0) return alfi_set_error(ctx, ALFI_E_SINGULAR, "a patch operator is singular to working precision (pivoted inversion)");
-  // probe the repaired patches again (the list stays as it is: copy it, the kernel appends to chk_list)
-  std::vector<int32_t> h_list((size_t)nflag);
-  ALFI_HIP_CHECK(ctx, hipMemcpy(h_list.data(), L->chk_list, sizeof(int32_t) * (size_t)nflag, hipMemcpyDeviceToHost));
-  int32_t* d_list = nullptr;
-  ALFI_HIP_CHECK(ctx, hipMalloc((void**)&d_list, sizeof(int32_t) * (size_t)nflag));
-  ALFI_HIP_CHECK(ctx, hipMemcpy(d_list, h_list.data(), sizeof(int32_t) * (size_t)nflag, hipMemcpyHostToDevice));
+  // probe again (all patches: the apply kernels work on whole levels)
   ALFI_HIP_CHECK(ctx, hipMemsetAsync(L->chk, 0, 2 * sizeof(double), ctx->stream));
-  rc = launch_check(L, d_list, nflag, tol);
+  rc = launch_check(L, tol);
   double worst2 = 0.0;
   int nflag2 = 0;
   if (rc == 0) rc = read_check(L, &worst2, &nflag2);
-  (void)hipFree(d_list);
   if (rc != 0) return rc;
   L->chk_repaired = nflag - nflag2;
   L->chk_worst_after = worst2;

@@ -628,6 +628,11 @@ int launch_patch_apply_range(alfi_level* L, int64_t p0, int64_t p1, const double
   alfi_ctx* ctx = L->ctx;
   if (p1 <= p0) return 0;
   int t = alfi_prof_begin(ctx, ALFI_EV_PATCH_APPLY);
+  if (L->cond) {                                // condensed factors (kernels_bigpatch.hip)
+    ALFI_CHECK(launch_cond_apply_range(L, p0, p1, x));
+    alfi_prof_end(ctx, t);
+    return 0;
+  }
   if (L->max_np > SMALL_PATCH_MAX) {            // one workgroup per patch (kernels_bigpatch.hip)
     ALFI_CHECK(launch_big_apply_range(L, p0, p1, x));
     alfi_prof_end(ctx, t);

@@ -330,6 +330,8 @@ def localize_level(L, part):
         cnt = np.diff(nptr)[porder]
         out.patch_ptr = np.concatenate([[0], np.cumsum(cnt)]).astype(np.int64)
         out.patch_dofs = ld[order].astype(np.int32)
+        if getattr(L, "patch_groups", None) is not None:        # labels of condensed patch factors follow their dofs
+            out.patch_groups = np.asarray(L.patch_groups)[idx][order].astype(np.int32)
         out.patch_ids = sel[porder]
         out.npatch_int = int(np.count_nonzero(~has_ghost))
     else:
@@ -572,6 +574,8 @@ class DistMultigrid(object):
                     self.halos[dl.id] = hb
                 if LL.level > 0:
                     dl.set_patches(LL.patch_ptr, LL.patch_dofs)
+                    if hip.condense_patches(LL):
+                        dl.set_patch_groups(LL.patch_groups)
                     dl.factor()
                     if p.distributed and overlap and p.nb_own * p.bs >= overlap_min_dofs:
                         # interior rows / patches are worked on while the forward halo is in flight.  Opt-in

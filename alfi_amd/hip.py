@@ -165,6 +165,17 @@ class Level(object):
         pd = np.ascontiguousarray(patch_dofs, dtype=np.int32)
         self.ctx.check(self.ctx.lib.alfi_patches_set(self.h, len(pp) - 1, _ptr(pp), _ptr(pd)))
 
+    def set_patch_groups(self, groups):
+        """Condensed patch factors (alfi_patches_set_groups): one label per entry of patch_dofs, >= 0 = group of the patch the
+        entry belongs to, -1 = skeleton; None = dense inverses."""
+        g = None if groups is None else np.ascontiguousarray(groups, dtype=np.int32)
+        self.ctx.check(self.ctx.lib.alfi_patches_set_groups(self.h, _ptr(g)))
+
+    def factor_bytes(self):
+        b = ctypes.c_int64()
+        self.ctx.check(self.ctx.lib.alfi_patches_factor_bytes(self.h, ctypes.byref(b)))
+        return b.value
+
     def set_multiplicative(self, iterset, symmetrise):
         """Multiplicative sweeps in the order ``iterset`` (None / empty = back to additive); returns the number of
         dependency wavefronts one sweep was scheduled into."""
@@ -298,6 +309,13 @@ def coarse_inverse(A_bsr):
     return np.linalg.inv(A)
 
 
+def condense_patches(L):
+    """Whether the level's patch factors are stored condensed: the generator supplied group labels (macro-star patches of
+    the Scott-Vogelius hierarchy, sv.macro_cell_groups) and ALFI_CONDENSE is not 0."""
+    import os
+    return getattr(L, "patch_groups", None) is not None and os.environ.get("ALFI_CONDENSE", "1") != "0"
+
+
 class Multigrid(object):
     """Device-resident PCMG (solver.py:359-379) built from alfi_amd.problem.build_hierarchy output."""
 
@@ -309,6 +327,8 @@ class Multigrid(object):
             dl = Level(ctx, L.A, L.bc_dofs)
             if L.level > 0:
                 dl.set_patches(L.patch_ptr, L.patch_dofs)
+                if condense_patches(L):
+                    dl.set_patch_groups(L.patch_groups)
                 dl.factor()
             elif coarse_inv is not None:
                 dl.set_coarse_inverse(coarse_inv)          # an inverse supplied by the caller (numpy array / device pointer)

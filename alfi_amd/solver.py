@@ -210,6 +210,16 @@ class HipPatchPC(object):
         self.patch_ptr, self.patch_dofs = ptr, dofs
         self.level = hip.Level(pc.ctx, L.A, L.bc_dofs)
         self.level.set_patches(ptr, dofs)
+        # macro-star patches on an Alfeld-split mesh (ScottVogeliusSolver: the reference keeps SPARSE patch factors there,
+        # solver.py:655-659): store the factors condensed -- interiors of the macro cells + skeleton -- unless the sweep is
+        # multiplicative (that kernel multiplies with dense inverses)
+        self.condensed = False
+        import os
+        if (ctype == "python" and getattr(L.V.mesh, "macro_mesh", None) is not None and not self.multiplicative
+                and os.environ.get("ALFI_CONDENSE", "1") != "0" and type(ctor).__name__ == "MacroStar"):
+            from .sv import macro_cell_groups
+            self.level.set_patch_groups(macro_cell_groups(L.V, dofs))
+            self.condensed = True
         self.level.factor()
         self.wavefronts = self.level.set_multiplicative(self.iterset, self.symmetrise) if self.multiplicative else 0
         self.n = L.n

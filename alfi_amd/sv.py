@@ -46,6 +46,23 @@ def macro_star_patches(V):
     return ptr, dofs, seeds
 
 
+def macro_cell_groups(V, patch_dofs):
+    """Group labels for condensed patch factors (alfi_patches_set_groups / hip.Level.set_patch_groups): a dof whose node
+    lies strictly inside one macro cell of the Alfeld-split mesh -- every cell holding the node is a child of the same macro
+    cell (bary cell c*(d+1)+i is child i of macro cell c, bary.py:148-151) -- gets that macro cell's number, every dof on the
+    macro skeleton gets -1.  Interiors of different macro cells never share a cell, hence no operator entry: inside any
+    patch they are coupled only through the skeleton."""
+    mesh, d = V.mesh, V.dim
+    nloc = V.cell_nodes.shape[1]
+    macro = np.repeat(np.arange(mesh.num_cells, dtype=np.int64) // (d + 1), nloc)
+    lo = np.full(V.num_nodes, np.iinfo(np.int64).max, dtype=np.int64)
+    hi = np.full(V.num_nodes, -1, dtype=np.int64)
+    np.minimum.at(lo, V.cell_nodes.ravel(), macro)
+    np.maximum.at(hi, V.cell_nodes.ravel(), macro)
+    label = np.where(lo == hi, lo, -1)
+    return label[np.asarray(patch_dofs, dtype=np.int64) // d].astype(np.int32)
+
+
 def _coarse_macro_cell_of_nodes(Vf):
     """For every fine node one fine cell holding it, and the coarse MACRO cell that cell lies in."""
     mf = Vf.mesh
@@ -264,6 +281,8 @@ def build_sv_hierarchy(problem, nref, k, Re, gamma=1e4, advect=True, patches=Tru
         L.nu, L.gamma = nu, gamma
         if patches and l > 0:
             L.patch_ptr, L.patch_dofs, L.patch_seeds = macro_star_patches(V)
+            # the factors of these patches can be stored condensed: interiors of the macro cells + skeleton
+            L.patch_groups = macro_cell_groups(V, L.patch_dofs)
         if l > 0:
             transfers.append(build_sv_transfer_data(Vprev, V, nu, gamma, (rowptr, colidx)))
         levels.append(L)

@@ -67,6 +67,13 @@ def build_problem(cfg, verbose, lazy=False):
     return lv, tr, k
 
 
+def apply_kernel_name(L):
+    from alfi_amd.hip import condense_patches
+    if condense_patches(L):
+        return "cond_apply_kernel"
+    return "big_apply_kernel" if np.diff(L.patch_ptr).max() > 160 else "patch_apply_kernel"
+
+
 def vcycle_bytes(levels, dmg, k):
     """Algorithmic HBM bytes of one V-cycle and of one patch_apply_kernel launch per level."""
     total = 0.0
@@ -76,8 +83,9 @@ def vcycle_bytes(levels, dmg, k):
             total += 8.0 * L.n * L.n
             continue
         npatch, sum_n, sum_n2 = dl.patch_stats()
-        b_apply_kernel = 8.0 * sum_n2 + 20.0 * sum_n          # inverse + int32 dofs + gathered x + staged result
-        b_patch = 8.0 * sum_n2 + 28.0 * sum_n + 8.0 * L.n      # + dof-wise sum (read staged, write y)
+        fbytes = float(dl.factor_bytes())                      # 8 sum n_p^2 for dense inverses, less for condensed factors
+        b_apply_kernel = fbytes + 20.0 * sum_n                 # factors + int32 dofs + gathered x + staged result
+        b_patch = fbytes + 28.0 * sum_n + 8.0 * L.n            # + dof-wise sum (read staged, write y)
         bs = L.bs
         b_spmv = (8.0 * bs * bs + 4.0) * L.A.nnzb + 4.0 * (L.A.nbrows + 1) + 16.0 * L.n
         b_blas1 = 8.0 * L.n * (k * k + 3 * k + 2)
@@ -200,7 +208,7 @@ def main_distributed(args, rank, world, local_rank):
                  "true_residual_norm": rn, "rhs_norm": float(np.linalg.norm(b)), "rtol": rtol, "atol": atol,
                  "pressure_dofs": int(Bm.shape[0])}
         sad.close()
-    bytes_apply = 8.0 * sum_n2 + 20.0 * sum_n
+    bytes_apply = float(fin.factor_bytes()) + 20.0 * sum_n
     # with the halo overlap one apply is three launches of patch_apply_kernel (interior half | boundary | interior half):
     # account per apply, not per launch
     applies = args.steps * 2 * k
@@ -228,7 +236,7 @@ def main_distributed(args, rank, world, local_rank):
                        "generation": "rank-local (alfi_amd.lazy)" if lazy else "global on every rank",
                        "distributed_levels": [int(p.level) for p in dmg.parts if p.distributed]},
             "dof_smooths_per_s": L.n * 2 * k * vps,
-            "roofline": {"kernel": "big_apply_kernel" if np.diff(L.patch_ptr).max() > 160 else "patch_apply_kernel", "bound": "hbm", "achieved": local_gbs, "peak": HBM_PEAK_GBS,
+            "roofline": {"kernel": apply_kernel_name(L), "bound": "hbm", "achieved": local_gbs, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": local_gbs / HBM_PEAK_GBS, "traffic": None,
                          "note": "rank 0's finest-level applies (its share of the patches; one apply = up to three "
                                  "launches around the halo exchanges), HIP events",
@@ -511,10 +519,12 @@ def main():
                    "cycle": "V(k,k), 1 cycle per step", "parallelism": "1 GPU",
                    "patch_composition": args.patch_composition, "wavefronts_per_sweep": wavefronts},
         "dof_smooths_per_s": L.n * smooths_per_cycle_finest * vps,
+        "patch_factor_GB": [round(dl.factor_bytes() / 1e9, 3) for dl in dmg.levels[1:]],
+        "patch_factor_bytes_per_dof_finest": dmg.levels[-1].factor_bytes() / float(L.n),
         "fcycle_ms": fcycle_ms,
         "vcycle_algorithmic_GB": total_bytes / 1e9,
         "vcycle_hbm_frac_of_peak": total_bytes / 1e9 / (elapsed / args.steps) / HBM_PEAK_GBS,
-        "roofline": {"kernel": "big_apply_kernel" if np.diff(L.patch_ptr).max() > 160 else "patch_apply_kernel", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
+        "roofline": {"kernel": apply_kernel_name(L), "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                      "avg_launch_us": 1e3 * t_apply_ms / max(n_apply, 1), "launches": int(n_apply),
                      "bytes_per_launch_avg": bytes_apply_total / max(n_apply, 1),

@@ -146,6 +146,19 @@ int alfi_residual(alfi_level* lvl, const double* db, const double* dx, double* d
 int alfi_patches_set(alfi_level* lvl, int64_t npatch, const int64_t* patch_ptr_host, const int32_t* patch_dofs_host);
 /* PCSetUp_PATCH with save_operators + dense_inverse (solver.py:320, 602): A_p = A[dofs_p, dofs_p], store inv(A_p). */
 int alfi_patches_factor(alfi_level* lvl);
+/* Condensed patch factors (optional, between alfi_patches_set and alfi_patches_factor).  group[q] (one label per entry of
+ * patch_dofs) >= 0: the entry belongs to that group of its patch; -1: it belongs to the patch's skeleton.  A group must be
+ * coupled to the rest of its patch only through skeleton entries (verified against the operator's sparsity; violated:
+ * ALFI_E_ARG) and hold <= 64 entries coupled to <= 64 skeleton entries; patches must consist of whole nodes.  The library
+ * then stores inv(A_p) EXACTLY as a block factorisation -- X_g = inv(A_gg), B_g = A[S_g, g], W_g = X_g A[g, S_g] per group
+ * and inv(A_SS - sum_g B_g W_g) -- instead of the dense inverse: the same result in exact arithmetic and to rounding,
+ * sum_g (m_g^2 + 2 m_g s_g) + s^2 doubles instead of n_p^2, both in memory and in the bytes an apply streams.  Made for
+ * the macro-star patches of the Scott-Vogelius discretisation (alfi/relaxation.py:163-177 on the Alfeld-split meshes of
+ * alfi/bary.py, where the reference itself keeps SPARSE patch factors, alfi/solver.py:655-659): the dofs interior to one
+ * macro cell form a group; 7 x less for [P3]^3.  group == NULL: back to dense inverses.  alfi_patches_factor_bytes: the bytes
+ * the factors of the level occupy (= the bytes one additive apply reads). */
+int alfi_patches_set_groups(alfi_level* lvl, const int32_t* group_host);
+int alfi_patches_factor_bytes(alfi_level* lvl, int64_t* bytes);
 /* Every alfi_patches_factor ends with a residual probe of every stored inverse, rho_p = || A_p (X_p e) - e ||_inf with a
  * fixed +-1 vector e, and re-inverts the patches with rho_p > 1e-6 (ALFI_PATCH_CHECK_TOL) -- or with a zero pivot -- by
  * Gauss-Jordan with partial pivoting (the reference factors with pivoted LAPACK / UMFPACK LU, solver.py:599-602, 655-659;

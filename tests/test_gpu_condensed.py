@@ -1,0 +1,100 @@
+"""Condensed patch factors (alfi_patches_set_groups): the exact block factorisation of the macro-star patch inverses --
+interiors of the macro cells + skeleton -- against the dense inverses and the oracle.  -m gpu.
+
+Reference: macro-star patches of the Scott-Vogelius solver (alfi/relaxation.py:163-177, alfi/solver.py:339-342) on
+Alfeld-split meshes (alfi/bary.py), where the reference keeps sparse LU factors of the patch matrices
+(alfi/solver.py:655-659) instead of dense inverses."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def relerr(a, b):
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-300)
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from alfi_amd import hip
+    c = hip.Context(0)
+    yield c
+    c.close()
+
+
+@pytest.mark.parametrize("case", ["2d-P2", "3d-P2", "3d-P3"])
+def test_condensed_apply_equals_dense_inverse_apply(ctx, case):
+    from alfi_amd import hip
+    from alfi_amd.problem import TwoDimLidDrivenCavityProblem, ThreeDimLidDrivenCavityProblem
+    from alfi_amd.sv import build_sv_hierarchy
+    from oracle import alfi_oracle as O
+    prob, nref, k = {"2d-P2": (TwoDimLidDrivenCavityProblem(2), 2, 2), "3d-P2": (ThreeDimLidDrivenCavityProblem(1), 1, 2),
+                     "3d-P3": (ThreeDimLidDrivenCavityProblem(1), 1, 3)}[case]
+    lv, _ = build_sv_hierarchy(prob, nref, k, Re=100.0)
+    L = lv[-1]
+    assert (L.patch_groups >= 0).any() and (L.patch_groups < 0).any()
+    x = np.random.default_rng(0).standard_normal(L.n)
+    out = {}
+    for mode in ("dense", "condensed"):
+        dl = hip.Level(ctx, L.A, L.bc_dofs)
+        dl.set_patches(L.patch_ptr, L.patch_dofs)
+        if mode == "condensed":
+            dl.set_patch_groups(L.patch_groups)
+        dl.factor()
+        worst, flagged, _, _ = dl.patch_check()
+        assert 0.0 <= worst < 1e-7 and flagged == 0
+        dx, dy = ctx.vec(x), ctx.vec(L.n)
+        dl.patch_apply(dx, dy)
+        out[mode] = (dy.get(), dl.factor_bytes())
+        dl.patch_apply(dx, dy)
+        assert np.array_equal(dy.get(), out[mode][0])               # deterministic
+        dl.close()
+    ref = O.PatchSmoother(L.A.to_scipy().tocsr(), L.patch_ptr, L.patch_dofs, L.bc_dofs).apply(x)
+    assert relerr(out["dense"][0], ref) < 1e-7
+    assert relerr(out["condensed"][0], ref) < 1e-7
+    assert relerr(out["condensed"][0], out["dense"][0]) < 1e-8
+    n2 = float((np.diff(L.patch_ptr).astype(np.float64) ** 2).sum())
+    print("%s: %d patches up to %d dofs, dense %.2f MB, condensed %.2f MB (%.1f x)"
+          % (case, len(L.patch_ptr) - 1, np.diff(L.patch_ptr).max(), out["dense"][1] / 1e6, out["condensed"][1] / 1e6,
+             out["dense"][1] / out["condensed"][1]))
+    assert out["condensed"][1] < 8 * n2
+    if case == "3d-P3":
+        assert out["dense"][1] > 3 * out["condensed"][1]
+
+
+def test_groups_that_are_coupled_are_refused(ctx):
+    from alfi_amd import hip
+    from alfi_amd.problem import TwoDimLidDrivenCavityProblem
+    from alfi_amd.sv import build_sv_hierarchy
+    lv, _ = build_sv_hierarchy(TwoDimLidDrivenCavityProblem(2), 1, 2, Re=10.0)
+    L = lv[-1]
+    dl = hip.Level(ctx, L.A, L.bc_dofs)
+    dl.set_patches(L.patch_ptr, L.patch_dofs)
+    bad = np.arange(len(L.patch_dofs), dtype=np.int32) // L.bs        # every node its own group: neighbours are coupled
+    with pytest.raises(hip.AlfiHipError, match="coupled"):
+        dl.set_patch_groups(bad)
+    dl.set_patch_groups(None)                                          # back to dense
+    dl.factor()
+    dl.close()
+
+
+def test_cycles_with_condensed_factors_match_the_oracle(ctx):
+    """The whole PCMG cycle of the 3-D [P3]^3 Scott-Vogelius hierarchy (what hip.Multigrid builds by default: condensed
+    macro-star factors) against the oracle."""
+    from alfi_amd import hip
+    from alfi_amd.problem import ThreeDimLidDrivenCavityProblem
+    from alfi_amd.sv import build_sv_hierarchy
+    from oracle import alfi_oracle as O
+    lv, tr = build_sv_hierarchy(ThreeDimLidDrivenCavityProblem(1), 1, 3, Re=100.0)
+    mg = hip.Multigrid(ctx, lv, tr, 3, robust_restriction=True)
+    assert mg.levels[-1].factor_bytes() < 0.5 * 8 * float((np.diff(lv[-1].patch_ptr).astype(np.float64) ** 2).sum())
+    omg = O.build_oracle_mg(lv, tr, 3, schoeberl_restriction=True)
+    L = lv[-1]
+    b = np.random.default_rng(0).standard_normal(L.n)
+    b[L.bc_dofs] = 0
+    db, dx = ctx.vec(b), ctx.vec(L.n)
+    mg.vcycle(db, dx)
+    assert relerr(dx.get(), omg.vcycle(1, b, np.zeros(L.n))) < 1e-5
+    mg.fcycle(db, dx)
+    assert relerr(dx.get(), omg.fcycle(b)) < 1e-5
+    mg.close()
