@@ -789,14 +789,44 @@ __global__ __launch_bounds__(256) void cond_schur_kernel(int64_t p0, CondDev cd,
   }
 }
 
-// additive apply, stage 1, condensed patches [p0, p1): one workgroup per patch.  Dynamic LDS (doubles): xs (n: gathered x,
-// condensed order; interior slices become t_g, the skeleton slice becomes x_S - sum B_g t_g), us (sum_g s_g), ys (s).
+// additive apply, stage 1, condensed patches [p0, p1): one workgroup of COND_WAVES waves per patch.  Dynamic LDS (doubles):
+// xs (n: gathered x, condensed order; interior slices become t_g, the skeleton slice becomes x_S - sum B_g t_g), us
+// (sum_g s_g), ys (s).  The small matrices are streamed with COND_U loads in flight per lane (they are read once).
+constexpr int COND_WAVES = 8;
+constexpr int COND_U = 8;
+
+// acc += sum_k M[k * ld + lane] * bcast_k, k < m, for the lanes < rows; bcast_k = lane k's value of `v`
 template <bool NT>
-__global__ __launch_bounds__(256) void cond_apply_kernel(int64_t p0, int64_t p1, CondDev cd,
-                                                          const int64_t* __restrict__ patch_ptr,
-                                                          const int64_t* __restrict__ stage_ptr,
-                                                          const double* __restrict__ x, double* __restrict__ stage, int umax) {
+__device__ __forceinline__ double cond_gemv_shfl(const double* __restrict__ M, int ld, int rows, int m, double v, int lane,
+                                                 double acc) {
+  const bool act = lane < rows;
+  int k = 0;
+  for (; k + COND_U <= m; k += COND_U) {
+    double a[COND_U];
+#pragma unroll
+    for (int u = 0; u < COND_U; ++u) {
+      const double* q = M + (int64_t)(k + u) * ld + lane;
+      a[u] = act ? (NT ? __builtin_nontemporal_load(q) : *q) : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < COND_U; ++u) acc = __builtin_fma(a[u], __shfl(v, k + u, 64), acc);
+  }
+  for (; k < m; ++k) {
+    const double* q = M + (int64_t)k * ld + lane;
+    const double a = act ? (NT ? __builtin_nontemporal_load(q) : *q) : 0.0;
+    acc = __builtin_fma(a, __shfl(v, k, 64), acc);
+  }
+  return acc;
+}
+
+template <bool NT>
+__global__ __launch_bounds__(64 * COND_WAVES) void cond_apply_kernel(int64_t p0, int64_t p1, CondDev cd,
+                                                                     const int64_t* __restrict__ patch_ptr,
+                                                                     const int64_t* __restrict__ stage_ptr,
+                                                                     const double* __restrict__ x, double* __restrict__ stage,
+                                                                     int umax) {
   extern __shared__ double cond_dsmem[];
+  constexpr int NT_ = 64 * COND_WAVES;
   const int64_t p = p0 + blockIdx.x;
   if (p >= p1) return;
   const int64_t off = patch_ptr[p];
@@ -806,53 +836,44 @@ __global__ __launch_bounds__(256) void cond_apply_kernel(int64_t p0, int64_t p1,
   double* xs = cond_dsmem;
   double* us = xs + n;
   double* ys = us + umax;
-  for (int i = threadIdx.x; i < n; i += 256) xs[i] = x[cd.dofs[off + i]];
+  for (int i = threadIdx.x; i < n; i += NT_) xs[i] = x[cd.dofs[off + i]];
   __syncthreads();
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int64_t g0 = cd.gptr[p], g1 = cd.gptr[p + 1];
   // phase 1: t_g = X_g x_g (kept in the lanes' registers and written over x_g), u_g = B_g t_g
-  for (int64_t g = g0 + wave; g < g1; g += 4) {
+  for (int64_t g = g0 + wave; g < g1; g += COND_WAVES) {
     const int m = cd.g_m[g], sc = cd.g_sc[g], o = cd.g_off[g];
     const double* X = cd.mat + cd.g_mat[g];
     const double* B = X + (int64_t)m * m;
     const double xg = lane < m ? xs[o + lane] : 0.0;
-    double t = 0.0;
-    for (int k = 0; k < m; ++k) {
-      const double xv = __shfl(xg, k, 64);
-      const double a = lane < m ? (NT ? __builtin_nontemporal_load(X + (int64_t)k * m + lane) : X[(int64_t)k * m + lane]) : 0.0;
-      t = __builtin_fma(a, xv, t);
-    }
-    double u = 0.0;
-    for (int k = 0; k < m; ++k) {
-      const double tv = __shfl(t, k, 64);
-      const double b = lane < sc ? (NT ? __builtin_nontemporal_load(B + (int64_t)k * sc + lane) : B[(int64_t)k * sc + lane]) : 0.0;
-      u = __builtin_fma(b, tv, u);
-    }
+    const double t = cond_gemv_shfl<NT>(X, m, m, m, xg, lane, 0.0);
+    const double u = cond_gemv_shfl<NT>(B, sc, sc, m, t, lane, 0.0);
     if (lane < m) xs[o + lane] = t;              // only this wave reads or writes the slice of its group
     if (lane < sc) us[cd.g_uoff[g] + lane] = u;
   }
   __syncthreads();
   // phase 2: the right-hand side of the Schur system, contributions in a fixed order
   const int64_t srow0 = cd.sptr[p];
-  for (int i = threadIdx.x; i < s; i += 256) {
+  for (int i = threadIdx.x; i < s; i += NT_) {
     double acc = xs[nI + i];
     for (int32_t q = cd.s_uptr[srow0 + i]; q < cd.s_uptr[srow0 + i + 1]; ++q) acc -= us[cd.s_uidx[q]];
     xs[nI + i] = acc;
   }
   __syncthreads();
-  // phase 3: y_S = inv(Sigma) rhs, row pieces dealt to the four waves
+  // phase 3: y_S = inv(Sigma) rhs, row pieces dealt to the waves
   if (s > 0) {
     const int ld = (s + 1) & ~1;
     const double* T = cd.sinv + cd.sinv_ptr[p];
     int piece = 0, row0 = 0;
+    // pieces of 64 rows (not 128) so that a skeleton of a few hundred dofs still occupies every wave
     for (; row0 + 128 <= ld; row0 += 128, ++piece)
-      if (piece % 4 == wave) big_piece<64, NT>(T + (int64_t)row0 * s, s, xs + nI, lane, ys + row0);
+      if (piece % COND_WAVES == wave) big_piece<64, NT>(T + (int64_t)row0 * s, s, xs + nI, lane, ys + row0);
     const int rem = ld - row0;
-#define ALFI_BIG_PIECE(R)                                                                          \
-  if (rem & R) {                                                                                   \
-    if (piece % 4 == wave) big_piece<R / 2, NT>(T + (int64_t)row0 * s, s, xs + nI, lane, ys + row0); \
-    row0 += R;                                                                                     \
-    ++piece;                                                                                       \
+#define ALFI_BIG_PIECE(R)                                                                                   \
+  if (rem & R) {                                                                                            \
+    if (piece % COND_WAVES == wave) big_piece<R / 2, NT>(T + (int64_t)row0 * s, s, xs + nI, lane, ys + row0); \
+    row0 += R;                                                                                              \
+    ++piece;                                                                                                \
   }
     ALFI_BIG_PIECE(64)
     ALFI_BIG_PIECE(32)
@@ -865,18 +886,15 @@ __global__ __launch_bounds__(256) void cond_apply_kernel(int64_t p0, int64_t p1,
   __syncthreads();
   // phase 4: y_g = t_g - W_g y_S[S_g] and the skeleton part, into the staging slots of the ascending order
   double* out = stage + stage_ptr[p];
-  for (int64_t g = g0 + wave; g < g1; g += 4) {
+  for (int64_t g = g0 + wave; g < g1; g += COND_WAVES) {
     const int m = cd.g_m[g], sc = cd.g_sc[g], o = cd.g_off[g];
     const double* W = cd.mat + cd.g_mat[g] + (int64_t)m * m + (int64_t)sc * m;
-    const int32_t* si = cd.sidx + cd.g_sidx[g];
-    double acc = lane < m ? xs[o + lane] : 0.0;
-    for (int j = 0; j < sc; ++j) {
-      const double w = lane < m ? (NT ? __builtin_nontemporal_load(W + (int64_t)j * m + lane) : W[(int64_t)j * m + lane]) : 0.0;
-      acc = __builtin_fma(-w, ys[si[j]], acc);
-    }
+    const double yv = lane < sc ? ys[cd.sidx[cd.g_sidx[g] + lane]] : 0.0;      // lane j holds y_S[S_g[j]]
+    const double tg = lane < m ? xs[o + lane] : 0.0;
+    const double acc = cond_gemv_shfl<NT>(W, m, m, sc, -yv, lane, tg);
     if (lane < m) out[cd.slot[off + o + lane]] = acc;
   }
-  for (int i = threadIdx.x; i < s; i += 256) out[cd.slot[off + nI + i]] = ys[i];
+  for (int i = threadIdx.x; i < s; i += NT_) out[cd.slot[off + nI + i]] = ys[i];
 }
 
 // the whole operator of a (coarse) level as ONE dense N x N matrix (N = n rounded up to 64, identity padding): zero / pad,
@@ -1124,7 +1142,7 @@ int launch_cond_apply_range(alfi_level* L, int64_t p0, int64_t p1, const double*
   alfi_ctx* ctx = L->ctx;
   if (p1 <= p0) return 0;
   static const bool nt = !(getenv("ALFI_NT") && atoi(getenv("ALFI_NT")) == 0);
-  dim3 grid((unsigned)(p1 - p0)), block(256);
+  dim3 grid((unsigned)(p1 - p0)), block(64 * COND_WAVES);
   const size_t lds = (size_t)L->cond_lds_bytes;
   if (lds > 64 * 1024) {                          // beyond the default dynamic LDS limit (gfx950 has 160 KB per CU)
     ALFI_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&cond_apply_kernel<true>),
