@@ -792,7 +792,6 @@ __global__ __launch_bounds__(256) void cond_schur_kernel(int64_t p0, CondDev cd,
 // additive apply, stage 1, condensed patches [p0, p1): one workgroup of COND_WAVES waves per patch.  Dynamic LDS (doubles):
 // xs (n: gathered x, condensed order; interior slices become t_g, the skeleton slice becomes x_S - sum B_g t_g), us
 // (sum_g s_g), ys (s).  The small matrices are streamed with COND_U loads in flight per lane (they are read once).
-constexpr int COND_WAVES = 8;
 constexpr int COND_U = 8;
 
 // acc += sum_k M[k * ld + lane] * bcast_k, k < m, for the lanes < rows; bcast_k = lane k's value of `v`
@@ -819,7 +818,7 @@ __device__ __forceinline__ double cond_gemv_shfl(const double* __restrict__ M, i
   return acc;
 }
 
-template <bool NT>
+template <bool NT, int COND_WAVES>
 __global__ __launch_bounds__(64 * COND_WAVES) void cond_apply_kernel(int64_t p0, int64_t p1, CondDev cd,
                                                                      const int64_t* __restrict__ patch_ptr,
                                                                      const int64_t* __restrict__ stage_ptr,
@@ -1142,20 +1141,27 @@ int launch_cond_apply_range(alfi_level* L, int64_t p0, int64_t p1, const double*
   alfi_ctx* ctx = L->ctx;
   if (p1 <= p0) return 0;
   static const bool nt = !(getenv("ALFI_NT") && atoi(getenv("ALFI_NT")) == 0);
-  dim3 grid((unsigned)(p1 - p0)), block(64 * COND_WAVES);
+  // waves per patch: 8 (measured on config 5, finest level, same box: 4 waves 4.16 TB/s, 8 waves 5.00, 16 waves 4.68);
+  // ALFI_COND_WAVES = 4 / 8 / 16 for A/B runs
+  static const int waves = getenv("ALFI_COND_WAVES") ? atoi(getenv("ALFI_COND_WAVES")) : 8;
+  dim3 grid((unsigned)(p1 - p0));
   const size_t lds = (size_t)L->cond_lds_bytes;
-  if (lds > 64 * 1024) {                          // beyond the default dynamic LDS limit (gfx950 has 160 KB per CU)
-    ALFI_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&cond_apply_kernel<true>),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    ALFI_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&cond_apply_kernel<false>),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+#define ALFI_COND_LAUNCH(NTV, WV)                                                                                       \
+  do {                                                                                                                  \
+    if (lds > 64 * 1024)                                                                                                \
+      ALFI_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&cond_apply_kernel<NTV, WV>),               \
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                   \
+    hipLaunchKernelGGL((cond_apply_kernel<NTV, WV>), grid, dim3(64 * WV), lds, ctx->stream, p0, p1, L->cd, L->patch_ptr, \
+                       L->stage_ptr, x, L->stage, L->cond_umax);                                                        \
+  } while (0)
+  if (waves == 4) {
+    if (nt) ALFI_COND_LAUNCH(true, 4); else ALFI_COND_LAUNCH(false, 4);
+  } else if (waves == 16) {
+    if (nt) ALFI_COND_LAUNCH(true, 16); else ALFI_COND_LAUNCH(false, 16);
+  } else {
+    if (nt) ALFI_COND_LAUNCH(true, 8); else ALFI_COND_LAUNCH(false, 8);
   }
-  if (nt)
-    hipLaunchKernelGGL(cond_apply_kernel<true>, grid, block, lds, ctx->stream, p0, p1, L->cd, L->patch_ptr, L->stage_ptr, x,
-                       L->stage, L->cond_umax);
-  else
-    hipLaunchKernelGGL(cond_apply_kernel<false>, grid, block, lds, ctx->stream, p0, p1, L->cd, L->patch_ptr, L->stage_ptr, x,
-                       L->stage, L->cond_umax);
+#undef ALFI_COND_LAUNCH
   ALFI_HIP_CHECK(ctx, hipGetLastError());
   return 0;
 }
