@@ -717,6 +717,7 @@ int alfi_patches_set(alfi_level* L, int64_t npatch, const int64_t* pptr, const i
   L->inv = nullptr; L->stage = nullptr; L->dof_ptr = nullptr; L->dof_pos = nullptr;
   L->factored = false;
   free_cond(L);
+  L->inv_shrunk = false;
   L->npatch = npatch;
   const int64_t sum_n = npatch > 0 ? pptr[npatch] : 0;
   if (sum_n > INT32_MAX) return alfi_set_error(ctx, ALFI_E_ARG, "too many patch dofs for int32 staging indices");
@@ -790,6 +791,12 @@ int alfi_patches_set_groups(alfi_level* L, const int32_t* group) {
   ALFI_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
   free_cond(L);
   L->factored = false;
+  if (L->inv_shrunk) {                                   // condensed before: the dense storage was released
+    dev_free(L->inv);
+    L->inv = nullptr;
+    L->inv_shrunk = false;
+    ALFI_CHECK(dev_alloc(ctx, &L->inv, L->inv_doubles));
+  }
   if (!group) return 0;                                  // back to dense inverses
   if (L->mult) return alfi_set_error(ctx, ALFI_E_STATE, "condensed patch factors do not support multiplicative sweeps");
   const int bs = L->bs;
@@ -932,6 +939,7 @@ int alfi_patches_set_groups(alfi_level* L, const int32_t* group) {
   dev_free(L->inv);
   L->inv = nullptr;
   ALFI_CHECK(dev_alloc(ctx, &L->inv, 16));
+  L->inv_shrunk = true;
   L->cd = cd;
   L->cond = true;
   L->h_sptr = sptr;

@@ -216,6 +216,7 @@ struct alfi_level {
   int64_t chk_flagged = 0, chk_repaired = 0;
   // condensed patch factors (alfi_patches_set_groups)
   bool cond = false;
+  bool inv_shrunk = false;               // the dense inverse storage was released in favour of the condensed factors
   CondDev cd;
   std::vector<void*> cond_allocs;        // every device array cd points to
   std::vector<int64_t> h_sptr;           // host copy of cd.sptr (sizes of the Schur complements)

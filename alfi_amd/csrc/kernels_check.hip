@@ -286,13 +286,13 @@ int patch_verify_and_repair(alfi_level* L, int unpivoted_status) {
   if (nflag > L->chk_cap)
     return alfi_set_error(ctx, ALFI_E_SINGULAR, "%d of %lld patch inverses fail the residual probe (worst %.3e)", nflag,
                           (long long)L->npatch, worst);
-  constexpr int REPAIR_MAX_NP = 1024;
+  constexpr int REPAIR_MAX_NP = PATCH_MAX;     // (a 2000-dof patch takes ~0.5 s of one workgroup: a rare-path safety net)
   if (L->cond)
     return alfi_set_error(ctx, ALFI_E_SINGULAR, "%d condensed patch factors fail the residual probe (worst %.3e); use dense "
                           "inverses (alfi_patches_set_groups(NULL)) for this operator", nflag, worst);
   if (L->max_np > REPAIR_MAX_NP)
     return alfi_set_error(ctx, ALFI_E_SINGULAR, "%d patch inverses fail the residual probe (worst %.3e) and the pivoted "
-                          "repair handles patches of at most %d dofs", nflag, worst, REPAIR_MAX_NP);
+                          "repair handles patches of at most %d dofs", nflag, worst, (int)REPAIR_MAX_NP);
   // pivoted re-inversion of the flagged patches, in batches bounded by 1 GiB of scratch
   const int64_t stride = (int64_t)L->max_np * L->max_np;
   const int64_t per_batch = std::max<int64_t>(1, ((int64_t)1 << 27) / stride);
@@ -301,6 +301,13 @@ int patch_verify_and_repair(alfi_level* L, int unpivoted_status) {
   ALFI_HIP_CHECK(ctx, hipMemsetAsync(L->status, 0, sizeof(int), ctx->stream));
   const size_t lds = (size_t)L->max_np * (2 * sizeof(double) + 2 * sizeof(int32_t));
   int rc = 0;
+  if (lds > 64 * 1024) {     // beyond the default dynamic LDS limit (gfx950: 160 KB per CU)
+    hipError_t ea = L->bs == 2 ? hipFuncSetAttribute(reinterpret_cast<const void*>(&patch_repair_kernel<2>),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
+                               : hipFuncSetAttribute(reinterpret_cast<const void*>(&patch_repair_kernel<3>),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (ea != hipSuccess) rc = alfi_set_error(ctx, ALFI_E_HIP, "hipFuncSetAttribute: %s", hipGetErrorString(ea));
+  }
   for (int64_t b0 = 0; b0 < nflag && rc == 0; b0 += per_batch) {
     const int64_t nb = std::min<int64_t>(per_batch, nflag - b0);
     dim3 grid((unsigned)nb), block(256);

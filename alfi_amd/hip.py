@@ -188,6 +188,19 @@ class Level(object):
     def factor(self):
         self.ctx.check(self.ctx.lib.alfi_patches_factor(self.h))
 
+    def factor_with_fallback(self):
+        """factor(); if CONDENSED factors fail the residual probe (they are not repaired in place), fall back to dense
+        inverses for this level -- those go through the pivoted repair -- and factor again.  Returns True if it fell back."""
+        try:
+            self.factor()
+            return False
+        except AlfiHipError as e:
+            if "condensed" not in str(e):
+                raise
+        self.set_patch_groups(None)
+        self.factor()
+        return True
+
     def patch_check(self):
         """(worst residual || A_p X_p e - e || of the fast inversion, patches flagged, patches repaired by the pivoted
         re-inversion, worst residual afterwards) of the last ``factor()``."""
@@ -329,7 +342,7 @@ class Multigrid(object):
                 dl.set_patches(L.patch_ptr, L.patch_dofs)
                 if condense_patches(L):
                     dl.set_patch_groups(L.patch_groups)
-                dl.factor()
+                dl.factor_with_fallback()
             elif coarse_inv is not None:
                 dl.set_coarse_inverse(coarse_inv)          # an inverse supplied by the caller (numpy array / device pointer)
             else:

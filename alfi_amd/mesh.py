@@ -104,7 +104,12 @@ class SimplexMesh(object):
         return vm, em, fm
 
     def cell_geometry(self):
-        """Barycentric-coordinate gradients g (nc, dim+1, dim) and cell volumes (nc,)."""
+        """Barycentric-coordinate gradients g (nc, dim+1, dim) and cell volumes (nc,); computed once per mesh."""
+        if getattr(self, "_geometry", None) is None:
+            self._geometry = self._cell_geometry()
+        return self._geometry
+
+    def _cell_geometry(self):
         x = self.coords[self.cells]                       # (nc, d+1, d)
         J = (x[:, 1:, :] - x[:, :1, :]).transpose(0, 2, 1)  # columns = edge vectors
         det = np.linalg.det(J)

@@ -48,6 +48,11 @@ def test_condensed_apply_equals_dense_inverse_apply(ctx, case):
         out[mode] = (dy.get(), dl.factor_bytes())
         dl.patch_apply(dx, dy)
         assert np.array_equal(dy.get(), out[mode][0])               # deterministic
+        if mode == "condensed":                                      # and back to dense inverses on the same level
+            dl.set_patch_groups(None)
+            dl.factor()
+            dl.patch_apply(dx, dy)
+            assert np.array_equal(dy.get(), out["dense"][0]) and dl.factor_bytes() == out["dense"][1]
         dl.close()
     ref = O.PatchSmoother(L.A.to_scipy().tocsr(), L.patch_ptr, L.patch_dofs, L.bc_dofs).apply(x)
     assert relerr(out["dense"][0], ref) < 1e-7

@@ -205,3 +205,45 @@ def test_partitioned_newton(tmp_path):
     assert np.abs(z["u"] - s.u).max() < 1e-7 * np.abs(s.u).max()
     assert np.abs(z["p"] - s.p).max() < 1e-6 * np.abs(s.p).max()
     s.close()
+
+
+def _bench(args, env_extra, timeout=900):
+    import json
+    env = dict(os.environ, **env_extra)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)                                     # the launcher under test sets them itself
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, cwd=ROOT, capture_output=True,
+                         text=True, timeout=timeout)
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    return out, (json.loads(lines[-1]) if lines else None)
+
+
+def test_bench_starts_its_own_ranks_shared_gpu():
+    """`python bench.py --gpus N` without a launcher starts the N rank processes itself (before anything touches a GPU),
+    relays rank 0's JSON line and reports the process group's size.  Here: 2 ranks sharing the box's GPU over gloo (callback
+    transport, rank-local generation) -- a functional run of exactly the driver's command shape."""
+    out, d = _bench(["--gpus", "2", "--config", "tiny", "--steps", "2", "--warmup", "1"],
+                    {"ALFI_DIST_BACKEND": "gloo", "ALFI_DIST_MIN_DOFS": "1000"})
+    assert out.returncode == 0 and d is not None, out.stderr[-3000:]
+    assert d["n_gpus"] == 2 and d["n_ranks_seen"] == 2 and d["config"]["transport"] == "callback"
+    assert d["config"]["generation"].startswith("rank-local") and d["rel_residual_after_timed_cycles"] < 0.5
+    assert len(d["setup_s"]["host_peak_rss_GB_per_rank"]) == 2
+
+
+def test_bench_launcher_fails_loudly_when_a_rank_cannot_start():
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("needs a box with fewer GPUs than ranks")
+    out, d = _bench(["--gpus", "2", "--config", "tiny", "--steps", "1", "--warmup", "0"], {"ALFI_DIST_BACKEND": "nccl"}, 300)
+    assert out.returncode != 0 and d is None
+
+
+def test_two_rank_rccl_run():
+    """The native RCCL transport with more than one rank: needs two GPUs (RCCL refuses several ranks on one device)."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("fewer than 2 GPUs visible")
+    out, d = _bench(["--gpus", "2", "--config", "cfg4t", "--steps", "3", "--warmup", "1"], {"ALFI_DIST_MIN_DOFS": "1000"})
+    assert out.returncode == 0 and d is not None, out.stderr[-3000:]
+    assert d["n_ranks_seen"] == 2 and d["config"]["transport"] == "rccl" and d["config"]["backend"] == "nccl"
+    assert d["rel_residual_after_timed_cycles"] < 0.5
