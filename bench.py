@@ -497,7 +497,7 @@ def main():
         pmc = json.load(open(pmc_file))
         traffic = pmc.get("hbm_bytes_per_launch")
         traffic_source = {"measured_in_this_run": False, "file": os.path.relpath(pmc_file, ROOT),
-                          "collected": pmc.get("collected", "round 1 (2026-10-03), rocprofv3 --pmc, another box"),
+                          "collected": pmc.get("collected", "an earlier rocprofv3 --pmc run on another box; see tag"),
                           "tag": pmc.get("tag")}
 
     out = {

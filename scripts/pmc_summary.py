@@ -4,7 +4,10 @@
 gfx950 corrections (MI355X_MICROARCH.md, HBM section): FETCH_SIZE is reported in KiB and tallies the 128-B requests of a
 wide streaming read at 64 B => bytes = 2 * 1024 * FETCH_SIZE; WRITE_SIZE (KiB) is exact for streaming stores.
 
-usage: pmc_summary.py <fetch_dir> <write_dir> <kernel-name-prefix> <out.json> [tag] [first] [grids]
+usage: pmc_summary.py <fetch_dir> <write_dir> <kernel-name-prefix> <out.json> [tag] [first] [grids] [skip]
+
+``skip``: leading launches of the kernel to drop -- since round 2 every patch factorisation ends with a residual probe that
+runs the level's apply kernel once (one launch per smoothed level before the first cycle).
 
 ``first``: only the first N launches of the kernel -- the V-cycle of ``bench.py --steps 1 --warmup 0`` (60 patch applies, 79
 SpMVs on config 4); the full cycles bench.py runs afterwards for ``fcycle_ms`` have a different mix of levels.
@@ -18,14 +21,14 @@ import sys
 import pandas as pd
 
 
-def per_kernel(d, counter, prefix, first=None, grids=None):
+def per_kernel(d, counter, prefix, first=None, grids=None, skip=0):
     f = glob.glob(d + "/**/*_counter_collection.csv", recursive=True)[0]
     t = pd.read_csv(f)
     t = t[(t["Counter_Name"] == counter) & t["Kernel_Name"].str.startswith(prefix)]
     if grids:
         t = t[t["Grid_Size"].isin(grids)]
     # one row per dispatch and counter instance: sum the instances, keep dispatch order
-    v = t.groupby("Dispatch_Id", sort=True)["Counter_Value"].sum().to_numpy()
+    v = t.groupby("Dispatch_Id", sort=True)["Counter_Value"].sum().to_numpy()[skip:]
     return v[:first] if first else v
 
 
@@ -33,11 +36,13 @@ def main():
     fetch_dir, write_dir, prefix, out = sys.argv[1:5]
     tag = sys.argv[5] if len(sys.argv) > 5 else ""
     first = int(sys.argv[6]) if len(sys.argv) > 6 else None
-    grids = [int(g) for g in sys.argv[7].split(",")] if len(sys.argv) > 7 else None
-    f, w = (per_kernel(fetch_dir, "FETCH_SIZE", prefix, first, grids),
-            per_kernel(write_dir, "WRITE_SIZE", prefix, first, grids))
+    grids = [int(g) for g in sys.argv[7].split(",")] if len(sys.argv) > 7 and sys.argv[7] not in ("", "-") else None
+    skip = int(sys.argv[8]) if len(sys.argv) > 8 else 0
+    first = first or None
+    f, w = (per_kernel(fetch_dir, "FETCH_SIZE", prefix, first, grids, skip),
+            per_kernel(write_dir, "WRITE_SIZE", prefix, first, grids, skip))
     fb, wb = 2.0 * 1024.0 * f.mean(), 1024.0 * w.mean()
-    res = {"kernel": prefix, "tag": tag, "launches": int(len(f)),
+    res = {"kernel": prefix, "tag": tag, "launches": int(len(f)), "skipped_leading_launches": skip,
            "fetch_size_KiB_avg_raw": float(f.mean()), "write_size_KiB_avg_raw": float(w.mean()),
            "fetch_bytes_per_launch": fb, "write_bytes_per_launch": wb, "hbm_bytes_per_launch": fb + wb,
            "fetch_bytes_per_launch_max": 2048.0 * float(f.max()),
