@@ -1173,14 +1173,15 @@ int alfi_smooth_fgmres(alfi_level* L, int k, const double* db, double* dx, int n
   ALFI_CHECK(ensure_fgmres_workspace(L, k));
   ctx->cur_tag = L->id;
   {
-    // small unpartitioned levels (<= 1 M dofs, <= 2 M operator blocks: a smoother iteration is launch latency, not
-    // bandwidth): the four-launch iteration.  ALFI_FUSED_SMOOTHER=0 keeps the general path (A/B measurements).
+    // unpartitioned levels with short operator rows: the four-launch iteration (on the small levels a smoother iteration is
+    // launch latency, on the large 2-D ones the folded vector passes save BLAS-1 traffic, which is comparable to the patch
+    // traffic there).  ALFI_FUSED_SMOOTHER=0 keeps the general path (A/B measurements).
     static const bool allow = !(getenv("ALFI_FUSED_SMOOTHER") && atoi(getenv("ALFI_FUSED_SMOOTHER")) == 0);
     // (rows of up to ~32 blocks -- the 2-D operators; with the 50 .. 100 blocks per row of the 3-D ones the flat segmented
     // product of the general path is the faster kernel and the fused iteration gains nothing: cfg3 19.0 vs 18.9 ms, cfg2
     // 5.10 vs 5.43 ms, same box)
     if (allow && !L->distributed && L->n_own == L->n && !L->mult && k + 1 <= 16 && L->A_own.flat &&
-        L->A_own.nnzb <= SPMV_ALIGNED_MAX && L->A_own.nnzb <= 32 * L->A_own.nbrows && red_blocks_for(L->n) <= 256)
+        L->A_own.nnzb <= 32 * L->A_own.nbrows)
       return smooth_fgmres_fused(L, k, db, dx, nonzero_guess);
   }
   const int K = L->kmax;

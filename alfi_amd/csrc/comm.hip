@@ -14,6 +14,7 @@
 #include <dlfcn.h>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <rccl/rccl.h>
 #include "common.h"
 
@@ -42,8 +43,11 @@ bool resolve(void* h, const char* name, F* out) {
   return *out != nullptr;
 }
 
+std::mutex g_api_mutex;     // ctxs of different threads may create their communicators concurrently
+
 // nullptr + g_api_error on failure
 RcclApi* rccl() {
+  std::lock_guard<std::mutex> lock(g_api_mutex);
   if (g_api.handle) return &g_api;
   const char* names[] = {getenv("ALFI_RCCL_LIB"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
   void* h = nullptr;

@@ -414,15 +414,17 @@ __device__ __forceinline__ void block_store_partials(double (&acc)[NV], double* 
         red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
 }
 
-// every thread of the block gets out[v] = sum_{b < nblocks <= 256} partial[b][v], summed in one fixed order: all blocks
-// of a launch (and the kernels that follow) see the identical value, and no separate reduction launch is needed
+// every thread of the block gets out[v] = sum_{b < nblocks <= RED_BLOCKS} partial[b][v], summed in one fixed order: all
+// blocks of a launch (and the kernels that follow) see the identical value, and no separate reduction launch is needed
 template <int NV>
 __device__ __forceinline__ void block_reduce_partials(const double* __restrict__ partial, int nblocks, double (&out)[NV]) {
   __shared__ double red2[4][NV];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
 #pragma unroll
   for (int v = 0; v < NV; ++v) {
-    const double s = wave_sum((int)threadIdx.x < nblocks ? partial[(int64_t)threadIdx.x * RED_MAXV + v] : 0.0);
+    double s = 0.0;
+    for (int b = threadIdx.x; b < nblocks; b += 256) s += partial[(int64_t)b * RED_MAXV + v];
+    s = wave_sum(s);
     if (lane == 0) red2[wave][v] = s;
   }
   __syncthreads();
@@ -613,7 +615,7 @@ __global__ __launch_bounds__(256) void patch_sum_scale_kernel(int64_t n, const i
 }
 
 // w = A z on the block rows [0, nbrows) of a flat-layout BSR matrix, LPR lanes per block row, and in the same pass the
-// partials of V_v . w for v < NV (gridDim.x <= 256 blocks, grid-stride over the rows)
+// partials of V_v . w for v < NV (gridDim.x <= RED_BLOCKS blocks, grid-stride over the rows)
 template <int BS, int LPR, int NV>
 __global__ __launch_bounds__(256) void bsr_spmv_dot_kernel(int64_t nbrows, const int32_t* __restrict__ rowptr,
                                                             const int32_t* __restrict__ colflag,
@@ -859,7 +861,7 @@ static int launch_spmv_dot_lpr(alfi_ctx* ctx, const DevBSR& A, const double* z, 
                                int nv, double* partial, int* nblocks) {
   const int64_t rows_per_block = 256 / LPR;
   int64_t g = (A.nbrows + rows_per_block - 1) / rows_per_block;
-  if (g > 256) g = 256;
+  if (g > RED_BLOCKS) g = RED_BLOCKS;      // one partial per block: at most RED_BLOCKS of them
   if (g < 1) g = 1;
   *nblocks = (int)g;
 #define ALFI_CASE(N)                                                                                                 \

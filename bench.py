@@ -532,7 +532,9 @@ def main():
         "spmv_finest": {"achieved_GBps": spmv_gbs, "frac": spmv_gbs / HBM_PEAK_GBS,
                         "avg_launch_us": 1e3 * t_spmv_ms / max(n_spmv, 1)},
         "events_ms": {kname: round(v[0], 3) for kname, v in prof_all.items()},
-        "events_note": "device time per event class of ONE extra, fully instrumented V-cycle after the timed region",
+        "events_note": "device time per event class of ONE extra, fully instrumented V-cycle after the timed region; on "
+                       "launch-bound configurations (cfg2, cfg3) the event records lengthen the intervals they bracket and "
+                       "the classes sum to more than the cycle: use the kernel trace (profiles/r02_kernel_trace_*.txt) there",
         "rel_residual_after_timed_cycles": res,
         "setup_s": {"host_generation": round(t_gen, 1), "device_setup_incl_patch_inversion": round(t_setup, 1),
                     "host_peak_rss_GB": round(resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 1e6, 1)},

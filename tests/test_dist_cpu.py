@@ -198,3 +198,32 @@ def test_spmd_outer_solve_matches_serial(case, world):
     assert not np.isnan(xu).any() and not np.isnan(xp).any()             # every velocity dof and every cell has one owner
     assert np.abs(xu - xs[:L.n]).max() < 1e-6 * np.abs(xs[:L.n]).max()
     assert np.abs(xp - xs[L.n:]).max() < 1e-5 * np.abs(xs[L.n:]).max()
+
+
+@pytest.mark.parametrize("case,world", [("3d-P2FB-3lev", 4), ("2d-all-distributed", 3), ("3d-P1FB", 2)])
+def test_neighbour_tables_of_the_native_transport_are_consistent(case, world):
+    """What alfi_level_set_neighbours receives on every rank (and the grouped ncclSend / ncclRecv of comm.hip then use): for
+    every pair of ranks the sender's count equals the receiver's, the sender's segment holds exactly the nodes the receiver
+    lists as its ghosts owned by the sender, in the receiver's ghost order; the counts add up to the halo sizes; a rank is
+    never its own neighbour.  No GPU, no process group: all ranks' partitions are computed here."""
+    from alfi_amd import dist as D
+    lv, tr, k, min_dofs = _hier(case)
+    splits = D.choose_splits(lv, world, min_dofs)
+    parts = [D.build_parts(lv, tr, splits, r) for r in range(world)]
+    for l in range(len(lv)):
+        for a in range(world):
+            pa = parts[a][l]
+            nbr = np.flatnonzero((pa.send_counts > 0) | (pa.recv_counts > 0))
+            assert a not in nbr
+            assert pa.send_counts[nbr].sum() == sum(len(s) for s in pa.send_nodes) and pa.recv_counts[nbr].sum() == pa.nb_ghost
+            send_off = np.concatenate([[0], np.cumsum(pa.send_counts)])
+            send_all = np.concatenate(pa.send_nodes) if pa.send_counts.sum() else np.zeros(0, dtype=np.int64)
+            for b in range(world):
+                pb = parts[b][l]
+                assert pa.send_counts[b] == pb.recv_counts[a]
+                if pa.send_counts[b] == 0:
+                    continue
+                # global ids of what a packs for b == b's ghosts owned by a, in b's ghost order
+                seg = pa.own_nodes[send_all[send_off[b]:send_off[b + 1]]]
+                roff = np.concatenate([[0], np.cumsum(pb.recv_counts)])
+                assert np.array_equal(seg, pb.ghosts[roff[a]:roff[a + 1]])
