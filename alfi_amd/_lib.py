@@ -60,6 +60,7 @@ SIGNATURES = {
     "alfi_patches_factor_bytes": (ctypes.c_int, [vp, ctypes.POINTER(ctypes.c_int64)]),
     "alfi_patches_check": (ctypes.c_int, [vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int64),
                                           ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_double)]),
+    "alfi_patches_set_partition_of_unity": (ctypes.c_int, [vp, ctypes.c_int]),
     "alfi_patches_set_multiplicative": (ctypes.c_int, [vp, ctypes.c_int64, vp, ctypes.c_int]),
     "alfi_patches_multiplicative_levels": (ctypes.c_int, [vp, ctypes.POINTER(ctypes.c_int64)]),
     "alfi_patch_apply": (ctypes.c_int, [vp, vp, vp]),

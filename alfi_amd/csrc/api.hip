@@ -970,6 +970,7 @@ int alfi_patches_set_multiplicative(alfi_level* L, int64_t nit, const int64_t* i
   if (nit == 0) return 0;
   if (nit < 0 || !iterset) return alfi_set_error(ctx, ALFI_E_ARG, "bad iteration set");
   if (L->cond) return alfi_set_error(ctx, ALFI_E_STATE, "multiplicative sweeps need dense patch inverses (alfi_patches_set_groups(NULL))");
+  if (L->pou) return alfi_set_error(ctx, ALFI_E_STATE, "partition of unity applies to the additive smoother");
   // partitioned levels: every rank sweeps over its own patches with the residual of its local vector (ghost slots hold
   // the rank's own contributions only) and the ghost contributions are added onto their owners at the end -- what
   // PCPATCH does under MPI: local Gauss-Seidel, additive between ranks [3P]
@@ -1026,6 +1027,12 @@ int alfi_patches_set_multiplicative(alfi_level* L, int64_t nit, const int64_t* i
   ALFI_CHECK(dev_upload(ctx, &L->mult_seq, seq.data(), nit));
   L->mult = true;
   L->mult_symmetrise = symmetrise != 0;
+  return 0;
+}
+
+int alfi_patches_set_partition_of_unity(alfi_level* L, int on) {
+  if (on && L->mult) return alfi_set_error(L->ctx, ALFI_E_STATE, "partition of unity applies to the additive smoother");
+  L->pou = on != 0;
   return 0;
 }
 

@@ -207,6 +207,7 @@ struct alfi_level {
   int32_t* dof_ptr = nullptr;     // (n+1) CSR dof -> positions in stage
   int32_t* dof_pos = nullptr;     // (sum_n)
   bool factored = false;
+  bool pou = false;               // patch_pc_patch_partition_of_unity: additive results weighted by 1 / multiplicity
   int* status = nullptr;          // device flag: nonzero if a zero pivot was met
   // residual probe of the stored inverses + pivoted repair (kernels_check.hip)
   double* chk = nullptr;          // device: [0] worst residual (as ordered bits), [1] number of flagged patches (int)

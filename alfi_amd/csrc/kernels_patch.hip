@@ -512,11 +512,13 @@ __global__ __launch_bounds__(256) void patch_sum_kernel(int64_t i0, int64_t n, c
                                                          const int32_t* __restrict__ dof_pos,
                                                          const double* __restrict__ stage,
                                                          const uint8_t* __restrict__ bc_mask,
-                                                         const double* __restrict__ x, double* __restrict__ y) {
+                                                         const double* __restrict__ x, double* __restrict__ y, int pou) {
   const int64_t i = i0 + (int64_t)blockIdx.x * 256 + threadIdx.x;   // dofs [i0, n)
   if (i >= n) return;
   double s = 0.0;
-  for (int32_t q = dof_ptr[i]; q < dof_ptr[i + 1]; ++q) s += stage[dof_pos[q]];
+  const int32_t q0 = dof_ptr[i], q1 = dof_ptr[i + 1];
+  for (int32_t q = q0; q < q1; ++q) s += stage[dof_pos[q]];
+  if (pou && q1 - q0 > 1) s /= (double)(q1 - q0);   // patch_pc_patch_partition_of_unity: weight 1 / (patches holding the dof)
   y[i] = bc_mask[i] ? x[i] : s;   // Dirichlet dofs: y[bc] = x[bc]
 }
 
@@ -674,7 +676,7 @@ int launch_patch_sum_range(alfi_level* L, int64_t i0, int64_t i1, const double* 
   int t = alfi_prof_begin(ctx, ALFI_EV_PATCH_SCATTER);
   dim3 grid((unsigned)((i1 - i0 + 255) / 256)), block(256);
   hipLaunchKernelGGL(patch_sum_kernel, grid, block, 0, ctx->stream, i0, i1, L->dof_ptr, L->dof_pos, L->stage, L->bc_mask,
-                     x, y);
+                     x, y, L->pou ? 1 : 0);
   ALFI_HIP_CHECK(ctx, hipGetLastError());
   alfi_prof_end(ctx, t);
   return 0;

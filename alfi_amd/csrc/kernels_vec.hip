@@ -590,7 +590,7 @@ __global__ __launch_bounds__(256) void patch_sum_scale_kernel(int64_t n, const i
                                                                double* __restrict__ v,
                                                                const double* __restrict__ normpart, int nblocks,
                                                                const double* __restrict__ h, double* __restrict__ hs, int j,
-                                                               int K) {
+                                                               int K, int pou) {
   double s2[1];
   block_reduce_partials<1>(normpart, nblocks, s2);
   const double tt = sqrt(s2[0]);
@@ -607,7 +607,9 @@ __global__ __launch_bounds__(256) void patch_sum_scale_kernel(int64_t n, const i
   }
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
     double s = 0.0;
-    for (int32_t q = dof_ptr[i]; q < dof_ptr[i + 1]; ++q) s += stage[dof_pos[q]];
+    const int32_t q0 = dof_ptr[i], q1 = dof_ptr[i + 1];
+    for (int32_t q = q0; q < q1; ++q) s += stage[dof_pos[q]];
+    if (pou && q1 - q0 > 1) s /= (double)(q1 - q0);
     const double wi = w[i];
     z[i] = f * (bc_mask[i] ? wi : s);   // Dirichlet dofs: the smoother copies its argument there
     v[i] = f * wi;
@@ -851,7 +853,7 @@ int launch_patch_sum_scale(alfi_level* L, const double* w, double* z, double* v,
   alfi_ctx* ctx = L->ctx;
   const int64_t n = L->n;
   hipLaunchKernelGGL(patch_sum_scale_kernel, ew_grid(n), dim3(256), 0, ctx->stream, n, L->dof_ptr, L->dof_pos, L->stage,
-                     L->bc_mask, w, z, v, normpart, nblocks, h, hs, j, K);
+                     L->bc_mask, w, z, v, normpart, nblocks, h, hs, j, K, L->pou ? 1 : 0);
   ALFI_HIP_CHECK(ctx, hipGetLastError());
   return 0;
 }

@@ -176,6 +176,9 @@ class Level(object):
         self.ctx.check(self.ctx.lib.alfi_patches_factor_bytes(self.h, ctypes.byref(b)))
         return b.value
 
+    def set_partition_of_unity(self, on=True):
+        self.ctx.check(self.ctx.lib.alfi_patches_set_partition_of_unity(self.h, 1 if on else 0))
+
     def set_multiplicative(self, iterset, symmetrise):
         """Multiplicative sweeps in the order ``iterset`` (None / empty = back to additive); returns the number of
         dependency wavefronts one sweep was scheduled into."""

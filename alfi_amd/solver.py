@@ -177,8 +177,9 @@ class HipPatchPC(object):
             raise NotImplementedError("patch local_type %r" % local_type)
         self.multiplicative = local_type == "multiplicative"
         self.symmetrise = _truthy(opts.getString("patch_pc_patch_symmetrise_sweep", "false"))
-        if _truthy(opts.getString("patch_pc_patch_partition_of_unity", "false")):
-            raise NotImplementedError("partition_of_unity weighting (the reference always sets it False, solver.py:321)")
+        self.partition_of_unity = _truthy(opts.getString("patch_pc_patch_partition_of_unity", "false"))
+        if self.partition_of_unity and self.multiplicative:
+            raise NotImplementedError("partition_of_unity with multiplicative sweeps")
         sub_mat = opts.getString("patch_pc_patch_sub_mat_type", "seqdense")
         if sub_mat not in ("seqdense", "dense", "seqaij", "aij"):
             raise NotImplementedError("patch sub_mat_type %r" % sub_mat)
@@ -186,13 +187,21 @@ class HipPatchPC(object):
         # UMFPACK / PARDISO) asks for the same operator A_p^-1 as seqdense + dense_inverse (solver.py:599-602); here both
         # are the explicit dense inverse -- macro-star patches are inverted on the FP64 matrix cores
         ctype = opts.getString("patch_pc_patch_construct_type", "star")
-        if ctype == "star":
-            if opts.getInt("patch_pc_patch_construct_dim", 0) != 0:
-                raise NotImplementedError("only vertex stars (construct_dim 0)")
+        cdim = opts.getInt("patch_pc_patch_construct_dim", 0)
+        ctor = None
+        if ctype == "star" and cdim == 0:
             ptr, dofs, _ = L.V.star_patches()
             self.iterset = np.arange(len(ptr) - 1)
-        elif ctype == "python":
-            ctor = _resolve(opts.getString("patch_pc_patch_construct_python_type"))()
+        elif ctype in ("star", "python"):
+            if ctype == "star":
+                # built-in stars of edges / faces / cells (patch_pc_patch_construct_dim != 0; the reference passes 0,
+                # solver.py:338): the same point sets as the python Star constructor seeded on that stratum
+                from .relaxation import Star
+                ctor = Star()
+                pc.options = dict(pc.options)
+                pc.options[pc.getOptionsPrefix() + "patch_pc_patch_construction_Star_dim"] = cdim
+            else:
+                ctor = _resolve(opts.getString("patch_pc_patch_construct_python_type"))()
             # firedrake.PatchPC hands the constructor its inner PCPATCH object, whose options prefix is the outer one
             # + "patch_" [3P]: that is where pc_patch_construction_<Name>_sort_order lives (solver.py:335, 342)
             inner = PC(pc.ctx, pc.level_data, options=pc.options, prefix=pc.getOptionsPrefix() + "patch_")
@@ -216,11 +225,14 @@ class HipPatchPC(object):
         self.condensed = False
         import os
         if (ctype == "python" and getattr(L.V.mesh, "macro_mesh", None) is not None and not self.multiplicative
-                and os.environ.get("ALFI_CONDENSE", "1") != "0" and type(ctor).__name__ == "MacroStar"):
+                and os.environ.get("ALFI_CONDENSE", "1") != "0" and type(ctor).__name__ == "MacroStar"
+                and ctype == "python"):
             from .sv import macro_cell_groups
             self.level.set_patch_groups(macro_cell_groups(L.V, dofs))
             self.condensed = True
         self.level.factor()
+        if self.partition_of_unity:
+            self.level.set_partition_of_unity(True)
         self.wavefronts = self.level.set_multiplicative(self.iterset, self.symmetrise) if self.multiplicative else 0
         self.n = L.n
 

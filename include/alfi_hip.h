@@ -169,6 +169,9 @@ int alfi_patches_check(alfi_level* lvl, double* worst_residual, int64_t* flagged
 /* PCApply_PATCH, additive, no partition of unity (solver.py:321-322): y = sum_p R_p^T inv(A_p) R_p x; y[bc] = x[bc].
  * x is not modified.  Deterministic (no atomics): patch results are staged and summed dof-wise in a fixed order. */
 int alfi_patch_apply(alfi_level* lvl, const double* dx, double* dy);
+/* patch_pc_patch_partition_of_unity (solver.py:321; the reference always passes False): on != 0 weights the additive sum
+ * of every dof by 1 / (number of patches holding it), as PCPATCH does with its dof_weights [3P]. */
+int alfi_patches_set_partition_of_unity(alfi_level* lvl, int on);
 /* PCPATCH local_type multiplicative (solver.py:322-324, 332-335): visit the patches in the order `iterset_host` (nit
  * positions; the concatenation of one coordinate-sorted permutation per '|' sweep of the constructor's sort_order,
  * relaxation.py:139-150, so a patch may appear more than once), each solve seeing the residual left by all earlier

@@ -133,9 +133,13 @@ def apply_bcs_matrix(A, bc_dofs):
 # S5/S6: PatchPC / PCPATCH additive star smoother, dense explicit inverses (alfi/solver.py:318-328, 599-602)
 # ---------------------------------------------------------------------------------------------------------------------
 class PatchSmoother(object):
-    def __init__(self, A, patch_ptr, patch_dofs, bc_dofs, local_type="additive", iterset=None, symmetrise=False):
+    def __init__(self, A, patch_ptr, patch_dofs, bc_dofs, local_type="additive", iterset=None, symmetrise=False,
+                 partition_of_unity=False):
         """local_type / iterset / symmetrise: ``patch_pc_patch_local_type``, the iteration set returned by the patch
-        constructor (relaxation.py:139-150) and ``patch_pc_patch_symmetrise_sweep`` (solver.py:322-324)."""
+        constructor (relaxation.py:139-150) and ``patch_pc_patch_symmetrise_sweep`` (solver.py:322-324);
+        partition_of_unity: ``patch_pc_patch_partition_of_unity`` (solver.py:321, always False in the reference): the
+        additive sum of a dof is weighted by 1 / (number of patches holding it) [3P: PCPATCH dof_weights]."""
+        self.pou = partition_of_unity
         self.A = sp.csr_matrix(A)
         self.patch_ptr, self.patch_dofs, self.bc_dofs = patch_ptr, patch_dofs, bc_dofs
         self.local_type, self.symmetrise = local_type, symmetrise
@@ -184,6 +188,8 @@ class PatchSmoother(object):
         for p, Ainv in enumerate(self.inv):
             dofs = self.patch_dofs[self.patch_ptr[p]:self.patch_ptr[p + 1]]
             y[dofs] += Ainv @ x[dofs]
+        if self.pou:
+            y /= np.maximum(np.bincount(self.patch_dofs, minlength=len(x)), 1)
         y[self.bc_dofs] = x[self.bc_dofs]
         return y
 

@@ -211,6 +211,53 @@ def test_multiplicative_sweeps_over_macro_star_patches(dim):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("dim", [2, 3])
+def test_partition_of_unity_and_stars_of_edges(dim):
+    """Two PCPATCH options the reference never changes from their defaults (solver.py:321, 338) but a drop-in accepts:
+    ``patch_pc_patch_partition_of_unity: True`` (additive sums weighted by 1 / multiplicity) and the built-in star with
+    ``patch_pc_patch_construct_dim: 1`` (one patch per edge: the edge and the faces around it)."""
+    import alfi_amd
+    from alfi_amd import hip
+    from oracle import alfi_oracle as O
+    prob = TwoDimLidDrivenCavityProblem(4) if dim == 2 else ThreeDimLidDrivenCavityProblem(2)
+    lv, _ = build_hierarchy(prob, 1, 2, Re=100.0)
+    L = lv[-1]
+    ctx = hip.Context(0)
+    x = np.random.default_rng(9).standard_normal(L.n)
+    A = L.A.to_scipy().tocsr()
+    opts = alfi_amd.mg_levels_solver(dim, smoothing=2)
+    opts["patch_pc_patch_partition_of_unity"] = True
+    pc = alfi_amd.PC(ctx, L, options=opts)
+    obj = alfi_amd.HipPatchPC()
+    obj.initialize(pc)
+    y = np.zeros(L.n)
+    obj.apply(pc, x, y)
+    ref = O.PatchSmoother(A, obj.patch_ptr, obj.patch_dofs, L.bc_dofs, partition_of_unity=True).apply(x)
+    assert np.abs(y - ref).max() < 1e-7 * np.abs(ref).max()
+    plain = O.PatchSmoother(A, obj.patch_ptr, obj.patch_dofs, L.bc_dofs).apply(x)
+    assert np.abs(plain - ref).max() > 1e-2 * np.abs(ref).max()
+    obj.level.close()
+    opts = alfi_amd.mg_levels_solver(dim, smoothing=2)
+    opts["patch_pc_patch_construct_dim"] = 1
+    pc = alfi_amd.PC(ctx, L, options=opts)
+    obj = alfi_amd.HipPatchPC()
+    obj.initialize(pc)
+    sizes = np.diff(obj.patch_ptr)
+    m = L.V.mesh
+    nfree_edges = int(np.count_nonzero(~L.V.bc_node_mask[np.asarray(L.V.edge_nodes).ravel()]))
+    if dim == 2:
+        assert len(sizes) == nfree_edges and (sizes == 2).all()           # an edge star holds the edge's own P2 node
+    else:
+        assert sizes.max() == 3 * 7 and len(sizes) >= nfree_edges         # edge node + the 6 face bubbles around an interior edge
+    y = np.zeros(L.n)
+    obj.apply(pc, x, y)
+    ref = O.PatchSmoother(A, obj.patch_ptr, obj.patch_dofs, L.bc_dofs).apply(x)
+    assert np.abs(y - ref).max() < 1e-7 * np.abs(ref).max()
+    obj.level.close()
+    ctx.close()
+
+
+@pytest.mark.gpu
 def test_schoeberl_transfer_object_protocol():
     from alfi_amd import hip, Constant, Function, PkP0SchoeberlTransfer
     from oracle import alfi_oracle as O
