@@ -277,3 +277,75 @@ def bfs3d_mesh(n):
     renum = np.full(full.num_vertices, -1, dtype=np.int64)
     renum[used] = np.arange(used.shape[0])
     return SimplexMesh(full.coords[used], renum[cells])
+
+
+# -- gmsh 2.2 ASCII meshes: the format of the reference's channel meshes (examples/bfs3d/coarse*.msh, written by gmsh from
+#    backwards-facing-step-3d.geo; firedrake.Mesh reads them, bfs3d.py:13-16) -----------------------------------------------
+def read_gmsh(path):
+    """Simplicial mesh from a gmsh ``$MeshFormat 2.2 0 8`` ASCII file: ``$Nodes`` (id x y z) and ``$Elements`` (id type
+    ntags tags... nodes); tetrahedra (type 4) / triangles (type 2) are the cells in 3-D / 2-D, the elements one dimension
+    lower (triangles / lines, type 1) carry the physical tag of the boundary they lie on -- kept in
+    ``mesh.boundary_tags``: {sorted vertex tuple of the facet: physical tag} (bfs3d.py:23-26 uses 1 = inflow, 3 = walls;
+    2 = outflow stays natural)."""
+    with open(path) as fh:
+        lines = fh.read().split("\n")
+    pos = {l.strip(): i for i, l in enumerate(lines) if l.startswith("$")}
+    if "$MeshFormat" not in pos or not lines[pos["$MeshFormat"] + 1].startswith("2."):
+        raise ValueError("%s: not a gmsh 2.x ASCII mesh" % path)
+    if lines[pos["$MeshFormat"] + 1].split()[1] != "0":
+        raise ValueError("%s: binary gmsh files are not supported" % path)
+    n0 = pos["$Nodes"]
+    nn = int(lines[n0 + 1])
+    tab = np.array([l.split() for l in lines[n0 + 2:n0 + 2 + nn]], dtype=np.float64)
+    ids = tab[:, 0].astype(np.int64)
+    renum = np.full(ids.max() + 1, -1, dtype=np.int64)
+    renum[ids] = np.arange(nn)
+    xyz = tab[:, 1:4]
+    e0 = pos["$Elements"]
+    ne = int(lines[e0 + 1])
+    by_type = {}
+    for l in lines[e0 + 2:e0 + 2 + ne]:
+        t = l.split()
+        et, ntags = int(t[1]), int(t[2])
+        by_type.setdefault(et, []).append((int(t[3]) if ntags else 0, [int(v) for v in t[3 + ntags:]]))
+    nv_of = {1: 2, 2: 3, 4: 4, 15: 1}
+    dim = 3 if 4 in by_type else 2
+    cell_t, facet_t = (4, 2) if dim == 3 else (2, 1)
+    if cell_t not in by_type:
+        raise ValueError("%s holds no simplicial cells" % path)
+    cells = renum[np.array([v[:nv_of[cell_t]] for _, v in by_type[cell_t]], dtype=np.int64)]
+    used = np.unique(cells)
+    compact = np.full(nn, -1, dtype=np.int64)
+    compact[used] = np.arange(used.shape[0])
+    coords = xyz[used][:, :dim] if dim == 2 and np.abs(xyz[used][:, 2]).max() == 0.0 else xyz[used]
+    mesh = SimplexMesh(coords[:, :dim] if dim == 2 else coords, compact[cells])
+    mesh.boundary_tags = {}
+    for tag, v in by_type.get(facet_t, []):
+        key = tuple(sorted(int(compact[renum[q]]) for q in v[:nv_of[facet_t]]))
+        if min(key) >= 0:
+            mesh.boundary_tags[key] = tag
+    return mesh
+
+
+def write_gmsh(mesh, path, tag_of_facet=None):
+    """The inverse of ``read_gmsh`` for this package's own meshes (tests, exchanging meshes with gmsh-based tools):
+    ``tag_of_facet``: callable on the boundary facet centroids (nbf, dim) -> integer physical tags (default 1)."""
+    dim = mesh.dim
+    bf = mesh.boundary_facets
+    cent = mesh.coords[mesh.facets[bf]].mean(axis=1)
+    tags = np.ones(len(bf), dtype=np.int64) if tag_of_facet is None else np.asarray(tag_of_facet(cent), dtype=np.int64)
+    with open(path, "w") as fh:
+        fh.write("$MeshFormat\n2.2 0 8\n$EndMeshFormat\n$Nodes\n%d\n" % mesh.num_vertices)
+        for i, x in enumerate(mesh.coords):
+            xyz = list(x) + [0.0] * (3 - dim)
+            fh.write("%d %.16g %.16g %.16g\n" % (i + 1, xyz[0], xyz[1], xyz[2]))
+        fh.write("$EndNodes\n$Elements\n%d\n" % (len(bf) + mesh.num_cells))
+        k = 1
+        ft, ct = (2, 4) if dim == 3 else (1, 2)
+        for f, t in zip(bf, tags):
+            fh.write("%d %d 2 %d %d %s\n" % (k, ft, t, t, " ".join(str(int(v) + 1) for v in mesh.facets[f])))
+            k += 1
+        for c in mesh.cells:
+            fh.write("%d %d 2 1 1 %s\n" % (k, ct, " ".join(str(int(v) + 1) for v in c)))
+            k += 1
+        fh.write("$EndElements\n")

@@ -106,13 +106,16 @@ class ThreeDimBackwardsFacingStepProblem(NavierStokesProblem):
     """examples/bfs3d/bfs3d.py:8-33 on the structured stand-in for the gmsh channel (``mesh.bfs3d_mesh``): Poiseuille
     inflow at x = 0 (label 1), no-slip walls (label 3), natural outflow at x = 10 (label 2)."""
 
-    def __init__(self, baseN=1):
+    def __init__(self, baseN=1, msh=None):
+        """msh: path of a gmsh 2.2 ASCII mesh of the channel (the reference's ``--mesh coarse30.msh``, bfs3d.py:13-16,
+        37-39); None: the structured stand-in with baseN cubes per unit length."""
         self.baseN = baseN
+        self.msh = msh
         self.dim = 3
 
     def mesh(self, distribution_parameters=None):
-        from .mesh import bfs3d_mesh
-        return bfs3d_mesh(self.baseN)
+        from .mesh import bfs3d_mesh, read_gmsh
+        return read_gmsh(self.msh) if self.msh else bfs3d_mesh(self.baseN)
 
     def driver(self, x):
         """poiseuille_flow (bfs3d.py:19-21): the inflow profile, extended along the channel as the linearisation state."""

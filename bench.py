@@ -45,11 +45,15 @@ HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec (MI355X_MICROARCH.md: 8.0 TB/s 
 def describe(cfg):
     dim, baseN, nref, ke, Re, k = CONFIGS[cfg]
     if dim == "sv":
-        return ("bfs3d Scott-Vogelius [P%d]^3 on Alfeld-split meshes (structured 10x2x1 channel with step, baseN %d, nref %d), "
-                "Re=%g, gamma=1e4, FGMRES(%d)+macro-star patches" % (ke, baseN, nref, Re, k))
+        base = "gmsh mesh %s" % os.path.basename(BFS3D_MESH) if BFS3D_MESH else "structured 10x2x1 channel with step, baseN %d" % baseN
+        return ("bfs3d Scott-Vogelius [P%d]^3 on Alfeld-split meshes (%s, nref %d), "
+                "Re=%g, gamma=1e4, FGMRES(%d)+macro-star patches" % (ke, base, nref, Re, k))
     el = "[P2]^2" if dim == 2 else ("[P1+FB]^3" if ke == 1 else "[P2+FB]^3")
     return "ldc%dd %s-P0, N=%d (baseN %d, nref %d), Re=%g, gamma=1e4, FGMRES(%d)+star patches" % (
         dim, el, baseN * 2 ** nref, baseN, nref, Re, k)
+
+
+BFS3D_MESH = None      # --mesh: a gmsh 2.2 ASCII channel mesh for the Scott-Vogelius configs instead of the structured stand-in
 
 
 def build_problem(cfg, verbose, lazy=False):
@@ -60,7 +64,7 @@ def build_problem(cfg, verbose, lazy=False):
     if dim == "sv":
         from alfi_amd.problem import ThreeDimBackwardsFacingStepProblem
         from alfi_amd.sv import build_sv_hierarchy
-        lv, tr = build_sv_hierarchy(ThreeDimBackwardsFacingStepProblem(baseN), nref, ke, Re=Re)
+        lv, tr = build_sv_hierarchy(ThreeDimBackwardsFacingStepProblem(baseN, msh=BFS3D_MESH), nref, ke, Re=Re)
         return lv, tr, k
     prob = TwoDimLidDrivenCavityProblem(baseN) if dim == 2 else ThreeDimLidDrivenCavityProblem(baseN)
     lv, tr = build_hierarchy(prob, nref, ke, Re=Re, verbose=verbose, lazy=lazy)
@@ -348,8 +352,13 @@ def main():
     ap.add_argument("--graph", action="store_true",
                     help="after the timed (eager, event-instrumented) cycles also time the same cycles replayed as a "
                          "hipGraph (alfi_ctx_set_graph) and report them as `graph_replay`; single GPU only")
+    ap.add_argument("--mesh", default=None,
+                    help="config 5 only: gmsh 2.2 ASCII mesh of the channel (the reference's examples/bfs3d/coarse*.msh, "
+                         "bfs3d.py:37-39) as the base mesh instead of the structured stand-in")
     ap.add_argument("--verbose", action="store_true")
     args = ap.parse_args()
+    global BFS3D_MESH
+    BFS3D_MESH = args.mesh
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # plain `python bench.py --gpus N`: this process only starts the N rank processes (before anything here touches a

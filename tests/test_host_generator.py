@@ -217,3 +217,57 @@ def test_divergence_matrix_reproduces_the_augmented_lagrangian_term(mk, k):
     Bfull_u = B @ u.ravel()
     interior = ~L.V.bc_node_mask[L.V.cell_nodes].any(axis=1)
     assert interior.any() and np.allclose(Bfull_u[interior], -vol[interior])
+
+
+def test_gmsh_reader_round_trip_and_channel_problem(tmp_path):
+    """gmsh 2.2 ASCII meshes (the format of the reference's examples/bfs3d/coarse*.msh): write the structured channel with
+    the reference's physical tags (1 inflow x = 0, 2 outflow x = 10, 3 walls; bfs3d.py:23-26), read it back -- same
+    geometry, same boundary -- and run the problem / hierarchy set-up on it, with shuffled node ids and cell orientations."""
+    from alfi_amd.mesh import bfs3d_mesh, read_gmsh, write_gmsh
+    from alfi_amd.problem import ThreeDimBackwardsFacingStepProblem
+    from alfi_amd.fespace import VectorFunctionSpace
+    from alfi_amd.elements import NodalElement
+    m = bfs3d_mesh(1)
+    path = str(tmp_path / "channel.msh")
+
+    def tags(c):
+        return np.where(c[:, 0] < 1e-12, 1, np.where(c[:, 0] > 10 - 1e-12, 2, 3))
+    write_gmsh(m, path, tags)
+    r = read_gmsh(path)
+    assert r.num_cells == m.num_cells and r.num_vertices == m.num_vertices
+    assert np.isclose(r.cell_geometry()[1].sum(), 19.0)                           # 10 x 2 x 1 minus the 1 x 1 x 1 step
+    assert len(r.boundary_tags) == len(r.boundary_facets)
+    cent = {k: r.coords[list(k)].mean(axis=0) for k in r.boundary_tags}
+    assert all((t == 2) == (abs(cent[k][0] - 10.0) < 1e-12) for k, t in r.boundary_tags.items())
+    # a file with permuted node ids, non-contiguous numbering and flipped tets reads to the same mesh geometry
+    lines = open(path).read().split("\\n")
+    rng = np.random.default_rng(0)
+    nn = m.num_vertices
+    new_id = rng.permutation(nn) * 3 + 7
+    out, section = [], None
+    for l in lines:
+        if l.startswith("$"):
+            section = l
+            out.append(l)
+            continue
+        t = l.split()
+        if section == "$Nodes" and len(t) == 4:
+            out.append("%d %s %s %s" % (new_id[int(t[0]) - 1], t[1], t[2], t[3]))
+        elif section == "$Elements" and len(t) > 4:
+            nt = int(t[2])
+            vs = [str(new_id[int(v) - 1]) for v in t[3 + nt:]]
+            if t[1] == "4" and int(t[0]) % 2 == 0:
+                vs[0], vs[1] = vs[1], vs[0]
+            out.append(" ".join(t[:3 + nt] + vs))
+        else:
+            out.append(l)
+    path2 = str(tmp_path / "shuffled.msh")
+    open(path2, "w").write("\\n".join(out))
+    r2 = read_gmsh(path2)
+    assert r2.num_cells == m.num_cells and np.isclose(r2.cell_geometry()[1].sum(), 19.0)
+    prob = ThreeDimBackwardsFacingStepProblem(msh=path2)
+    mh = prob.mesh_hierarchy("uniform", 1)
+    assert mh[1].num_cells == 8 * m.num_cells and np.isclose(mh[1].cell_geometry()[1].sum(), 19.0)
+    V = VectorFunctionSpace(mh[0], NodalElement(3, 2, False), dirichlet=prob.dirichlet_facets)
+    Vs = VectorFunctionSpace(m, NodalElement(3, 2, False), dirichlet=prob.dirichlet_facets)
+    assert V.num_nodes == Vs.num_nodes and len(V.bc_nodes) == len(Vs.bc_nodes)
