@@ -69,6 +69,8 @@ SIGNATURES = {
     "alfi_patch_get_inverse": (ctypes.c_int, [vp, ctypes.c_int64, vp]),
     "alfi_smooth_fgmres": (ctypes.c_int, [vp, ctypes.c_int, vp, vp, ctypes.c_int]),
     "alfi_coarse_factor": (ctypes.c_int, [vp]),
+    "alfi_coarse_factor_sparse": (ctypes.c_int, [vp, vp, ctypes.c_int, ctypes.c_int]),
+    "alfi_coarse_factor_bytes": (ctypes.c_int, [vp, ctypes.POINTER(ctypes.c_int64)]),
     "alfi_coarse_residual": (ctypes.c_int, [vp, ctypes.POINTER(ctypes.c_double)]),
     "alfi_coarse_set_inverse": (ctypes.c_int, [vp, vp, ctypes.c_int]),
     "alfi_coarse_solve": (ctypes.c_int, [vp, vp, vp]),

@@ -594,6 +594,7 @@ int alfi_level_destroy(alfi_level* L) {
   dev_free(L->w);
   dev_free(L->hs);
   if (L->cinv_owned) dev_free(L->cinv);
+  mf_free(L->mf);
   dev_free(L->mg_b);
   dev_free(L->mg_x);
   dev_free(L->mg_r);
@@ -1272,6 +1273,8 @@ int alfi_coarse_set_inverse(alfi_level* L, const double* inv, int inv_is_device)
   if (L->cinv_owned) dev_free(L->cinv);
   L->cinv = nullptr;
   L->cinv_owned = false;
+  mf_free(L->mf);
+  L->mf = nullptr;
   if (inv_is_device) {
     L->cinv = const_cast<double*>(inv);
   } else {
@@ -1301,6 +1304,8 @@ int alfi_coarse_factor(alfi_level* L) {
   if (L->cinv_owned) dev_free(L->cinv);
   L->cinv = nullptr;
   L->cinv_owned = false;
+  mf_free(L->mf);
+  L->mf = nullptr;
   double* inv = nullptr;
   ALFI_CHECK(dev_alloc(ctx, &inv, L->n * L->n));
   ALFI_HIP_CHECK(ctx, hipMemsetAsync(L->status, 0, sizeof(int), ctx->stream));
@@ -1344,17 +1349,83 @@ int alfi_coarse_factor(alfi_level* L) {
   return 0;
 }
 
+// || A x - e ||_inf for x = solve(e), e a +-1 vector: the residual probe shared by the dense and the sparse coarse solver
+static int coarse_probe(alfi_level* L, double* worst_out) {
+  alfi_ctx* ctx = L->ctx;
+  std::vector<double> e((size_t)L->n), r((size_t)L->n);
+  probe_vector(&e);
+  double *de = nullptr, *dy = nullptr, *dr = nullptr;
+  int rc = dev_upload(ctx, &de, e.data(), L->n);
+  if (rc == 0) rc = dev_alloc(ctx, &dy, L->n);
+  if (rc == 0) rc = dev_alloc(ctx, &dr, L->n);
+  if (rc == 0) rc = L->mf ? mf_solve(L, de, dy) : launch_dense_gemv(ctx, L->cinv, de, dy, L->n);
+  if (rc == 0) rc = launch_bsr_spmv(ctx, L->A, dy, dr, nullptr, 1.0, 0);
+  if (rc == 0 && hipMemcpyAsync(r.data(), dr, sizeof(double) * L->n, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) rc = ALFI_E_HIP;
+  if (rc == 0 && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = ALFI_E_HIP;
+  dev_free(de);
+  dev_free(dy);
+  dev_free(dr);
+  if (rc != 0) return rc;
+  double worst = 0.0;
+  for (int64_t i = 0; i < L->n; ++i) {
+    const double d = std::fabs(r[i] - e[i]);
+    if (!(d <= worst)) worst = d == d ? d : INFINITY;
+  }
+  *worst_out = worst;
+  return 0;
+}
+
+// Sparse direct factorisation of the level operator (multifrontal, mf_coarse.h) for coarse grids beyond the dense inverse.
+// coords: nbrows x dim node coordinates (host) for the geometric nested dissection, or NULL (BFS level sets of the graph).
+int alfi_coarse_factor_sparse(alfi_level* L, const double* coords, int dim, int leaf_nodes) {
+  alfi_ctx* ctx = L->ctx;
+  if (L->has_halo && L->n_own != L->n)
+    return alfi_set_error(ctx, ALFI_E_STATE, "alfi_coarse_factor_sparse needs a level owned by one rank");
+  if (coords && (dim < 1 || dim > 3)) return alfi_set_error(ctx, ALFI_E_ARG, "node coordinates of dimension %d", dim);
+  ALFI_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  ALFI_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  if (L->cinv_owned) dev_free(L->cinv);
+  L->cinv = nullptr;
+  L->cinv_owned = false;
+  ALFI_HIP_CHECK(ctx, hipMemsetAsync(L->status, 0, sizeof(int), ctx->stream));
+  ALFI_CHECK(mf_factor(L, coords, dim, leaf_nodes));
+  int st = 0;
+  ALFI_HIP_CHECK(ctx, hipMemcpy(&st, L->status, sizeof(int), hipMemcpyDeviceToHost));
+  int rc = 0;
+  if (st != 0) rc = alfi_set_error(ctx, ALFI_E_SINGULAR, "zero pivot block in a front of the coarse factorisation");
+  double worst = 0.0;
+  if (rc == 0) rc = coarse_probe(L, &worst);
+  if (rc == 0) {
+    L->cinv_residual = worst;
+    if (!(worst <= 1e-5))
+      rc = alfi_set_error(ctx, ALFI_E_SINGULAR, "sparse coarse factorisation fails the residual probe: || A x - e || = %.3e", worst);
+  }
+  if (rc != 0) {
+    mf_free(L->mf);
+    L->mf = nullptr;
+  }
+  return rc;
+}
+
+int alfi_coarse_factor_bytes(alfi_level* L, int64_t* bytes) {
+  if (L->mf) *bytes = mf_bytes(L->mf);
+  else if (L->cinv) *bytes = L->n * L->n * 8;
+  else return alfi_set_error(L->ctx, ALFI_E_STATE, "no coarse factorisation");
+  return 0;
+}
+
 int alfi_coarse_residual(alfi_level* L, double* worst) {
-  if (!L->cinv) return alfi_set_error(L->ctx, ALFI_E_STATE, "no coarse inverse");
+  if (!L->cinv && !L->mf) return alfi_set_error(L->ctx, ALFI_E_STATE, "no coarse inverse");
   *worst = L->cinv_residual;
   return 0;
 }
 
 int alfi_coarse_solve(alfi_level* L, const double* db, double* dx) {
-  if (!L->cinv) return alfi_set_error(L->ctx, ALFI_E_STATE, "alfi_coarse_solve before alfi_coarse_set_inverse");
+  if (!L->cinv && !L->mf) return alfi_set_error(L->ctx, ALFI_E_STATE, "alfi_coarse_solve before alfi_coarse_set_inverse");
   L->ctx->cur_tag = L->id;
   int t = alfi_prof_begin(L->ctx, ALFI_EV_COARSE);
-  ALFI_CHECK(launch_dense_gemv(L->ctx, L->cinv, db, dx, L->n));
+  if (L->mf) ALFI_CHECK(mf_solve(L, db, dx));
+  else ALFI_CHECK(launch_dense_gemv(L->ctx, L->cinv, db, dx, L->n));
   alfi_prof_end(L->ctx, t);
   return 0;
 }
@@ -1576,7 +1647,7 @@ int alfi_mg_create(alfi_ctx* ctx, int nlevels, alfi_level** levels, alfi_transfe
       return alfi_set_error(ctx, ALFI_E_STATE, "level %d: patches not factored", l);
   }
   // a rank that only holds ghost copies of its lowest level (the owner solves it) needs no coarse inverse
-  if (levels[0]->n_own > 0 && !levels[0]->cinv) return alfi_set_error(ctx, ALFI_E_STATE, "coarse level has no inverse");
+  if (levels[0]->n_own > 0 && !levels[0]->cinv && !levels[0]->mf) return alfi_set_error(ctx, ALFI_E_STATE, "coarse level has no inverse");
   alfi_mg* mg = new alfi_mg();
   mg->ctx = ctx;
   mg->levels.assign(levels, levels + nlevels);
@@ -1679,6 +1750,7 @@ static void cycle_signature(alfi_mg* mg, std::vector<uint64_t>* sig) {
     push(L->patch_ptr);
     push(L->patch_dofs);
     push(L->cinv);
+    push(L->mf);
     push(L->V);
     push(L->mult_seq);
     sig->push_back((uint64_t)L->npatch);

@@ -239,6 +239,7 @@ struct alfi_level {
   // coarse dense inverse
   double* cinv = nullptr;
   bool cinv_owned = false;
+  struct MfDev* mf = nullptr;     // sparse (multifrontal) coarse factorisation, alfi_coarse_factor_sparse
   double cinv_residual = -1.0;    // || A X e - e ||_inf of the inverse built by alfi_coarse_factor (-1: supplied by the caller)
   // multigrid work vectors (owned by alfi_mg but stored per level)
   double *mg_b = nullptr, *mg_x = nullptr, *mg_r = nullptr;
@@ -336,6 +337,10 @@ int launch_big_factor_transfer(alfi_transfer* tr);                              
 int launch_big_apply_arrays(alfi_ctx* ctx, int64_t npatch, int max_np, const int64_t* patch_ptr,
                             const int32_t* patch_dofs, const int64_t* inv_ptr, const int64_t* stage_ptr, const double* inv,
                             const double* x, double* stage);
+int mf_factor(alfi_level* lvl, const double* coords, int dim, int leaf_nodes);   // multifrontal L D U of the level operator
+int mf_solve(alfi_level* lvl, const double* b, double* x);
+void mf_free(struct MfDev* m);
+int64_t mf_bytes(const struct MfDev* m);
 int launch_coarse_factor(alfi_level* lvl, double* out);                                   // dense inverse of the whole level operator
 int launch_big_factor(alfi_level* lvl);
 // condensed patches (kernels_bigpatch.hip): block factorisation / its apply for the patches [p0, p1)

@@ -930,14 +930,21 @@ __global__ void coarse_scatter_kernel(int64_t nbrows, const int32_t* __restrict_
 
 // Where the matrices of a batch come from: the level's operator (patch smoother), the dense blocks of a transfer, or the
 // whole operator of a level (C: the coarse grid, one matrix).
+struct MfFill;     // multifrontal coarse factorisation (mf_coarse.h): the fronts of one tree height
+void mf_fill_dispatch(const MfFill* f, alfi_ctx* ctx, int64_t p0, int64_t nb, const int64_t* d_scr_ptr, double* dst);
+void mf_store_dispatch(const MfFill* f, alfi_ctx* ctx, int64_t p0, int64_t nb, const int64_t* d_scr_ptr, const double* res);
+
 struct BigSource {
+  const MfFill* M = nullptr;
   alfi_level* L = nullptr;
   alfi_transfer* T = nullptr;
   alfi_level* C = nullptr;
   alfi_level* K = nullptr;        // condensed patches: the Schur complements of the level's patches
   void fill(alfi_ctx* ctx, int64_t p0, int64_t nb, const int64_t* d_scr_ptr, double* dst) const {
     dim3 block(256);
-    if (K) {
+    if (M) {
+      mf_fill_dispatch(M, ctx, p0, nb, d_scr_ptr, dst);
+    } else if (K) {
       const size_t lds = (size_t)(3 * K->max_np) * sizeof(int32_t);
       if (K->bs == 2)
         hipLaunchKernelGGL(cond_fill_kernel<2>, dim3((unsigned)nb), block, lds, ctx->stream, p0, K->cd, K->patch_ptr,
@@ -1070,8 +1077,10 @@ static int big_factor_core(alfi_ctx* ctx, const BigSource& src, int64_t npatch, 
       hipLaunchKernelGGL(big_gemm_kernel, dim3((unsigned)(tiles * tiles), (unsigned)nb), block, 0, ctx->stream, 1,
                          d_patch_ptr, p0, d_scr_ptr, scr, scrR, scrA, tiles);
       result = scrA;
-      if (dense_out) {
-        // the coarse operator (one matrix, hundreds of pivot blocks): a second Newton-Schulz step.  The matrix is
+      static const bool mf_ns2 = !(getenv("ALFI_MF_NS2") && atoi(getenv("ALFI_MF_NS2")) == 0);
+      if (dense_out || (src.M && mf_ns2)) {
+        // the coarse operator (one matrix, hundreds of pivot blocks; or the fronts of its sparse factorisation, whose errors
+        // travel up the elimination tree through the Schur complements): a second Newton-Schulz step.  The matrix is
         // filled again (into the buffer that held the first iterate's predecessor), R = I - A X, X <- X + X R.
         src.fill(ctx, p0, nb, d_scr_ptr, scr);
         hipLaunchKernelGGL(big_gemm_kernel, dim3((unsigned)(tiles * tiles), (unsigned)nb), block, 0, ctx->stream, 0,
@@ -1081,7 +1090,9 @@ static int big_factor_core(alfi_ctx* ctx, const BigSource& src, int64_t npatch, 
         result = scr;
       }
     }
-    if (dense_out) {
+    if (src.M) {
+      mf_store_dispatch(src.M, ctx, p0, nb, d_scr_ptr, result);
+    } else if (dense_out) {
       // (a kernel, not hipMemcpy2DAsync: the runtime splits a pitched device copy into one copy per row -- 17 320 copy
       // launches, 0.45 s, for the 23 355 rows of config 4's coarse inverse)
       const int64_t n = h_patch_ptr[1] - h_patch_ptr[0];
@@ -1171,3 +1182,5 @@ int launch_cond_apply_range(alfi_level* L, int64_t p0, int64_t p1, const double*
   ALFI_HIP_CHECK(ctx, hipGetLastError());
   return 0;
 }
+
+#include "mf_coarse.h"

@@ -602,7 +602,7 @@ class DistMultigrid(object):
         """Coarse solve of the rank that owns level 0: the library's own dense factorisation of the (complete) local
         operator, or an inverse the caller computes from the global one."""
         if coarse_inverse is None:
-            dl.coarse_factor()
+            dl.coarse_factor_auto()      # (local numbering: no coordinates -- the sparse path bisects by graph level sets)
             return
         inv = coarse_inverse(A0)
         if isinstance(inv, tuple):

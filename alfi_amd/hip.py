@@ -258,6 +258,34 @@ class Level(object):
         self.ctx.check(self.ctx.lib.alfi_coarse_factor(self.h))
         return self.coarse_residual()
 
+    def coarse_factor_sparse(self, node_coords=None, leaf_nodes=0):
+        """Sparse direct factorisation of this level's operator (multifrontal block L D U on a nested-dissection ordering,
+        alfi_coarse_factor_sparse) for coarse grids whose dense inverse (8 n^2 bytes) is too large; ``node_coords``
+        (nodes, dim) drives the geometric bisection (None: level sets of the graph).  Returns the probe residual."""
+        if node_coords is None:
+            self.ctx.check(self.ctx.lib.alfi_coarse_factor_sparse(self.h, None, 0, int(leaf_nodes)))
+        else:
+            xy = np.ascontiguousarray(node_coords, dtype=np.float64)
+            assert xy.ndim == 2 and xy.shape[0] * self.bs == self.n, (xy.shape, self.n, self.bs)
+            self.ctx.check(self.ctx.lib.alfi_coarse_factor_sparse(self.h, _ptr(xy), int(xy.shape[1]), int(leaf_nodes)))
+        return self.coarse_residual()
+
+    def coarse_factor_auto(self, node_coords=None, mode=None):
+        """The coarse factorisation the front ends use: ``mode`` "dense", "sparse" or "auto" (sparse from
+        ``coarse_sparse_min()`` dofs on).  Mode and coordinates are remembered, so a later call without arguments
+        (new operator values, every Newton step) repeats the same choice."""
+        if mode is not None or node_coords is not None or not hasattr(self, "_coarse_choice"):
+            self._coarse_choice = (mode or "auto", node_coords)
+        mode, node_coords = self._coarse_choice
+        if mode == "sparse" or (mode == "auto" and self.n >= coarse_sparse_min()):
+            return self.coarse_factor_sparse(node_coords)
+        return self.coarse_factor()
+
+    def coarse_factor_bytes(self):
+        b = ctypes.c_int64()
+        self.ctx.check(self.ctx.lib.alfi_coarse_factor_bytes(self.h, ctypes.byref(b)))
+        return b.value
+
     def coarse_residual(self):
         """|| A X e - e ||_inf of the coarse inverse built by ``coarse_factor`` (-1 for a caller-supplied inverse)."""
         w = ctypes.c_double()
@@ -332,10 +360,19 @@ def condense_patches(L):
     return getattr(L, "patch_groups", None) is not None and os.environ.get("ALFI_CONDENSE", "1") != "0"
 
 
+def coarse_sparse_min():
+    """Coarse grids from this many dofs on get the sparse factorisation by default (dense inverse: 8 n^2 bytes and one n x n
+    GEMV per cycle; sparse: O(n^{4/3}) bytes and ~6 launches per tree height)."""
+    import os
+    return int(os.environ.get("ALFI_COARSE_SPARSE_MIN", 8192))
+
+
 class Multigrid(object):
     """Device-resident PCMG (solver.py:359-379) built from alfi_amd.problem.build_hierarchy output."""
 
-    def __init__(self, ctx, levels, transfers, k, robust_restriction=False, coarse_inv=None, verbose=False):
+    def __init__(self, ctx, levels, transfers, k, robust_restriction=False, coarse_inv=None, verbose=False, coarse="auto"):
+        """coarse: "dense" (explicit inverse, alfi_coarse_factor), "sparse" (multifrontal factors, alfi_coarse_factor_sparse)
+        or "auto": sparse from COARSE_SPARSE_MIN dofs on (env ALFI_COARSE_SPARSE_MIN)."""
         import time
         t0 = time.time()
         dlevels = []
@@ -348,8 +385,8 @@ class Multigrid(object):
                 dl.factor_with_fallback()
             elif coarse_inv is not None:
                 dl.set_coarse_inverse(coarse_inv)          # an inverse supplied by the caller (numpy array / device pointer)
-            else:
-                dl.coarse_factor()                         # the library's own factorisation
+            else:                                          # the library's own factorisation, dense or multifrontal
+                dl.coarse_factor_auto(getattr(getattr(L, "V", None), "node_coords", None), coarse)
             dlevels.append(dl)
         self._from_device_levels(ctx, dlevels, transfers, k, robust_restriction)
         if verbose:

@@ -110,7 +110,7 @@ class HipNavierStokesSolver(object):
         """New operator values on every level: re-gather and re-invert the patches, new coarse inverse."""
         self.hmg.update(self.levels)
         self.hmg.mg.levels[0].update_values(self.levels[0].A.vals)
-        self.hmg.mg.levels[0].coarse_factor()
+        self.hmg.mg.levels[0].coarse_factor_auto()
 
     def _set_parameters(self):
         for T, dt in zip(self.transfers, self.hmg.mg.transfers):            # AutoSchoeberlTransfer.rebuild, transfer.py:173-184

@@ -276,7 +276,7 @@ class HipMG(object):
                 if coarse_inv is not None:
                     dl.set_coarse_inverse(coarse_inv)
                 else:
-                    dl.coarse_factor()
+                    dl.coarse_factor_auto(getattr(getattr(L, "V", None), "node_coords", None))
                 dlevels.append(dl)
                 self.pcs.append(None)
                 self.pc_objs.append(None)

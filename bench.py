@@ -84,7 +84,9 @@ def vcycle_bytes(levels, dmg, k):
     per_level_apply = {}
     for L, dl in zip(levels, dmg.levels):
         if L.level == 0:
-            total += 8.0 * L.n * L.n
+            # dense inverse: one n x n GEMV; multifrontal factors: both sweeps read them once, twice with the refinement step
+            fb = float(dl.coarse_factor_bytes())
+            total += fb if fb == 8.0 * L.n * L.n else 2.0 * fb
             continue
         npatch, sum_n, sum_n2 = dl.patch_stats()
         fbytes = float(dl.factor_bytes())                      # 8 sum n_p^2 for dense inverses, less for condensed factors
@@ -529,6 +531,10 @@ def main():
                    "patch_composition": args.patch_composition, "wavefronts_per_sweep": wavefronts},
         "dof_smooths_per_s": L.n * smooths_per_cycle_finest * vps,
         "patch_factor_GB": [round(dl.factor_bytes() / 1e9, 3) for dl in dmg.levels[1:]],
+        "coarse_solver": {"kind": "dense inverse" if dmg.levels[0].coarse_factor_bytes() == 8 * lv[0].n * lv[0].n
+                          else "multifrontal L D U + 1 refinement step", "dofs": lv[0].n,
+                          "factor_GB": round(dmg.levels[0].coarse_factor_bytes() / 1e9, 3),
+                          "probe_residual": dmg.levels[0].coarse_residual()},
         "patch_factor_bytes_per_dof_finest": dmg.levels[-1].factor_bytes() / float(L.n),
         "fcycle_ms": fcycle_ms,
         "vcycle_algorithmic_GB": total_bytes / 1e9,

@@ -202,6 +202,14 @@ int alfi_smooth_fgmres(alfi_level* lvl, int k, const double* db, double* dx, int
  * alfi_coarse_set_inverse: an inverse computed by the caller instead (row-major n x n, host or device memory).
  * The solve is a device GEMV either way. */
 int alfi_coarse_factor(alfi_level* lvl);
+/* alfi_coarse_factor_sparse: the same exact coarse solve for operators beyond the dense inverse -- a multifrontal block
+ * L D U on a nested-dissection ordering (what the reference obtains from MUMPS / SuperLU_DIST, alfi/solver.py:369-378),
+ * dense fronts on the FP64 matrix cores, plus one step of iterative refinement per solve.  coords: nbrows x dim node
+ * coordinates in host memory for the geometric bisection, or NULL (level sets of the operator's graph); leaf_nodes: nodes
+ * per leaf subdomain (<= 0: default 64).  Same residual probe as alfi_coarse_factor.
+ * alfi_coarse_factor_bytes: device bytes of the stored factors (dense: 8 n^2). */
+int alfi_coarse_factor_sparse(alfi_level* lvl, const double* node_coords, int dim, int leaf_nodes);
+int alfi_coarse_factor_bytes(alfi_level* lvl, int64_t* bytes);
 int alfi_coarse_residual(alfi_level* lvl, double* worst);
 int alfi_coarse_set_inverse(alfi_level* lvl, const double* inv, int inv_is_device);
 int alfi_coarse_solve(alfi_level* lvl, const double* db, double* dx);
