@@ -114,7 +114,7 @@ def test_hip_patch_pc_and_mg_from_options():
     assert np.abs(y2 - y).max() < 1e-10 * np.abs(y).max()
     # unsupported modes are refused loudly
     o3 = alfi_amd.mg_levels_solver(3, smoothing=3)
-    o3["patch_pc_patch_partition_of_unity"] = True
+    o3["patch_pc_patch_sub_mat_type"] = "baij"
     with pytest.raises(NotImplementedError):
         alfi_amd.HipPatchPC().initialize(alfi_amd.PC(ctx, L, options=o3))
 
