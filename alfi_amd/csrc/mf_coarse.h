@@ -127,26 +127,53 @@ struct MfBuilder {
     keys(D, &key);
     std::vector<std::pair<double, int32_t>> order(D.size());
     for (size_t q = 0; q < D.size(); ++q) order[q] = {key[q], D[q]};
-    const size_t mid = D.size() / 2;
+    size_t mid = D.size() / 2;
     std::nth_element(order.begin(), order.begin() + mid, order.end());
-    tag += 2;
-    const int32_t in2 = tag;
-    std::vector<int32_t> D1, D2, S;
-    D2.reserve(D.size() - mid);
-    for (size_t q = mid; q < order.size(); ++q) {
-      D2.push_back(order[q].second);
-      mark[order[q].second] = in2;
+    // nodes with the median key stay together (a cut along a mesh plane / one BFS level gives a one-layer separator; a cut
+    // through the ties a jagged, thicker one) unless that leaves a side with less than a quarter of the nodes
+    {
+      const double km = order[mid].first;
+      auto below = std::partition(order.begin(), order.end(), [km](const std::pair<double, int32_t>& o) { return o.first < km; });
+      auto upto = std::partition(below, order.end(), [km](const std::pair<double, int32_t>& o) { return o.first <= km; });
+      const size_t nlt = (size_t)(below - order.begin()), nle = (size_t)(upto - order.begin());
+      const size_t quarter = D.size() / 4, half = D.size() / 2;
+      const bool ok_lt = nlt >= quarter && D.size() - nlt >= quarter, ok_le = nle >= quarter && D.size() - nle >= quarter;
+      const size_t d_lt = half > nlt ? half - nlt : nlt - half, d_le = half > nle ? half - nle : nle - half;
+      if (ok_lt && (!ok_le || d_lt <= d_le)) mid = nlt;
+      else if (ok_le) mid = nle;
+      else std::sort(below, upto);      // a level too large to keep together: ties by node number, cut in the middle
     }
-    for (size_t q = 0; q < mid; ++q) {
-      const int32_t i = order[q].second;
+    tag += 2;
+    const int32_t in1 = tag - 1, in2 = tag;
+    for (size_t q = 0; q < mid; ++q) mark[order[q].second] = in1;
+    for (size_t q = mid; q < order.size(); ++q) mark[order[q].second] = in2;
+    // two candidate vertex separators of the edge cut: the nodes of the first half with a neighbour in the second, or the
+    // other way round -- the smaller one is taken (for a cut along a mesh plane: the plane, not the layer of cells below it)
+    size_t n12 = 0, n21 = 0;
+    for (size_t q = 0; q < order.size(); ++q) {
+      const int32_t i = order[q].second, other = q < mid ? in2 : in1;
       bool sep = false;
-      for (int64_t k = xadj[i]; k < xadj[i + 1] && !sep; ++k) sep = mark[adj[k]] == in2;
-      (sep ? S : D1).push_back(i);
+      for (int64_t k = xadj[i]; k < xadj[i + 1] && !sep; ++k) sep = mark[adj[k]] == other;
+      if (sep) {
+        dist[i] = 1;
+        ++(q < mid ? n12 : n21);
+      } else {
+        dist[i] = 0;
+      }
+    }
+    const bool from_first = n12 <= n21;
+    std::vector<int32_t> D1, D2, S;
+    for (size_t q = 0; q < order.size(); ++q) {
+      const int32_t i = order[q].second;
+      const bool first = q < mid;
+      if (dist[i] == 1 && first == from_first) S.push_back(i);
+      else (first ? D1 : D2).push_back(i);
     }
     std::vector<int32_t>().swap(D);
     if (S.empty()) {              // the halves do not touch: any node serves as the (formal) separator
-      S.push_back(D1.back());
-      D1.pop_back();
+      std::vector<int32_t>& from = D1.size() > 1 || D2.empty() ? D1 : D2;
+      S.push_back(from.back());
+      from.pop_back();
     }
     int c1 = -1, c2 = -1, first = (int)nodes.size();
     if (!D1.empty()) c1 = build(D1);

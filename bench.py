@@ -33,6 +33,9 @@ CONFIGS = {
     "cfg4": (3, 7, 3, 2, 1000.0, 10),
     "cfg4s": (3, 7, 2, 2, 1000.0, 10),   # config 4 truncated by one level (N = 28), for quick tuning runs
     "cfg4t": (3, 7, 1, 2, 1000.0, 10),   # two levels, N = 14 (173 k dofs): the per-rank share of config 4's level 2 at 8 GPUs
+    # the coarse grid of the reference's largest defined run (ldc3d [P1+FB]^3, baseN 18, examples/generate_submission:10-23:
+    # 243 k coarse dofs -- 473 GB as a dense inverse, hence the multifrontal coarse solver) with two of its four refinements
+    "cfg6": (3, 18, 2, 1, 100.0, 10),
     "tiny": (3, 2, 1, 2, 1000.0, 4),
     # config 5 on ONE GPU: bfs3d channel, Scott-Vogelius [P3]^3 on Alfeld-split meshes, macro-star patches (up to 2175 dofs),
     # macro-cell transfer blocks of 390; baseN 1 (114 tets), nref 2 -> 441 k velocity dofs, 33 GB of patch inverses
