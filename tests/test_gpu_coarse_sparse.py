@@ -90,3 +90,41 @@ def test_sparse_factor_of_a_refined_level_as_large_coarse_grid():
     assert dl.coarse_factor_bytes() < 0.5 * 8 * L.n * L.n
     dl.close()
     ctx.close()
+
+
+def test_single_front_and_disconnected_graph():
+    """Edge cases of the ordering: an operator that fits one leaf (one front, no boundary, no sweeps beyond the root) and a
+    block-diagonal operator of two uncoupled copies (the bisection finds halves that do not touch: a formal separator)."""
+    import scipy.sparse as sp
+    from alfi_amd import hip
+    from alfi_amd.problem import BSR
+    lv, _ = _level("2d", 4)
+    L = lv[0]
+    A = L.A.to_scipy().tocsr()
+    ctx = hip.Context(0)
+    rng = np.random.default_rng(3)
+    # one leaf
+    dl = hip.Level(ctx, L.A, L.bc_dofs)
+    assert dl.coarse_factor_sparse(None, leaf_nodes=10 ** 6) < 1e-8
+    b = rng.standard_normal(L.n)
+    bx, xx = ctx.vec(b), ctx.vec(L.n)
+    dl.coarse_solve(bx, xx)
+    want = spla.splu(A.tocsc()).solve(b)
+    assert np.abs(xx.get() - want).max() < 1e-9 * np.abs(want).max()
+    dl.close()
+    # two uncoupled copies, small leaves, with and without coordinates
+    A2 = sp.block_diag([A, 2.0 * A]).tocsr()
+    B2 = BSR.from_scipy(A2, L.A.bs)
+    bc2 = np.concatenate([L.bc_dofs, L.bc_dofs + L.n]).astype(np.int32)
+    xy = np.vstack([L.V.node_coords, L.V.node_coords + np.array([3.0, 0.0])])
+    lu2 = spla.splu(A2.tocsc())
+    for coords in (None, xy):
+        d2 = hip.Level(ctx, B2, bc2)
+        assert d2.coarse_factor_sparse(coords, leaf_nodes=5) < 1e-8
+        b = rng.standard_normal(2 * L.n)
+        bx, xx = ctx.vec(b), ctx.vec(2 * L.n)
+        d2.coarse_solve(bx, xx)
+        want = lu2.solve(b)
+        assert np.abs(xx.get() - want).max() < 1e-9 * np.abs(want).max()
+        d2.close()
+    ctx.close()

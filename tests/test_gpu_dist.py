@@ -67,9 +67,12 @@ def test_partitioned_cycles_match_single_gpu(case, world, robust, overlap, tmp_p
     assert np.abs(dv - ov).max() / np.abs(ov).max() < CYCLE_TOL
 
 
-@pytest.mark.parametrize("exact_norm,tol,transport", [("1", 1e-6, "rccl"), ("0", CYCLE_TOL, "rccl"),
-                                                      ("1", 1e-6, "callback")])
-def test_rccl_code_path_with_a_one_rank_group(tmp_path, exact_norm, tol, transport):
+@pytest.mark.parametrize("exact_norm,tol,transport,sparse_min", [("1", 1e-6, "rccl", None), ("0", CYCLE_TOL, "rccl", None),
+                                                                 ("1", 1e-6, "callback", None),
+                                                                 # the coarse owner factors with the multifrontal solver
+                                                                 # (local numbering, level-set bisection)
+                                                                 ("1", 1e-6, "rccl", "0")])
+def test_rccl_code_path_with_a_one_rank_group(tmp_path, exact_norm, tol, transport, sparse_min):
     """The RCCL transports of alfi_amd.dist on the one GPU of the box: a 1-rank process group with the exchange points
     forced on (empty halos, 1-rank all-reduces).  "rccl": the library's own communicator (alfi_ctx_comm_init from a unique
     id, the exchanges issued by the library on its stream -- the product path of bench.py --gpus N); "callback": the
@@ -119,6 +122,8 @@ def test_rccl_code_path_with_a_one_rank_group(tmp_path, exact_norm, tol, transpo
     # to rounding; default: |w|^2 = |w_old|^2 - |h|^2 from the single all-reduce of the iteration
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), ALFI_DIST_EXACT_NORM=exact_norm,
                ALFI_DIST_TRANSPORT=transport, ALFI_DIST_OVERLAP_MIN_DOFS="0")      # the asynchronous (overlapped) exchanges too, on these small levels
+    if sparse_min is not None:
+        env["ALFI_COARSE_SPARSE_MIN"] = sparse_min
     out = subprocess.run([sys.executable, str(script)], env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "ONE-RANK-RCCL-OK" in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]
 

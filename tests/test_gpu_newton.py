@@ -41,10 +41,15 @@ def host_newton(solver, re, u, p, tol):
                                              # SUPG-stabilised momentum equation (stabilisation.py:47-97; the authors'
                                              # production option, examples/generate_submission:18-20)
                                              (lambda: TwoDimLidDrivenCavityProblem(8), 2, 1, "supg"),
-                                             (lambda: ThreeDimLidDrivenCavityProblem(2), 1, 1, "supg")])
-def test_newton_continuation_matches_direct_solver(mk, ke, nref, disc):
+                                             (lambda: ThreeDimLidDrivenCavityProblem(2), 1, 1, "supg"),
+                                             # the coarse grid re-factored at every Newton step by the multifrontal solver
+                                             (lambda: ThreeDimLidDrivenCavityProblem(2), 2, 1, "pkp0-sparse-coarse")])
+def test_newton_continuation_matches_direct_solver(mk, ke, nref, disc, monkeypatch):
     from alfi_amd.nssolver import HipNavierStokesSolver, run_solver
     prob = mk()
+    if disc == "pkp0-sparse-coarse":
+        monkeypatch.setenv("ALFI_COARSE_SPARSE_MIN", "0")
+        disc = "pkp0"
     if disc == "supg":
         s = HipNavierStokesSolver(prob, nref, ke, stabilisation_type="supg", stabilisation_weight=0.05)
     else:
