@@ -34,11 +34,21 @@ struct MfDev {
           *g_ptr = nullptr, *g_idx = nullptr;
   double *fac = nullptr, *contrib = nullptr, *vloc = nullptr, *tmp_r = nullptr, *tmp_x = nullptr;
   std::vector<void*> allocs;
+  // the symbolic plan kept for re-factorisations with new operator values (every Newton step): host copies of the sizes
+  // and offsets, the device index arrays of the assembly (MfFactorArgs, owned through allocs)
+  std::vector<int32_t> h_ns, h_nb;
+  std::vector<int64_t> h_xoff, h_loff, h_woff, h_fsb, h_fbs, h_uo, h_fss;
+  int64_t tmp_doubles = 0, nnzb = 0;
+  struct MfFactorArgs* fa = nullptr;
+  int leaf = 0;
+  bool with_coords = false;
 };
 
+void mf_free_args(struct MfFactorArgs* a);
 void mf_free(MfDev* m) {
   if (!m) return;
   for (void* p : m->allocs) (void)hipFree(p);
+  mf_free_args(m->fa);
   delete m;
 }
 int64_t mf_bytes(const MfDev* m) { return m ? m->fac_doubles * 8 : 0; }
@@ -209,6 +219,8 @@ struct MfFactorArgs {
   const double* vals;
   int flat;
 };
+
+void mf_free_args(MfFactorArgs* a) { delete a; }
 
 // zero + identity padding of the N x N scratch matrices of a batch
 __global__ void mf_pad_kernel(int64_t pbase, const int32_t* __restrict__ ns, const int64_t* __restrict__ scr_ptr,
@@ -473,12 +485,14 @@ static int mf_up(alfi_ctx* ctx, MfDev* m, T** dst, const std::vector<T>& src) {
   return 0;
 }
 
-int mf_factor(alfi_level* L, const double* coords, int dim, int leaf_nodes) {
+static int mf_numeric(alfi_level* L, MfDev* m);
+
+// ordering, symbolic factorisation and the device index arrays: *out owns everything (mf_free)
+static int mf_analyse(alfi_level* L, const double* coords, int dim, int leaf_nodes, MfDev** out) {
   alfi_ctx* ctx = L->ctx;
   const int bs = L->bs;
   const int64_t nbn = L->A.nbrows;
   if (L->A.nbcols != nbn) return alfi_set_error(ctx, ALFI_E_ARG, "sparse coarse factorisation needs a square operator");
-  if (leaf_nodes <= 0) leaf_nodes = getenv("ALFI_MF_LEAF") ? atoi(getenv("ALFI_MF_LEAF")) : 64;
   // the operator's graph, symmetrised
   std::vector<int32_t> rowptr((size_t)nbn + 1), colidx((size_t)L->A.nnzb);
   ALFI_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
@@ -554,6 +568,9 @@ int mf_factor(alfi_level* L, const double* coords, int dim, int leaf_nodes) {
   m->nnode = nt;
   m->H = H;
   m->refine = getenv("ALFI_MF_REFINE") ? atoi(getenv("ALFI_MF_REFINE")) : 1;
+  m->leaf = leaf_nodes;
+  m->with_coords = coords != nullptr;
+  m->nnzb = L->A.nnzb;
   m->lp.assign((size_t)H + 1, 0);
   for (int p = 0; p < nt; ++p) ++m->lp[T[order[p]].height + 1];
   for (int h = 0; h < H; ++h) m->lp[h + 1] += m->lp[h];
@@ -673,44 +690,64 @@ int mf_factor(alfi_level* L, const double* coords, int dim, int leaf_nodes) {
   MF_TRY(dalloc(&m->vloc, L->n));
   MF_TRY(dalloc(&m->tmp_r, L->n));
   MF_TRY(dalloc(&m->tmp_x, L->n));
-  // factorisation-time data (freed below)
-  std::vector<void*> scratch;
-  MfFactorArgs a;
-  std::memset(&a, 0, sizeof(a));
-  a.bs = bs;
-  a.ns = m->ns;
-  a.nb = m->nb;
-  a.vals = L->A.vals;
-  a.flat = L->A.flat;
-  auto sup = [&](auto** dst, const auto& src) {
-    typedef typename std::remove_reference<decltype(src)>::type::value_type V;
-    V* d = nullptr;
-    int r = mf_up<V>(ctx, nullptr, &d, src);
-    if (r == 0) scratch.push_back(d);
-    *dst = d;
-    return r;
-  };
+  // device index arrays of the assembly, kept with the plan
+  MfFactorArgs* fa = new MfFactorArgs;
+  std::memset(fa, 0, sizeof(*fa));
+  m->fa = fa;
+  fa->bs = bs;
+  fa->ns = m->ns;
+  fa->nb = m->nb;
   {
     int32_t* d32 = nullptr;
     int64_t* d64 = nullptr;
     int4* d4 = nullptr;
-    MF_TRY(sup(&d32, snn)); a.snn = d32;
-    MF_TRY(sup(&d32, child)); a.child = d32;
-    MF_TRY(sup(&d32, cmap)); a.cmap = d32;
-    MF_TRY(sup(&d64, fsb)); a.fsb_off = d64;
-    MF_TRY(sup(&d64, fbs)); a.fbs_off = d64;
-    MF_TRY(sup(&d64, uo)); a.u_off = d64;
-    MF_TRY(sup(&d64, fss)); a.fss_off = d64;
-    MF_TRY(sup(&d64, cmp)); a.cmap_ptr = d64;
-    MF_TRY(sup(&d64, ssp)); a.ss_ptr = d64;
-    MF_TRY(sup(&d64, obp)); a.ob_ptr = d64;
-    MF_TRY(sup(&d4, sse)); a.ss_ent = d4;
-    MF_TRY(sup(&d4, obe)); a.ob_ent = d4;
+    MF_TRY(mf_up(ctx, m, &d32, snn)); fa->snn = d32;
+    MF_TRY(mf_up(ctx, m, &d32, child)); fa->child = d32;
+    MF_TRY(mf_up(ctx, m, &d32, cmap)); fa->cmap = d32;
+    MF_TRY(mf_up(ctx, m, &d64, fsb)); fa->fsb_off = d64;
+    MF_TRY(mf_up(ctx, m, &d64, fbs)); fa->fbs_off = d64;
+    MF_TRY(mf_up(ctx, m, &d64, uo)); fa->u_off = d64;
+    MF_TRY(mf_up(ctx, m, &d64, fss)); fa->fss_off = d64;
+    MF_TRY(mf_up(ctx, m, &d64, cmp)); fa->cmap_ptr = d64;
+    MF_TRY(mf_up(ctx, m, &d64, ssp)); fa->ss_ptr = d64;
+    MF_TRY(mf_up(ctx, m, &d64, obp)); fa->ob_ptr = d64;
+    MF_TRY(mf_up(ctx, m, &d4, sse)); fa->ss_ent = d4;
+    MF_TRY(mf_up(ctx, m, &d4, obe)); fa->ob_ent = d4;
   }
-  if (rc == 0) {
+#undef MF_TRY
+  m->h_ns = ns;
+  m->h_nb = nb;
+  m->h_xoff = xoff;
+  m->h_loff = loff;
+  m->h_woff = woff;
+  m->h_fsb = fsb;
+  m->h_fbs = fbs;
+  m->h_uo = uo;
+  m->h_fss = fss;
+  m->tmp_doubles = tmp;
+  if (rc != 0) {
+    mf_free(m);
+    return rc;
+  }
+  *out = m;
+  return 0;
+}
+
+// numeric factorisation with the operator's current values
+static int mf_numeric(alfi_level* L, MfDev* m) {
+  alfi_ctx* ctx = L->ctx;
+  const int H = m->H;
+  const std::vector<int32_t>&ns = m->h_ns, &nb = m->h_nb;
+  const std::vector<int64_t>&xoff = m->h_xoff, &loff = m->h_loff, &woff = m->h_woff, &fsb = m->h_fsb, &fbs = m->h_fbs,
+                             &uo = m->h_uo, &fss = m->h_fss;
+  const int64_t tmp = m->tmp_doubles, fac = m->fac_doubles;
+  MfFactorArgs a = *m->fa;
+  a.vals = L->A.vals;
+  a.flat = L->A.flat;
+  int rc = 0;
+  {
     hipError_t e = hipMalloc((void**)&a.tmp, (size_t)std::max<int64_t>(tmp, 1) * 8);
-    if (e != hipSuccess) rc = alfi_set_error(ctx, ALFI_E_HIP, "front storage of %.1f GB: %s", 8e-9 * (double)tmp, hipGetErrorString(e));
-    else scratch.push_back(a.tmp);
+    if (e != hipSuccess) return alfi_set_error(ctx, ALFI_E_HIP, "front storage of %.1f GB: %s", 8e-9 * (double)tmp, hipGetErrorString(e));
   }
   if (rc == 0 && hipMemsetAsync(a.tmp, 0, (size_t)tmp * 8, ctx->stream) != hipSuccess) rc = ALFI_E_HIP;
   if (rc == 0 && hipMemsetAsync(m->fac, 0, (size_t)fac * 8, ctx->stream) != hipSuccess) rc = ALFI_E_HIP;
@@ -776,19 +813,34 @@ int mf_factor(alfi_level* L, const double* coords, int dim, int leaf_nodes) {
       }
     }
   }
-#undef MF_TRY
   (void)hipStreamSynchronize(ctx->stream);
-  for (void* p : scratch) (void)hipFree(p);
+  (void)hipFree(a.tmp);
   if (rc == 0 && ctx->big_arena_bytes > ((size_t)1 << 30)) {
     (void)hipFree(ctx->big_arena);
     ctx->big_arena = nullptr;
     ctx->big_arena_bytes = 0;
   }
+  return rc;
+}
+
+// (Re-)factorisation of the level operator.  The plan of an earlier call is reused when it was made for the same ordering
+// request (the sparsity of a level never changes; new values arrive through alfi_level_update_values).
+int mf_factor(alfi_level* L, const double* coords, int dim, int leaf_nodes) {
+  if (leaf_nodes <= 0) leaf_nodes = getenv("ALFI_MF_LEAF") ? atoi(getenv("ALFI_MF_LEAF")) : 64;
+  MfDev* m = L->mf;
+  if (m && (m->leaf != leaf_nodes || m->with_coords != (coords != nullptr) || m->nnzb != L->A.nnzb || m->n != L->n)) {
+    mf_free(m);
+    L->mf = m = nullptr;
+  }
+  if (!m) {
+    ALFI_CHECK(mf_analyse(L, coords, dim, leaf_nodes, &m));
+  }
+  const int rc = mf_numeric(L, m);
   if (rc != 0) {
     mf_free(m);
+    L->mf = nullptr;
     return rc;
   }
-  if (L->mf) mf_free(L->mf);
   L->mf = m;
   return 0;
 }

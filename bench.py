@@ -41,6 +41,7 @@ CONFIGS = {
     # macro-cell transfer blocks of 390; baseN 1 (114 tets), nref 2 -> 441 k velocity dofs, 33 GB of patch inverses
     "cfg5": ("sv", 1, 2, 3, 500.0, 10),
     "cfg5s": ("sv", 1, 1, 3, 500.0, 10),
+    "cfg5L": ("sv", 1, 3, 3, 500.0, 10),   # one more refinement: 3.4 M velocity dofs, ~40 GB of condensed factors on ONE GPU
 }
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 TB/s achievable)
 

@@ -128,3 +128,36 @@ def test_single_front_and_disconnected_graph():
         assert np.abs(xx.get() - want).max() < 1e-9 * np.abs(want).max()
         d2.close()
     ctx.close()
+
+
+def test_refactorisation_with_new_values_reuses_the_plan():
+    """alfi_level_update_values + alfi_coarse_factor_sparse (what every Newton step does): the ordering and the symbolic
+    factorisation are kept, the numeric factors follow the new values."""
+    import time
+    from alfi_amd import hip
+    lv, _ = _level("3d", 4, k=2)
+    L = lv[0]
+    ctx = hip.Context(0)
+    dl = hip.Level(ctx, L.A, L.bc_dofs)
+    t0 = time.time()
+    dl.coarse_factor_sparse(None)
+    t_first = time.time() - t0
+    A = L.A.to_scipy().tocsr()
+    rng = np.random.default_rng(4)
+    b = rng.standard_normal(L.n)
+    bx, xx = ctx.vec(b), ctx.vec(L.n)
+    # new values: another Reynolds number on the same sparsity
+    lv2, _ = _level("3d", 4, k=2, Re=200.0)
+    assert np.array_equal(lv2[0].A.colidx, L.A.colidx)
+    dl.update_values(lv2[0].A.vals)
+    t0 = time.time()
+    assert dl.coarse_factor_sparse(None) < 1e-7
+    t_again = time.time() - t0
+    dl.coarse_solve(bx, xx)
+    want = spla.splu(lv2[0].A.to_scipy().tocsc()).solve(b)
+    assert np.abs(xx.get() - want).max() < 1e-9 * np.abs(want).max()
+    old = spla.splu(A.tocsc()).solve(b)
+    assert np.abs(xx.get() - old).max() > 1e-6 * np.abs(old).max()        # (it is the new operator that was factored)
+    print("first factorisation %.3f s, with the plan %.3f s" % (t_first, t_again))
+    dl.close()
+    ctx.close()
