@@ -768,7 +768,10 @@ int alfi_patches_set(alfi_level* L, int64_t npatch, const int64_t* pptr, const i
   ALFI_CHECK(dev_upload(ctx, &L->stage_ptr, stage_ptr.data(), npatch + 1));
   ALFI_CHECK(dev_upload(ctx, &L->dof_ptr, dof_ptr.data(), L->n + 1));
   ALFI_CHECK(dev_upload(ctx, &L->dof_pos, dof_pos.data(), sum_n));
-  ALFI_CHECK(dev_alloc(ctx, &L->inv, ip));
+  // the dense inverses (8 sum n_p^2 bytes) are allocated by the first alfi_patches_factor that needs them: a level that
+  // gets condensed factors (alfi_patches_set_groups) never holds them -- 265 GB for the 3.4 M-dof Scott-Vogelius level
+  ALFI_CHECK(dev_alloc(ctx, &L->inv, 16));
+  L->inv_shrunk = true;
   ALFI_CHECK(dev_alloc(ctx, &L->stage, sp));
   ALFI_HIP_CHECK(ctx, hipMemsetAsync(L->stage, 0, (size_t)std::max<int64_t>(sp, 1) * sizeof(double), ctx->stream));
   L->h_patch_ptr.assign(pptr, pptr + npatch + 1);
@@ -792,13 +795,7 @@ int alfi_patches_set_groups(alfi_level* L, const int32_t* group) {
   ALFI_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
   free_cond(L);
   L->factored = false;
-  if (L->inv_shrunk) {                                   // condensed before: the dense storage was released
-    dev_free(L->inv);
-    L->inv = nullptr;
-    L->inv_shrunk = false;
-    ALFI_CHECK(dev_alloc(ctx, &L->inv, L->inv_doubles));
-  }
-  if (!group) return 0;                                  // back to dense inverses
+  if (!group) return 0;                                  // back to dense inverses (allocated by alfi_patches_factor)
   if (L->mult) return alfi_set_error(ctx, ALFI_E_STATE, "condensed patch factors do not support multiplicative sweeps");
   const int bs = L->bs;
   const int64_t npatch = L->npatch, nb = L->A.nbrows, nnzb = L->A.nnzb;
@@ -937,10 +934,12 @@ int alfi_patches_set_groups(alfi_level* L, const int32_t* group) {
   ALFI_CHECK(dev_alloc(ctx, &cd.sinv, sinv_off));
   L->cond_allocs.push_back(cd.sinv);
   // the dense inverses are not needed any more
-  dev_free(L->inv);
-  L->inv = nullptr;
-  ALFI_CHECK(dev_alloc(ctx, &L->inv, 16));
-  L->inv_shrunk = true;
+  if (!L->inv_shrunk) {
+    dev_free(L->inv);
+    L->inv = nullptr;
+    ALFI_CHECK(dev_alloc(ctx, &L->inv, 16));
+    L->inv_shrunk = true;
+  }
   L->cd = cd;
   L->cond = true;
   L->h_sptr = sptr;
@@ -1048,6 +1047,13 @@ int alfi_patches_factor(alfi_level* L) {
   int t = alfi_prof_begin(ctx, ALFI_EV_PATCH_FACTOR);
   ALFI_HIP_CHECK(ctx, hipMemsetAsync(L->status, 0, sizeof(int), ctx->stream));
   static const bool force_big = getenv("ALFI_FORCE_BIG_FACTOR") && atoi(getenv("ALFI_FORCE_BIG_FACTOR")) == 1;
+  if (!L->cond && L->inv_shrunk) {                 // first dense factorisation of this patch set
+    ALFI_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    dev_free(L->inv);
+    L->inv = nullptr;
+    ALFI_CHECK(dev_alloc(ctx, &L->inv, L->inv_doubles));
+    L->inv_shrunk = false;
+  }
   if (L->cond) {
     ALFI_CHECK(launch_cond_factor(L));            // condensed factors: group inverses + Schur complements
   } else if (L->max_np > SMALL_PATCH_MAX || force_big) {
