@@ -21,6 +21,8 @@ def main():
     from alfi_amd.dist import DistMultigrid
     lv, tr, k, min_dofs = _hier(case)
     dmg = DistMultigrid(lv, tr, k, robust_restriction=bool(robust), min_dofs=min_dofs)
+    if os.environ.get("ALFI_TEST_EXPECT_TRANSPORT"):
+        assert dmg.transport == os.environ["ALFI_TEST_EXPECT_TRANSPORT"], dmg.transport
     b = np.random.default_rng(0).standard_normal(lv[-1].n)
     b[lv[-1].bc_dofs] = 0.0
     db, dx = dmg.local_vec(b), dmg.local_vec()

@@ -27,6 +27,25 @@ def _free_port():
                                                        ("3d-P2FB-3lev", 4, 1, "1"), ("3d-P2FB", 2, 1, "0"),
                                                        ("2d-SV", 3, 1, "1"), ("3d-SV-P3", 2, 1, "1")])
 def test_partitioned_cycles_match_single_gpu(case, world, robust, overlap, tmp_path):
+    _partitioned_cycles(case, world, robust, overlap, tmp_path, {})
+
+
+@pytest.mark.parametrize("case,world,robust,overlap", [("2d-all-distributed", 2, 0, "1"), ("2d-coarse-on-rank0", 3, 1, "0"),
+                                                       ("3d-P2FB", 2, 1, "1"), ("3d-P2FB-3lev", 4, 1, "1"),
+                                                       ("3d-SV-P3", 2, 1, "0")])
+def test_native_transport_with_several_ranks(case, world, robust, overlap, tmp_path):
+    """The PRODUCT transport (csrc/comm.hip: the library's own communicator, neighbour tables, grouped ncclSend / ncclRecv,
+    all-reduces, the asynchronous side stream of the overlapped exchanges) with 2-4 ranks.  RCCL refuses several ranks on
+    one device, so on this one-GPU box the nine librccl entry points comm.hip resolves are served by
+    tests/mock_rccl (ALFI_RCCL_LIB): shared-memory mailboxes between the rank processes, same call sequence, same
+    message sizes and ordering -- a wrong neighbour table, count or offset fails here as it would over xGMI."""
+    from tests.mock_rccl.build import build
+    lib = build()
+    _partitioned_cycles(case, world, robust, overlap, tmp_path, {"ALFI_DIST_TRANSPORT": "rccl", "ALFI_RCCL_LIB": lib,
+                                                                  "ALFI_TEST_EXPECT_TRANSPORT": "rccl"})
+
+
+def _partitioned_cycles(case, world, robust, overlap, tmp_path, extra_env):
     from alfi_amd import hip
     from oracle import alfi_oracle as O
     from tests.test_dist_cpu import _hier
@@ -39,6 +58,7 @@ def test_partitioned_cycles_match_single_gpu(case, world, robust, overlap, tmp_p
         env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), OMP_NUM_THREADS="4", ALFI_DIST_OVERLAP=overlap,
                    ALFI_DIST_OVERLAP_MIN_DOFS="0")       # exercise the overlapped sequence on these small levels too
+        env.update(extra_env)
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dist_gpu_worker.py"), case,
                                        str(robust), str(tmp_path)], env=env, cwd=ROOT))
     # the single-GPU references while the ranks run
@@ -233,6 +253,19 @@ def test_bench_starts_its_own_ranks_shared_gpu():
     assert d["n_gpus"] == 2 and d["n_ranks_seen"] == 2 and d["config"]["transport"] == "callback"
     assert d["config"]["generation"].startswith("rank-local") and d["rel_residual_after_timed_cycles"] < 0.5
     assert len(d["setup_s"]["host_peak_rss_GB_per_rank"]) == 2
+
+
+def test_bench_multi_rank_with_the_native_transport():
+    """The driver's multi-GPU bench command with the product transport (library-owned communicator, no Python at the
+    exchange points, rank-local generation) on 4 ranks; librccl's entry points served by tests/mock_rccl because the box
+    has one GPU.  What the 8-GPU run executes, minus RCCL's own wire protocol."""
+    from tests.mock_rccl.build import build
+    out, d = _bench(["--gpus", "4", "--config", "tiny", "--steps", "2", "--warmup", "1"],
+                    {"ALFI_DIST_BACKEND": "gloo", "ALFI_DIST_MIN_DOFS": "500", "ALFI_DIST_TRANSPORT": "rccl",
+                     "ALFI_RCCL_LIB": build()})
+    assert out.returncode == 0 and d is not None, out.stderr[-3000:]
+    assert d["n_gpus"] == 4 and d["n_ranks_seen"] == 4 and d["config"]["transport"] == "rccl"
+    assert d["rel_residual_after_timed_cycles"] < 0.5
 
 
 def test_bench_launcher_fails_loudly_when_a_rank_cannot_start():
