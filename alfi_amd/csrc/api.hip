@@ -417,6 +417,7 @@ int alfi_level_create(alfi_ctx* ctx, int64_t nbrows, int bs, const int32_t* brow
   }
   L->n_own = L->n;
   L->A_own = L->A;
+  for (int64_t i = 0; i < nbrows; ++i) L->max_row_blocks = std::max<int>(L->max_row_blocks, browptr[i + 1] - browptr[i]);
   *out = L;
   return 0;
 }
@@ -929,6 +930,19 @@ int alfi_patches_set_groups(alfi_level* L, const int32_t* group) {
   ALFI_CHECK(cond_upload(L, &cd.sinv_ptr, sinv_ptr));
   ALFI_CHECK(cond_upload(L, &cd.s_uptr, s_uptr));
   ALFI_CHECK(cond_upload(L, &cd.s_uidx, s_uidx));
+  {
+    // dispatch order of a full-range apply: descending factor bytes (group matrices + inv(Sigma)), ties by index
+    std::vector<int64_t> pbytes((size_t)L->npatch, 0);
+    for (int64_t p = 0; p < L->npatch; ++p) {
+      const int64_t s = sptr[p + 1] - sptr[p];
+      pbytes[p] = s * s;
+      for (int64_t g = gptr[p]; g < gptr[p + 1]; ++g) pbytes[p] += (int64_t)g_m[g] * (g_m[g] + 2 * g_sc[g]);
+    }
+    std::vector<int32_t> order((size_t)L->npatch);
+    for (int64_t p = 0; p < L->npatch; ++p) order[p] = (int32_t)p;
+    std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return pbytes[a] > pbytes[b]; });
+    ALFI_CHECK(cond_upload(L, &cd.order, order));
+  }
   ALFI_CHECK(dev_alloc(ctx, &cd.mat, mat_off));
   L->cond_allocs.push_back(cd.mat);
   ALFI_CHECK(dev_alloc(ctx, &cd.sinv, sinv_off));
@@ -1191,11 +1205,12 @@ int alfi_smooth_fgmres(alfi_level* L, int k, const double* db, double* dx, int n
     // launch latency, on the large 2-D ones the folded vector passes save BLAS-1 traffic, which is comparable to the patch
     // traffic there).  ALFI_FUSED_SMOOTHER=0 keeps the general path (A/B measurements).
     static const bool allow = !(getenv("ALFI_FUSED_SMOOTHER") && atoi(getenv("ALFI_FUSED_SMOOTHER")) == 0);
-    // (rows of up to ~32 blocks -- the 2-D operators; with the 50 .. 100 blocks per row of the 3-D ones the flat segmented
-    // product of the general path is the faster kernel and the fused iteration gains nothing: cfg3 19.0 vs 18.9 ms, cfg2
-    // 5.10 vs 5.43 ms, same box)
+    // (uniformly short rows -- the 2-D operators, <= 32 blocks; with the 50 .. 125 blocks per row of the 3-D ones the flat
+    // segmented product of the general path is the faster kernel -- cfg3 19.0 vs 18.9 ms, cfg2 5.10 vs 5.43 ms, same box --
+    // and with the bimodal rows of [P1+FB]^3 (12 blocks on the face nodes, 75 on the vertices, 17 on average) the
+    // lanes-per-row product of the fused iteration idles most of its lanes: config 6 188.8 ms fused, 175.0 ms general)
     if (allow && !L->distributed && L->n_own == L->n && !L->mult && k + 1 <= 16 && L->A_own.flat &&
-        L->A_own.nnzb <= 32 * L->A_own.nbrows)
+        L->max_row_blocks <= 32)
       return smooth_fgmres_fused(L, k, db, dx, nonzero_guess);
   }
   const int K = L->kmax;

@@ -164,6 +164,7 @@ struct CondDev {
   const int32_t* s_uidx = nullptr;
   double* mat = nullptr;
   double* sinv = nullptr;
+  const int32_t* order = nullptr;  // (npatch) patches by descending factor bytes: dispatch order of a full-range apply
 };
 
 struct alfi_level {
@@ -175,6 +176,7 @@ struct alfi_level {
   // partition: owned prefix [0, n_own) of the local numbering, then ghosts (serial: n_own == n)
   int64_t n_own = 0;
   DevBSR A_own;             // view of A restricted to the owned block rows
+  int max_row_blocks = 0;   // longest block row of A
   // overlap of the forward halo with work that needs no ghost value (alfi_level_set_overlap)
   bool overlap = false;
   DevBSR A_int, A_bnd;       // owned rows without / with ghost columns (own chunk tables)

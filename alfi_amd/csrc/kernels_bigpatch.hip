@@ -823,11 +823,13 @@ __global__ __launch_bounds__(64 * COND_WAVES) void cond_apply_kernel(int64_t p0,
                                                                      const int64_t* __restrict__ patch_ptr,
                                                                      const int64_t* __restrict__ stage_ptr,
                                                                      const double* __restrict__ x, double* __restrict__ stage,
-                                                                     int umax) {
+                                                                     int umax, int ordered) {
   extern __shared__ double cond_dsmem[];
   constexpr int NT_ = 64 * COND_WAVES;
-  const int64_t p = p0 + blockIdx.x;
-  if (p >= p1) return;
+  if (p0 + blockIdx.x >= p1) return;
+  // full-range launches walk the patches largest first (workgroups are dispatched in index order: with ~7 patches per CU
+  // at config 5's size the big patches must not come last); range launches (overlapped exchanges) keep the natural order
+  const int64_t p = ordered ? cd.order[blockIdx.x] : p0 + blockIdx.x;
   const int64_t off = patch_ptr[p];
   const int n = (int)(patch_ptr[p + 1] - off);
   const int nI = cd.p_nI[p];
@@ -1162,6 +1164,8 @@ int launch_cond_apply_range(alfi_level* L, int64_t p0, int64_t p1, const double*
   // ALFI_COND_WAVES = 4 / 8 / 16 for A/B runs
   static const int waves = getenv("ALFI_COND_WAVES") ? atoi(getenv("ALFI_COND_WAVES")) : 8;
   dim3 grid((unsigned)(p1 - p0));
+  static const bool allow_order = !(getenv("ALFI_COND_ORDER") && atoi(getenv("ALFI_COND_ORDER")) == 0);
+  const int ordered = allow_order && p0 == 0 && p1 == L->npatch && L->cd.order ? 1 : 0;
   const size_t lds = (size_t)L->cond_lds_bytes;
 #define ALFI_COND_LAUNCH(NTV, WV)                                                                                       \
   do {                                                                                                                  \
@@ -1169,7 +1173,7 @@ int launch_cond_apply_range(alfi_level* L, int64_t p0, int64_t p1, const double*
       ALFI_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&cond_apply_kernel<NTV, WV>),               \
                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                   \
     hipLaunchKernelGGL((cond_apply_kernel<NTV, WV>), grid, dim3(64 * WV), lds, ctx->stream, p0, p1, L->cd, L->patch_ptr, \
-                       L->stage_ptr, x, L->stage, L->cond_umax);                                                        \
+                       L->stage_ptr, x, L->stage, L->cond_umax, ordered);                                               \
   } while (0)
   if (waves == 4) {
     if (nt) ALFI_COND_LAUNCH(true, 4); else ALFI_COND_LAUNCH(false, 4);

@@ -375,6 +375,9 @@ def localize_transfer(T, Lf, pc, pf):
 def localize(levels, transfers, parts):
     """(local levels, local transfers, first level present) for the rank the parts belong to."""
     present = [p.nb_loc > 0 for p in parts]
+    if True not in present:
+        raise ValueError("rank %d holds no part of any level: no level reaches min_dofs, so nothing is partitioned over the "
+                         "%d ranks (lower min_dofs / ALFI_DIST_MIN_DOFS or use fewer ranks)" % (parts[0].rank, len(parts[0].splits) - 1))
     lmin = present.index(True)
     assert all(present[lmin:]), "levels present on a rank must be contiguous"
     llev = [localize_level(levels[l], parts[l]) for l in range(lmin, len(levels))]
