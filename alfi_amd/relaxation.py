@@ -10,6 +10,8 @@ with DMPlex's point numbering convention (cells, then vertices, then edges, then
 The built-in ``patch_pc_patch_construct_type: star`` (solver.py:337-338) does not go through this module: it uses the
 vectorised ``VectorFunctionSpace.star_patches``; ``tests/test_frontend.py`` checks that both agree.
 """
+import itertools
+
 import numpy as np
 
 
@@ -96,21 +98,35 @@ class PlexLike(object):
     def getSupport(self, p):
         if self._support is None:
             self._build_support()
-        return np.array(self._support[p], dtype=np.int64)
+            self._support_arr = {}
+        a = self._support_arr.get(p)
+        if a is None:
+            a = self._support_arr[p] = np.array(self._support[p], dtype=np.int64)
+        return a
 
     def getTransitiveClosure(self, p, useCone=True):
-        seen, frontier = [int(p)], [int(p)]
+        # memoised: a macro-star constructor asks for the star of the same point from every patch that contains it
+        # (2 M star requests for 0.3 M distinct points on the 441 k-dof channel); the order of the points is DMPlex's
+        # breadth-first one either way
+        cache = self.__dict__.setdefault("_closure_cache", ({}, {}))[0 if useCone else 1]
+        p = int(p)
+        hit = cache.get(p)
+        if hit is not None:
+            return hit, None
+        seen, mark, frontier = [p], {p}, [p]
         nxt = self.getCone if useCone else self.getSupport
         while frontier:
             new = []
             for q in frontier:
                 for r in nxt(q):
                     r = int(r)
-                    if r not in seen:
+                    if r not in mark:
+                        mark.add(r)
                         seen.append(r)
                         new.append(r)
             frontier = new
-        return np.array(seen, dtype=np.int64), None
+        out = cache[p] = np.array(seen, dtype=np.int64)
+        return out, None
 
     def getLabelValue(self, name, p):
         lab = self.labels.get(name)
@@ -259,10 +275,11 @@ class MacroStar(OrderedRelaxation):
         if dm.getLabelValue("MacroVertices", vertex) != 1:
             return None
         s = list(self.star(dm, vertex))
-        closures = sum((list(self.closure(dm, e)) for e in s), [])
+        # (concatenations written with chain: the same lists as sum(..., []) without its quadratic copying)
+        closures = list(itertools.chain.from_iterable(self.closure(dm, e) for e in s))
         # literal: every closure point whose label is not 1 (relaxation.py:174), not only vertices
         the_vertices_we_care_about = [v for v in closures if dm.getLabelValue("MacroVertices", v) != 1]
-        their_star = sum((list(self.star(dm, v)) for v in the_vertices_we_care_about), [])
+        their_star = list(itertools.chain.from_iterable(self.star(dm, v) for v in the_vertices_we_care_about))
         return s + their_star
 
 
