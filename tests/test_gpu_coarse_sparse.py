@@ -161,3 +161,29 @@ def test_refactorisation_with_new_values_reuses_the_plan():
     print("first factorisation %.3f s, with the plan %.3f s" % (t_first, t_again))
     dl.close()
     ctx.close()
+
+
+def test_the_reference_largest_coarse_grid():
+    """Full size: the coarse grid of the reference's largest defined run (ldc3d [P1+FB]^3, baseN 18,
+    examples/generate_submission:10-23): 236 361 dofs -- 447 GB as a dense inverse.  Size-independent property instead of
+    an oracle solve: the residual of the returned solution, computed on the host."""
+    from alfi_amd import hip
+    lv, _ = build_hierarchy(ThreeDimLidDrivenCavityProblem(18), 0, 1, Re=100.0, patches=False)
+    L = lv[0]
+    assert L.n == 236361
+    ctx = hip.Context(0)
+    dl = hip.Level(ctx, L.A, L.bc_dofs)
+    res = dl.coarse_factor_sparse(None)
+    assert res < 1e-7, res
+    assert dl.coarse_factor_bytes() < 12e9          # (dense: 4.5e11)
+    A = L.A.to_scipy().tocsr()
+    rng = np.random.default_rng(5)
+    for _ in range(2):
+        b = rng.standard_normal(L.n)
+        bx, xx = ctx.vec(b), ctx.vec(L.n)
+        dl.coarse_solve(bx, xx)
+        x = xx.get()
+        r = np.abs(A @ x - b).max() / np.abs(b).max()
+        assert r < 1e-8, r
+    dl.close()
+    ctx.close()
