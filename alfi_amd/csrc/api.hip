@@ -156,6 +156,23 @@ static void free_bsr(DevBSR* d) {
 // a host callback (alfi_ctx_set_comm) ----------------------------------------------------------------------------------
 static int comm_call(alfi_level* L, int op, int64_t offset, int64_t count) {
   alfi_ctx* ctx = L->ctx;
+  switch (op) {             // bookkeeping for alfi_ctx_comm_stats
+    case ALFI_COMM_ALLREDUCE:
+      ++ctx->comm_nred;
+      ctx->comm_sent += count;
+      break;
+    case ALFI_COMM_HALO_FWD:
+    case ALFI_COMM_HALO_FWD_BEGIN:
+      ++ctx->comm_nhalo;
+      ctx->comm_sent += L->halo_nsend * L->bs;
+      break;
+    case ALFI_COMM_HALO_REV:
+    case ALFI_COMM_HALO_REV_BEGIN:
+      ++ctx->comm_nhalo;
+      ctx->comm_sent += L->halo_nghost * L->bs;
+      break;
+    default: break;
+  }
   if (ctx->nat) {
     switch (op) {
       case ALFI_COMM_ALLREDUCE: return native_allreduce(ctx, offset, count);
@@ -1847,6 +1864,14 @@ static int run_cycle(alfi_mg* mg, int kind, const double* db, double* dx) {
 int alfi_mg_vcycle(alfi_mg* mg, const double* db, double* dx) { return run_cycle(mg, 0, db, dx); }
 
 int alfi_mg_fcycle(alfi_mg* mg, const double* db, double* dx) { return run_cycle(mg, 1, db, dx); }
+
+int alfi_ctx_comm_stats(alfi_ctx* ctx, int64_t* halo_exchanges, int64_t* allreduces, int64_t* doubles_sent, int reset) {
+  if (halo_exchanges) *halo_exchanges = ctx->comm_nhalo;
+  if (allreduces) *allreduces = ctx->comm_nred;
+  if (doubles_sent) *doubles_sent = ctx->comm_sent;
+  if (reset) ctx->comm_nhalo = ctx->comm_nred = ctx->comm_sent = 0;
+  return 0;
+}
 
 int alfi_ctx_set_graph(alfi_ctx* ctx, int on) {
   ctx->use_graph = on != 0;

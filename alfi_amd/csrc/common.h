@@ -10,6 +10,8 @@
 struct alfi_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
+  // exchange points since alfi_ctx_comm_stats(reset): halo exchanges (forward + reverse), all-reduces, doubles this rank sent
+  int64_t comm_nhalo = 0, comm_nred = 0, comm_sent = 0;
   bool use_graph = false;           // alfi_ctx_set_graph: replay whole cycles as hipGraphs (not while profiling / partitioned)
   void* big_arena = nullptr;        // scratch of the large-block factorisation (kernels_bigpatch.hip), kept between calls
   size_t big_arena_bytes = 0;

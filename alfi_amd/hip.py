@@ -62,6 +62,12 @@ class Context(object):
         return v
 
     # profiling (PETSc-event style report, driver.py:77-92) ----------------------------------------------------------------
+    def comm_stats(self, reset=False):
+        """(halo exchanges, all-reduces, doubles sent by this rank) since the last reset (alfi_ctx_comm_stats)."""
+        a, b, c = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int64()
+        self.check(self.lib.alfi_ctx_comm_stats(self.h, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c), 1 if reset else 0))
+        return a.value, b.value, c.value
+
     def set_graph(self, on=True):
         """Replay whole multigrid cycles as hipGraphs (alfi_ctx_set_graph)."""
         self.check(self.lib.alfi_ctx_set_graph(self.h, 1 if on else 0))

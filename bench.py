@@ -193,8 +193,10 @@ def main_distributed(args, rank, world, local_rank):
     if True:                                         # device time of the exchange points: one extra, untimed cycle
         ctx.prof_enable(2)
         ctx.prof_reset()
+        ctx.comm_stats(reset=True)
         dmg.vcycle(db, dx)
         dmg.sync()
+        n_halo, n_red, sent = ctx.comm_stats()
         comm_ms = ctx.prof_get()["COMM"][0]
         ctx.prof_enable(False)
         prof = dict(prof, COMM=(comm_ms * args.steps, prof["COMM"][1]))
@@ -225,7 +227,7 @@ def main_distributed(args, rank, world, local_rank):
     local_gbs = bytes_apply * applies / (ms_f * 1e-3) / 1e9 if ms_f > 0 else 0.0
     rss_gb = resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 1e6
     stats = torch.tensor([float(npatch), float(dmg.n_own), float(dmg.n_loc - dmg.n_own), local_gbs, comm_ms, rss_gb,
-                          t_gen, t_setup], dtype=torch.float64, device="cuda")
+                          t_gen, t_setup, float(n_halo), float(n_red), 8e-6 * sent], dtype=torch.float64, device="cuda")
     allstats = [torch.zeros_like(stats) for _ in range(world)]
     dist.all_gather(allstats, stats)
     if rank == 0:
@@ -254,7 +256,13 @@ def main_distributed(args, rank, world, local_rank):
             "events_ms_rank0": {kname: round(v[0], 3) for kname, v in prof.items()},
             "per_rank": {"patches_finest": [r[0] for r in per_rank], "owned_dofs": [r[1] for r in per_rank],
                          "ghost_dofs": [r[2] for r in per_rank], "patch_apply_GBps": [round(r[3], 1) for r in per_rank],
-                         "comm_ms_per_cycle": [round(r[4], 3) for r in per_rank]},
+                         "comm_ms_per_cycle": [round(r[4], 3) for r in per_rank],
+                         # exchange points of ONE V-cycle as the library counts them (alfi_ctx_comm_stats): halo exchanges
+                         # (forward + reverse-add; each one grouped send/recv with the level's real neighbours), all-reduces
+                         # (<= 12 doubles each), MB this rank sends
+                         "halo_exchanges_per_cycle": [int(r[8]) for r in per_rank],
+                         "allreduces_per_cycle": [int(r[9]) for r in per_rank],
+                         "MB_sent_per_cycle": [round(r[10], 2) for r in per_rank]},
             "rel_residual_after_timed_cycles": res,
             "setup_s": {"host_generation": round(max(r[6] for r in per_rank), 1),
                         "partition_and_device_setup": round(max(r[7] for r in per_rank), 1),

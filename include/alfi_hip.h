@@ -87,6 +87,9 @@ int alfi_prof_get_level(alfi_ctx* ctx, int ev, int level_id, double* total_ms, i
 int alfi_comm_unique_id(void* id_out, int64_t len);                                  /* ncclGetUniqueId */
 int alfi_ctx_comm_init(alfi_ctx* ctx, const void* id, int rank, int nranks);        /* ncclCommInitRank on the ctx's device */
 int alfi_ctx_comm_size(alfi_ctx* ctx, int* rank, int* nranks);
+/* exchange points issued since the last reset: halo exchanges (forward and reverse-add), all-reduces, and the doubles this
+ * rank sent in them (either transport).  What the reference spends in PetscSF scatters and MPI_Allreduce [3P]. */
+int alfi_ctx_comm_stats(alfi_ctx* ctx, int64_t* halo_exchanges, int64_t* allreduces, int64_t* doubles_sent, int reset);
 int alfi_ctx_comm_destroy(alfi_ctx* ctx);                                            /* also done by alfi_ctx_destroy */
 /* (2) CALLBACK (test transport: CPU-staged exchanges between ranks sharing one GPU, gloo): the library packs / unpacks
  *     halo buffers and calls `fn` at every exchange point; the host program performs the exchange stream-ordered on the
