@@ -97,6 +97,7 @@ class HipNavierStokesSolver(object):
         bc_nodes = L.V.bc_nodes
         self.u.reshape(-1, dim)[bc_nodes] = problem.driver(L.V.node_coords[bc_nodes])
         self.p = np.zeros(self.n_p)
+        self._load = None
         self.area = float(self.vol.sum())
 
     # -- device side (overridden by alfi_amd.dist.DistNavierStokesSolver for partitioned levels) -------------------------
@@ -176,6 +177,8 @@ class HipNavierStokesSolver(object):
                 _hostlib.supg(L.V, wind, self.nu, self.supg_weight, self.supg_magic, F=Fs)
                 Fu = Fu + Fs
         Fu = Fu + self.B_raw.T @ p
+        if self._load is not None:                   # body force (manufactured solutions, examples/mms.py): F_u -= (f, v)
+            Fu = Fu - self._load
         Fu[L.bc_dofs] = 0.0
         Fp = self.B_raw @ u
         return Fu, Fp
@@ -188,6 +191,10 @@ class HipNavierStokesSolver(object):
         else:
             adv, self.nu = 1.0, self.char_L * self.char_U / re
         self._set_parameters()
+        self._load = None
+        if hasattr(self.problem, "rhs"):             # NavierStokesProblem.rhs (problem.py:46-47 of the reference): default none
+            from .mms import load_vector
+            self._load = load_vector(self.levels[-1].V, lambda x: self.problem.rhs(x, re))
         u, p = self.u.copy(), self.p.copy()
         lin_its, newton_its = 0, 0
         Fu, Fp = self.residual(u, p, adv)

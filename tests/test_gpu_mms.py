@@ -1,0 +1,29 @@
+"""Manufactured solutions (the reference's own convergence study, examples/mms.py with examples/mmsldc2d): the discrete
+solution of the GPU solve loop against the EXACT solution of the continuous Navier-Stokes problem -- the one check in this
+suite that involves neither the oracle nor the product's own generator on both sides.  Expected orders: [P2]^2-P0 is
+limited by the piecewise constant pressure (velocity L2 error O(h^2), gradient O(h), pressure O(h)); Scott-Vogelius
+[P2]^2-P1dg on Alfeld splits is pressure-robust and of full order (O(h^3), O(h^2), O(h^2)), exactly divergence-free.
+-m gpu"""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "scripts"))
+
+
+@pytest.mark.parametrize("disc,rates", [("pkp0", {"velocity": 1.8, "velocitygrad": 0.85, "pressure": 0.85}),
+                                        ("sv", {"velocity": 2.7, "velocitygrad": 1.8, "pressure": 1.7})])
+def test_convergence_orders_2d(disc, rates):
+    from mms import study
+    from alfi_amd.mms import convergence_orders
+    hs, out = study(2, 4, [1, 2, 3], 2, disc, [1.0, 100.0], verbose=False)
+    for re in (1.0, 100.0):
+        for name, want in rates.items():
+            orders = convergence_orders(out[re][name])
+            assert orders[-1] > want, (disc, re, name, out[re][name], orders)
+        if disc == "sv":       # div [P2]^2 is contained in the pressure space: exactly divergence-free
+            assert max(out[re]["divergence"]) < 1e-7, out[re]["divergence"]
