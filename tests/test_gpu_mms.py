@@ -27,3 +27,16 @@ def test_convergence_orders_2d(disc, rates):
             assert orders[-1] > want, (disc, re, name, out[re][name], orders)
         if disc == "sv":       # div [P2]^2 is contained in the pressure space: exactly divergence-free
             assert max(out[re]["divergence"]) < 1e-7, out[re]["divergence"]
+
+
+@pytest.mark.parametrize("k,rates", [(1, {"velocity": 1.6, "velocitygrad": 0.9, "pressure": 0.9}),
+                                     (2, {"velocity": 1.7, "velocitygrad": 0.9, "pressure": 0.85})])
+def test_convergence_orders_3d_on_the_baseline_elements(k, rates):
+    """examples/mmsldc3d: [P1+FB]^3-P0 (config 3's element) and [P2+FB]^3-P0 (config 4's) on [0, 2]^3, N = 4 -> 8, Re = 1:
+    second order for the velocity, first order for its gradient and for the pressure."""
+    from mms import study
+    from alfi_amd.mms import convergence_orders
+    hs, out = study(3, 2, [1, 2], k, "pkp0", [1.0], verbose=False)
+    for name, want in rates.items():
+        orders = convergence_orders(out[1.0][name])
+        assert orders[-1] > want, (k, name, out[1.0][name], orders)
