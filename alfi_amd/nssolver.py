@@ -193,6 +193,9 @@ class HipNavierStokesSolver(object):
         self._set_parameters()
         self._load = None
         if hasattr(self.problem, "rhs"):             # NavierStokesProblem.rhs (problem.py:46-47 of the reference): default none
+            if self.supg:
+                raise NotImplementedError("a body force with SUPG: the stabilisation's strong residual (stabilisation.py:"
+                                          "86-91) would have to carry it; built for rhs = 0 only")
             from .mms import load_vector
             self._load = load_vector(self.levels[-1].V, lambda x: self.problem.rhs(x, re))
         u, p = self.u.copy(), self.p.copy()
