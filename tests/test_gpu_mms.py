@@ -40,3 +40,16 @@ def test_convergence_orders_3d_on_the_baseline_elements(k, rates):
     for name, want in rates.items():
         orders = convergence_orders(out[1.0][name])
         assert orders[-1] > want, (k, name, out[1.0][name], orders)
+
+
+def test_convergence_orders_3d_scott_vogelius_p3():
+    """Config 5's discretisation -- [P3]^3 - P2dg on Alfeld splits, macro-star patches with condensed factors, macro-cell
+    transfer blocks -- against the exact solution: orders towards 4 / 3 / 3 and a divergence at rounding level."""
+    from mms import study
+    from alfi_amd.mms import convergence_orders
+    hs, out = study(3, 1, [1, 2], 3, "sv", [1.0], verbose=False)
+    want = {"velocity": 3.4, "velocitygrad": 2.4, "pressure": 2.3}
+    for name, w in want.items():
+        orders = convergence_orders(out[1.0][name])
+        assert orders[-1] > w, (name, out[1.0][name], orders)
+    assert max(out[1.0]["divergence"]) < 1e-9
