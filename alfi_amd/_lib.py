@@ -40,6 +40,7 @@ SIGNATURES = {
     "alfi_ctx_set_comm": (ctypes.c_int, [vp, vp, vp, vp, ctypes.c_int64]),
     "alfi_comm_unique_id": (ctypes.c_int, [vp, ctypes.c_int64]),
     "alfi_ctx_comm_init": (ctypes.c_int, [vp, vp, ctypes.c_int, ctypes.c_int]),
+    "alfi_level_set_sum_exchange": (ctypes.c_int, [vp, ctypes.c_int, vp, vp, vp, ctypes.c_int64, vp, vp, vp]),
     "alfi_ctx_comm_stats": (ctypes.c_int, [vp, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64),
                                            ctypes.POINTER(ctypes.c_int64), ctypes.c_int]),
     "alfi_ctx_comm_size": (ctypes.c_int, [vp, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]),

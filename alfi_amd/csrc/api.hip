@@ -171,10 +171,15 @@ static int comm_call(alfi_level* L, int op, int64_t offset, int64_t count) {
       ++ctx->comm_nhalo;
       ctx->comm_sent += L->halo_nghost * L->bs;
       break;
+    case ALFI_COMM_HALO_SUM:
+      ++ctx->comm_nhalo;
+      ctx->comm_sent += L->sum_nsend * L->bs;
+      break;
     default: break;
   }
   if (ctx->nat) {
     switch (op) {
+      case ALFI_COMM_HALO_SUM: return native_exchange(L, 2, false);
       case ALFI_COMM_ALLREDUCE: return native_allreduce(ctx, offset, count);
       case ALFI_COMM_HALO_FWD: return native_exchange(L, 0, false);
       case ALFI_COMM_HALO_REV: return native_exchange(L, 1, false);
@@ -238,6 +243,18 @@ static int halo_rev(alfi_level* L, double* v) {
   ALFI_CHECK(launch_copy(ctx, L->halo_recvbuf, v + L->n_own, L->halo_nghost * L->bs));
   ALFI_CHECK(comm_call(L, ALFI_COMM_HALO_REV, 0, 0));
   ALFI_CHECK(launch_halo_add(ctx, v, L->halo_sendbuf, L->rev_nodes, L->rev_ptr, L->rev_pos, L->rev_nuniq, L->bs));
+  alfi_prof_end(ctx, t);
+  return 0;
+}
+
+// merged reverse-add + forward (alfi_level_set_sum_exchange): afterwards every holder of a shared node -- owner and ghost
+// copies -- has the sum of all holders' values, added in one fixed order
+static int halo_sum(alfi_level* L, double* v) {
+  alfi_ctx* ctx = L->ctx;
+  int t = alfi_prof_begin(ctx, ALFI_EV_COMM);
+  ALFI_CHECK(launch_halo_pack(ctx, L->sum_sendbuf, v, L->sum_send_nodes, L->sum_nsend, L->bs));
+  ALFI_CHECK(comm_call(L, ALFI_COMM_HALO_SUM, 0, 0));
+  ALFI_CHECK(launch_halo_sum(ctx, v, L->sum_recvbuf, L->sum_nodes, L->sum_ptr, L->sum_src, L->sum_nshared, L->bs));
   alfi_prof_end(ctx, t);
   return 0;
 }
@@ -643,11 +660,11 @@ int alfi_level_id(alfi_level* L, int* id) {
 // product is formed on the owned rows.
 // y = A x (mode 0) or y = b - A x (mode 1) on the owned rows of a level.  With alfi_level_set_overlap the rows without
 // ghost columns are multiplied while the forward halo of x is in flight.
-static int level_spmv(alfi_level* L, const double* dx, double* dy, const double* db, int mode) {
+static int level_spmv(alfi_level* L, const double* dx, double* dy, const double* db, int mode, bool ghosts_current = false) {
   alfi_ctx* ctx = L->ctx;
   ctx->cur_tag = L->id;
   int t;
-  if (L->distributed && L->overlap) {
+  if (L->distributed && L->overlap && !ghosts_current) {
     ALFI_CHECK(halo_fwd_begin(L, dx));
     t = alfi_prof_begin(ctx, ALFI_EV_MATMULT);
     ALFI_CHECK(launch_bsr_spmv(ctx, L->A_int, dx, dy, db, 1.0, mode));
@@ -658,7 +675,7 @@ static int level_spmv(alfi_level* L, const double* dx, double* dy, const double*
     alfi_prof_end(ctx, t);
     return 0;
   }
-  if (L->distributed) ALFI_CHECK(halo_fwd(L, const_cast<double*>(dx)));
+  if (L->distributed && !ghosts_current) ALFI_CHECK(halo_fwd(L, const_cast<double*>(dx)));
   t = alfi_prof_begin(ctx, ALFI_EV_MATMULT);
   ALFI_CHECK(launch_bsr_spmv(ctx, L->A_own, dx, dy, db, 1.0, mode));
   alfi_prof_end(ctx, t);
@@ -671,8 +688,11 @@ int alfi_residual(alfi_level* L, const double* db, const double* dx, double* dr)
 
 // PCApply_PATCH on a (possibly partitioned) level: ghost values in, local patch solves, ghost contributions back to
 // their owners, Dirichlet dofs copied
-static int level_patch_apply(alfi_level* L, const double* dx, double* dy) {
+// ghosts_current (smoother only): with a sum-exchange plan the one exchange after the local solves leaves the total on the
+// ghost copies too; *ghosts_current tells the caller that the product A y needs no forward exchange
+static int level_patch_apply(alfi_level* L, const double* dx, double* dy, bool* ghosts_current = nullptr) {
   alfi_ctx* ctx = L->ctx;
+  if (ghosts_current) *ghosts_current = false;
   if (L->mult) {
     // multiplicative sweep (PCApply_PATCH, local_type multiplicative [3P]): y = 0, then wavefront by wavefront in
     // iteration order and, with symmetrise_sweep, back again in reverse order
@@ -714,7 +734,14 @@ static int level_patch_apply(alfi_level* L, const double* dx, double* dy) {
   }
   if (L->distributed) ALFI_CHECK(halo_fwd(L, const_cast<double*>(dx)));
   ALFI_CHECK(launch_patch_apply(L, dx, dy));    // includes y[bc] = x[bc] (no patch holds a Dirichlet dof, so the
-  if (L->distributed) ALFI_CHECK(halo_rev(L, dy));  // reverse-add brings nothing to those entries)
+                                                // exchange brings nothing to those entries)
+  static const bool allow_sum = !(getenv("ALFI_DIST_SUM_EXCHANGE") && atoi(getenv("ALFI_DIST_SUM_EXCHANGE")) == 0);
+  if (L->distributed && ghosts_current && L->sum_ready && allow_sum && !L->pou) {
+    ALFI_CHECK(halo_sum(L, dy));
+    *ghosts_current = true;
+  } else if (L->distributed) {
+    ALFI_CHECK(halo_rev(L, dy));
+  }
   return 0;
 }
 
@@ -1268,8 +1295,9 @@ int alfi_smooth_fgmres(alfi_level* L, int k, const double* db, double* dx, int n
   ALFI_CHECK(launch_scale_by_inv(ctx, V, w, hs + hl.beta, n));
   alfi_prof_end(ctx, t);
   for (int j = 0; j < k; ++j) {
-    ALFI_CHECK(level_patch_apply(L, V + (int64_t)j * ldv, Z + (int64_t)j * ldv));   // z_j = M^-1 v_j
-    ALFI_CHECK(alfi_spmv(L, Z + (int64_t)j * ldv, w));                               // w = A z_j
+    bool zghosts = false;
+    ALFI_CHECK(level_patch_apply(L, V + (int64_t)j * ldv, Z + (int64_t)j * ldv, &zghosts));   // z_j = M^-1 v_j
+    ALFI_CHECK(level_spmv(L, Z + (int64_t)j * ldv, w, nullptr, 0, zghosts));                 // w = A z_j
     t = alfi_prof_begin(ctx, ALFI_EV_BLAS1);
     // h = V^T w (classical GS); fused: the partials stay in red_partial and the projection kernel sums them
     ALFI_CHECK(launch_multi_dot(ctx, V, ldv, j + 1, w, fused ? nullptr : hdots, n));

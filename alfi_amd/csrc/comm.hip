@@ -12,6 +12,7 @@
 // librccl is resolved at run time (dlopen): the library itself has no link-time dependency on it and loads on hosts
 // without RCCL; whichever copy the process already holds (PyTorch ships one with the same SONAME) is reused.
 #include <dlfcn.h>
+#include <algorithm>
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
@@ -126,21 +127,23 @@ int native_exchange(alfi_level* L, int dir, bool async) {
     ALFI_HIP_CHECK(ctx, hipStreamWaitEvent(N->side, N->ev_ready, 0));
     s = N->side;
   }
-  const size_t nn = L->nbr_rank.size();
+  const std::vector<int>& nbr = dir == 2 ? L->sum_rank : L->nbr_rank;
+  const size_t nn = nbr.size();
   if (nn > 0) {
-    // forward: my send-buffer segments go out, my receive-buffer segments come in; reverse: the other way round
-    const double* out = dir == 0 ? L->halo_sendbuf : L->halo_recvbuf;
-    double* in = dir == 0 ? L->halo_recvbuf : L->halo_sendbuf;
-    const std::vector<int64_t>& ooff = dir == 0 ? L->nbr_send_off : L->nbr_recv_off;
-    const std::vector<int64_t>& ocnt = dir == 0 ? L->nbr_send_cnt : L->nbr_recv_cnt;
-    const std::vector<int64_t>& ioff = dir == 0 ? L->nbr_recv_off : L->nbr_send_off;
-    const std::vector<int64_t>& icnt = dir == 0 ? L->nbr_recv_cnt : L->nbr_send_cnt;
+    // forward: my send-buffer segments go out, my receive-buffer segments come in; reverse: the other way round; sum
+    // exchange (dir 2): its own buffers, the same segment layout both ways
+    const double* out = dir == 2 ? L->sum_sendbuf : dir == 0 ? L->halo_sendbuf : L->halo_recvbuf;
+    double* in = dir == 2 ? L->sum_recvbuf : dir == 0 ? L->halo_recvbuf : L->halo_sendbuf;
+    const std::vector<int64_t>& ooff = dir == 2 ? L->sum_off : dir == 0 ? L->nbr_send_off : L->nbr_recv_off;
+    const std::vector<int64_t>& ocnt = dir == 2 ? L->sum_cnt : dir == 0 ? L->nbr_send_cnt : L->nbr_recv_cnt;
+    const std::vector<int64_t>& ioff = dir == 2 ? L->sum_off : dir == 0 ? L->nbr_recv_off : L->nbr_send_off;
+    const std::vector<int64_t>& icnt = dir == 2 ? L->sum_cnt : dir == 0 ? L->nbr_recv_cnt : L->nbr_send_cnt;
     ALFI_NCCL_CHECK(ctx, api, api->GroupStart());
     for (size_t i = 0; i < nn; ++i) {
       if (ocnt[i] > 0)
-        ALFI_NCCL_CHECK(ctx, api, api->Send(out + ooff[i], (size_t)ocnt[i], ncclDouble, L->nbr_rank[i], N->comm, s));
+        ALFI_NCCL_CHECK(ctx, api, api->Send(out + ooff[i], (size_t)ocnt[i], ncclDouble, nbr[i], N->comm, s));
       if (icnt[i] > 0)
-        ALFI_NCCL_CHECK(ctx, api, api->Recv(in + ioff[i], (size_t)icnt[i], ncclDouble, L->nbr_rank[i], N->comm, s));
+        ALFI_NCCL_CHECK(ctx, api, api->Recv(in + ioff[i], (size_t)icnt[i], ncclDouble, nbr[i], N->comm, s));
     }
     ALFI_NCCL_CHECK(ctx, api, api->GroupEnd());
   }
@@ -245,6 +248,66 @@ int alfi_level_set_neighbours(alfi_level* L, int nnbr, const int32_t* ranks, con
   L->nbr_send_cnt = scnt;
   L->nbr_recv_off = roff;
   L->nbr_recv_cnt = rcnt;
+  return 0;
+}
+
+int alfi_level_set_sum_exchange(alfi_level* L, int nnbr, const int32_t* ranks, const int64_t* counts,
+                                const int32_t* send_nodes, int64_t nshared, const int32_t* sum_nodes, const int32_t* sum_ptr,
+                                const int32_t* sum_src) {
+  alfi_ctx* ctx = L->ctx;
+  if (!L->has_halo) return alfi_set_error(ctx, ALFI_E_STATE, "alfi_level_set_sum_exchange before alfi_level_set_partition");
+  if (!ctx->nat) return alfi_set_error(ctx, ALFI_E_STATE, "the sum exchange needs the native transport (alfi_ctx_comm_init)");
+  if (nnbr < 0 || nshared < 0 || (nnbr > 0 && (!ranks || !counts || !send_nodes)) || (nshared > 0 && (!sum_nodes || !sum_ptr || !sum_src)))
+    return alfi_set_error(ctx, ALFI_E_ARG, "NULL sum-exchange arrays");
+  const int me = ctx->nat->rank, world = ctx->nat->nranks;
+  const int64_t nloc = L->n / L->bs;
+  std::vector<int> nr;
+  std::vector<int64_t> off, cnt;
+  int64_t total = 0;
+  for (int i = 0; i < nnbr; ++i) {
+    if (ranks[i] < 0 || ranks[i] >= world || ranks[i] == me || (i > 0 && ranks[i] <= ranks[i - 1]))
+      return alfi_set_error(ctx, ALFI_E_ARG, "neighbour ranks must be ascending, distinct from this rank and inside the group");
+    if (counts[i] <= 0) return alfi_set_error(ctx, ALFI_E_ARG, "a sum-exchange neighbour shares no node");
+    nr.push_back(ranks[i]);
+    off.push_back(total * L->bs);
+    cnt.push_back(counts[i] * L->bs);
+    total += counts[i];
+  }
+  for (int64_t i = 0; i < total; ++i)
+    if (send_nodes[i] < 0 || send_nodes[i] >= nloc) return alfi_set_error(ctx, ALFI_E_ARG, "sum exchange: send node out of range");
+  for (int64_t u = 0; u < nshared; ++u) {
+    if (sum_nodes[u] < 0 || sum_nodes[u] >= nloc || sum_ptr[u + 1] <= sum_ptr[u])
+      return alfi_set_error(ctx, ALFI_E_ARG, "sum exchange: shared node %lld malformed", (long long)u);
+    int own = 0;
+    for (int32_t q = sum_ptr[u]; q < sum_ptr[u + 1]; ++q) {
+      if (sum_src[q] >= total) return alfi_set_error(ctx, ALFI_E_ARG, "sum exchange: source beyond the receive buffer");
+      own += sum_src[q] < 0;
+    }
+    if (own != 1) return alfi_set_error(ctx, ALFI_E_ARG, "sum exchange: every shared node sums exactly one own value");
+  }
+  ALFI_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  ALFI_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  for (void* p : {(void*)L->sum_send_nodes, (void*)L->sum_nodes, (void*)L->sum_ptr, (void*)L->sum_src, (void*)L->sum_sendbuf,
+                  (void*)L->sum_recvbuf})
+    if (p) (void)hipFree(p);
+  L->sum_send_nodes = L->sum_nodes = L->sum_ptr = L->sum_src = nullptr;
+  L->sum_sendbuf = L->sum_recvbuf = nullptr;
+  L->sum_ready = false;
+  auto up = [&](int32_t** d, const int32_t* h, int64_t n) {
+    if (hipMalloc((void**)d, (size_t)std::max<int64_t>(n, 1) * 4) != hipSuccess) return false;
+    return n == 0 || hipMemcpy(*d, h, (size_t)n * 4, hipMemcpyHostToDevice) == hipSuccess;
+  };
+  bool ok = up(&L->sum_send_nodes, send_nodes, total) && up(&L->sum_nodes, sum_nodes, nshared) &&
+            up(&L->sum_ptr, sum_ptr, nshared + 1) && up(&L->sum_src, sum_src, nshared > 0 ? sum_ptr[nshared] : 0);
+  ok = ok && hipMalloc((void**)&L->sum_sendbuf, (size_t)std::max<int64_t>(total * L->bs, 1) * 8) == hipSuccess;
+  ok = ok && hipMalloc((void**)&L->sum_recvbuf, (size_t)std::max<int64_t>(total * L->bs, 1) * 8) == hipSuccess;
+  if (!ok) return alfi_set_error(ctx, ALFI_E_HIP, "sum-exchange buffers: %s", hipGetErrorString(hipGetLastError()));
+  L->sum_rank = nr;
+  L->sum_off = off;
+  L->sum_cnt = cnt;
+  L->sum_nsend = total;
+  L->sum_nshared = nshared;
+  L->sum_ready = true;
   return 0;
 }
 

@@ -194,6 +194,14 @@ struct alfi_level {
   std::vector<int> nbr_rank;
   std::vector<int64_t> nbr_send_off, nbr_send_cnt, nbr_recv_off, nbr_recv_cnt;
   int64_t rev_nuniq = 0;                    // reverse-add: unique owned nodes receiving contributions
+  // merged reverse-add + forward exchange (alfi_level_set_sum_exchange; native transport only): every holder of a shared
+  // node sends its partial value to every other holder, all add in ascending rank order
+  bool sum_ready = false;
+  std::vector<int> sum_rank;
+  std::vector<int64_t> sum_off, sum_cnt;    // doubles, per neighbour (same layout for send and receive)
+  int32_t *sum_send_nodes = nullptr, *sum_nodes = nullptr, *sum_ptr = nullptr, *sum_src = nullptr;
+  int64_t sum_nsend = 0, sum_nshared = 0;   // nodes
+  double *sum_sendbuf = nullptr, *sum_recvbuf = nullptr;
   int32_t *rev_nodes = nullptr, *rev_ptr = nullptr, *rev_pos = nullptr;
   int32_t* bc_dofs = nullptr;
   int64_t nbc = 0;
@@ -385,6 +393,8 @@ int launch_remove_mean(alfi_ctx* ctx, double* x, int64_t n);
 int launch_xmy(alfi_ctx* ctx, double* w, const double* b, int64_t n);                                   // w = b - w                                            // x -= mean(x)
 // halo helpers
 int launch_halo_pack(alfi_ctx* ctx, double* buf, const double* v, const int32_t* nodes, int64_t nnodes, int bs);
+int launch_halo_sum(alfi_ctx* ctx, double* v, const double* buf, const int32_t* nodes, const int32_t* ptr, const int32_t* src,
+                    int64_t nshared, int bs);   // v[node] = sum over its sources (src < 0: v[node] itself), fixed order
 int launch_halo_add(alfi_ctx* ctx, double* v, const double* buf, const int32_t* rev_nodes, const int32_t* rev_ptr,
                     const int32_t* rev_pos, int64_t nuniq, int bs);
 int launch_scale_by_inv(alfi_ctx* ctx, double* v, const double* w, const double* scal, int64_t n);  // v = w / *scal

@@ -838,6 +838,23 @@ __global__ void halo_add_kernel(double* __restrict__ v, const double* __restrict
     v[at] = s;
   }
 }
+__global__ void halo_sum_kernel(double* __restrict__ v, const double* __restrict__ buf, const int32_t* __restrict__ nodes,
+                                const int32_t* __restrict__ ptr, const int32_t* __restrict__ src, int64_t total, int bs) {
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t u = e / bs;
+    const int c = (int)(e - u * bs);
+    const int64_t at = (int64_t)nodes[u] * bs + c;
+    const double own = v[at];
+    double s = 0.0;
+    for (int32_t q = ptr[u]; q < ptr[u + 1]; ++q) s += src[q] < 0 ? own : buf[(int64_t)src[q] * bs + c];
+    v[at] = s;
+  }
+}
+int launch_halo_sum(alfi_ctx* ctx, double* v, const double* buf, const int32_t* nodes, const int32_t* ptr, const int32_t* src,
+                    int64_t nshared, int bs) {
+  ALFI_LAUNCH_EW(halo_sum_kernel, nshared * bs, v, buf, nodes, ptr, src, nshared * bs, bs);
+  return 0;
+}
 int launch_halo_pack(alfi_ctx* ctx, double* buf, const double* v, const int32_t* nodes, int64_t nnodes, int bs) {
   ALFI_LAUNCH_EW(halo_pack_kernel, nnodes * bs, buf, v, nodes, nnodes * bs, bs);
   return 0;

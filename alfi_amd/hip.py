@@ -152,6 +152,18 @@ class Level(object):
                                                              _ptr(sn), sp_, rp_, int(nb_ghost)))
         self.n_own = int(nb_owned) * self.bs
 
+    def set_sum_exchange(self, ranks, counts, send_nodes, sum_nodes, sum_ptr, sum_src):
+        """Plan of the merged reverse-add + forward exchange of the smoother (alfi_level_set_sum_exchange, native transport)."""
+        ranks = np.ascontiguousarray(ranks, dtype=np.int32)
+        counts = np.ascontiguousarray(counts, dtype=np.int64)
+        send_nodes = np.ascontiguousarray(send_nodes, dtype=np.int32)
+        sum_nodes = np.ascontiguousarray(sum_nodes, dtype=np.int32)
+        sum_ptr = np.ascontiguousarray(sum_ptr, dtype=np.int32)
+        sum_src = np.ascontiguousarray(sum_src, dtype=np.int32)
+        assert send_nodes.shape[0] == counts.sum() and sum_ptr.shape[0] == sum_nodes.shape[0] + 1
+        self.ctx.check(self.ctx.lib.alfi_level_set_sum_exchange(self.h, len(ranks), _ptr(ranks), _ptr(counts), _ptr(send_nodes),
+                                                                len(sum_nodes), _ptr(sum_nodes), _ptr(sum_ptr), _ptr(sum_src)))
+
     def set_neighbours(self, ranks, send_nodes, recv_nodes):
         """Native transport: neighbour ranks (ascending) and the nodes sent to / received from each."""
         r = np.ascontiguousarray(ranks, dtype=np.int32)

@@ -103,7 +103,8 @@ int alfi_ctx_comm_destroy(alfi_ctx* ctx);                                       
  *   ALFI_COMM_HALO_REV_BEGIN / _END: the same for the reverse route.
  * Every rank of the group reaches every call (the exchanges are collective). */
 enum { ALFI_COMM_ALLREDUCE = 0, ALFI_COMM_HALO_FWD = 1, ALFI_COMM_HALO_REV = 2, ALFI_COMM_HALO_FWD_BEGIN = 3,
-       ALFI_COMM_HALO_FWD_END = 4, ALFI_COMM_HALO_REV_BEGIN = 5, ALFI_COMM_HALO_REV_END = 6 };
+       ALFI_COMM_HALO_FWD_END = 4, ALFI_COMM_HALO_REV_BEGIN = 5, ALFI_COMM_HALO_REV_END = 6,
+       ALFI_COMM_HALO_SUM = 7 /* native transport only: never handed to a callback */ };
 typedef int (*alfi_comm_fn)(void* user, int op, int level_id, int64_t offset, int64_t count);
 /* dred: device buffer of dred_len >= 64 doubles owned by the caller (reduction scratch the callback all-reduces). */
 int alfi_ctx_set_comm(alfi_ctx* ctx, alfi_comm_fn fn, void* user, double* dred, int64_t dred_len);
@@ -129,6 +130,18 @@ int alfi_level_set_partition(alfi_level* lvl, int64_t nb_owned, int distributed,
  * neighbour on a level passes nnbr = 0. */
 int alfi_level_set_neighbours(alfi_level* lvl, int nnbr, const int32_t* ranks_host, const int64_t* send_nodes_host,
                               const int64_t* recv_nodes_host);
+/* Native transport: plan of the merged reverse-add + forward exchange of the smoother ("sum exchange").  A node held by
+ * several ranks (its owner and the ranks keeping a ghost copy) gets the SUM of the holders' values on every holder in ONE
+ * exchange: each rank sends its value of every shared node to every other holder; all add the contributions in the same
+ * (ascending rank) order, so owner and copies agree bitwise.  The smoother then applies z = M^-1 v with one exchange
+ * after the local patch solves and the following product A z needs no forward exchange: 2 halo exchanges per FGMRES
+ * iteration instead of 3.  ranks_host: ascending neighbour ranks; counts_host[i]: shared nodes with neighbour i (the same
+ * number goes out and comes in); send_nodes_host: local node of every outgoing entry, neighbour by neighbour; the nshared
+ * shared local nodes sum_nodes_host with CSR sum_ptr_host / sum_src_host: position of each contribution in the receive
+ * buffer (neighbour segments in the order of ranks_host), -1 = this rank's own value. */
+int alfi_level_set_sum_exchange(alfi_level* lvl, int nnbr, const int32_t* ranks_host, const int64_t* counts_host,
+                                const int32_t* send_nodes_host, int64_t nshared, const int32_t* sum_nodes_host,
+                                const int32_t* sum_ptr_host, const int32_t* sum_src_host);
 /* Communication / computation overlap on a distributed level (after alfi_level_set_partition and alfi_patches_set): the
  * caller numbered the owned nodes so that the first nb_interior have operator rows without ghost columns, and ordered the
  * patches so that the first npatch_interior hold no ghost dof.  SpMV and patch apply then run those parts between

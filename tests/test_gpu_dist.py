@@ -266,6 +266,15 @@ def test_bench_multi_rank_with_the_native_transport():
     assert out.returncode == 0 and d is not None, out.stderr[-3000:]
     assert d["n_gpus"] == 4 and d["n_ranks_seen"] == 4 and d["config"]["transport"] == "rccl"
     assert d["rel_residual_after_timed_cycles"] < 0.5
+    # the merged reverse-add + forward exchange of the smoother (alfi_level_set_sum_exchange): same result, a third fewer
+    # halo exchanges than the three-per-iteration sequence
+    out0, d0 = _bench(["--gpus", "4", "--config", "tiny", "--steps", "2", "--warmup", "1"],
+                      {"ALFI_DIST_BACKEND": "gloo", "ALFI_DIST_MIN_DOFS": "500", "ALFI_DIST_TRANSPORT": "rccl",
+                       "ALFI_RCCL_LIB": build(), "ALFI_DIST_SUM_EXCHANGE": "0"})
+    assert out0.returncode == 0 and d0 is not None, out0.stderr[-3000:]
+    h1, h0 = d["per_rank"]["halo_exchanges_per_cycle"][0], d0["per_rank"]["halo_exchanges_per_cycle"][0]
+    assert h1 < 0.8 * h0, (h1, h0)
+    assert abs(d["rel_residual_after_timed_cycles"] - d0["rel_residual_after_timed_cycles"]) < 1e-6 * d0["rel_residual_after_timed_cycles"]
 
 
 def test_bench_launcher_fails_loudly_when_a_rank_cannot_start():
