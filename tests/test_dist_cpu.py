@@ -227,3 +227,44 @@ def test_neighbour_tables_of_the_native_transport_are_consistent(case, world):
                 seg = pa.own_nodes[send_all[send_off[b]:send_off[b + 1]]]
                 roff = np.concatenate([[0], np.cumsum(pb.recv_counts)])
                 assert np.array_equal(seg, pb.ghosts[roff[a]:roff[a + 1]])
+
+
+@pytest.mark.parametrize("case,world", [("3d-P2FB", 4), ("2d-all-distributed", 3)])
+def test_sum_exchange_plan(case, world):
+    """The plan of the merged reverse-add + forward exchange (LevelPart.set_sum_plan -> alfi_level_set_sum_exchange),
+    emulated with NumPy: after ONE exchange among the holders of every shared node, owner and ghost copies all carry the
+    sum of the holders' partial values; the neighbour segments of two ranks mirror each other."""
+    from alfi_amd.dist import choose_splits, build_parts
+    lv, tr, k, _ = _hier(case)
+    splits = choose_splits(lv, world, 1)
+    parts = [build_parts(lv, tr, splits, r, None) for r in range(world)]
+    l = len(lv) - 1
+    nb = lv[l].A.nbrows
+    rng = np.random.default_rng(0)
+    vals = [rng.standard_normal(parts[r][l].nb_loc) for r in range(world)]
+    total = np.zeros(nb)
+    for r in range(world):
+        np.add.at(total, parts[r][l].nodes, vals[r])
+    for r in range(world):
+        P = parts[r][l]
+        bufs = []
+        for q, c in zip(P.sum_ranks, P.sum_counts):
+            Q = parts[q][l]
+            i = list(Q.sum_ranks).index(r)
+            o = int(Q.sum_counts[:i].sum())
+            assert int(Q.sum_counts[i]) == int(c)
+            seg = Q.sum_send_nodes[o:o + int(c)]
+            mine = P.sum_send_nodes[int(P.sum_counts[:list(P.sum_ranks).index(q)].sum()):][:int(c)]
+            assert np.array_equal(Q.nodes[seg], P.nodes[mine])          # the same global nodes, in the same order
+            bufs.append(vals[q][seg])
+        recv = np.concatenate(bufs) if bufs else np.zeros(0)
+        out = vals[r].copy()
+        for i, n in enumerate(P.sum_nodes):
+            src = P.sum_src[P.sum_ptr[i]:P.sum_ptr[i + 1]]
+            assert np.count_nonzero(src < 0) == 1
+            out[n] = sum(vals[r][n] if s < 0 else recv[s] for s in src)
+        shared = np.zeros(P.nb_loc, dtype=bool)
+        shared[P.sum_nodes] = True
+        assert shared[P.nb_own:].all()                                   # every ghost copy takes part
+        assert np.abs(out[shared] - total[P.nodes][shared]).max() < 1e-12
+        assert np.array_equal(out[~shared], vals[r][~shared])
