@@ -1253,8 +1253,11 @@ int alfi_smooth_fgmres(alfi_level* L, int k, const double* db, double* dx, int n
     // segmented product of the general path is the faster kernel -- cfg3 19.0 vs 18.9 ms, cfg2 5.10 vs 5.43 ms, same box --
     // and with the bimodal rows of [P1+FB]^3 (12 blocks on the face nodes, 75 on the vertices, 17 on average) the
     // lanes-per-row product of the fused iteration idles most of its lanes: config 6 188.8 ms fused, 175.0 ms general)
+    // ... except on levels of <= 50 000 dofs, which are bound by the number of dependent launches whatever the rows look
+    // like: config 3 18.66 -> 18.12-18.23 ms with its two smallest smoothed levels on the fused iteration (same box)
+    static const int64_t small_n = getenv("ALFI_FUSED_SMALL_N") ? atoll(getenv("ALFI_FUSED_SMALL_N")) : 50000;
     if (allow && !L->distributed && L->n_own == L->n && !L->mult && k + 1 <= 16 && L->A_own.flat &&
-        L->max_row_blocks <= 32)
+        (L->max_row_blocks <= 32 || L->n <= small_n))
       return smooth_fgmres_fused(L, k, db, dx, nonzero_guess);
   }
   const int K = L->kmax;
