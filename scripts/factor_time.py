@@ -1,0 +1,19 @@
+"""Patch factorisation time of the finest level of a bench configuration (gather + inversion + residual probe);
+ALFI_FORCE_BIG_FACTOR=1 sends small patches through the blocked MFMA path instead of the register Gauss-Jordan.
+usage: python scripts/factor_time.py cfg4s"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import bench
+from alfi_amd import hip
+lv, tr, k = bench.build_problem(sys.argv[1], False)
+L = lv[-1]
+ctx = hip.Context(0)
+dl = hip.Level(ctx, L.A, L.bc_dofs)
+dl.set_patches(L.patch_ptr, L.patch_dofs)
+dl.factor(); ctx.sync()
+t0 = time.time()
+for _ in range(3):
+    dl.factor()
+ctx.sync()
+print("%s FORCE_BIG=%s: factor %.1f ms per call (%d patches, max %d dofs)" % (sys.argv[1], os.environ.get("ALFI_FORCE_BIG_FACTOR", "0"), (time.time() - t0) / 3 * 1e3, len(L.patch_ptr) - 1, np.diff(L.patch_ptr).max()))
