@@ -111,7 +111,7 @@ SIGNATURES = {
 
 COMM_ID_BYTES = 128      # ALFI_COMM_ID_BYTES
 
-EVENTS = ["PATCH_APPLY", "PATCH_SCATTER", "PATCH_FACTOR", "MATMULT", "BLAS1", "PROLONG", "RESTRICT", "COARSE", "COMM"]
+EVENTS = ["PATCH_APPLY", "PATCH_SCATTER", "PATCH_FACTOR", "MATMULT", "BLAS1", "PROLONG", "RESTRICT", "COARSE", "COMM", "KSP_TINY"]
 
 _lib = None
 

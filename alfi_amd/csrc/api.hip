@@ -131,6 +131,7 @@ static int upload_bsr(alfi_ctx* ctx, DevBSR* d, const alfi_bsr_host* h, int bs) 
     for (int64_t i = 0; i < h->nbrows; ++i) cf[h->rowptr[i]] |= (int32_t)0x80000000;
     ALFI_CHECK(dev_upload(ctx, &d->colidx, cf.data(), d->nnzb));
     ALFI_CHECK(build_chunk_tables(ctx, d, h->rowptr, h->nbrows, -1));
+    ALFI_CHECK(build_spmv_dedup(ctx, d));        // (device-side: sorts every group of SPMV_WG columns in LDS)
     ALFI_CHECK(dev_alloc(ctx, &d->carry, d->nchunks * bs));
     ALFI_CHECK(dev_alloc(ctx, &d->carry_row, d->nchunks));
     const int64_t padded = ((d->nnzb + 63) / 64) * 64 * bs * bs;
@@ -149,6 +150,9 @@ static void free_bsr(DevBSR* d) {
   dev_free(d->chunk_start);
   dev_free(d->carry);
   dev_free(d->carry_row);
+  dev_free(d->lidx);
+  dev_free(d->ucol);
+  dev_free(d->uptr);
   *d = DevBSR();
 }
 
@@ -541,6 +545,7 @@ static int make_row_view(alfi_ctx* ctx, const DevBSR& A, const std::vector<int32
   V->chunk_row = nullptr;
   V->carry = nullptr;
   V->carry_row = nullptr;
+  V->dedup = false;                     // the de-duplication groups are counted from block 0 of the upload
   std::vector<int32_t> chunk_row((size_t)std::max<int64_t>(V->nchunks, 1));
   int64_t row = r0;
   for (int64_t c = 0; c < V->nchunks; ++c) {
@@ -1256,8 +1261,14 @@ int alfi_smooth_fgmres(alfi_level* L, int k, const double* db, double* dx, int n
     // ... except on levels of <= 50 000 dofs, which are bound by the number of dependent launches whatever the rows look
     // like: config 3 18.66 -> 18.12-18.23 ms with its two smallest smoothed levels on the fused iteration (same box)
     static const int64_t small_n = getenv("ALFI_FUSED_SMALL_N") ? atoll(getenv("ALFI_FUSED_SMALL_N")) : 50000;
-    if (allow && !L->distributed && L->n_own == L->n && !L->mult && k + 1 <= 16 && L->A_own.flat &&
-        (L->max_row_blocks <= 32 || L->n <= small_n))
+    const bool fusable = allow && !L->distributed && L->n_own == L->n && !L->mult && k + 1 <= 16 && L->A_own.flat;
+    // tiny levels (operator + dense inverses of a smoother iteration below ALFI_TINY_BYTES, default 3.5 MB): the whole call
+    // as ONE launch of ONE workgroup (kernels_tiny.hip) -- ~30 dependent launches of 5-8 us become one kernel whose phases
+    // are separated by __syncthreads() only
+    static const int64_t tiny_bytes = getenv("ALFI_TINY_BYTES") ? atoll(getenv("ALFI_TINY_BYTES")) : 3500000;
+    if (fusable && !L->cond && L->max_np <= SMALL_PATCH_MAX && tiny_level_bytes(L) <= tiny_bytes)
+      return launch_smooth_tiny(L, k, db, dx, nonzero_guess);
+    if (fusable && (L->max_row_blocks <= 32 || L->n <= small_n))
       return smooth_fgmres_fused(L, k, db, dx, nonzero_guess);
   }
   const int K = L->kmax;

@@ -26,6 +26,7 @@ struct RcclApi {
   ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
   ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;        // optional
   ncclResult_t (*GroupStart)() = nullptr;
   ncclResult_t (*GroupEnd)() = nullptr;
   ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
@@ -58,7 +59,8 @@ RcclApi* rccl() {
     if (h) break;
   }
   if (!h) {
-    g_api_error = std::string("cannot load librccl: ") + (dlerror() ? dlerror() : "not found");
+    const char* e = dlerror();          // (one call: dlerror() clears the message it returns)
+    g_api_error = std::string("cannot load librccl: ") + (e ? e : "not found");
     return nullptr;
   }
   RcclApi a;
@@ -68,6 +70,7 @@ RcclApi* rccl() {
         resolve(h, "ncclGroupEnd", &a.GroupEnd) && resolve(h, "ncclSend", &a.Send) && resolve(h, "ncclRecv", &a.Recv) &&
         resolve(h, "ncclAllReduce", &a.AllReduce) && resolve(h, "ncclGetErrorString", &a.GetErrorString)))
     return nullptr;
+  a.CommAbort = reinterpret_cast<decltype(a.CommAbort)>(dlsym(h, "ncclCommAbort"));
   g_api = a;
   return &g_api;
 }
@@ -78,6 +81,7 @@ struct NativeComm {
   ncclComm_t comm = nullptr;
   int rank = 0, nranks = 1;
   bool own_dred = false;
+  bool failed = false;             // an exchange failed: the peers may be blocked in their half; abort instead of destroy
   hipStream_t side = nullptr;      // asynchronous exchanges (overlap with interior work) run here
   hipEvent_t ev_ready = nullptr;   // ctx stream -> side stream: buffers packed
   hipEvent_t ev_done = nullptr;    // side stream -> ctx stream: exchange finished
@@ -94,9 +98,12 @@ struct NativeComm {
 void native_destroy(alfi_ctx* ctx) {
   NativeComm* N = ctx->nat;
   if (!N) return;
+  // after a failed exchange the streams may hold an RCCL kernel that waits for a peer: abort the communicator first
+  const bool abort = N->failed && N->comm && g_api.handle && g_api.CommAbort;
+  if (abort) (void)g_api.CommAbort(N->comm);
   (void)hipStreamSynchronize(ctx->stream);
   if (N->side) (void)hipStreamSynchronize(N->side);
-  if (N->comm && g_api.handle) (void)g_api.CommDestroy(N->comm);
+  if (!abort && N->comm && g_api.handle) (void)g_api.CommDestroy(N->comm);
   if (N->ev_ready) (void)hipEventDestroy(N->ev_ready);
   if (N->ev_done) (void)hipEventDestroy(N->ev_done);
   if (N->side) (void)hipStreamDestroy(N->side);
@@ -139,13 +146,20 @@ int native_exchange(alfi_level* L, int dir, bool async) {
     const std::vector<int64_t>& ioff = dir == 2 ? L->sum_off : dir == 0 ? L->nbr_recv_off : L->nbr_send_off;
     const std::vector<int64_t>& icnt = dir == 2 ? L->sum_cnt : dir == 0 ? L->nbr_recv_cnt : L->nbr_send_cnt;
     ALFI_NCCL_CHECK(ctx, api, api->GroupStart());
-    for (size_t i = 0; i < nn; ++i) {
-      if (ocnt[i] > 0)
-        ALFI_NCCL_CHECK(ctx, api, api->Send(out + ooff[i], (size_t)ocnt[i], ncclDouble, nbr[i], N->comm, s));
-      if (icnt[i] > 0)
-        ALFI_NCCL_CHECK(ctx, api, api->Recv(in + ioff[i], (size_t)icnt[i], ncclDouble, nbr[i], N->comm, s));
+    // a failing Send / Recv must not leave the group open on this thread (every later call on the communicator, CommDestroy
+    // included, would be queued behind it): remember the first error, close the group, then report
+    ncclResult_t first = ncclSuccess;
+    for (size_t i = 0; i < nn && first == ncclSuccess; ++i) {
+      if (ocnt[i] > 0) first = api->Send(out + ooff[i], (size_t)ocnt[i], ncclDouble, nbr[i], N->comm, s);
+      if (first == ncclSuccess && icnt[i] > 0)
+        first = api->Recv(in + ioff[i], (size_t)icnt[i], ncclDouble, nbr[i], N->comm, s);
     }
-    ALFI_NCCL_CHECK(ctx, api, api->GroupEnd());
+    const ncclResult_t closed = api->GroupEnd();
+    if (first != ncclSuccess || closed != ncclSuccess) {
+      N->failed = true;
+      return alfi_set_error(ctx, ALFI_E_COMM, "halo exchange with %zu neighbours failed: %s", nn,
+                            api->GetErrorString(first != ncclSuccess ? first : closed));
+    }
   }
   if (async) ALFI_HIP_CHECK(ctx, hipEventRecord(N->ev_done, N->side));
   return 0;

@@ -129,7 +129,16 @@ struct DevBSR {
   // small matrices (nnzb <= SPMV_ALIGNED_MAX): chunks of whole block rows, chunk c = blocks [chunk_start[c], chunk_start[c+1])
   bool aligned = false;
   int64_t* chunk_start = nullptr;   // (nchunks + 1)
+  // large matrices: x columns de-duplicated per workgroup (4 chunks = SPMV_WG blocks; neighbouring block rows share most of
+  // their columns -- config 4: 247 distinct columns among 1024 blocks).  ucol[uptr[g] .. uptr[g+1]) = distinct columns of
+  // group g ascending, lidx[k] = position of block k's column in its group's list (bit 15 = first block of a block row)
+  bool dedup = false;
+  uint16_t* lidx = nullptr;
+  int32_t* ucol = nullptr;
+  int32_t* uptr = nullptr;
 };
+constexpr int SPMV_WG = 4 * SPMV_CHUNK;      // blocks per workgroup of the flat product
+constexpr int SPMV_DEDUP_MAX = 1024;         // distinct columns per group the product stages in LDS (24 KiB at bs = 3)
 constexpr int64_t SPMV_ALIGNED_MAX = (int64_t)1 << 21;   // blocks; beyond, the product is bandwidth-bound and equal-sized
                                                           // chunks (+ the fix-up launch) keep every lane busy
 __host__ __device__ inline int64_t bsr_val_index(int flat, int64_t k, int rc, int bb) {
@@ -333,6 +342,7 @@ struct alfi_saddle {
 int launch_bsr_spmv(alfi_ctx* ctx, const DevBSR& A, const double* x, double* y, const double* b, double alpha, int mode);
 // host (nnzb, bs, bs) values -> d->vals in d's layout (staged through a bounded device buffer)
 int upload_bsr_values(alfi_ctx* ctx, DevBSR* d, const double* host_vals);
+int build_spmv_dedup(alfi_ctx* ctx, DevBSR* d);     // column de-duplication tables of the flat product (kernels_vec.hip)
 int launch_patch_gather_dense(alfi_level* lvl);
 int launch_patch_invert(alfi_level* lvl);
 // kernels_check.hip: probe || A_p X_p e - e || of every stored inverse, pivoted re-inversion of the patches that fail
@@ -411,5 +421,8 @@ int launch_patch_sum_scale(alfi_level* lvl, const double* w, double* z, double* 
 // w = A z with the partials of V_v . w (v < nv <= 16) in the same pass; *nblocks = number of partials per vector
 int launch_bsr_spmv_dot(alfi_ctx* ctx, const DevBSR& A, const double* z, double* w, const double* V, int64_t stride, int nv,
                         double* partial, int* nblocks);
+// one-workgroup FGMRES(k) + patch smoother of a tiny level (kernels_tiny.hip)
+int64_t tiny_level_bytes(const alfi_level* lvl);
+int launch_smooth_tiny(alfi_level* lvl, int k, const double* db, double* dx, int nonzero_guess);
 int launch_fgmres_finish_fused(alfi_ctx* ctx, const double* normpart, int nblocks, const double* h, double* hs, int k, int K);
 int launch_update_solution(alfi_ctx* ctx, double* x, const double* Z, int64_t stride, int k, const double* y, int64_t n);

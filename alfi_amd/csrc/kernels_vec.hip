@@ -200,6 +200,251 @@ __global__ __launch_bounds__(256) void bsr_spmv_fixup_kernel(int64_t nchunks, co
   for (int r = 0; r < BS; ++r) y[(int64_t)R * BS + r] += mode == 0 ? s[r] : -alpha * s[r];
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The same product with the x gathers de-duplicated per workgroup (DevBSR::dedup).  A workgroup owns SPMV_WG = 1024
+// consecutive blocks (4 waves x 256); neighbouring block rows of the Morton-numbered operators share most of their columns
+// (config 4: 247 distinct columns among 1024 blocks), so the workgroup first stages the distinct x entries of its group in
+// LDS -- one 8 bs-byte gather per DISTINCT column instead of one per block: a quarter of the scattered requests -- and the
+// waves then take x from LDS through a 2-byte local index (bit 15 = first block of a block row; 2 + ~1 bytes of index
+// stream per block instead of 4).  Everything else (lane-major value planes, segmented scan, carries, fix-up) as above.
+// ---------------------------------------------------------------------------------------------------------------------
+template <int BS>
+__global__ __launch_bounds__(256) void bsr_spmv_dedup_kernel(int64_t nnzb, int64_t nchunks,
+                                                              const uint16_t* __restrict__ lidx,
+                                                              const int32_t* __restrict__ ucol,
+                                                              const int32_t* __restrict__ uptr,
+                                                              const int32_t* __restrict__ colflag,
+                                                              const double* __restrict__ vals,
+                                                              const int32_t* __restrict__ chunk_row,
+                                                              const double* __restrict__ x, double* __restrict__ y,
+                                                              const double* __restrict__ b, double alpha, int mode,
+                                                              double* __restrict__ carry_out,
+                                                              int32_t* __restrict__ carry_row) {
+  constexpr int BB = BS * BS;
+  __shared__ double xs[SPMV_DEDUP_MAX * BS];
+  const int lane = threadIdx.x & 63;
+  const int64_t g = blockIdx.x;
+  const int64_t chunk = g * 4 + (threadIdx.x >> 6);
+  const bool active = chunk < nchunks;
+  const int64_t base = chunk * SPMV_CHUNK;
+  // value planes of the first iteration are requested before the staging barrier (independent of x)
+  const int32_t u0 = uptr[g], nu = uptr[g + 1] - u0;
+  for (int i = threadIdx.x; i < nu; i += 256) {
+    const int64_t c = __builtin_nontemporal_load(ucol + u0 + i);
+#pragma unroll
+    for (int q = 0; q < BS; ++q) xs[i * BS + q] = x[c * BS + q];
+  }
+  __syncthreads();
+  if (!active) return;
+  int R = chunk_row[chunk];
+  int Rlast = R;
+  double carry[BS];
+#pragma unroll
+  for (int r = 0; r < BS; ++r) carry[r] = 0.0;
+  auto store_row = [&](int row, const double* s) {
+#pragma unroll
+    for (int r = 0; r < BS; ++r) {
+      const int64_t i = (int64_t)row * BS + r;
+      y[i] = mode == 0 ? s[r] : b[i] - alpha * s[r];
+    }
+  };
+#pragma unroll
+  for (int u = 0; u < SPMV_U; ++u) {
+    const int64_t k = base + u * 64 + lane;
+    const bool valid = k < nnzb;
+    const uint16_t li = valid ? __builtin_nontemporal_load(lidx + k) : (uint16_t)0;
+    const bool head = (li & 0x8000u) != 0;
+    const int lc = li & 0x7fff;
+    double p[BS];
+#pragma unroll
+    for (int r = 0; r < BS; ++r) p[r] = 0.0;
+    if (valid) {
+      const double* v = vals + (k >> 6) * (64 * BB);
+      double a[BB], xv[BS];
+#pragma unroll
+      for (int q = 0; q < BB / 2; ++q) {
+        const spmv_d2 t = __builtin_nontemporal_load(reinterpret_cast<const spmv_d2*>(v + q * 128) + lane);
+        a[2 * q] = t.x;
+        a[2 * q + 1] = t.y;
+      }
+      if (BB & 1) a[BB - 1] = __builtin_nontemporal_load(v + (BB / 2) * 128 + lane);
+#pragma unroll
+      for (int c = 0; c < BS; ++c) xv[c] = xs[lc * BS + c];
+#pragma unroll
+      for (int r = 0; r < BS; ++r)
+#pragma unroll
+        for (int c = 0; c < BS; ++c) p[r] = __builtin_fma(a[r * BS + c], xv[c], p[r]);
+    }
+    const unsigned long long hm = __ballot(head);
+    if (u > 0) {
+      if ((hm & 1ull) && lane == 0) store_row(Rlast, carry);
+      R = Rlast + (int)(hm & 1ull);
+    }
+    const int row = R + __popcll(hm & ((2ull << lane) - 2ull));
+    int f = head ? 1 : 0;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      double tp[BS];
+#pragma unroll
+      for (int r = 0; r < BS; ++r) tp[r] = __shfl_up(p[r], d);
+      const int tf = __shfl_up(f, d);
+      if (lane >= d && !f) {
+#pragma unroll
+        for (int r = 0; r < BS; ++r) p[r] += tp[r];
+        f = tf;
+      }
+    }
+    if (!f) {
+#pragma unroll
+      for (int r = 0; r < BS; ++r) p[r] += carry[r];
+    }
+    if (lane < 63 && ((hm >> (lane + 1)) & 1ull)) store_row(row, p);
+#pragma unroll
+    for (int r = 0; r < BS; ++r) carry[r] = __shfl(p[r], 63);
+    Rlast = __shfl(row, 63);
+  }
+  const int64_t kend = base + SPMV_CHUNK;
+  if (lane == 0) {
+    const bool closed = kend >= nnzb || colflag[kend] < 0;
+    if (closed) {
+      store_row(Rlast, carry);
+      carry_row[chunk] = -1;
+    } else {
+#pragma unroll
+      for (int r = 0; r < BS; ++r) carry_out[chunk * BS + r] = carry[r];
+      carry_row[chunk] = Rlast;
+    }
+  }
+}
+
+// Setup of the de-duplication tables, one workgroup per group of SPMV_WG blocks: bitonic sort of the group's columns in LDS,
+// distinct values flagged and counted, every block's column located by binary search.  Pass 1 leaves the distinct columns
+// of group g at tmp[g * SPMV_WG ..) and their number in nuniq[g]; the host scans nuniq; pass 2 compacts.
+__global__ __launch_bounds__(256) void spmv_dedup_sort_kernel(int64_t nnzb, const int32_t* __restrict__ colflag,
+                                                               uint16_t* __restrict__ lidx, int32_t* __restrict__ tmp,
+                                                               int32_t* __restrict__ nuniq) {
+  static_assert(SPMV_WG == 1024, "the LDS sort below is written for 1024 keys");
+  __shared__ int32_t key[SPMV_WG];
+  __shared__ int32_t uniq[SPMV_WG];
+  __shared__ int32_t cnt;
+  const int64_t k0 = (int64_t)blockIdx.x * SPMV_WG;
+  const int t = threadIdx.x;
+  if (t == 0) cnt = 0;
+  for (int i = t; i < SPMV_WG; i += 256) key[i] = k0 + i < nnzb ? (colflag[k0 + i] & 0x7fffffff) : 0x7fffffff;
+  __syncthreads();
+  for (int size = 2; size <= SPMV_WG; size <<= 1)
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      for (int i = t; i < SPMV_WG / 2; i += 256) {
+        const int lo = 2 * i - (i & (stride - 1));       // element with bit `stride` clear
+        const int hi = lo + stride;
+        const bool up = (lo & size) == 0;
+        const int32_t a = key[lo], c = key[hi];
+        if ((a > c) == up) {
+          key[lo] = c;
+          key[hi] = a;
+        }
+      }
+      __syncthreads();
+    }
+  // distinct values, in order: position = number of distinct values in front (serial prefix per thread chunk of 4 + scan)
+  int flag[4], local = 0;
+  for (int q = 0; q < 4; ++q) {
+    const int i = t * 4 + q;
+    flag[q] = key[i] != 0x7fffffff && (i == 0 || key[i] != key[i - 1]) ? 1 : 0;
+    local += flag[q];
+  }
+  __shared__ int32_t part[256];
+  part[t] = local;
+  __syncthreads();
+  for (int d = 1; d < 256; d <<= 1) {
+    const int v = t >= d ? part[t - d] : 0;
+    __syncthreads();
+    part[t] += v;
+    __syncthreads();
+  }
+  int pos = part[t] - local;
+  for (int q = 0; q < 4; ++q)
+    if (flag[q]) uniq[pos++] = key[t * 4 + q];
+  if (t == 255) cnt = part[255];
+  __syncthreads();
+  const int nu = cnt;
+  for (int i = t; i < nu; i += 256) tmp[k0 + i] = uniq[i];
+  if (t == 0) nuniq[blockIdx.x] = nu;
+  for (int i = t; i < SPMV_WG; i += 256) {
+    const int64_t k = k0 + i;
+    if (k >= nnzb) break;
+    const int32_t cf = colflag[k];
+    const int32_t c = cf & 0x7fffffff;
+    int lo = 0, hi = nu - 1;
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (uniq[mid] < c) lo = mid + 1;
+      else hi = mid;
+    }
+    lidx[k] = (uint16_t)(lo | (cf < 0 ? 0x8000 : 0));
+  }
+}
+
+__global__ __launch_bounds__(256) void spmv_dedup_compact_kernel(const int32_t* __restrict__ tmp,
+                                                                  const int32_t* __restrict__ uptr,
+                                                                  int32_t* __restrict__ ucol) {
+  const int64_t g = blockIdx.x;
+  const int32_t u0 = uptr[g], nu = uptr[g + 1] - u0;
+  for (int i = threadIdx.x; i < nu; i += 256) ucol[u0 + i] = tmp[g * SPMV_WG + i];
+}
+
+int build_spmv_dedup(alfi_ctx* ctx, DevBSR* d) {
+  d->dedup = false;
+  static const bool allow = !(getenv("ALFI_SPMV_DEDUP") && atoi(getenv("ALFI_SPMV_DEDUP")) == 0);
+  if (!allow || !d->flat || d->aligned || d->nnzb < SPMV_WG) return 0;
+  const int64_t nnzb = d->nnzb, ng = (nnzb + SPMV_WG - 1) / SPMV_WG;
+  int32_t *tmp = nullptr, *nuniq = nullptr;
+  ALFI_HIP_CHECK(ctx, hipMalloc((void**)&d->lidx, (size_t)nnzb * sizeof(uint16_t)));
+  hipError_t e = hipMalloc((void**)&tmp, (size_t)ng * SPMV_WG * sizeof(int32_t));
+  if (e == hipSuccess) e = hipMalloc((void**)&nuniq, (size_t)ng * sizeof(int32_t));
+  if (e == hipSuccess) e = hipMalloc((void**)&d->uptr, (size_t)(ng + 1) * sizeof(int32_t));
+  std::vector<int32_t> uptr((size_t)ng + 1, 0);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(spmv_dedup_sort_kernel, dim3((unsigned)ng), dim3(256), 0, ctx->stream, nnzb, d->colidx, d->lidx, tmp,
+                       nuniq);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipMemcpyAsync(uptr.data() + 1, nuniq, (size_t)ng * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  bool fits = e == hipSuccess;
+  if (fits) {
+    int64_t tot = 0;
+    for (int64_t g = 0; g < ng; ++g) {
+      tot += uptr[g + 1];
+      fits = fits && tot <= INT32_MAX;
+      uptr[g + 1] = (int32_t)tot;
+    }
+  }
+  if (fits) {
+    e = hipMalloc((void**)&d->ucol, (size_t)std::max<int64_t>(uptr[ng], 1) * sizeof(int32_t));
+    if (e == hipSuccess) e = hipMemcpyAsync(d->uptr, uptr.data(), (size_t)(ng + 1) * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) {
+      hipLaunchKernelGGL(spmv_dedup_compact_kernel, dim3((unsigned)ng), dim3(256), 0, ctx->stream, tmp, d->uptr, d->ucol);
+      e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  }
+  (void)hipFree(tmp);
+  (void)hipFree(nuniq);
+  if (e != hipSuccess || !fits) {
+    (void)hipFree(d->lidx);
+    (void)hipFree(d->ucol);
+    (void)hipFree(d->uptr);
+    d->lidx = nullptr;
+    d->ucol = nullptr;
+    d->uptr = nullptr;
+    if (e != hipSuccess) return alfi_set_error(ctx, ALFI_E_HIP, "SpMV de-duplication tables: %s", hipGetErrorString(e));
+    return 0;
+  }
+  d->dedup = true;
+  return 0;
+}
+
 // host-layout values of blocks [k0, k0 + nblk) -> lane-major
 __global__ void bsr_vals_to_lanes_kernel(const double* __restrict__ src, double* __restrict__ dst, int64_t k0,
                                          int64_t total, int bb) {
@@ -265,7 +510,11 @@ static int launch_bsr_spmv_bs(alfi_ctx* ctx, const DevBSR& A, const double* x, d
       return 0;
     }
     const int64_t nchunks = (A.nnzb + SPMV_CHUNK - 1) / SPMV_CHUNK;   // A may be a block-row-range view of the upload
-    if (nt)
+    if (A.dedup && !A.view && A.kbase == 0)
+      hipLaunchKernelGGL((bsr_spmv_dedup_kernel<BS>), dim3((unsigned)((nchunks + 3) / 4)), dim3(256), 0, ctx->stream,
+                         A.nnzb, nchunks, A.lidx, A.ucol, A.uptr, A.colidx, A.vals, A.chunk_row, x, y, b, alpha, mode,
+                         A.carry, A.carry_row);
+    else if (nt)
       hipLaunchKernelGGL((bsr_spmv_flat_kernel<BS, true, false>), dim3((unsigned)((nchunks + 3) / 4)), dim3(256), 0,
                          ctx->stream, A.kbase, A.nnzb, nchunks, (const int64_t*)nullptr, A.colidx, A.vals, A.chunk_row, x,
                          y, b, alpha, mode, A.carry, A.carry_row, xcd);
@@ -532,45 +781,7 @@ __global__ __launch_bounds__(256) void norm_init_finish_kernel(const double* __r
   }
 }
 
-// column j of the Hessenberg: h[0..j] = the CGS dots, h[j+1] = tt = sqrt(sum of nblocks partials); Givens update
-// (KSPFGMRESUpdateHessenberg [3P]).  Partitioned levels pass the all-reduced values (nblocks = 1).
-// ww != nullptr (partitioned levels, one all-reduce per iteration): |w_new|^2 = |w|^2 - sum_i h_i^2 with the all-reduced
-// *ww = |w|^2 (w before the projection) and h; V is orthonormal, so this is the same number up to O(eps |w|^2).
-__device__ __forceinline__ double pythagoras_norm2(const double* ww, const double* h, int j) {
-  double s = *ww;
-  for (int i = 0; i <= j; ++i) s -= h[i] * h[i];
-  return s > 0.0 ? s : 0.0;
-}
-
-// one thread: column j of the Hessenberg from the CGS dots h[0..j] and tt = |w_new|, Givens update, rotated rhs
-__device__ __forceinline__ void hessenberg_column(double* __restrict__ hs, int K, int j, const double* __restrict__ h,
-                                                  double tt) {
-  HsLayout L(K);
-  hs[L.tt] = tt;
-  double* hcol = hs + L.H(j);
-  for (int i = 0; i <= j; ++i) hcol[i] = h[i];
-  hcol[j + 1] = tt;
-  double* cs = hs + L.cs;
-  double* sn = hs + L.sn;
-  double* grs = hs + L.grs;
-  for (int i = 0; i < j; ++i) {
-    const double t = hcol[i];
-    hcol[i] = cs[i] * t + sn[i] * hcol[i + 1];
-    hcol[i + 1] = -sn[i] * t + cs[i] * hcol[i + 1];
-  }
-  const double den = hypot(hcol[j], hcol[j + 1]);
-  if (den != 0.0) {
-    cs[j] = hcol[j] / den;
-    sn[j] = hcol[j + 1] / den;
-  } else {
-    cs[j] = 1.0;
-    sn[j] = 0.0;
-  }
-  grs[j + 1] = -sn[j] * grs[j];
-  grs[j] = cs[j] * grs[j];
-  hcol[j] = den;
-  hcol[j + 1] = 0.0;
-}
+// (pythagoras_norm2, hessenberg_column, fgmres_back_substitution: hs_layout.h -- shared with kernels_tiny.hip)
 
 // ---------------------------------------------------------------------------------------------------------------------
 // Fused smoother iteration for small levels (a smoother iteration there is a chain of launches of a few microseconds
@@ -691,15 +902,7 @@ __global__ __launch_bounds__(256) void hessenberg_update_kernel(const double* __
 // back substitution on the triangularised Hessenberg (KSPFGMRESBuildSoln [3P]) -> y
 __global__ void fgmres_finish_kernel(double* __restrict__ hs, int k, int K) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  HsLayout L(K);
-  double* y = hs + L.y;
-  const double* grs = hs + L.grs;
-  for (int i = k - 1; i >= 0; --i) {
-    double s = grs[i];
-    for (int q = i + 1; q < k; ++q) s -= hs[L.H(q) + i] * y[q];
-    const double d = hs[L.H(i) + i];
-    y[i] = d != 0.0 ? s / d : 0.0;
-  }
+  fgmres_back_substitution(hs, k, K);
 }
 
 #define ALFI_NV_SWITCH(NVAL, MACRO) \

@@ -68,6 +68,19 @@ def choose_splits(levels, world, min_dofs=400000):
     return out
 
 
+def overlap_decision(splits, bs, distributed, overlap, overlap_min_dofs):
+    """Whether a level hides its halo exchanges behind interior work (alfi_level_set_overlap).  The decision is COLLECTIVE:
+    the overlapped smoother iteration exchanges forward / reverse / forward, the plain one forward / sum, so two neighbours
+    that decide differently pair send/recv groups of different counts and directions (an RCCL hang or wrong halos).  It is
+    therefore taken from the split points -- identical on every rank -- by the SMALLEST owned share of the level, not from
+    the calling rank's own share."""
+    if not (distributed and overlap):
+        return False
+    shares = np.diff(np.asarray(splits, dtype=np.int64))
+    shares = shares[shares > 0]
+    return bool(shares.size > 0 and int(shares.min()) * bs >= overlap_min_dofs)
+
+
 class LevelPart(object):
     """One rank's view of one level: owned range, ghosts, local numbering, halo plan."""
 
@@ -563,14 +576,18 @@ class DistMultigrid(object):
 
     def __init__(self, levels, transfers, k, robust_restriction=False, group=None, device=None, min_dofs=400000,
                  coarse_inverse=None, verbose=False, force_distributed=False, overlap=None, overlap_min_dofs=None,
-                 transport=None):
+                 transport=None, on_stage=None):
         """transport: "rccl" -- the library's own RCCL communicator serves every exchange point of a cycle (no Python
         between the kernels; the default whenever the process group's backend is nccl) -- or "callback": the library
         calls back into this module, which exchanges through torch.distributed (the test transport: gloo, ranks sharing
-        a GPU).  ALFI_DIST_TRANSPORT overrides."""
+        a GPU).  ALFI_DIST_TRANSPORT overrides.  on_stage(name): called at "partition", "localize", "comm_init",
+        "upload_factor" (bench.py's per-rank stage markers); ``setup_s`` holds the seconds each took."""
         import os
+        import time
         import torch
         from . import hip
+        stage = on_stage or (lambda name: None)
+        self.setup_s = {}
         self.comm = Comm(group)
         rank = self.comm.rank
         if transport is None:
@@ -591,26 +608,41 @@ class DistMultigrid(object):
             device = torch.device("cuda", torch.cuda.current_device())
         self.device = device
         self.stream = torch.cuda.Stream(device=device)
+        stage("partition")
+        t0 = time.time()
         self.splits = choose_splits(levels, self.comm.world, min_dofs)
         self.parts = build_parts(levels, transfers, self.splits, rank, self.comm.all_gather_object,
                                  force_distributed_above=min_dofs if force_distributed else None)
+        self.setup_s["partition"] = time.time() - t0
+        stage("localize")
+        t0 = time.time()
         llev, ltr, self.lmin = localize(levels, transfers, self.parts)
+        self.setup_s["localize"] = time.time() - t0
         self.local_levels, self.local_transfers = llev, ltr
         self.k = k
         with torch.cuda.stream(self.stream):
             self.ctx = ctx = hip.Context(device.index or 0, stream=self.stream.cuda_stream)
             if transport == "rccl":
                 from . import _lib
+                stage("comm_init")
+                t0 = time.time()
                 box = [_lib.comm_unique_id() if rank == 0 else None]
                 self.comm.dist.broadcast_object_list(box, src=self.comm.dist.get_global_rank(group, 0) if group else 0,
                                                      group=group)
                 ctx.comm_init(box[0], rank, self.comm.world)          # collective: ncclCommInitRank
+                lib_rank, lib_world = ctx.comm_size()
+                if (lib_rank, lib_world) != (rank, self.comm.world):
+                    raise RuntimeError("the library's communicator reports rank %d of %d, the process group rank %d of %d"
+                                       % (lib_rank, lib_world, rank, self.comm.world))
+                self.setup_s["comm_init"] = time.time() - t0
             else:
                 self.red = torch.zeros(RED_LEN, dtype=torch.float64, device=device)
                 self._cb = CommFn(self._callback)
                 ctx.set_comm(self._cb, self.red.data_ptr(), RED_LEN)
             self.halos = {}
             self.levels = []
+            stage("upload_factor")
+            t0 = time.time()
             for LL in llev:
                 p = LL.part
                 dl = hip.Level(ctx, LL.A, LL.bc_dofs)
@@ -632,8 +664,8 @@ class DistMultigrid(object):
                     dl.set_patches(LL.patch_ptr, LL.patch_dofs)
                     if hip.condense_patches(LL):
                         dl.set_patch_groups(LL.patch_groups)
-                    dl.factor()
-                    if p.distributed and overlap and p.nb_own * p.bs >= overlap_min_dofs:
+                    dl.factor_with_fallback()
+                    if overlap_decision(p.splits, p.bs, p.distributed, overlap, overlap_min_dofs):
                         # interior rows / patches are worked on while the forward halo is in flight.  Opt-in
                         # (ALFI_DIST_OVERLAP_MIN_DOFS = smallest per-rank share that overlaps): the split launches and the
                         # asynchronous begin/end pairs (RCCL's own stream, two cross-stream waits each) have a fixed cost
@@ -646,6 +678,7 @@ class DistMultigrid(object):
                 self.levels.append(dl)
             self.mg = hip.Multigrid.__new__(hip.Multigrid)
             self.mg._from_device_levels(ctx, self.levels, ltr, k, robust_restriction)
+            self.setup_s["upload_factor"] = time.time() - t0
         self.fine = llev[-1]
         self.n_own = self.fine.n_own
         self.n_loc = self.fine.n
@@ -713,7 +746,7 @@ class DistMultigrid(object):
                 LL.A = new.A
                 dl.update_values(new.A.vals)
                 if LL.level > 0:
-                    dl.factor()
+                    dl.factor_with_fallback()
                 elif LL.part.nb_own > 0:
                     self._coarse(dl, levels[0].A, coarse_inverse)
 

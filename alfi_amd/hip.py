@@ -50,6 +50,12 @@ class Context(object):
         buf = ctypes.create_string_buffer(bytes(unique_id), _lib.COMM_ID_BYTES)
         self.check(self.lib.alfi_ctx_comm_init(self.h, ctypes.cast(buf, vp), int(rank), int(nranks)))
 
+    def comm_size(self):
+        """(rank, ranks) of the communicator the library itself exchanges over (alfi_ctx_comm_size)."""
+        r, n = ctypes.c_int(), ctypes.c_int()
+        self.check(self.lib.alfi_ctx_comm_size(self.h, ctypes.byref(r), ctypes.byref(n)))
+        return r.value, n.value
+
     # vectors ----------------------------------------------------------------------------------------------------------
     def vec(self, n_or_array):
         if isinstance(n_or_array, (int, np.integer)):
@@ -429,6 +435,24 @@ class Multigrid(object):
         self.h = h
         self.k = k
         ctx.sync()
+
+    def variant(self, robust_restriction):
+        """A second cycle handle (alfi_mg) over the SAME device levels and transfers with the other restriction setting
+        (`--restriction`, alfi/driver.py:41); ``close_handle()`` releases it without touching the shared levels."""
+        other = Multigrid.__new__(Multigrid)
+        other.ctx, other.levels, other.transfers, other.k = self.ctx, self.levels, self.transfers, self.k
+        lv = (vp * len(self.levels))(*[l.h for l in self.levels])
+        tr = (vp * max(1, len(self.transfers)))(*[t.h for t in self.transfers])
+        h = vp()
+        self.ctx.check(self.ctx.lib.alfi_mg_create(self.ctx.h, len(self.levels), lv, tr, int(self.k),
+                                                   1 if robust_restriction else 0, ctypes.byref(h)))
+        other.h = h
+        return other
+
+    def close_handle(self):
+        if self.h:
+            self.ctx.lib.alfi_mg_destroy(self.h)
+            self.h = None
 
     def vcycle(self, b, x):
         self.ctx.check(self.ctx.lib.alfi_mg_vcycle(self.h, b.ptr, x.ptr))

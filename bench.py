@@ -43,6 +43,7 @@ CONFIGS = {
     "cfg5s": ("sv", 1, 1, 3, 500.0, 10),
     "cfg5L": ("sv", 1, 3, 3, 500.0, 10),   # one more refinement: 3.4 M velocity dofs, ~40 GB of condensed factors on ONE GPU
 }
+SETUP_KEYS = ("comm_init", "partition", "localize", "upload_factor")     # DistMultigrid.setup_s, reported per rank
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 TB/s achievable)
 
 
@@ -117,10 +118,66 @@ def claim_stdout():
     return emit
 
 
+class Stages(object):
+    """Per-rank stage markers: one stderr line per stage and, when the launcher set ALFI_BENCH_STAGE_DIR, a file the
+    launcher's watchdog reads.  A rank that hangs (a communicator that never forms, an exchange whose groups do not pair)
+    is then reported with the stage it hangs in instead of a silent driver timeout."""
+
+    def __init__(self, rank):
+        self.rank, self.t0, self.cur, self.seen = rank, time.time(), "start", []
+        d = os.environ.get("ALFI_BENCH_STAGE_DIR")
+        self.path = os.path.join(d, "rank%d.stage" % rank) if d else None
+        spec = os.environ.get("ALFI_BENCH_TEST_HANG", "")        # "<rank>:<stage>": fault injection for the watchdog test
+        self.hang = tuple(spec.split(":", 1)) if ":" in spec else None
+
+    def __call__(self, name):
+        self.cur = name
+        dt = time.time() - self.t0
+        self.seen.append((name, round(dt, 1)))
+        sys.stderr.write("[alfi bench] rank %d: stage %s (+%.1f s)\n" % (self.rank, name, dt))
+        sys.stderr.flush()
+        if self.path:
+            with open(self.path, "w") as f:
+                f.write("%s %.1f\n" % (name, dt))
+        if self.hang and self.hang == (str(self.rank), name):
+            while True:                                          # never reached in production
+                time.sleep(3600)
+
+
+def bench_timeout_s():
+    return float(os.environ.get("ALFI_BENCH_TIMEOUT_S", "900"))
+
+
+def start_rank_watchdog(stages):
+    """In-rank half of the watchdog (covers the `torch.distributed.run` launch, where no parent of ours watches): a daemon
+    thread that ends THIS process with the stage it is stuck in once ALFI_BENCH_TIMEOUT_S have passed.  The blocking calls
+    of a rank (ncclCommInitRank, stream synchronisation, torch.distributed) run inside ctypes / torch with the GIL
+    released, so the thread gets to run while the main thread hangs."""
+    import threading
+    limit = bench_timeout_s()
+    if limit <= 0 or os.environ.get("ALFI_BENCH_RANK_WATCHDOG", "1") == "0":
+        return None
+    done = threading.Event()
+
+    def watch():
+        if done.wait(limit):
+            return
+        sys.stderr.write("[alfi bench] rank %d: WATCHDOG: no result after %.0f s, stuck in stage %r; stages so far %r\n"
+                         % (stages.rank, limit, stages.cur, stages.seen))
+        sys.stderr.flush()
+        os._exit(124)
+    th = threading.Thread(target=watch, name="alfi-bench-watchdog", daemon=True)
+    th.start()
+    return done
+
+
 def main_distributed(args, rank, world, local_rank):
     """One process per GPU: the fixed config-4 mesh partitioned over the ranks (strong scaling), halos and reductions over
     RCCL issued by the library itself.  Every rank builds the integer side of the hierarchy (meshes, numbering, graphs,
     patches: what the partitioner needs) and assembles operator / transfer values for its own rows only."""
+    stage = Stages(rank)
+    watchdog_done = start_rank_watchdog(stage)
+    stage("import_torch")
     import torch
     import torch.distributed as dist
     emit = claim_stdout()
@@ -131,6 +188,7 @@ def main_distributed(args, rank, world, local_rank):
     backend = os.environ.get("ALFI_DIST_BACKEND", "nccl")
     local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
+    stage("process_group_init")
     if backend == "nccl":
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     else:
@@ -138,17 +196,19 @@ def main_distributed(args, rank, world, local_rank):
     from alfi_amd._hostlib import cpu_share
     os.environ.setdefault("ALFI_HOST_THREADS", str(max(1, cpu_share() // world)))    # host generator threads of this rank
     from alfi_amd.dist import DistMultigrid
+    stage("host_generation")
     t0 = time.time()
     lazy = CONFIGS[args.config][0] != "sv" and os.environ.get("ALFI_DIST_GLOBAL_GENERATION") != "1"
     lv, tr, k = build_problem(args.config, args.verbose and rank == 0, lazy=lazy)
     t_gen = time.time() - t0
 
     t0 = time.time()
-    dmg = DistMultigrid(lv, tr, k, robust_restriction=False,
+    dmg = DistMultigrid(lv, tr, k, robust_restriction=args.restriction,
                         min_dofs=int(os.environ.get("ALFI_DIST_MIN_DOFS", "400000")), verbose=args.verbose,
-                        force_distributed=os.environ.get("ALFI_DIST_FORCE") == "1")
+                        force_distributed=os.environ.get("ALFI_DIST_FORCE") == "1", on_stage=stage)
     dmg.sync()
     t_setup = time.time() - t0
+    stage("first_cycle")
     L = lv[-1]
     b = np.random.default_rng(0).standard_normal(L.n)
     b[L.bc_dofs] = 0.0
@@ -157,6 +217,7 @@ def main_distributed(args, rank, world, local_rank):
     for _ in range(args.warmup):
         dmg.vcycle(db, dx)
     dmg.sync()
+    stage("timed_cycles")
     # events around the dominant kernel only (the roofline block needs them): the small distributed levels are bound by
     # per-launch latency and every event record adds to it; the exchanges are timed in one extra cycle afterwards
     prof_mode = {"0": False, "1": True}.get(os.environ.get("ALFI_BENCH_PROF", "3"), 3)
@@ -177,6 +238,7 @@ def main_distributed(args, rank, world, local_rank):
     dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     elapsed = float(tmax.item())
 
+    stage("post_measurements")
     # convergence sanity on the timed iterate: global residual norm
     dr = dmg.local_vec()
     with torch.cuda.stream(dmg.stream):
@@ -200,6 +262,20 @@ def main_distributed(args, rank, world, local_rank):
         comm_ms = ctx.prof_get()["COMM"][0]
         ctx.prof_enable(False)
         prof = dict(prof, COMM=(comm_ms * args.steps, prof["COMM"][1]))
+    # the Amdahl term of the partitioned cycle: device time this rank spends on levels ONE rank owns entirely (the coarse
+    # grid and the levels below min_dofs live on rank 0, as the reference telescopes its coarse solve, solver.py:354-358),
+    # every event class of one more untimed, fully instrumented cycle
+    ctx.prof_enable(True)
+    ctx.prof_reset()
+    dmg.vcycle(db, dx)
+    dmg.sync()
+    single_ms = 0.0
+    for dl, p in zip(dmg.levels, dmg.parts[dmg.lmin:]):
+        if not p.distributed and p.nb_own > 0:
+            single_ms += sum(v[0] for v in ctx.prof_get(dl.id).values())
+    ctx.prof_enable(False)
+    lib_rank, lib_world = ctx.comm_size() if dmg.transport == "rccl" else (rank, None)
+    nbr_max = max([int(np.count_nonzero((p.send_counts > 0) | (p.recv_counts > 0))) for p in dmg.parts] + [0])
     outer = None
     if args.outer and CONFIGS[args.config][0] != "sv":
         # one Newton-step linear solve on the partitioned levels (alfi_amd.dist.DistSaddle), outside the timed region
@@ -227,7 +303,9 @@ def main_distributed(args, rank, world, local_rank):
     local_gbs = bytes_apply * applies / (ms_f * 1e-3) / 1e9 if ms_f > 0 else 0.0
     rss_gb = resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 1e6
     stats = torch.tensor([float(npatch), float(dmg.n_own), float(dmg.n_loc - dmg.n_own), local_gbs, comm_ms, rss_gb,
-                          t_gen, t_setup, float(n_halo), float(n_red), 8e-6 * sent], dtype=torch.float64, device="cuda")
+                          t_gen, t_setup, float(n_halo), float(n_red), 8e-6 * sent, float(nbr_max), single_ms,
+                          float(lib_world if lib_world is not None else -1)] + [dmg.setup_s.get(kk, 0.0) for kk in SETUP_KEYS],
+                         dtype=torch.float64, device="cuda")
     allstats = [torch.zeros_like(stats) for _ in range(world)]
     dist.all_gather(allstats, stats)
     if rank == 0:
@@ -236,13 +314,22 @@ def main_distributed(args, rank, world, local_rank):
         out = {
             "metric": ("V-cycles/sec on bfs3d SV P3-P2dg (DoF*smooths/sec in dof_smooths_per_s)" if CONFIGS[args.config][0] == "sv"
                    else "V-cycles/sec on ldc%dd P2-P0 (DoF*smooths/sec in dof_smooths_per_s)" % CONFIGS[args.config][0]),
-            "value": vps, "unit": "V-cycles/s", "n_gpus": world, "n_ranks_seen": int(dist.get_world_size()),
+            "value": vps, "unit": "V-cycles/s", "n_gpus": world,
+            # size of the communicator the LIBRARY exchanges over (alfi_ctx_comm_size), agreed by every rank; with the
+            # callback test transport there is no such communicator and the process group's size is reported instead
+            "n_ranks_seen": (int(per_rank[0][13]) if per_rank[0][13] >= 0 and len(set(r[13] for r in per_rank)) == 1
+                             else int(dist.get_world_size()) if per_rank[0][13] < 0 else -1),
+            "n_ranks_seen_source": "alfi_ctx_comm_size (library-owned RCCL communicator)" if per_rank[0][13] >= 0
+                                   else "torch.distributed world size (callback test transport)",
+            "process_group_size": int(dist.get_world_size()),
+            "neighbours_max": int(max(r[11] for r in per_rank)),
+            "single_owner_levels_ms": round(per_rank[0][12], 3),
             "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": describe(args.config), "name": args.config, "velocity_dofs": int(L.n),
                        "levels": len(lv), "patches_finest": int(len(L.patch_ptr) - 1),
-                       "cycle": "V(k,k), 1 cycle per step",
+                       "cycle": "V(k,k), 1 cycle per step", "robust_restriction": bool(args.restriction),
                        "parallelism": "mesh partition over %d GPUs (Morton boxes, RCCL halos + all-reduce)" % world,
                        "backend": backend, "transport": dmg.transport,
                        "generation": "rank-local (alfi_amd.lazy)" if lazy else "global on every rank",
@@ -262,7 +349,10 @@ def main_distributed(args, rank, world, local_rank):
                          # (<= 12 doubles each), MB this rank sends
                          "halo_exchanges_per_cycle": [int(r[8]) for r in per_rank],
                          "allreduces_per_cycle": [int(r[9]) for r in per_rank],
-                         "MB_sent_per_cycle": [round(r[10], 2) for r in per_rank]},
+                         "MB_sent_per_cycle": [round(r[10], 2) for r in per_rank],
+                         "neighbours_max": [int(r[11]) for r in per_rank],
+                         "single_owner_levels_ms": [round(r[12], 3) for r in per_rank],
+                         "setup_s": {kk: [round(r[14 + i], 2) for r in per_rank] for i, kk in enumerate(SETUP_KEYS)}},
             "rel_residual_after_timed_cycles": res,
             "setup_s": {"host_generation": round(max(r[6] for r in per_rank), 1),
                         "partition_and_device_setup": round(max(r[7] for r in per_rank), 1),
@@ -274,10 +364,15 @@ def main_distributed(args, rank, world, local_rank):
         }
         if outer is not None:
             out["outer_solve"] = outer
+        assert out["neighbours_max"] <= min(world - 1, 7) or world > 8, "a rank exchanges with more than 7 neighbours"
         emit(json.dumps(out))
+    stage("teardown")
     dist.barrier()
     dmg.close()
     dist.destroy_process_group()
+    if watchdog_done is not None:
+        watchdog_done.set()
+    stage("done")
 
 
 def spawn_ranks(n):
@@ -298,20 +393,54 @@ def spawn_ranks(n):
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
+    import tempfile
+    stage_dir = tempfile.mkdtemp(prefix="alfi_bench_stages_")
+    limit = bench_timeout_s()
     procs = []
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), ALFI_BENCH_STAGE_DIR=stage_dir)
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: the only mode the host driver supports
+        # children are NEW processes started before anything in this parent touched a GPU -- never an exec of an
+        # initialised one; they stay in this process's group and session, so whoever ends the launcher's group ends them too
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=subprocess.PIPE if r == 0 else sys.stderr, cwd=os.getcwd()))
+
+    def last_stages():
+        out = []
+        for r in range(n):
+            try:
+                out.append("rank %d: %s" % (r, open(os.path.join(stage_dir, "rank%d.stage" % r)).read().strip()))
+            except OSError:
+                out.append("rank %d: (no stage reported -- still importing / starting)" % r)
+        return "; ".join(out)
+
+    def end_children():
+        for p in procs:                                            # exactly the children started above, by PID
+            if p.poll() is None:
+                p.send_signal(signal.SIGTERM)
+        for p in procs:
+            try:
+                p.wait(timeout=20)
+            except subprocess.TimeoutExpired:
+                p.kill()
+                p.wait()
+
+    def on_term(signum, frame):                                    # the launcher itself is being ended: take the ranks along
+        sys.stderr.write("bench.py: signal %d; last stages -- %s\n" % (signum, last_stages()))
+        end_children()
+        raise SystemExit(128 + signum)
+    signal.signal(signal.SIGTERM, on_term)
+
     line = None
     failed = None
+    timed_out = False
     import selectors
     sel = selectors.DefaultSelector()
     sel.register(procs[0].stdout, selectors.EVENT_READ)
     buf = b""
     open_out = True
+    t_start = time.time()
     while True:
         if open_out:
             for _ in sel.select(timeout=0.5):
@@ -329,17 +458,25 @@ def spawn_ranks(n):
             break
         if all(c == 0 for c in codes) and not open_out:
             break
-    if failed is not None:
-        for p in procs:                                            # exactly the children started above, by PID
-            if p.poll() is None:
-                p.send_signal(signal.SIGTERM)
-        for p in procs:
-            try:
-                p.wait(timeout=20)
-            except subprocess.TimeoutExpired:
-                p.kill()
-        sys.stderr.write("bench.py: rank %d exited with code %d\n" % failed)
+        # watchdog (ALFI_BENCH_TIMEOUT_S, 0 = off): a communicator that never forms or an exchange whose send/recv groups
+        # do not pair would otherwise spin until the driver's own limit and leave nothing to diagnose; the grace period
+        # lets the ranks' own watchdogs (same limit) report first
+        if limit > 0 and time.time() - t_start > limit + 15.0:
+            timed_out = True
+            break
+    if failed is not None or timed_out:
+        stages_txt = last_stages()
+        end_children()
+        if timed_out:
+            sys.stderr.write("bench.py: WATCHDOG: no result after %.0f s (ALFI_BENCH_TIMEOUT_S); last stages -- %s\n"
+                             % (limit, stages_txt))
+        else:
+            sys.stderr.write("bench.py: rank %d exited with code %d; last stages -- %s\n" % (failed + (stages_txt,)))
+        import shutil
+        shutil.rmtree(stage_dir, ignore_errors=True)
         raise SystemExit(1)
+    import shutil
+    shutil.rmtree(stage_dir, ignore_errors=True)
     for cand in buf.decode(errors="replace").splitlines():
         if cand.startswith("{"):
             line = cand
@@ -360,6 +497,11 @@ def main():
     ap.add_argument("--patch-composition", default="additive", choices=["additive", "multiplicative"],
                     help="multiplicative: symmetrised Gauss-Seidel patch sweeps ordered by the problem's "
                          "relaxation_direction (alfi/solver.py:306-335); the headline metric is quoted on additive")
+    ap.add_argument("--restriction", action="store_true",
+                    help="Schoeberl's robust restriction (alfi/driver.py:41 `--restriction`, transfer.py:261-275): off by "
+                         "default as in the reference's CLI; its production lines switch it on (examples/Makefile:6-16). "
+                         "The single-GPU line always times the other setting as well and reports it as "
+                         "`other_restriction_setting`")
     ap.add_argument("--outer", action="store_true",
                     help="also time one outer linear solve (FGMRES + fieldsplit Schur, alfi/solver.py:386-422) and "
                          "report it as `outer_solve`; not part of the headline metric")
@@ -404,7 +546,7 @@ def main():
     t_gen = time.time() - t0
     ctx = hip.Context(0)
     t0 = time.time()
-    dmg = hip.Multigrid(ctx, lv, tr, k, robust_restriction=False, verbose=args.verbose)
+    dmg = hip.Multigrid(ctx, lv, tr, k, robust_restriction=args.restriction, verbose=args.verbose)
     ctx.sync()
     t_setup = time.time() - t0
     L = lv[-1]
@@ -464,6 +606,31 @@ def main():
         dmg.fcycle(db, dxf)
     ctx.sync()
     fcycle_ms = 1e3 * (time.perf_counter() - t0) / 2
+
+    # the other restriction setting, same levels / factors / transfers (a second alfi_mg over the same handles), untimed
+    # warm-up + the same number of steps without events; reported next to the headline, never as `value`
+    other = dmg.variant(robust_restriction=not args.restriction)
+    dxo = ctx.vec(L.n)
+    other.vcycle(db, dxo)
+    ctx.sync()
+    t0 = time.perf_counter()
+    for _ in range(max(args.steps, 2)):
+        other.vcycle(db, dxo)
+    ctx.sync()
+    other_ms = 1e3 * (time.perf_counter() - t0) / max(args.steps, 2)
+    dmg.levels[-1].residual(db, dxo, dr)
+    other_res = float(np.linalg.norm(dr.get()) / np.linalg.norm(b))
+    other.close_handle()
+    # the timed setting again without any HIP event (what a production cycle costs; on launch-bound configs the event
+    # records around the dominant kernel lengthen the cycle)
+    dxn = ctx.vec(L.n)
+    dmg.vcycle(db, dxn)
+    ctx.sync()
+    t0 = time.perf_counter()
+    for _ in range(max(args.steps, 2)):
+        dmg.vcycle(db, dxn)
+    ctx.sync()
+    noevents_ms = 1e3 * (time.perf_counter() - t0) / max(args.steps, 2)
 
     graph_replay = None
     if args.graph:
@@ -540,7 +707,14 @@ def main():
         "config": {"workload": describe(args.config), "name": args.config, "velocity_dofs": int(L.n),
                    "levels": nlev, "patches_finest": int(dmg.levels[-1].patch_stats()[0]),
                    "cycle": "V(k,k), 1 cycle per step", "parallelism": "1 GPU",
+                   "robust_restriction": bool(args.restriction),
                    "patch_composition": args.patch_composition, "wavefronts_per_sweep": wavefronts},
+        "ms_per_step_without_events": noevents_ms,
+        "other_restriction_setting": {"robust_restriction": not args.restriction, "ms_per_step": other_ms,
+                                      "v_cycles_per_s": 1e3 / other_ms, "rel_residual_after_cycles": other_res,
+                                      "cycles": max(args.steps, 2) + 1,
+                                      "note": "same hierarchy, the reference's `--restriction` flag flipped "
+                                              "(examples/Makefile:6-16 passes it, driver.py:41 defaults it off); no events"},
         "dof_smooths_per_s": L.n * smooths_per_cycle_finest * vps,
         "patch_factor_GB": [round(dl.factor_bytes() / 1e9, 3) for dl in dmg.levels[1:]],
         "coarse_solver": {"kind": "dense inverse" if dmg.levels[0].coarse_factor_bytes() == 8 * lv[0].n * lv[0].n
@@ -592,18 +766,26 @@ def main():
                               "rhs_norm": float(np.linalg.norm(b)), "rtol": rtol, "atol": atol,
                               "pressure_dofs": int(Bm.shape[0]), "divergence_setup_s": round(t_b, 1)}
         sad.close()
+    baseline_failed = False
     if not args.no_cpu_baseline:
         try:
             from bench_cpu import cpu_baseline
-            out["cpu_baseline"] = cpu_baseline(args.config, lv, tr, k, vps)
-        except Exception as e:       # the baseline is a reported extra; never let it take the GPU number down
+            out["cpu_baseline"] = cpu_baseline(args.config, lv, tr, k, vps, robust_restriction=args.restriction)
+        except Exception as e:
+            # the GPU line is still printed (it is measured and valid), but the failure is LOUD: a non-null `error` field,
+            # the traceback on stderr and a non-zero exit code after the line is out
+            import traceback
+            traceback.print_exc()
             out["cpu_baseline"] = {"value": None, "unit": "V-cycles/s", "cores": 0, "kind": "port",
-                                   "sample": "failed: %r" % (e,)}
+                                   "sample": "failed", "error": "%s: %s" % (type(e).__name__, e)}
+            baseline_failed = True
     else:
         out["cpu_baseline"] = {"value": None, "unit": "V-cycles/s", "cores": 0, "kind": "port", "sample": "skipped"}
     emit(json.dumps(out))
     dmg.close()
     ctx.close()
+    if baseline_failed:
+        raise SystemExit(3)
 
 
 if __name__ == "__main__":

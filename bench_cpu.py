@@ -44,8 +44,8 @@ def _port_bytes(levels, transfers):
     return total
 
 
-def cpu_baseline(cfg_name, lv, tr, k, gpu_vps):
-    from oracle.c_oracle import CMultigrid, lib
+def cpu_baseline(cfg_name, lv, tr, k, gpu_vps, robust_restriction=False):
+    from oracle.c_oracle import CMultigrid, lib, spmv
     cores = lib().oracle_num_threads()
     need, avail = _port_bytes(lv, tr), _host_memory_available()
     full = os.environ.get("ALFI_CPU_BASELINE", "full") != "truncated" and (avail is None or 1.2 * need < avail)
@@ -57,7 +57,7 @@ def cpu_baseline(cfg_name, lv, tr, k, gpu_vps):
         what = "levels 0..%d of the same hierarchy (host memory: need %.0f GB, %.0f GB left)" % (
             len(slv) - 1, need / 1e9, (avail or 0) / 1e9)
     t0 = time.time()
-    mg = CMultigrid(slv, strr, k)
+    mg = CMultigrid(slv, strr, k, robust_restriction=robust_restriction)
     t_setup = time.time() - t0
     L = slv[-1]
     b = np.random.default_rng(0).standard_normal(L.n)
@@ -71,17 +71,19 @@ def cpu_baseline(cfg_name, lv, tr, k, gpu_vps):
         if n >= 3 and (time.time() - t0 > 25.0 or n >= 10):
             break
     per_cycle = (time.time() - t0) / n
-    res = float(np.linalg.norm(b - L.A.to_scipy() @ x) / np.linalg.norm(b)) if L.n < 3e6 else None
+    # convergence of the sample itself (the port's own BSR product: no SciPy copy of the 1e9-entry operator at full size)
+    res = float(np.linalg.norm(spmv(L.A, x, b=b, alpha=1.0)) / np.linalg.norm(b))
     if full:
         value = 1.0 / per_cycle
         sample = ("%d V-cycle(s) on %s (%d dofs), %.2f s each, after one warm-up cycle; patch inversion (%.1f s) excluded as "
                   "on the GPU side" % (n, what, L.n, per_cycle, t_setup))
         return {"value": value, "unit": "V-cycles/s", "cores": int(cores), "kind": "port", "sample": sample,
                 "extrapolated": False, "gpu_over_cpu": gpu_vps / value if value > 0 else None,
-                "rel_residual_after_sample": res}
+                "rel_residual_after_sample": res, "cycles_in_sample": n + 1, "robust_restriction": bool(robust_restriction)}
     scale = L.n / lv[-1].n
     value = scale / per_cycle
     return {"value": value, "unit": "V-cycles/s", "cores": int(cores), "kind": "port", "extrapolated": True,
             "sample": "EXTRAPOLATED: %d V-cycle(s) on %s (%d of %d dofs), %.2f s each, scaled by the dof ratio %.4f"
                       % (n, what, L.n, lv[-1].n, per_cycle, scale),
-            "gpu_over_cpu": None}
+            "gpu_over_cpu": None, "rel_residual_after_sample": res, "cycles_in_sample": n + 1,
+            "robust_restriction": bool(robust_restriction)}

@@ -60,7 +60,8 @@ enum {
   ALFI_EV_RESTRICT = 6,      /* SchoeberlRestrict */
   ALFI_EV_COARSE = 7,        /* coarse solve */
   ALFI_EV_COMM = 8,          /* halo pack/exchange/unpack and all-reduces (VecScatter / MPI_Allreduce in the reference) */
-  ALFI_EV_COUNT = 9
+  ALFI_EV_KSP_TINY = 9,      /* a whole KSPSolve(FGMRES(k) + PCPATCH) of a tiny level run as one single-workgroup kernel */
+  ALFI_EV_COUNT = 10
 };
 /* on = 1: a hipEvent pair around every launch of the classes above; on = 2: PATCH_APPLY and COMM only (fewer event
  * records on launch-bound levels); on = 3: PATCH_APPLY only; 0: off */

@@ -268,3 +268,16 @@ def test_sum_exchange_plan(case, world):
         assert shared[P.nb_own:].all()                                   # every ghost copy takes part
         assert np.abs(out[shared] - total[P.nodes][shared]).max() < 1e-12
         assert np.array_equal(out[~shared], vals[r][~shared])
+
+
+def test_overlap_decision_is_collective():
+    """Every rank must take the same overlap decision for a level (the overlapped and the plain smoother iteration issue
+    different exchange sequences): it follows from the split points alone, by the smallest share."""
+    from alfi_amd.dist import overlap_decision
+    splits = np.array([0, 1000, 2500, 3000])
+    for thr, want in ((0, True), (1500, True), (1501, False), (4000, False), (1 << 62, False)):
+        got = {overlap_decision(splits, 3, True, True, thr) for _rank in range(3)}
+        assert got == {want}, (thr, got)
+    assert not overlap_decision(splits, 3, False, True, 0) and not overlap_decision(splits, 3, True, False, 0)
+    # a rank with an empty share (single-owner level forced distributed) does not veto
+    assert overlap_decision(np.array([0, 1000, 1000]), 2, True, True, 2000)

@@ -45,6 +45,24 @@ def test_native_transport_with_several_ranks(case, world, robust, overlap, tmp_p
                                                                   "ALFI_TEST_EXPECT_TRANSPORT": "rccl"})
 
 
+def test_overlap_threshold_between_the_ranks_shares(tmp_path):
+    """the overlapped smoother iteration exchanges forward / reverse / forward, the plain one forward / sum.  With
+    uneven shares and ALFI_DIST_OVERLAP_MIN_DOFS between them a per-rank decision pairs send/recv groups of different counts
+    and directions.  The decision is now collective (smallest share of the level, alfi_amd.dist.overlap_decision): the run
+    with the threshold between the two ranks' shares matches the single-GPU result like every other run."""
+    from alfi_amd.dist import choose_splits
+    from tests.mock_rccl.build import build
+    from tests.test_dist_cpu import _hier
+    lv, tr, k, min_dofs = _hier("2d-all-distributed")
+    shares = np.diff(choose_splits(lv, 2, min_dofs)[-1]) * lv[-1].bs
+    assert shares.min() != shares.max(), "the weighted split of this case is expected to be uneven"
+    thr = int(shares.min() + shares.max()) // 2
+    assert shares.min() < thr <= shares.max()
+    _partitioned_cycles("2d-all-distributed", 2, 1, "1", tmp_path,
+                        {"ALFI_DIST_TRANSPORT": "rccl", "ALFI_RCCL_LIB": build(), "ALFI_TEST_EXPECT_TRANSPORT": "rccl",
+                         "ALFI_DIST_OVERLAP_MIN_DOFS": str(thr)})
+
+
 def _partitioned_cycles(case, world, robust, overlap, tmp_path, extra_env):
     from alfi_amd import hip
     from oracle import alfi_oracle as O
@@ -265,6 +283,10 @@ def test_bench_multi_rank_with_the_native_transport():
                      "ALFI_RCCL_LIB": build()})
     assert out.returncode == 0 and d is not None, out.stderr[-3000:]
     assert d["n_gpus"] == 4 and d["n_ranks_seen"] == 4 and d["config"]["transport"] == "rccl"
+    assert d["n_ranks_seen_source"].startswith("alfi_ctx_comm_size") and d["process_group_size"] == 4
+    assert 1 <= d["neighbours_max"] <= 3 and d["single_owner_levels_ms"] > 0.0
+    assert set(d["per_rank"]["setup_s"]) == {"comm_init", "partition", "localize", "upload_factor"}
+    assert d["config"]["robust_restriction"] is False
     assert d["rel_residual_after_timed_cycles"] < 0.5
     # the merged reverse-add + forward exchange of the smoother (alfi_level_set_sum_exchange): same result, a third fewer
     # halo exchanges than the three-per-iteration sequence
@@ -275,6 +297,26 @@ def test_bench_multi_rank_with_the_native_transport():
     h1, h0 = d["per_rank"]["halo_exchanges_per_cycle"][0], d0["per_rank"]["halo_exchanges_per_cycle"][0]
     assert h1 < 0.8 * h0, (h1, h0)
     assert abs(d["rel_residual_after_timed_cycles"] - d0["rel_residual_after_timed_cycles"]) < 1e-6 * d0["rel_residual_after_timed_cycles"]
+
+
+@pytest.mark.parametrize("rank_watchdog", ["1", "0"])
+def test_bench_watchdog_ends_a_hung_run(rank_watchdog):
+    """A rank that never reaches the first collective of the cycle (fault injection: ALFI_BENCH_TEST_HANG=<rank>:<stage>)
+    leaves its peers blocked in an exchange.  `bench.py --gpus 2` must then exit non-zero within ALFI_BENCH_TIMEOUT_S (plus the
+    launcher's grace period), end the children it started and say which stage every rank was in -- once with the ranks' own
+    watchdog threads (the torch.distributed.run launch has only those), once with the launcher's alone."""
+    import time
+    from tests.mock_rccl.build import build
+    t0 = time.time()
+    out, d = _bench(["--gpus", "2", "--config", "tiny", "--steps", "1", "--warmup", "1"],
+                    {"ALFI_DIST_BACKEND": "gloo", "ALFI_DIST_MIN_DOFS": "1000", "ALFI_DIST_TRANSPORT": "rccl",
+                     "ALFI_RCCL_LIB": build(), "ALFI_BENCH_TEST_HANG": "1:first_cycle", "ALFI_BENCH_TIMEOUT_S": "45",
+                     "ALFI_BENCH_RANK_WATCHDOG": rank_watchdog}, timeout=240)
+    took = time.time() - t0
+    assert out.returncode != 0 and d is None, out.stdout[-500:]
+    assert took < 150, took
+    assert "WATCHDOG" in out.stderr and "first_cycle" in out.stderr, out.stderr[-3000:]
+    assert "rank 1" in out.stderr
 
 
 def test_bench_launcher_fails_loudly_when_a_rank_cannot_start():
