@@ -127,6 +127,28 @@ def supg(V, U, nu, weight, magic, rowptr=None, colidx=None, vals=None, F=None, n
         raise RuntimeError("supg failed (%d): sparsity pattern does not cover the mesh" % rc)
 
 
+def contributors(cell_nodes, nnode, rowptr, colidx):
+    """(cptr int64 (nnzb + 1), ccell int32, cba uint16): for every BSR block the (cell, b * nloc + a) pairs that contribute to
+    it, in a fixed order -- the gather lists of the device assembly (alfi_level_set_assembly)."""
+    cn = np.ascontiguousarray(cell_nodes, dtype=np.int32)
+    ncell, nloc = cn.shape
+    if nloc * nloc > 65535:
+        raise ValueError("element with %d nodes: the pair code does not fit 16 bits" % nloc)
+    rowptr = np.ascontiguousarray(rowptr, dtype=np.int32)
+    colidx = np.ascontiguousarray(colidx, dtype=np.int32)
+    cptr = np.zeros(colidx.shape[0] + 1, dtype=np.int64)
+    fn = lib().alfi_host_contributors
+    fn.restype = ctypes.c_int
+    rc = fn(ctypes.c_int64(ncell), ctypes.c_int(nloc), _p(cn), ctypes.c_int64(nnode), _p(rowptr), _p(colidx), _p(cptr), None, None)
+    if rc != 0:
+        raise RuntimeError("contributors failed (%d): sparsity pattern does not cover the mesh" % rc)
+    assert cptr[-1] == ncell * nloc * nloc
+    ccell = np.empty(cptr[-1], dtype=np.int32)
+    cba = np.empty(cptr[-1], dtype=np.uint16)
+    fn(ctypes.c_int64(ncell), ctypes.c_int(nloc), _p(cn), ctypes.c_int64(nnode), _p(rowptr), _p(colidx), _p(cptr), _p(ccell), _p(cba))
+    return cptr, ccell, cba
+
+
 def apply_bc_bsr(nrow, d, rowptr, colidx, vals, bcmask, row_ids=None):
     """Dirichlet rows / columns -> identity.  row_ids: the node of each block row when the rows are a subset."""
     bcmask = np.ascontiguousarray(bcmask, dtype=np.uint8)

@@ -142,6 +142,7 @@ static int upload_bsr(alfi_ctx* ctx, DevBSR* d, const alfi_bsr_host* h, int bs) 
   }
   return upload_bsr_values(ctx, d, h->vals);
 }
+static void free_assembly(AssemblyDev* S);
 static void free_bsr(DevBSR* d) {
   dev_free(d->rowptr);
   dev_free(d->colidx);
@@ -605,6 +606,7 @@ int alfi_level_destroy(alfi_level* L) {
   (void)hipStreamSynchronize(L->ctx->stream);
   free_row_view(&L->A_int);
   free_row_view(&L->A_bnd);
+  free_assembly(&L->asmb);
   free_bsr(&L->A);
   dev_free(L->bc_dofs);
   dev_free(L->bc_mask);
@@ -650,6 +652,98 @@ int alfi_level_update_values(alfi_level* L, const double* bvals) {
   L->A_int.vals = L->A_bnd.vals = L->A.vals;
   L->factored = false;
   return 0;
+}
+
+static void free_assembly(AssemblyDev* S) {
+  dev_free(S->cptr); dev_free(S->ccell); dev_free(S->cba); dev_free(S->cell_nodes); dev_free(S->grad); dev_free(S->vol);
+  dev_free(S->Ta); dev_free(S->Tb); dev_free(S->Kv); dev_free(S->Dv);
+  *S = AssemblyDev();
+}
+
+int alfi_level_set_assembly(alfi_level* L, int64_t ncell, int nloc, const int32_t* cell_nodes, const double* grad,
+                            const double* vol, const double* Ta, const double* Tb, const double* Kvals, const double* Dvals,
+                            const int64_t* cptr, const int32_t* ccell, const uint16_t* cba) {
+  alfi_ctx* ctx = L->ctx;
+  if (!cell_nodes || !grad || !vol || !Ta || !Tb || !Kvals || !Dvals || !cptr || !ccell || !cba)
+    return alfi_set_error(ctx, ALFI_E_ARG, "NULL argument");
+  if (ncell < 1 || nloc < 1 || nloc * nloc > 65535) return alfi_set_error(ctx, ALFI_E_ARG, "bad cell counts (%lld cells, %d nodes each)", (long long)ncell, nloc);
+  if (!L->A.flat) return alfi_set_error(ctx, ALFI_E_STATE, "device assembly needs the lane-major operator layout (no empty block rows)");
+  if (L->has_halo) return alfi_set_error(ctx, ALFI_E_STATE, "device assembly is built for unpartitioned levels");
+  const int64_t nnzb = L->A.nnzb, nb = L->A.nbrows, npairs = ncell * nloc * nloc;
+  const int d = L->bs, nv = d + 1;
+  if (cptr[0] != 0 || cptr[nnzb] != npairs)
+    return alfi_set_error(ctx, ALFI_E_ARG, "contributor lists hold %lld pairs, expected cells x nodes^2 = %lld", (long long)cptr[nnzb], (long long)npairs);
+  for (int64_t k = 0; k < nnzb; ++k)
+    if (cptr[k + 1] <= cptr[k]) return alfi_set_error(ctx, ALFI_E_ARG, "block %lld has no contributing cell", (long long)k);
+  for (int64_t q = 0; q < npairs; ++q)
+    if (ccell[q] < 0 || ccell[q] >= ncell || cba[q] >= nloc * nloc) return alfi_set_error(ctx, ALFI_E_ARG, "contributor %lld out of range", (long long)q);
+  for (int64_t i = 0; i < ncell * nloc; ++i)
+    if (cell_nodes[i] < 0 || cell_nodes[i] >= nb) return alfi_set_error(ctx, ALFI_E_ARG, "cell node out of range");
+  ALFI_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  ALFI_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  free_assembly(&L->asmb);
+  AssemblyDev S;
+  S.nloc = nloc;
+  S.ncell = ncell;
+  S.npairs = npairs;
+  int rc = dev_upload(ctx, &S.cptr, cptr, nnzb + 1);
+  if (rc == 0) rc = dev_upload(ctx, &S.ccell, ccell, npairs);
+  if (rc == 0) rc = dev_upload(ctx, &S.cba, cba, npairs);
+  if (rc == 0) rc = dev_upload(ctx, &S.cell_nodes, cell_nodes, ncell * nloc);
+  if (rc == 0) rc = dev_upload(ctx, &S.grad, grad, ncell * nv * d);
+  if (rc == 0) rc = dev_upload(ctx, &S.vol, vol, ncell);
+  if (rc == 0) rc = dev_upload(ctx, &S.Ta, Ta, (int64_t)nloc * nloc * nloc * nv);
+  if (rc == 0) rc = dev_upload(ctx, &S.Tb, Tb, (int64_t)nloc * nloc * nloc * nv);
+  // K and D in the operator's own (lane-major) layout: upload through a DevBSR that shares the level's structure
+  const int64_t padded = ((nnzb + 63) / 64) * 64 * d * d;
+  for (int which = 0; which < 2 && rc == 0; ++which) {
+    double** dst = which == 0 ? &S.Kv : &S.Dv;
+    rc = dev_alloc(ctx, dst, padded);
+    if (rc == 0 && hipMemsetAsync(*dst, 0, sizeof(double) * padded, ctx->stream) != hipSuccess) rc = ALFI_E_HIP;
+    if (rc == 0) {
+      DevBSR tmp = L->A;
+      tmp.vals = *dst;
+      rc = upload_bsr_values(ctx, &tmp, which == 0 ? Kvals : Dvals);
+    }
+  }
+  if (rc != 0) {
+    free_assembly(&S);
+    return rc;
+  }
+  S.ready = true;
+  L->asmb = S;
+  return 0;
+}
+
+int alfi_level_assemble(alfi_level* L, double nu, double gamma, double adv, const double* d_state, int apply_bc) {
+  alfi_ctx* ctx = L->ctx;
+  if (!L->asmb.ready) return alfi_set_error(ctx, ALFI_E_STATE, "alfi_level_assemble before alfi_level_set_assembly");
+  if (adv != 0.0 && !d_state) return alfi_set_error(ctx, ALFI_E_ARG, "advection needs the state");
+  ctx->cur_tag = L->id;
+  int t = alfi_prof_begin(ctx, ALFI_EV_PATCH_FACTOR);       // PCPatchComputeOp
+  ALFI_CHECK(launch_assemble_gather(L, nu, gamma, adv, d_state, apply_bc));
+  alfi_prof_end(ctx, t);
+  L->factored = false;
+  return 0;
+}
+
+int alfi_level_get_values(alfi_level* L, double* bvals) {
+  alfi_ctx* ctx = L->ctx;
+  const int bb = L->bs * L->bs;
+  if (L->A.nnzb == 0) return 0;
+  ALFI_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  if (!L->A.flat) {
+    ALFI_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    ALFI_HIP_CHECK(ctx, hipMemcpy(bvals, L->A.vals, (size_t)L->A.nnzb * bb * sizeof(double), hipMemcpyDeviceToHost));
+    return 0;
+  }
+  double* tmp = nullptr;
+  ALFI_CHECK(dev_alloc(ctx, &tmp, L->A.nnzb * bb));
+  int rc = launch_vals_from_lanes(ctx, L->A, tmp);
+  if (rc == 0 && hipMemcpyAsync(bvals, tmp, (size_t)L->A.nnzb * bb * sizeof(double), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) rc = ALFI_E_HIP;
+  if (rc == 0 && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = ALFI_E_HIP;
+  dev_free(tmp);
+  return rc;
 }
 
 int alfi_level_size(alfi_level* L, int64_t* n) {
@@ -1262,11 +1356,14 @@ int alfi_smooth_fgmres(alfi_level* L, int k, const double* db, double* dx, int n
     // like: config 3 18.66 -> 18.12-18.23 ms with its two smallest smoothed levels on the fused iteration (same box)
     static const int64_t small_n = getenv("ALFI_FUSED_SMALL_N") ? atoll(getenv("ALFI_FUSED_SMALL_N")) : 50000;
     const bool fusable = allow && !L->distributed && L->n_own == L->n && !L->mult && k + 1 <= 16 && L->A_own.flat;
-    // tiny levels (operator + dense inverses of a smoother iteration below ALFI_TINY_BYTES, default 3.5 MB): the whole call
-    // as ONE launch of ONE workgroup (kernels_tiny.hip) -- ~30 dependent launches of 5-8 us become one kernel whose phases
-    // are separated by __syncthreads() only
-    static const int64_t tiny_bytes = getenv("ALFI_TINY_BYTES") ? atoll(getenv("ALFI_TINY_BYTES")) : 3500000;
-    if (fusable && !L->cond && L->max_np <= SMALL_PATCH_MAX && tiny_level_bytes(L) <= tiny_bytes)
+    // tiny levels (operator + dense inverses of a smoother iteration below ALFI_TINY_BYTES): the whole call as ONE launch of
+    // ONE workgroup (kernels_tiny.hip) -- ~30 dependent launches become one kernel whose phases are separated by
+    // __syncthreads() only.  OPT-IN (default 0 = never): measured on ldc2d it does not beat the launch
+    // chain even on the 1 250-dof level (0.46 ms per cycle against ~0.4 ms): every phase is a chain of two or three dependent
+    // global loads at ~2 us each -- the level's data does not survive in L2 between two visits of the level -- and one
+    // workgroup has 16 waves to hide them where the launch chain has a few hundred
+    static const int64_t tiny_bytes = getenv("ALFI_TINY_BYTES") ? atoll(getenv("ALFI_TINY_BYTES")) : 0;
+    if (fusable && !L->cond && L->kmax <= 15 && L->max_np <= SMALL_PATCH_MAX && tiny_level_bytes(L) <= tiny_bytes)
       return launch_smooth_tiny(L, k, db, dx, nonzero_guess);
     if (fusable && (L->max_row_blocks <= 32 || L->n <= small_n))
       return smooth_fgmres_fused(L, k, db, dx, nonzero_guess);
@@ -1298,7 +1395,10 @@ int alfi_smooth_fgmres(alfi_level* L, int k, const double* db, double* dx, int n
   // itself -- every block in the same fixed order -- instead of waiting for a one-block reduction launch.
   const int G = red_blocks_for(n);
   static const bool allow_fused = !(getenv("ALFI_FUSED_REDUCE") && atoi(getenv("ALFI_FUSED_REDUCE")) == 0);   // A/B switch
-  const bool fused = allow_fused && !par && G <= 256 && k + 1 <= 16;
+  // (G = n / 4096 partials per vector; ALFI_FUSED_REDUCE_MAX = 512 would include config 3's finest level, 319 partials:
+  // measured 18.31 against 18.13 ms per cycle, the re-summation in every consumer block costs more than the launch)
+  static const int fused_max = getenv("ALFI_FUSED_REDUCE_MAX") ? atoi(getenv("ALFI_FUSED_REDUCE_MAX")) : 256;
+  const bool fused = allow_fused && !par && G <= fused_max && k + 1 <= 16;
   t = alfi_prof_begin(ctx, ALFI_EV_BLAS1);
   ALFI_CHECK(launch_norm_partials(ctx, w, n));
   if (par) ALFI_CHECK(launch_reduce_partials(ctx, ctx->red_partial, G, 1, nrm2));

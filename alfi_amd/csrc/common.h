@@ -178,8 +178,26 @@ struct CondDev {
   const int32_t* order = nullptr;  // (npatch) patches by descending factor bytes: dispatch order of a full-range apply
 };
 
+// device-side data of the operator refresh (alfi_level_set_assembly, kernels_assemble.hip)
+struct AssemblyDev {
+  bool ready = false;
+  int nloc = 0;
+  int64_t ncell = 0, npairs = 0;
+  int64_t* cptr = nullptr;       // (nnzb + 1) contributor lists per block
+  int32_t* ccell = nullptr;      // (npairs) cell
+  uint16_t* cba = nullptr;       // (npairs) b * nloc + a
+  int32_t* cell_nodes = nullptr; // (ncell, nloc)
+  double* grad = nullptr;        // (ncell, d + 1, d) gradients of the barycentric coordinates
+  double* vol = nullptr;         // (ncell)
+  double* Ta = nullptr;          // (nloc * nloc, nloc, d + 1): [b * nloc + a][k][i] = T1[k, i, b, a]
+  double* Tb = nullptr;          // (nloc * nloc, d + 1, nloc): [b * nloc + a][i][k] = T1[b, i, k, a]
+  double* Kv = nullptr;          // viscous part, the operator's lane-major layout
+  double* Dv = nullptr;          // grad-div part
+};
+
 struct alfi_level {
   alfi_ctx* ctx = nullptr;
+  AssemblyDev asmb;
   int id = 0;
   int64_t n = 0;  // scalar dofs
   int bs = 0;
@@ -421,6 +439,10 @@ int launch_patch_sum_scale(alfi_level* lvl, const double* w, double* z, double* 
 // w = A z with the partials of V_v . w (v < nv <= 16) in the same pass; *nblocks = number of partials per vector
 int launch_bsr_spmv_dot(alfi_ctx* ctx, const DevBSR& A, const double* z, double* w, const double* V, int64_t stride, int nv,
                         double* partial, int* nblocks);
+int launch_assemble_gather(alfi_level* lvl, double nu, double gamma, double adv, const double* d_state, int apply_bc);
+int launch_vals_from_lanes(alfi_ctx* ctx, const DevBSR& A, double* d_out);
+int launch_patch_invert_mfma(alfi_ctx* ctx, int64_t npatch, int max_np, const int64_t* patch_ptr, const int64_t* inv_ptr,
+                             double* inv, int* status, int* handled);   // kernels_invert.hip
 // one-workgroup FGMRES(k) + patch smoother of a tiny level (kernels_tiny.hip)
 int64_t tiny_level_bytes(const alfi_level* lvl);
 int launch_smooth_tiny(alfi_level* lvl, int k, const double* db, double* dx, int nonzero_guess);

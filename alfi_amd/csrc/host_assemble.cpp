@@ -226,6 +226,61 @@ int alfi_host_assemble_bsr(int64_t ncell, int nloc, int d, const int32_t* cell_n
   return err ? -2 : 0;
 }
 
+// Contributor lists for the DEVICE assembly of the level operators (csrc/kernels_assemble.hip): for every block (r, c) of the
+// BSR sparsity the (cell, b * nloc + a) pairs with r = node a and c = node b of the cell, cells ascending and, inside a cell, b
+// ascending -- a fixed order, so that the device sums every operator entry in the same order on every run (no atomics).
+// cptr: (nnzb + 1) int64.  Call with ccell == nullptr to fill cptr only (counting pass).
+int alfi_host_contributors(int64_t ncell, int nloc, const int32_t* cell_nodes, int64_t nnode, const int32_t* rowptr,
+                           const int32_t* colidx, int64_t* cptr, int32_t* ccell, uint16_t* cba) {
+  std::vector<int64_t> nptr(nnode + 1, 0);                  // node -> cells (ascending)
+  for (int64_t c = 0; c < ncell; ++c)
+    for (int a = 0; a < nloc; ++a) nptr[cell_nodes[c * nloc + a] + 1]++;
+  for (int64_t i = 0; i < nnode; ++i) nptr[i + 1] += nptr[i];
+  std::vector<int32_t> ncells(nptr[nnode]);
+  {
+    std::vector<int64_t> fill(nptr.begin(), nptr.end() - 1);
+    for (int64_t c = 0; c < ncell; ++c)
+      for (int a = 0; a < nloc; ++a) ncells[fill[cell_nodes[c * nloc + a]]++] = (int32_t)c;
+  }
+  const int64_t nnzb = rowptr[nnode];
+  const bool counting = (ccell == nullptr);
+  int err = 0;
+  if (counting) std::fill(cptr, cptr + nnzb + 1, (int64_t)0);
+  // the blocks of block row r are touched by the thread that owns r only: no atomics, a fixed order
+#pragma omp parallel
+  {
+    std::vector<int64_t> cursor;
+#pragma omp for schedule(dynamic, 512)
+    for (int64_t r = 0; r < nnode; ++r) {
+      const int64_t lo = rowptr[r], hi = rowptr[r + 1];
+      if (!counting) cursor.assign(cptr + lo, cptr + hi);
+      for (int64_t q = nptr[r]; q < nptr[r + 1]; ++q) {
+        const int32_t cell = ncells[q];
+        const int32_t* cn = cell_nodes + (int64_t)cell * nloc;
+        int a = 0;
+        while (a < nloc && cn[a] != r) ++a;
+        for (int b = 0; b < nloc; ++b) {
+          const int64_t pos = find_col(colidx, lo, hi, cn[b]);
+          if (pos >= hi || colidx[pos] != cn[b]) {
+            err = 1;
+            continue;
+          }
+          if (counting) {
+            cptr[pos + 1]++;
+          } else {
+            const int64_t at = cursor[pos - lo]++;
+            ccell[at] = cell;
+            cba[at] = (uint16_t)(b * nloc + a);
+          }
+        }
+      }
+    }
+  }
+  if (counting)
+    for (int64_t k = 0; k < nnzb; ++k) cptr[k + 1] += cptr[k];
+  return err ? -2 : 0;
+}
+
 // Dense interior blocks of the Schoeberl transfer, assembled directly: block `blk` (= coarse cell) receives the
 // contributions of its nch children (fine cells blk*nch .. blk*nch+nch-1) restricted to the block's interior dofs.
 // blk_local[node] = position of the node inside its block (0..m/d-1) or -1.  KII, DII: (nblk, m, m) row-major.

@@ -1,0 +1,323 @@
+// S5: batched in-place inversion of the star-patch matrices (33 .. 160 dofs) on the FP64 matrix cores.
+// (PCPATCH's `dense_inverse`, alfi/solver.py:599-602: LAPACK getrf + getri per patch in the reference, paid on every
+// Newton step.)
+//
+// Block Gauss-Jordan with 4 x 4 pivot blocks -- the k depth of v_mfma_f64_16x16x4 -- on a register-resident matrix:
+// a workgroup (8 waves) holds one padded patch matrix as NT x NT tiles of 16 x 16 in the MFMA accumulator layout, wave w
+// the tiles (ti, tj) with ti % 4 == w >> 1, tj % 2 == w & 1 (<= 15 tiles = 60 doubles per lane for NT = 10).  Step s
+// (pivot rows / columns K = 4 s .. 4 s + 3):
+//     panels      the owners put the raw row panel A[K, :] (4 x N) and column panel A[:, K] (N x 4) into LDS   -- barrier
+//     pivot       every lane factors the 4 x 4 block D = A[K, K] = L U (unpivoted, redundantly: no second barrier)
+//     operands    the four scalar Gauss-Jordan steps of the block, delayed: B = rows r_t = the scaled pivot rows at the time of
+//                 step t (L^-1 A[K, :], scaled), A-operand = columns c_t at the time of step t (A[:, K] U^-1, unscaled);
+//                 columns K of B and rows K of A zeroed
+//     update      ONE rank-4 MFMA per tile:  A <- A - sum_t c_t r_t^T               (all tiles, no special cases)
+//     fix-up      rows K <- D^-1 A[K, :] (back substitution on the lane's own column), columns K <- - (A[:, K] U^-1) L^-1 (one
+//                 more MFMA per tile of that tile column), A[K, K] <- U^-1 L^-1
+// D^-1 is never formed: see Lu4 below.
+// Against the rank-1 register kernel it replaces (patch_invert_big_kernel: 21 LDS operand reads and one barrier per
+// pivot for 100 FMAs, 9.5 TFLOP/s = 12 % of peak at config 4): a quarter of the barriers, and the operands of the 2 n^3
+// flops travel inside the MFMA instead of through LDS broadcasts.  No pivoting across blocks (as before): every
+// factorisation is followed by the residual probe + pivoted repair of kernels_check.hip.
+//
+// MFMA operand maps (cdna_hip_programming.md): A[m = lane & 15][k = lane >> 4], B[k = lane >> 4][n = lane & 15],
+// C/D: column = lane & 15, row = (lane >> 4) + 4 * reg.
+#include <cstdlib>
+#include <type_traits>
+#include "common.h"
+
+namespace {
+
+typedef double inv_d4 __attribute__((ext_vector_type(4)));
+
+// Unpivoted LU of the 4 x 4 pivot block D = L U (L unit lower) in registers.  The block step never forms D^-1: with patch
+// operators of condition ~ gamma / nu = 1e7 the 4 x 4 diagonal blocks are that ill-conditioned themselves (gamma b b^T + nu K
+// per node), and a Schur complement formed as A[:, K] (D^-1 A[K, :]) loses cond(D) eps -- measured: 62 % of config 4's patches
+// fail the 1e-6 residual probe (worst 2e-3) -- whereas (A[:, K] U^-1)(L^-1 A[K, :]) is what the scalar elimination computes.
+struct Lu4 {
+  double l10, l20, l30, l21, l31, l32;        // L
+  double u01, u02, u03, u12, u13, u23;        // strict upper part of U
+  double i0, i1, i2, i3;                      // 1 / U_tt
+  double s01, s02, s03, s12, s13, s23;        // U_ut / U_uu: the scaled pivot rows inside the block
+};
+
+// 1 / x: hardware estimate + two Newton steps (the IEEE division sequence is ~12 dependent FP64 instructions, and four of
+// them sit on the critical path of every block step)
+__device__ __forceinline__ double recip(double x) {
+  double r = __builtin_amdgcn_rcp(x);
+  r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
+  r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
+  return r;
+}
+
+__device__ __forceinline__ void lu4(const double (&d)[4][4], Lu4& f, bool& bad) {
+  const double u00 = d[0][0];
+  f.i0 = recip(u00);
+  f.u01 = d[0][1]; f.u02 = d[0][2]; f.u03 = d[0][3];
+  f.l10 = d[1][0] * f.i0; f.l20 = d[2][0] * f.i0; f.l30 = d[3][0] * f.i0;
+  const double u11 = __builtin_fma(-f.l10, f.u01, d[1][1]);
+  f.u12 = __builtin_fma(-f.l10, f.u02, d[1][2]);
+  f.u13 = __builtin_fma(-f.l10, f.u03, d[1][3]);
+  f.i1 = recip(u11);
+  f.l21 = __builtin_fma(-f.l20, f.u01, d[2][1]) * f.i1;
+  f.l31 = __builtin_fma(-f.l30, f.u01, d[3][1]) * f.i1;
+  const double u22 = __builtin_fma(-f.l21, f.u12, __builtin_fma(-f.l20, f.u02, d[2][2]));
+  f.u23 = __builtin_fma(-f.l21, f.u13, __builtin_fma(-f.l20, f.u03, d[2][3]));
+  f.i2 = recip(u22);
+  f.l32 = __builtin_fma(-f.l31, f.u12, __builtin_fma(-f.l30, f.u02, d[3][2])) * f.i2;
+  const double u33 = __builtin_fma(-f.l32, f.u23, __builtin_fma(-f.l31, f.u13, __builtin_fma(-f.l30, f.u03, d[3][3])));
+  f.i3 = recip(u33);
+  if (u00 == 0.0 || u11 == 0.0 || u22 == 0.0 || u33 == 0.0) bad = true;
+  f.s01 = f.u01 * f.i0; f.s02 = f.u02 * f.i0; f.s03 = f.u03 * f.i0;
+  f.s12 = f.u12 * f.i1; f.s13 = f.u13 * f.i1;
+  f.s23 = f.u23 * f.i2;
+}
+
+__device__ __forceinline__ double sel4(int i, double a0, double a1, double a2, double a3) {
+  return i == 0 ? a0 : i == 1 ? a1 : i == 2 ? a2 : a3;
+}
+
+// x = one column of the raw row panel A[K, c].  r[t] = the scaled pivot row t at the time of scalar step t (the B operand of
+// the rank-4 update); z[t] = (D^-1 A[K, c])[t], the final content of the rows K
+__device__ __forceinline__ void row_panel(const Lu4& f, const double (&x)[4], double (&r)[4], double (&z)[4]) {
+  const double y0 = x[0];
+  const double y1 = __builtin_fma(-f.l10, y0, x[1]);
+  const double y2 = __builtin_fma(-f.l21, y1, __builtin_fma(-f.l20, y0, x[2]));
+  const double y3 = __builtin_fma(-f.l32, y2, __builtin_fma(-f.l31, y1, __builtin_fma(-f.l30, y0, x[3])));
+  r[0] = y0 * f.i0; r[1] = y1 * f.i1; r[2] = y2 * f.i2; r[3] = y3 * f.i3;
+  z[3] = r[3];
+  z[2] = __builtin_fma(-f.s23, z[3], r[2]);
+  z[1] = __builtin_fma(-f.s13, z[3], __builtin_fma(-f.s12, z[2], r[1]));
+  z[0] = __builtin_fma(-f.s03, z[3], __builtin_fma(-f.s02, z[2], __builtin_fma(-f.s01, z[1], r[0])));
+}
+
+// x = one row of the raw column panel A[i, K].  c[t] = the column t at the time of scalar step t (the A operand)
+__device__ __forceinline__ void col_panel(const Lu4& f, const double (&x)[4], double (&c)[4]) {
+  c[0] = x[0];
+  c[1] = __builtin_fma(-f.s01, c[0], x[1]);
+  c[2] = __builtin_fma(-f.s12, c[1], __builtin_fma(-f.s02, c[0], x[2]));
+  c[3] = __builtin_fma(-f.s23, c[2], __builtin_fma(-f.s13, c[1], __builtin_fma(-f.s03, c[0], x[3])));
+}
+
+// w = x D^-1 = (x U^-1) L^-1 for one row x (4 entries): the final content of the columns K is - w, row lk of D^-1 is this with
+// x = e_lk
+__device__ __forceinline__ void times_dinv(const Lu4& f, const double (&x)[4], double (&w)[4]) {
+  const double v0 = x[0] * f.i0;
+  const double v1 = __builtin_fma(-f.u01, v0, x[1]) * f.i1;
+  const double v2 = __builtin_fma(-f.u12, v1, __builtin_fma(-f.u02, v0, x[2])) * f.i2;
+  const double v3 = __builtin_fma(-f.u23, v2, __builtin_fma(-f.u13, v1, __builtin_fma(-f.u03, v0, x[3]))) * f.i3;
+  w[3] = v3;
+  w[2] = __builtin_fma(-f.l32, w[3], v2);
+  w[1] = __builtin_fma(-f.l31, w[3], __builtin_fma(-f.l21, w[2], v1));
+  w[0] = __builtin_fma(-f.l30, w[3], __builtin_fma(-f.l20, w[2], __builtin_fma(-f.l10, w[1], v0)));
+}
+
+// 8 waves per patch: wave w holds the tiles (ti, tj) with ti % 4 == w >> 1, tj % 2 == w & 1 -- at most 3 x 5 = 15 tiles = 60
+// doubles per lane for NT = 10, so the whole working set stays in architectural VGPRs (with 4 waves and 25 tiles per wave the
+// accumulators live in AGPRs and every panel extraction / fix-up pays v_accvgpr moves; the compiler spilled 100+ registers),
+// and two waves share a SIMD: the scalar section of one (pivot-block LU: four dependent divisions) runs under the MFMAs of
+// the other.  The loop over the pivot tiles is FULLY unrolled, so every accumulator index is a compile-time constant and
+// "is this my tile row / column" is a wave-uniform branch, not a select over all tiles.
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, N>(f);
+  }
+}
+
+template <int NT>
+__global__ __launch_bounds__(512) void patch_invert_mfma_kernel(const int64_t* __restrict__ patch_ptr,
+                                                                 const int64_t* __restrict__ inv_ptr,
+                                                                 double* __restrict__ inv, int* __restrict__ status) {
+  constexpr int N = 16 * NT;
+  constexpr int NA = (NT + 3) / 4;            // tile rows per wave (ti = 4 a + wr)
+  constexpr int NB = (NT + 1) / 2;            // tile columns per wave (tj = 2 b + wc)
+  __shared__ double Rraw[2][4][N];            // raw row panel   A[K, :]
+  __shared__ double Craw[2][N][4];            // raw column panel A[:, K]
+  const int64_t p = blockIdx.x;
+  const int n = (int)(patch_ptr[p + 1] - patch_ptr[p]);
+  const int ld = (n + 1) & ~1;
+  double* S = inv + inv_ptr[p];
+  // wave index as an SGPR value: the conditions below become scalar branches
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int lm = lane & 15, lk = lane >> 4;
+  inv_d4 acc[NA][NB];
+#pragma unroll
+  for (int a = 0; a < NA; ++a)
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      const int ti = 4 * a + wr, tj = 2 * b + wc;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int r = 16 * ti + lk + 4 * g, c = 16 * tj + lm;
+        acc[a][b][g] = (r < n && c < n) ? S[(int64_t)r * ld + c] : (r == c ? 1.0 : 0.0);
+      }
+    }
+  __syncthreads();  // all loads done before anyone stores (the result goes back in place, in another layout)
+  bool bad = false;
+  static_for<0, NT>([&](auto TK) __attribute__((always_inline)) {
+    constexpr int tk = decltype(TK)::value;   // the pivot tile: a compile-time constant, so is every accumulator index below
+    if (16 * tk >= n) return;                 // uniform: the remaining pivots are identity padding
+    const bool own_r = (tk & 3) == wr, own_c = (tk & 1) == wc;     // wave-uniform
+    constexpr int ar = tk >> 2, bc = tk >> 1; // my tile index of tile row / column tk (when I own it)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int s = 4 * tk + q;
+      if (4 * s >= n) continue;               // uniform
+      const int buf = s & 1;
+      const bool colgrp = (lm >> 2) == q;     // lanes holding the columns K of a tile of tile column tk (as C/D columns) and
+                                              // the rows K of a tile of tile row tk (as A-operand rows)
+      // ---- raw panels -> LDS
+      if (own_r) {
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+          if (2 * b + wc < NT) Rraw[buf][lk][16 * (2 * b + wc) + lm] = acc[ar][b][q];
+      }
+      if (own_c && colgrp) {
+#pragma unroll
+        for (int a = 0; a < NA; ++a)
+          if (4 * a + wr < NT) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) Craw[buf][16 * (4 * a + wr) + lk + 4 * g][lm & 3] = acc[a][bc][g];
+          }
+      }
+      __syncthreads();
+      // ---- LU of the pivot block, redundantly on every lane (no second barrier)
+      double d[4][4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) d[i][j] = Rraw[buf][i][4 * s + j];
+      Lu4 f;
+      lu4(d, f, bad);
+      // ---- operands of the rank-4 update  A <- A - sum_t c_t r_t^T  (the four scalar Gauss-Jordan steps, delayed).
+      //      Lane (lm, lk) needs r_lk of its columns and c_lk of its rows only: r = diag(1 / U_tt) L^-1 x and c = x S^-1 with
+      //      S = the unit upper triangular diag(U)^-1 U.  Both triangular inverses are formed explicitly (6 entries each, per
+      //      step) and every operand is a 4-term dot product with the lane's own coefficients -- the forward substitutions per
+      //      operand were most of the FP64 VALU work of a step.  (Triangular factors of an unpivoted LU without growth are
+      //      well conditioned even where D itself is not.)
+      const double m10 = -f.l10, m21 = -f.l21, m32 = -f.l32;             // L^-1
+      const double m20 = __builtin_fma(f.l21, f.l10, -f.l20), m31 = __builtin_fma(f.l32, f.l21, -f.l31);
+      const double m30 = __builtin_fma(-m32, f.l20, __builtin_fma(-m31, f.l10, -f.l30));
+      const double li0 = sel4(lk, 1.0, m10, m20, m30), li1 = sel4(lk, 0.0, 1.0, m21, m31), li2 = sel4(lk, 0.0, 0.0, 1.0, m32),
+                   li3 = lk == 3 ? 1.0 : 0.0;                             // row lk of L^-1
+      const double isel = sel4(lk, f.i0, f.i1, f.i2, f.i3);
+      const double rc0 = li0 * isel, rc1 = li1 * isel, rc2 = li2 * isel, rc3 = li3 * isel;
+      const double t01 = -f.s01, t12 = -f.s12, t23 = -f.s23;             // S^-1 (unit upper)
+      const double t02 = __builtin_fma(f.s01, f.s12, -f.s02), t13 = __builtin_fma(f.s12, f.s23, -f.s13);
+      const double t03 = __builtin_fma(-t02, f.s23, __builtin_fma(-t01, f.s13, -f.s03));
+      const double cc0 = sel4(lk, 1.0, t01, t02, t03), cc1 = sel4(lk, 0.0, 1.0, t12, t13), cc2 = sel4(lk, 0.0, 0.0, 1.0, t23),
+                   cc3 = lk == 3 ? 1.0 : 0.0;                             // column lk of S^-1
+      double bop[NB], aop[NA], vop[NA];
+#pragma unroll
+      for (int b = 0; b < NB; ++b) {
+        const int tj = 2 * b + wc;
+        bop[b] = 0.0;
+        if (tj < NT) {
+          const int c = 16 * tj + lm;
+          const double rv = __builtin_fma(rc3, Rraw[buf][3][c], __builtin_fma(rc2, Rraw[buf][2][c],
+                            __builtin_fma(rc1, Rraw[buf][1][c], rc0 * Rraw[buf][0][c])));
+          bop[b] = (tj == tk && colgrp) ? 0.0 : rv;                      // columns K: left to the fix-up
+        }
+      }
+#pragma unroll
+      for (int a = 0; a < NA; ++a) {
+        const int ti = 4 * a + wr;
+        aop[a] = vop[a] = 0.0;
+        if (ti < NT) {
+          const int i = 16 * ti + lm;
+          const double cv = __builtin_fma(cc3, Craw[buf][i][3], __builtin_fma(cc2, Craw[buf][i][2],
+                            __builtin_fma(cc1, Craw[buf][i][1], cc0 * Craw[buf][i][0])));
+          aop[a] = (ti == tk && colgrp) ? 0.0 : cv;                      // rows K: left to the fix-up
+          vop[a] = cv * isel;                                            // (A[:, K] U^-1)[row][lk]
+        }
+      }
+#pragma unroll
+      for (int a = 0; a < NA; ++a)
+        if (4 * a + wr < NT) {
+#pragma unroll
+          for (int b = 0; b < NB; ++b)
+            if (2 * b + wc < NT) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(-aop[a], bop[b], acc[a][b], 0, 0, 0);
+        }
+      // ---- columns K <- - A[:, K] D^-1 = - (A[:, K] U^-1) L^-1 (rows outside K): one more MFMA per tile of tile column tk,
+      //      A-operand v = A[:, K] U^-1 (the c_t scaled by 1 / U_tt), B-operand - L^-1 (unit lower triangular, explicit: 6
+      //      entries) placed on the columns K of the tile.  A[K, K] <- D^-1 = U^-1 L^-1 on the 16 lanes that hold it.
+      //      (Triangular solves per ENTRY instead -- 80 dependent chains per step on a quarter of the lanes -- made the
+      //      kernel slower than the rank-1 register kernel it replaces: 22 against 18 ms at config 4's level 2.)
+      if (own_c) {
+        const int cq = lm & 3;
+        const double b2 = colgrp ? -sel4(cq, li0, li1, li2, li3) : 0.0;
+        double dkk = 0.0;                                                 // D^-1[lk][cq]
+        {
+          const double x[4] = {lk == 0 ? 1.0 : 0.0, lk == 1 ? 1.0 : 0.0, lk == 2 ? 1.0 : 0.0, lk == 3 ? 1.0 : 0.0};
+          double w[4];
+          times_dinv(f, x, w);
+          dkk = sel4(cq, w[0], w[1], w[2], w[3]);
+        }
+#pragma unroll
+        for (int a = 0; a < NA; ++a)
+          if (4 * a + wr < NT) {
+            const inv_d4 zero = {0.0, 0.0, 0.0, 0.0};
+            const inv_d4 t = __builtin_amdgcn_mfma_f64_16x16x4f64(vop[a], b2, zero, 0, 0, 0);
+            if (colgrp) {
+              const bool pivot_tile = (4 * a + wr) == tk;
+#pragma unroll
+              for (int g = 0; g < 4; ++g) acc[a][bc][g] = (pivot_tile && g == q) ? dkk : t[g];   // rows K of the pivot tile: g == q
+            }
+          }
+      }
+      // ---- rows K <- D^-1 A[K, :] (columns outside K): register q of the tiles of tile row tk
+      if (own_r) {
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+          const bool in_k = (2 * b + wc) == tk && colgrp;
+          if (2 * b + wc < NT) {
+            const int c = 16 * (2 * b + wc) + lm;
+            const double x[4] = {Rraw[buf][0][c], Rraw[buf][1][c], Rraw[buf][2][c], Rraw[buf][3][c]};
+            double r[4], z[4];
+            row_panel(f, x, r, z);                                        // two triangular solves: D^-1 is never formed
+            if (!in_k) acc[ar][b][q] = sel4(lk, z[0], z[1], z[2], z[3]);   // (D^-1 A[K, :])[lk][c]
+          }
+        }
+      }
+    }
+  });
+  if (bad && threadIdx.x == 0) atomicExch(status, 1);
+#pragma unroll
+  for (int a = 0; a < NA; ++a)
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      const int ti = 4 * a + wr, tj = 2 * b + wc;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int r = 16 * ti + lk + 4 * g, c = 16 * tj + lm;
+        // r == n < ld: the padding row; it stayed zero through the elimination and must be stored (the apply reads row pairs)
+        if (ti < NT && tj < NT && r < ld && c < n) S[patch_inv_index(r, c, n, ld)] = (r < n) ? acc[a][b][g] : 0.0;
+      }
+    }
+}
+
+}  // namespace
+
+// in-place inversion (row-major n x ld in, row-piece layout out) of patches with 33 .. 160 dofs on the matrix cores;
+// returns 1 if the sizes are handled here, 0 if the caller should use the register kernel
+int launch_patch_invert_mfma(alfi_ctx* ctx, int64_t npatch, int max_np, const int64_t* patch_ptr, const int64_t* inv_ptr,
+                             double* inv, int* status, int* handled) {
+  static const bool allow = !(getenv("ALFI_INVERT_MFMA") && atoi(getenv("ALFI_INVERT_MFMA")) == 0);
+  *handled = 0;
+  if (!allow || max_np <= 32 || max_np > 160) return 0;
+  dim3 grid((unsigned)npatch), block(512);
+  if (max_np <= 64)
+    hipLaunchKernelGGL(patch_invert_mfma_kernel<4>, grid, block, 0, ctx->stream, patch_ptr, inv_ptr, inv, status);
+  else if (max_np <= 96)
+    hipLaunchKernelGGL(patch_invert_mfma_kernel<6>, grid, block, 0, ctx->stream, patch_ptr, inv_ptr, inv, status);
+  else if (max_np <= 128)
+    hipLaunchKernelGGL(patch_invert_mfma_kernel<8>, grid, block, 0, ctx->stream, patch_ptr, inv_ptr, inv, status);
+  else
+    hipLaunchKernelGGL(patch_invert_mfma_kernel<10>, grid, block, 0, ctx->stream, patch_ptr, inv_ptr, inv, status);
+  ALFI_HIP_CHECK(ctx, hipGetLastError());
+  *handled = 1;
+  return 0;
+}

@@ -572,6 +572,11 @@ int launch_patch_invert_arrays(alfi_ctx* ctx, int64_t npatch, int max_np, const 
                                const int64_t* inv_ptr, double* inv, int* status) {
   if (npatch == 0) return 0;
   if (max_np <= 32) return launch_invert_small_any(ctx, max_np, npatch, patch_ptr, inv_ptr, 0, 0, inv, status);
+  {
+    int handled = 0;       // 33 .. 160 dofs: block Gauss-Jordan on the FP64 matrix cores (kernels_invert.hip)
+    ALFI_CHECK(launch_patch_invert_mfma(ctx, npatch, max_np, patch_ptr, inv_ptr, inv, status, &handled));
+    if (handled) return 0;
+  }
   dim3 grid((unsigned)npatch), block(256);
   if (max_np <= 112)
     hipLaunchKernelGGL(patch_invert_big_kernel<7>, grid, block, 0, ctx->stream, patch_ptr, inv_ptr, inv, status);

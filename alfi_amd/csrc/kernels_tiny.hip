@@ -128,30 +128,55 @@ __device__ __forceinline__ void tiny_spmv(const TinyArgs& a, const double* __res
   }
 }
 
-// stage <- inv(A_p) x_p for every patch: G lanes per patch (a power of two <= 64), lane l owns the row pairs 2l, 2l + 2G, ...
-// of the row-piece layout (patch_inv_index); x_p read through the caches (the lanes of a group read the same address)
+// stage <- inv(A_p) x_p for every patch: G lanes per patch (a power of two, 8 .. 64, 2 G >= max_np / 2 ... see the launcher),
+// lane l owns the row pairs 2l, 2l + 2G, ... of the row-piece layout (patch_inv_index).  x_p is fetched ONCE per group -- lane
+// l loads the entries l, l + G, l + 2G, l + 3G -- and broadcast by shuffles, so that a patch costs two dependent global
+// loads (index, value) and then only independent loads of the inverse: with one workgroup on the whole level nothing else
+// hides the latency of a longer chain.
 __device__ __forceinline__ void tiny_patch_solve(const TinyArgs& a, const double* __restrict__ x) {
   const int G = a.G;
   const int l = threadIdx.x & (G - 1);
   const int per_pass = TINY_THREADS / G;
-  for (int64_t p = threadIdx.x / G; p < a.npatch; p += per_pass) {
-    const int64_t off = a.patch_ptr[p];
-    const int n = (int)(a.patch_ptr[p + 1] - off);
+  const int64_t npass = (a.npatch + per_pass - 1) / per_pass;
+  for (int64_t pass = 0; pass < npass; ++pass) {          // uniform trip count: the shuffles need all lanes
+    const int64_t p = pass * per_pass + threadIdx.x / G;
+    const bool live = p < a.npatch;
+    int n = 0;
+    int64_t off = 0;
+    if (live) {
+      off = a.patch_ptr[p];
+      n = (int)(a.patch_ptr[p + 1] - off);
+    }
     const int ld = (n + 1) & ~1;
-    const double* ip = a.inv + a.inv_ptr[p];
-    double* st = a.stage + a.stage_ptr[p];
-    for (int r = 2 * l; r < ld; r += 2 * G) {
-      const double* base = ip + patch_inv_index(r, 0, n, ld);
-      const int rows = (int)(patch_inv_index(r, 1, n, ld) - patch_inv_index(r, 0, n, ld));
+    double xr[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) xr[u] = (l + u * G < n) ? x[a.patch_dofs[off + l + u * G]] : 0.0;
+    const double* ip = a.inv + (live ? a.inv_ptr[p] : 0);
+    double* st = a.stage + (live ? a.stage_ptr[p] : 0);
+    int nmax = n;                                          // longest patch among the groups of this wave
+    for (int o = G; o < 64; o <<= 1) nmax = max(nmax, __shfl_xor(nmax, o));
+    const int npairs = (nmax + 2 * G - 1) / (2 * G);       // row-pair rounds (1 up to 2 G dofs)
+    for (int rp = 0; rp < npairs; ++rp) {
+      const int r = 2 * l + rp * 2 * G;
+      const bool active = live && r < ld;
+      const double* base = ip;
+      int rows = 2;
+      if (active) {
+        base = ip + patch_inv_index(r, 0, n, ld);
+        rows = (int)(patch_inv_index(r, 1, n, ld) - patch_inv_index(r, 0, n, ld));
+      }
       double acc0 = 0.0, acc1 = 0.0;
-      int c = 0;
-      for (; c + 4 <= n; c += 4) {
+      for (int c0 = 0; c0 < nmax; c0 += 4) {
         double2 v[4];
         double xc[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-          xc[u] = x[a.patch_dofs[off + c + u]];
-          v[u] = *reinterpret_cast<const double2*>(base + (int64_t)(c + u) * rows);
+          const int c = c0 + u;
+          const int src = c & (G - 1), which = c / G;      // entry c sits in register `which` of lane `src` of the group
+          const double x0 = __shfl(xr[0], src, G), x1 = __shfl(xr[1], src, G), x2 = __shfl(xr[2], src, G),
+                       x3 = __shfl(xr[3], src, G);
+          xc[u] = which == 0 ? x0 : which == 1 ? x1 : which == 2 ? x2 : x3;
+          v[u] = (active && c < n) ? *reinterpret_cast<const double2*>(base + (int64_t)c * rows) : make_double2(0.0, 0.0);
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -159,13 +184,7 @@ __device__ __forceinline__ void tiny_patch_solve(const TinyArgs& a, const double
           acc1 = __builtin_fma(v[u].y, xc[u], acc1);
         }
       }
-      for (; c < n; ++c) {
-        const double xc = x[a.patch_dofs[off + c]];
-        const double2 v = *reinterpret_cast<const double2*>(base + (int64_t)c * rows);
-        acc0 = __builtin_fma(v.x, xc, acc0);
-        acc1 = __builtin_fma(v.y, xc, acc1);
-      }
-      *reinterpret_cast<double2*>(st + r) = make_double2(acc0, acc1);
+      if (active) *reinterpret_cast<double2*>(st + r) = make_double2(acc0, acc1);
     }
   }
 }
@@ -175,6 +194,10 @@ __global__ __launch_bounds__(TINY_THREADS) void smooth_tiny_kernel(TinyArgs a) {
   __shared__ double red[TINY_WAVES][TINY_NV];
   __shared__ double sums[TINY_NV];
   __shared__ double ysol[TINY_NV];
+  // the Hessenberg / Givens data of the call lives in LDS: its recurrences run on ONE thread while the others wait at the
+  // next barrier, and in global memory every dependent access of that chain costs a microsecond (measured: 38 us per
+  // iteration on a 1 250-dof level, most of it this chain)
+  __shared__ double hsl[8 + TINY_NV * (TINY_NV + 1) + 6 * TINY_NV + 8];
   const int t = threadIdx.x;
   const int64_t n = a.n;
   const int k = a.k, K = a.K;
@@ -205,11 +228,11 @@ __global__ __launch_bounds__(TINY_THREADS) void smooth_tiny_kernel(TinyArgs a) {
     const double f = tt != 0.0 ? 1.0 / tt : 0.0;
     if (t == 0) {
       if (j == 0) {                       // beta = |r0|, rotated rhs = beta e_1
-        a.hs[hl.beta] = tt;
-        a.hs[hl.grs] = tt;
-        for (int i = 1; i <= K; ++i) a.hs[hl.grs + i] = 0.0;
+        hsl[hl.beta] = tt;
+        hsl[hl.grs] = tt;
+        for (int i = 1; i <= K; ++i) hsl[hl.grs + i] = 0.0;
       } else {
-        hessenberg_column(a.hs, K, j - 1, sums, tt);      // sums = the dots h of iteration j - 1 (untouched since)
+        hessenberg_column(hsl, K, j - 1, sums, tt);       // sums = the dots h of iteration j - 1 (untouched since)
       }
     }
     tiny_patch_solve(a, a.w);                                           // stage <- patch solves of w
@@ -264,11 +287,12 @@ __global__ __launch_bounds__(TINY_THREADS) void smooth_tiny_kernel(TinyArgs a) {
     }
   }
   if (t == 0) {
-    hessenberg_column(a.hs, K, k - 1, sums, sqrt(norm2));
-    fgmres_back_substitution(a.hs, k, K);
-    for (int v = 0; v < k; ++v) ysol[v] = a.hs[hl.y + v];
+    hessenberg_column(hsl, K, k - 1, sums, sqrt(norm2));
+    fgmres_back_substitution(hsl, k, K);
+    for (int v = 0; v < k; ++v) ysol[v] = hsl[hl.y + v];
   }
   __syncthreads();
+  for (int i = t; i < hl.total; i += TINY_THREADS) a.hs[i] = hsl[i];     // (the level's array mirrors the last call, as elsewhere)
   for (int64_t i = t; i < n; i += TINY_THREADS) {                       // x += Z y
     double xi = a.x[i];
 #pragma unroll
@@ -298,8 +322,8 @@ int launch_smooth_tiny(alfi_level* L, int k, const double* db, double* dx, int n
   int lpr = 2;
   while (lpr < 64 && 2 * lpr <= avg) lpr <<= 1;          // ~2 blocks per lane: short dependent chains, few idle lanes
   a.lpr = lpr;
-  int G = 1;
-  while (G < 64 && 2 * G < L->max_np) G <<= 1;           // one row pair per lane up to 128 dofs, two beyond
+  int G = 8;
+  while (G < 64 && 4 * G < L->max_np) G <<= 1;           // four x entries per lane: G >= max_np / 4 (max_np <= 160 -> G <= 64)
   a.G = G;
   a.pou = L->pou ? 1 : 0;
   a.rowptr = L->A_own.rowptr;

@@ -219,11 +219,15 @@ __global__ __launch_bounds__(256) void bsr_spmv_dedup_kernel(int64_t nnzb, int64
                                                               const double* __restrict__ x, double* __restrict__ y,
                                                               const double* __restrict__ b, double alpha, int mode,
                                                               double* __restrict__ carry_out,
-                                                              int32_t* __restrict__ carry_row) {
+                                                              int32_t* __restrict__ carry_row, int xcd_map) {
   constexpr int BB = BS * BS;
   __shared__ double xs[SPMV_DEDUP_MAX * BS];
   const int lane = threadIdx.x & 63;
-  const int64_t g = blockIdx.x;
+  int64_t g = blockIdx.x;
+  if (xcd_map) {      // workgroup b runs on XCD b % 8: give every XCD (= every L2) one contiguous eighth of the groups
+    const int64_t nb = gridDim.x, per = nb >> 3, rem = nb & 7, xcd = g & 7, idx = g >> 3;
+    g = xcd * per + (xcd < rem ? xcd : rem) + idx;
+  }
   const int64_t chunk = g * 4 + (threadIdx.x >> 6);
   const bool active = chunk < nchunks;
   const int64_t base = chunk * SPMV_CHUNK;
@@ -513,7 +517,7 @@ static int launch_bsr_spmv_bs(alfi_ctx* ctx, const DevBSR& A, const double* x, d
     if (A.dedup && !A.view && A.kbase == 0)
       hipLaunchKernelGGL((bsr_spmv_dedup_kernel<BS>), dim3((unsigned)((nchunks + 3) / 4)), dim3(256), 0, ctx->stream,
                          A.nnzb, nchunks, A.lidx, A.ucol, A.uptr, A.colidx, A.vals, A.chunk_row, x, y, b, alpha, mode,
-                         A.carry, A.carry_row);
+                         A.carry, A.carry_row, xcd);
     else if (nt)
       hipLaunchKernelGGL((bsr_spmv_flat_kernel<BS, true, false>), dim3((unsigned)((nchunks + 3) / 4)), dim3(256), 0,
                          ctx->stream, A.kbase, A.nnzb, nchunks, (const int64_t*)nullptr, A.colidx, A.vals, A.chunk_row, x,

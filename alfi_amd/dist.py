@@ -922,8 +922,8 @@ def _dist_ns_solver_class():
 
     class DistNavierStokesSolver(HipNavierStokesSolver):
         """HipNavierStokesSolver with the device side on partitioned levels (one process per GPU): DistMultigrid + DistSaddle.
-        Every rank rediscretises the global operators on its host cores (as every rank generates the global hierarchy) and
-        uploads its own rows; the Newton state is replicated, the update of each linear solve gathered from its owners."""
+        Every rank rediscretises ITS OWN rows of the level operators on its host cores (``_rediscretise``) and uploads them;
+        the Newton state is replicated, the update of each linear solve gathered from its owners."""
 
         def __init__(self, *args, min_dofs=400000, group=None, **kwargs):
             self._min_dofs, self._group = min_dofs, group
@@ -941,6 +941,21 @@ def _dist_ns_solver_class():
 
         def _push_operators(self):
             self.dmg.update(self.levels)
+
+        def _rediscretise(self, u, adv):
+            """Every rank assembles ITS rows only: the level operators become lazy (alfi_amd.lazy.LazyOperator: sparsity now,
+            values of a row subset on demand) and DistMultigrid.update cuts the rank's rows out of them -- one rank per mesh
+            partition assembling its own cells, as in the reference (alfi/solver.py:604-605).  SUPG terms are assembled by
+            the global host pass and keep the replicated path."""
+            if self.supg:
+                return super()._rediscretise(u, adv)
+            from .lazy import LazyOperator
+            for L, w in zip(self.levels, self._winds(u)):
+                V = L.V
+                L.A = LazyOperator(V, L.A.rowptr, L.A.colidx, V.mesh.cell_geometry(), V.element.reference_tensors(), self.nu,
+                                   self.gamma, adv, np.ascontiguousarray(w))
+                L.nu = self.nu
+            self._push_operators()
 
         def _set_parameters(self):
             # transfers present on this rank link local levels lmin.. ; their (nu, gamma) follow the solver's

@@ -184,6 +184,37 @@ class Level(object):
         vals = np.ascontiguousarray(vals, dtype=np.float64)
         self.ctx.check(self.ctx.lib.alfi_level_update_values(self.h, _ptr(vals)))
 
+    def set_assembly(self, V, K_vals, D_vals, rowptr, colidx):
+        """Hand the level what the device-side operator refresh needs (alfi_level_set_assembly): the cells of the nodal
+        space ``V`` (alfi_amd.fespace), the advection tensor of its element and the state-independent parts K (viscous) and
+        D (grad-div) of the operator, both (nnzb, bs, bs) on the level's sparsity."""
+        from . import _hostlib
+        g, vol = V.mesh.cell_geometry()
+        T1 = np.ascontiguousarray(V.element.reference_tensors()["T1"], dtype=np.float64)     # [k, i, b, a]
+        Ta = np.ascontiguousarray(np.transpose(T1, (2, 3, 0, 1)))                            # [b, a, k, i]
+        Tb = np.ascontiguousarray(np.transpose(T1, (0, 3, 1, 2)))                            # [b, a, i, k] = T1[b, i, k, a]
+        cn = np.ascontiguousarray(V.cell_nodes, dtype=np.int32)
+        cptr, ccell, cba = _hostlib.contributors(cn, V.num_nodes, rowptr, colidx)
+        g = np.ascontiguousarray(g, dtype=np.float64)
+        vol = np.ascontiguousarray(vol, dtype=np.float64)
+        K = np.ascontiguousarray(K_vals, dtype=np.float64)
+        D = np.ascontiguousarray(D_vals, dtype=np.float64)
+        self.ctx.check(self.ctx.lib.alfi_level_set_assembly(self.h, cn.shape[0], cn.shape[1], _ptr(cn), _ptr(g), _ptr(vol),
+                                                            _ptr(Ta), _ptr(Tb), _ptr(K), _ptr(D), _ptr(cptr), _ptr(ccell),
+                                                            _ptr(cba)))
+
+    def assemble(self, nu, gamma, adv, state=None, apply_bc=True):
+        """A = nu K + gamma D + adv N(state) written into the level's operator on the device (alfi_level_assemble);
+        ``state``: DeviceVec / RawVec with the level's nodal field.  The patches must be factored again afterwards."""
+        self.ctx.check(self.ctx.lib.alfi_level_assemble(self.h, float(nu), float(gamma), float(adv),
+                                                        state.ptr if state is not None else None, 1 if apply_bc else 0))
+
+    def get_values(self):
+        """The operator values in the host layout (nnzb, bs, bs)."""
+        out = np.empty((self.nnzb, self.bs, self.bs))
+        self.ctx.check(self.ctx.lib.alfi_level_get_values(self.h, _ptr(out)))
+        return out
+
     def set_patches(self, patch_ptr, patch_dofs):
         pp = np.ascontiguousarray(patch_ptr, dtype=np.int64)
         pd = np.ascontiguousarray(patch_dofs, dtype=np.int32)

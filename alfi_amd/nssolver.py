@@ -41,10 +41,20 @@ class HipNavierStokesSolver(object):
 
     def __init__(self, problem, nref, k, gamma=1e4, smoothing=None, restriction=False, ctx=None, verbose=False,
                  snes_rtol=None, snes_atol=None, snes_stol=1e-6, snes_max_it=20, discretisation="pkp0", stabilisation_type=None,
-                 stabilisation_weight=None, supg_magic=9.0):
+                 stabilisation_weight=None, supg_magic=9.0, device_assembly=None):
         """discretisation: "pkp0" ([P_k(+FB)]^d - P0 on the uniform hierarchy, ConstantPressureSolver solver.py:561-602) or
-        "sv" ([P_k]^d - P_{k-1}^dg on the barycentric hierarchy with macro-star patches, ScottVogeliusSolver :604-662)."""
+        "sv" ([P_k]^d - P_{k-1}^dg on the barycentric hierarchy with macro-star patches, ScottVogeliusSolver :604-662).
+        device_assembly: refresh the level operators of every Newton step ON THE DEVICE (alfi_level_assemble: what
+        PatchPC.update does inside PCPATCH, solver.py:320, 325) instead of rediscretising on the host and re-uploading;
+        default: on, unless SUPG is requested (its terms are assembled by the host generator) or ALFI_DEVICE_ASSEMBLY=0."""
+        import os
         self.problem, self.gamma, self.verbose = problem, float(gamma), verbose
+        if device_assembly is None:
+            device_assembly = os.environ.get("ALFI_DEVICE_ASSEMBLY", "1") != "0" and stabilisation_type in ("none", None)
+        if device_assembly and stabilisation_type not in ("none", None):
+            raise NotImplementedError("device assembly covers the viscous, grad-div and advection terms; SUPG is host-assembled")
+        self.device_assembly = bool(device_assembly)
+        self.timings = {"assemble_s": 0.0, "factor_s": 0.0, "residual_s": 0.0, "solve_s": 0.0, "newton_steps": 0}
         self._ctx_arg = ctx
         dim = problem.dim
         self.sv = discretisation == "sv"
@@ -85,6 +95,14 @@ class HipNavierStokesSolver(object):
             self.B, self.vol = build_pressure_coupling(L)                     # Dirichlet columns zeroed: the Jacobian's B
             self.B_raw, _ = build_pressure_coupling(L, zero_bc_columns=False)  # all columns: the residual's B
         self._create_device(restriction)
+        self._asm_ready = False
+        if self.device_assembly:
+            if not hasattr(self, "hmg") or any(T.inject_map is None for T in self.transfers):
+                # partitioned levels (alfi_amd.dist) and the non-nested barycentric hierarchy (point-evaluation inject) keep
+                # the host path
+                self.device_assembly = False
+            else:
+                self._setup_device_assembly()
         self.rtol, self.atol = self.params["ksp_rtol"], self.params["ksp_atol"]
         tol2, tol3 = (1e-9, 1e-8), (1e-8, 1e-8)                            # snes_rtol / snes_atol, solver.py:484-499
         self.snes_rtol = snes_rtol if snes_rtol is not None else (tol2 if dim == 2 else tol3)[0]
@@ -112,6 +130,57 @@ class HipNavierStokesSolver(object):
         self.hmg.update(self.levels)
         self.hmg.mg.levels[0].update_values(self.levels[0].A.vals)
         self.hmg.mg.levels[0].coarse_factor_auto()
+
+    # -- operator refresh on the device ---------------------------------------------------------------------------------------
+    def _setup_device_assembly(self):
+        """Once: the state-independent parts K (viscous, nu = 1) and D (grad-div, gamma = 1) of every level operator, the cells
+        and the contributor lists go to the device (alfi_level_set_assembly); per-level state vectors for the injected field."""
+        self._dstate = []
+        for L, dl in zip(self.levels, self.hmg.mg.levels):
+            K = _assemble(L, 1.0, 0.0, 0.0, None, False, self.sv)
+            D = _assemble(L, 0.0, 1.0, 0.0, None, False, self.sv)
+            dl.set_assembly(L.V, K, D, L.A.rowptr, L.A.colidx)
+            self._dstate.append(self.ctx.vec(L.n))
+        self._dres = self.ctx.vec(self.levels[-1].n)
+        self._asm_ready = True
+
+    def _device_states(self, u):
+        """Current velocity on every level, on the device: the finest uploaded, the coarser ones by inject (solver.py:595)."""
+        self._dstate[-1].set(u)
+        for l in range(len(self.levels) - 1, 0, -1):
+            self.hmg.mg.transfers[l - 1].inject(self._dstate[l], self._dstate[l - 1])
+
+    def _rediscretise_device(self, u, adv):
+        t0 = time.time()
+        self._device_states(u)
+        mgl = self.hmg.mg.levels
+        for dl, st in zip(mgl, self._dstate):
+            dl.assemble(self.nu, self.gamma, adv, st if adv else None, True)
+        self.ctx.sync()
+        t1 = time.time()
+        for L, dl in zip(self.levels, mgl):
+            L.nu = self.nu
+            if L.level > 0:
+                dl.factor_with_fallback()
+        mgl[0].coarse_factor_auto()
+        self.ctx.sync()
+        self.timings["assemble_s"] += t1 - t0
+        self.timings["factor_s"] += time.time() - t1
+
+    def _residual_device(self, u, p, adv):
+        """F_u = (nu K + gamma D) u + 1/2 N(u) u + B^T p - f: one product with the operator assembled with HALF the advection
+        term and without boundary conditions (N(u) u = 2 (u . grad) u); the Jacobian is assembled over it before the solve."""
+        L = self.levels[-1]
+        fin = self.hmg.mg.levels[-1]
+        self._dstate[-1].set(u)
+        fin.assemble(self.nu, self.gamma, 0.5 * adv, self._dstate[-1] if adv else None, False)
+        fin.spmv(self._dstate[-1], self._dres)
+        Fu = self._dres.get()
+        Fu += self.B_raw.T @ p
+        if self._load is not None:
+            Fu -= self._load
+        Fu[L.bc_dofs] = 0.0
+        return Fu, self.B_raw @ u
 
     def _set_parameters(self):
         for T, dt in zip(self.transfers, self.hmg.mg.transfers):            # AutoSchoeberlTransfer.rebuild, transfer.py:173-184
@@ -154,6 +223,8 @@ class HipNavierStokesSolver(object):
         return A
 
     def _rediscretise(self, u, adv):
+        if self.device_assembly:
+            return self._rediscretise_device(u, adv)
         winds = self._winds(u)
         for L, w in zip(self.levels, winds):
             L.A = BSR(L.A.nbrows, L.A.nbcols, L.bs, L.A.rowptr, L.A.colidx, self.level_values(L, w, adv, True))
@@ -162,6 +233,8 @@ class HipNavierStokesSolver(object):
 
     def residual(self, u, p, adv):
         """F(u, p) of solver.py:565-568 (rhs = 0), Dirichlet rows zeroed (``bc.zero(F)``, solver.py:282-286)."""
+        if self.device_assembly:
+            return self._residual_device(u, p, adv)
         L = self.levels[-1]
         d = self.problem.dim
         wind = np.ascontiguousarray(u.reshape(-1, d))
@@ -200,19 +273,26 @@ class HipNavierStokesSolver(object):
             self._load = load_vector(self.levels[-1].V, lambda x: self.problem.rhs(x, re))
         u, p = self.u.copy(), self.p.copy()
         lin_its, newton_its = 0, 0
+        t_r = time.time()
         Fu, Fp = self.residual(u, p, adv)
+        self.timings["residual_s"] += time.time() - t_r
         f0 = fnorm = float(np.sqrt(Fu @ Fu + Fp @ Fp))
         hist = [fnorm]
         small_step = False
         while fnorm > max(self.snes_rtol * f0, self.snes_atol) and newton_its < self.snes_max_it and not small_step:
             self._rediscretise(u, adv)
             rhs = -np.concatenate([Fu, Fp])
+            t_s = time.time()
             delta, its, rn = self._linear_solve(rhs)
+            self.timings["solve_s"] += time.time() - t_s
             u += delta[:self.n_u]
             p += delta[self.n_u:]
             lin_its += its
             newton_its += 1
+            self.timings["newton_steps"] += 1
+            t_r = time.time()
             Fu, Fp = self.residual(u, p, adv)
+            self.timings["residual_s"] += time.time() - t_r
             fnorm = float(np.sqrt(Fu @ Fu + Fp @ Fp))
             hist.append(fnorm)
             # SNESConvergedDefault [3P] with snes_stol (solver.py:490, 498): the step is small relative to the iterate

@@ -199,7 +199,18 @@ def main_distributed(args, rank, world, local_rank):
     stage("host_generation")
     t0 = time.time()
     lazy = CONFIGS[args.config][0] != "sv" and os.environ.get("ALFI_DIST_GLOBAL_GENERATION") != "1"
-    lv, tr, k = build_problem(args.config, args.verbose and rank == 0, lazy=lazy)
+    # the integer side is generated ONCE per node (rank 0, with all of the job's host threads) and mapped copy-on-write by
+    # the other ranks (alfi_amd.shared); ALFI_DIST_SHARED_GENERATION=0: every rank generates its own copy
+    shared = world > 1 and os.environ.get("ALFI_DIST_SHARED_GENERATION", "1") != "0"
+    if shared:
+        from alfi_amd import _hostlib
+        from alfi_amd.shared import build_shared
+        nthr = lambda n: _hostlib.lib().alfi_host_set_num_threads(int(n))
+        lv, tr, k = build_shared(lambda: build_problem(args.config, args.verbose, lazy=lazy), rank, dist.barrier,
+                                 "%s_%s" % (os.environ.get("MASTER_PORT", "0"), args.config), set_threads=nthr,
+                                 all_threads=cpu_share(), my_threads=max(1, cpu_share() // world))
+    else:
+        lv, tr, k = build_problem(args.config, args.verbose and rank == 0, lazy=lazy)
     t_gen = time.time() - t0
 
     t0 = time.time()
@@ -332,7 +343,8 @@ def main_distributed(args, rank, world, local_rank):
                        "cycle": "V(k,k), 1 cycle per step", "robust_restriction": bool(args.restriction),
                        "parallelism": "mesh partition over %d GPUs (Morton boxes, RCCL halos + all-reduce)" % world,
                        "backend": backend, "transport": dmg.transport,
-                       "generation": "rank-local (alfi_amd.lazy)" if lazy else "global on every rank",
+                       "generation": ("integers once per node, shared through /dev/shm; " if shared else "integers on every rank; ")
+                                     + ("values rank-local (alfi_amd.lazy)" if lazy else "values global"),
                        "distributed_levels": [int(p.level) for p in dmg.parts if p.distributed]},
             "dof_smooths_per_s": L.n * 2 * k * vps,
             "roofline": {"kernel": apply_kernel_name(L), "bound": "hbm", "achieved": local_gbs, "peak": HBM_PEAK_GBS,
@@ -611,7 +623,8 @@ def main():
     # warm-up + the same number of steps without events; reported next to the headline, never as `value`
     other = dmg.variant(robust_restriction=not args.restriction)
     dxo = ctx.vec(L.n)
-    other.vcycle(db, dxo)
+    for _ in range(max(args.warmup, 1)):       # (the host work in between lets the clocks drop: warm up again)
+        other.vcycle(db, dxo)
     ctx.sync()
     t0 = time.perf_counter()
     for _ in range(max(args.steps, 2)):
@@ -624,7 +637,8 @@ def main():
     # the timed setting again without any HIP event (what a production cycle costs; on launch-bound configs the event
     # records around the dominant kernel lengthen the cycle)
     dxn = ctx.vec(L.n)
-    dmg.vcycle(db, dxn)
+    for _ in range(max(args.warmup, 1)):
+        dmg.vcycle(db, dxn)
     ctx.sync()
     t0 = time.perf_counter()
     for _ in range(max(args.steps, 2)):
@@ -712,7 +726,7 @@ def main():
         "ms_per_step_without_events": noevents_ms,
         "other_restriction_setting": {"robust_restriction": not args.restriction, "ms_per_step": other_ms,
                                       "v_cycles_per_s": 1e3 / other_ms, "rel_residual_after_cycles": other_res,
-                                      "cycles": max(args.steps, 2) + 1,
+                                      "cycles": max(args.steps, 2) + max(args.warmup, 1),
                                       "note": "same hierarchy, the reference's `--restriction` flag flipped "
                                               "(examples/Makefile:6-16 passes it, driver.py:41 defaults it off); no events"},
         "dof_smooths_per_s": L.n * smooths_per_cycle_finest * vps,

@@ -150,6 +150,21 @@ int alfi_level_set_sum_exchange(alfi_level* lvl, int nnbr, const int32_t* ranks_
 int alfi_level_set_overlap(alfi_level* lvl, int64_t nb_interior, int64_t npatch_interior);
 /* new Newton step / new Reynolds number: same sparsity, new values (PatchPC.update -> PCSetUp_PATCH [3P]). */
 int alfi_level_update_values(alfi_level* lvl, const double* bvals_host);
+/* Operator refresh on the device (PatchPC.update: `precompute_element_tensors` + `save_operators`, alfi/solver.py:320, 325;
+ * PETSc event PCPatchComputeOp, alfi/driver.py:80).  alfi_level_set_assembly hands over, once, what does not change
+ * between Newton steps: the cells (nodes, gradients of the barycentric coordinates (ncell, d+1, d), volumes), the reference
+ * tensor T1 of the advection term in the two orders the kernel reads -- Ta[b*nloc+a][k][i] = T1[k,i,b,a],
+ * Tb[b*nloc+a][i][k] = T1[b,i,k,a] --, the viscous and grad-div parts K, D of the operator (host BSR layout (nnzb, bs, bs),
+ * the level's sparsity) and the contributor lists (cptr (nnzb+1), ccell, cba = b*nloc+a per pair; fixed order).
+ * alfi_level_assemble then writes  A = nu K + gamma D + adv N(state)  into the level's operator (the linearisation of
+ * alfi/solver.py:565-568 about the DEVICE-resident nodal field `d_state`, n doubles), Dirichlet rows / columns as identity
+ * when apply_bc != 0; the patches must be factored again afterwards (alfi_patches_factor).  Unpartitioned levels only. */
+int alfi_level_set_assembly(alfi_level* lvl, int64_t ncell, int nloc, const int32_t* cell_nodes, const double* grad,
+                            const double* vol, const double* Ta, const double* Tb, const double* Kvals_host,
+                            const double* Dvals_host, const int64_t* cptr, const int32_t* ccell, const uint16_t* cba);
+int alfi_level_assemble(alfi_level* lvl, double nu, double gamma, double adv, const double* d_state, int apply_bc);
+/* the operator values in the host layout (nnzb, bs, bs) -- diagnostics / tests */
+int alfi_level_get_values(alfi_level* lvl, double* bvals_host);
 int alfi_level_size(alfi_level* lvl, int64_t* n);
 int alfi_level_id(alfi_level* lvl, int* id); /* creation-order id within the ctx, used by alfi_prof_get_level */
 int alfi_spmv(alfi_level* lvl, const double* dx, double* dy);                        /* y = A x      */

@@ -124,8 +124,10 @@ def test_oracles_reproduce_sv_golden(name):
     mg = O.build_oracle_mg(lv, tr, ks, schoeberl_restriction=True)
     assert rel(mg.levels[-1]["A"] @ g["x"], g["A_x"]) < 1e-14
     assert rel(mg.levels[-1]["smoother"].apply(g["x"]), g["patch_apply_x"]) < 1e-9
-    assert rel(mg.prolong(top, g["uc"]), g["prolong_uc"]) < 1e-10
-    assert rel(mg.restrict(top, g["x"]), g["restrict_x"]) < 1e-10
+    # (LU solves of macro-cell blocks with cond ~ gamma / nu = 1e6 .. 1e7: another host's BLAS / LAPACK moves the result by
+    # cond * eps ~ 1e-10 .. 1e-9 -- seen 1.5e-10 on the GPU box's CPU -- hence 1e-9 where the fixture's own machine gives 1e-12)
+    assert rel(mg.prolong(top, g["uc"]), g["prolong_uc"]) < 1e-9
+    assert rel(mg.restrict(top, g["x"]), g["restrict_x"]) < 1e-9
     assert rel(mg.vcycle(top, g["b"], np.zeros(L.n)), g["vcycle_b"]) < 1e-8
     B, M, Minv = build_sv_pressure_coupling(L)
     assert rel(B @ g["x"], g["B_x"]) < 1e-13 and rel(Minv.diagonal(), g["Minv_diag"]) < 1e-13

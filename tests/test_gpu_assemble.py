@@ -1,0 +1,81 @@
+"""Operator refresh on the device (alfi_level_set_assembly / alfi_level_assemble: what PatchPC.update does inside PCPATCH on
+every Newton step, alfi/solver.py:320, 325) against the host generator's assembly of the same linearisation
+(alfi/solver.py:565-568), and the Newton loop with either.  -m gpu."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from alfi_amd.problem import TwoDimLidDrivenCavityProblem, ThreeDimLidDrivenCavityProblem
+
+CASES = [("2d-P2", lambda: TwoDimLidDrivenCavityProblem(4), 2, 2), ("3d-P1FB", lambda: ThreeDimLidDrivenCavityProblem(2), 1, 1),
+         ("3d-P2FB", lambda: ThreeDimLidDrivenCavityProblem(2), 2, 1)]
+
+
+@pytest.mark.parametrize("name,mk,k,nref", CASES, ids=[c[0] for c in CASES])
+def test_device_assembled_operator_equals_the_host_generators(name, mk, k, nref):
+    """Every level: A = nu K + gamma D + N(w) with Dirichlet rows / columns as identity, for a random state w, a non-trivial
+    (nu, gamma), with and without advection, with and without boundary conditions -- entry by entry to 1e-13 of the largest
+    entry (the two sides sum the cell contributions in different orders)."""
+    from alfi_amd.nssolver import HipNavierStokesSolver
+    s = HipNavierStokesSolver(mk(), nref, k, gamma=1e4, device_assembly=True)
+    assert s.device_assembly
+    s.nu = 0.037
+    rng = np.random.default_rng(11)
+    for L, dl, st in zip(s.levels, s.hmg.mg.levels, s._dstate):
+        w = rng.standard_normal((L.V.num_nodes, L.V.dim))
+        st.set(w.ravel())
+        for adv, bc in ((1.0, True), (0.5, False), (0.0, True)):
+            ref = s.level_values(L, w, adv, bc) if adv == 1.0 else None
+            if ref is None:       # level_values has no scaling of the advection term: build it from its pieces
+                from alfi_amd.nssolver import _assemble
+                from alfi_amd import _hostlib
+                ref = _assemble(L, s.nu, s.gamma, adv, w if adv else None, False, False)
+                if bc:
+                    _hostlib.apply_bc_bsr(L.V.num_nodes, L.V.dim, L.A.rowptr, L.A.colidx, ref, np.repeat(L.V.bc_node_mask, L.V.dim))
+            dl.assemble(s.nu, s.gamma, adv, st if adv else None, bc)
+            got = dl.get_values()
+            assert got.shape == ref.shape
+            assert np.abs(got - ref).max() <= 1e-13 * np.abs(ref).max(), (name, L.level, adv, bc)
+        # deterministic: a second assembly gives the same bits
+        dl.assemble(s.nu, s.gamma, 1.0, st, True)
+        a1 = dl.get_values()
+        dl.assemble(s.nu, s.gamma, 1.0, st, True)
+        assert np.array_equal(a1, dl.get_values())
+    s.close()
+
+
+def test_device_residual_equals_the_host_residual():
+    from alfi_amd.nssolver import HipNavierStokesSolver
+    sd = HipNavierStokesSolver(ThreeDimLidDrivenCavityProblem(2), 1, 2, device_assembly=True)
+    sh = HipNavierStokesSolver(ThreeDimLidDrivenCavityProblem(2), 1, 2, device_assembly=False)
+    rng = np.random.default_rng(5)
+    u = sd.u + 0.1 * rng.standard_normal(sd.n_u)
+    u[sd.levels[-1].bc_dofs] = sd.u[sd.levels[-1].bc_dofs]
+    p = rng.standard_normal(sd.n_p)
+    for s in (sd, sh):
+        s.nu = 2.0 / 50.0
+    Fd, Gd = sd.residual(u, p, 1.0)
+    Fh, Gh = sh.residual(u, p, 1.0)
+    assert np.abs(Fd - Fh).max() <= 1e-12 * np.abs(Fh).max() and np.array_equal(Gd, Gh)
+    sd.close()
+    sh.close()
+
+
+@pytest.mark.parametrize("mk,k,nref", [(lambda: TwoDimLidDrivenCavityProblem(8), 2, 2), (lambda: ThreeDimLidDrivenCavityProblem(2), 1, 2)],
+                         ids=["ldc2d", "ldc3d-P1FB"])
+def test_newton_with_device_and_host_assembly_agree(mk, k, nref):
+    """Reynolds continuation with the operators refreshed on the device and on the host: same Newton and Krylov counts, same
+    solution (the two assemblies differ by summation order only)."""
+    from alfi_amd.nssolver import HipNavierStokesSolver, run_solver
+    out = {}
+    for dev in (True, False):
+        s = HipNavierStokesSolver(mk(), nref, k, device_assembly=dev)
+        res = run_solver(s, [10, 100])
+        out[dev] = (s.u.copy(), s.p.copy(), [(res[r]["nonlinear_iter"], res[r]["linear_iter"], res[r]["converged"]) for r in (10, 100)],
+                    dict(s.timings))
+        s.close()
+    assert all(c for _, _, c in out[True][2]) and out[True][2] == out[False][2]
+    assert np.abs(out[True][0] - out[False][0]).max() <= 1e-8 * np.abs(out[False][0]).max()
+    assert np.abs(out[True][1] - out[False][1]).max() <= 1e-7 * np.abs(out[False][1]).max()
+    assert out[True][3]["newton_steps"] > 0

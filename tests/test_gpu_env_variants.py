@@ -27,3 +27,21 @@ def test_switch(env, tol):
     m = re.search(r"RELERR (\S+)", out.stdout)
     assert out.returncode == 0 and m, out.stdout[-2000:] + out.stderr[-3000:]
     assert float(m.group(1)) < tol, (env, m.group(1))
+
+
+@pytest.mark.parametrize("env", [{},                                                  # defaults: four-launch fused iteration on the small levels
+                                 {"ALFI_TINY_BYTES": "1000000"},                      # one-workgroup kernel on the tiny levels
+                                 {"ALFI_FUSED_SMOOTHER": "0"},                        # the general launch chain
+                                 {"ALFI_TINY_BYTES": "1000000000"},                   # every level through the one-workgroup kernel
+                                 {"ALFI_SPMV_DEDUP": "0"},                            # direct x gathers in the large SpMV
+                                 {"ALFI_SPMV_ALIGNED": "0", "ALFI_FUSED_SMOOTHER": "0"},   # de-duplicated SpMV on small levels too
+                                 {"ALFI_SPMV_ALIGNED": "0", "ALFI_XCD_MAP": "1", "ALFI_FUSED_SMOOTHER": "0"},
+                                 {"ALFI_FUSED_REDUCE_MAX": "0"}, {"ALFI_INVERT_MFMA": "0"}])
+def test_smoother_paths(env):
+    """Every implementation of the level smoother (alfi/solver.py:313-328) and of the level product behind it gives the
+    oracle's FGMRES iterate (1e-7) and cycles (1e-5)."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "gpu_env_pkp0_worker.py")],
+                         env=dict(os.environ, **env), cwd=ROOT, capture_output=True, text=True, timeout=900)
+    ms, mc = re.search(r"SMOOTH (\S+)", out.stdout), re.search(r"CYCLE (\S+)", out.stdout)
+    assert out.returncode == 0 and ms and mc, out.stdout[-2000:] + out.stderr[-3000:]
+    assert float(ms.group(1)) < 1e-7 and float(mc.group(1)) < 1e-5, (env, ms.group(1), mc.group(1))

@@ -62,3 +62,54 @@ def test_lazy_operator_materialises_to_the_global_one():
         _same_bsr(l.A.materialise(), g.A)
         rows = np.arange(g.A.nbrows)[::-3]                      # any order, any subset
         _same_bsr(l.A.select_rows(rows), g.A.select_rows(rows))
+
+
+def _shared_worker(rank, world, port, q):
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from alfi_amd.problem import ThreeDimLidDrivenCavityProblem, build_hierarchy
+        from alfi_amd.shared import build_shared, _path
+        calls = []
+
+        def build():
+            calls.append(1)
+            return build_hierarchy(ThreeDimLidDrivenCavityProblem(2), 1, 2, Re=100.0, lazy=True)
+        lv, tr = build_shared(build, rank, dist.barrier, "test_%d" % port)
+        L = lv[-1]
+        own = L.A.select_rows(np.arange(rank, L.A.nbrows, world))       # rank-local values from the shared integer side
+        # copy-on-write: a write by one rank is private to it
+        L.patch_dofs[0] = -7 - rank
+        dist.barrier()
+        q.put((rank, len(calls), int(L.n), float(np.abs(own.vals).sum()), int(L.patch_dofs[0]), os.path.exists(_path("test_%d" % port))))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_hierarchy_generated_once_and_shared_between_ranks():
+    """alfi_amd.shared (gloo, world 3): rank 0 generates, the others map the file copy-on-write; every rank can assemble its
+    own rows from the shared integer side, writes stay private, and nothing is left in /dev/shm."""
+    import multiprocessing as mp
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    world = 3
+    procs = [ctx.Process(target=_shared_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = sorted(q.get(timeout=300) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert [o[1] for o in out] == [1, 0, 0]                      # built once
+    assert len({o[2] for o in out}) == 1 and all(o[3] > 0 for o in out)
+    assert [o[4] for o in out] == [-7, -8, -9]                   # private writes
+    assert not any(o[5] for o in out)                            # file already unlinked
