@@ -41,32 +41,23 @@ struct Lu4 {
   double s01, s02, s03, s12, s13, s23;        // U_ut / U_uu: the scaled pivot rows inside the block
 };
 
-// 1 / x: hardware estimate + two Newton steps (the IEEE division sequence is ~12 dependent FP64 instructions, and four of
-// them sit on the critical path of every block step)
-__device__ __forceinline__ double recip(double x) {
-  double r = __builtin_amdgcn_rcp(x);
-  r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
-  r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
-  return r;
-}
-
 __device__ __forceinline__ void lu4(const double (&d)[4][4], Lu4& f, bool& bad) {
   const double u00 = d[0][0];
-  f.i0 = recip(u00);
+  f.i0 = 1.0 / u00;
   f.u01 = d[0][1]; f.u02 = d[0][2]; f.u03 = d[0][3];
   f.l10 = d[1][0] * f.i0; f.l20 = d[2][0] * f.i0; f.l30 = d[3][0] * f.i0;
   const double u11 = __builtin_fma(-f.l10, f.u01, d[1][1]);
   f.u12 = __builtin_fma(-f.l10, f.u02, d[1][2]);
   f.u13 = __builtin_fma(-f.l10, f.u03, d[1][3]);
-  f.i1 = recip(u11);
+  f.i1 = 1.0 / u11;
   f.l21 = __builtin_fma(-f.l20, f.u01, d[2][1]) * f.i1;
   f.l31 = __builtin_fma(-f.l30, f.u01, d[3][1]) * f.i1;
   const double u22 = __builtin_fma(-f.l21, f.u12, __builtin_fma(-f.l20, f.u02, d[2][2]));
   f.u23 = __builtin_fma(-f.l21, f.u13, __builtin_fma(-f.l20, f.u03, d[2][3]));
-  f.i2 = recip(u22);
+  f.i2 = 1.0 / u22;
   f.l32 = __builtin_fma(-f.l31, f.u12, __builtin_fma(-f.l30, f.u02, d[3][2])) * f.i2;
   const double u33 = __builtin_fma(-f.l32, f.u23, __builtin_fma(-f.l31, f.u13, __builtin_fma(-f.l30, f.u03, d[3][3])));
-  f.i3 = recip(u33);
+  f.i3 = 1.0 / u33;
   if (u00 == 0.0 || u11 == 0.0 || u22 == 0.0 || u33 == 0.0) bad = true;
   f.s01 = f.u01 * f.i0; f.s02 = f.u02 * f.i0; f.s03 = f.u03 * f.i0;
   f.s12 = f.u12 * f.i1; f.s13 = f.u13 * f.i1;
@@ -192,24 +183,13 @@ __global__ __launch_bounds__(512) void patch_invert_mfma_kernel(const int64_t* _
         for (int j = 0; j < 4; ++j) d[i][j] = Rraw[buf][i][4 * s + j];
       Lu4 f;
       lu4(d, f, bad);
-      // ---- operands of the rank-4 update  A <- A - sum_t c_t r_t^T  (the four scalar Gauss-Jordan steps, delayed).
-      //      Lane (lm, lk) needs r_lk of its columns and c_lk of its rows only: r = diag(1 / U_tt) L^-1 x and c = x S^-1 with
-      //      S = the unit upper triangular diag(U)^-1 U.  Both triangular inverses are formed explicitly (6 entries each, per
-      //      step) and every operand is a 4-term dot product with the lane's own coefficients -- the forward substitutions per
-      //      operand were most of the FP64 VALU work of a step.  (Triangular factors of an unpivoted LU without growth are
-      //      well conditioned even where D itself is not.)
-      const double m10 = -f.l10, m21 = -f.l21, m32 = -f.l32;             // L^-1
-      const double m20 = __builtin_fma(f.l21, f.l10, -f.l20), m31 = __builtin_fma(f.l32, f.l21, -f.l31);
-      const double m30 = __builtin_fma(-m32, f.l20, __builtin_fma(-m31, f.l10, -f.l30));
-      const double li0 = sel4(lk, 1.0, m10, m20, m30), li1 = sel4(lk, 0.0, 1.0, m21, m31), li2 = sel4(lk, 0.0, 0.0, 1.0, m32),
-                   li3 = lk == 3 ? 1.0 : 0.0;                             // row lk of L^-1
+      // ---- operands of the rank-4 update  A <- A - sum_t c_t r_t^T  (the four scalar Gauss-Jordan steps, delayed), by
+      //      forward substitution with the SAME rounded L, U entries the pivots were computed with.  (Forming L^-1 and
+      //      diag(U)^-1 U explicitly and taking each operand as a 4-term dot product is a third of the FP64 work, and fails the
+      //      residual probe exactly like an explicit D^-1 does: 1.5e-4 on the [P2+FB]^3 test patches.  The second pivot of a
+      //      node's gamma b b^T + nu K block is a cancellation of O(gamma) terms down to O(nu); only substitutions that repeat
+      //      the elimination's own roundings stay consistent with it.)
       const double isel = sel4(lk, f.i0, f.i1, f.i2, f.i3);
-      const double rc0 = li0 * isel, rc1 = li1 * isel, rc2 = li2 * isel, rc3 = li3 * isel;
-      const double t01 = -f.s01, t12 = -f.s12, t23 = -f.s23;             // S^-1 (unit upper)
-      const double t02 = __builtin_fma(f.s01, f.s12, -f.s02), t13 = __builtin_fma(f.s12, f.s23, -f.s13);
-      const double t03 = __builtin_fma(-t02, f.s23, __builtin_fma(-t01, f.s13, -f.s03));
-      const double cc0 = sel4(lk, 1.0, t01, t02, t03), cc1 = sel4(lk, 0.0, 1.0, t12, t13), cc2 = sel4(lk, 0.0, 0.0, 1.0, t23),
-                   cc3 = lk == 3 ? 1.0 : 0.0;                             // column lk of S^-1
       double bop[NB], aop[NA], vop[NA];
 #pragma unroll
       for (int b = 0; b < NB; ++b) {
@@ -217,8 +197,11 @@ __global__ __launch_bounds__(512) void patch_invert_mfma_kernel(const int64_t* _
         bop[b] = 0.0;
         if (tj < NT) {
           const int c = 16 * tj + lm;
-          const double rv = __builtin_fma(rc3, Rraw[buf][3][c], __builtin_fma(rc2, Rraw[buf][2][c],
-                            __builtin_fma(rc1, Rraw[buf][1][c], rc0 * Rraw[buf][0][c])));
+          const double x0 = Rraw[buf][0][c], x1 = Rraw[buf][1][c], x2 = Rraw[buf][2][c], x3 = Rraw[buf][3][c];
+          const double y1 = __builtin_fma(-f.l10, x0, x1);
+          const double y2 = __builtin_fma(-f.l21, y1, __builtin_fma(-f.l20, x0, x2));
+          const double y3 = __builtin_fma(-f.l32, y2, __builtin_fma(-f.l31, y1, __builtin_fma(-f.l30, x0, x3)));
+          const double rv = sel4(lk, x0, y1, y2, y3) * isel;             // r_lk = (L^-1 x)_lk / U_lk,lk
           bop[b] = (tj == tk && colgrp) ? 0.0 : rv;                      // columns K: left to the fix-up
         }
       }
@@ -228,8 +211,10 @@ __global__ __launch_bounds__(512) void patch_invert_mfma_kernel(const int64_t* _
         aop[a] = vop[a] = 0.0;
         if (ti < NT) {
           const int i = 16 * ti + lm;
-          const double cv = __builtin_fma(cc3, Craw[buf][i][3], __builtin_fma(cc2, Craw[buf][i][2],
-                            __builtin_fma(cc1, Craw[buf][i][1], cc0 * Craw[buf][i][0])));
+          const double x[4] = {Craw[buf][i][0], Craw[buf][i][1], Craw[buf][i][2], Craw[buf][i][3]};
+          double c[4];
+          col_panel(f, x, c);
+          const double cv = sel4(lk, c[0], c[1], c[2], c[3]);
           aop[a] = (ti == tk && colgrp) ? 0.0 : cv;                      // rows K: left to the fix-up
           vop[a] = cv * isel;                                            // (A[:, K] U^-1)[row][lk]
         }
@@ -248,6 +233,11 @@ __global__ __launch_bounds__(512) void patch_invert_mfma_kernel(const int64_t* _
       //      kernel slower than the rank-1 register kernel it replaces: 22 against 18 ms at config 4's level 2.)
       if (own_c) {
         const int cq = lm & 3;
+        const double m10 = -f.l10, m21 = -f.l21, m32 = -f.l32;           // L^-1 (only here: the final columns K)
+        const double m20 = __builtin_fma(f.l21, f.l10, -f.l20), m31 = __builtin_fma(f.l32, f.l21, -f.l31);
+        const double m30 = __builtin_fma(-m32, f.l20, __builtin_fma(-m31, f.l10, -f.l30));
+        const double li0 = sel4(lk, 1.0, m10, m20, m30), li1 = sel4(lk, 0.0, 1.0, m21, m31), li2 = sel4(lk, 0.0, 0.0, 1.0, m32),
+                     li3 = lk == 3 ? 1.0 : 0.0;
         const double b2 = colgrp ? -sel4(cq, li0, li1, li2, li3) : 0.0;
         double dkk = 0.0;                                                 // D^-1[lk][cq]
         {
@@ -307,7 +297,10 @@ int launch_patch_invert_mfma(alfi_ctx* ctx, int64_t npatch, int max_np, const in
                              double* inv, int* status, int* handled) {
   static const bool allow = !(getenv("ALFI_INVERT_MFMA") && atoi(getenv("ALFI_INVERT_MFMA")) == 0);
   *handled = 0;
-  if (!allow || max_np <= 32 || max_np > 160) return 0;
+  // up to 112 dofs the rank-1 register kernel (7 x 7 tiles, two workgroups per CU) is the faster one -- measured at
+  // [P1+FB]^3's 111 dofs: 5.5 against 9.8 ms for 35 937 patches; ALFI_INVERT_MFMA=2 sends those sizes here too (tests)
+  static const bool all_sizes = getenv("ALFI_INVERT_MFMA") && atoi(getenv("ALFI_INVERT_MFMA")) == 2;
+  if (!allow || max_np <= 32 || max_np > 160 || (max_np <= 112 && !all_sizes)) return 0;
   dim3 grid((unsigned)npatch), block(512);
   if (max_np <= 64)
     hipLaunchKernelGGL(patch_invert_mfma_kernel<4>, grid, block, 0, ctx->stream, patch_ptr, inv_ptr, inv, status);

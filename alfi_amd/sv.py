@@ -11,6 +11,8 @@ Everything here is host-side input generation (the role Firedrake plays for the 
 transfers and cycles is the same libalfi_hip.so entry points as for the PkP0 discretisation.  Implemented for k = 2 and,
 in 3-D, k = 3 (the inf-sup stable pair of config 5: macro stars of up to ~1600 dofs, macro-cell transfer blocks of 390).
 """
+import os
+
 import numpy as np
 import scipy.sparse as sp
 
@@ -44,6 +46,70 @@ def macro_star_patches(V):
     ptr, dofs, kept = patch_points_to_dofs(V, dm, patches)
     seeds = np.array([ms.seeds[i] - dm.vStart for i in kept], dtype=np.int64)     # the macro vertex of every patch
     return ptr, dofs, seeds
+
+
+def macro_star_patches_fast(V):
+    """The same patches as ``macro_star_patches`` (the reference's MacroStar constructor, relaxation.py:163-177, with its
+    literal label test on EVERY closure point) from sparse incidence products instead of one Python closure walk per
+    point: 19 of the 34 s of host generation at config 5's size, 150 of 281 s with one more refinement.
+
+    For a macro vertex v let C(v) = closure of the cells holding v.  The constructor returns star(v) and the stars of all
+    points of C(v) that are not macro vertices, i.e. in terms of the entities that carry nodes
+      vertices:  v and the non-macro vertices (macro-cell barycentres) of C(v);
+      edges:     the edges of C(v) and the edges holding one of those barycentres;
+      faces:     the faces of C(v), the faces holding an edge of C(v), the faces holding one of those barycentres.
+    tests/test_sv.py checks equality with the literal constructor patch by patch (2-D and 3-D)."""
+    import scipy.sparse as sp
+    mesh, d = V.mesh, V.dim
+    nc, nv, ne, nf = mesh.num_cells, mesh.num_vertices, mesh.num_edges, mesh.num_faces
+    macro = np.flatnonzero(mesh.macro_vertex_mask)
+
+    def inc(rows, cols, shape):
+        return sp.csr_matrix((np.ones(rows.size, dtype=np.int32), (rows, cols)), shape=shape)
+    cells = np.repeat(np.arange(nc), d + 1)
+    Mvc = inc(mesh.cells.ravel(), cells, (nv, nc))                                    # vertex x cell
+    Mec = inc(mesh.cell_edges.ravel(), np.repeat(np.arange(nc), mesh.cell_edges.shape[1]), (ne, nc))
+    Mev = inc(np.repeat(np.arange(ne), 2), mesh.edges.ravel(), (ne, nv))              # edge x vertex
+    Cv = Mvc.T.tocsr()[:, macro]                                                      # cell x macro vertex: cells holding v
+    Vc = (Mvc @ Cv).tocsr()                                                           # vertices of C(v)
+    nonmacro = sp.diags((~mesh.macro_vertex_mask).astype(np.int32))
+    Bv = (nonmacro @ Vc).tocsr()                                                      # ... that are not macro vertices
+    Ec = (Mec @ Cv).tocsr()
+    E = (Ec + Mev @ Bv).tocsc()
+    Bc = Bv.tocsc()
+    F = None
+    if d == 3 and V.element.has_face_nodes:
+        Mfc = inc(mesh.cell_faces.ravel(), np.repeat(np.arange(nc), 4), (nf, nc))
+        Mfv = inc(np.repeat(np.arange(nf), 3), mesh.faces.ravel(), (nf, nv))
+        # face x edge: the three vertex pairs of a face looked up among the (sorted) edges
+        ekey = mesh.edges[:, 0].astype(np.int64) * nv + mesh.edges[:, 1]
+        order = np.argsort(ekey)
+        f = mesh.faces.astype(np.int64)
+        fe = []
+        for a, b in ((0, 1), (0, 2), (1, 2)):
+            lo, hi = np.minimum(f[:, a], f[:, b]), np.maximum(f[:, a], f[:, b])
+            fe.append(order[np.searchsorted(ekey[order], lo * nv + hi)])
+        Mfe = inc(np.repeat(np.arange(nf), 3), np.stack(fe, axis=1).ravel(), (nf, ne))
+        F = (Mfc @ Cv + Mfe @ Ec + Mfv @ Bv).tocsc()
+    en = None if V.edge_nodes is None else np.asarray(V.edge_nodes, dtype=np.int64).reshape(ne, -1)
+    ptr, dofs, seeds = [0], [], []
+    comp = np.arange(d, dtype=np.int64)
+    for j, v in enumerate(macro):
+        nodes = [np.array([V.vertex_nodes[v]], dtype=np.int64),
+                 V.vertex_nodes[Bc.indices[Bc.indptr[j]:Bc.indptr[j + 1]]].astype(np.int64)]
+        if en is not None:
+            nodes.append(en[E.indices[E.indptr[j]:E.indptr[j + 1]]].ravel())
+        if F is not None:
+            nodes.append(V.face_nodes[F.indices[F.indptr[j]:F.indptr[j + 1]]].astype(np.int64))
+        nodes = np.unique(np.concatenate(nodes))
+        nodes = nodes[~V.bc_node_mask[nodes]]
+        if nodes.size == 0:
+            continue
+        dofs.append((nodes[:, None] * d + comp).ravel())
+        ptr.append(ptr[-1] + nodes.size * d)
+        seeds.append(v)
+    return (np.array(ptr, dtype=np.int64), np.concatenate(dofs).astype(np.int32) if dofs else np.zeros(0, dtype=np.int32),
+            np.array(seeds, dtype=np.int64))
 
 
 def macro_cell_groups(V, patch_dofs):
@@ -280,7 +346,9 @@ def build_sv_hierarchy(problem, nref, k, Re, gamma=1e4, advect=True, patches=Tru
         L.bc_dofs = V.bc_dofs
         L.nu, L.gamma = nu, gamma
         if patches and l > 0:
-            L.patch_ptr, L.patch_dofs, L.patch_seeds = macro_star_patches(V)
+            # (ALFI_MACROSTAR_LITERAL=1: the constructor's own point-by-point walk instead of the incidence products)
+            literal = os.environ.get("ALFI_MACROSTAR_LITERAL") == "1"
+            L.patch_ptr, L.patch_dofs, L.patch_seeds = (macro_star_patches if literal else macro_star_patches_fast)(V)
             # the factors of these patches can be stored condensed: interiors of the macro cells + skeleton
             L.patch_groups = macro_cell_groups(V, L.patch_dofs)
         if l > 0:

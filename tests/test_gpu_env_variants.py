@@ -36,7 +36,7 @@ def test_switch(env, tol):
                                  {"ALFI_SPMV_DEDUP": "0"},                            # direct x gathers in the large SpMV
                                  {"ALFI_SPMV_ALIGNED": "0", "ALFI_FUSED_SMOOTHER": "0"},   # de-duplicated SpMV on small levels too
                                  {"ALFI_SPMV_ALIGNED": "0", "ALFI_XCD_MAP": "1", "ALFI_FUSED_SMOOTHER": "0"},
-                                 {"ALFI_FUSED_REDUCE_MAX": "0"}, {"ALFI_INVERT_MFMA": "0"}])
+                                 {"ALFI_FUSED_REDUCE_MAX": "0"}, {"ALFI_INVERT_MFMA": "0"}, {"ALFI_INVERT_MFMA": "2"}])
 def test_smoother_paths(env):
     """Every implementation of the level smoother (alfi/solver.py:313-328) and of the level product behind it gives the
     oracle's FGMRES iterate (1e-7) and cycles (1e-5)."""

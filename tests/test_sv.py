@@ -192,3 +192,20 @@ def test_macro_cell_groups_give_an_exact_block_factorisation():
         dense_total += n * n
         cond_total += cond
     assert cond_total < 0.35 * dense_total                  # [P2]^3 macro stars: 5.9 x on the device (whole-node groups)
+
+
+@pytest.mark.parametrize("case", ["2d-P2", "3d-P2", "3d-P3", "bfs3d-P3"])
+def test_vectorised_macro_stars_equal_the_literal_constructor(case):
+    """sv.macro_star_patches_fast (sparse incidence products) against sv.macro_star_patches (the reference's MacroStar
+    callback run point by point, relaxation.py:163-177): identical patch pointers, dofs and seed vertices on every level."""
+    from alfi_amd import sv
+    from alfi_amd.problem import (TwoDimLidDrivenCavityProblem, ThreeDimLidDrivenCavityProblem,
+                                  ThreeDimBackwardsFacingStepProblem)
+    prob, nref, k = {"2d-P2": (TwoDimLidDrivenCavityProblem(3), 1, 2), "3d-P2": (ThreeDimLidDrivenCavityProblem(2), 1, 2),
+                     "3d-P3": (ThreeDimLidDrivenCavityProblem(1), 1, 3),
+                     "bfs3d-P3": (ThreeDimBackwardsFacingStepProblem(1), 1, 3)}[case]
+    lv, _ = sv.build_sv_hierarchy(prob, nref, k, Re=100.0)
+    for L in lv[1:]:
+        a, b = sv.macro_star_patches(L.V), sv.macro_star_patches_fast(L.V)
+        assert all(np.array_equal(x, y) for x, y in zip(a, b))
+        assert np.array_equal(L.patch_ptr, b[0]) and np.array_equal(L.patch_dofs, b[1])      # the hierarchy uses the fast one
