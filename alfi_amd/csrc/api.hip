@@ -1294,7 +1294,7 @@ static int ensure_fgmres_workspace(alfi_level* L, int k) {
 // FGMRES(k) on a small, unpartitioned level with the additive smoother: four launches per iteration (see the kernels in
 // kernels_vec.hip).  Same algorithm as the general path below -- right-preconditioned FGMRES, classical Gram-Schmidt,
 // explicit norms -- with the normalisation of the new Krylov vector moved behind the patch solves (they are linear).
-static int smooth_fgmres_fused(alfi_level* L, int k, const double* db, double* dx, int nonzero_guess) {
+static int smooth_fgmres_fused(alfi_level* L, int k, const double* db, double* dx, int nonzero_guess, bool flat_spmv) {
   alfi_ctx* ctx = L->ctx;
   const int K = L->kmax;
   const int64_t n = L->n;
@@ -1322,9 +1322,22 @@ static int smooth_fgmres_fused(alfi_level* L, int k, const double* db, double* d
     ALFI_CHECK(launch_patch_sum_scale(L, w, zj, V + (int64_t)j * n, normpart, G, hdots, hs, j, K));   // z_j, v_j, H column j-1
     alfi_prof_end(ctx, t);
     int nb = 0;
-    t = alfi_prof_begin(ctx, ALFI_EV_MATMULT);
-    ALFI_CHECK(launch_bsr_spmv_dot(ctx, L->A_own, zj, w, V, n, j + 1, ctx->red_partial, &nb));    // w = A z_j, V^T w partials
-    alfi_prof_end(ctx, t);
+    if (!flat_spmv) {
+      t = alfi_prof_begin(ctx, ALFI_EV_MATMULT);
+      ALFI_CHECK(launch_bsr_spmv_dot(ctx, L->A_own, zj, w, V, n, j + 1, ctx->red_partial, &nb));  // w = A z_j, V^T w partials
+      alfi_prof_end(ctx, t);
+    } else {
+      // long or very uneven block rows (the 3-D operators): the nnz-balanced product, then the dots as their own pass; up to
+      // 256 partials per vector the projection kernel sums them itself, beyond a one-block reduction does
+      t = alfi_prof_begin(ctx, ALFI_EV_MATMULT);
+      ALFI_CHECK(launch_bsr_spmv(ctx, L->A_own, zj, w, nullptr, 1.0, 0));
+      alfi_prof_end(ctx, t);
+      t = alfi_prof_begin(ctx, ALFI_EV_BLAS1);
+      const bool in_consumer = G <= 256;
+      ALFI_CHECK(launch_multi_dot(ctx, V, n, j + 1, w, in_consumer ? nullptr : hdots, n));
+      alfi_prof_end(ctx, t);
+      nb = in_consumer ? G : 0;
+    }
     t = alfi_prof_begin(ctx, ALFI_EV_BLAS1);
     ALFI_CHECK(launch_multi_axpy_norm(ctx, V, n, j + 1, hdots, w, n, ctx->red_partial2, nb));     // h, w -= V h, |w|^2 partials
     alfi_prof_end(ctx, t);
@@ -1365,8 +1378,15 @@ int alfi_smooth_fgmres(alfi_level* L, int k, const double* db, double* dx, int n
     static const int64_t tiny_bytes = getenv("ALFI_TINY_BYTES") ? atoll(getenv("ALFI_TINY_BYTES")) : 0;
     if (fusable && !L->cond && L->kmax <= 15 && L->max_np <= SMALL_PATCH_MAX && tiny_level_bytes(L) <= tiny_bytes)
       return launch_smooth_tiny(L, k, db, dx, nonzero_guess);
-    if (fusable && (L->max_row_blocks <= 32 || L->n <= small_n))
-      return smooth_fgmres_fused(L, k, db, dx, nonzero_guess);
+    // every unpartitioned additive level takes the iteration with the normalisation folded behind the (linear) patch
+    // solves -- patch_sum_scale_kernel writes z_j and v_j in one pass, no separate v = w / |w| launch; the product is the
+    // lanes-per-row kernel with the dots folded in where the rows are short, the nnz-balanced one + a dot pass elsewhere.
+    // ALFI_FUSED_ALL=1 sends the latter levels there too; measured (round 3, same box, ms per V-cycle): config 3 17.33 against
+    // 17.35, config 4 163.1 / 163.3, config 5 27.24 / 27.10 -- the launch it saves is worth nothing on levels whose kernels
+    // run for tens of microseconds, so the default keeps the general launch chain below for them
+    static const bool fused_all = getenv("ALFI_FUSED_ALL") && atoi(getenv("ALFI_FUSED_ALL")) == 1;
+    const bool short_rows = L->max_row_blocks <= 32 || L->n <= small_n;
+    if (fusable && (short_rows || fused_all)) return smooth_fgmres_fused(L, k, db, dx, nonzero_guess, !short_rows);
   }
   const int K = L->kmax;
   const int64_t n = L->n_own;    // vector kernels and reductions run on the owned prefix

@@ -104,8 +104,13 @@ __global__ __launch_bounds__(256) void patch_check_kernel(const int32_t* __restr
   }
 }
 
-// Gauss-Jordan with partial pivoting, one workgroup per flagged patch: gather A_p into the n x n row-major scratch W,
-// invert in place (row interchanges, undone as column interchanges at the end), store in the row-piece layout.
+// LU with partial pivoting + two triangular sweeps, one workgroup per flagged patch (what LAPACK's getrf + getri amount to):
+// gather A_p into the n x n row-major scratch W, factor P A = L U in place, then X = U^-1 (L^-1 P) row by row into the
+// second scratch Y (every thread owns columns of X: coalesced, no reduction), store in the row-piece layout.
+// (Round 2 re-inverted by Gauss-JORDAN with partial pivoting.  Its right residual || A X - I || grows like cond(A)^2 eps:
+// on config 4's patches, cond ~ 1e7, it returned 2e-3 where the UNPIVOTED register kernel it was meant to back up gives
+// 5e-8 -- found in round 3 by flagging every patch (ALFI_PATCH_CHECK_TOL=3e-9, scripts/repair_check.py).  Solving
+// A x_j = e_j column by column through the LU factors is backward stable per column: cond(A) eps.)
 template <int BS>
 __global__ __launch_bounds__(256) void patch_repair_kernel(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colidx,
                                                             const double* __restrict__ vals, int flat,
@@ -119,14 +124,15 @@ __global__ __launch_bounds__(256) void patch_repair_kernel(const int32_t* __rest
   const int64_t off = patch_ptr[p];
   const int n = (int)(patch_ptr[p + 1] - off);
   const int ld = (n + 1) & ~1;
-  double* prow = reinterpret_cast<double*>(smem);        // n: scaled pivot row
+  double* prow = reinterpret_cast<double*>(smem);        // n: pivot row
   double* mcol = prow + n;                               // n: multipliers of the pivot column
   int32_t* dofs_s = reinterpret_cast<int32_t*>(mcol + n);   // n
-  int32_t* perm = dofs_s + n;                            // n
+  int32_t* perm = dofs_s + n;                            // n: row k was exchanged with row perm[k] at step k
   __shared__ double red_v[256];
   __shared__ int red_i[256];
   __shared__ int bad_s;
-  double* W = scratch + (int64_t)blockIdx.x * scratch_stride;
+  double* W = scratch + (int64_t)blockIdx.x * scratch_stride;     // L \ U
+  double* Y = W + (int64_t)n * n;                                   // L^-1 P, then X
   const int tid = threadIdx.x;
   if (tid == 0) bad_s = 0;
   for (int i = tid; i < n; i += 256) dofs_s[i] = patch_dofs[off + i];
@@ -145,6 +151,7 @@ __global__ __launch_bounds__(256) void patch_repair_kernel(const int32_t* __rest
     }
   }
   __syncthreads();
+  // ---- P A = L U
   for (int k = 0; k < n; ++k) {
     // pivot search: largest |W[i][k]|, i >= k (ties: smallest i)
     double bv = -1.0;
@@ -173,26 +180,24 @@ __global__ __launch_bounds__(256) void patch_repair_kernel(const int32_t* __rest
     }
     if (tid == 0) perm[k] = pr;
     if (pr != k)
-      for (int j = tid; j < n; j += 256) {
+      for (int j = tid; j < n; j += 256) {     // whole rows: the multipliers already stored move with their rows
         const double t = W[(int64_t)k * n + j];
         W[(int64_t)k * n + j] = W[(int64_t)pr * n + j];
         W[(int64_t)pr * n + j] = t;
       }
     __syncthreads();
     const double ip = 1.0 / W[(int64_t)k * n + k];
-    for (int j = tid; j < n; j += 256) {
-      prow[j] = (j == k) ? ip : W[(int64_t)k * n + j] * ip;
-      mcol[j] = (j == k) ? 0.0 : W[(int64_t)j * n + k];
+    for (int j = k + 1 + tid; j < n; j += 256) {
+      prow[j] = W[(int64_t)k * n + j];
+      const double l = W[(int64_t)j * n + k] * ip;
+      mcol[j] = l;
+      W[(int64_t)j * n + k] = l;
     }
     __syncthreads();
-    for (int64_t e = tid; e < (int64_t)n * n; e += 256) {
-      const int i = (int)(e / n), j = (int)(e % n);
-      if (i == k)
-        W[e] = prow[j];
-      else if (j == k)
-        W[e] = -mcol[i] * ip;
-      else
-        W[e] = __builtin_fma(-mcol[i], prow[j], W[e]);
+    const int m = n - k - 1;                   // trailing block (k+1 .. n-1)^2
+    for (int64_t e = tid; e < (int64_t)m * m; e += 256) {
+      const int i = k + 1 + (int)(e / m), j = k + 1 + (int)(e % m);
+      W[(int64_t)i * n + j] = __builtin_fma(-mcol[i], prow[j], W[(int64_t)i * n + j]);
     }
     __syncthreads();
   }
@@ -200,21 +205,42 @@ __global__ __launch_bounds__(256) void patch_repair_kernel(const int32_t* __rest
     if (tid == 0) atomicExch(status, 1);
     return;
   }
-  // inv(P A) = inv(A) P^T: undo the row interchanges as column interchanges, last first
-  for (int k = n - 1; k >= 0; --k) {
-    const int pr = perm[k];
-    if (pr != k)
-      for (int i = tid; i < n; i += 256) {
-        const double t = W[(int64_t)i * n + k];
-        W[(int64_t)i * n + k] = W[(int64_t)i * n + pr];
-        W[(int64_t)i * n + pr] = t;
+  // ---- Y = L^-1 P: thread c owns column c; (P e_c) = e_q with q = where the row exchanges move row c ... followed forward
+  for (int c = tid; c < n; c += 256) {
+    // P applied to the identity: row r of P is e_{src(r)}; build column c of P = position q with src(q) == c
+    int q = c;
+    // the exchanges were applied to ROWS in order k = 0 .. n-1: the row that started at position c ends at position q
+    for (int k = 0; k < n; ++k) {
+      const int pr = perm[k];
+      if (pr != k) {
+        if (q == k) q = pr;
+        else if (q == pr) q = k;
       }
-    __syncthreads();
+    }
+    for (int i = 0; i < n; ++i) Y[(int64_t)i * n + c] = (i == q) ? 1.0 : 0.0;
   }
+  __syncthreads();
+  for (int i = 1; i < n; ++i) {                // forward: Y[i][:] -= sum_{j < i} L[i][j] Y[j][:]   (unit diagonal)
+    for (int c = tid; c < n; c += 256) {
+      double acc = Y[(int64_t)i * n + c];
+      for (int j = 0; j < i; ++j) acc = __builtin_fma(-W[(int64_t)i * n + j], Y[(int64_t)j * n + c], acc);
+      Y[(int64_t)i * n + c] = acc;
+    }
+    // (thread c only ever touches column c of Y: no barrier needed between the rows)
+  }
+  for (int i = n - 1; i >= 0; --i) {           // backward: X[i][:] = (Y[i][:] - sum_{j > i} U[i][j] X[j][:]) / U[i][i]
+    const double id = 1.0 / W[(int64_t)i * n + i];
+    for (int c = tid; c < n; c += 256) {
+      double acc = Y[(int64_t)i * n + c];
+      for (int j = i + 1; j < n; ++j) acc = __builtin_fma(-W[(int64_t)i * n + j], Y[(int64_t)j * n + c], acc);
+      Y[(int64_t)i * n + c] = acc * id;
+    }
+  }
+  __syncthreads();
   double* S = inv + inv_ptr[p];
   for (int64_t e = tid; e < (int64_t)ld * n; e += 256) {
     const int r = (int)(e / n), c = (int)(e % n);
-    S[patch_inv_index(r, c, n, ld)] = r < n ? W[(int64_t)r * n + c] : 0.0;      // r == n: the zero padding row
+    S[patch_inv_index(r, c, n, ld)] = r < n ? Y[(int64_t)r * n + c] : 0.0;      // r == n: the zero padding row
   }
 }
 
@@ -294,7 +320,7 @@ int patch_verify_and_repair(alfi_level* L, int unpivoted_status) {
     return alfi_set_error(ctx, ALFI_E_SINGULAR, "%d patch inverses fail the residual probe (worst %.3e) and the pivoted "
                           "repair handles patches of at most %d dofs", nflag, worst, (int)REPAIR_MAX_NP);
   // pivoted re-inversion of the flagged patches, in batches bounded by 1 GiB of scratch
-  const int64_t stride = (int64_t)L->max_np * L->max_np;
+  const int64_t stride = 2 * (int64_t)L->max_np * L->max_np;      // L \ U and the inverse being built
   const int64_t per_batch = std::max<int64_t>(1, ((int64_t)1 << 27) / stride);
   double* scratch = nullptr;
   ALFI_HIP_CHECK(ctx, hipMalloc((void**)&scratch, sizeof(double) * (size_t)(std::min<int64_t>(per_batch, nflag) * stride)));
@@ -334,7 +360,13 @@ int patch_verify_and_repair(alfi_level* L, int unpivoted_status) {
   if (rc != 0) return rc;
   L->chk_repaired = nflag - nflag2;
   L->chk_worst_after = worst2;
-  if (nflag2 > 0)
+  // A patch that stays above the tolerance after a pivoted LU inversion is ill-conditioned, not mis-factored: the probe
+  // residual of a backward-stable inverse scales like cond(A_p) eps (gamma / nu h^-2 eps: 5e-8 at Re 5000 on the shipped
+  // meshes, more on finer levels at Re 10 000).  LAPACK -- the reference's patch solver -- would hand back the same
+  // inverse without complaint, so this is reported (alfi_patches_check: worst residual afterwards, flagged != repaired), not
+  // an error; only a residual beyond ALFI_PATCH_CHECK_FAIL (default 1000 x the tolerance) or a non-finite one fails the setup.
+  static const double fail = getenv("ALFI_PATCH_CHECK_FAIL") ? atof(getenv("ALFI_PATCH_CHECK_FAIL")) : 1e3 * tol;
+  if (nflag2 > 0 && !(worst2 <= fail))
     return alfi_set_error(ctx, ALFI_E_SINGULAR, "%d patch inverses still fail the residual probe after pivoted re-inversion "
                           "(worst %.3e): the patch operators are singular to working precision", nflag2, worst2);
   return 0;

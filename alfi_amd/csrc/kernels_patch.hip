@@ -640,7 +640,13 @@ int launch_patch_apply_range(alfi_level* L, int64_t p0, int64_t p1, const double
     alfi_prof_end(ctx, t);
     return 0;
   }
-  if (L->max_np > SMALL_PATCH_MAX) {            // one workgroup per patch (kernels_bigpatch.hip)
+  // levels with FEW star patches of 3-D size (the lower levels of a hierarchy: 125 and 729 patches under config 3's 35 937):
+  // a wave per patch streams ~100 KB through one wave -- ~19 us however few patches there are -- so they take the
+  // workgroup-per-patch kernel of the macro stars as well (row pieces dealt to 4 waves, several workgroups per patch when
+  // the chip would stay empty): config 3 17.77 -> 17.46 ms per cycle.  ALFI_SMALL_LEVEL_WG = the patch count up to which
+  // (default 1000; 0: never).
+  static const int64_t few = getenv("ALFI_SMALL_LEVEL_WG") ? atoll(getenv("ALFI_SMALL_LEVEL_WG")) : 1000;
+  if (L->max_np > SMALL_PATCH_MAX || (L->max_np > 64 && L->npatch <= few)) {   // one workgroup per patch (kernels_bigpatch.hip)
     ALFI_CHECK(launch_big_apply_range(L, p0, p1, x));
     alfi_prof_end(ctx, t);
     return 0;

@@ -115,7 +115,31 @@ class ThreeDimBackwardsFacingStepProblem(NavierStokesProblem):
 
     def mesh(self, distribution_parameters=None):
         from .mesh import bfs3d_mesh, read_gmsh
-        return read_gmsh(self.msh) if self.msh else bfs3d_mesh(self.baseN)
+        if not self.msh:
+            return bfs3d_mesh(self.baseN)
+        mesh = read_gmsh(self.msh)
+        self.check_boundary_tags(mesh)
+        return mesh
+
+    def check_boundary_tags(self, mesh):
+        """The reference applies its boundary conditions by physical tag (1 = inflow, 3 = walls Dirichlet, 2 = outflow natural,
+        bfs3d.py:23-26); here the Dirichlet part of the boundary is chosen geometrically (``dirichlet_facets``: everything
+        but the outflow plane x = 10), because the refined levels of the hierarchy carry no tags.  A gmsh channel of another
+        length or orientation would silently get wrong conditions: refuse a mesh whose tags disagree with the predicate."""
+        tags = getattr(mesh, "boundary_tags", None)
+        if not tags:
+            return
+        bf = mesh.boundary_facets
+        keys = [tuple(sorted(int(v) for v in mesh.facets[f])) for f in bf]
+        tagged = np.array([tags.get(kk, -1) for kk in keys])
+        geo = np.asarray(self.dirichlet_facets(mesh.coords[mesh.facets[bf]].mean(axis=1)), dtype=bool)
+        known = tagged >= 0
+        by_tag = np.isin(tagged, (1, 3))
+        bad = known & (by_tag != geo)
+        if bad.any():
+            raise ValueError("%s: %d boundary facets whose physical tag (1 / 3 = Dirichlet, 2 = natural outflow, bfs3d.py:23-26) "
+                             "disagrees with the geometric choice of the Dirichlet boundary (x < 10): this is not the "
+                             "reference's channel" % (self.msh, int(bad.sum())))
 
     def driver(self, x):
         """poiseuille_flow (bfs3d.py:19-21): the inflow profile, extended along the channel as the linearisation state."""

@@ -11,7 +11,7 @@ runs the level's apply kernel once (one launch per smoothed level before the fir
 
 ``first``: only the first N launches of the kernel -- the V-cycle of ``bench.py --steps 1 --warmup 0`` (60 patch applies, 79
 SpMVs on config 4); the full cycles bench.py runs afterwards for ``fcycle_ms`` have a different mix of levels.
-``grids``: comma-separated Grid_Size values -- only launches of those sizes (config 5: the smoother's big_apply_kernel launches,
+``grids``: ``max`` (only the launches on the kernel's largest grid: the finest level) or comma-separated Grid_Size values -- only launches of those sizes (config 5: the smoother's big_apply_kernel launches,
 903680 and 310272 threads; the transfers' interior solves use the same kernel on smaller grids).
 """
 import glob
@@ -25,7 +25,9 @@ def per_kernel(d, counter, prefix, first=None, grids=None, skip=0):
     f = glob.glob(d + "/**/*_counter_collection.csv", recursive=True)[0]
     t = pd.read_csv(f)
     t = t[(t["Counter_Name"] == counter) & t["Kernel_Name"].str.startswith(prefix)]
-    if grids:
+    if grids == "max":         # the launches on the largest grid only (the finest level)
+        t = t[t["Grid_Size"] == t["Grid_Size"].max()]
+    elif grids:
         t = t[t["Grid_Size"].isin(grids)]
     # one row per dispatch and counter instance: sum the instances, keep dispatch order
     v = t.groupby("Dispatch_Id", sort=True)["Counter_Value"].sum().to_numpy()[skip:]
@@ -36,7 +38,9 @@ def main():
     fetch_dir, write_dir, prefix, out = sys.argv[1:5]
     tag = sys.argv[5] if len(sys.argv) > 5 else ""
     first = int(sys.argv[6]) if len(sys.argv) > 6 else None
-    grids = [int(g) for g in sys.argv[7].split(",")] if len(sys.argv) > 7 and sys.argv[7] not in ("", "-") else None
+    grids = None
+    if len(sys.argv) > 7 and sys.argv[7] not in ("", "-"):
+        grids = "max" if sys.argv[7] == "max" else [int(g) for g in sys.argv[7].split(",")]
     skip = int(sys.argv[8]) if len(sys.argv) > 8 else 0
     first = first or None
     f, w = (per_kernel(fetch_dir, "FETCH_SIZE", prefix, first, grids, skip),

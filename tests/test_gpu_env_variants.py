@@ -32,11 +32,16 @@ def test_switch(env, tol):
 @pytest.mark.parametrize("env", [{},                                                  # defaults: four-launch fused iteration on the small levels
                                  {"ALFI_TINY_BYTES": "1000000"},                      # one-workgroup kernel on the tiny levels
                                  {"ALFI_FUSED_SMOOTHER": "0"},                        # the general launch chain
+                                 {"ALFI_FUSED_ALL": "1"},                             # normalisation folded behind the patch solves on every level
+                                 {"ALFI_SMALL_LEVEL_WG": "0"},                        # a wave per patch on every level
                                  {"ALFI_TINY_BYTES": "1000000000"},                   # every level through the one-workgroup kernel
                                  {"ALFI_SPMV_DEDUP": "0"},                            # direct x gathers in the large SpMV
                                  {"ALFI_SPMV_ALIGNED": "0", "ALFI_FUSED_SMOOTHER": "0"},   # de-duplicated SpMV on small levels too
                                  {"ALFI_SPMV_ALIGNED": "0", "ALFI_XCD_MAP": "1", "ALFI_FUSED_SMOOTHER": "0"},
-                                 {"ALFI_FUSED_REDUCE_MAX": "0"}, {"ALFI_INVERT_MFMA": "0"}, {"ALFI_INVERT_MFMA": "2"}])
+                                 {"ALFI_FUSED_REDUCE_MAX": "0"}, {"ALFI_INVERT_MFMA": "0"}, {"ALFI_INVERT_MFMA": "2"},
+                                 # EVERY patch flagged by the residual probe and re-inverted by the pivoted LU repair
+                                 # (kernels_check.hip), 14-dof and 153-dof patches alike
+                                 {"ALFI_PATCH_CHECK_TOL": "1e-14", "ALFI_PATCH_CHECK_FAIL": "1e-6"}])
 def test_smoother_paths(env):
     """Every implementation of the level smoother (alfi/solver.py:313-328) and of the level product behind it gives the
     oracle's FGMRES iterate (1e-7) and cycles (1e-5)."""

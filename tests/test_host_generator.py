@@ -271,3 +271,9 @@ def test_gmsh_reader_round_trip_and_channel_problem(tmp_path):
     V = VectorFunctionSpace(mh[0], NodalElement(3, 2, False), dirichlet=prob.dirichlet_facets)
     Vs = VectorFunctionSpace(m, NodalElement(3, 2, False), dirichlet=prob.dirichlet_facets)
     assert V.num_nodes == Vs.num_nodes and len(V.bc_nodes) == len(Vs.bc_nodes)
+    # the Dirichlet boundary is chosen geometrically (x < 10), the reference chooses by tag (bfs3d.py:23-26): a
+    # mesh whose tags say otherwise -- here: inflow and outflow swapped -- is refused instead of silently mis-conditioned
+    path3 = str(tmp_path / "swapped.msh")
+    write_gmsh(m, path3, lambda c: np.where(c[:, 0] < 1e-12, 2, np.where(c[:, 0] > 10 - 1e-12, 1, 3)))
+    with pytest.raises(ValueError, match="disagrees with the geometric choice"):
+        ThreeDimBackwardsFacingStepProblem(msh=path3).mesh()
