@@ -63,7 +63,8 @@ def load(path):
 def build_shared(build, rank, barrier, tag, set_threads=None, all_threads=None, my_threads=None):
     """``build()`` runs on rank 0 only (with ``all_threads`` host threads if ``set_threads`` is given), everyone returns the
     same object.  ``barrier``: a collective over the node's ranks (called twice).  The file is unlinked as soon as every rank
-    has mapped it, so nothing stays behind in /dev/shm (held in memory) when the run ends or dies later."""
+    has mapped it, so nothing stays behind in /dev/shm (held in memory) when the run ends or dies later.  If the file cannot
+    be written (no /dev/shm, not enough room) the other ranks fall back to building their own copy: slower, never wrong."""
     path = _path(tag)
     obj, err = None, None
     if rank == 0:
@@ -71,21 +72,32 @@ def build_shared(build, rank, barrier, tag, set_threads=None, all_threads=None, 
             if set_threads and all_threads:
                 set_threads(all_threads)
             obj = build()
-            dump(obj, path)
         except BaseException as e:                 # the others must not wait for a file that never comes
             err = e
-            try:
-                with open(path, "wb") as f:
-                    f.write(b"FAILED")
-            except OSError:
-                pass
         finally:
             if set_threads and my_threads:
                 set_threads(my_threads)
+        try:
+            if err is None:
+                dump(obj, path)
+            else:
+                raise OSError("generation failed")
+        except (OSError, pickle.PicklingError, MemoryError) as e:
+            try:
+                with open(path, "wb") as f:        # a marker the others recognise (bad magic)
+                    f.write(b"UNAVAILABLE")
+            except OSError:
+                pass
+            if err is None:
+                import sys
+                sys.stderr.write("[alfi_amd.shared] cannot share the generated hierarchy (%s): every rank builds its own\n" % (e,))
     barrier()
     try:
         if rank != 0:
-            obj = load(path)
+            try:
+                obj = load(path)
+            except (OSError, ValueError, struct.error, pickle.UnpicklingError):
+                obj = build()                      # rank 0 could not write the file (or failed: then this fails the same way)
     finally:
         barrier()
         if rank == 0:

@@ -277,3 +277,30 @@ def test_gmsh_reader_round_trip_and_channel_problem(tmp_path):
     write_gmsh(m, path3, lambda c: np.where(c[:, 0] < 1e-12, 2, np.where(c[:, 0] > 10 - 1e-12, 1, 3)))
     with pytest.raises(ValueError, match="disagrees with the geometric choice"):
         ThreeDimBackwardsFacingStepProblem(msh=path3).mesh()
+
+
+@pytest.mark.parametrize("dim,k", [(2, 2), (3, 1), (3, 2)])
+def test_contributor_lists_of_the_device_assembly(dim, k):
+    """_hostlib.contributors (the gather lists of alfi_level_set_assembly): every (cell, a, b) triple appears exactly once, in
+    the block (node a, node b) of the level's sparsity, cells ascending inside a block; summing host element matrices through
+    the lists reproduces the assembled operator."""
+    from alfi_amd import _hostlib
+    from alfi_amd.problem import TwoDimLidDrivenCavityProblem, ThreeDimLidDrivenCavityProblem, build_hierarchy
+    prob = TwoDimLidDrivenCavityProblem(3) if dim == 2 else ThreeDimLidDrivenCavityProblem(2)
+    lv, _ = build_hierarchy(prob, 1, k, Re=10.0)
+    L = lv[-1]
+    V, A = L.V, L.A
+    cn = V.cell_nodes
+    nloc = cn.shape[1]
+    cptr, ccell, cba = _hostlib.contributors(cn, V.num_nodes, A.rowptr, A.colidx)
+    assert cptr[0] == 0 and cptr[-1] == cn.shape[0] * nloc * nloc and (np.diff(cptr) >= 1).all()
+    rows = np.repeat(np.arange(A.nbrows), np.diff(A.rowptr))
+    blk = np.repeat(np.arange(A.nnzb), np.diff(cptr))
+    a, b = cba.astype(np.int64) % nloc, cba.astype(np.int64) // nloc
+    assert np.array_equal(cn[ccell, a], rows[blk]) and np.array_equal(cn[ccell, b], A.colidx[blk])
+    # every triple once
+    key = (ccell.astype(np.int64) * nloc + a) * nloc + b
+    assert np.array_equal(np.sort(key), np.arange(key.size))
+    # fixed order: cells ascending inside a block
+    same = blk[1:] == blk[:-1]
+    assert (ccell[1:][same] >= ccell[:-1][same]).all()
