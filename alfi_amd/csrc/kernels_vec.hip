@@ -78,7 +78,7 @@ __global__ __launch_bounds__(256) void bsr_spmv_flat_kernel(int64_t kbase, int64
   // interleaved order (5.44 vs 5.50 TB/s, same box) -- x already lives in the Infinity Cache and the interleaved order
   // spreads the value stream over the HBM channels more evenly -- so it is off by default.
   int64_t blk = blockIdx.x;
-  if (xcd_map) {
+  if (xcd_map == 1) {
     const int64_t nb = gridDim.x, per = nb >> 3, rem = nb & 7, xcd = blk & 7, idx = blk >> 3;
     blk = xcd * per + (xcd < rem ? xcd : rem) + idx;
   }
@@ -224,9 +224,19 @@ __global__ __launch_bounds__(256) void bsr_spmv_dedup_kernel(int64_t nnzb, int64
   __shared__ double xs[SPMV_DEDUP_MAX * BS];
   const int lane = threadIdx.x & 63;
   int64_t g = blockIdx.x;
-  if (xcd_map) {      // workgroup b runs on XCD b % 8: give every XCD (= every L2) one contiguous eighth of the groups
+  if (xcd_map == 1) {      // workgroup b runs on XCD b % 8: give every XCD (= every L2) one contiguous eighth of the groups
     const int64_t nb = gridDim.x, per = nb >> 3, rem = nb & 7, xcd = g & 7, idx = g >> 3;
     g = xcd * per + (xcd < rem ? xcd : rem) + idx;
+  } else if (xcd_map > 1) {
+    // strips: XCD x takes the groups of strips x, x + 8, x + 16, ... (xcd_map groups each): rows that share x entries meet
+    // in ONE L2, while at any moment the eight XCDs stream eight neighbouring strips -- the value stream stays spread over
+    // the HBM channels, which the contiguous-eighth map above loses.  The tail (last incomplete round of strips) keeps the
+    // plain order.
+    const int64_t S = xcd_map, nb = gridDim.x, full = nb / (8 * S) * (8 * S);
+    if (g < full) {
+      const int64_t xcd = g & 7, i = g >> 3, strip = i / S, within = i - strip * S;
+      g = (strip * 8 + xcd) * S + within;
+    }
   }
   const int64_t chunk = g * 4 + (threadIdx.x >> 6);
   const bool active = chunk < nchunks;
@@ -499,7 +509,10 @@ static int launch_bsr_spmv_bs(alfi_ctx* ctx, const DevBSR& A, const double* x, d
     // operator values and indices are used once per product: stream them past the caches (nontemporal) so that x and y
     // keep the L2 / Infinity Cache.  ALFI_NT=0 switches to plain loads (A/B measurements).
     static const bool nt = !(getenv("ALFI_NT") && atoi(getenv("ALFI_NT")) == 0);
-    static const int xcd = (getenv("ALFI_XCD_MAP") && atoi(getenv("ALFI_XCD_MAP")) == 1) ? 1 : 0;
+    // ALFI_XCD_MAP: 0 plain interleaved order, 1 contiguous eighths (measured slower, both kernels), > 1 strips of that many
+    // workgroups per XCD (de-duplicated kernel only).  Default 64: config 4 finest, same box, 6.29 -> 6.45 TB/s for any strip
+    // size 16 .. 1024
+    static const int xcd = getenv("ALFI_XCD_MAP") ? atoi(getenv("ALFI_XCD_MAP")) : 64;
     if (A.aligned) {          // whole rows per chunk: one launch, no fix-up
       const int64_t nchunks = A.nchunks;
       if (nt)

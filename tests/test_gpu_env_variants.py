@@ -38,6 +38,8 @@ def test_switch(env, tol):
                                  {"ALFI_SPMV_DEDUP": "0"},                            # direct x gathers in the large SpMV
                                  {"ALFI_SPMV_ALIGNED": "0", "ALFI_FUSED_SMOOTHER": "0"},   # de-duplicated SpMV on small levels too
                                  {"ALFI_SPMV_ALIGNED": "0", "ALFI_XCD_MAP": "1", "ALFI_FUSED_SMOOTHER": "0"},
+                                 {"ALFI_SPMV_ALIGNED": "0", "ALFI_XCD_MAP": "2", "ALFI_FUSED_SMOOTHER": "0"},   # strips of 2 workgroups per XCD
+                                 {"ALFI_SPMV_ALIGNED": "0", "ALFI_XCD_MAP": "0", "ALFI_FUSED_SMOOTHER": "0"},
                                  {"ALFI_FUSED_REDUCE_MAX": "0"}, {"ALFI_INVERT_MFMA": "0"}, {"ALFI_INVERT_MFMA": "2"},
                                  # EVERY patch flagged by the residual probe and re-inverted by the pivoted LU repair
                                  # (kernels_check.hip), 14-dof and 153-dof patches alike
