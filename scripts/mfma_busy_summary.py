@@ -16,8 +16,8 @@ def main():
     launches = collections.defaultdict(set)
     for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
-            k = re.sub(r"\(.*", "", r["Kernel_Name"])
-            k = re.sub(r"^void ", "", k).replace("(anonymous namespace)::", "")
+            k = r["Kernel_Name"].replace("(anonymous namespace)::", "")
+            k = re.sub(r"^void ", "", re.sub(r"\(.*", "", k))
             agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
             launches[k].add(r["Dispatch_Id"])
     res = {}
