@@ -330,25 +330,19 @@ __global__ __launch_bounds__(256) void patch_apply_small_kernel(int64_t p0, int6
     rows = (int)(patch_inv_index(r, 1, n, ld) - patch_inv_index(r, 0, n, ld));
   }
   double acc0 = 0.0, acc1 = 0.0;
-  // all lanes of the wave run the same trip count (the shuffles need them); n differs between the groups of a wave
-  int nmax = n;
+  // ALL 2 G columns of the lane's row pair are requested before the first one is used (a patch is at most 2 G wide): 16 / 32
+  // independent 16-byte loads in flight per lane instead of 4 -- a wave only has 8 (4) patches of 1.5 (6) KB to stream, so
+  // its run time is the latency of its load batches, not their bandwidth
+  double2 v[2 * G];
 #pragma unroll
-  for (int o = G; o < 64; o <<= 1) nmax = max(nmax, __shfl_xor(nmax, o));
-  for (int c0 = 0; c0 < nmax; c0 += 4) {
-    double2 v[4];
-    double xc[4];
+  for (int c = 0; c < 2 * G; ++c)
+    v[c] = (active && c < n) ? load_pair<NT>(base + (int64_t)c * rows) : make_double2(0.0, 0.0);
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int c = c0 + u;
-      const double lo = __shfl(xa, c & (G - 1), G), hi = __shfl(xb, c & (G - 1), G);
-      xc[u] = c < G ? lo : hi;
-      v[u] = (active && c < n) ? load_pair<NT>(base + (int64_t)c * rows) : make_double2(0.0, 0.0);
-    }
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      acc0 = __builtin_fma(v[u].x, xc[u], acc0);
-      acc1 = __builtin_fma(v[u].y, xc[u], acc1);
-    }
+  for (int c = 0; c < 2 * G; ++c) {
+    const double lo = __shfl(xa, c & (G - 1), G), hi = __shfl(xb, c & (G - 1), G);
+    const double xc = c < G ? lo : hi;
+    acc0 = __builtin_fma(v[c].x, xc, acc0);
+    acc1 = __builtin_fma(v[c].y, xc, acc1);
   }
   if (active) *reinterpret_cast<double2*>(stage + stage_ptr[p] + r) = make_double2(acc0, acc1);
 }

@@ -623,7 +623,10 @@ def main():
     # warm-up + the same number of steps without events; reported next to the headline, never as `value`
     other = dmg.variant(robust_restriction=not args.restriction)
     dxo = ctx.vec(L.n)
-    for _ in range(max(args.warmup, 1)):       # (the host work in between lets the clocks drop: warm up again)
+    # (the host work in between lets the clocks drop, and they take ~0.1 s of load to come back: warm up for at least 0.3 s
+    # -- with config 2's 5 ms cycles five warm-up cycles are not enough and the loop reads 7-8 ms)
+    n_warm = max(args.warmup, 1, int(0.3 / max(elapsed / args.steps, 1e-4)))
+    for _ in range(n_warm):
         other.vcycle(db, dxo)
     ctx.sync()
     t0 = time.perf_counter()
@@ -637,7 +640,7 @@ def main():
     # the timed setting again without any HIP event (what a production cycle costs; on launch-bound configs the event
     # records around the dominant kernel lengthen the cycle)
     dxn = ctx.vec(L.n)
-    for _ in range(max(args.warmup, 1)):
+    for _ in range(n_warm):
         dmg.vcycle(db, dxn)
     ctx.sync()
     t0 = time.perf_counter()
@@ -726,7 +729,7 @@ def main():
         "ms_per_step_without_events": noevents_ms,
         "other_restriction_setting": {"robust_restriction": not args.restriction, "ms_per_step": other_ms,
                                       "v_cycles_per_s": 1e3 / other_ms, "rel_residual_after_cycles": other_res,
-                                      "cycles": max(args.steps, 2) + max(args.warmup, 1),
+                                      "cycles": max(args.steps, 2) + n_warm,
                                       "note": "same hierarchy, the reference's `--restriction` flag flipped "
                                               "(examples/Makefile:6-16 passes it, driver.py:41 defaults it off); no events"},
         "dof_smooths_per_s": L.n * smooths_per_cycle_finest * vps,
