@@ -657,6 +657,7 @@ int alfi_level_update_values(alfi_level* L, const double* bvals) {
 static void free_assembly(AssemblyDev* S) {
   dev_free(S->cptr); dev_free(S->ccell); dev_free(S->cba); dev_free(S->cell_nodes); dev_free(S->grad); dev_free(S->vol);
   dev_free(S->Ta); dev_free(S->Tb); dev_free(S->Kv); dev_free(S->Dv);
+  dev_free(S->wq); dev_free(S->phi); dev_free(S->dphi); dev_free(S->d2phi); dev_free(S->hcell); dev_free(S->diag);
   *S = AssemblyDev();
 }
 
@@ -725,6 +726,59 @@ int alfi_level_assemble(alfi_level* L, double nu, double gamma, double adv, cons
   alfi_prof_end(ctx, t);
   L->factored = false;
   return 0;
+}
+
+int alfi_level_set_supg(alfi_level* L, int nq, const double* wq, const double* phi, const double* dphi, const double* d2phi,
+                        const double* hcell, const int32_t* diag) {
+  alfi_ctx* ctx = L->ctx;
+  AssemblyDev& S = L->asmb;
+  if (!S.ready) return alfi_set_error(ctx, ALFI_E_STATE, "alfi_level_set_supg before alfi_level_set_assembly");
+  if (nq < 1 || !wq || !phi || !dphi || !d2phi || !hcell || !diag) return alfi_set_error(ctx, ALFI_E_ARG, "NULL / empty SUPG tables");
+  if (S.nloc * L->bs > 64) return alfi_set_error(ctx, ALFI_E_ARG, "SUPG kernel handles elements of at most 64 dofs, got %d", S.nloc * L->bs);
+  const int64_t nb = L->A.nbrows;
+  {
+    std::vector<int32_t> rowptr(nb + 1);
+    ALFI_HIP_CHECK(ctx, hipMemcpy(rowptr.data(), L->A.rowptr, sizeof(int32_t) * (nb + 1), hipMemcpyDeviceToHost));
+    for (int64_t r = 0; r < nb; ++r)
+      if (diag[r] < rowptr[r] || diag[r] >= rowptr[r + 1]) return alfi_set_error(ctx, ALFI_E_ARG, "diagonal block of row %lld out of its row", (long long)r);
+  }
+  for (int64_t c = 0; c < S.ncell; ++c)
+    if (!(hcell[c] > 0.0)) return alfi_set_error(ctx, ALFI_E_ARG, "cell size of cell %lld is not positive", (long long)c);
+  ALFI_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  ALFI_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  dev_free(S.wq); dev_free(S.phi); dev_free(S.dphi); dev_free(S.d2phi); dev_free(S.hcell); dev_free(S.diag);
+  S.wq = S.phi = S.dphi = S.d2phi = S.hcell = nullptr;
+  S.diag = nullptr;
+  S.supg_ready = false;
+  const int nv = L->bs + 1, nloc = S.nloc;
+  ALFI_CHECK(dev_upload(ctx, &S.wq, wq, nq));
+  ALFI_CHECK(dev_upload(ctx, &S.phi, phi, (int64_t)nq * nloc));
+  ALFI_CHECK(dev_upload(ctx, &S.dphi, dphi, (int64_t)nq * nloc * nv));
+  ALFI_CHECK(dev_upload(ctx, &S.d2phi, d2phi, (int64_t)nq * nloc * nv * nv));
+  ALFI_CHECK(dev_upload(ctx, &S.hcell, hcell, S.ncell));
+  ALFI_CHECK(dev_upload(ctx, &S.diag, diag, nb));
+  S.nq = nq;
+  S.supg_ready = true;
+  return 0;
+}
+
+int alfi_level_supg(alfi_level* L, double nu, double weight, double magic, const double* d_state, int add_to_operator, double* d_F) {
+  alfi_ctx* ctx = L->ctx;
+  if (!L->asmb.supg_ready) return alfi_set_error(ctx, ALFI_E_STATE, "alfi_level_supg before alfi_level_set_supg");
+  if (!d_state) return alfi_set_error(ctx, ALFI_E_ARG, "SUPG needs the state");
+  if (!add_to_operator && !d_F) return 0;
+  ctx->cur_tag = L->id;
+  int t = alfi_prof_begin(ctx, ALFI_EV_PATCH_FACTOR);       // PCPatchComputeOp
+  ALFI_CHECK(launch_supg(L, nu, weight, magic, d_state, add_to_operator, d_F));
+  alfi_prof_end(ctx, t);
+  if (add_to_operator) L->factored = false;
+  return 0;
+}
+
+int alfi_level_apply_bc(alfi_level* L) {
+  if (!L->asmb.ready) return alfi_set_error(L->ctx, ALFI_E_STATE, "alfi_level_apply_bc before alfi_level_set_assembly");
+  L->factored = false;
+  return launch_apply_bc(L);
 }
 
 int alfi_level_get_values(alfi_level* L, double* bvals) {

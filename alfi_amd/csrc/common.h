@@ -193,6 +193,15 @@ struct AssemblyDev {
   double* Tb = nullptr;          // (nloc * nloc, d + 1, nloc): [b * nloc + a][i][k] = T1[b, i, k, a]
   double* Kv = nullptr;          // viscous part, the operator's lane-major layout
   double* Dv = nullptr;          // grad-div part
+  // SUPG (alfi_level_set_supg): quadrature tables of the element and the cell sizes
+  bool supg_ready = false;
+  int nq = 0;
+  double* wq = nullptr;          // (nq) weights summing to 1
+  double* phi = nullptr;         // (nq, nloc)
+  double* dphi = nullptr;        // (nq, nloc, d + 1) derivatives w.r.t. the barycentric coordinates
+  double* d2phi = nullptr;       // (nq, nloc, d + 1, d + 1)
+  double* hcell = nullptr;       // (ncell) cell size (2 x circumradius)
+  int32_t* diag = nullptr;       // (nodes) index of the diagonal block of every block row
 };
 
 struct alfi_level {
@@ -441,6 +450,8 @@ int launch_bsr_spmv_dot(alfi_ctx* ctx, const DevBSR& A, const double* z, double*
                         double* partial, int* nblocks);
 int launch_assemble_gather(alfi_level* lvl, double nu, double gamma, double adv, const double* d_state, int apply_bc);
 int launch_vals_from_lanes(alfi_ctx* ctx, const DevBSR& A, double* d_out);
+int launch_supg(alfi_level* lvl, double nu, double weight, double magic, const double* d_state, int add_vals, double* d_F);
+int launch_apply_bc(alfi_level* lvl);
 int launch_patch_invert_mfma(alfi_ctx* ctx, int64_t npatch, int max_np, const int64_t* patch_ptr, const int64_t* inv_ptr,
                              double* inv, int* status, int* handled);   // kernels_invert.hip
 // one-workgroup FGMRES(k) + patch smoother of a tiny level (kernels_tiny.hip)

@@ -203,6 +203,35 @@ class Level(object):
                                                             _ptr(Ta), _ptr(Tb), _ptr(K), _ptr(D), _ptr(cptr), _ptr(ccell),
                                                             _ptr(cba)))
 
+    def set_supg(self, V, rowptr, colidx, nq=None):
+        """Quadrature tables for the device-side SUPG terms (alfi_level_set_supg): the rule and tabulation of
+        ``_hostlib.supg`` (degree 2k), cell sizes, diagonal blocks."""
+        from . import _hostlib
+        from .elements import simplex_quadrature
+        el, d = V.element, V.dim
+        deg = 3 if (el.bubble or el.degree == 3) else el.degree
+        lam, wq = simplex_quadrature(d, nq or (deg + 1))
+        phi, dphi = el.tabulate(lam)
+        d2phi = el.tabulate_hessian(lam)
+        h = _hostlib.cell_size(V.mesh)
+        rowptr = np.asarray(rowptr, dtype=np.int64)
+        colidx = np.asarray(colidx)
+        rows = np.repeat(np.arange(len(rowptr) - 1), np.diff(rowptr))
+        diag = np.flatnonzero(colidx == rows).astype(np.int32)
+        assert diag.shape[0] == len(rowptr) - 1, "every block row needs its diagonal block"
+        arrs = [np.ascontiguousarray(a, dtype=np.float64) for a in (wq, phi, dphi, d2phi, h)]
+        self.ctx.check(self.ctx.lib.alfi_level_set_supg(self.h, len(wq), _ptr(arrs[0]), _ptr(arrs[1]), _ptr(arrs[2]),
+                                                        _ptr(arrs[3]), _ptr(arrs[4]), _ptr(diag)))
+
+    def supg(self, nu, weight, magic, state, add_to_operator=True, F=None):
+        """SUPG terms about ``state`` on the device (alfi_level_supg): the linearisation into the operator and / or the
+        residual contribution added to the device vector ``F``."""
+        self.ctx.check(self.ctx.lib.alfi_level_supg(self.h, float(nu), float(weight), float(magic), state.ptr,
+                                                    1 if add_to_operator else 0, F.ptr if F is not None else None))
+
+    def apply_bc(self):
+        self.ctx.check(self.ctx.lib.alfi_level_apply_bc(self.h))
+
     def assemble(self, nu, gamma, adv, state=None, apply_bc=True):
         """A = nu K + gamma D + adv N(state) written into the level's operator on the device (alfi_level_assemble);
         ``state``: DeviceVec / RawVec with the level's nodal field.  The patches must be factored again afterwards."""

@@ -46,13 +46,11 @@ class HipNavierStokesSolver(object):
         "sv" ([P_k]^d - P_{k-1}^dg on the barycentric hierarchy with macro-star patches, ScottVogeliusSolver :604-662).
         device_assembly: refresh the level operators of every Newton step ON THE DEVICE (alfi_level_assemble: what
         PatchPC.update does inside PCPATCH, solver.py:320, 325) instead of rediscretising on the host and re-uploading;
-        default: on, unless SUPG is requested (its terms are assembled by the host generator) or ALFI_DEVICE_ASSEMBLY=0."""
+        default: on (viscous, grad-div, advection and SUPG terms), unless ALFI_DEVICE_ASSEMBLY=0."""
         import os
         self.problem, self.gamma, self.verbose = problem, float(gamma), verbose
         if device_assembly is None:
-            device_assembly = os.environ.get("ALFI_DEVICE_ASSEMBLY", "1") != "0" and stabilisation_type in ("none", None)
-        if device_assembly and stabilisation_type not in ("none", None):
-            raise NotImplementedError("device assembly covers the viscous, grad-div and advection terms; SUPG is host-assembled")
+            device_assembly = os.environ.get("ALFI_DEVICE_ASSEMBLY", "1") != "0"
         self.device_assembly = bool(device_assembly)
         self.timings = {"assemble_s": 0.0, "factor_s": 0.0, "residual_s": 0.0, "solve_s": 0.0, "newton_steps": 0}
         self._ctx_arg = ctx
@@ -140,6 +138,8 @@ class HipNavierStokesSolver(object):
             K = _assemble(L, 1.0, 0.0, 0.0, None, False, self.sv)
             D = _assemble(L, 0.0, 1.0, 0.0, None, False, self.sv)
             dl.set_assembly(L.V, K, D, L.A.rowptr, L.A.colidx)
+            if self.supg:
+                dl.set_supg(L.V, L.A.rowptr, L.A.colidx)
             self._dstate.append(self.ctx.vec(L.n))
         self._dres = self.ctx.vec(self.levels[-1].n)
         self._asm_ready = True
@@ -155,7 +155,12 @@ class HipNavierStokesSolver(object):
         self._device_states(u)
         mgl = self.hmg.mg.levels
         for dl, st in zip(mgl, self._dstate):
-            dl.assemble(self.nu, self.gamma, adv, st if adv else None, True)
+            if adv and self.supg:     # A = nu K + gamma D + N(w) + the linearised SUPG term, THEN the boundary conditions
+                dl.assemble(self.nu, self.gamma, adv, st, False)
+                dl.supg(self.nu, self.supg_weight, self.supg_magic, st, True, None)
+                dl.apply_bc()
+            else:
+                dl.assemble(self.nu, self.gamma, adv, st if adv else None, True)
         self.ctx.sync()
         t1 = time.time()
         for L, dl in zip(self.levels, mgl):
@@ -175,6 +180,8 @@ class HipNavierStokesSolver(object):
         self._dstate[-1].set(u)
         fin.assemble(self.nu, self.gamma, 0.5 * adv, self._dstate[-1] if adv else None, False)
         fin.spmv(self._dstate[-1], self._dres)
+        if adv and self.supg:         # + the SUPG residual, gathered on the device into the same vector
+            fin.supg(self.nu, self.supg_weight, self.supg_magic, self._dstate[-1], False, self._dres)
         Fu = self._dres.get()
         Fu += self.B_raw.T @ p
         if self._load is not None:

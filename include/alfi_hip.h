@@ -163,6 +163,19 @@ int alfi_level_set_assembly(alfi_level* lvl, int64_t ncell, int nloc, const int3
                             const double* vol, const double* Ta, const double* Tb, const double* Kvals_host,
                             const double* Dvals_host, const int64_t* cptr, const int32_t* ccell, const uint16_t* cba);
 int alfi_level_assemble(alfi_level* lvl, double nu, double gamma, double adv, const double* d_state, int apply_bc);
+/* SUPG stabilisation on the device (alfi/stabilisation.py:47-97 with the Shakib coefficient, alfi/solver.py:204-234; the
+ * reference's production option `--stabilisation-type supg`).  alfi_level_set_supg (after alfi_level_set_assembly) hands over the
+ * quadrature tables of the element -- weights wq (nq, summing to 1), phi (nq, nloc), dphi (nq, nloc, d+1), d2phi (nq, nloc, d+1,
+ * d+1): basis and derivatives w.r.t. the barycentric coordinates --, the cell sizes hcell (ncell; Firedrake's CellSize) and,
+ * per block row, the index of its diagonal block.  alfi_level_supg then adds, about the device-resident state, the Newton
+ * linearisation of `weight * beta * (Lu, (u . grad) v)` to the level operator (add_to_operator != 0; call between
+ * alfi_level_assemble(..., apply_bc = 0) and alfi_level_apply_bc) and / or its residual contribution to d_F (n doubles, may be
+ * NULL).  alfi_level_apply_bc turns the Dirichlet rows / columns of the operator into identity afterwards. */
+int alfi_level_set_supg(alfi_level* lvl, int nq, const double* wq, const double* phi, const double* dphi, const double* d2phi,
+                        const double* hcell, const int32_t* diag_block);
+int alfi_level_supg(alfi_level* lvl, double nu, double weight, double magic, const double* d_state, int add_to_operator,
+                    double* d_F);
+int alfi_level_apply_bc(alfi_level* lvl);
 /* the operator values in the host layout (nnzb, bs, bs) -- diagnostics / tests */
 int alfi_level_get_values(alfi_level* lvl, double* bvals_host);
 int alfi_level_size(alfi_level* lvl, int64_t* n);

@@ -17,6 +17,8 @@ def main():
     ap.add_argument("config")
     ap.add_argument("--host", action="store_true", help="host rediscretisation (the round-2 path)")
     ap.add_argument("--re", type=float, nargs="+", default=[10.0, 100.0])
+    ap.add_argument("--supg", type=float, default=None, metavar="WEIGHT",
+                    help="SUPG stabilisation with this weight (the reference's production runs: 0.05, generate_submission:18-20)")
     args = ap.parse_args()
     import bench
     from alfi_amd.nssolver import HipNavierStokesSolver
@@ -24,7 +26,8 @@ def main():
     dim, baseN, nref, ke, Re, k = bench.CONFIGS[args.config]
     prob = TwoDimLidDrivenCavityProblem(baseN) if dim == 2 else ThreeDimLidDrivenCavityProblem(baseN)
     t0 = time.time()
-    s = HipNavierStokesSolver(prob, nref, ke, device_assembly=not args.host)
+    s = HipNavierStokesSolver(prob, nref, ke, device_assembly=not args.host,
+                              stabilisation_type="supg" if args.supg is not None else None, stabilisation_weight=args.supg)
     print("%s: %d velocity + %d pressure dofs, setup %.1f s, device assembly %s" % (args.config, s.n_u, s.n_p, time.time() - t0,
                                                                                   s.device_assembly), flush=True)
     for re in args.re:

@@ -79,3 +79,45 @@ def test_newton_with_device_and_host_assembly_agree(mk, k, nref):
     assert np.abs(out[True][0] - out[False][0]).max() <= 1e-8 * np.abs(out[False][0]).max()
     assert np.abs(out[True][1] - out[False][1]).max() <= 1e-7 * np.abs(out[False][1]).max()
     assert out[True][3]["newton_steps"] > 0
+
+
+@pytest.mark.parametrize("name,mk,k,nref", CASES, ids=[c[0] for c in CASES])
+def test_device_supg_terms_equal_the_host_generators(name, mk, k, nref):
+    """The SUPG stabilisation (stabilisation.py:47-97, solver.py:204-234) assembled on the device -- element matrices by one wave
+    per cell, gathered per block in a fixed order -- against alfi_host_supg on every level: linearisation inside the operator
+    (with advection and boundary conditions) entry by entry, and the residual contribution; several scratch batches."""
+    from alfi_amd import _hostlib
+    from alfi_amd.nssolver import HipNavierStokesSolver
+    s = HipNavierStokesSolver(mk(), nref, k, gamma=1e4, device_assembly=True, stabilisation_type="supg", stabilisation_weight=0.05)
+    assert s.device_assembly and s.supg
+    s.nu = 2.0 / 300.0
+    rng = np.random.default_rng(13)
+    for L, dl, st in zip(s.levels, s.hmg.mg.levels, s._dstate):
+        w = rng.standard_normal((L.V.num_nodes, L.V.dim))
+        st.set(w.ravel())
+        ref = s.level_values(L, w, 1.0, True)                       # host: assemble + supg + bc
+        dl.assemble(s.nu, s.gamma, 1.0, st, False)
+        dl.supg(s.nu, s.supg_weight, s.supg_magic, st, True, None)
+        dl.apply_bc()
+        got = dl.get_values()
+        assert np.abs(got - ref).max() <= 1e-12 * np.abs(ref).max(), (name, L.level, np.abs(got - ref).max(), np.abs(ref).max())
+        Fh = np.zeros(L.n)
+        _hostlib.supg(L.V, w, s.nu, s.supg_weight, s.supg_magic, F=Fh)
+        dF = s.ctx.vec(L.n)
+        dl.supg(s.nu, s.supg_weight, s.supg_magic, st, False, dF)
+        assert np.abs(dF.get() - Fh).max() <= 1e-12 * max(np.abs(Fh).max(), 1e-300), (name, L.level)
+    s.close()
+
+
+def test_newton_with_supg_on_the_device_and_on_the_host_agree():
+    from alfi_amd.nssolver import HipNavierStokesSolver, run_solver
+    out = {}
+    for dev in (True, False):
+        s = HipNavierStokesSolver(ThreeDimLidDrivenCavityProblem(2), 2, 1, device_assembly=dev, stabilisation_type="supg",
+                                  stabilisation_weight=0.05)
+        res = run_solver(s, [10, 100])
+        out[dev] = (s.u.copy(), s.p.copy(), [(res[r]["nonlinear_iter"], res[r]["linear_iter"], res[r]["converged"]) for r in (10, 100)])
+        s.close()
+    assert all(c for _, _, c in out[True][2]) and out[True][2] == out[False][2]
+    assert np.abs(out[True][0] - out[False][0]).max() <= 1e-8 * np.abs(out[False][0]).max()
+    assert np.abs(out[True][1] - out[False][1]).max() <= 1e-7 * np.abs(out[False][1]).max()
