@@ -1092,7 +1092,7 @@ int alfi_patches_set_groups(alfi_level* L, const int32_t* group) {
       g_sc.push_back(sc);
       g_uoff.push_back(uoff);
       g_mat.push_back(mat_off);
-      mat_off += (int64_t)m * m + 2 * (int64_t)m * sc;
+      mat_off += cond_group_doubles(m, sc);
       uoff += sc;
     }
     if (uoff > umax) umax = uoff;
@@ -1133,12 +1133,69 @@ int alfi_patches_set_groups(alfi_level* L, const int32_t* group) {
     for (int64_t p = 0; p < L->npatch; ++p) {
       const int64_t s = sptr[p + 1] - sptr[p];
       pbytes[p] = s * s;
-      for (int64_t g = gptr[p]; g < gptr[p + 1]; ++g) pbytes[p] += (int64_t)g_m[g] * (g_m[g] + 2 * g_sc[g]);
+      for (int64_t g = gptr[p]; g < gptr[p + 1]; ++g) pbytes[p] += cond_group_doubles(g_m[g], g_sc[g]);
     }
     std::vector<int32_t> order((size_t)L->npatch);
     for (int64_t p = 0; p < L->npatch; ++p) order[p] = (int32_t)p;
     std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return pbytes[a] > pbytes[b]; });
     ALFI_CHECK(cond_upload(L, &cd.order, order));
+  }
+  {
+    // tables of the three-launch apply (kernels_bigpatch.hip): chunks of <= 256 rows of inv(Sigma) for the sigma kernel
+    // (COND_SIGMA_ROWS), row pairs of the group matrices, the row-sorted order of the u buffer
+    std::vector<int32_t> ch_patch, ch_row, xp_grp, bp_grp, g_xp(g_m.size()), g_bp(g_m.size()), u_dst;
+    std::vector<int64_t> chptr((size_t)npatch + 1, 0), uptr((size_t)npatch + 1, 0), xp_ptr((size_t)npatch + 1, 0),
+        bp_ptr((size_t)npatch + 1, 0);
+    int lds_front = 0, lds_back = 0;
+    for (int64_t p = 0; p < npatch; ++p) {
+      const int s = (int)(sptr[p + 1] - sptr[p]), ld = (s + 1) & ~1;
+      for (int r = 0; r < ld; r += 256) {
+        ch_patch.push_back((int32_t)p);
+        ch_row.push_back(r);
+      }
+      chptr[p + 1] = (int64_t)ch_patch.size();
+      int uo = 0, xp = 0, bp = 0;
+      for (int64_t g = gptr[p]; g < gptr[p + 1]; ++g) {
+        g_xp[g] = xp;
+        g_bp[g] = bp;
+        for (int i = 0; i < cond_ldim(g_m[g]) / 2; ++i) xp_grp.push_back((int32_t)g);
+        for (int j = 0; j < cond_ldim(g_sc[g]) / 2; ++j) bp_grp.push_back((int32_t)g);
+        xp += cond_ldim(g_m[g]) / 2;
+        bp += cond_ldim(g_sc[g]) / 2;
+        uo += g_sc[g];
+      }
+      uptr[p + 1] = uptr[p] + uo;
+      xp_ptr[p + 1] = xp_ptr[p] + xp;
+      bp_ptr[p + 1] = bp_ptr[p] + bp;
+      // every entry of the u buffer is one contribution to one skeleton row: s_uidx restricted to the patch is a permutation
+      const int32_t qb = s_uptr[sptr[p]], qe = s_uptr[sptr[p + 1]];
+      if (qe - qb != uo) return alfi_set_error(ctx, ALFI_E_ARG, "patch %lld: inconsistent skeleton contributions", (long long)p);
+      u_dst.resize((size_t)uptr[p + 1]);
+      for (int32_t q = qb; q < qe; ++q) u_dst[uptr[p] + s_uidx[q]] = q - qb;
+      lds_front = std::max(lds_front, (int)((pp[p + 1] - pp[p] + p_nI[p] + uo + 2) * (int64_t)sizeof(double)));
+      lds_back = std::max(lds_back, (int)((s + uo + 2) * (int64_t)sizeof(double)));
+    }
+    if (ch_patch.empty()) { ch_patch.push_back(0); ch_row.push_back(0); }
+    if (xp_grp.empty()) xp_grp.push_back(0);
+    if (bp_grp.empty()) bp_grp.push_back(0);
+    if (u_dst.empty()) u_dst.push_back(0);
+    if (lds_front > 150 * 1024)
+      return alfi_set_error(ctx, ALFI_E_ARG, "condensed apply would need %d bytes of LDS per patch", lds_front);
+    ALFI_CHECK(cond_upload(L, &cd.ch_patch, ch_patch));
+    ALFI_CHECK(cond_upload(L, &cd.ch_row, ch_row));
+    ALFI_CHECK(cond_upload(L, &cd.uptr, uptr));
+    ALFI_CHECK(cond_upload(L, &cd.u_dst, u_dst));
+    ALFI_CHECK(cond_upload(L, &cd.xp_ptr, xp_ptr));
+    ALFI_CHECK(cond_upload(L, &cd.xp_grp, xp_grp));
+    ALFI_CHECK(cond_upload(L, &cd.g_xp, g_xp));
+    ALFI_CHECK(cond_upload(L, &cd.bp_ptr, bp_ptr));
+    ALFI_CHECK(cond_upload(L, &cd.bp_grp, bp_grp));
+    ALFI_CHECK(cond_upload(L, &cd.g_bp, g_bp));
+    L->h_cond_chptr = chptr;
+    L->cond_lds_front = lds_front;
+    L->cond_lds_back = lds_back;
+    ALFI_CHECK(dev_alloc(ctx, &cd.tmp, sum_n > 0 ? sum_n : 1));
+    L->cond_allocs.push_back(cd.tmp);
   }
   ALFI_CHECK(dev_alloc(ctx, &cd.mat, mat_off));
   L->cond_allocs.push_back(cd.mat);

@@ -176,7 +176,27 @@ struct CondDev {
   double* mat = nullptr;
   double* sinv = nullptr;
   const int32_t* order = nullptr;  // (npatch) patches by descending factor bytes: dispatch order of a full-range apply
+  // three-launch apply (cond_front / cond_sigma / cond_back): the rows of inv(Sigma) in chunks of COND_SIGMA_ROWS
+  const int32_t* ch_patch = nullptr;  // per chunk: its patch (natural order; the chunks of patch p: h_cond_chptr[p .. p + 1])
+  const int32_t* ch_row = nullptr;    //            its first row
+  double* tmp = nullptr;              // (sum_n) per patch [t_g ... | y_S] between the launches
+  const int64_t* uptr = nullptr;      // (npatch+1) prefix sums of the patches' u buffer lengths
+  const int32_t* u_dst = nullptr;     // (sum of those) u buffer entry -> its place in the row-sorted order (inverse of s_uidx)
+  // row PAIRS (rows 2 i, 2 i + 1 of a group's X / W, or of its B): a lane of cond_front / cond_back owns one
+  const int64_t* xp_ptr = nullptr;    // (npatch+1) prefix sums of the patches' X / W row pairs
+  const int32_t* xp_grp = nullptr;    // per pair: its group
+  const int32_t* g_xp = nullptr;      // per group: its first pair in the patch's list
+  const int64_t* bp_ptr = nullptr;    // the same for the rows of B (the u buffer)
+  const int32_t* bp_grp = nullptr;
+  const int32_t* g_bp = nullptr;
 };
+
+// storage of one group's matrices in CondDev::mat: [X (m x m) | B (sc x m) | W (m x sc)], column-major each, the leading
+// dimensions rounded up to EVEN (a lane streams two rows of a column with one 16-byte load; the pad row is never stored)
+__host__ __device__ inline int cond_ldim(int rows) { return (rows + 1) & ~1; }
+__host__ __device__ inline int64_t cond_group_doubles(int m, int sc) {
+  return (int64_t)cond_ldim(m) * m + (int64_t)cond_ldim(sc) * m + (int64_t)cond_ldim(m) * sc;
+}
 
 // device-side data of the operator refresh (alfi_level_set_assembly, kernels_assemble.hip)
 struct AssemblyDev {
@@ -270,7 +290,8 @@ struct alfi_level {
   std::vector<void*> cond_allocs;        // every device array cd points to
   std::vector<int64_t> h_sptr;           // host copy of cd.sptr (sizes of the Schur complements)
   int64_t cond_ngroups = 0, cond_mat_doubles = 0, cond_sinv_doubles = 0;
-  int cond_lds_bytes = 0, cond_max_s = 0, cond_umax = 0;
+  int cond_lds_bytes = 0, cond_max_s = 0, cond_umax = 0, cond_lds_front = 0, cond_lds_back = 0;
+  std::vector<int64_t> h_cond_chptr;      // (npatch+1) chunks of the three-launch condensed apply
   std::vector<int64_t> h_cond_gptr;      // host copy of cd.gptr
   // multiplicative sweeps: positions of the iteration sequence grouped into dependency wavefronts
   bool mult = false, mult_symmetrise = false;

@@ -415,6 +415,91 @@ __device__ __forceinline__ void big_piece(const double* __restrict__ T, int n, c
   if (cg == 0) *reinterpret_cast<double2*>(out + 2 * l) = make_double2(acc0, acc1);
 }
 
+// Rows [r0, r1) of y = T x for a wave, T in the row-piece layout (pieces of 128 rows, then the binary digits of the rest;
+// piece (row0, P rows): entry (r, c) at T[row0 * n + c * P + (r - row0)]).  The range is cut into aligned power-of-two
+// blocks of rows inside the stored pieces: a block of 2 G rows takes G lanes per column and 64 / G columns per load
+// instruction.  Used where whole pieces dealt round-robin leave waves idle (a Schur complement of 312 rows is
+// 2 x 128 + 32 + 16 + 8: two of eight waves would stream 82 % of it).
+template <int G, bool NT>
+__device__ __forceinline__ void big_block(const double* __restrict__ Tp, int P, int n, const double* __restrict__ xs, int lane,
+                                          double* __restrict__ out, int lim) {
+  constexpr int C = 64 / G, U = 8;
+  const int cg = lane / G, l = lane % G;
+  const double* base = Tp + 2 * l;
+  double acc0 = 0.0, acc1 = 0.0;
+  int j = cg;
+  for (; j + (U - 1) * C < n; j += U * C) {
+    big_d2 v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const big_d2* q = reinterpret_cast<const big_d2*>(base + (int64_t)(j + u * C) * P);
+      v[u] = NT ? __builtin_nontemporal_load(q) : *q;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const double xj = xs[j + u * C];
+      acc0 = __builtin_fma(v[u].x, xj, acc0);
+      acc1 = __builtin_fma(v[u].y, xj, acc1);
+    }
+  }
+  for (; j < n; j += C) {
+    const big_d2* q = reinterpret_cast<const big_d2*>(base + (int64_t)j * P);
+    const big_d2 v = NT ? __builtin_nontemporal_load(q) : *q;
+    const double xj = xs[j];
+    acc0 = __builtin_fma(v.x, xj, acc0);
+    acc1 = __builtin_fma(v.y, xj, acc1);
+  }
+  if (C > 1) {
+#pragma unroll
+    for (int o = G; o < 64; o <<= 1) {
+      acc0 += __shfl_xor(acc0, o);
+      acc1 += __shfl_xor(acc1, o);
+    }
+  }
+  if (cg == 0) {                       // lim: rows of the range that exist (the pad row of an odd n is not written)
+    if (2 * l < lim) out[2 * l] = acc0;
+    if (2 * l + 1 < lim) out[2 * l + 1] = acc1;
+  }
+}
+
+template <bool NT>
+__device__ __forceinline__ void big_rows(const double* __restrict__ T, int n, int ld, int r0, int r1,
+                                         const double* __restrict__ xs, int lane, double* __restrict__ ys) {
+  // ys: n doubles (LDS or global); rows >= n (the zero pad row) are not stored
+  const int full = ld & ~127;
+  int r = r0;
+  while (r < r1) {
+    int row0, P;                       // the stored piece that holds row r
+    if (r < full) {
+      row0 = r & ~127;
+      P = 128;
+    } else {
+      row0 = full;
+      P = 64;
+      const int rem = ld - full;
+      for (; P >= 2; P >>= 1)
+        if (rem & P) {
+          if (r < row0 + P) break;
+          row0 += P;
+        }
+    }
+    const int o = r - row0;
+    int R = P;                         // the largest aligned power-of-two block at o that ends inside the piece and the range
+    while (R > 2 && ((o & (R - 1)) != 0 || o + R > P || r + R > r1)) R >>= 1;
+    const double* Tp = T + (int64_t)row0 * n + o;
+    switch (R) {
+      case 128: big_block<64, NT>(Tp, P, n, xs, lane, ys + r, n - r); break;
+      case 64: big_block<32, NT>(Tp, P, n, xs, lane, ys + r, n - r); break;
+      case 32: big_block<16, NT>(Tp, P, n, xs, lane, ys + r, n - r); break;
+      case 16: big_block<8, NT>(Tp, P, n, xs, lane, ys + r, n - r); break;
+      case 8: big_block<4, NT>(Tp, P, n, xs, lane, ys + r, n - r); break;
+      case 4: big_block<2, NT>(Tp, P, n, xs, lane, ys + r, n - r); break;
+      default: big_block<1, NT>(Tp, P, n, xs, lane, ys + r, n - r); break;
+    }
+    r += R;
+  }
+}
+
 template <bool NT>
 __global__ __launch_bounds__(256) void big_apply_kernel(int64_t p0, int64_t npatch, const int64_t* __restrict__ patch_ptr,
                                                          const int32_t* __restrict__ patch_dofs,
@@ -662,7 +747,7 @@ __global__ __launch_bounds__(256) void cond_fill_kernel(int64_t p0, CondDev cd, 
   int64_t m1 = m0;
   if (g1 > g0) {
     const int64_t gl = g1 - 1;
-    m1 = cd.g_mat[gl] + (int64_t)cd.g_m[gl] * cd.g_m[gl] + 2 * (int64_t)cd.g_m[gl] * cd.g_sc[gl];
+    m1 = cd.g_mat[gl] + cond_group_doubles(cd.g_m[gl], cd.g_sc[gl]);
   }
   for (int64_t e = m0 + threadIdx.x; e < m1; e += 256) cd.mat[e] = 0.0;
   double* S = scr + scr_ptr[blockIdx.x];
@@ -687,20 +772,21 @@ __global__ __launch_bounds__(256) void cond_fill_kernel(int64_t p0, CondDev cd, 
       if (r < nI && c < nI) {
         const int64_t g = g0 + grp[r];
         if (grp[c] != grp[r]) { atomicExch(status, 2); continue; }      // two groups are coupled: not a valid condensation
-        const int m = cd.g_m[g];
-        cd.mat[cd.g_mat[g] + (int64_t)(c - cd.g_off[g]) * m + (r - cd.g_off[g])] = v;                     // X storage <- A_gg
+        const int ldm = cond_ldim(cd.g_m[g]);
+        cd.mat[cd.g_mat[g] + (int64_t)(c - cd.g_off[g]) * ldm + (r - cd.g_off[g])] = v;                   // X storage <- A_gg
       } else if (r < nI) {                       // A[g, S]: into the W storage
         const int64_t g = g0 + grp[r];
         const int m = cd.g_m[g], sc = cd.g_sc[g];
         const int jj = cond_find(cd.sidx + cd.g_sidx[g], sc, c - nI);
         if (jj < 0) { atomicExch(status, 2); continue; }
-        cd.mat[cd.g_mat[g] + (int64_t)m * m + (int64_t)sc * m + (int64_t)jj * m + (r - cd.g_off[g])] = v;
+        const int ldm = cond_ldim(m);
+        cd.mat[cd.g_mat[g] + (int64_t)ldm * m + (int64_t)cond_ldim(sc) * m + (int64_t)jj * ldm + (r - cd.g_off[g])] = v;
       } else if (c < nI) {                       // A[S, g]: B storage (sc x m, column-major)
         const int64_t g = g0 + grp[c];
         const int m = cd.g_m[g], sc = cd.g_sc[g];
         const int jj = cond_find(cd.sidx + cd.g_sidx[g], sc, r - nI);
         if (jj < 0) { atomicExch(status, 2); continue; }
-        cd.mat[cd.g_mat[g] + (int64_t)m * m + (int64_t)(c - cd.g_off[g]) * sc + jj] = v;
+        cd.mat[cd.g_mat[g] + (int64_t)cond_ldim(m) * m + (int64_t)(c - cd.g_off[g]) * cond_ldim(sc) + jj] = v;
       } else {
         S[(int64_t)(r - nI) * N + (c - nI)] = v;
       }
@@ -714,12 +800,13 @@ __global__ __launch_bounds__(256) void cond_group_kernel(int64_t g_begin, int64_
   if (g >= g_end) return;
   const int lane = threadIdx.x & 63;
   const int m = cd.g_m[g], sc = cd.g_sc[g];
+  const int ldm = cond_ldim(m);
   double* X = cd.mat + cd.g_mat[g];
-  double* W = X + (int64_t)m * m + (int64_t)sc * m;
+  double* W = X + (int64_t)ldm * m + (int64_t)cond_ldim(sc) * m;
   double a[COND_GMAX], a0[COND_GMAX];        // row `lane` of the matrix being inverted / of A_gg itself
 #pragma unroll
   for (int j = 0; j < COND_GMAX; ++j) {
-    a[j] = (lane < m && j < m) ? X[(int64_t)j * m + lane] : (lane == j ? 1.0 : 0.0);
+    a[j] = (lane < m && j < m) ? X[(int64_t)j * ldm + lane] : (lane == j ? 1.0 : 0.0);
     a0[j] = a[j];
   }
   bool bad = false;
@@ -742,13 +829,13 @@ __global__ __launch_bounds__(256) void cond_group_kernel(int64_t g_begin, int64_
   if (lane < m) {
 #pragma unroll
     for (int j = 0; j < COND_GMAX; ++j)
-      if (j < m) X[(int64_t)j * m + lane] = a[j];
+      if (j < m) X[(int64_t)j * ldm + lane] = a[j];
   }
   // W[:, c] solves A_gg w = A[g, S_g][:, c]: w = X b, then two steps of iterative refinement w += X (b - A_gg w).  The
   // explicit inverse alone leaves a residual of cond(A_gg) * eps * |b|, and |b| ~ gamma here (the grad-div coupling to
   // the skeleton): measured 2.6e-5 in the patch probe for [P3]^3 against 1e-9 with the refinement.
   for (int c = 0; c < sc; ++c) {
-    const double b = lane < m ? W[(int64_t)c * m + lane] : 0.0;
+    const double b = lane < m ? W[(int64_t)c * ldm + lane] : 0.0;
     double w = 0.0;
 #pragma unroll
     for (int k = 0; k < COND_GMAX; ++k) w = __builtin_fma(a[k], __shfl(b, k, 64), w);
@@ -762,7 +849,7 @@ __global__ __launch_bounds__(256) void cond_group_kernel(int64_t g_begin, int64_
       for (int k = 0; k < COND_GMAX; ++k) dw = __builtin_fma(a[k], __shfl(r, k, 64), dw);
       w += dw;
     }
-    if (lane < m) W[(int64_t)c * m + lane] = w;
+    if (lane < m) W[(int64_t)c * ldm + lane] = w;
   }
 }
 
@@ -776,13 +863,14 @@ __global__ __launch_bounds__(256) void cond_schur_kernel(int64_t p0, CondDev cd,
   double* S = scr + scr_ptr[blockIdx.x];
   for (int64_t g = cd.gptr[p]; g < cd.gptr[p + 1]; ++g) {
     const int m = cd.g_m[g], sc = cd.g_sc[g];
-    const double* B = cd.mat + cd.g_mat[g] + (int64_t)m * m;
-    const double* W = B + (int64_t)sc * m;
+    const int ldm = cond_ldim(m), ldsc = cond_ldim(sc);
+    const double* B = cd.mat + cd.g_mat[g] + (int64_t)ldm * m;
+    const double* W = B + (int64_t)ldsc * m;
     const int32_t* si = cd.sidx + cd.g_sidx[g];
     for (int e = threadIdx.x; e < sc * sc; e += 256) {
       const int i = e % sc, j = e / sc;
       double acc = 0.0;
-      for (int k = 0; k < m; ++k) acc = __builtin_fma(B[(int64_t)k * sc + i], W[(int64_t)j * m + k], acc);
+      for (int k = 0; k < m; ++k) acc = __builtin_fma(B[(int64_t)k * ldsc + i], W[(int64_t)j * ldm + k], acc);
       S[(int64_t)si[i] * N + si[j]] -= acc;
     }
     __syncthreads();
@@ -823,7 +911,7 @@ __global__ __launch_bounds__(64 * COND_WAVES) void cond_apply_kernel(int64_t p0,
                                                                      const int64_t* __restrict__ patch_ptr,
                                                                      const int64_t* __restrict__ stage_ptr,
                                                                      const double* __restrict__ x, double* __restrict__ stage,
-                                                                     int umax, int ordered) {
+                                                                     int umax, int ordered, int balanced) {
   extern __shared__ double cond_dsmem[];
   constexpr int NT_ = 64 * COND_WAVES;
   if (p0 + blockIdx.x >= p1) return;
@@ -844,11 +932,12 @@ __global__ __launch_bounds__(64 * COND_WAVES) void cond_apply_kernel(int64_t p0,
   // phase 1: t_g = X_g x_g (kept in the lanes' registers and written over x_g), u_g = B_g t_g
   for (int64_t g = g0 + wave; g < g1; g += COND_WAVES) {
     const int m = cd.g_m[g], sc = cd.g_sc[g], o = cd.g_off[g];
+    const int ldm = cond_ldim(m), ldsc = cond_ldim(sc);
     const double* X = cd.mat + cd.g_mat[g];
-    const double* B = X + (int64_t)m * m;
+    const double* B = X + (int64_t)ldm * m;
     const double xg = lane < m ? xs[o + lane] : 0.0;
-    const double t = cond_gemv_shfl<NT>(X, m, m, m, xg, lane, 0.0);
-    const double u = cond_gemv_shfl<NT>(B, sc, sc, m, t, lane, 0.0);
+    const double t = cond_gemv_shfl<NT>(X, ldm, m, m, xg, lane, 0.0);
+    const double u = cond_gemv_shfl<NT>(B, ldsc, sc, m, t, lane, 0.0);
     if (lane < m) xs[o + lane] = t;              // only this wave reads or writes the slice of its group
     if (lane < sc) us[cd.g_uoff[g] + lane] = u;
   }
@@ -862,7 +951,13 @@ __global__ __launch_bounds__(64 * COND_WAVES) void cond_apply_kernel(int64_t p0,
   }
   __syncthreads();
   // phase 3: y_S = inv(Sigma) rhs, row pieces dealt to the waves
-  if (s > 0) {
+  if (s > 0 && balanced) {
+    // rows dealt to the waves in equal shares (multiples of 16 rows: 128-byte segments per column)
+    const int ld = (s + 1) & ~1;
+    const int share = ((ld + COND_WAVES - 1) / COND_WAVES + 15) & ~15;
+    const int r0 = wave * share, r1 = min(ld, r0 + share);
+    if (r0 < r1) big_rows<NT>(cd.sinv + cd.sinv_ptr[p], s, ld, r0, r1, xs + nI, lane, ys);
+  } else if (s > 0) {
     const int ld = (s + 1) & ~1;
     const double* T = cd.sinv + cd.sinv_ptr[p];
     int piece = 0, row0 = 0;
@@ -889,11 +984,212 @@ __global__ __launch_bounds__(64 * COND_WAVES) void cond_apply_kernel(int64_t p0,
   double* out = stage + stage_ptr[p];
   for (int64_t g = g0 + wave; g < g1; g += COND_WAVES) {
     const int m = cd.g_m[g], sc = cd.g_sc[g], o = cd.g_off[g];
-    const double* W = cd.mat + cd.g_mat[g] + (int64_t)m * m + (int64_t)sc * m;
+    const int ldm = cond_ldim(m);
+    const double* W = cd.mat + cd.g_mat[g] + (int64_t)ldm * m + (int64_t)cond_ldim(sc) * m;
     const double yv = lane < sc ? ys[cd.sidx[cd.g_sidx[g] + lane]] : 0.0;      // lane j holds y_S[S_g[j]]
     const double tg = lane < m ? xs[o + lane] : 0.0;
-    const double acc = cond_gemv_shfl<NT>(W, m, m, sc, -yv, lane, tg);
+    const double acc = cond_gemv_shfl<NT>(W, ldm, m, sc, -yv, lane, tg);
     if (lane < m) out[cd.slot[off + o + lane]] = acc;
+  }
+  for (int i = threadIdx.x; i < s; i += NT_) out[cd.slot[off + nI + i]] = ys[i];
+}
+
+// The same apply as THREE launches (the default; ALFI_COND_SPLIT=0 keeps the one-kernel form above).  Measured on config 5's
+// finest level (1765 macro stars, 4.85 GB of factors; kernel trace, same box): the one-launch kernel takes 949 us; its
+// group phases -- a wave per group, a lane per row, 8-byte loads, 30-95 % of the lanes without a row for groups of 3, 9 or
+// 45 entries -- run at 4.0 TB/s and its Schur phase leaves waves idle (312 rows = 2 x 128 + 32 + 16 + 8 over 8 waves).
+// Split: (front) t_g = X_g x_g, u_g = B_g t_g and the Schur right-hand side, a workgroup per patch, a lane per PAIR of rows
+// with the pairs of different groups side by side in a wave; (sigma) y_S = inv(Sigma) rhs with a workgroup per <= 256 ROWS
+// (3 workgroups for the largest patches, the rows dealt in equal shares to the 4 waves: 6.4 TB/s); (back)
+// y_g = t_g - W_g y_S[S_g] and the staging, a workgroup per patch, row pairs again.  t and y_S travel through cd.tmp
+// (sum_n doubles), the right-hand side through the patch's own staging slots (overwritten by the back kernel): 16 (n + s)
+// bytes of extra traffic per patch against megabytes of factors.
+
+// wave-wide maximum of a small non-negative int
+__device__ __forceinline__ int cond_wave_max(int v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o));
+  return v;
+}
+
+// TWO ROWS of a group product per lane (rows 2 i, 2 i + 1 of a column-major block with an even leading dimension: one
+// 16-byte load per column):   acc += sum_{k < kn} M[k * ld + (0, 1)] * v[k],   M -> the lane's rows, v -> LDS (the group's
+// operand).  kn differs between the lanes of a wave; the loop runs to the wave's maximum with the loads predicated.
+template <bool NT, int RU>
+__device__ __forceinline__ void cond_row2_dot(const double* __restrict__ M, int ld, int kn, const double* __restrict__ v,
+                                              double& acc0, double& acc1) {
+  const int kmax = cond_wave_max(kn);
+  for (int k = 0; k < kmax; k += RU) {
+    big_d2 a[RU];
+#pragma unroll
+    for (int u = 0; u < RU; ++u) {
+      const big_d2* q = reinterpret_cast<const big_d2*>(M + (int64_t)(k + u) * ld);
+      const big_d2 z = {0.0, 0.0};
+      a[u] = (k + u < kn) ? (NT ? __builtin_nontemporal_load(q) : *q) : z;
+    }
+#pragma unroll
+    for (int u = 0; u < RU; ++u) {
+      const double vk = (k + u < kn) ? v[k + u] : 0.0;
+      acc0 = __builtin_fma(a[u].x, vk, acc0);
+      acc1 = __builtin_fma(a[u].y, vk, acc1);
+    }
+  }
+}
+
+template <bool NT, int COND_WAVES, int RU>
+__global__ __launch_bounds__(64 * COND_WAVES) void cond_front_kernel(int64_t p0, int64_t p1, CondDev cd,
+                                                                     const int64_t* __restrict__ patch_ptr,
+                                                                     const int64_t* __restrict__ stage_ptr,
+                                                                     const double* __restrict__ x, double* __restrict__ stage,
+                                                                     int ordered) {
+  extern __shared__ double cond_dsmem[];
+  constexpr int NT_ = 64 * COND_WAVES;
+  if (p0 + blockIdx.x >= p1) return;
+  const int64_t p = ordered ? cd.order[blockIdx.x] : p0 + blockIdx.x;
+  const int64_t off = patch_ptr[p];
+  const int n = (int)(patch_ptr[p + 1] - off);
+  const int nI = cd.p_nI[p];
+  const int s = n - nI;
+  const int64_t uo0 = cd.uptr[p];
+  double* xs = cond_dsmem;          // n
+  double* ts = xs + n;              // nI
+  double* us = ts + nI;             // u buffer, in the order the right-hand side sums it (u_dst)
+  // gather x: 4 index loads, then 4 value loads in flight per thread (the two loads of an entry depend on each other)
+  for (int i0 = threadIdx.x; i0 < n; i0 += 4 * NT_) {
+    int32_t d[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) d[u] = (i0 + u * NT_ < n) ? cd.dofs[off + i0 + u * NT_] : 0;
+    double v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) v[u] = (i0 + u * NT_ < n) ? x[d[u]] : 0.0;
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (i0 + u * NT_ < n) xs[i0 + u * NT_] = v[u];
+  }
+  __syncthreads();
+  double* tmp = cd.tmp + off;
+  // t = X x, a lane per pair of interior entries (whole waves stay in cond_row2_dot: the loop bounds are uniform)
+  const int64_t xp0 = cd.xp_ptr[p], bp0 = cd.bp_ptr[p];
+  const int nxp = (int)(cd.xp_ptr[p + 1] - xp0), nbp = (int)(cd.bp_ptr[p + 1] - bp0);
+  for (int q0 = 0; q0 < nxp; q0 += NT_) {
+    const int q = q0 + threadIdx.x;
+    const bool act = q < nxp;
+    const int32_t g = act ? cd.xp_grp[xp0 + q] : (int32_t)cd.gptr[p];
+    const int m = cd.g_m[g], o = cd.g_off[g], i = 2 * (q - cd.g_xp[g]);
+    double t0 = 0.0, t1 = 0.0;
+    cond_row2_dot<NT, RU>(cd.mat + cd.g_mat[g] + i, cond_ldim(m), act ? m : 0, xs + o, t0, t1);
+    if (act) {
+      ts[o + i] = t0;
+      tmp[o + i] = t0;
+      if (i + 1 < m) {
+        ts[o + i + 1] = t1;
+        tmp[o + i + 1] = t1;
+      }
+    }
+  }
+  __syncthreads();
+  // u = B t, a lane per pair of entries of the patch's u buffer
+  for (int q0 = 0; q0 < nbp; q0 += NT_) {
+    const int q = q0 + threadIdx.x;
+    const bool act = q < nbp;
+    const int32_t g = act ? cd.bp_grp[bp0 + q] : (int32_t)cd.gptr[p];
+    const int m = cd.g_m[g], sc = cd.g_sc[g], j = 2 * (q - cd.g_bp[g]);
+    const int64_t ue = uo0 + cd.g_uoff[g] + j;
+    const int32_t d0 = act ? cd.u_dst[ue] : 0, d1 = (act && j + 1 < sc) ? cd.u_dst[ue + 1] : 0;
+    double u0 = 0.0, u1 = 0.0;
+    cond_row2_dot<NT, RU>(cd.mat + cd.g_mat[g] + (int64_t)cond_ldim(m) * m + j, cond_ldim(sc), act ? m : 0,
+                          ts + cd.g_off[g], u0, u1);
+    if (act) {
+      us[d0] = u0;
+      if (j + 1 < sc) us[d1] = u1;
+    }
+  }
+  __syncthreads();
+  // right-hand side of the Schur system: the contributions to a row are adjacent in us, summed in ascending order
+  const int64_t srow0 = cd.sptr[p];
+  const int32_t qb = cd.s_uptr[srow0];
+  double* rhs = stage + stage_ptr[p] + nI;
+  for (int i = threadIdx.x; i < s; i += NT_) {
+    double acc = xs[nI + i];
+    const int32_t qe = cd.s_uptr[srow0 + i + 1] - qb;
+    for (int32_t q = cd.s_uptr[srow0 + i] - qb; q < qe; ++q) acc -= us[q];
+    rhs[i] = acc;
+  }
+}
+
+constexpr int COND_SIGMA_ROWS = 256;      // rows of inv(Sigma) per workgroup of the sigma kernel (4 waves)
+template <bool NT>
+__global__ __launch_bounds__(256) void cond_sigma_kernel(int64_t c0, CondDev cd, const int64_t* __restrict__ patch_ptr,
+                                                         const int64_t* __restrict__ stage_ptr,
+                                                         const double* __restrict__ stage) {
+  extern __shared__ double cond_dsmem[];
+  const int64_t c = c0 + blockIdx.x;
+  const int64_t p = cd.ch_patch[c];
+  const int r0 = cd.ch_row[c];
+  const int64_t off = patch_ptr[p];
+  const int n = (int)(patch_ptr[p + 1] - off);
+  const int nI = cd.p_nI[p];
+  const int s = n - nI;
+  const int ld = (s + 1) & ~1;
+  const double* rhs = stage + stage_ptr[p] + nI;
+  for (int i = threadIdx.x; i < s; i += 256) cond_dsmem[i] = rhs[i];
+  __syncthreads();
+  const int r1 = min(ld, r0 + COND_SIGMA_ROWS);
+  const int share = (((r1 - r0) + 3) / 4 + 15) & ~15;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int a = r0 + wave * share, b = min(r1, a + share);
+  if (a < b) big_rows<NT>(cd.sinv + cd.sinv_ptr[p], s, ld, a, b, cond_dsmem, lane, cd.tmp + off + nI);
+}
+
+template <bool NT, int COND_WAVES, int RU>
+__global__ __launch_bounds__(64 * COND_WAVES) void cond_back_kernel(int64_t p0, int64_t p1, CondDev cd,
+                                                                    const int64_t* __restrict__ patch_ptr,
+                                                                    const int64_t* __restrict__ stage_ptr,
+                                                                    double* __restrict__ stage, int ordered) {
+  extern __shared__ double cond_dsmem[];
+  constexpr int NT_ = 64 * COND_WAVES;
+  if (p0 + blockIdx.x >= p1) return;
+  const int64_t p = ordered ? cd.order[blockIdx.x] : p0 + blockIdx.x;
+  const int64_t off = patch_ptr[p];
+  const int n = (int)(patch_ptr[p + 1] - off);
+  const int nI = cd.p_nI[p];
+  const int s = n - nI;
+  const int uo = (int)(cd.uptr[p + 1] - cd.uptr[p]);
+  const int64_t g0 = cd.gptr[p];
+  double* ys = cond_dsmem;          // s
+  double* yg = ys + s;              // uo: y_S[S_g], group after group (the layout of the u buffer)
+  const double* tmp = cd.tmp + off;
+  for (int i = threadIdx.x; i < s; i += NT_) ys[i] = tmp[nI + i];
+  // the positions S_g of all groups (adjacent in sidx), 4 loads in flight per thread
+  const int32_t* si = cd.sidx + (uo > 0 ? cd.g_sidx[g0] : 0);
+  int32_t sq[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) sq[u] = (threadIdx.x + u * NT_ < uo) ? si[threadIdx.x + u * NT_] : 0;
+  __syncthreads();
+#pragma unroll
+  for (int u = 0; u < 4; ++u)
+    if (threadIdx.x + u * NT_ < uo) yg[threadIdx.x + u * NT_] = ys[sq[u]];
+  for (int q = threadIdx.x + 4 * NT_; q < uo; q += NT_) yg[q] = ys[si[q]];
+  __syncthreads();
+  double* out = stage + stage_ptr[p];
+  // y_g = t_g - W_g y_S[S_g], a lane per pair of interior entries
+  const int64_t xp0 = cd.xp_ptr[p];
+  const int nxp = (int)(cd.xp_ptr[p + 1] - xp0);
+  for (int q0 = 0; q0 < nxp; q0 += NT_) {
+    const int q = q0 + threadIdx.x;
+    const bool act = q < nxp;
+    const int32_t g = act ? cd.xp_grp[xp0 + q] : (int32_t)g0;
+    const int m = cd.g_m[g], sc = cd.g_sc[g], o = cd.g_off[g], i = 2 * (q - cd.g_xp[g]);
+    const int ldm = cond_ldim(m);
+    const double tg0 = act ? tmp[o + i] : 0.0, tg1 = (act && i + 1 < m) ? tmp[o + i + 1] : 0.0;
+    const int32_t sl0 = act ? cd.slot[off + o + i] : 0, sl1 = (act && i + 1 < m) ? cd.slot[off + o + i + 1] : 0;
+    double y0 = 0.0, y1 = 0.0;
+    cond_row2_dot<NT, RU>(cd.mat + cd.g_mat[g] + (int64_t)ldm * m + (int64_t)cond_ldim(sc) * m + i, ldm, act ? sc : 0,
+                          yg + cd.g_uoff[g], y0, y1);
+    if (act) {
+      out[sl0] = tg0 - y0;
+      if (i + 1 < m) out[sl1] = tg1 - y1;
+    }
   }
   for (int i = threadIdx.x; i < s; i += NT_) out[cd.slot[off + nI + i]] = ys[i];
 }
@@ -1166,14 +1462,50 @@ int launch_cond_apply_range(alfi_level* L, int64_t p0, int64_t p1, const double*
   dim3 grid((unsigned)(p1 - p0));
   static const bool allow_order = !(getenv("ALFI_COND_ORDER") && atoi(getenv("ALFI_COND_ORDER")) == 0);
   const int ordered = allow_order && p0 == 0 && p1 == L->npatch && L->cd.order ? 1 : 0;
+  static const bool split = !(getenv("ALFI_COND_SPLIT") && atoi(getenv("ALFI_COND_SPLIT")) == 0);
+  if (split && L->cd.tmp) {
+    const size_t lds_f = (size_t)L->cond_lds_front, lds_s = (size_t)(L->cond_max_s + 2) * sizeof(double);
+    const size_t lds_b = (size_t)L->cond_lds_back;
+    const int64_t c0 = L->h_cond_chptr[p0], c1 = L->h_cond_chptr[p1];
+#define ALFI_COND_LAUNCH3(NTV, WV, RU)                                                                                    \
+  do {                                                                                                                    \
+    if (lds_f > 64 * 1024)                                                                                                \
+      ALFI_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&cond_front_kernel<NTV, WV, RU>),             \
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_f));                   \
+    hipLaunchKernelGGL((cond_front_kernel<NTV, WV, RU>), grid, dim3(64 * WV), lds_f, ctx->stream, p0, p1, L->cd,          \
+                       L->patch_ptr, L->stage_ptr, x, L->stage, ordered);                                                 \
+    if (c1 > c0)                                                                                                          \
+      hipLaunchKernelGGL((cond_sigma_kernel<NTV>), dim3((unsigned)(c1 - c0)), dim3(256), lds_s, ctx->stream, c0, L->cd,   \
+                         L->patch_ptr, L->stage_ptr, L->stage);                                                           \
+    if (lds_b > 64 * 1024)                                                                                                \
+      ALFI_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&cond_back_kernel<NTV, WV, RU>),              \
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b));                   \
+    hipLaunchKernelGGL((cond_back_kernel<NTV, WV, RU>), grid, dim3(64 * WV), lds_b, ctx->stream, p0, p1, L->cd,           \
+                       L->patch_ptr, L->stage_ptr, L->stage, ordered);                                                    \
+  } while (0)
+    // ALFI_COND_RU: columns in flight per lane in the group products (8; 16 for A/B runs)
+    static const int ru = getenv("ALFI_COND_RU") ? atoi(getenv("ALFI_COND_RU")) : 8;
+    if (waves == 16) {
+      if (nt) ALFI_COND_LAUNCH3(true, 16, 8); else ALFI_COND_LAUNCH3(false, 16, 8);
+    } else if (ru == 16) {
+      if (nt) ALFI_COND_LAUNCH3(true, 8, 16); else ALFI_COND_LAUNCH3(false, 8, 16);
+    } else {
+      if (nt) ALFI_COND_LAUNCH3(true, 8, 8); else ALFI_COND_LAUNCH3(false, 8, 8);
+    }
+#undef ALFI_COND_LAUNCH3
+    ALFI_HIP_CHECK(ctx, hipGetLastError());
+    return 0;
+  }
   const size_t lds = (size_t)L->cond_lds_bytes;
+  // ALFI_COND_BALANCE=0: whole row pieces dealt round-robin to the waves (rounds 1-2)
+  static const int balanced = !(getenv("ALFI_COND_BALANCE") && atoi(getenv("ALFI_COND_BALANCE")) == 0);
 #define ALFI_COND_LAUNCH(NTV, WV)                                                                                       \
   do {                                                                                                                  \
     if (lds > 64 * 1024)                                                                                                \
       ALFI_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&cond_apply_kernel<NTV, WV>),               \
                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                   \
     hipLaunchKernelGGL((cond_apply_kernel<NTV, WV>), grid, dim3(64 * WV), lds, ctx->stream, p0, p1, L->cd, L->patch_ptr, \
-                       L->stage_ptr, x, L->stage, L->cond_umax, ordered);                                               \
+                       L->stage_ptr, x, L->stage, L->cond_umax, ordered, balanced);                                     \
   } while (0)
   if (waves == 4) {
     if (nt) ALFI_COND_LAUNCH(true, 4); else ALFI_COND_LAUNCH(false, 4);
