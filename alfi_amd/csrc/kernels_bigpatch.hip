@@ -1467,30 +1467,43 @@ int launch_cond_apply_range(alfi_level* L, int64_t p0, int64_t p1, const double*
     const size_t lds_f = (size_t)L->cond_lds_front, lds_s = (size_t)(L->cond_max_s + 2) * sizeof(double);
     const size_t lds_b = (size_t)L->cond_lds_back;
     const int64_t c0 = L->h_cond_chptr[p0], c1 = L->h_cond_chptr[p1];
-#define ALFI_COND_LAUNCH3(NTV, WV, RU)                                                                                    \
+#define ALFI_COND_LAUNCH3(GNT, WV, RU)                                                                                    \
   do {                                                                                                                    \
     if (lds_f > 64 * 1024)                                                                                                \
-      ALFI_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&cond_front_kernel<NTV, WV, RU>),             \
+      ALFI_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&cond_front_kernel<GNT, WV, RU>),             \
                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_f));                   \
-    hipLaunchKernelGGL((cond_front_kernel<NTV, WV, RU>), grid, dim3(64 * WV), lds_f, ctx->stream, p0, p1, L->cd,          \
+    hipLaunchKernelGGL((cond_front_kernel<GNT, WV, RU>), dim3(grid.x), dim3(64 * WV), lds_f, ctx->stream, p0, p1, L->cd,  \
                        L->patch_ptr, L->stage_ptr, x, L->stage, ordered);                                                 \
-    if (c1 > c0)                                                                                                          \
-      hipLaunchKernelGGL((cond_sigma_kernel<NTV>), dim3((unsigned)(c1 - c0)), dim3(256), lds_s, ctx->stream, c0, L->cd,   \
-                         L->patch_ptr, L->stage_ptr, L->stage);                                                           \
+    if (c1 > c0) {                                                                                                        \
+      if (nt)                                                                                                             \
+        hipLaunchKernelGGL((cond_sigma_kernel<true>), dim3((unsigned)(c1 - c0)), dim3(256), lds_s, ctx->stream, c0, L->cd, \
+                           L->patch_ptr, L->stage_ptr, L->stage);                                                         \
+      else                                                                                                                \
+        hipLaunchKernelGGL((cond_sigma_kernel<false>), dim3((unsigned)(c1 - c0)), dim3(256), lds_s, ctx->stream, c0,      \
+                           L->cd, L->patch_ptr, L->stage_ptr, L->stage);                                                  \
+    }                                                                                                                     \
     if (lds_b > 64 * 1024)                                                                                                \
-      ALFI_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&cond_back_kernel<NTV, WV, RU>),              \
+      ALFI_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&cond_back_kernel<GNT, WV, RU>),              \
                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b));                   \
-    hipLaunchKernelGGL((cond_back_kernel<NTV, WV, RU>), grid, dim3(64 * WV), lds_b, ctx->stream, p0, p1, L->cd,           \
+    hipLaunchKernelGGL((cond_back_kernel<GNT, WV, RU>), dim3(grid.x), dim3(64 * WV), lds_b, ctx->stream, p0, p1, L->cd,   \
                        L->patch_ptr, L->stage_ptr, L->stage, ordered);                                                    \
   } while (0)
-    // ALFI_COND_RU: columns in flight per lane in the group products (8; 16 for A/B runs)
+    // Same-box kernel traces on config 5: the group matrices are read better WITHOUT the nontemporal hint (front 218 ->
+    // 208 us, back 128 -> 123 us on the finest level; a column of 45 doubles shares its first and last 128-byte line with
+    // its neighbours), inv(Sigma) with it (519 against 573 us): ALFI_COND_GROUP_NT=1 for A/B runs.  16 waves per patch
+    // where a launch has fewer patches than the chip has workgroup slots (level 1, 303 patches: front + back 69 -> 58 us;
+    // finest level, 1765 patches: 345 -> 358 us): ALFI_COND_WAVES=8 / 16 forces one.  ALFI_COND_RU=16: 16 columns in
+    // flight per lane instead of 8 (no gain).
+    static const bool gnt = getenv("ALFI_COND_GROUP_NT") && atoi(getenv("ALFI_COND_GROUP_NT")) != 0;
     static const int ru = getenv("ALFI_COND_RU") ? atoi(getenv("ALFI_COND_RU")) : 8;
-    if (waves == 16) {
-      if (nt) ALFI_COND_LAUNCH3(true, 16, 8); else ALFI_COND_LAUNCH3(false, 16, 8);
+    static const int waves_env = getenv("ALFI_COND_WAVES") ? atoi(getenv("ALFI_COND_WAVES")) : 0;
+    const int wv = waves_env ? waves_env : (p1 - p0 < 1024 ? 16 : 8);
+    if (wv == 16) {
+      if (gnt) ALFI_COND_LAUNCH3(true, 16, 8); else ALFI_COND_LAUNCH3(false, 16, 8);
     } else if (ru == 16) {
-      if (nt) ALFI_COND_LAUNCH3(true, 8, 16); else ALFI_COND_LAUNCH3(false, 8, 16);
+      if (gnt) ALFI_COND_LAUNCH3(true, 8, 16); else ALFI_COND_LAUNCH3(false, 8, 16);
     } else {
-      if (nt) ALFI_COND_LAUNCH3(true, 8, 8); else ALFI_COND_LAUNCH3(false, 8, 8);
+      if (gnt) ALFI_COND_LAUNCH3(true, 8, 8); else ALFI_COND_LAUNCH3(false, 8, 8);
     }
 #undef ALFI_COND_LAUNCH3
     ALFI_HIP_CHECK(ctx, hipGetLastError());

@@ -79,6 +79,8 @@ def build_problem(cfg, verbose, lazy=False):
 def apply_kernel_name(L):
     from alfi_amd.hip import condense_patches
     if condense_patches(L):
+        if os.environ.get("ALFI_COND_SPLIT", "1") != "0":      # one apply = three launches (kernels_bigpatch.hip)
+            return "cond_front_kernel + cond_sigma_kernel + cond_back_kernel"
         return "cond_apply_kernel"
     return "big_apply_kernel" if np.diff(L.patch_ptr).max() > 160 else "patch_apply_kernel"
 

@@ -1,6 +1,6 @@
 #!/bin/bash
 # End-of-round artefacts for profiles/ (round 3).  Outputs: gpurun_out/r03f/.  PART selects what to run (the whole set
-# does not fit one call comfortably): headline | pmc | configs | dist | setup
+# does not fit one call comfortably): headline | pmc | configs | cfg5 | cfg5L | dist | setup
 cd "$GRAFT_REPO_ROOT" || exit 1
 export TMPDIR=/tmp
 O=$GRAFT_REPO_ROOT/gpurun_out/r03f
@@ -41,6 +41,38 @@ if [ "$PART" = configs ]; then
     rm -rf $O/trace_$CFG
   done
   for C in cfg2 cfg3 cfg5 cfg6; do head -c 300 $O/r03_bench_$C.json; echo; done
+fi
+if [ "$PART" = cfg5 ]; then
+  # condensed apply as three launches: same-box A/B against the one-launch kernel, the bench line, a kernel trace, HBM traffic
+  for V in 0 1 0 1; do
+    ALFI_COND_SPLIT=$V python bench.py --config cfg5 --steps 10 --warmup 3 --no-cpu-baseline > $O/ab_cfg5_split$V.json 2> $O/ab_cfg5_split$V.err
+    python - $O/ab_cfg5_split$V.json $V <<'PY' | tee -a $O/r03_cond_apply_ab_cfg5.txt
+import json, sys
+d = json.load(open(sys.argv[1])); r = d["roofline"]
+print("ALFI_COND_SPLIT=%s  %s: %.2f ms/V-cycle without events, finest-level apply %.1f us = %.0f GB/s, all levels %.0f GB/s"
+      % (sys.argv[2], r["kernel"], d["ms_per_step_without_events"], r["finest_level_avg_launch_us"], r["finest_level_GBps"], r["achieved"]))
+PY
+  done
+  python bench.py --config cfg5 --steps 10 --warmup 3 > $O/r03_bench_cfg5.json 2> $O/bench_cfg5.err
+  cd /tmp
+  rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_cfg5 -- python3 $GRAFT_REPO_ROOT/bench.py --config cfg5 --no-cpu-baseline --steps 10 --warmup 3 > $O/r03_bench_cfg5_under_rocprof.json 2> $O/prof_cfg5.err
+  rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc5_fetch -- python3 $GRAFT_REPO_ROOT/bench.py --config cfg5 --no-cpu-baseline --steps 1 --warmup 0 > $O/pmc5_fetch.json 2> $O/pmc5_fetch.err
+  rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc5_write -- python3 $GRAFT_REPO_ROOT/bench.py --config cfg5 --no-cpu-baseline --steps 1 --warmup 0 > $O/pmc5_write.json 2> $O/pmc5_write.err
+  cd $GRAFT_REPO_ROOT
+  find $O/prof_cfg5 -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $O/r03_cfg5_kernel_stats.csv
+  python - $O/prof_cfg5 <<'PY' > $O/r03_cond_apply_trace_cfg5.txt
+import glob, sys, pandas as pd
+t = pd.read_csv(glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True)[0])
+t["dur_us"] = (t["End_Timestamp"] - t["Start_Timestamp"]) / 1e3
+t["name"] = t["Kernel_Name"].str.replace(r"\(.*", "", regex=True).str.replace("void ", "")
+c = t[t["name"].str.contains("cond_front|cond_back|cond_sigma|cond_apply")]
+print("config 5, condensed apply: launches by kernel and grid (the larger grid of each kernel = the finest level), durations in us")
+print(c.groupby(["name", "Grid_Size_X", "VGPR_Count"])["dur_us"].agg(["count", "mean", "min", "max"]).round(1).to_string())
+PY
+  cat $O/r03_cond_apply_trace_cfg5.txt
+  python scripts/pmc_summary.py $O/pmc5_fetch $O/pmc5_write "void cond_front_kernel+void cond_sigma_kernel+void cond_back_kernel" $O/pmc_patch_apply_cfg5.json "r03 end of round ($STAMP) cond_front + cond_sigma + cond_back (one apply of the condensed macro-star factors = three launches; counters of the three added), the 40 applies of the first V-cycle" 40
+  rm -rf $O/prof_cfg5 $O/pmc5_fetch $O/pmc5_write
+  head -c 400 $O/r03_bench_cfg5.json; echo
 fi
 if [ "$PART" = cfg5L ]; then
   python bench.py --config cfg5L --steps 5 --warmup 2 --no-cpu-baseline > $O/r03_bench_cfg5L.json 2> $O/bench_cfg5L.err

@@ -24,6 +24,12 @@ import pandas as pd
 def per_kernel(d, counter, prefix, first=None, grids=None, skip=0):
     f = glob.glob(d + "/**/*_counter_collection.csv", recursive=True)[0]
     t = pd.read_csv(f)
+    # several kernels that together make one operation ("void a+void b+void c": launched in turn, the same number of
+    # times): the counters of the i-th launch of each are added
+    if "+" in prefix:
+        parts = [per_kernel(d, counter, q, first, grids, skip) for q in prefix.split("+")]
+        m = min(len(q) for q in parts)
+        return sum(q[:m] for q in parts)
     t = t[(t["Counter_Name"] == counter) & t["Kernel_Name"].str.startswith(prefix)]
     if grids == "max":         # the launches on the largest grid only (the finest level)
         t = t[t["Grid_Size"] == t["Grid_Size"].max()]
