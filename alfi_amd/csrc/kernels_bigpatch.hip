@@ -702,7 +702,8 @@ int launch_big_apply_arrays(alfi_ctx* ctx, int64_t npatch, int max_np, const int
 // ---------------------------------------------------------------------------------------------------------------------
 // 4. Condensed patch factors (CondDev, common.h): setup = fill (operator entries into the group matrices and the Schur
 //    scratch), group step (X_g = inv(A_gg), W_g = X_g A[g, S_g]), Schur step (Sigma -= B_g W_g), blocked inversion of
-//    Sigma by the kernels above; apply = one workgroup per patch, five short phases.
+//    Sigma by the kernels above; apply = three launches (cond_front / cond_sigma / cond_back below), or the one-launch
+//    kernel of rounds 1-2 (cond_apply_kernel, ALFI_COND_SPLIT=0).
 // ---------------------------------------------------------------------------------------------------------------------
 constexpr int COND_GMAX = 64;     // a group / its coupled skeleton set holds at most 64 entries (a lane per row)
 
