@@ -415,7 +415,8 @@ int launch_coarse_factor(alfi_level* lvl, double* out);                         
 int launch_big_factor(alfi_level* lvl);
 // condensed patches (kernels_bigpatch.hip): block factorisation / its apply for the patches [p0, p1)
 int launch_cond_factor(alfi_level* lvl);
-int launch_cond_apply_range(alfi_level* lvl, int64_t p0, int64_t p1, const double* x);                                                    // gather + blocked MFMA inversion
+int launch_cond_apply_range(alfi_level* lvl, int64_t p0, int64_t p1, const double* x);
+int launch_cond_schur_one(alfi_level* lvl, int64_t p, const int64_t* d_zero, double* scr);   // repair path (kernels_check.hip)                                                    // gather + blocked MFMA inversion
 int launch_patch_sum(alfi_level* lvl, const double* x, double* y);             // stage 2
 int launch_patch_sum_range(alfi_level* lvl, int64_t i0, int64_t i1, const double* x, double* y);   // stage 2, dofs [i0, i1)
 // one dependency wavefront of a multiplicative sweep: patches seq[0..count): y_p += inv(A_p) (x - A y)_p

@@ -1453,6 +1453,16 @@ int launch_cond_factor(alfi_level* L) {
   return big_factor_core(L->ctx, src, L->npatch, L->h_sptr.data(), L->cd.sptr, L->cd.sinv_ptr, L->cd.sinv, L->status);
 }
 
+// the Schur complement of ONE condensed patch into scr (N x N row-major, N = s rounded up to BIG_NB, identity padding);
+// d_zero: a device int64 holding 0 (the patch's offset in scr).  The repair path of kernels_check.hip.
+int launch_cond_schur_one(alfi_level* L, int64_t p, const int64_t* d_zero, double* scr) {
+  BigSource src;
+  src.K = L;
+  src.fill(L->ctx, p, 1, d_zero, scr);
+  ALFI_HIP_CHECK(L->ctx, hipGetLastError());
+  return 0;
+}
+
 int launch_cond_apply_range(alfi_level* L, int64_t p0, int64_t p1, const double* x) {
   alfi_ctx* ctx = L->ctx;
   if (p1 <= p0) return 0;

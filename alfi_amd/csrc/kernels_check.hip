@@ -111,14 +111,17 @@ __global__ __launch_bounds__(256) void patch_check_kernel(const int32_t* __restr
 // on config 4's patches, cond ~ 1e7, it returned 2e-3 where the UNPIVOTED register kernel it was meant to back up gives
 // 5e-8 -- found in round 3 by flagging every patch (ALFI_PATCH_CHECK_TOL=3e-9, scripts/repair_check.py).  Solving
 // A x_j = e_j column by column through the LU factors is backward stable per column: cond(A) eps.)
-template <int BS>
+// DENSE: the matrix is not gathered from the level operator but copied from ``dense`` (row-major, leading dimension
+// ``dense_ld``) -- the Schur complement of a condensed patch (patch_ptr = CondDev::sptr, inv = CondDev::sinv).
+template <int BS, bool DENSE>
 __global__ __launch_bounds__(256) void patch_repair_kernel(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colidx,
                                                             const double* __restrict__ vals, int flat,
                                                             const int64_t* __restrict__ patch_ptr,
                                                             const int32_t* __restrict__ patch_dofs,
                                                             const int64_t* __restrict__ inv_ptr, double* __restrict__ inv,
                                                             const int32_t* __restrict__ list, double* __restrict__ scratch,
-                                                            int64_t scratch_stride, int* __restrict__ status) {
+                                                            int64_t scratch_stride, int* __restrict__ status,
+                                                            const double* __restrict__ dense, int dense_ld) {
   extern __shared__ unsigned char smem[];
   const int64_t p = list[blockIdx.x];
   const int64_t off = patch_ptr[p];
@@ -135,11 +138,15 @@ __global__ __launch_bounds__(256) void patch_repair_kernel(const int32_t* __rest
   double* Y = W + (int64_t)n * n;                                   // L^-1 P, then X
   const int tid = threadIdx.x;
   if (tid == 0) bad_s = 0;
-  for (int i = tid; i < n; i += 256) dofs_s[i] = patch_dofs[off + i];
-  for (int64_t e = tid; e < (int64_t)n * n; e += 256) W[e] = 0.0;
+  if (DENSE) {
+    for (int64_t e = tid; e < (int64_t)n * n; e += 256) W[e] = dense[(e / n) * dense_ld + e % n];
+  } else {
+    for (int i = tid; i < n; i += 256) dofs_s[i] = patch_dofs[off + i];
+    for (int64_t e = tid; e < (int64_t)n * n; e += 256) W[e] = 0.0;
+  }
   __syncthreads();
   const int wave = tid >> 6, lane = tid & 63;
-  for (int r = wave; r < n; r += 4) {
+  for (int r = wave; r < n && !DENSE; r += 4) {
     const int gr = dofs_s[r];
     const int brow = gr / BS, rr = gr % BS;
     const int32_t lo = rowptr[brow], hi = rowptr[brow + 1];
@@ -284,6 +291,69 @@ static int read_check(alfi_level* L, double* worst, int* nflag) {
   return 0;
 }
 
+// Condensed factors (CondDev): a patch that fails the probe gets its Schur complement formed again (fill / group / Schur
+// kernels of the setup, one patch at a time: the rare path) and inverted by the pivoted LU above, in place in
+// CondDev::sinv -- the level keeps its condensed storage (round 2 fell back to dense inverses for the whole level: 6.8 x
+// the memory exactly when a patch is ill-conditioned).  The group inverses X_g come from an unpivoted elimination with two
+// refinement steps on W_g (cond_group_kernel); a zero pivot there has already failed the factorisation.
+static int cond_repair(alfi_level* L, double tol, int nflag, double worst) {
+  alfi_ctx* ctx = L->ctx;
+  const int smax = L->cond_max_s;
+  if (smax > 4096)
+    return alfi_set_error(ctx, ALFI_E_SINGULAR, "%d condensed patch factors fail the residual probe (worst %.3e) and the "
+                          "pivoted repair handles Schur complements of at most 4096 dofs", nflag, worst);
+  std::vector<int32_t> list((size_t)nflag);
+  ALFI_HIP_CHECK(ctx, hipMemcpyAsync(list.data(), L->chk_list, sizeof(int32_t) * (size_t)nflag, hipMemcpyDeviceToHost, ctx->stream));
+  ALFI_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  const int64_t N = ((int64_t)smax + 63) / 64 * 64;
+  double *sig = nullptr, *scratch = nullptr;
+  int64_t* zero = nullptr;
+  ALFI_HIP_CHECK(ctx, hipMalloc((void**)&sig, sizeof(double) * (size_t)(N * N)));
+  hipError_t e = hipMalloc((void**)&scratch, sizeof(double) * (size_t)(2 * (int64_t)smax * smax));
+  if (e == hipSuccess) e = hipMalloc((void**)&zero, sizeof(int64_t));
+  if (e == hipSuccess) e = hipMemsetAsync(zero, 0, sizeof(int64_t), ctx->stream);
+  if (e == hipSuccess) e = hipMemsetAsync(L->status, 0, sizeof(int), ctx->stream);
+  const size_t lds = (size_t)smax * (2 * sizeof(double) + 2 * sizeof(int32_t));
+  if (e == hipSuccess && lds > 64 * 1024)
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&patch_repair_kernel<3, true>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  int rc = e == hipSuccess ? 0 : alfi_set_error(ctx, ALFI_E_HIP, "condensed repair: %s", hipGetErrorString(e));
+  for (int i = 0; i < nflag && rc == 0; ++i) {
+    const int64_t p = list[(size_t)i];
+    const int sp = (int)(L->h_sptr[p + 1] - L->h_sptr[p]);
+    if (sp == 0) continue;
+    rc = launch_cond_schur_one(L, p, zero, sig);
+    if (rc != 0) break;
+    const int Np = (sp + 63) / 64 * 64;              // the padded leading dimension of the setup's Schur scratch (BIG_NB)
+    hipLaunchKernelGGL((patch_repair_kernel<3, true>), dim3(1), dim3(256), lds, ctx->stream, (const int32_t*)nullptr,
+                       (const int32_t*)nullptr, (const double*)nullptr, 0, L->cd.sptr, (const int32_t*)nullptr, L->cd.sinv_ptr,
+                       L->cd.sinv, L->chk_list + i, scratch, (int64_t)0, L->status, (const double*)sig, Np);
+    if (hipGetLastError() != hipSuccess) rc = alfi_set_error(ctx, ALFI_E_HIP, "patch_repair_kernel launch failed");
+  }
+  int st = 0;
+  if (rc == 0 && hipMemcpyAsync(&st, L->status, sizeof(int), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) rc = ALFI_E_HIP;
+  (void)hipStreamSynchronize(ctx->stream);
+  (void)hipFree(sig);
+  (void)hipFree(scratch);
+  (void)hipFree(zero);
+  if (rc != 0) return rc;
+  if (st != 0) return alfi_set_error(ctx, ALFI_E_SINGULAR, "a condensed patch operator is singular to working precision (pivoted inversion)");
+  ALFI_HIP_CHECK(ctx, hipMemsetAsync(L->chk, 0, 2 * sizeof(double), ctx->stream));
+  rc = launch_check(L, tol);
+  double worst2 = 0.0;
+  int nflag2 = 0;
+  if (rc == 0) rc = read_check(L, &worst2, &nflag2);
+  if (rc != 0) return rc;
+  L->chk_repaired = nflag - nflag2;
+  L->chk_worst_after = worst2;
+  static const double fail = getenv("ALFI_PATCH_CHECK_FAIL") ? atof(getenv("ALFI_PATCH_CHECK_FAIL")) : 1e3 * tol;
+  if (nflag2 > 0 && !(worst2 <= fail))
+    return alfi_set_error(ctx, ALFI_E_SINGULAR, "%d condensed patch factors still fail the residual probe after pivoted "
+                          "re-inversion of their Schur complements (worst %.3e); use dense inverses "
+                          "(alfi_patches_set_groups(NULL)) for this operator", nflag2, worst2);
+  return 0;
+}
+
 // Called by alfi_patches_factor after the fast inversion.  unpivoted_status: the zero-pivot flag of that inversion (a
 // patch that met one holds non-finite entries and is caught by the probe).
 int patch_verify_and_repair(alfi_level* L, int unpivoted_status) {
@@ -313,9 +383,7 @@ int patch_verify_and_repair(alfi_level* L, int unpivoted_status) {
     return alfi_set_error(ctx, ALFI_E_SINGULAR, "%d of %lld patch inverses fail the residual probe (worst %.3e)", nflag,
                           (long long)L->npatch, worst);
   constexpr int REPAIR_MAX_NP = PATCH_MAX;     // (a 2000-dof patch takes ~0.5 s of one workgroup: a rare-path safety net)
-  if (L->cond)
-    return alfi_set_error(ctx, ALFI_E_SINGULAR, "%d condensed patch factors fail the residual probe (worst %.3e); use dense "
-                          "inverses (alfi_patches_set_groups(NULL)) for this operator", nflag, worst);
+  if (L->cond) return cond_repair(L, tol, nflag, worst);
   if (L->max_np > REPAIR_MAX_NP)
     return alfi_set_error(ctx, ALFI_E_SINGULAR, "%d patch inverses fail the residual probe (worst %.3e) and the pivoted "
                           "repair handles patches of at most %d dofs", nflag, worst, (int)REPAIR_MAX_NP);
@@ -328,9 +396,9 @@ int patch_verify_and_repair(alfi_level* L, int unpivoted_status) {
   const size_t lds = (size_t)L->max_np * (2 * sizeof(double) + 2 * sizeof(int32_t));
   int rc = 0;
   if (lds > 64 * 1024) {     // beyond the default dynamic LDS limit (gfx950: 160 KB per CU)
-    hipError_t ea = L->bs == 2 ? hipFuncSetAttribute(reinterpret_cast<const void*>(&patch_repair_kernel<2>),
+    hipError_t ea = L->bs == 2 ? hipFuncSetAttribute(reinterpret_cast<const void*>(&patch_repair_kernel<2, false>),
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
-                               : hipFuncSetAttribute(reinterpret_cast<const void*>(&patch_repair_kernel<3>),
+                               : hipFuncSetAttribute(reinterpret_cast<const void*>(&patch_repair_kernel<3, false>),
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (ea != hipSuccess) rc = alfi_set_error(ctx, ALFI_E_HIP, "hipFuncSetAttribute: %s", hipGetErrorString(ea));
   }
@@ -338,11 +406,13 @@ int patch_verify_and_repair(alfi_level* L, int unpivoted_status) {
     const int64_t nb = std::min<int64_t>(per_batch, nflag - b0);
     dim3 grid((unsigned)nb), block(256);
     if (L->bs == 2)
-      hipLaunchKernelGGL(patch_repair_kernel<2>, grid, block, lds, ctx->stream, L->A.rowptr, L->A.colidx, L->A.vals, L->A.flat,
-                         L->patch_ptr, L->patch_dofs, L->inv_ptr, L->inv, L->chk_list + b0, scratch, stride, L->status);
+      hipLaunchKernelGGL((patch_repair_kernel<2, false>), grid, block, lds, ctx->stream, L->A.rowptr, L->A.colidx, L->A.vals,
+                         L->A.flat, L->patch_ptr, L->patch_dofs, L->inv_ptr, L->inv, L->chk_list + b0, scratch, stride,
+                         L->status, (const double*)nullptr, 0);
     else
-      hipLaunchKernelGGL(patch_repair_kernel<3>, grid, block, lds, ctx->stream, L->A.rowptr, L->A.colidx, L->A.vals, L->A.flat,
-                         L->patch_ptr, L->patch_dofs, L->inv_ptr, L->inv, L->chk_list + b0, scratch, stride, L->status);
+      hipLaunchKernelGGL((patch_repair_kernel<3, false>), grid, block, lds, ctx->stream, L->A.rowptr, L->A.colidx, L->A.vals,
+                         L->A.flat, L->patch_ptr, L->patch_dofs, L->inv_ptr, L->inv, L->chk_list + b0, scratch, stride,
+                         L->status, (const double*)nullptr, 0);
     if (hipGetLastError() != hipSuccess) rc = alfi_set_error(ctx, ALFI_E_HIP, "patch_repair_kernel launch failed");
   }
   int st = 0;

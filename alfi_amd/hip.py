@@ -276,8 +276,10 @@ class Level(object):
         self.ctx.check(self.ctx.lib.alfi_patches_factor(self.h))
 
     def factor_with_fallback(self):
-        """factor(); if CONDENSED factors fail the residual probe (they are not repaired in place), fall back to dense
-        inverses for this level -- those go through the pivoted repair -- and factor again.  Returns True if it fell back."""
+        """factor(); condensed factors that fail the residual probe are repaired in place (pivoted LU of their Schur
+        complements, kernels_check.hip).  Only if they STILL fail beyond ALFI_PATCH_CHECK_FAIL -- or the repair does not
+        apply (Schur complements above 4096 dofs) -- fall back to dense inverses for this level and factor again.  Returns
+        True if it fell back."""
         try:
             self.factor()
             return False

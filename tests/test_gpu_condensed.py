@@ -103,3 +103,25 @@ def test_cycles_with_condensed_factors_match_the_oracle(ctx):
     mg.fcycle(db, dx)
     assert relerr(dx.get(), omg.fcycle(b)) < 1e-5
     mg.close()
+
+
+def test_flagged_condensed_factors_are_repaired_in_place():
+    """A condensed factor that fails the residual probe of alfi_patches_factor keeps its condensed storage: its Schur
+    complement is formed again and inverted by LU with partial pivoting (round 2 fell back to dense inverses for the whole
+    level).  Forced here for every patch by a probe tolerance no inverse reaches (own process: the library reads its
+    switches once)."""
+    import os
+    import re
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, ALFI_PATCH_CHECK_TOL="1e-14", ALFI_PATCH_CHECK_FAIL="1e-6")
+    out = subprocess.run([sys.executable, os.path.join(root, "tests", "gpu_cond_repair_worker.py")], env=env, cwd=root,
+                         capture_output=True, text=True, timeout=900)
+    m = re.search(r"CHECK (\d+) (\d+) (\S+) (\S+) BYTES (\d+) (\d+) RELERR (\S+)", out.stdout)
+    assert out.returncode == 0 and m, out.stdout[-2000:] + out.stderr[-3000:]
+    flagged, repaired = int(m.group(1)), int(m.group(2))
+    worst, after, err = float(m.group(3)), float(m.group(4)), float(m.group(7))
+    assert flagged > 0                                     # every patch went through the repair ...
+    assert after < 1e-7 and err < 1e-7                     # ... and comes out as accurate as the fast factorisation
+    assert int(m.group(5)) < int(m.group(6)) / 2           # still condensed: far below the 8 sum n_p^2 bytes of dense inverses

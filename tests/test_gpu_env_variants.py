@@ -20,7 +20,15 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
                                      # block elimination without the Newton-Schulz polish: the residual probe of
                                      # alfi_patches_factor (7e-6 here) would reject these inverses at its default 1e-6
                                      ({"ALFI_BIG_POLISH": "0", "ALFI_PATCH_CHECK_TOL": "1e-3"}, 5e-2),
-                                     ({"ALFI_TRANSFER_REFINE": "0"}, 1e-3)])      # explicit block inverses without refinement
+                                     ({"ALFI_TRANSFER_REFINE": "0"}, 1e-3),       # explicit block inverses without refinement
+                                     # condensed macro-star factors: the one-launch apply of rounds 1-2, and the settings of
+                                     # the three-launch one that the defaults do not take on this hierarchy
+                                     ({"ALFI_COND_SPLIT": "0"}, 1e-5), ({"ALFI_COND_SPLIT": "0", "ALFI_COND_BALANCE": "0"}, 1e-5),
+                                     ({"ALFI_COND_WAVES": "8", "ALFI_COND_GROUP_NT": "1"}, 1e-5),
+                                     ({"ALFI_COND_WAVES": "8", "ALFI_COND_RU": "16"}, 1e-5),
+                                     # EVERY condensed patch flagged by the residual probe: Schur complements formed again
+                                     # and re-inverted in place by the pivoted LU (kernels_check.hip: cond_repair)
+                                     ({"ALFI_PATCH_CHECK_TOL": "1e-14", "ALFI_PATCH_CHECK_FAIL": "1e-6"}, 1e-5)])
 def test_switch(env, tol):
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "gpu_env_variant_worker.py")],
                          env=dict(os.environ, **env), cwd=ROOT, capture_output=True, text=True, timeout=600)
