@@ -42,7 +42,21 @@ CONFIGS = {
     "cfg5": ("sv", 1, 2, 3, 500.0, 10),
     "cfg5s": ("sv", 1, 1, 3, 500.0, 10),
     "cfg5L": ("sv", 1, 3, 3, 500.0, 10),   # one more refinement: 3.4 M velocity dofs, ~40 GB of condensed factors on ONE GPU
+    # config 5 on the reference's OWN channel mesh (examples/bfs3d/coarse60.msh, gmsh 2.2 ASCII: 299 nodes, 912 tets, physical
+    # tags 1 / 2 / 3; kept as an input fixture under tests/golden/meshes/): unstructured, macro stars up to 3615 dofs, a
+    # 56 784-dof coarse grid (multifrontal solver).  One refinement: 440 022 velocity dofs; two: 3.47 M
+    "cfg5m": ("sv", "bfs3d_coarse60.msh", 1, 3, 500.0, 10),
+    "cfg5mL": ("sv", "bfs3d_coarse60.msh", 2, 3, 500.0, 10),
 }
+MESH_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests", "golden", "meshes")
+
+
+def config_mesh(cfg):
+    """The gmsh file of a config (None: structured); --mesh overrides it for the Scott-Vogelius configs."""
+    base = CONFIGS[cfg][1]
+    if BFS3D_MESH:
+        return BFS3D_MESH
+    return os.path.join(MESH_DIR, base) if isinstance(base, str) else None
 SETUP_KEYS = ("comm_init", "partition", "localize", "upload_factor")     # DistMultigrid.setup_s, reported per rank
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 TB/s achievable)
 
@@ -50,7 +64,8 @@ HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec (MI355X_MICROARCH.md: 8.0 TB/s 
 def describe(cfg):
     dim, baseN, nref, ke, Re, k = CONFIGS[cfg]
     if dim == "sv":
-        base = "gmsh mesh %s" % os.path.basename(BFS3D_MESH) if BFS3D_MESH else "structured 10x2x1 channel with step, baseN %d" % baseN
+        msh = config_mesh(cfg)
+        base = "gmsh mesh %s" % os.path.basename(msh) if msh else "structured 10x2x1 channel with step, baseN %d" % baseN
         return ("bfs3d Scott-Vogelius [P%d]^3 on Alfeld-split meshes (%s, nref %d), "
                 "Re=%g, gamma=1e4, FGMRES(%d)+macro-star patches" % (ke, base, nref, Re, k))
     el = "[P2]^2" if dim == 2 else ("[P1+FB]^3" if ke == 1 else "[P2+FB]^3")
@@ -69,7 +84,8 @@ def build_problem(cfg, verbose, lazy=False):
     if dim == "sv":
         from alfi_amd.problem import ThreeDimBackwardsFacingStepProblem
         from alfi_amd.sv import build_sv_hierarchy
-        lv, tr = build_sv_hierarchy(ThreeDimBackwardsFacingStepProblem(baseN, msh=BFS3D_MESH), nref, ke, Re=Re)
+        msh = config_mesh(cfg)
+        lv, tr = build_sv_hierarchy(ThreeDimBackwardsFacingStepProblem(1 if msh else baseN, msh=msh), nref, ke, Re=Re)
         return lv, tr, k
     prob = TwoDimLidDrivenCavityProblem(baseN) if dim == 2 else ThreeDimLidDrivenCavityProblem(baseN)
     lv, tr = build_hierarchy(prob, nref, ke, Re=Re, verbose=verbose, lazy=lazy)

@@ -142,12 +142,14 @@ def _bench_problem(name):
     return bench.build_problem(name, False)
 
 
-@pytest.mark.parametrize("name", ["cfg5", "cfg6", "cfg5L"])
+@pytest.mark.parametrize("name", ["cfg5", "cfg6", "cfg5L", "cfg5m"])
 def test_full_size_properties_of_the_widened_configs(name):
     """bench.py's configurations beyond BASELINE's first four at their bench sizes: config 5 on one GPU (bfs3d Scott-Vogelius
     [P3]^3, 441 k dofs, macro stars of up to 2175 dofs as CONDENSED factors), config 6 (ldc3d [P1+FB]^3 over the reference's
     largest coarse grid: 14.7 M dofs, multifrontal coarse solver) and config 5 with one more refinement (3.47 M dofs, 47 GB of
-    condensed factors; 8 s of host generation since the macro-star constructor is vectorised, 281 s before).  Size-independent properties:
+    condensed factors; 8 s of host generation since the macro-star constructor is vectorised, 281 s before), and config 5 on the
+    reference's own gmsh channel (cfg5m: examples/bfs3d/coarse60.msh kept as an input fixture, 912 unstructured tets, one
+    refinement: 440 022 dofs, macro stars of up to 3615 dofs, 56 784-dof coarse grid).  Size-independent properties:
     every patch passes the residual probe, the smoother is linear and copies Dirichlet entries, the level product agrees with
     SciPy on sampled rows, prolongation and robust restriction are adjoint, V-cycles contract the residual."""
     from alfi_amd import hip

@@ -304,3 +304,31 @@ def test_contributor_lists_of_the_device_assembly(dim, k):
     # fixed order: cells ascending inside a block
     same = blk[1:] == blk[:-1]
     assert (ccell[1:][same] >= ccell[:-1][same]).all()
+
+
+def test_the_references_own_channel_mesh():
+    """tests/golden/meshes/bfs3d_coarse60.msh (data shipped with the reference's bfs3d example, bfs3d.py:13-16): read as
+    written by gmsh -- 299 nodes, 912 tetrahedra, the channel's volume, every boundary facet tagged, tags 1 / 3 exactly on the
+    geometric Dirichlet boundary and tag 2 exactly on the outflow plane (bfs3d.py:23-26) -- and the Scott-Vogelius set-up
+    runs on it: Alfeld split, macro-star patches with interiors and skeleton, condensable groups."""
+    import os
+    from alfi_amd.mesh import read_gmsh
+    from alfi_amd.problem import ThreeDimBackwardsFacingStepProblem
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "meshes", "bfs3d_coarse60.msh")
+    r = read_gmsh(path)
+    assert r.num_vertices == 299 and r.num_cells == 912
+    vol = r.cell_geometry()[1]
+    assert (vol > 0).all() and np.isclose(vol.sum(), 19.0)
+    assert len(r.boundary_tags) == len(r.boundary_facets)
+    cent = {k: r.coords[list(k)].mean(axis=0) for k in r.boundary_tags}
+    assert all((t == 2) == (abs(cent[k][0] - 10.0) < 1e-9) for k, t in r.boundary_tags.items())
+    assert all((t == 1) == (abs(cent[k][0]) < 1e-9) for k, t in r.boundary_tags.items())
+    prob = ThreeDimBackwardsFacingStepProblem(1, msh=path)
+    m = prob.mesh()                                      # runs check_boundary_tags
+    assert m.num_cells == 912
+    from alfi_amd.sv import build_sv_hierarchy
+    lv, tr = build_sv_hierarchy(prob, 1, 2, Re=100.0)    # [P2]^3: small enough for the CPU suite
+    L = lv[-1]
+    assert len(lv) == 2 and L.patch_groups is not None
+    assert (L.patch_groups >= 0).any() and (L.patch_groups < 0).any()
+    assert np.diff(L.patch_ptr).max() > 500
