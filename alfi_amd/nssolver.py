@@ -95,9 +95,8 @@ class HipNavierStokesSolver(object):
         self._create_device(restriction)
         self._asm_ready = False
         if self.device_assembly:
-            if not hasattr(self, "hmg") or any(T.inject_map is None for T in self.transfers):
-                # partitioned levels (alfi_amd.dist) and the non-nested barycentric hierarchy (point-evaluation inject) keep
-                # the host path
+            if not hasattr(self, "hmg"):
+                # partitioned levels (alfi_amd.dist) keep the host path (every rank its own rows)
                 self.device_assembly = False
             else:
                 self._setup_device_assembly()
@@ -145,8 +144,15 @@ class HipNavierStokesSolver(object):
         self._asm_ready = True
 
     def _device_states(self, u):
-        """Current velocity on every level, on the device: the finest uploaded, the coarser ones by inject (solver.py:595)."""
+        """Current velocity on every level, on the device: the finest uploaded, the coarser ones by inject (solver.py:595).
+        Nested hierarchy: alfi_inject on the device.  Barycentric hierarchy (Scott-Vogelius): the coarse nodes are not fine
+        nodes, inject is a point evaluation (sv.bary_injection, a sparse matrix) -- applied on the host, where u already is,
+        and uploaded: a few megabytes per Newton step."""
         self._dstate[-1].set(u)
+        if any(T.inject_map is None for T in self.transfers):
+            for st, w in zip(self._dstate[:-1], self._winds(u)[:-1]):
+                st.set(np.ascontiguousarray(w).ravel())
+            return
         for l in range(len(self.levels) - 1, 0, -1):
             self.hmg.mg.transfers[l - 1].inject(self._dstate[l], self._dstate[l - 1])
 

@@ -10,15 +10,17 @@ from alfi_amd.problem import TwoDimLidDrivenCavityProblem, ThreeDimLidDrivenCavi
 
 CASES = [("2d-P2", lambda: TwoDimLidDrivenCavityProblem(4), 2, 2), ("3d-P1FB", lambda: ThreeDimLidDrivenCavityProblem(2), 1, 1),
          ("3d-P2FB", lambda: ThreeDimLidDrivenCavityProblem(2), 2, 1)]
+# Scott-Vogelius pairs on the barycentric hierarchy (full grad-div term, [P3]^3 with 20 nodes per cell)
+SV_CASES = [("2d-SV-P2", lambda: TwoDimLidDrivenCavityProblem(2), 2, 1), ("3d-SV-P3", lambda: ThreeDimLidDrivenCavityProblem(1), 3, 1)]
 
 
-@pytest.mark.parametrize("name,mk,k,nref", CASES, ids=[c[0] for c in CASES])
+@pytest.mark.parametrize("name,mk,k,nref", CASES + SV_CASES, ids=[c[0] for c in CASES + SV_CASES])
 def test_device_assembled_operator_equals_the_host_generators(name, mk, k, nref):
     """Every level: A = nu K + gamma D + N(w) with Dirichlet rows / columns as identity, for a random state w, a non-trivial
     (nu, gamma), with and without advection, with and without boundary conditions -- entry by entry to 1e-13 of the largest
     entry (the two sides sum the cell contributions in different orders)."""
     from alfi_amd.nssolver import HipNavierStokesSolver
-    s = HipNavierStokesSolver(mk(), nref, k, gamma=1e4, device_assembly=True)
+    s = HipNavierStokesSolver(mk(), nref, k, gamma=1e4, device_assembly=True, discretisation="sv" if "SV" in name else "pkp0")
     assert s.device_assembly
     s.nu = 0.037
     rng = np.random.default_rng(11)
@@ -30,7 +32,7 @@ def test_device_assembled_operator_equals_the_host_generators(name, mk, k, nref)
             if ref is None:       # level_values has no scaling of the advection term: build it from its pieces
                 from alfi_amd.nssolver import _assemble
                 from alfi_amd import _hostlib
-                ref = _assemble(L, s.nu, s.gamma, adv, w if adv else None, False, False)
+                ref = _assemble(L, s.nu, s.gamma, adv, w if adv else None, False, s.sv)
                 if bc:
                     _hostlib.apply_bc_bsr(L.V.num_nodes, L.V.dim, L.A.rowptr, L.A.colidx, ref, np.repeat(L.V.bc_node_mask, L.V.dim))
             dl.assemble(s.nu, s.gamma, adv, st if adv else None, bc)
@@ -79,6 +81,22 @@ def test_newton_with_device_and_host_assembly_agree(mk, k, nref):
     assert np.abs(out[True][0] - out[False][0]).max() <= 1e-8 * np.abs(out[False][0]).max()
     assert np.abs(out[True][1] - out[False][1]).max() <= 1e-7 * np.abs(out[False][1]).max()
     assert out[True][3]["newton_steps"] > 0
+
+
+def test_sv_newton_with_device_and_host_assembly_agree():
+    """Scott-Vogelius pair on the barycentric hierarchy (non-nested: the coarse states come from the point-evaluation inject
+    applied on the host and uploaded): Reynolds continuation with device and host assembly -- same counts, same solution."""
+    from alfi_amd.nssolver import HipNavierStokesSolver, run_solver
+    out = {}
+    for dev in (True, False):
+        s = HipNavierStokesSolver(TwoDimLidDrivenCavityProblem(4), 2, 2, discretisation="sv", device_assembly=dev)
+        assert s.device_assembly == dev
+        res = run_solver(s, [10, 100])
+        out[dev] = (s.u.copy(), s.p.copy(), [(res[r]["nonlinear_iter"], res[r]["linear_iter"], res[r]["converged"]) for r in (10, 100)])
+        s.close()
+    assert all(c for _, _, c in out[True][2]) and out[True][2] == out[False][2]
+    assert np.abs(out[True][0] - out[False][0]).max() <= 1e-8 * np.abs(out[False][0]).max()
+    assert np.abs(out[True][1] - out[False][1]).max() <= 1e-6 * np.abs(out[False][1]).max()
 
 
 @pytest.mark.parametrize("name,mk,k,nref", CASES, ids=[c[0] for c in CASES])
