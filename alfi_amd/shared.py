@@ -28,14 +28,21 @@ def dump(obj, path):
     raws = [b.raw() for b in bufs]
     header = struct.pack("<8sQQ", MAGIC, len(data), len(raws)) + b"".join(struct.pack("<Q", r.nbytes) for r in raws)
     tmp = path + ".tmp.%d" % os.getpid()
-    with open(tmp, "wb") as f:
-        f.write(header)
-        f.write(data)
-        for r in raws:
-            pad = (-f.tell()) % 64
-            f.write(b"\0" * pad)
-            f.write(r)
-    os.replace(tmp, path)
+    try:
+        with open(tmp, "wb") as f:
+            f.write(header)
+            f.write(data)
+            for r in raws:
+                pad = (-f.tell()) % 64
+                f.write(b"\0" * pad)
+                f.write(r)
+        os.replace(tmp, path)
+    except BaseException:
+        try:                                       # a partial file in /dev/shm is held in memory: do not leave it behind
+            os.unlink(tmp)
+        except OSError:
+            pass
+        raise
     return sum(r.nbytes for r in raws)
 
 

@@ -113,3 +113,43 @@ def test_hierarchy_generated_once_and_shared_between_ranks():
     assert len({o[2] for o in out}) == 1 and all(o[3] > 0 for o in out)
     assert [o[4] for o in out] == [-7, -8, -9]                   # private writes
     assert not any(o[5] for o in out)                            # file already unlinked
+
+
+def test_shared_generation_falls_back_when_the_file_cannot_be_written(tmp_path, monkeypatch):
+    """No room / no /dev/shm: rank 0 leaves a marker (or nothing) instead of the file and every other rank builds its own
+    copy -- slower, never wrong; a partial file is not left behind."""
+    import os
+    from alfi_amd import shared
+    made = []
+
+    def build():
+        made.append(1)
+        return {"a": np.arange(1000, dtype=np.int64), "b": [np.ones(7), "x"]}
+    # a directory that does not exist: neither the file nor the marker can be written
+    monkeypatch.setattr(shared, "_path", lambda tag: str(tmp_path / "missing" / ("f_" + tag)))
+    r0 = shared.build_shared(build, 0, lambda: None, "t")
+    r1 = shared.build_shared(build, 1, lambda: None, "t")
+    assert len(made) == 2 and np.array_equal(r0["a"], r1["a"])
+    # the dump dies half way (disk full): the marker is written, no .tmp file stays, rank 1 builds
+    monkeypatch.setattr(shared, "_path", lambda tag: str(tmp_path / ("f_" + tag)))
+    real_dumps = shared.pickle.dumps
+
+    monkeypatch.setattr(shared.pickle, "dumps", lambda *a, **k: (_ for _ in ()).throw(OSError(28, "No space left on device")))
+    made.clear()
+    # rank 0 and rank 1 in turn; rank 0's second barrier would unlink the marker, so keep its path alive with a no-op unlink
+    monkeypatch.setattr(shared.os, "unlink", lambda p: None)
+    r0 = shared.build_shared(build, 0, lambda: None, "u")
+    monkeypatch.setattr(shared.pickle, "dumps", real_dumps)
+    assert open(str(tmp_path / "f_u"), "rb").read() == b"UNAVAILABLE"
+    r1 = shared.build_shared(build, 1, lambda: None, "u")
+    assert len(made) == 2 and np.array_equal(r0["a"], r1["a"])
+    assert not [f for f in os.listdir(str(tmp_path)) if ".tmp." in f]
+    # and the normal path round-trips through the file: arrays equal, copy-on-write views
+    monkeypatch.undo()
+    monkeypatch.setattr(shared, "_path", lambda tag: str(tmp_path / ("g_" + tag)))
+    obj = build()
+    shared.dump(obj, str(tmp_path / "g_v"))
+    back = shared.load(str(tmp_path / "g_v"))
+    assert np.array_equal(back["a"], obj["a"]) and back["b"][1] == "x"
+    back["a"][0] = -1                                   # private write
+    assert shared.load(str(tmp_path / "g_v"))["a"][0] == 0
