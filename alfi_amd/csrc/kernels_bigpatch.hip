@@ -795,30 +795,29 @@ __global__ __launch_bounds__(256) void cond_fill_kernel(int64_t p0, CondDev cd, 
   }
 }
 
-// one wave per group: X = inv(A_gg) by Gauss-Jordan (lane = row, the row in registers), then W = X A[g, S_g] in place
-__global__ __launch_bounds__(256) void cond_group_kernel(int64_t g_begin, int64_t g_end, CondDev cd, int* __restrict__ status) {
-  const int64_t g = g_begin + (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (g >= g_end) return;
-  const int lane = threadIdx.x & 63;
-  const int m = cd.g_m[g], sc = cd.g_sc[g];
-  const int ldm = cond_ldim(m);
-  double* X = cd.mat + cd.g_mat[g];
-  double* W = X + (int64_t)ldm * m + (int64_t)cond_ldim(sc) * m;
-  double a[COND_GMAX], a0[COND_GMAX];        // row `lane` of the matrix being inverted / of A_gg itself
+// one wave per group: X = inv(A_gg) by Gauss-Jordan (lane = row, the row in registers), then W = X A[g, S_g] in place.
+// GM: the register extent, the smallest of 4 / 12 / 24 / 46 / 64 that holds the group (the groups of a [P3]^3 macro star have
+// 3, 9 or 45 entries; with the full 64 x 64 elimination for every group this kernel was the largest of config 5's
+// re-factorisation, 84 of 173 ms).  The padding rows are identity rows: their pivots are 1 and their multipliers 0, so the
+// entries of the group come out the same for every GM.
+template <int GM>
+__device__ __noinline__ void cond_group_body(int m, int sc, int ldm, double* __restrict__ X, double* __restrict__ W, int lane,
+                                                int* __restrict__ status) {
+  double a[GM], a0[GM];                      // row `lane` of the matrix being inverted / of A_gg itself
 #pragma unroll
-  for (int j = 0; j < COND_GMAX; ++j) {
+  for (int j = 0; j < GM; ++j) {
     a[j] = (lane < m && j < m) ? X[(int64_t)j * ldm + lane] : (lane == j ? 1.0 : 0.0);
     a0[j] = a[j];
   }
   bool bad = false;
 #pragma unroll
-  for (int k = 0; k < COND_GMAX; ++k) {
+  for (int k = 0; k < GM; ++k) {
     const double piv = __shfl(a[k], k, 64);
     if (piv == 0.0) bad = true;
     const double ip = 1.0 / piv;
     const double mk = (lane == k) ? 0.0 : a[k] * ip;
 #pragma unroll
-    for (int j = 0; j < COND_GMAX; ++j) {
+    for (int j = 0; j < GM; ++j) {
       const double rk = __shfl(a[j], k, 64);
       if (j == k)
         a[j] = (lane == k) ? ip : -mk;
@@ -829,7 +828,7 @@ __global__ __launch_bounds__(256) void cond_group_kernel(int64_t g_begin, int64_
   if (bad && lane == 0) atomicExch(status, 1);
   if (lane < m) {
 #pragma unroll
-    for (int j = 0; j < COND_GMAX; ++j)
+    for (int j = 0; j < GM; ++j)
       if (j < m) X[(int64_t)j * ldm + lane] = a[j];
   }
   // W[:, c] solves A_gg w = A[g, S_g][:, c]: w = X b, then two steps of iterative refinement w += X (b - A_gg w).  The
@@ -839,19 +838,34 @@ __global__ __launch_bounds__(256) void cond_group_kernel(int64_t g_begin, int64_
     const double b = lane < m ? W[(int64_t)c * ldm + lane] : 0.0;
     double w = 0.0;
 #pragma unroll
-    for (int k = 0; k < COND_GMAX; ++k) w = __builtin_fma(a[k], __shfl(b, k, 64), w);
+    for (int k = 0; k < GM; ++k) w = __builtin_fma(a[k], __shfl(b, k, 64), w);
     for (int it = 0; it < 2; ++it) {
       double r = b;
 #pragma unroll
-      for (int k = 0; k < COND_GMAX; ++k) r = __builtin_fma(-a0[k], __shfl(w, k, 64), r);
+      for (int k = 0; k < GM; ++k) r = __builtin_fma(-a0[k], __shfl(w, k, 64), r);
       if (lane >= m) r = 0.0;
       double dw = 0.0;
 #pragma unroll
-      for (int k = 0; k < COND_GMAX; ++k) dw = __builtin_fma(a[k], __shfl(r, k, 64), dw);
+      for (int k = 0; k < GM; ++k) dw = __builtin_fma(a[k], __shfl(r, k, 64), dw);
       w += dw;
     }
     if (lane < m) W[(int64_t)c * ldm + lane] = w;
   }
+}
+
+__global__ __launch_bounds__(256) void cond_group_kernel(int64_t g_begin, int64_t g_end, CondDev cd, int* __restrict__ status) {
+  const int64_t g = g_begin + (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (g >= g_end) return;
+  const int lane = threadIdx.x & 63;
+  const int m = cd.g_m[g], sc = cd.g_sc[g];
+  const int ldm = cond_ldim(m);
+  double* X = cd.mat + cd.g_mat[g];
+  double* W = X + (int64_t)ldm * m + (int64_t)cond_ldim(sc) * m;
+  if (m <= 4) cond_group_body<4>(m, sc, ldm, X, W, lane, status);
+  else if (m <= 12) cond_group_body<12>(m, sc, ldm, X, W, lane, status);
+  else if (m <= 24) cond_group_body<24>(m, sc, ldm, X, W, lane, status);
+  else if (m <= 46) cond_group_body<46>(m, sc, ldm, X, W, lane, status);     // (48: the compiler gives up unrolling)
+  else cond_group_body<COND_GMAX>(m, sc, ldm, X, W, lane, status);
 }
 
 // workgroup per patch of the batch: Sigma -= B_g W_g, group after group (a fixed order: deterministic)
