@@ -957,6 +957,37 @@ def _dist_ns_solver_class():
                 L.nu = self.nu
             self._push_operators()
 
+        def residual(self, u, p, adv):
+            """F(u, p) with every rank assembling ITS rows of (nu K + gamma D + 1/2 N(u)) u only -- one pass over its own
+            cells instead of two global assemblies on every rank (the replicated host path of the base class, whose cost per
+            rank GROWS with the number of ranks sharing the host's cores) -- and the pieces gathered.  SUPG keeps the
+            replicated path."""
+            if self.supg:
+                return super().residual(u, p, adv)
+            from . import _hostlib
+            from .lazy import _take_rows, _row_map
+            from .problem import BSR
+            L = self.levels[-1]
+            V, d = L.V, L.V.dim
+            part = self.dmg.fine.part
+            rows = np.asarray(part.own_nodes, dtype=np.int64)
+            ptr, cols = _take_rows(L.A.rowptr, L.A.colidx, rows)
+            ptr32 = ptr.astype(np.int32)
+            g, vol = V.mesh.cell_geometry()
+            wind = np.ascontiguousarray(u.reshape(-1, d))
+            vals = _hostlib.assemble_bsr(V.cell_nodes, g, vol, V.element.reference_tensors(), d, ptr32, cols, nu=self.nu,
+                                         gamma=self.gamma, adv=0.5 * adv, wind=wind if adv else None,
+                                         row_map=_row_map(V.num_nodes, rows))
+            f_own = BSR(len(rows), V.num_nodes, d, ptr32, cols, vals).to_scipy() @ u
+            Fu = np.zeros(self.n_u)
+            for dofs, f in self.dmg.comm.all_gather_object((part.own_dofs(), f_own)):
+                Fu[dofs] = f
+            Fu += self.B_raw.T @ p
+            if self._load is not None:
+                Fu -= self._load
+            Fu[L.bc_dofs] = 0.0
+            return Fu, self.B_raw @ u
+
         def _set_parameters(self):
             # transfers present on this rank link local levels lmin.. ; their (nu, gamma) follow the solver's
             ltr = self.dmg.local_transfers
