@@ -453,19 +453,30 @@ def localize(levels, transfers, parts):
     return llev, ltr, lmin
 
 
-def localize_pressure(B, mass_diag, cell_nodes, part, bs):
-    """The rank's share of the P0 pressure space for the outer solve: a cell belongs to the rank that owns its lowest-numbered
-    node (all its nodes are then local: they are columns of that node's operator row).  Returns (owned cell ids ascending,
-    B_loc = rows of B for those cells with columns in the local dof numbering (scipy CSR, n_p_own x n_loc), mass_diag_loc)."""
+def localize_pressure(B, mass_diag, cell_nodes, part, bs, mass_inv=None):
+    """The rank's share of the discontinuous pressure space for the outer solve: a cell -- with its one (P0) or several
+    (P_{k-1}^dg of the Scott-Vogelius pair: rows c * npc .. c * npc + npc - 1 of B, sv.build_sv_pressure_coupling) pressure
+    dofs -- belongs to the rank that owns its lowest-numbered node (all its nodes are then local: they are columns of that
+    node's operator row).  Returns (owned pressure rows ascending, B_loc = those rows of B with columns in the local dof
+    numbering (scipy CSR, n_p_own x n_loc), mass_diag_loc or None, the rows' diagonal blocks of ``mass_inv`` or None)."""
     import scipy.sparse as sp
-    low = np.asarray(cell_nodes).min(axis=1).astype(np.int64)
+    cell_nodes = np.asarray(cell_nodes)
+    npc = int(B.shape[0]) // cell_nodes.shape[0]
+    assert npc * cell_nodes.shape[0] == B.shape[0], "pressure dofs must come cell by cell"
+    low = cell_nodes.min(axis=1).astype(np.int64)
     cells = np.flatnonzero((low >= part.lo) & (low < part.hi))
-    Bl = sp.csr_matrix(B)[cells].tocoo()
+    prows = (cells[:, None] * npc + np.arange(npc)).ravel()
+    Bl = sp.csr_matrix(B)[prows].tocoo()
     lcol = part.g2l(Bl.col // bs) * bs + Bl.col % bs
     assert (lcol >= 0).all(), "a velocity dof of an owned cell is not in the local node set"
-    Bloc = sp.csr_matrix((Bl.data, (Bl.row, lcol)), shape=(len(cells), part.nb_loc * bs))
+    Bloc = sp.csr_matrix((Bl.data, (Bl.row, lcol)), shape=(len(prows), part.nb_loc * bs))
     Bloc.sort_indices()
-    return cells, Bloc, np.asarray(mass_diag)[cells]
+    md = np.asarray(mass_diag)[prows] if mass_diag is not None else None
+    Mi = None
+    if mass_inv is not None:
+        Mi = sp.csr_matrix(mass_inv)[prows][:, prows].tocsr()     # block diagonal by cell: closed under the selection
+        Mi.sort_indices()
+    return prows, Bloc, md, Mi
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -797,13 +808,17 @@ class DistSaddle(object):
     rank's rows of the discrete divergence.  Velocity dofs are owned with their nodes, pressure dofs with their cells
     (``localize_pressure``); every reduction is one all-reduce."""
 
-    def __init__(self, dmg, B, mass_diag, cell_nodes, nu, gamma, remove_constant_nullspace=True):
+    def __init__(self, dmg, B, mass_diag, cell_nodes, nu, gamma, remove_constant_nullspace=True, mass_inv=None):
+        """mass_inv: scipy sparse inverse of the block-diagonal pressure mass matrix (discontinuous P_{k-1} pressure of the
+        Scott-Vogelius pair, DGMassInv solver.py:15-38) -- replaces ``mass_diag`` (P0); ``self.cells`` then holds the owned
+        pressure ROWS (npc per owned cell)."""
         import torch
         from . import hip
         self.dmg, self.nu, self.gamma, self.remove_nullspace = dmg, float(nu), float(gamma), remove_constant_nullspace
         F = dmg.fine
         self.part, self.bs = F.part, F.bs
-        self.cells, Bloc, md = localize_pressure(B, mass_diag, cell_nodes, self.part, self.bs)
+        self.cells, Bloc, md, Mi = localize_pressure(B, None if mass_inv is not None else mass_diag, cell_nodes, self.part,
+                                                     self.bs, mass_inv)
         self.n_own, self.n_loc, self.np_own = dmg.n_own, dmg.n_loc, len(self.cells)
         self.n = self.n_own + self.np_own
         self.np_global = int(B.shape[0])
@@ -811,7 +826,8 @@ class DistSaddle(object):
         with torch.cuda.stream(dmg.stream):
             self.B = hip.Csr(dmg.ctx, Bloc)
             self.BT = hip.Csr(dmg.ctx, Bloc.T.tocsr())
-            self.minv = torch.tensor(1.0 / md, dtype=torch.float64, device=dev)
+            self.Minv = hip.Csr(dmg.ctx, Mi) if Mi is not None else None
+            self.minv = torch.tensor(1.0 / md, dtype=torch.float64, device=dev) if Mi is None else None
             self.wa, self.wb, self.wc = (torch.zeros(max(self.n_loc, 1), dtype=torch.float64, device=dev) for _ in range(3))
             self.wq = torch.zeros(max(self.np_own, 1), dtype=torch.float64, device=dev)
         self.level = dmg.levels[-1]
@@ -844,7 +860,10 @@ class DistSaddle(object):
         self.level.halo_forward(self._raw(self.wb))
         self.B.mult(self._raw(self.wb), self._raw(self.wq), b=self._raw(v[n_own:]), alpha=1.0, mode=1)
         yp = z[n_own:]
-        torch.mul(self.wq[:self.np_own], self.minv, out=yp)
+        if self.Minv is not None:                   # block-diagonal M^-1: rows and columns of the rank's own cells only
+            self.Minv.mult(self._raw(self.wq), self._raw(yp))
+        else:
+            torch.mul(self.wq[:self.np_own], self.minv, out=yp)
         yp.mul_(-(self.nu + self.gamma))
         self.BT.mult(self._raw(yp), self._raw(self.wc))
         self.level.halo_reverse_add(self._raw(self.wc))
@@ -915,6 +934,8 @@ class DistSaddle(object):
     def close(self):
         self.B.close()
         self.BT.close()
+        if self.Minv is not None:
+            self.Minv.close()
 
 
 def _dist_ns_solver_class():
@@ -930,14 +951,12 @@ def _dist_ns_solver_class():
             super().__init__(*args, **kwargs)
 
         def _create_device(self, restriction):
-            if self.sv:
-                raise NotImplementedError("partitioned outer solve: P0 pressure pairs")
             self.dmg = DistMultigrid(self.levels, self.transfers, self.params["fieldsplit_0"]["mg_levels"]["ksp_max_it"],
                                      robust_restriction=restriction, group=self._group, min_dofs=self._min_dofs)
             self.ctx = self.dmg.ctx
             L = self.levels[-1]
             self.saddle = DistSaddle(self.dmg, self.B, self.vol, L.V.cell_nodes, self.nu, self.gamma,
-                                     remove_constant_nullspace=self.nullspace)
+                                     remove_constant_nullspace=self.nullspace, mass_inv=self.Minv if self.sv else None)
 
         def _push_operators(self):
             self.dmg.update(self.levels)
@@ -947,7 +966,7 @@ def _dist_ns_solver_class():
             values of a row subset on demand) and DistMultigrid.update cuts the rank's rows out of them -- one rank per mesh
             partition assembling its own cells, as in the reference (alfi/solver.py:604-605).  SUPG terms are assembled by
             the global host pass and keep the replicated path."""
-            if self.supg:
+            if self.supg or self.sv:       # (Scott-Vogelius values: the global host pass, then every rank cuts its rows)
                 return super()._rediscretise(u, adv)
             from .lazy import LazyOperator
             for L, w in zip(self.levels, self._winds(u)):
@@ -976,8 +995,8 @@ def _dist_ns_solver_class():
             g, vol = V.mesh.cell_geometry()
             wind = np.ascontiguousarray(u.reshape(-1, d))
             vals = _hostlib.assemble_bsr(V.cell_nodes, g, vol, V.element.reference_tensors(), d, ptr32, cols, nu=self.nu,
-                                         gamma=self.gamma, adv=0.5 * adv, wind=wind if adv else None,
-                                         row_map=_row_map(V.num_nodes, rows))
+                                         gamma=0.0 if self.sv else self.gamma, gamma_full=self.gamma if self.sv else 0.0,
+                                         adv=0.5 * adv, wind=wind if adv else None, row_map=_row_map(V.num_nodes, rows))
             f_own = BSR(len(rows), V.num_nodes, d, ptr32, cols, vals).to_scipy() @ u
             Fu = np.zeros(self.n_u)
             for dofs, f in self.dmg.comm.all_gather_object((part.own_dofs(), f_own)):

@@ -306,12 +306,17 @@ def main_distributed(args, rank, world, local_rank):
     lib_rank, lib_world = ctx.comm_size() if dmg.transport == "rccl" else (rank, None)
     nbr_max = max([int(np.count_nonzero((p.send_counts > 0) | (p.recv_counts > 0))) for p in dmg.parts] + [0])
     outer = None
-    if args.outer and CONFIGS[args.config][0] != "sv":
+    if args.outer:
         # one Newton-step linear solve on the partitioned levels (alfi_amd.dist.DistSaddle), outside the timed region
         from alfi_amd.dist import DistSaddle
-        from alfi_amd.problem import build_pressure_coupling
-        Bm, vol = build_pressure_coupling(L)
-        sad = DistSaddle(dmg, Bm, vol, L.V.cell_nodes, L.nu, L.gamma, remove_constant_nullspace=True)
+        if CONFIGS[args.config][0] == "sv":      # discontinuous P2 pressure, block DGMassInv; bfs3d has an outflow: no nullspace
+            from alfi_amd.sv import build_sv_pressure_coupling
+            Bm, _, Minv = build_sv_pressure_coupling(L)
+            sad = DistSaddle(dmg, Bm, None, L.V.cell_nodes, L.nu, L.gamma, remove_constant_nullspace=False, mass_inv=Minv)
+        else:
+            from alfi_amd.problem import build_pressure_coupling
+            Bm, vol = build_pressure_coupling(L)
+            sad = DistSaddle(dmg, Bm, vol, L.V.cell_nodes, L.nu, L.gamma, remove_constant_nullspace=True)
         rtol, atol = (1e-9, 1e-10) if L.bs == 2 else (1e-8, 1e-8)
         rhs = torch.tensor(np.concatenate([b[dmg.fine.part.own_dofs()], np.zeros(sad.np_own)]), dtype=torch.float64,
                            device=dmg.device)

@@ -11,6 +11,7 @@ sys.path.insert(0, ROOT)
 
 def main():
     out = sys.argv[1]
+    disc = sys.argv[2] if len(sys.argv) > 2 else "pkp0"
     import torch
     import torch.distributed as dist
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
@@ -19,7 +20,8 @@ def main():
     from alfi_amd.dist import DistNavierStokesSolver
     from alfi_amd.nssolver import run_solver
     from alfi_amd.problem import TwoDimLidDrivenCavityProblem
-    s = DistNavierStokesSolver(TwoDimLidDrivenCavityProblem(8), 1, 2, min_dofs=1)
+    s = DistNavierStokesSolver(TwoDimLidDrivenCavityProblem(4 if disc == "sv" else 8), 2 if disc == "sv" else 1, 2, min_dofs=1,
+                               discretisation=disc)
     res = run_solver(s, [10, 100])
     if rank == 0:
         np.savez(os.path.join(out, "newton.npz"), u=s.u, p=s.p, its=[res[r]["linear_iter"] for r in (10, 100)],

@@ -23,8 +23,13 @@ def main():
     lv, tr, k, min_dofs = _hier(case)
     L = lv[-1]
     dmg = DistMultigrid(lv, tr, k, robust_restriction=False, min_dofs=min_dofs)
-    B, vol = build_pressure_coupling(L)
-    sad = DistSaddle(dmg, B, vol, L.V.cell_nodes, L.nu, L.gamma, remove_constant_nullspace=True)
+    if "SV" in case:
+        from alfi_amd.sv import build_sv_pressure_coupling
+        B, _, Minv = build_sv_pressure_coupling(L)
+        sad = DistSaddle(dmg, B, None, L.V.cell_nodes, L.nu, L.gamma, remove_constant_nullspace=True, mass_inv=Minv)
+    else:
+        B, vol = build_pressure_coupling(L)
+        sad = DistSaddle(dmg, B, vol, L.V.cell_nodes, L.nu, L.gamma, remove_constant_nullspace=True)
     b = np.random.default_rng(0).standard_normal(L.n)
     b[L.bc_dofs] = 0.0
     p = dmg.fine.part

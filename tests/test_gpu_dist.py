@@ -183,7 +183,7 @@ def test_partitioned_multiplicative(case, world, tmp_path):
         assert os.path.exists(os.path.join(str(tmp_path), "rank%d.ok" % r))
 
 
-@pytest.mark.parametrize("case,world", [("2d-all-distributed", 2), ("3d-P2FB", 3)])
+@pytest.mark.parametrize("case,world", [("2d-all-distributed", 2), ("3d-P2FB", 3), ("2d-SV", 2), ("3d-SV-P3", 2)])
 def test_partitioned_outer_solve(case, world, tmp_path):
     """alfi_amd.dist.DistSaddle (host-driven FGMRES around the library's partitioned cycles, halo routes and divergence
     products) against the single-GPU alfi_saddle_solve: same iteration count, same solution."""
@@ -203,8 +203,13 @@ def test_partitioned_outer_solve(case, world, tmp_path):
                                        str(tmp_path)], env=env, cwd=ROOT))
     ctx = hip.Context(0)
     mg = hip.Multigrid(ctx, lv, tr, k, robust_restriction=False)
-    B, vol = build_pressure_coupling(L)
-    sad = hip.Saddle(mg, B, vol, L.nu, L.gamma, remove_constant_nullspace=True)
+    if "SV" in case:      # Scott-Vogelius pair: discontinuous P_{k-1} pressure, block-diagonal mass inverse (DGMassInv)
+        from alfi_amd.sv import build_sv_pressure_coupling
+        B, _, Minv = build_sv_pressure_coupling(L)
+        sad = hip.Saddle(mg, B, None, L.nu, L.gamma, remove_constant_nullspace=True, mass_inv=Minv)
+    else:
+        B, vol = build_pressure_coupling(L)
+        sad = hip.Saddle(mg, B, vol, L.nu, L.gamma, remove_constant_nullspace=True)
     db, dx = ctx.vec(np.concatenate([b, np.zeros(B.shape[0])])), ctx.vec(L.n + B.shape[0])
     its_s, rn = sad.solve(db, dx, 1e-9, 1e-12, 500, 30)
     xs = dx.get()
@@ -224,9 +229,11 @@ def test_partitioned_outer_solve(case, world, tmp_path):
     assert np.abs(xp - xs[L.n:]).max() < 1e-5 * np.abs(xs[L.n:]).max()
 
 
-def test_partitioned_newton(tmp_path):
+@pytest.mark.parametrize("disc", ["pkp0", "sv"])
+def test_partitioned_newton(tmp_path, disc):
     """Newton + Reynolds continuation with every linear solve on partitioned levels (2 ranks): same Newton / Krylov counts
-    and the same solution as the single-GPU solver."""
+    and the same solution as the single-GPU solver.  ``sv``: the Scott-Vogelius pair on the barycentric hierarchy (macro-star
+    patches as condensed factors, discontinuous P1 pressure owned cell by cell, block DGMassInv)."""
     from alfi_amd.nssolver import HipNavierStokesSolver, run_solver
     from alfi_amd.problem import TwoDimLidDrivenCavityProblem
     world = 2
@@ -236,8 +243,9 @@ def test_partitioned_newton(tmp_path):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), OMP_NUM_THREADS="4")
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dist_gpu_newton_worker.py"),
-                                       str(tmp_path)], env=env, cwd=ROOT))
-    s = HipNavierStokesSolver(TwoDimLidDrivenCavityProblem(8), 1, 2)
+                                       str(tmp_path), disc], env=env, cwd=ROOT))
+    s = (HipNavierStokesSolver(TwoDimLidDrivenCavityProblem(4), 2, 2, discretisation="sv") if disc == "sv"
+         else HipNavierStokesSolver(TwoDimLidDrivenCavityProblem(8), 1, 2))
     res = run_solver(s, [10, 100])
     for p in procs:
         assert p.wait(timeout=600) == 0
