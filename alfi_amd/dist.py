@@ -966,13 +966,13 @@ def _dist_ns_solver_class():
             values of a row subset on demand) and DistMultigrid.update cuts the rank's rows out of them -- one rank per mesh
             partition assembling its own cells, as in the reference (alfi/solver.py:604-605).  SUPG terms are assembled by
             the global host pass and keep the replicated path."""
-            if self.supg or self.sv:       # (Scott-Vogelius values: the global host pass, then every rank cuts its rows)
+            if self.supg:
                 return super()._rediscretise(u, adv)
             from .lazy import LazyOperator
             for L, w in zip(self.levels, self._winds(u)):
                 V = L.V
                 L.A = LazyOperator(V, L.A.rowptr, L.A.colidx, V.mesh.cell_geometry(), V.element.reference_tensors(), self.nu,
-                                   self.gamma, adv, np.ascontiguousarray(w))
+                                   self.gamma, adv, np.ascontiguousarray(w), full_div=self.sv)
                 L.nu = self.nu
             self._push_operators()
 

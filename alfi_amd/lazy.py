@@ -40,7 +40,9 @@ class LazyOperator(object):
 
     is_lazy = True
 
-    def __init__(self, V, rowptr, colidx, geometry, tensors, nu, gamma, adv, wind):
+    def __init__(self, V, rowptr, colidx, geometry, tensors, nu, gamma, adv, wind, full_div=False):
+        """full_div: the Scott-Vogelius grad-div term gamma (div u, div v) (solver.py:616) instead of the cell-averaged one."""
+        self.full_div = bool(full_div)
         self.V = V
         self.nbrows = self.nbcols = V.num_nodes
         self.bs = V.dim
@@ -65,8 +67,9 @@ class LazyOperator(object):
         ptr, cols = _take_rows(self.rowptr, self.colidx, rows)
         ptr32 = ptr.astype(np.int32)
         vals = _hostlib.assemble_bsr(V.cell_nodes, self.g, self.vol, self.tens, d, ptr32, cols, nu=self.nu,
-                                     gamma=self.gamma, adv=self.adv, wind=self.wind if self.adv else None,
-                                     row_map=_row_map(V.num_nodes, rows))
+                                     gamma=0.0 if self.full_div else self.gamma,
+                                     gamma_full=self.gamma if self.full_div else 0.0, adv=self.adv,
+                                     wind=self.wind if self.adv else None, row_map=_row_map(V.num_nodes, rows))
         _hostlib.apply_bc_bsr(len(rows), d, ptr32, cols, vals, self._bcmask, row_ids=rows)
         return BSR(len(rows), self.nbcols, d, ptr32, cols, vals)
 

@@ -153,3 +153,19 @@ def test_shared_generation_falls_back_when_the_file_cannot_be_written(tmp_path, 
     assert np.array_equal(back["a"], obj["a"]) and back["b"][1] == "x"
     back["a"][0] = -1                                   # private write
     assert shared.load(str(tmp_path / "g_v"))["a"][0] == 0
+
+
+def test_lazy_operator_with_the_full_grad_div_term():
+    """LazyOperator(full_div=True): rows of the Scott-Vogelius level operator (gamma (div u, div v), solver.py:616) for a node
+    subset equal the rows of the globally assembled one."""
+    from alfi_amd.lazy import LazyOperator
+    from alfi_amd.problem import TwoDimLidDrivenCavityProblem
+    from alfi_amd.sv import build_sv_hierarchy
+    lv, _ = build_sv_hierarchy(TwoDimLidDrivenCavityProblem(2), 1, 2, Re=50.0)
+    L = lv[-1]
+    V = L.V
+    wind = TwoDimLidDrivenCavityProblem(2).driver(V.node_coords)
+    op = LazyOperator(V, L.A.rowptr, L.A.colidx, V.mesh.cell_geometry(), V.element.reference_tensors(), L.nu, L.gamma, 1.0,
+                      np.ascontiguousarray(wind), full_div=True)
+    rows = np.arange(1, V.num_nodes, 3)
+    _same_bsr(op.select_rows(rows), L.A.select_rows(rows))
