@@ -1158,10 +1158,10 @@ int alfi_patches_set_groups(alfi_level* L, const int32_t* group) {
       for (int64_t g = gptr[p]; g < gptr[p + 1]; ++g) {
         g_xp[g] = xp;
         g_bp[g] = bp;
-        for (int i = 0; i < cond_ldim(g_m[g]) / 2; ++i) xp_grp.push_back((int32_t)g);
-        for (int j = 0; j < cond_ldim(g_sc[g]) / 2; ++j) bp_grp.push_back((int32_t)g);
-        xp += cond_ldim(g_m[g]) / 2;
-        bp += cond_ldim(g_sc[g]) / 2;
+        for (int i = 0; i < cond_pairs(g_m[g]); ++i) xp_grp.push_back((int32_t)g);
+        for (int j = 0; j < cond_pairs(g_sc[g]); ++j) bp_grp.push_back((int32_t)g);
+        xp += cond_pairs(g_m[g]);
+        bp += cond_pairs(g_sc[g]);
         uo += g_sc[g];
       }
       uptr[p + 1] = uptr[p] + uo;
@@ -1191,6 +1191,72 @@ int alfi_patches_set_groups(alfi_level* L, const int32_t* group) {
     ALFI_CHECK(cond_upload(L, &cd.bp_ptr, bp_ptr));
     ALFI_CHECK(cond_upload(L, &cd.bp_grp, bp_grp));
     ALFI_CHECK(cond_upload(L, &cd.g_bp, g_bp));
+    {
+      // chunks of consecutive groups: at most 256 row pairs of X / W and of B each, with the descriptors of the chunks and of
+      // every row pair (CondChunk / CondXPair / CondBPair, common.h)
+      std::vector<CondChunk> gc;
+      std::vector<CondXPair> xpd((size_t)xp_ptr[npatch]);
+      std::vector<CondBPair> bpd((size_t)bp_ptr[npatch]);
+      std::vector<int64_t> gcptr((size_t)npatch + 1, 0), stage_off((size_t)npatch + 1, 0);
+      for (int64_t p = 0; p < npatch; ++p)          // the staging layout of alfi_patches_set: ld_p = n_p rounded up to even
+        stage_off[p + 1] = stage_off[p] + ((pp[p + 1] - pp[p] + 1) & ~(int64_t)1);
+      int lds_gf = 0, lds_gb = 0;
+      for (int64_t p = 0; p < npatch; ++p) {
+        for (int64_t g = gptr[p]; g < gptr[p + 1]; ++g) {
+          const int m = g_m[g], sc = g_sc[g], ldm = cond_ldim(m), ldsc = cond_ldim(sc);
+          for (int q = 0; q < cond_pairs(m); ++q) {
+            CondXPair& d = xpd[(size_t)(xp_ptr[p] + g_xp[g] + q)];
+            d.xoff = g_mat[g] + 2 * q;
+            d.woff = g_mat[g] + (int64_t)ldm * m + (int64_t)ldsc * m + 2 * q;
+            d.ld = ldm; d.m = m; d.sc = sc; d.o = g_off[g]; d.uo = g_uoff[g]; d.i = 2 * q;
+            d.sl0 = c_slot[pp[p] + g_off[g] + 2 * q];
+            d.sl1 = 2 * q + 1 < m ? c_slot[pp[p] + g_off[g] + 2 * q + 1] : -1;
+          }
+          for (int q = 0; q < cond_pairs(sc); ++q) {
+            CondBPair& d = bpd[(size_t)(bp_ptr[p] + g_bp[g] + q)];
+            d.boff = g_mat[g] + (int64_t)ldm * m + 2 * q;
+            d.ld = ldsc; d.m = m; d.o = g_off[g];
+            d.d0 = u_dst[(size_t)(uptr[p] + g_uoff[g] + 2 * q)];
+            d.d1 = 2 * q + 1 < sc ? u_dst[(size_t)(uptr[p] + g_uoff[g] + 2 * q + 1)] : -1;
+            d.pad = 0;
+          }
+        }
+        int64_t g = gptr[p];
+        while (g < gptr[p + 1]) {
+          CondChunk c;
+          const int64_t ga = g;
+          int xp = 0, bp = 0, ne = 0, nu = 0;
+          while (g < gptr[p + 1] && xp + cond_pairs(g_m[g]) <= 256 && bp + cond_pairs(g_sc[g]) <= 256) {
+            xp += cond_pairs(g_m[g]);
+            bp += cond_pairs(g_sc[g]);
+            ne += g_m[g];
+            nu += g_sc[g];
+            ++g;
+          }
+          c.off = pp[p]; c.ubase = uptr[p]; c.sidx0 = g_sidx[ga]; c.stage_off = stage_off[p];
+          c.xq0 = (int32_t)(xp_ptr[p] + g_xp[ga]); c.xq1 = c.xq0 + xp;
+          c.bq0 = (int32_t)(bp_ptr[p] + g_bp[ga]); c.bq1 = c.bq0 + bp;
+          c.e0 = g_off[ga]; c.ne = ne; c.u0 = g_uoff[ga]; c.nu = nu; c.nI = p_nI[p]; c.pad = 0;
+          gc.push_back(c);
+          lds_gf = std::max(lds_gf, (int)(2 * ne * sizeof(double)));
+          lds_gb = std::max(lds_gb, (int)(nu * sizeof(double)));
+        }
+        gcptr[p + 1] = (int64_t)gc.size();
+      }
+      if (xp_ptr[npatch] > INT32_MAX || bp_ptr[npatch] > INT32_MAX)
+        return alfi_set_error(ctx, ALFI_E_ARG, "condensed factors: too many row pairs on one level");
+      if (gc.empty()) gc.push_back(CondChunk());
+      xpd.push_back(CondXPair());                   // one entry past the end: lanes without a pair read descriptor [q0]
+      bpd.push_back(CondBPair());
+      ALFI_CHECK(cond_upload(L, &cd.gc, gc));
+      ALFI_CHECK(cond_upload(L, &cd.xpd, xpd));
+      ALFI_CHECK(cond_upload(L, &cd.bpd, bpd));
+      L->h_cond_gcptr = gcptr;
+      L->cond_lds_gfront = lds_gf + 16;
+      L->cond_lds_gback = lds_gb + 16;
+      ALFI_CHECK(dev_alloc(ctx, &cd.ubuf, uptr[npatch] > 0 ? uptr[npatch] : 1));
+      L->cond_allocs.push_back(cd.ubuf);
+    }
     L->h_cond_chptr = chptr;
     L->cond_lds_front = lds_front;
     L->cond_lds_back = lds_back;

@@ -189,11 +189,42 @@ struct CondDev {
   const int64_t* bp_ptr = nullptr;    // the same for the rows of B (the u buffer)
   const int32_t* bp_grp = nullptr;
   const int32_t* g_bp = nullptr;
+  // chunks of consecutive groups of one patch (<= 256 row pairs of X / W and of B): the work units of cond_gfront / cond_gback.
+  // Everything a workgroup / a lane needs is in ONE descriptor each (a chain patch -> groups -> group data of dependent
+  // loads in front of the first matrix byte is what bounds these short workgroups).
+  const struct CondChunk* gc = nullptr;   // (nchunk)
+  const struct CondXPair* xpd = nullptr;  // per row pair of X / W, patch after patch (the order of xp_grp)
+  const struct CondBPair* bpd = nullptr;  // per row pair of B
+  double* ubuf = nullptr;             // (sum of the u buffer lengths) u_g = B_g t_g in the row-sorted order of u_dst
+};
+struct CondChunk {
+  int64_t off;        // patch_ptr[p]
+  int64_t ubase;      // uptr[p]
+  int64_t sidx0;      // first entry of the chunk's S_g lists in CondDev::sidx
+  int64_t stage_off;  // stage_ptr[p]
+  int32_t xq0, xq1;   // the chunk's X / W row pairs in xpd
+  int32_t bq0, bq1;   // the chunk's B row pairs in bpd
+  int32_t e0, ne;     // its interior entries (adjacent in the condensed order)
+  int32_t u0, nu;     // its entries of the patch's u layout
+  int32_t nI, pad;
+};
+struct CondXPair {
+  int64_t xoff, woff; // the pair's rows in X and in W (offsets into CondDev::mat)
+  int32_t ld, m, sc;  // leading dimension of X / W, columns of X (= group size), columns of W
+  int32_t o, uo, i;   // group's first interior entry, its offset in the u layout, the pair's first row inside the group
+  int32_t sl0, sl1;   // staging slots of the two rows (-1: the row does not exist)
+};
+struct CondBPair {
+  int64_t boff;       // the pair's rows in B
+  int32_t ld, m, o;   // leading dimension, columns (= group size), group's first interior entry
+  int32_t d0, d1;     // places of the two results in the row-sorted u buffer (-1: the row does not exist)
+  int32_t pad;
 };
 
 // storage of one group's matrices in CondDev::mat: [X (m x m) | B (sc x m) | W (m x sc)], column-major each, the leading
 // dimensions rounded up to EVEN (a lane streams two rows of a column with one 16-byte load; the pad row is never stored)
 __host__ __device__ inline int cond_ldim(int rows) { return (rows + 1) & ~1; }
+__host__ __device__ inline int cond_pairs(int rows) { return (rows + 1) / 2; }     // row pairs a lane each
 __host__ __device__ inline int64_t cond_group_doubles(int m, int sc) {
   return (int64_t)cond_ldim(m) * m + (int64_t)cond_ldim(sc) * m + (int64_t)cond_ldim(m) * sc;
 }
@@ -292,6 +323,8 @@ struct alfi_level {
   int64_t cond_ngroups = 0, cond_mat_doubles = 0, cond_sinv_doubles = 0;
   int cond_lds_bytes = 0, cond_max_s = 0, cond_umax = 0, cond_lds_front = 0, cond_lds_back = 0;
   std::vector<int64_t> h_cond_chptr;      // (npatch+1) chunks of the three-launch condensed apply
+  std::vector<int64_t> h_cond_gcptr;      // (npatch+1) group chunks of the patches
+  int cond_lds_gfront = 0, cond_lds_gback = 0;
   std::vector<int64_t> h_cond_gptr;      // host copy of cd.gptr
   // multiplicative sweeps: positions of the iteration sequence grouped into dependency wavefronts
   bool mult = false, mult_symmetrise = false;

@@ -1209,6 +1209,151 @@ __global__ __launch_bounds__(64 * COND_WAVES) void cond_back_kernel(int64_t p0, 
   for (int i = threadIdx.x; i < s; i += NT_) out[cd.slot[off + nI + i]] = ys[i];
 }
 
+// ---- the group products by CHUNKS of groups (the default since the end of round 3; ALFI_COND_SPLIT=2 keeps the per-patch
+// front / back kernels above).  With a workgroup per patch the front and back launches on config 5's finest level spend their
+// second half on the ~1000 small stars of the level -- short chains of dependent phases, 3 workgroups per CU because the LDS
+// is sized for the largest star -- at a third of the bandwidth of the first half.  Here the unit of work is a run of
+// consecutive groups of one patch holding at most 256 row pairs of X / W and of B (8 macro-cell groups of a [P3]^3 star):
+// every workgroup is 256 threads with a few KB of LDS, a lane owns at most one row pair per phase, big and small stars
+// make the same kind of workgroup.  What needed the whole patch moves: the u buffer goes to global memory (cd.ubuf, in the
+// row-sorted order) and the Schur right-hand side is formed by the sigma workgroups themselves (each of the <= 3 per patch
+// forms all of it, in the same fixed order: bitwise the same), which also stage the skeleton part of the result.
+// the first COND_U columns of a row pair, requested early (before a barrier the loads do not depend on)
+template <bool NT>
+__device__ __forceinline__ void cond_row2_prefetch(const double* __restrict__ M, int ld, int kn, big_d2 (&a)[COND_U]) {
+#pragma unroll
+  for (int u = 0; u < COND_U; ++u) {
+    const big_d2* q = reinterpret_cast<const big_d2*>(M + (int64_t)u * ld);
+    const big_d2 z = {0.0, 0.0};
+    a[u] = (u < kn) ? (NT ? __builtin_nontemporal_load(q) : *q) : z;
+  }
+}
+// ... and the product continued from them
+template <bool NT>
+__device__ __forceinline__ void cond_row2_finish(const double* __restrict__ M, int ld, int kn, const double* __restrict__ v,
+                                                 const big_d2 (&a)[COND_U], double& acc0, double& acc1) {
+#pragma unroll
+  for (int u = 0; u < COND_U; ++u) {
+    const double vk = (u < kn) ? v[u] : 0.0;
+    acc0 = __builtin_fma(a[u].x, vk, acc0);
+    acc1 = __builtin_fma(a[u].y, vk, acc1);
+  }
+  const int rest = kn > COND_U ? kn - COND_U : 0;
+  cond_row2_dot<NT, COND_U>(M + (int64_t)COND_U * ld, ld, rest, v + COND_U, acc0, acc1);
+}
+
+template <bool NT>
+__global__ __launch_bounds__(256) void cond_gfront_kernel(int64_t k0, CondDev cd, const double* __restrict__ x) {
+  extern __shared__ double cond_dsmem[];
+  const CondChunk c = cd.gc[k0 + blockIdx.x];
+  double* xs = cond_dsmem;                           // c.ne
+  double* ts = xs + c.ne;                            // c.ne
+  const int tid = threadIdx.x;
+  const bool xact = c.xq0 + tid < c.xq1, bact = c.bq0 + tid < c.bq1;
+  // one descriptor per lane and phase, requested together with the gather of x
+  const CondXPair xd = cd.xpd[xact ? c.xq0 + tid : c.xq0];
+  const CondBPair bd = cd.bpd[bact ? c.bq0 + tid : c.bq0];
+  for (int i = tid; i < c.ne; i += 256) xs[i] = x[cd.dofs[c.off + c.e0 + i]];
+  // the first columns of both products do not depend on anything computed here
+  big_d2 xa[COND_U], ba[COND_U];
+  cond_row2_prefetch<NT>(cd.mat + xd.xoff, xd.ld, xact ? xd.m : 0, xa);
+  cond_row2_prefetch<NT>(cd.mat + bd.boff, bd.ld, bact ? bd.m : 0, ba);
+  __syncthreads();
+  double* tmp = cd.tmp + c.off;
+  {
+    double t0 = 0.0, t1 = 0.0;
+    cond_row2_finish<NT>(cd.mat + xd.xoff, xd.ld, xact ? xd.m : 0, xs + (xd.o - c.e0), xa, t0, t1);
+    if (xact) {
+      const int e = xd.o + xd.i;
+      ts[e - c.e0] = t0;
+      tmp[e] = t0;
+      if (xd.sl1 >= 0) {
+        ts[e - c.e0 + 1] = t1;
+        tmp[e + 1] = t1;
+      }
+    }
+  }
+  __syncthreads();
+  {
+    double v0 = 0.0, v1 = 0.0;
+    cond_row2_finish<NT>(cd.mat + bd.boff, bd.ld, bact ? bd.m : 0, ts + (bd.o - c.e0), ba, v0, v1);
+    if (bact) {
+      cd.ubuf[c.ubase + bd.d0] = v0;
+      if (bd.d1 >= 0) cd.ubuf[c.ubase + bd.d1] = v1;
+    }
+  }
+}
+
+// y_S = inv(Sigma) rhs for a chunk of <= 256 rows, the right-hand side formed here: rhs_i = x_i - sum of the row's
+// contributions in cd.ubuf (adjacent, ascending: the order of the other forms of the apply); the chunk's rows of y_S go to
+// cd.tmp AND to their staging slots.
+template <bool NT>
+__global__ __launch_bounds__(256) void cond_gsigma_kernel(int64_t c0, CondDev cd, const int64_t* __restrict__ patch_ptr,
+                                                          const int64_t* __restrict__ stage_ptr, const double* __restrict__ x,
+                                                          double* __restrict__ stage) {
+  extern __shared__ double cond_dsmem[];
+  const int64_t c = c0 + blockIdx.x;
+  const int64_t p = cd.ch_patch[c];
+  const int r0 = cd.ch_row[c];
+  const int64_t off = patch_ptr[p];
+  const int n = (int)(patch_ptr[p + 1] - off);
+  const int nI = cd.p_nI[p];
+  const int s = n - nI;
+  const int ld = (s + 1) & ~1;
+  const int64_t srow0 = cd.sptr[p];
+  const int32_t qb = cd.s_uptr[srow0];
+  const double* ub = cd.ubuf + cd.uptr[p];
+  double* rhs = cond_dsmem;                          // s
+  double* ys = rhs + ld;                             // the chunk's rows (<= 256)
+  for (int i = threadIdx.x; i < s; i += 256) {
+    double acc = x[cd.dofs[off + nI + i]];
+    const int32_t qe = cd.s_uptr[srow0 + i + 1] - qb;
+    for (int32_t q = cd.s_uptr[srow0 + i] - qb; q < qe; ++q) acc -= ub[q];
+    rhs[i] = acc;
+  }
+  __syncthreads();
+  const int r1 = min(ld, r0 + COND_SIGMA_ROWS);
+  const int share = (((r1 - r0) + 3) / 4 + 15) & ~15;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int a = r0 + wave * share, b = min(r1, a + share);
+  // (big_rows indexes its output by the row number and skips the pad row r = s: the chunk's slice, shifted)
+  if (a < b) big_rows<NT>(cd.sinv + cd.sinv_ptr[p], s, ld, a, b, rhs, lane, ys - r0);
+  __syncthreads();
+  double* out = stage + stage_ptr[p];
+  double* tmp = cd.tmp + off + nI;
+  for (int i = r0 + threadIdx.x; i < min(r1, s); i += 256) {
+    const double v = ys[i - r0];
+    tmp[i] = v;
+    out[cd.slot[off + nI + i]] = v;
+  }
+}
+
+template <bool NT>
+__global__ __launch_bounds__(256) void cond_gback_kernel(int64_t k0, CondDev cd, double* __restrict__ stage) {
+  extern __shared__ double cond_dsmem[];
+  const CondChunk c = cd.gc[k0 + blockIdx.x];
+  const int tid = threadIdx.x;
+  const bool act = c.xq0 + tid < c.xq1;
+  const CondXPair xd = cd.xpd[act ? c.xq0 + tid : c.xq0];
+  const double* tmp = cd.tmp + c.off;
+  // y_S[S_g] of the chunk's groups (adjacent in sidx and in the u layout)
+  const int32_t* si = cd.sidx + c.sidx0;
+  double* yg = cond_dsmem;                           // c.nu
+  for (int q = tid; q < c.nu; q += 256) yg[q] = tmp[c.nI + si[q]];
+  const int e = xd.o + xd.i;
+  const double tg0 = act ? tmp[e] : 0.0, tg1 = (act && xd.sl1 >= 0) ? tmp[e + 1] : 0.0;
+  big_d2 wa[COND_U];
+  cond_row2_prefetch<NT>(cd.mat + xd.woff, xd.ld, act ? xd.sc : 0, wa);
+  __syncthreads();
+  double y0 = 0.0, y1 = 0.0;
+  cond_row2_finish<NT>(cd.mat + xd.woff, xd.ld, act ? xd.sc : 0, yg + (xd.uo - c.u0), wa, y0, y1);
+  if (act) {
+    double* out = stage + c.stage_off;
+    out[xd.sl0] = tg0 - y0;
+    if (xd.sl1 >= 0) out[xd.sl1] = tg1 - y1;
+  }
+}
+
 // out (n x n, row-major) = the leading n x n part of the padded N x N scratch
 __global__ void dense_unpad_kernel(int64_t n, int64_t N, const double* __restrict__ S, double* __restrict__ out) {
   for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n * n; e += (int64_t)gridDim.x * blockDim.x)
@@ -1487,7 +1632,44 @@ int launch_cond_apply_range(alfi_level* L, int64_t p0, int64_t p1, const double*
   dim3 grid((unsigned)(p1 - p0));
   static const bool allow_order = !(getenv("ALFI_COND_ORDER") && atoi(getenv("ALFI_COND_ORDER")) == 0);
   const int ordered = allow_order && p0 == 0 && p1 == L->npatch && L->cd.order ? 1 : 0;
-  static const bool split = !(getenv("ALFI_COND_SPLIT") && atoi(getenv("ALFI_COND_SPLIT")) == 0);
+  static const int split_mode = getenv("ALFI_COND_SPLIT") ? atoi(getenv("ALFI_COND_SPLIT")) : 1;
+  static const bool split = split_mode != 0;
+  // ALFI_COND_SPLIT: 1 (default) the group products by chunks of groups where a launch has fewer than 1024 patches (config 5,
+  // level 1, 303 stars: front + back 48 -> 39 us) and by patch otherwise (finest level, 1765 stars: 326 against 338 us -- the
+  // descriptors of the chunked form are 8 % more bytes, and both forms run at 5.6-5.8 TB/s of actual HBM traffic); 2 always by
+  // patch; 3 always by chunks; 0 the one-launch kernel
+  if ((split_mode == 3 || (split_mode == 1 && p1 - p0 < 1024)) && L->cd.tmp && L->cd.ubuf) {
+    // group products by chunks of groups, the Schur right-hand side formed by the sigma workgroups
+    static const bool gnt = getenv("ALFI_COND_GROUP_NT") && atoi(getenv("ALFI_COND_GROUP_NT")) != 0;
+    const int64_t k0 = L->h_cond_gcptr[p0], k1 = L->h_cond_gcptr[p1];
+    const int64_t c0 = L->h_cond_chptr[p0], c1 = L->h_cond_chptr[p1];
+    const size_t lds_f = (size_t)L->cond_lds_gfront, lds_b = (size_t)L->cond_lds_gback;
+    const size_t lds_s = (size_t)(L->cond_max_s + 2 + 256) * sizeof(double);
+    if (k1 > k0) {
+      if (gnt)
+        hipLaunchKernelGGL((cond_gfront_kernel<true>), dim3((unsigned)(k1 - k0)), dim3(256), lds_f, ctx->stream, k0, L->cd, x);
+      else
+        hipLaunchKernelGGL((cond_gfront_kernel<false>), dim3((unsigned)(k1 - k0)), dim3(256), lds_f, ctx->stream, k0, L->cd, x);
+    }
+    if (c1 > c0) {
+      if (nt)
+        hipLaunchKernelGGL((cond_gsigma_kernel<true>), dim3((unsigned)(c1 - c0)), dim3(256), lds_s, ctx->stream, c0, L->cd,
+                           L->patch_ptr, L->stage_ptr, x, L->stage);
+      else
+        hipLaunchKernelGGL((cond_gsigma_kernel<false>), dim3((unsigned)(c1 - c0)), dim3(256), lds_s, ctx->stream, c0, L->cd,
+                           L->patch_ptr, L->stage_ptr, x, L->stage);
+    }
+    if (k1 > k0) {
+      if (gnt)
+        hipLaunchKernelGGL((cond_gback_kernel<true>), dim3((unsigned)(k1 - k0)), dim3(256), lds_b, ctx->stream, k0, L->cd,
+                           L->stage);
+      else
+        hipLaunchKernelGGL((cond_gback_kernel<false>), dim3((unsigned)(k1 - k0)), dim3(256), lds_b, ctx->stream, k0, L->cd,
+                           L->stage);
+    }
+    ALFI_HIP_CHECK(ctx, hipGetLastError());
+    return 0;
+  }
   if (split && L->cd.tmp) {
     const size_t lds_f = (size_t)L->cond_lds_front, lds_s = (size_t)(L->cond_max_s + 2) * sizeof(double);
     const size_t lds_b = (size_t)L->cond_lds_back;

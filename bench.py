@@ -95,7 +95,10 @@ def build_problem(cfg, verbose, lazy=False):
 def apply_kernel_name(L):
     from alfi_amd.hip import condense_patches
     if condense_patches(L):
-        if os.environ.get("ALFI_COND_SPLIT", "1") != "0":      # one apply = three launches (kernels_bigpatch.hip)
+        mode = os.environ.get("ALFI_COND_SPLIT", "1")           # one apply = three launches (kernels_bigpatch.hip)
+        if mode == "3":
+            return "cond_gfront_kernel + cond_gsigma_kernel + cond_gback_kernel"
+        if mode != "0":   # (default 1: these on launches of >= 1024 patches, the chunked cond_g* kernels on smaller ones)
             return "cond_front_kernel + cond_sigma_kernel + cond_back_kernel"
         return "cond_apply_kernel"
     return "big_apply_kernel" if np.diff(L.patch_ptr).max() > 160 else "patch_apply_kernel"

@@ -44,7 +44,7 @@ if [ "$PART" = configs ]; then
 fi
 if [ "$PART" = cfg5 ]; then
   # condensed apply as three launches: same-box A/B against the one-launch kernel, the bench line, a kernel trace, HBM traffic
-  for V in 0 1 0 1; do
+  for V in 0 3 1 0 3 1; do
     ALFI_COND_SPLIT=$V python bench.py --config cfg5 --steps 10 --warmup 3 --no-cpu-baseline > $O/ab_cfg5_split$V.json 2> $O/ab_cfg5_split$V.err
     python - $O/ab_cfg5_split$V.json $V <<'PY' | tee -a $O/r03_cond_apply_ab_cfg5.txt
 import json, sys
@@ -65,12 +65,12 @@ import glob, sys, pandas as pd
 t = pd.read_csv(glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True)[0])
 t["dur_us"] = (t["End_Timestamp"] - t["Start_Timestamp"]) / 1e3
 t["name"] = t["Kernel_Name"].str.replace(r"\(.*", "", regex=True).str.replace("void ", "")
-c = t[t["name"].str.contains("cond_front|cond_back|cond_sigma|cond_apply")]
+c = t[t["name"].str.contains("cond_front|cond_back|cond_sigma|cond_apply|cond_gfront|cond_gback|cond_gsigma")]
 print("config 5, condensed apply: launches by kernel and grid (the larger grid of each kernel = the finest level), durations in us")
 print(c.groupby(["name", "Grid_Size_X", "VGPR_Count"])["dur_us"].agg(["count", "mean", "min", "max"]).round(1).to_string())
 PY
   cat $O/r03_cond_apply_trace_cfg5.txt
-  python scripts/pmc_summary.py $O/pmc5_fetch $O/pmc5_write "void cond_front_kernel+void cond_sigma_kernel+void cond_back_kernel" $O/pmc_patch_apply_cfg5.json "r03 end of round ($STAMP) cond_front + cond_sigma + cond_back (one apply of the condensed macro-star factors = three launches; counters of the three added), the 40 applies of the first V-cycle" 40
+  python scripts/pmc_summary.py $O/pmc5_fetch $O/pmc5_write "void cond_front_kernel+void cond_sigma_kernel+void cond_back_kernel|void cond_gfront_kernel+void cond_gsigma_kernel+void cond_gback_kernel" $O/pmc_patch_apply_cfg5.json "r03 end of round ($STAMP) one apply of the condensed macro-star factors = three launches, counters of the three added: cond_front + cond_sigma + cond_back on the finest level, cond_gfront + cond_gsigma + cond_gback on level 1; all applies of the run"
   rm -rf $O/prof_cfg5 $O/pmc5_fetch $O/pmc5_write
   head -c 400 $O/r03_bench_cfg5.json; echo
 fi

@@ -1,13 +1,16 @@
 #!/bin/bash
+# HBM traffic of the three launches of the condensed apply, kernel by kernel (config 5)
 cd "$GRAFT_REPO_ROOT" || exit 1
 export TMPDIR=/tmp
 O=$GRAFT_REPO_ROOT/gpurun_out/r3p
 mkdir -p $O
-timeout 1800 python -m pytest tests/test_gpu_assemble.py tests/test_gpu_newton.py -x -q -m gpu > $O/pytest.log 2>&1
-echo "pytest exit $?" >> $O/pytest.log; tail -12 $O/pytest.log | cut -c1-300
-ALFI_SUPG_SCRATCH_MB=1 timeout 1800 python -m pytest tests/test_gpu_assemble.py -x -q -m gpu -k supg > $O/pytest_batches.log 2>&1
-echo "pytest exit $?" >> $O/pytest_batches.log; tail -4 $O/pytest_batches.log | cut -c1-300
-python scripts/newton_step_time.py cfg4s --supg 0.05 > $O/newton_cfg4s_supg_device.txt 2>&1
-python scripts/newton_step_time.py cfg4s --supg 0.05 --host > $O/newton_cfg4s_supg_host.txt 2>&1
-python scripts/newton_step_time.py cfg4 --supg 0.05 --re 10 100 1000 > $O/newton_cfg4_supg_device.txt 2>&1
-for f in $O/newton_*.txt; do echo "== $f"; grep -v amdgpu $f | tail -n 4; done
+cd /tmp
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/f -- python3 $GRAFT_REPO_ROOT/bench.py --config cfg5 --no-cpu-baseline --steps 1 --warmup 0 > $O/f.json 2> $O/f.err
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/w -- python3 $GRAFT_REPO_ROOT/bench.py --config cfg5 --no-cpu-baseline --steps 1 --warmup 0 > $O/w.json 2> $O/w.err
+cd $GRAFT_REPO_ROOT
+for K in cond_gfront_kernel cond_gsigma_kernel cond_gback_kernel; do
+  python scripts/pmc_summary.py $O/f $O/w "void $K" $O/pmc_$K.json "$K finest level" 0 max | python -c "
+import json,sys
+d=json.loads(sys.stdin.read()); print('$K', 'fetch GB', round(d['fetch_bytes_per_launch']/1e9,4), 'write GB', round(d['write_bytes_per_launch']/1e9,4), 'launches', d['launches'])"
+done
+rm -rf $O/f $O/w

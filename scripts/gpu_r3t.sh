@@ -20,7 +20,7 @@ f = glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True)[0]
 t = pd.read_csv(f)
 t["dur_us"] = (t["End_Timestamp"] - t["Start_Timestamp"]) / 1e3
 t["name"] = t["Kernel_Name"].str.replace(r"\(.*", "", regex=True).str.replace("void ", "")
-c = t[t["name"].str.contains("cond_front|cond_back|cond_sigma|cond_apply")]
+c = t[t["name"].str.contains("cond_front|cond_back|cond_sigma|cond_apply|cond_g")]
 g = c.groupby(["name", "Grid_Size_X", "VGPR_Count"])["dur_us"].agg(["count", "mean", "min", "max"]).round(1)
 print(g.to_string())
 d = json.load(open(sys.argv[2]))

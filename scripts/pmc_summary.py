@@ -26,6 +26,10 @@ def per_kernel(d, counter, prefix, first=None, grids=None, skip=0):
     t = pd.read_csv(f)
     # several kernels that together make one operation ("void a+void b+void c": launched in turn, the same number of
     # times): the counters of the i-th launch of each are added
+    # "a+b+c|d+e+f": two such operations (the launches of the first, then of the second): one list of per-operation sums
+    if "|" in prefix:
+        import numpy as np
+        return np.concatenate([per_kernel(d, counter, q, None, grids, 0) for q in prefix.split("|")])[skip:][:first]
     if "+" in prefix:
         parts = [per_kernel(d, counter, q, first, grids, skip) for q in prefix.split("+")]
         m = min(len(q) for q in parts)

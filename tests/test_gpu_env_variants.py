@@ -24,8 +24,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
                                      # condensed macro-star factors: the one-launch apply of rounds 1-2, and the settings of
                                      # the three-launch one that the defaults do not take on this hierarchy
                                      ({"ALFI_COND_SPLIT": "0"}, 1e-5), ({"ALFI_COND_SPLIT": "0", "ALFI_COND_BALANCE": "0"}, 1e-5),
-                                     ({"ALFI_COND_WAVES": "8", "ALFI_COND_GROUP_NT": "1"}, 1e-5),
-                                     ({"ALFI_COND_WAVES": "8", "ALFI_COND_RU": "16"}, 1e-5),
+                                     ({"ALFI_COND_GROUP_NT": "1"}, 1e-5),
+                                     # three launches: a workgroup per PATCH in the group products (2), per chunk of groups
+                                     # (3); the default picks by the number of patches of the launch
+                                     ({"ALFI_COND_SPLIT": "2"}, 1e-5), ({"ALFI_COND_SPLIT": "3"}, 1e-5),
+                                     ({"ALFI_COND_SPLIT": "3", "ALFI_COND_GROUP_NT": "1"}, 1e-5),
+                                     ({"ALFI_COND_SPLIT": "2", "ALFI_COND_WAVES": "8", "ALFI_COND_GROUP_NT": "1"}, 1e-5),
+                                     ({"ALFI_COND_SPLIT": "2", "ALFI_COND_WAVES": "8", "ALFI_COND_RU": "16"}, 1e-5),
                                      # EVERY condensed patch flagged by the residual probe: Schur complements formed again
                                      # and re-inverted in place by the pivoted LU (kernels_check.hip: cond_repair)
                                      ({"ALFI_PATCH_CHECK_TOL": "1e-14", "ALFI_PATCH_CHECK_FAIL": "1e-6"}, 1e-5)])
