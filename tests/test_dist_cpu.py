@@ -156,7 +156,7 @@ def _saddle_worker(rank, world, port, case, q):
         mg = DistOracle(llev, ltr, lmin, k, comm, robust=False)
         B, vol = build_pressure_coupling(L)
         p = llev[-1].part
-        cells, Bloc, md = D.localize_pressure(B, vol, L.V.cell_nodes, p, L.bs)
+        cells, Bloc, md, _ = D.localize_pressure(B, vol, L.V.cell_nodes, p, L.bs)
         b = np.random.default_rng(0).standard_normal(L.n)
         b[L.bc_dofs] = 0.0
         rhs = np.concatenate([b[p.own_dofs()], np.zeros(len(cells))])
@@ -281,3 +281,30 @@ def test_overlap_decision_is_collective():
     assert not overlap_decision(splits, 3, False, True, 0) and not overlap_decision(splits, 3, True, False, 0)
     # a rank with an empty share (single-owner level forced distributed) does not veto
     assert overlap_decision(np.array([0, 1000, 1000]), 2, True, True, 2000)
+
+
+def test_pressure_rows_of_the_dg_pair_are_owned_cell_by_cell():
+    """localize_pressure for the Scott-Vogelius pair: npc pressure dofs per cell (rows c * npc .. of B) go with the cell to the
+    owner of its lowest-numbered node; over the ranks every pressure row is owned exactly once, the local B reproduces the
+    global rows, and the selected block of the mass inverse is that of the owned cells."""
+    sys.path.insert(0, ROOT)
+    import scipy.sparse as sp
+    from alfi_amd import dist as D
+    from alfi_amd.sv import build_sv_pressure_coupling
+    lv, tr, _, min_dofs = _hier("2d-SV")
+    L = lv[-1]
+    B, M, Minv = build_sv_pressure_coupling(L)
+    world = 3
+    splits = D.choose_splits(lv, world, min_dofs)
+    seen = np.zeros(B.shape[0], dtype=int)
+    u = np.random.default_rng(1).standard_normal(L.n)
+    for r in range(world):
+        part = D.build_parts(lv, tr, splits, r, None)[-1]
+        prows, Bloc, md, Mi = D.localize_pressure(B, None, L.V.cell_nodes, part, L.bs, Minv)
+        assert md is None and len(prows) % 3 == 0                    # P1dg in 2-D: 3 dofs per cell
+        seen[prows] += 1
+        loc = np.concatenate([part.own_dofs(), (part.ghosts[:, None] * L.bs + np.arange(L.bs)).ravel()])
+        assert np.allclose(Bloc @ u[loc], (B @ u)[prows])
+        assert abs(Mi - sp.csr_matrix(Minv)[prows][:, prows]).max() == 0.0
+        assert np.allclose((Mi @ (sp.csr_matrix(M)[prows][:, prows])).toarray(), np.eye(len(prows)), atol=1e-10)
+    assert (seen == 1).all()
