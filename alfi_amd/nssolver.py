@@ -86,8 +86,8 @@ class HipNavierStokesSolver(object):
         self.nu = self.char_L * self.char_U
         self.Minv = None
         if self.sv:
-            self.B, M, self.Minv = build_sv_pressure_coupling(L)             # Dirichlet columns zeroed: the Jacobian's B
-            self.B_raw, _, _ = build_sv_pressure_coupling(L, zero_bc_columns=False)
+            # B with the Dirichlet columns zeroed (the Jacobian's) and with all columns (the residual's), one pass
+            self.B, self.B_raw, M, self.Minv = build_sv_pressure_coupling(L, both=True)
             self.vol = np.asarray(M.sum(axis=1)).ravel()                    # int psi_j: weights of the pressure integral
         else:
             self.B, self.vol = build_pressure_coupling(L)                     # Dirichlet columns zeroed: the Jacobian's B
