@@ -1191,7 +1191,9 @@ int alfi_patches_set_groups(alfi_level* L, const int32_t* group) {
     ALFI_CHECK(cond_upload(L, &cd.bp_ptr, bp_ptr));
     ALFI_CHECK(cond_upload(L, &cd.bp_grp, bp_grp));
     ALFI_CHECK(cond_upload(L, &cd.g_bp, g_bp));
-    {
+    // (only where the chunked form is used: levels with fewer than 1024 patches, or every level with ALFI_COND_SPLIT=3 -- the
+    // descriptors are 80 KB per large macro star)
+    if (npatch < 1024 || (getenv("ALFI_COND_SPLIT") && atoi(getenv("ALFI_COND_SPLIT")) == 3)) {
       // chunks of consecutive groups: at most 256 row pairs of X / W and of B each, with the descriptors of the chunks and of
       // every row pair (CondChunk / CondXPair / CondBPair, common.h)
       std::vector<CondChunk> gc;
