@@ -13,6 +13,9 @@ What is derived, and from which lines of the reference (/root/reference/alfi):
 * the velocity-block form ``nu (2 sym grad u, grad v) + gamma (cell_avg(div u), div v)`` (solver.py:565-568,
   transfer.py:319-324): one element matrix on a simplex with rational vertex coordinates, integrated exactly with
   int_K l^alpha = |K| d! alpha! / (|alpha| + d)!.
+* the Scott-Vogelius pair (solver.py:612-630): the velocity form with the FULL grad-div term, the discrete divergence against
+  the discontinuous P_{k-1} pressure basis and the pressure mass matrix of DGMassInv (solver.py:15-38), exactly on one simplex
+  (``sv_matrices``), with the identity gamma B^T M^-1 B = gamma (div u, div v) checked in rationals by the consumer.
 * nodal interpolation (firedrake.prolong [3P], transfer.py:284-286): row of a fine node = coarse basis at that node.  For
   2-D P2 the values are {1, 3/8, 3/4, -1/8, 1/2, 1/4, 0} with at most 6 non-zeros per row.
 
@@ -95,7 +98,7 @@ def element_nodes(dim, name):
     nv = dim + 1
     unit = lambda i: tuple(Fraction(int(j == i)) for j in range(nv))
     nodes = [unit(i) for i in range(nv)]
-    degree = {"P1+FB": 1, "P2": 2, "P2+FB": 2, "P3": 3}[name]
+    degree = {"P1": 1, "P1+FB": 1, "P2": 2, "P2+FB": 2, "P3": 3}[name]
     for a, b in itertools.combinations(range(nv), 2):
         for s in range(1, degree):
             t = Fraction(s, degree)
@@ -113,7 +116,7 @@ def element_span(dim, name):
     """A spanning set of the scalar space: homogeneous monomials of degree k in the barycentric coordinates (they span P_k on
     the simplex because sum(l) = 1) plus, for '+FB', the facet bubbles 27 l_j l_k l_l of the four faces."""
     nv = dim + 1
-    degree = {"P1+FB": 1, "P2": 2, "P2+FB": 2, "P3": 3}[name]
+    degree = {"P1": 1, "P1+FB": 1, "P2": 2, "P2+FB": 2, "P3": 3}[name]
     span = []
     for combo in itertools.combinations_with_replacement(range(nv), degree):
         e = [0] * nv
@@ -187,6 +190,38 @@ def element_matrix(dim, name, vertices, nu, gamma):
                     v = nu * vol * ((gg if c == d else 0) + I[d][c]) + gamma * vol * avg[a][c] * avg[b][d]
                     A[a][c][b][d] = v
     return nodes, A
+
+
+def sv_matrices(dim, name, pname, vertices, nu, gamma):
+    """Scott-Vogelius pair [name]^dim - pname^dg on the simplex ``vertices`` (solver.py:612-630), exactly:
+    A[a][c][b][d] = nu (2 sym grad u, grad v) + gamma (div u, div v)   (the FULL grad-div term, solver.py:616),
+    B[j][a][x] = - int psi_j d_x phi_a   (``- div(u) * q * dx``, solver.py:619),   M[j][l] = int psi_j psi_l   (DGMassInv,
+    solver.py:15-38).  Returns (velocity nodes, pressure nodes, A, B, M); div [P_k]^d lies in P_{k-1}, so
+    gamma B^T M^-1 B reproduces the grad-div part of A exactly (checked by the consumer in rationals)."""
+    nodes, basis = nodal_basis(dim, name)
+    pnodes, pbasis = nodal_basis(dim, pname)
+    grads, vol = barycentric_gradients(vertices)
+    nu, gamma = Fraction(nu), Fraction(gamma)
+    n, m = len(nodes), len(pnodes)
+    dphi = [[None] * dim for _ in range(n)]
+    for a in range(n):
+        dl = [p_diff(basis[a], i) for i in range(dim + 1)]
+        for x in range(dim):
+            acc = {}
+            for i in range(dim + 1):
+                acc = p_add(acc, p_scale(dl[i], grads[i][x]))
+            dphi[a][x] = acc
+    A = [[[[Fraction(0) for _ in range(dim)] for _ in range(n)] for _ in range(dim)] for _ in range(n)]
+    for a in range(n):
+        for b in range(n):
+            I = [[p_average(p_mul(dphi[a][x], dphi[b][y])) for y in range(dim)] for x in range(dim)]
+            gg = sum(I[x][x] for x in range(dim))
+            for c in range(dim):
+                for d in range(dim):
+                    A[a][c][b][d] = nu * vol * ((gg if c == d else 0) + I[d][c]) + gamma * vol * I[c][d]
+    B = [[[-vol * p_average(p_mul(pbasis[j], dphi[a][x])) for x in range(dim)] for a in range(n)] for j in range(m)]
+    M = [[vol * p_average(p_mul(pbasis[j], pbasis[l])) for l in range(m)] for j in range(m)]
+    return nodes, pnodes, A, B, M
 
 
 def interpolation_row(dim, name, lam):

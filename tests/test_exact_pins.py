@@ -130,3 +130,61 @@ def test_nodal_prolongation_rows_are_the_coarse_basis_at_the_fine_nodes(dim, nam
         assert values == {Fraction(1), Fraction(3, 8), Fraction(3, 4), Fraction(-1, 8), Fraction(1, 2), Fraction(1, 4),
                           Fraction(0)}
         assert (np.abs(P) > 1e-14).sum(axis=1).max() <= 6
+
+
+@pytest.mark.parametrize("dim,name,pname,args", [(2, "P2", "P1", (2, 2, False)), (3, "P3", "P2", (3, 3, False))])
+def test_scott_vogelius_matrices_are_exact(dim, name, pname, args):
+    """The Scott-Vogelius ingredients of config 5 on one simplex against exact integration: the velocity block with the FULL
+    grad-div term (solver.py:616; the product's assembler with gamma_full), the discrete divergence against the discontinuous
+    P_{k-1} basis and the DG mass matrix (sv.build_sv_pressure_coupling; solver.py:619, 15-38).  And, in rationals, the
+    identity behind the augmented Lagrangian of the pair: gamma B^T M^-1 B IS gamma (div u, div v)."""
+    import scipy.sparse as sp
+    import sympy
+    from alfi_amd.sv import build_sv_pressure_coupling
+    nu, gamma = Fraction(3, 7), Fraction(1250, 3)
+    mesh, V = _one_cell_space(dim, args)
+    el, d, n = V.element, V.dim, V.element.nloc
+    nodes, pnodes, A, B, M = X.sv_matrices(dim, name, pname, SIMPLEX[dim], nu, gamma)
+    perm = _match(el.node_bary, nodes)
+    cn = V.cell_nodes[0]
+    exact = np.zeros((n * d, n * d))
+    for a in range(n):
+        for b in range(n):
+            for c in range(d):
+                for e in range(d):
+                    exact[cn[a] * d + c, cn[b] * d + e] = float(A[perm[a]][c][perm[b]][e])
+    rowptr, colidx = _hostlib.node_graph(V.cell_nodes, V.num_nodes)
+    g, vol = mesh.cell_geometry()
+    vals = _hostlib.assemble_bsr(V.cell_nodes, g, vol, el.reference_tensors(), d, rowptr, colidx, nu=float(nu), gamma=0.0,
+                                 gamma_full=float(gamma))
+    prod = sp.bsr_matrix((vals, colidx, rowptr), shape=(n * d, n * d)).toarray()
+    assert np.abs(prod - exact).max() < 1e-12 * np.abs(exact).max()
+    # pressure side: match the product's pressure nodes by position as well
+    class _L(object):
+        pass
+    L = _L()
+    L.V = V
+    Bp, Mp, Mip = build_sv_pressure_coupling(L, zero_bc_columns=False)
+    pel = NodalElement(dim, args[1] - 1, False)
+    pperm = _match(pel.node_bary, pnodes)
+    m = len(pnodes)
+    Bex = np.zeros((m, n * d))
+    for j in range(m):
+        for a in range(n):
+            for x in range(d):
+                Bex[j, cn[a] * d + x] = float(B[pperm[j]][perm[a]][x])
+    Mex = np.array([[float(M[pperm[j]][pperm[l]]) for l in range(m)] for j in range(m)])
+    assert np.abs(Bp.toarray() - Bex).max() < 1e-12 * np.abs(Bex).max()
+    assert np.abs(Mp.toarray() - Mex).max() < 1e-13 * np.abs(Mex).max()
+    assert np.abs(Mip.toarray() @ Mex - np.eye(m)).max() < 1e-10
+    # gamma B^T M^-1 B == the grad-div part of A, exactly
+    Bm = sympy.Matrix(m, n * dim, lambda j, q: sympy.Rational(B[j][q // dim][q % dim].numerator, B[j][q // dim][q % dim].denominator))
+    Mm = sympy.Matrix(m, m, lambda j, l: sympy.Rational(M[j][l].numerator, M[j][l].denominator))
+    G = Bm.T * Mm.inv() * Bm * sympy.Rational(gamma.numerator, gamma.denominator)
+    _, _, A0, _, _ = X.sv_matrices(dim, name, pname, SIMPLEX[dim], nu, 0)
+    for a in range(0, n, 3):
+        for b in range(n):
+            for c in range(dim):
+                for e in range(dim):
+                    diff = A[a][c][b][e] - A0[a][c][b][e]
+                    assert G[a * dim + c, b * dim + e] == sympy.Rational(diff.numerator, diff.denominator)
