@@ -33,6 +33,10 @@ def test_sv_generator_against_quadrature_and_polynomials():
         return np.stack([X[:, 0] ** 2 - X[:, 1], X[:, 0] * X[:, 1] + 1.0], axis=1).ravel()
     P = T.P.to_scipy()
     assert np.abs(P @ f(lv[0].V.node_coords) - f(L.V.node_coords)).max() < 1e-13
+    # ... and inject on the non-nested levels (point evaluation of the fine field at the coarse nodes, solver.py:641-644)
+    J = T.inject_matrix
+    assert np.abs(J @ f(L.V.node_coords).reshape(-1, 2) - f(lv[0].V.node_coords).reshape(-1, 2)).max() < 1e-13
+    assert np.abs(np.asarray(J.sum(axis=1)).ravel() - 1.0).max() < 1e-13       # a partition of unity per coarse node
     # robust prolongation keeps a divergence-free coarse field (discretely) divergence-free up to O(nu / gamma)
     ot = O.oracle_transfer(T, L, True).st
     uc = np.stack([lv[0].V.node_coords[:, 1] ** 2, lv[0].V.node_coords[:, 0] ** 2], axis=1).ravel()   # div = 0, in P2
@@ -58,6 +62,8 @@ def test_sv_p3_generator_3d():
         return np.stack([X[:, 0] ** 3 - X[:, 1] * X[:, 2], X[:, 0] * X[:, 1] ** 2 + 1.0, X[:, 2] ** 3 - X[:, 0]], axis=1).ravel()
     P = T.P.to_scipy()
     assert np.abs(P @ f(lv[0].V.node_coords) - f(L.V.node_coords)).max() < 1e-12
+    J = T.inject_matrix
+    assert np.abs(J @ f(L.V.node_coords).reshape(-1, 3) - f(lv[0].V.node_coords).reshape(-1, 3)).max() < 1e-12
     ot = O.oracle_transfer(T, L, True).st
     X = lv[0].V.node_coords
     uc = np.stack([X[:, 1] ** 3, X[:, 2] ** 3, X[:, 0] ** 3], axis=1).ravel()             # div = 0, in P3
