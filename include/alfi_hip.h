@@ -206,8 +206,11 @@ int alfi_patches_set_groups(alfi_level* lvl, const int32_t* group_host);
 int alfi_patches_factor_bytes(alfi_level* lvl, int64_t* bytes);
 /* Every alfi_patches_factor ends with a residual probe of every stored inverse, rho_p = || A_p (X_p e) - e ||_inf with a
  * fixed +-1 vector e, and re-inverts the patches with rho_p > 1e-6 (ALFI_PATCH_CHECK_TOL) -- or with a zero pivot -- by
- * Gauss-Jordan with partial pivoting (the reference factors with pivoted LAPACK / UMFPACK LU, solver.py:599-602, 655-659;
- * the fast kernels do not pivot).  ALFI_E_SINGULAR if a patch still fails afterwards.  This reports, for the last
+ * LU with partial pivoting and triangular sweeps (the reference factors with pivoted LAPACK / UMFPACK LU, solver.py:599-602,
+ * 655-659; the fast kernels do not pivot); for condensed factors the Schur complement of the flagged patch is formed again
+ * and re-inverted the same way, in place.  ALFI_E_SINGULAR if a patch still fails beyond ALFI_PATCH_CHECK_FAIL (1000 x the
+ * tolerance) afterwards.  The group matrices of a condensed factor are stored with even leading dimensions
+ * (alfi_patches_factor_bytes counts the padding).  This reports, for the last
  * factorisation: the worst residual of the fast inversion, how many patches were flagged and repaired, and the worst
  * residual after the repair (any pointer may be NULL; -1 = probe disabled with ALFI_PATCH_CHECK=0). */
 int alfi_patches_check(alfi_level* lvl, double* worst_residual, int64_t* flagged, int64_t* repaired, double* worst_after);
