@@ -127,9 +127,11 @@ def supg(V, U, nu, weight, magic, rowptr=None, colidx=None, vals=None, F=None, n
         raise RuntimeError("supg failed (%d): sparsity pattern does not cover the mesh" % rc)
 
 
-def contributors(cell_nodes, nnode, rowptr, colidx):
+def contributors(cell_nodes, nnode, rowptr, colidx, nindex=None, partial=False):
     """(cptr int64 (nnzb + 1), ccell int32, cba uint16): for every BSR block the (cell, b * nloc + a) pairs that contribute to
-    it, in a fixed order -- the gather lists of the device assembly (alfi_level_set_assembly)."""
+    it, in a fixed order -- the gather lists of the device assembly (alfi_level_set_assembly).  nindex: cell_nodes may index
+    up to nindex > nnode nodes (only the first nnode have operator rows); partial: pairs without a block are skipped (a
+    rank's ghost rows hold local columns only)."""
     cn = np.ascontiguousarray(cell_nodes, dtype=np.int32)
     ncell, nloc = cn.shape
     if nloc * nloc > 65535:
@@ -139,13 +141,16 @@ def contributors(cell_nodes, nnode, rowptr, colidx):
     cptr = np.zeros(colidx.shape[0] + 1, dtype=np.int64)
     fn = lib().alfi_host_contributors
     fn.restype = ctypes.c_int
-    rc = fn(ctypes.c_int64(ncell), ctypes.c_int(nloc), _p(cn), ctypes.c_int64(nnode), _p(rowptr), _p(colidx), _p(cptr), None, None)
+    tail = (ctypes.c_int64(int(nindex) if nindex is not None else int(nnode)), ctypes.c_int(1 if partial else 0))
+    rc = fn(ctypes.c_int64(ncell), ctypes.c_int(nloc), _p(cn), ctypes.c_int64(nnode), _p(rowptr), _p(colidx), _p(cptr), None, None,
+            *tail)
     if rc != 0:
         raise RuntimeError("contributors failed (%d): sparsity pattern does not cover the mesh" % rc)
-    assert cptr[-1] == ncell * nloc * nloc
+    assert partial or cptr[-1] == ncell * nloc * nloc
     ccell = np.empty(cptr[-1], dtype=np.int32)
     cba = np.empty(cptr[-1], dtype=np.uint16)
-    fn(ctypes.c_int64(ncell), ctypes.c_int(nloc), _p(cn), ctypes.c_int64(nnode), _p(rowptr), _p(colidx), _p(cptr), _p(ccell), _p(cba))
+    fn(ctypes.c_int64(ncell), ctypes.c_int(nloc), _p(cn), ctypes.c_int64(nnode), _p(rowptr), _p(colidx), _p(cptr), _p(ccell), _p(cba),
+       *tail)
     return cptr, ccell, cba
 
 

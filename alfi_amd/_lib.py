@@ -56,6 +56,9 @@ SIGNATURES = {
     "alfi_level_update_values": (ctypes.c_int, [vp, vp]),
     "alfi_level_set_assembly": (ctypes.c_int, [vp, ctypes.c_int64, ctypes.c_int, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "alfi_level_assemble": (ctypes.c_int, [vp, ctypes.c_double, ctypes.c_double, ctypes.c_double, vp, ctypes.c_int]),
+    "alfi_level_set_assembly_bc": (ctypes.c_int, [vp, vp, ctypes.c_int64]),
+    "alfi_level_assembly_state_size": (ctypes.c_int, [vp, ctypes.POINTER(ctypes.c_int64)]),
+    "alfi_level_assemble_mult": (ctypes.c_int, [vp, ctypes.c_double, ctypes.c_double, ctypes.c_double, vp, vp, vp]),
     "alfi_level_set_supg": (ctypes.c_int, [vp, ctypes.c_int, vp, vp, vp, vp, vp, vp]),
     "alfi_level_supg": (ctypes.c_int, [vp, ctypes.c_double, ctypes.c_double, ctypes.c_double, vp, ctypes.c_int, vp]),
     "alfi_level_apply_bc": (ctypes.c_int, [vp]),
@@ -117,7 +120,7 @@ SIGNATURES = {
 
 COMM_ID_BYTES = 128      # ALFI_COMM_ID_BYTES
 
-EVENTS = ["PATCH_APPLY", "PATCH_SCATTER", "PATCH_FACTOR", "MATMULT", "BLAS1", "PROLONG", "RESTRICT", "COARSE", "COMM", "KSP_TINY"]
+EVENTS = ["PATCH_APPLY", "PATCH_SCATTER", "PATCH_FACTOR", "MATMULT", "BLAS1", "PROLONG", "RESTRICT", "COARSE", "COMM"]
 
 _lib = None
 

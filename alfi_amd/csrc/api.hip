@@ -390,8 +390,8 @@ int alfi_ctx_set_comm(alfi_ctx* ctx, alfi_comm_fn fn, void* user, double* dred, 
   ctx->comm = fn;
   ctx->comm_user = user;
   ctx->dred = dred;
-  const char* e = getenv("ALFI_DIST_EXACT_NORM");   // 1: |w| by its own all-reduce, as PETSc's VecNorm (A/B, parity checks)
-  ctx->exact_norm = e && atoi(e) == 1;
+  const char* e = getenv("ALFI_DIST_EXACT_NORM");   // default: |w - V h| by its own all-reduce, as PETSc's VecNorm; 0: see comm.hip
+  ctx->exact_norm = !(e && atoi(e) == 0);
   return 0;
 }
 
@@ -623,6 +623,7 @@ int alfi_level_destroy(alfi_level* L) {
   dev_free(L->inv_ptr);
   dev_free(L->stage_ptr);
   dev_free(L->inv);
+  dev_free(L->inv_il);
   dev_free(L->stage);
   dev_free(L->dof_ptr);
   dev_free(L->dof_pos);
@@ -656,7 +657,7 @@ int alfi_level_update_values(alfi_level* L, const double* bvals) {
 
 static void free_assembly(AssemblyDev* S) {
   dev_free(S->cptr); dev_free(S->ccell); dev_free(S->cba); dev_free(S->cell_nodes); dev_free(S->grad); dev_free(S->vol);
-  dev_free(S->Ta); dev_free(S->Tb); dev_free(S->Kv); dev_free(S->Dv);
+  dev_free(S->Ta); dev_free(S->Tb); dev_free(S->Kv); dev_free(S->Dv); dev_free(S->scratch); dev_free(S->bc_all);
   dev_free(S->wq); dev_free(S->phi); dev_free(S->dphi); dev_free(S->d2phi); dev_free(S->hcell); dev_free(S->diag);
   *S = AssemblyDev();
 }
@@ -669,17 +670,29 @@ int alfi_level_set_assembly(alfi_level* L, int64_t ncell, int nloc, const int32_
     return alfi_set_error(ctx, ALFI_E_ARG, "NULL argument");
   if (ncell < 1 || nloc < 1 || nloc * nloc > 65535) return alfi_set_error(ctx, ALFI_E_ARG, "bad cell counts (%lld cells, %d nodes each)", (long long)ncell, nloc);
   if (!L->A.flat) return alfi_set_error(ctx, ALFI_E_STATE, "device assembly needs the lane-major operator layout (no empty block rows)");
-  if (L->has_halo) return alfi_set_error(ctx, ALFI_E_STATE, "device assembly is built for unpartitioned levels");
-  const int64_t nnzb = L->A.nnzb, nb = L->A.nbrows, npairs = ncell * nloc * nloc;
+  const int64_t nnzb = L->A.nnzb, nb = L->A.nbrows;
   const int d = L->bs, nv = d + 1;
-  if (cptr[0] != 0 || cptr[nnzb] != npairs)
-    return alfi_set_error(ctx, ALFI_E_ARG, "contributor lists hold %lld pairs, expected cells x nodes^2 = %lld", (long long)cptr[nnzb], (long long)npairs);
+  // Unpartitioned: the cells are the mesh, every (cell, a, b) pair contributes to a block.  Partitioned: the cells that touch
+  // a local node; their other nodes follow the local ones in the numbering of the state vector, and only the pairs with both
+  // nodes local contribute (the ghost rows of the local operator are restricted to local columns).
+  const bool part = L->has_halo;
+  const int64_t npairs = cptr[nnzb];
+  if (cptr[0] != 0 || (part ? npairs > ncell * nloc * nloc : npairs != ncell * nloc * nloc))
+    return alfi_set_error(ctx, ALFI_E_ARG, "contributor lists hold %lld pairs, expected %scells x nodes^2 = %lld", (long long)npairs,
+                          part ? "at most " : "", (long long)(ncell * nloc * nloc));
   for (int64_t k = 0; k < nnzb; ++k)
     if (cptr[k + 1] <= cptr[k]) return alfi_set_error(ctx, ALFI_E_ARG, "block %lld has no contributing cell", (long long)k);
   for (int64_t q = 0; q < npairs; ++q)
     if (ccell[q] < 0 || ccell[q] >= ncell || cba[q] >= nloc * nloc) return alfi_set_error(ctx, ALFI_E_ARG, "contributor %lld out of range", (long long)q);
-  for (int64_t i = 0; i < ncell * nloc; ++i)
-    if (cell_nodes[i] < 0 || cell_nodes[i] >= nb) return alfi_set_error(ctx, ALFI_E_ARG, "cell node out of range");
+  int64_t nstate = nb;
+  for (int64_t i = 0; i < ncell * nloc; ++i) {
+    if (cell_nodes[i] < 0 || (!part && cell_nodes[i] >= nb)) return alfi_set_error(ctx, ALFI_E_ARG, "cell node out of range");
+    nstate = std::max<int64_t>(nstate, (int64_t)cell_nodes[i] + 1);
+  }
+  for (int64_t q = 0; q < npairs; ++q) {     // the two nodes of a contributing pair are rows / columns of the local operator
+    const int32_t* cn = cell_nodes + (int64_t)ccell[q] * nloc;
+    if (cn[cba[q] % nloc] >= nb || cn[cba[q] / nloc] >= nb) return alfi_set_error(ctx, ALFI_E_ARG, "contributor %lld names a node without an operator row", (long long)q);
+  }
   ALFI_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   ALFI_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
   free_assembly(&L->asmb);
@@ -687,6 +700,7 @@ int alfi_level_set_assembly(alfi_level* L, int64_t ncell, int nloc, const int32_
   S.nloc = nloc;
   S.ncell = ncell;
   S.npairs = npairs;
+  S.nstate = nstate;
   int rc = dev_upload(ctx, &S.cptr, cptr, nnzb + 1);
   if (rc == 0) rc = dev_upload(ctx, &S.ccell, ccell, npairs);
   if (rc == 0) rc = dev_upload(ctx, &S.cba, cba, npairs);
@@ -722,10 +736,59 @@ int alfi_level_assemble(alfi_level* L, double nu, double gamma, double adv, cons
   if (adv != 0.0 && !d_state) return alfi_set_error(ctx, ALFI_E_ARG, "advection needs the state");
   ctx->cur_tag = L->id;
   int t = alfi_prof_begin(ctx, ALFI_EV_PATCH_FACTOR);       // PCPatchComputeOp
-  ALFI_CHECK(launch_assemble_gather(L, nu, gamma, adv, d_state, apply_bc));
+  ALFI_CHECK(launch_assemble_gather(L, nu, gamma, adv, d_state, apply_bc, L->A.vals));
   alfi_prof_end(ctx, t);
   L->factored = false;
   return 0;
+}
+
+static int level_spmv(alfi_level* L, const double* dx, double* dy, const double* db, int mode, bool ghosts_current = false);
+
+// Partitioned levels: the Dirichlet dofs among ALL local dofs (the level was created with the owned ones only: its smoother
+// copies x to y there, which must happen on the owner alone).  The refresh turns the rows / columns of these dofs into
+// identity, as firedrake.assemble(a, bcs) does on every rank's rows [3P].
+int alfi_level_set_assembly_bc(alfi_level* L, const int32_t* bc_dofs, int64_t nbc) {
+  alfi_ctx* ctx = L->ctx;
+  if (!L->asmb.ready) return alfi_set_error(ctx, ALFI_E_STATE, "alfi_level_set_assembly_bc before alfi_level_set_assembly");
+  if (nbc < 0 || (nbc > 0 && !bc_dofs)) return alfi_set_error(ctx, ALFI_E_ARG, "NULL argument");
+  std::vector<uint8_t> mask((size_t)std::max<int64_t>(L->n, 1), 0);
+  for (int64_t i = 0; i < nbc; ++i) {
+    if (bc_dofs[i] < 0 || bc_dofs[i] >= L->n) return alfi_set_error(ctx, ALFI_E_ARG, "Dirichlet dof %d out of range", bc_dofs[i]);
+    mask[(size_t)bc_dofs[i]] = 1;
+  }
+  ALFI_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  dev_free(L->asmb.bc_all);
+  L->asmb.bc_all = nullptr;
+  return dev_upload(ctx, &L->asmb.bc_all, mask.data(), (int64_t)mask.size());
+}
+
+int alfi_level_assembly_state_size(alfi_level* L, int64_t* n) {
+  if (!L->asmb.ready) return alfi_set_error(L->ctx, ALFI_E_STATE, "alfi_level_assembly_state_size before alfi_level_set_assembly");
+  *n = L->asmb.nstate * L->bs;
+  return 0;
+}
+
+// y = A(state) x with A = nu K + gamma D + adv N(state) WITHOUT boundary conditions, assembled into a second value array: the
+// level's own operator (the Jacobian the patches were factored from) is not touched.  The nonlinear residual of
+// alfi/solver.py:565-568 is one such product: F_u = (nu K + gamma D) u + 1/2 N(u) u = A(u; adv / 2) u.
+int alfi_level_assemble_mult(alfi_level* L, double nu, double gamma, double adv, const double* d_state, const double* dx,
+                             double* dy) {
+  alfi_ctx* ctx = L->ctx;
+  AssemblyDev& S = L->asmb;
+  if (!S.ready) return alfi_set_error(ctx, ALFI_E_STATE, "alfi_level_assemble_mult before alfi_level_set_assembly");
+  if (adv != 0.0 && !d_state) return alfi_set_error(ctx, ALFI_E_ARG, "advection needs the state");
+  if (!S.scratch) ALFI_CHECK(dev_alloc(ctx, &S.scratch, ((L->A.nnzb + 63) / 64) * 64 * (int64_t)L->bs * L->bs));
+  ctx->cur_tag = L->id;
+  int t = alfi_prof_begin(ctx, ALFI_EV_PATCH_FACTOR);
+  ALFI_CHECK(launch_assemble_gather(L, nu, gamma, adv, d_state, 0, S.scratch));
+  alfi_prof_end(ctx, t);
+  // the product through the level's own views (owned rows, interior / boundary split) with the value pointer exchanged:
+  // launches are stream-ordered and take their arguments by value, so the exchange is over when level_spmv returns
+  double* keep = L->A.vals;
+  L->A.vals = L->A_own.vals = L->A_int.vals = L->A_bnd.vals = S.scratch;
+  const int rc = level_spmv(L, dx, dy, nullptr, 0, false);
+  L->A.vals = L->A_own.vals = L->A_int.vals = L->A_bnd.vals = keep;
+  return rc;
 }
 
 int alfi_level_set_supg(alfi_level* L, int nq, const double* wq, const double* phi, const double* dphi, const double* d2phi,
@@ -813,7 +876,7 @@ int alfi_level_id(alfi_level* L, int* id) {
 // product is formed on the owned rows.
 // y = A x (mode 0) or y = b - A x (mode 1) on the owned rows of a level.  With alfi_level_set_overlap the rows without
 // ghost columns are multiplied while the forward halo of x is in flight.
-static int level_spmv(alfi_level* L, const double* dx, double* dy, const double* db, int mode, bool ghosts_current = false) {
+static int level_spmv(alfi_level* L, const double* dx, double* dy, const double* db, int mode, bool ghosts_current) {
   alfi_ctx* ctx = L->ctx;
   ctx->cur_tag = L->id;
   int t;
@@ -909,6 +972,10 @@ int alfi_patches_set(alfi_level* L, int64_t npatch, const int64_t* pptr, const i
   dev_free(L->inv_ptr);
   dev_free(L->stage_ptr);
   dev_free(L->inv);
+  dev_free(L->inv_il);
+  L->inv_il = nullptr;
+  L->il_doubles = 0;
+  L->il_valid = false;
   dev_free(L->stage);
   dev_free(L->dof_ptr);
   dev_free(L->dof_pos);
@@ -1278,6 +1345,7 @@ int alfi_patches_set_groups(alfi_level* L, const int32_t* group) {
   }
   L->cd = cd;
   L->cond = true;
+  L->il_valid = false;
   L->h_sptr = sptr;
   L->h_cond_gptr = gptr;
   L->cond_ngroups = (int64_t)g_off.size();
@@ -1398,6 +1466,7 @@ int alfi_patches_factor(alfi_level* L) {
     ALFI_CHECK(launch_patch_gather_dense(L));
     ALFI_CHECK(launch_patch_invert(L));
   }
+  ALFI_CHECK(build_patch_il(L));                  // small-patch levels: the wave-contiguous copy the apply streams
   alfi_prof_end(ctx, t);
   int st = 0;
   ALFI_HIP_CHECK(ctx, hipMemcpyAsync(&st, L->status, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
@@ -1460,9 +1529,12 @@ static int ensure_fgmres_workspace(alfi_level* L, int k) {
   dev_free(L->hs);
   L->V = L->Z = L->w = L->hs = nullptr;
   L->kmax = 0;
-  ALFI_CHECK(dev_alloc(ctx, &L->V, (int64_t)(k + 1) * L->n));
-  ALFI_CHECK(dev_alloc(ctx, &L->Z, (int64_t)k * L->n));
-  ALFI_CHECK(dev_alloc(ctx, &L->w, L->n));
+  // stride of the Krylov bases: the local length rounded up to even, so that every basis vector starts on a 16-byte
+  // boundary (the BLAS-1 kernels read entry pairs; n = 3 x nodes is odd on half of the 3-D levels)
+  L->ldv = (L->n + 1) & ~(int64_t)1;
+  ALFI_CHECK(dev_alloc(ctx, &L->V, (int64_t)(k + 1) * L->ldv));
+  ALFI_CHECK(dev_alloc(ctx, &L->Z, (int64_t)k * L->ldv));
+  ALFI_CHECK(dev_alloc(ctx, &L->w, L->ldv));
   HsLayout hl(k);
   ALFI_CHECK(dev_alloc(ctx, &L->hs, hl.total));
   ALFI_HIP_CHECK(ctx, hipMemsetAsync(L->hs, 0, sizeof(double) * hl.total, ctx->stream));
@@ -1476,7 +1548,7 @@ static int ensure_fgmres_workspace(alfi_level* L, int k) {
 static int smooth_fgmres_fused(alfi_level* L, int k, const double* db, double* dx, int nonzero_guess, bool flat_spmv) {
   alfi_ctx* ctx = L->ctx;
   const int K = L->kmax;
-  const int64_t n = L->n;
+  const int64_t n = L->n, ldv = L->ldv;
   HsLayout hl(K);
   double *V = L->V, *Z = L->Z, *w = L->w, *hs = L->hs;
   double* hdots = hs + hl.hd;
@@ -1495,15 +1567,15 @@ static int smooth_fgmres_fused(alfi_level* L, int k, const double* db, double* d
   const int G = red_blocks_for(n);
   const double* normpart = ctx->red_partial;
   for (int j = 0; j < k; ++j) {
-    double* zj = Z + (int64_t)j * n;
+    double* zj = Z + (int64_t)j * ldv;
     ALFI_CHECK(launch_patch_apply_range(L, 0, L->npatch, w));                                   // stage <- patch solves of w
     t = alfi_prof_begin(ctx, ALFI_EV_PATCH_SCATTER);
-    ALFI_CHECK(launch_patch_sum_scale(L, w, zj, V + (int64_t)j * n, normpart, G, hdots, hs, j, K));   // z_j, v_j, H column j-1
+    ALFI_CHECK(launch_patch_sum_scale(L, w, zj, V + (int64_t)j * ldv, normpart, G, hdots, hs, j, K));   // z_j, v_j, H column j-1
     alfi_prof_end(ctx, t);
     int nb = 0;
     if (!flat_spmv) {
       t = alfi_prof_begin(ctx, ALFI_EV_MATMULT);
-      ALFI_CHECK(launch_bsr_spmv_dot(ctx, L->A_own, zj, w, V, n, j + 1, ctx->red_partial, &nb));  // w = A z_j, V^T w partials
+      ALFI_CHECK(launch_bsr_spmv_dot(ctx, L->A_own, zj, w, V, ldv, j + 1, ctx->red_partial, &nb));  // w = A z_j, V^T w partials
       alfi_prof_end(ctx, t);
     } else {
       // long or very uneven block rows (the 3-D operators): the nnz-balanced product, then the dots as their own pass; up to
@@ -1513,18 +1585,18 @@ static int smooth_fgmres_fused(alfi_level* L, int k, const double* db, double* d
       alfi_prof_end(ctx, t);
       t = alfi_prof_begin(ctx, ALFI_EV_BLAS1);
       const bool in_consumer = G <= 256;
-      ALFI_CHECK(launch_multi_dot(ctx, V, n, j + 1, w, in_consumer ? nullptr : hdots, n));
+      ALFI_CHECK(launch_multi_dot(ctx, V, ldv, j + 1, w, in_consumer ? nullptr : hdots, n));
       alfi_prof_end(ctx, t);
       nb = in_consumer ? G : 0;
     }
     t = alfi_prof_begin(ctx, ALFI_EV_BLAS1);
-    ALFI_CHECK(launch_multi_axpy_norm(ctx, V, n, j + 1, hdots, w, n, ctx->red_partial2, nb));     // h, w -= V h, |w|^2 partials
+    ALFI_CHECK(launch_multi_axpy_norm(ctx, V, ldv, j + 1, hdots, w, n, ctx->red_partial2, nb));     // h, w -= V h, |w|^2 partials
     alfi_prof_end(ctx, t);
     normpart = ctx->red_partial2;
   }
   t = alfi_prof_begin(ctx, ALFI_EV_BLAS1);
   ALFI_CHECK(launch_fgmres_finish_fused(ctx, normpart, G, hdots, hs, k, K));                       // H column k-1, y
-  ALFI_CHECK(launch_update_solution(ctx, dx, Z, n, k, hs + hl.y, n));
+  ALFI_CHECK(launch_update_solution(ctx, dx, Z, ldv, k, hs + hl.y, n));
   alfi_prof_end(ctx, t);
   return 0;
 }
@@ -1548,15 +1620,6 @@ int alfi_smooth_fgmres(alfi_level* L, int k, const double* db, double* dx, int n
     // like: config 3 18.66 -> 18.12-18.23 ms with its two smallest smoothed levels on the fused iteration (same box)
     static const int64_t small_n = getenv("ALFI_FUSED_SMALL_N") ? atoll(getenv("ALFI_FUSED_SMALL_N")) : 50000;
     const bool fusable = allow && !L->distributed && L->n_own == L->n && !L->mult && k + 1 <= 16 && L->A_own.flat;
-    // tiny levels (operator + dense inverses of a smoother iteration below ALFI_TINY_BYTES): the whole call as ONE launch of
-    // ONE workgroup (kernels_tiny.hip) -- ~30 dependent launches become one kernel whose phases are separated by
-    // __syncthreads() only.  OPT-IN (default 0 = never): measured on ldc2d it does not beat the launch
-    // chain even on the 1 250-dof level (0.46 ms per cycle against ~0.4 ms): every phase is a chain of two or three dependent
-    // global loads at ~2 us each -- the level's data does not survive in L2 between two visits of the level -- and one
-    // workgroup has 16 waves to hide them where the launch chain has a few hundred
-    static const int64_t tiny_bytes = getenv("ALFI_TINY_BYTES") ? atoll(getenv("ALFI_TINY_BYTES")) : 0;
-    if (fusable && !L->cond && L->kmax <= 15 && L->max_np <= SMALL_PATCH_MAX && tiny_level_bytes(L) <= tiny_bytes)
-      return launch_smooth_tiny(L, k, db, dx, nonzero_guess);
     // every unpartitioned additive level takes the iteration with the normalisation folded behind the (linear) patch
     // solves -- patch_sum_scale_kernel writes z_j and v_j in one pass, no separate v = w / |w| launch; the product is the
     // lanes-per-row kernel with the dots folded in where the rows are short, the nnz-balanced one + a dot pass elsewhere.
@@ -1569,7 +1632,7 @@ int alfi_smooth_fgmres(alfi_level* L, int k, const double* db, double* dx, int n
   }
   const int K = L->kmax;
   const int64_t n = L->n_own;    // vector kernels and reductions run on the owned prefix
-  const int64_t ldv = L->n;      // stride of the Krylov bases (local length incl. ghost slots)
+  const int64_t ldv = L->ldv;    // stride of the Krylov bases (local length incl. ghost slots, rounded up to even)
   const bool par = L->distributed;
   HsLayout hl(K);
   double* V = L->V;
@@ -2297,12 +2360,18 @@ int alfi_csr_mult(alfi_csr* C, const double* dx, double* dy, const double* db, d
   return launch_csr_spmv(C->ctx, C->M, dx, dy, db, alpha, mode);
 }
 
+// On a PARTITIONED finest level (alfi_level_set_partition, distributed) the call is collective and the matrices are the rank's
+// pieces: B = the rank's pressure rows over all LOCAL velocity dofs (owned + ghost: n_loc columns), BT = its transpose (n_loc
+// rows; the ghost rows hold contributions for their owners, reverse-added).  Vectors then hold (owned velocity dofs | owned
+// pressure dofs) and every reduction is one all-reduce -- the same Krylov loop as on one GPU, no host arithmetic.
 int alfi_saddle_create(alfi_mg* mg, const alfi_csr_host* B, const alfi_csr_host* BT, const double* mass_diag,
                        double nu, double gamma, int remove_constant_nullspace, alfi_saddle** out) {
   if (!mg || !B || !BT || !mass_diag || !out) return alfi_set_error(mg ? mg->ctx : nullptr, ALFI_E_ARG, "NULL argument");
   alfi_ctx* ctx = mg->ctx;
   alfi_level* F = mg->levels.back();
-  if (F->has_halo) return alfi_set_error(ctx, ALFI_E_ARG, "the outer solve is not available on partitioned levels");
+  const bool par = F->distributed;
+  if (F->has_halo && !par)
+    return alfi_set_error(ctx, ALFI_E_ARG, "the finest level has a halo but is not distributed: no outer solve on it");
   if (B->ncols != F->n || BT->nrows != F->n || BT->ncols != B->nrows)
     return alfi_set_error(ctx, ALFI_E_ARG, "divergence matrix shape does not match the finest level");
   for (int64_t i = 0; i < B->nrows; ++i)
@@ -2312,18 +2381,45 @@ int alfi_saddle_create(alfi_mg* mg, const alfi_csr_host* B, const alfi_csr_host*
   S->ctx = ctx;
   S->mg = mg;
   S->fine = F;
-  S->nu_dofs = F->n;
+  S->par = par;
+  S->n_loc = F->n;
+  S->nu_dofs = par ? F->n_own : F->n;
   S->np_dofs = B->nrows;
+  S->np_global = (double)B->nrows;
   S->nu = nu;
   S->gamma = gamma;
   S->remove_nullspace = remove_constant_nullspace != 0;
-  std::vector<double> minv(B->nrows);
+  std::vector<double> minv(std::max<int64_t>(B->nrows, 1), 1.0);
   for (int64_t i = 0; i < B->nrows; ++i) minv[i] = 1.0 / mass_diag[i];
   int rc = upload_csr(ctx, &S->B, B);
   if (rc == 0) rc = upload_csr(ctx, &S->BT, BT);
-  if (rc == 0) rc = dev_upload(ctx, &S->minv, minv.data(), B->nrows);
-  if (rc == 0) rc = dev_alloc(ctx, &S->tmp_u, S->nu_dofs);
-  if (rc == 0) rc = dev_alloc(ctx, &S->tmp_p, S->np_dofs);
+  if (rc == 0) rc = dev_upload(ctx, &S->minv, minv.data(), (int64_t)minv.size());
+  if (rc == 0) rc = dev_alloc(ctx, &S->tmp_u, S->n_loc);
+  if (rc == 0) rc = dev_alloc(ctx, &S->tmp_p, std::max<int64_t>(S->np_dofs, 1));
+  if (rc == 0 && par) {
+    rc = dev_alloc(ctx, &S->wa, S->n_loc);
+    if (rc == 0) rc = dev_alloc(ctx, &S->wb, S->n_loc);
+    if (rc == 0) rc = dev_alloc(ctx, &S->wc, S->n_loc);
+    if (rc == 0 && hipMemsetAsync(S->wa, 0, sizeof(double) * S->n_loc, ctx->stream) != hipSuccess) rc = ALFI_E_HIP;
+    // pressure dofs of all ranks: one all-reduce at setup
+    if (rc == 0) {
+      const double mine = (double)B->nrows;
+      if (hipMemcpyAsync(ctx->dred + RED_MAXV, &mine, sizeof(double), hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
+          hipStreamSynchronize(ctx->stream) != hipSuccess)
+        rc = alfi_set_error(ctx, ALFI_E_HIP, "alfi_saddle_create: copy to the reduction buffer failed");
+    }
+    if (rc == 0) {
+      ctx->cur_tag = F->id;
+      rc = comm_allreduce(F, RED_MAXV, 1);
+    }
+    if (rc == 0) {
+      double tot = 0.0;
+      if (hipMemcpyAsync(&tot, ctx->dred + RED_MAXV, sizeof(double), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+          hipStreamSynchronize(ctx->stream) != hipSuccess)
+        rc = alfi_set_error(ctx, ALFI_E_HIP, "alfi_saddle_create: copy from the reduction buffer failed");
+      S->np_global = tot;
+    }
+  }
   if (rc != 0) {
     alfi_saddle_destroy(S);
     return rc;
@@ -2345,6 +2441,9 @@ int alfi_saddle_destroy(alfi_saddle* S) {
   dev_free(S->hs);
   dev_free(S->tmp_u);
   dev_free(S->tmp_p);
+  dev_free(S->wa);
+  dev_free(S->wb);
+  dev_free(S->wc);
   delete S;
   return 0;
 }
@@ -2359,6 +2458,16 @@ int alfi_saddle_update(alfi_saddle* S, double nu, double gamma) {
 int alfi_saddle_mult(alfi_saddle* S, const double* dx, double* dy) {
   alfi_ctx* ctx = S->ctx;
   const int64_t nu = S->nu_dofs;
+  if (S->par) {
+    alfi_level* F = S->fine;
+    ctx->cur_tag = F->id;
+    ALFI_CHECK(launch_copy(ctx, S->wa, dx, nu));
+    ALFI_CHECK(level_spmv(F, S->wa, S->wb, nullptr, 0));                          // ghosts of wa filled; owned rows of A
+    ALFI_CHECK(launch_csr_spmv(ctx, S->B, S->wa, dy + nu, nullptr, 0.0, 0));      // y_p = B u (needs the ghosts)
+    ALFI_CHECK(launch_csr_spmv(ctx, S->BT, dx + nu, S->wc, nullptr, 0.0, 0));     // partial B^T p on all local dofs
+    ALFI_CHECK(halo_rev(F, S->wc));                                               // ... summed onto their owners
+    return launch_add(ctx, dy, S->wb, S->wc, nu);
+  }
   ALFI_CHECK(alfi_spmv(S->fine, dx, dy));                                       // y_u = A x_u
   ALFI_CHECK(launch_csr_spmv(ctx, S->BT, dx + nu, dy, nullptr, 0.0, 2));        // y_u += B^T x_p
   ALFI_CHECK(launch_csr_spmv(ctx, S->B, dx, dy + nu, nullptr, 0.0, 0));         // y_p = B x_u
@@ -2378,15 +2487,39 @@ int alfi_saddle_set_mass_inverse(alfi_saddle* S, const alfi_csr_host* Minv) {
   return 0;
 }
 
+// y_p = -(nu + gamma) M^-1 q
+static int saddle_schur(alfi_saddle* S, const double* q, double* yp) {
+  if (S->has_Minv) return launch_csr_spmv(S->ctx, S->Minv, q, yp, nullptr, -(S->nu + S->gamma), 3);
+  return launch_scale_rows(S->ctx, yp, q, S->minv, -(S->nu + S->gamma), S->np_dofs);
+}
+
 int alfi_saddle_precond(alfi_saddle* S, const double* dx, double* dy) {
   alfi_ctx* ctx = S->ctx;
   const int64_t nu = S->nu_dofs, np = S->np_dofs;
+  if (S->par) {
+    alfi_level* F = S->fine;
+    ALFI_CHECK(launch_copy(ctx, S->wa, dx, nu));
+    ALFI_CHECK(alfi_mg_fcycle(S->mg, S->wa, S->wb));                              // y_u = MG(b_u)
+    ctx->cur_tag = F->id;
+    ALFI_CHECK(halo_fwd(F, S->wb));
+    ALFI_CHECK(launch_csr_spmv(ctx, S->B, S->wb, S->tmp_p, dx + nu, 1.0, 1));     // q = b_p - B y_u
+    ALFI_CHECK(saddle_schur(S, S->tmp_p, dy + nu));
+    ALFI_CHECK(launch_csr_spmv(ctx, S->BT, dy + nu, S->wc, nullptr, 0.0, 0));     // B^T y_p: partial sums on all local dofs
+    ALFI_CHECK(halo_rev(F, S->wc));
+    ALFI_CHECK(launch_xmy(ctx, S->wc, dx, nu));                                   // t = b_u - B^T y_p
+    ALFI_CHECK(alfi_mg_fcycle(S->mg, S->wc, S->wb));                              // y_u = MG(t)
+    ALFI_CHECK(launch_copy(ctx, dy, S->wb, nu));
+    if (S->remove_nullspace) {                                                    // y_p -= (sum over all ranks) / (all pressure dofs)
+      ctx->cur_tag = F->id;
+      ALFI_CHECK(launch_sum_to(ctx, dy + nu, np, ctx->dred + RED_MAXV));
+      ALFI_CHECK(comm_allreduce(F, RED_MAXV, 1));
+      ALFI_CHECK(launch_sub_scaled(ctx, dy + nu, np, ctx->dred + RED_MAXV, 1.0 / S->np_global));
+    }
+    return 0;
+  }
   ALFI_CHECK(alfi_mg_fcycle(S->mg, dx, dy));                                    // y_u = MG(b_u)
   ALFI_CHECK(launch_csr_spmv(ctx, S->B, dy, S->tmp_p, dx + nu, 1.0, 1));        // q = b_p - B y_u
-  if (S->has_Minv)                                                                // y_p = -(nu+gamma) M^-1 q
-    ALFI_CHECK(launch_csr_spmv(ctx, S->Minv, S->tmp_p, dy + nu, nullptr, -(S->nu + S->gamma), 3));
-  else
-    ALFI_CHECK(launch_scale_rows(ctx, dy + nu, S->tmp_p, S->minv, -(S->nu + S->gamma), np));
+  ALFI_CHECK(saddle_schur(S, S->tmp_p, dy + nu));                               // y_p = -(nu+gamma) M^-1 q
   ALFI_CHECK(launch_csr_spmv(ctx, S->BT, dy + nu, S->tmp_u, dx, 1.0, 1));       // t = b_u - B^T y_p
   ALFI_CHECK(alfi_mg_fcycle(S->mg, S->tmp_u, dy));                              // y_u = MG(t)
   if (S->remove_nullspace) ALFI_CHECK(launch_remove_mean(ctx, dy + nu, np));
@@ -2396,6 +2529,8 @@ int alfi_saddle_precond(alfi_saddle* S, const double* dx, double* dy) {
 int alfi_saddle_solve(alfi_saddle* S, const double* db, double* dx, double rtol, double atol, int max_it, int restart,
                       int* iterations, double* residual_norm) {
   alfi_ctx* ctx = S->ctx;
+  alfi_level* F = S->fine;
+  const bool par = S->par;
   const int64_t n = S->nu_dofs + S->np_dofs;
   if (restart < 1 || restart > RED_MAXV - 2) return alfi_set_error(ctx, ALFI_E_ARG, "restart must be in 1..%d", RED_MAXV - 2);
   if (restart != S->restart) {
@@ -2406,16 +2541,23 @@ int alfi_saddle_solve(alfi_saddle* S, const double* db, double* dx, double rtol,
     dev_free(S->hs);
     S->V = S->Z = S->w = S->hs = nullptr;
     S->restart = 0;
-    ALFI_CHECK(dev_alloc(ctx, &S->V, (int64_t)(restart + 1) * n));
-    ALFI_CHECK(dev_alloc(ctx, &S->Z, (int64_t)restart * n));
-    ALFI_CHECK(dev_alloc(ctx, &S->w, n));
+    S->ldv = (n + 1) & ~(int64_t)1;           // every basis vector on a 16-byte boundary
+    ALFI_CHECK(dev_alloc(ctx, &S->V, (int64_t)(restart + 1) * S->ldv));
+    ALFI_CHECK(dev_alloc(ctx, &S->Z, (int64_t)restart * S->ldv));
+    ALFI_CHECK(dev_alloc(ctx, &S->w, S->ldv));
     HsLayout hl0(restart);
     ALFI_CHECK(dev_alloc(ctx, &S->hs, hl0.total));
     S->restart = restart;
   }
   const int K = restart;
+  const int64_t ldv = S->ldv;
   HsLayout hl(K);
   double *V = S->V, *Z = S->Z, *w = S->w, *hs = S->hs;
+  // partitioned: dots and norms are reduced into the ctx's reduction buffer and all-reduced there (as in the level smoother);
+  // the values every rank reads back are identical, so all ranks take the same branches
+  double* hdots = par ? ctx->dred : hs + hl.hd;
+  double* nrm2 = par ? ctx->dred + RED_MAXV : nullptr;
+  const int G = red_blocks_for(n);
   ALFI_HIP_CHECK(ctx, hipMemsetAsync(hs, 0, sizeof(double) * hl.total, ctx->stream));
   ALFI_HIP_CHECK(ctx, hipMemsetAsync(dx, 0, sizeof(double) * n, ctx->stream));
   auto read = [&](const double* p, double* out) -> int {
@@ -2423,12 +2565,22 @@ int alfi_saddle_solve(alfi_saddle* S, const double* db, double* dx, double rtol,
     ALFI_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     return 0;
   };
+  // beta = |w| into hs (and the rotated right-hand side)
+  auto norm_init = [&]() -> int {
+    ALFI_CHECK(launch_norm_partials(ctx, w, n));
+    if (par) {
+      ctx->cur_tag = F->id;
+      ALFI_CHECK(launch_reduce_partials(ctx, ctx->red_partial, G, 1, nrm2));
+      ALFI_CHECK(comm_allreduce(F, RED_MAXV, 1));
+      return launch_norm_init_finish(ctx, nrm2, 1, hs, K);
+    }
+    return launch_norm_init_finish(ctx, ctx->red_partial, G, hs, K);
+  };
   int its = 0;
   double bnorm = 0.0, rnorm = 0.0;
   // r = b (zero initial guess)
   ALFI_CHECK(launch_copy(ctx, w, db, n));
-  ALFI_CHECK(launch_norm_partials(ctx, w, n));
-  ALFI_CHECK(launch_norm_init_finish(ctx, ctx->red_partial, red_blocks_for(n), hs, K));
+  ALFI_CHECK(norm_init());
   ALFI_CHECK(read(hs + hl.beta, &bnorm));
   rnorm = bnorm;
   const double tol = std::max(rtol * bnorm, atol);
@@ -2437,12 +2589,20 @@ int alfi_saddle_solve(alfi_saddle* S, const double* db, double* dx, double rtol,
     ALFI_CHECK(launch_scale_by_inv(ctx, V, w, hs + hl.beta, n));            // v_0 = r / |r|
     int j = 0;
     for (; j < K && its < max_it; ++j) {
-      double* zj = Z + (int64_t)j * n;
-      ALFI_CHECK(alfi_saddle_precond(S, V + (int64_t)j * n, zj));            // z_j = P^-1 v_j
+      double* zj = Z + (int64_t)j * ldv;
+      ALFI_CHECK(alfi_saddle_precond(S, V + (int64_t)j * ldv, zj));          // z_j = P^-1 v_j
       ALFI_CHECK(alfi_saddle_mult(S, zj, w));                               // w = K z_j
-      ALFI_CHECK(launch_multi_dot(ctx, V, n, j + 1, w, hs + hl.hd, n));
-      ALFI_CHECK(launch_multi_axpy_norm(ctx, V, n, j + 1, hs + hl.hd, w, n, ctx->red_partial2, 0));
-      ALFI_CHECK(launch_hessenberg_update(ctx, ctx->red_partial2, red_blocks_for(n), hs + hl.hd, hs, j, K, nullptr));
+      ALFI_CHECK(launch_multi_dot(ctx, V, ldv, j + 1, w, hdots, n));
+      if (par) {
+        ctx->cur_tag = F->id;
+        ALFI_CHECK(comm_allreduce(F, 0, j + 1));
+      }
+      ALFI_CHECK(launch_multi_axpy_norm(ctx, V, ldv, j + 1, hdots, w, n, ctx->red_partial2, 0));
+      if (par) {                                                            // |w - V h| by its own all-reduce (VecNorm)
+        ALFI_CHECK(launch_reduce_partials(ctx, ctx->red_partial2, G, 1, nrm2));
+        ALFI_CHECK(comm_allreduce(F, RED_MAXV, 1));
+      }
+      ALFI_CHECK(launch_hessenberg_update(ctx, par ? nrm2 : ctx->red_partial2, par ? 1 : G, hdots, hs, j, K, nullptr));
       ++its;
       double g = 0.0;
       ALFI_CHECK(read(hs + hl.grs + j + 1, &g));                            // |rotated rhs| = residual norm estimate
@@ -2452,24 +2612,22 @@ int alfi_saddle_solve(alfi_saddle* S, const double* db, double* dx, double rtol,
         ++j;
         break;
       }
-      if (j + 1 < K) ALFI_CHECK(launch_scale_by_inv(ctx, V + (int64_t)(j + 1) * n, w, hs + hl.tt, n));
+      if (j + 1 < K) ALFI_CHECK(launch_scale_by_inv(ctx, V + (int64_t)(j + 1) * ldv, w, hs + hl.tt, n));
     }
     ALFI_CHECK(launch_fgmres_finish(ctx, hs, j, K));
-    ALFI_CHECK(launch_update_solution(ctx, dx, Z, n, j, hs + hl.y, n));
+    ALFI_CHECK(launch_update_solution(ctx, dx, Z, ldv, j, hs + hl.y, n));
     if (converged || its >= max_it) break;
     // restart: true residual
     ALFI_CHECK(alfi_saddle_mult(S, dx, w));
     ALFI_CHECK(launch_xmy(ctx, w, db, n));                                   // w = b - K x
-    ALFI_CHECK(launch_norm_partials(ctx, w, n));
-    ALFI_CHECK(launch_norm_init_finish(ctx, ctx->red_partial, red_blocks_for(n), hs, K));
+    ALFI_CHECK(norm_init());
     ALFI_CHECK(read(hs + hl.beta, &rnorm));
     converged = rnorm <= tol;
   }
   // final true residual norm
   ALFI_CHECK(alfi_saddle_mult(S, dx, w));
   ALFI_CHECK(launch_xmy(ctx, w, db, n));
-  ALFI_CHECK(launch_norm_partials(ctx, w, n));
-  ALFI_CHECK(launch_norm_init_finish(ctx, ctx->red_partial, red_blocks_for(n), hs, K));
+  ALFI_CHECK(norm_init());
   double tn = 0.0;
   ALFI_CHECK(read(hs + hl.beta, &tn));
   if (iterations) *iterations = its;

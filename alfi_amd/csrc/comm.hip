@@ -27,6 +27,8 @@ struct RcclApi {
   ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
   ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;        // optional
+  ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
+  ncclResult_t (*CommUserRank)(const ncclComm_t, int*) = nullptr;
   ncclResult_t (*GroupStart)() = nullptr;
   ncclResult_t (*GroupEnd)() = nullptr;
   ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
@@ -68,7 +70,8 @@ RcclApi* rccl() {
   if (!(resolve(h, "ncclGetUniqueId", &a.GetUniqueId) && resolve(h, "ncclCommInitRank", &a.CommInitRank) &&
         resolve(h, "ncclCommDestroy", &a.CommDestroy) && resolve(h, "ncclGroupStart", &a.GroupStart) &&
         resolve(h, "ncclGroupEnd", &a.GroupEnd) && resolve(h, "ncclSend", &a.Send) && resolve(h, "ncclRecv", &a.Recv) &&
-        resolve(h, "ncclAllReduce", &a.AllReduce) && resolve(h, "ncclGetErrorString", &a.GetErrorString)))
+        resolve(h, "ncclAllReduce", &a.AllReduce) && resolve(h, "ncclGetErrorString", &a.GetErrorString) &&
+        resolve(h, "ncclCommCount", &a.CommCount) && resolve(h, "ncclCommUserRank", &a.CommUserRank)))
     return nullptr;
   a.CommAbort = reinterpret_cast<decltype(a.CommAbort)>(dlsym(h, "ncclCommAbort"));
   g_api = a;
@@ -216,15 +219,23 @@ int alfi_ctx_comm_init(alfi_ctx* ctx, const void* id, int rank, int nranks) {
     native_destroy(ctx);
     return alfi_set_error(ctx, ALFI_E_HIP, "communicator resources: %s", hipGetErrorString(e));
   }
-  const char* en = getenv("ALFI_DIST_EXACT_NORM");   // 1: |w| by its own all-reduce, as PETSc's VecNorm (A/B, parity checks)
-  ctx->exact_norm = en && atoi(en) == 1;
+  // |w - V h| of the partitioned FGMRES by its own all-reduce, as PETSc's VecNorm (the default).  ALFI_DIST_EXACT_NORM=0: from
+  // |w|^2 - |h|^2 with the dots' all-reduce (one reduction fewer per iteration; absolute error eps |w|^2, so a new direction
+  // that is small against w is mis-normalised -- measurements only)
+  const char* en = getenv("ALFI_DIST_EXACT_NORM");
+  ctx->exact_norm = !(en && atoi(en) == 0);
   return 0;
 }
 
+// what the COMMUNICATOR says (ncclCommUserRank / ncclCommCount on the ctx's ncclComm_t), not what alfi_ctx_comm_init was told
 int alfi_ctx_comm_size(alfi_ctx* ctx, int* rank, int* nranks) {
-  if (!ctx->nat) return alfi_set_error(ctx, ALFI_E_STATE, "no communicator (alfi_ctx_comm_init)");
-  if (rank) *rank = ctx->nat->rank;
-  if (nranks) *nranks = ctx->nat->nranks;
+  if (!ctx->nat || !ctx->nat->comm) return alfi_set_error(ctx, ALFI_E_STATE, "no communicator (alfi_ctx_comm_init)");
+  RcclApi* api = &g_api;
+  int r = -1, n = -1;
+  ALFI_NCCL_CHECK(ctx, api, api->CommUserRank(ctx->nat->comm, &r));
+  ALFI_NCCL_CHECK(ctx, api, api->CommCount(ctx->nat->comm, &n));
+  if (rank) *rank = r;
+  if (nranks) *nranks = n;
   return 0;
 }
 

@@ -34,7 +34,7 @@ struct alfi_ctx {
   // mesh-partition parallelism (alfi_ctx_set_comm)
   alfi_comm_fn comm = nullptr;
   void* comm_user = nullptr;
-  bool exact_norm = false;  // partitioned FGMRES: second all-reduce for |w| instead of the Pythagorean identity
+  bool exact_norm = true;   // partitioned FGMRES: second all-reduce for |w - V h| (PETSc's VecNorm); false: Pythagorean identity
   double* dred = nullptr;  // device buffer that is all-reduced: [0, RED_MAXV) dots, [RED_MAXV] norm^2 (caller-owned with
                            // alfi_ctx_set_comm, owned by the ctx with alfi_ctx_comm_init)
   // native transport (alfi_ctx_comm_init, comm.hip): the ctx owns an RCCL communicator and exchanges by itself
@@ -98,6 +98,19 @@ __host__ __device__ inline int64_t patch_inv_index(int r, int c, int n, int ld) 
     }
   }
   return (int64_t)row0 * n + (int64_t)c * rows + (r - row0);
+}
+
+// Interleaved storage of SMALL patch inverses (every n_p <= 2 G <= 32): G lanes share a patch (lane l owns the row pair
+// 2l, 2l + 1), PW = 64 / G patches share a wave, and the wave's PW patches are stored column by column,
+//     il[((w * nc + c) * PW * G + q * G + l) * 2 + (r & 1)],   p = w * PW + q,  l = r / 2,  c < nc = max_np of the level
+// (rows / columns a patch does not have are zero), so that one wave instruction -- column c of all PW patches -- reads
+// PW * G * 16 consecutive bytes and consecutive instructions continue where the previous one stopped.  The row-piece layout
+// above gives such a wave 3 pieces x 8 patches of 16 .. 64-byte segments per instruction.
+__host__ __device__ inline int64_t patch_il_index(int64_t p, int r, int c, int G, int nc) {
+  const int PW = 64 / G;
+  const int64_t w = p / PW;
+  const int q = (int)(p - w * PW);
+  return ((w * nc + c) * (int64_t)(PW * G) + q * G + (r >> 1)) * 2 + (r & 1);
 }
 
 // Block-CSR on the device.  Two value layouts:
@@ -234,6 +247,11 @@ struct AssemblyDev {
   bool ready = false;
   int nloc = 0;
   int64_t ncell = 0, npairs = 0;
+  int64_t nstate = 0;            // nodes of the state vector the cells index (= the level's nodes; on a partitioned level the
+                                 // local nodes followed by the other nodes of the cells that touch them)
+  double* scratch = nullptr;     // a second value array in the operator's layout (alfi_level_assemble_mult)
+  uint8_t* bc_all = nullptr;     // (n) partitioned levels: Dirichlet dofs among ALL local dofs, ghosts included
+                                 // (alfi_level_set_assembly_bc; the level's own mask marks owned dofs only)
   int64_t* cptr = nullptr;       // (nnzb + 1) contributor lists per block
   int32_t* ccell = nullptr;      // (npairs) cell
   uint16_t* cba = nullptr;       // (npairs) b * nloc + a
@@ -301,6 +319,12 @@ struct alfi_level {
   int64_t* inv_ptr = nullptr;     // (npatch+1) offsets (doubles) into inv
   int64_t* stage_ptr = nullptr;   // (npatch+1) offsets into stage (ld_p slots per patch, so 16-byte aligned)
   double* inv = nullptr;          // column-major padded inverses
+  // small-patch levels (all n_p <= 32: the 2-D stars): a wave-contiguous copy of the inverses the additive apply streams
+  // (patch_il_index below); derived from `inv` at the end of every factorisation / repair (kernels_patch.hip)
+  double* inv_il = nullptr;
+  int64_t il_doubles = 0;
+  int il_G = 0, il_nc = 0;        // lanes per patch (row pairs), columns stored per patch (= max_np)
+  bool il_valid = false;
   double* stage = nullptr;        // (sum ld_p) staged patch results
   int64_t stage_len = 0;
   int32_t* dof_ptr = nullptr;     // (n+1) CSR dof -> positions in stage
@@ -334,7 +358,8 @@ struct alfi_level {
   std::vector<int32_t> h_patch_dofs;    // host copy of the patch dofs (needed to build the wavefronts)
   // FGMRES workspace
   int kmax = 0;
-  double* V = nullptr;   // (kmax+1) x n
+  int64_t ldv = 0;       // stride of V and Z: n rounded up to even (16-byte aligned basis vectors)
+  double* V = nullptr;   // (kmax+1) x ldv
   double* Z = nullptr;   // kmax x n
   double* w = nullptr;   // n
   double* hs = nullptr;  // small device arrays: Hessenberg etc.
@@ -413,8 +438,15 @@ struct alfi_saddle {
   bool has_Minv = false;
   double nu = 0, gamma = 0;
   bool remove_nullspace = false;
+  // partitioned finest level: vectors hold (owned velocity dofs | owned pressure dofs); B has the rank's pressure rows over
+  // ALL local velocity dofs (owned + ghost), BT the local velocity rows (ghost rows = contributions for their owners)
+  bool par = false;
+  int64_t n_loc = 0;          // local velocity dofs incl. ghost slots (the length of a level vector)
+  double np_global = 0.0;     // pressure dofs of all ranks (mean removal)
+  double *wa = nullptr, *wb = nullptr, *wc = nullptr;   // level vectors (n_loc)
   // outer FGMRES workspace
   int restart = 0;
+  int64_t ldv = 0;            // stride of V, Z: n rounded up to even
   double *V = nullptr, *Z = nullptr, *w = nullptr, *hs = nullptr, *tmp_u = nullptr, *tmp_p = nullptr;
 };
 
@@ -450,6 +482,7 @@ int launch_big_factor(alfi_level* lvl);
 int launch_cond_factor(alfi_level* lvl);
 int launch_cond_apply_range(alfi_level* lvl, int64_t p0, int64_t p1, const double* x);
 int launch_cond_schur_one(alfi_level* lvl, int64_t p, const int64_t* d_zero, double* scr);   // repair path (kernels_check.hip)                                                    // gather + blocked MFMA inversion
+int build_patch_il(alfi_level* lvl);   // small-patch levels: (re)build the interleaved copy of the inverses from lvl->inv
 int launch_patch_sum(alfi_level* lvl, const double* x, double* y);             // stage 2
 int launch_patch_sum_range(alfi_level* lvl, int64_t i0, int64_t i1, const double* x, double* y);   // stage 2, dofs [i0, i1)
 // one dependency wavefront of a multiplicative sweep: patches seq[0..count): y_p += inv(A_p) (x - A y)_p
@@ -482,6 +515,9 @@ int launch_hessenberg_scale(alfi_ctx* ctx, const double* partial, int nblocks, c
 int launch_csr_spmv(alfi_ctx* ctx, const DevCSR& A, const double* x, double* y, const double* b, double alpha, int mode);
 int launch_scale_rows(alfi_ctx* ctx, double* y, const double* x, const double* d, double a, int64_t n);  // y = a d x
 int launch_remove_mean(alfi_ctx* ctx, double* x, int64_t n);
+int launch_sum_to(alfi_ctx* ctx, const double* x, int64_t n, double* out);             // *out = sum(x), fixed order
+int launch_sub_scaled(alfi_ctx* ctx, double* x, int64_t n, const double* s, double f); // x -= f * *s
+int launch_add(alfi_ctx* ctx, double* y, const double* a, const double* b, int64_t n); // y = a + b
 int launch_xmy(alfi_ctx* ctx, double* w, const double* b, int64_t n);                                   // w = b - w                                            // x -= mean(x)
 // halo helpers
 int launch_halo_pack(alfi_ctx* ctx, double* buf, const double* v, const int32_t* nodes, int64_t nnodes, int bs);
@@ -503,14 +539,12 @@ int launch_patch_sum_scale(alfi_level* lvl, const double* w, double* z, double* 
 // w = A z with the partials of V_v . w (v < nv <= 16) in the same pass; *nblocks = number of partials per vector
 int launch_bsr_spmv_dot(alfi_ctx* ctx, const DevBSR& A, const double* z, double* w, const double* V, int64_t stride, int nv,
                         double* partial, int* nblocks);
-int launch_assemble_gather(alfi_level* lvl, double nu, double gamma, double adv, const double* d_state, int apply_bc);
+int launch_assemble_gather(alfi_level* lvl, double nu, double gamma, double adv, const double* d_state, int apply_bc,
+                           double* out_vals);   // out_vals: the operator's layout (lvl->A.vals, or a scratch copy)
 int launch_vals_from_lanes(alfi_ctx* ctx, const DevBSR& A, double* d_out);
 int launch_supg(alfi_level* lvl, double nu, double weight, double magic, const double* d_state, int add_vals, double* d_F);
 int launch_apply_bc(alfi_level* lvl);
 int launch_patch_invert_mfma(alfi_ctx* ctx, int64_t npatch, int max_np, const int64_t* patch_ptr, const int64_t* inv_ptr,
                              double* inv, int* status, int* handled);   // kernels_invert.hip
-// one-workgroup FGMRES(k) + patch smoother of a tiny level (kernels_tiny.hip)
-int64_t tiny_level_bytes(const alfi_level* lvl);
-int launch_smooth_tiny(alfi_level* lvl, int k, const double* db, double* dx, int nonzero_guess);
 int launch_fgmres_finish_fused(alfi_ctx* ctx, const double* normpart, int nblocks, const double* h, double* hs, int k, int K);
 int launch_update_solution(alfi_ctx* ctx, double* x, const double* Z, int64_t stride, int k, const double* y, int64_t n);

@@ -230,13 +230,17 @@ int alfi_host_assemble_bsr(int64_t ncell, int nloc, int d, const int32_t* cell_n
 // BSR sparsity the (cell, b * nloc + a) pairs with r = node a and c = node b of the cell, cells ascending and, inside a cell, b
 // ascending -- a fixed order, so that the device sums every operator entry in the same order on every run (no atomics).
 // cptr: (nnzb + 1) int64.  Call with ccell == nullptr to fill cptr only (counting pass).
+// nindex >= nnode: cell_nodes may name nodes beyond the nnode rows of the sparsity (a rank's cells reach nodes it holds no
+// operator row for); partial != 0: pairs whose block is not in the sparsity are skipped instead of being an error (ghost rows
+// restricted to local columns).
 int alfi_host_contributors(int64_t ncell, int nloc, const int32_t* cell_nodes, int64_t nnode, const int32_t* rowptr,
-                           const int32_t* colidx, int64_t* cptr, int32_t* ccell, uint16_t* cba) {
-  std::vector<int64_t> nptr(nnode + 1, 0);                  // node -> cells (ascending)
+                           const int32_t* colidx, int64_t* cptr, int32_t* ccell, uint16_t* cba, int64_t nindex, int partial) {
+  if (nindex < nnode) nindex = nnode;
+  std::vector<int64_t> nptr(nindex + 1, 0);                 // node -> cells (ascending)
   for (int64_t c = 0; c < ncell; ++c)
     for (int a = 0; a < nloc; ++a) nptr[cell_nodes[c * nloc + a] + 1]++;
-  for (int64_t i = 0; i < nnode; ++i) nptr[i + 1] += nptr[i];
-  std::vector<int32_t> ncells(nptr[nnode]);
+  for (int64_t i = 0; i < nindex; ++i) nptr[i + 1] += nptr[i];
+  std::vector<int32_t> ncells(nptr[nindex]);
   {
     std::vector<int64_t> fill(nptr.begin(), nptr.end() - 1);
     for (int64_t c = 0; c < ncell; ++c)
@@ -262,7 +266,7 @@ int alfi_host_contributors(int64_t ncell, int nloc, const int32_t* cell_nodes, i
         for (int b = 0; b < nloc; ++b) {
           const int64_t pos = find_col(colidx, lo, hi, cn[b]);
           if (pos >= hi || colidx[pos] != cn[b]) {
-            err = 1;
+            if (!partial) err = 1;
             continue;
           }
           if (counting) {

@@ -382,17 +382,18 @@ __global__ void vals_from_lanes_kernel(const double* __restrict__ src, double* _
 
 }  // namespace
 
-int launch_assemble_gather(alfi_level* L, double nu, double gamma, double adv, const double* d_state, int apply_bc) {
+int launch_assemble_gather(alfi_level* L, double nu, double gamma, double adv, const double* d_state, int apply_bc,
+                           double* out_vals) {
   alfi_ctx* ctx = L->ctx;
   const AssemblyDev& S = L->asmb;
   const int64_t nnzb = L->A.nnzb;
   dim3 grid((unsigned)((nnzb + 255) / 256)), block(256);
   if (L->bs == 2)
     hipLaunchKernelGGL(assemble_gather_kernel<2>, grid, block, 0, ctx->stream, nnzb, S.nloc, S.cptr, S.ccell, S.cba, S.cell_nodes,
-                       S.grad, S.vol, S.Ta, S.Tb, S.Kv, S.Dv, d_state, L->bc_mask, nu, gamma, adv, apply_bc, L->A.vals);
+                       S.grad, S.vol, S.Ta, S.Tb, S.Kv, S.Dv, d_state, S.bc_all ? S.bc_all : L->bc_mask, nu, gamma, adv, apply_bc, out_vals);
   else
     hipLaunchKernelGGL(assemble_gather_kernel<3>, grid, block, 0, ctx->stream, nnzb, S.nloc, S.cptr, S.ccell, S.cba, S.cell_nodes,
-                       S.grad, S.vol, S.Ta, S.Tb, S.Kv, S.Dv, d_state, L->bc_mask, nu, gamma, adv, apply_bc, L->A.vals);
+                       S.grad, S.vol, S.Ta, S.Tb, S.Kv, S.Dv, d_state, S.bc_all ? S.bc_all : L->bc_mask, nu, gamma, adv, apply_bc, out_vals);
   ALFI_HIP_CHECK(ctx, hipGetLastError());
   return 0;
 }
@@ -460,9 +461,9 @@ int launch_apply_bc(alfi_level* L) {
   const int64_t nnzb = L->A.nnzb;
   dim3 grid((unsigned)((nnzb + 255) / 256)), block(256);
   if (L->bs == 2)
-    hipLaunchKernelGGL(apply_bc_kernel<2>, grid, block, 0, ctx->stream, nnzb, S.nloc, S.cptr, S.ccell, S.cba, S.cell_nodes, L->bc_mask, L->A.vals);
+    hipLaunchKernelGGL(apply_bc_kernel<2>, grid, block, 0, ctx->stream, nnzb, S.nloc, S.cptr, S.ccell, S.cba, S.cell_nodes, S.bc_all ? S.bc_all : L->bc_mask, L->A.vals);
   else
-    hipLaunchKernelGGL(apply_bc_kernel<3>, grid, block, 0, ctx->stream, nnzb, S.nloc, S.cptr, S.ccell, S.cba, S.cell_nodes, L->bc_mask, L->A.vals);
+    hipLaunchKernelGGL(apply_bc_kernel<3>, grid, block, 0, ctx->stream, nnzb, S.nloc, S.cptr, S.ccell, S.cba, S.cell_nodes, S.bc_all ? S.bc_all : L->bc_mask, L->A.vals);
   ALFI_HIP_CHECK(ctx, hipGetLastError());
   return 0;
 }

@@ -421,6 +421,7 @@ int patch_verify_and_repair(alfi_level* L, int unpivoted_status) {
   (void)hipFree(scratch);
   if (rc != 0) return rc;
   if (st != 0) return alfi_set_error(ctx, ALFI_E_SINGULAR, "a patch operator is singular to working precision (pivoted inversion)");
+  ALFI_CHECK(build_patch_il(L));      // small-patch levels: the repaired inverses into the interleaved copy the apply streams
   // probe again (all patches: the apply kernels work on whole levels)
   ALFI_HIP_CHECK(ctx, hipMemsetAsync(L->chk, 0, 2 * sizeof(double), ctx->stream));
   rc = launch_check(L, tol);

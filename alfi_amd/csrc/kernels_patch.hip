@@ -11,6 +11,7 @@
 // Roofline: apply is a GEMV streaming every inverse once (0.25 flop/B) -> HBM-bound; algorithmic bytes per patch
 // 8 n_p^2 + 28 n_p.  Inversion is 2 n_p^3 flops per patch in FP64; gfx950's FP64 MFMA rate
 // equals its FP64 vector rate (78.6 TF), so the inversion runs as a register-tiled Gauss-Jordan on the vector ALUs.
+#include <algorithm>
 #include <cstdlib>
 #include "common.h"
 
@@ -348,6 +349,82 @@ __global__ __launch_bounds__(256) void patch_apply_small_kernel(int64_t p0, int6
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// 3a'. the same apply from the INTERLEAVED copy of the inverses (patch_il_index, common.h): G lanes per patch, PW = 64 / G
+//      patches per wave, column c of the wave's PW patches = ONE contiguous request of PW * G * 16 bytes, the whole wave
+//      group nc such requests back to back.  (From the row-piece layout a wave instruction of the kernel above touches
+//      3 pieces x 8 patches: 24 segments of 16 .. 64 bytes in as many lines -- 4.1 TB/s on ldc2d's finest level.)
+//      G = ceil(max_np / 2) need not be a power of two (the 2-D stars: n_p = 14, G = 7, 9 patches per wave).
+// ---------------------------------------------------------------------------------------------------------------------
+template <int G, bool NT>
+__global__ __launch_bounds__(256) void patch_apply_il_kernel(int64_t p0, int64_t p1, int nc,
+                                                              const int64_t* __restrict__ patch_ptr,
+                                                              const int32_t* __restrict__ patch_dofs,
+                                                              const int64_t* __restrict__ stage_ptr,
+                                                              const double* __restrict__ il,
+                                                              const double* __restrict__ x, double* __restrict__ stage) {
+  constexpr int PW = 64 / G, LW = PW * G;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int64_t w = p0 / PW + (int64_t)blockIdx.x * 4 + wave;     // wave group; the grid covers [p0 / PW, (p1 - 1) / PW]
+  const int q = lane / G, l = lane - q * G;
+  const int64_t p = w * PW + q;
+  const bool inwave = lane < LW && w * PW < p1;                    // the group exists (its storage is allocated whole)
+  const bool live = inwave && p >= p0 && p < p1;
+  int n = 0;
+  int64_t off = 0;
+  if (live) {
+    off = patch_ptr[p];
+    n = (int)(patch_ptr[p + 1] - off);
+  }
+  double xa = 0.0, xb = 0.0;   // x_p[l], x_p[l + G]
+  if (l < n) xa = x[patch_dofs[off + l]];
+  if (l + G < n) xb = x[patch_dofs[off + l + G]];
+  // all nc columns of the lane's row pair are requested before the first one is used
+  const double* base = il + ((w * nc) * (int64_t)LW + lane) * 2;
+  double2 v[2 * G];
+#pragma unroll
+  for (int c = 0; c < 2 * G; ++c)
+    v[c] = (inwave && c < nc) ? load_pair<NT>(base + (int64_t)c * (2 * LW)) : make_double2(0.0, 0.0);
+  double acc0 = 0.0, acc1 = 0.0;
+  const int src0 = q * G;
+#pragma unroll
+  for (int c = 0; c < 2 * G; ++c) {
+    const double xc = __shfl(c < G ? xa : xb, src0 + (c < G ? c : c - G), 64);
+    acc0 = __builtin_fma(v[c].x, xc, acc0);
+    acc1 = __builtin_fma(v[c].y, xc, acc1);
+  }
+  // rows >= n of the interleaved copy are zero, so storing the pair is valid whenever its first row exists (stage has ld slots)
+  if (live && 2 * l < n) *reinterpret_cast<double2*>(stage + stage_ptr[p] + 2 * l) = make_double2(acc0, acc1);
+}
+
+// interleaved copy <- row-piece storage: one thread per (wave group, column, lane) writes its 16 bytes
+__global__ __launch_bounds__(256) void patch_il_build_kernel(int64_t npatch, int G, int nc, int64_t total,
+                                                              const int64_t* __restrict__ patch_ptr,
+                                                              const int64_t* __restrict__ inv_ptr,
+                                                              const double* __restrict__ inv, double* __restrict__ il) {
+  const int PW = 64 / G, LW = PW * G;
+  for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
+    const int lane = (int)(t % LW);
+    const int64_t wc = t / LW;
+    const int c = (int)(wc % nc);
+    const int64_t w = wc / nc;
+    const int q = lane / G, l = lane - q * G;
+    const int64_t p = w * PW + q;
+    double2 o = make_double2(0.0, 0.0);
+    if (p < npatch) {
+      const int n = (int)(patch_ptr[p + 1] - patch_ptr[p]);
+      const int ld = (n + 1) & ~1;
+      const int r = 2 * l;
+      if (c < n && r < ld) {
+        const double* S = inv + inv_ptr[p];
+        o.x = S[patch_inv_index(r, c, n, ld)];
+        o.y = r + 1 < n ? S[patch_inv_index(r + 1, c, n, ld)] : 0.0;
+      }
+    }
+    *reinterpret_cast<double2*>(il + t * 2) = o;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // 3b. multiplicative sweep, one dependency wavefront: one wave per patch p of the wavefront,
 //       r_p = x_p - (A y)_p ,   y_p += inv(A_p) r_p .
 //     The patches of a wavefront are mutually uncoupled (no operator entry links them), so they neither read what another
@@ -650,7 +727,26 @@ int launch_patch_apply_range(alfi_level* L, int64_t p0, int64_t p1, const double
   // the inverses are read once per apply: nontemporal loads keep x, the staging buffer and the index arrays in cache
   static const bool nt = !(getenv("ALFI_NT") && atoi(getenv("ALFI_NT")) == 0);
   static const bool small_ok = !(getenv("ALFI_SMALL_PATCH") && atoi(getenv("ALFI_SMALL_PATCH")) == 0);
-  if (small_ok && L->max_np <= 32) {
+  if (L->il_valid) {
+    // small patches, interleaved copy of the inverses: G lanes per patch, 64 / G patches per wave
+    const int PW = 64 / L->il_G;
+    const int64_t nwave = (p1 - 1) / PW - p0 / PW + 1;
+    dim3 igrid((unsigned)((nwave + 3) / 4));
+#define ALFI_IL(GV)                                                                                                      \
+  case GV:                                                                                                               \
+    if (nt)                                                                                                              \
+      hipLaunchKernelGGL((patch_apply_il_kernel<GV, true>), igrid, block, 0, ctx->stream, p0, p1, L->il_nc, L->patch_ptr, \
+                         L->patch_dofs, L->stage_ptr, L->inv_il, x, L->stage);                                           \
+    else                                                                                                                 \
+      hipLaunchKernelGGL((patch_apply_il_kernel<GV, false>), igrid, block, 0, ctx->stream, p0, p1, L->il_nc, L->patch_ptr, \
+                         L->patch_dofs, L->stage_ptr, L->inv_il, x, L->stage);                                           \
+    break;
+    switch (L->il_G) {
+      ALFI_IL(4) ALFI_IL(7) ALFI_IL(8) ALFI_IL(12) ALFI_IL(16)
+      default: return alfi_set_error(ctx, ALFI_E_STATE, "interleaved patch storage with %d lanes per patch", L->il_G);
+    }
+#undef ALFI_IL
+  } else if (small_ok && L->max_np <= 32) {
     // small patches: G lanes per patch, 64 / G patches per wave
     const int G = L->max_np <= 16 ? 8 : 16;
     dim3 sgrid((unsigned)((cnt * G + 255) / 256));
@@ -688,6 +784,37 @@ int launch_patch_sum_range(alfi_level* L, int64_t i0, int64_t i1, const double* 
 }
 
 int launch_patch_sum(alfi_level* L, const double* x, double* y) { return launch_patch_sum_range(L, 0, L->n, x, y); }
+
+// Small-patch levels (every n_p <= 32, dense inverses): (re)build the interleaved copy the additive apply streams.  Called
+// at the end of every factorisation and after a pivoted repair has rewritten some inverses.  ALFI_PATCH_IL=0: the apply
+// keeps reading the row-piece storage (A/B measurements).
+int build_patch_il(alfi_level* L) {
+  alfi_ctx* ctx = L->ctx;
+  L->il_valid = false;
+  static const bool allow = !(getenv("ALFI_PATCH_IL") && atoi(getenv("ALFI_PATCH_IL")) == 0);
+  if (!allow || L->cond || L->npatch == 0 || L->max_np > 32 || L->inv_shrunk) return 0;
+  const int need = (L->max_np + 1) / 2;
+  const int G = need <= 4 ? 4 : need <= 7 ? 7 : need <= 8 ? 8 : need <= 12 ? 12 : 16;
+  const int PW = 64 / G, LW = PW * G, nc = L->max_np;
+  const int64_t ngroups = (L->npatch + PW - 1) / PW;
+  const int64_t total = ngroups * nc * LW;          // 16-byte entries
+  if (!L->inv_il || L->il_doubles != 2 * total) {
+    ALFI_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    if (L->inv_il) (void)hipFree(L->inv_il);
+    L->inv_il = nullptr;
+    L->il_doubles = 0;
+    ALFI_HIP_CHECK(ctx, hipMalloc((void**)&L->inv_il, sizeof(double) * (size_t)(2 * total)));
+    L->il_doubles = 2 * total;
+  }
+  const int64_t blocks = std::min<int64_t>((total + 255) / 256, 8192);
+  hipLaunchKernelGGL(patch_il_build_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, L->npatch, G, nc, total,
+                     L->patch_ptr, L->inv_ptr, L->inv, L->inv_il);
+  ALFI_HIP_CHECK(ctx, hipGetLastError());
+  L->il_G = G;
+  L->il_nc = nc;
+  L->il_valid = true;
+  return 0;
+}
 
 int launch_patch_apply(alfi_level* L, const double* x, double* y) {
   ALFI_CHECK(launch_patch_apply_range(L, 0, L->npatch, x));

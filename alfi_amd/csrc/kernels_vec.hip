@@ -699,17 +699,44 @@ __device__ __forceinline__ void block_reduce_partials(const double* __restrict__
 }
 
 // partial[b][v] = sum over the block's slice of V_v[i] * w[i]   (gridDim.x blocks: RED_BLOCKS, or fewer on small levels)
-template <int NV>
+// VEC: every vector starts on a 16-byte boundary (even stride): a lane reads entry PAIRS, one 16-byte load per vector and
+// iteration -- the scalar form (8 bytes per lane and load) ran at 1.7-2 TB/s on a 1.2 M-dof level with ~1 workgroup per CU
+typedef double vec_d2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ vec_d2 ld2(const double* p, int64_t i2) { return reinterpret_cast<const vec_d2*>(p)[i2]; }
+__device__ __forceinline__ void st2(double* p, int64_t i2, vec_d2 v) { reinterpret_cast<vec_d2*>(p)[i2] = v; }
+__host__ inline bool vec2_ok(const void* a, const void* b, int64_t stride) {
+  return (stride & 1) == 0 && ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b)) & 15) == 0;
+}
+
+template <int NV, bool VEC>
 __global__ __launch_bounds__(256) void multi_dot_kernel(const double* __restrict__ V, int64_t stride,
                                                          const double* __restrict__ w, double* __restrict__ partial,
                                                          int64_t n) {
   double acc[NV];
 #pragma unroll
   for (int v = 0; v < NV; ++v) acc[v] = 0.0;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-    const double wi = w[i];
+  if (VEC) {
+    const int64_t n2 = n >> 1;
+#pragma unroll 2
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n2; i += (int64_t)gridDim.x * 256) {
+      const vec_d2 wi = ld2(w, i);
 #pragma unroll
-    for (int v = 0; v < NV; ++v) acc[v] = __builtin_fma(V[v * stride + i], wi, acc[v]);
+      for (int v = 0; v < NV; ++v) {
+        const vec_d2 a = ld2(V + v * stride, i);
+        acc[v] = __builtin_fma(a.y, wi.y, __builtin_fma(a.x, wi.x, acc[v]));
+      }
+    }
+    if ((n & 1) && blockIdx.x == gridDim.x - 1 && threadIdx.x == 255) {     // the odd last entry
+      const double wi = w[n - 1];
+#pragma unroll
+      for (int v = 0; v < NV; ++v) acc[v] = __builtin_fma(V[v * stride + n - 1], wi, acc[v]);
+    }
+  } else {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+      const double wi = w[i];
+#pragma unroll
+      for (int v = 0; v < NV; ++v) acc[v] = __builtin_fma(V[v * stride + i], wi, acc[v]);
+    }
   }
   block_store_partials<NV>(acc, partial);
 }
@@ -734,7 +761,7 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const double* __re
 
 // w -= sum_v h[v] V_v ; partial[b][0] = sum of w^2 over the block's slice.  hblocks > 0: h is not given but reduced here
 // from the hblocks (<= 256) dot partials hpart[b][v] of the preceding multi_dot_kernel; block 0 publishes it in h.
-template <int NV>
+template <int NV, bool VEC>
 __global__ __launch_bounds__(256) void multi_axpy_norm_kernel(const double* __restrict__ V, int64_t stride,
                                                                double* __restrict__ h, double* __restrict__ w,
                                                                double* __restrict__ partial, int64_t n,
@@ -751,29 +778,73 @@ __global__ __launch_bounds__(256) void multi_axpy_norm_kernel(const double* __re
     for (int v = 0; v < NV; ++v) hv[v] = h[v];
   }
   double acc[1] = {0.0};
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-    double wi = w[i];
+  if (VEC) {
+    const int64_t n2 = n >> 1;
+#pragma unroll 2
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n2; i += (int64_t)gridDim.x * 256) {
+      vec_d2 wi = ld2(w, i);
 #pragma unroll
-    for (int v = 0; v < NV; ++v) wi = __builtin_fma(-hv[v], V[v * stride + i], wi);
-    w[i] = wi;
-    acc[0] = __builtin_fma(wi, wi, acc[0]);
+      for (int v = 0; v < NV; ++v) {
+        const vec_d2 a = ld2(V + v * stride, i);
+        wi.x = __builtin_fma(-hv[v], a.x, wi.x);
+        wi.y = __builtin_fma(-hv[v], a.y, wi.y);
+      }
+      st2(w, i, wi);
+      acc[0] = __builtin_fma(wi.y, wi.y, __builtin_fma(wi.x, wi.x, acc[0]));
+    }
+    if ((n & 1) && blockIdx.x == gridDim.x - 1 && threadIdx.x == 255) {
+      double wi = w[n - 1];
+#pragma unroll
+      for (int v = 0; v < NV; ++v) wi = __builtin_fma(-hv[v], V[v * stride + n - 1], wi);
+      w[n - 1] = wi;
+      acc[0] = __builtin_fma(wi, wi, acc[0]);
+    }
+  } else {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+      double wi = w[i];
+#pragma unroll
+      for (int v = 0; v < NV; ++v) wi = __builtin_fma(-hv[v], V[v * stride + i], wi);
+      w[i] = wi;
+      acc[0] = __builtin_fma(wi, wi, acc[0]);
+    }
   }
   block_store_partials<1>(acc, partial);
 }
 
 // x += sum_v y[v] Z_v
-template <int NV>
+template <int NV, bool VEC>
 __global__ __launch_bounds__(256) void multi_axpy_add_kernel(const double* __restrict__ Z, int64_t stride,
                                                               const double* __restrict__ y, double* __restrict__ x,
                                                               int64_t n) {
   double yv[NV];
 #pragma unroll
   for (int v = 0; v < NV; ++v) yv[v] = y[v];
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-    double xi = x[i];
+  if (VEC) {
+    const int64_t n2 = n >> 1;
+#pragma unroll 2
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n2; i += (int64_t)gridDim.x * 256) {
+      vec_d2 xi = ld2(x, i);
 #pragma unroll
-    for (int v = 0; v < NV; ++v) xi = __builtin_fma(yv[v], Z[v * stride + i], xi);
-    x[i] = xi;
+      for (int v = 0; v < NV; ++v) {
+        const vec_d2 a = ld2(Z + v * stride, i);
+        xi.x = __builtin_fma(yv[v], a.x, xi.x);
+        xi.y = __builtin_fma(yv[v], a.y, xi.y);
+      }
+      st2(x, i, xi);
+    }
+    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+      double xi = x[n - 1];
+#pragma unroll
+      for (int v = 0; v < NV; ++v) xi = __builtin_fma(yv[v], Z[v * stride + n - 1], xi);
+      x[n - 1] = xi;
+    }
+  } else {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+      double xi = x[i];
+#pragma unroll
+      for (int v = 0; v < NV; ++v) xi = __builtin_fma(yv[v], Z[v * stride + i], xi);
+      x[i] = xi;
+    }
   }
 }
 
@@ -941,10 +1012,15 @@ int launch_multi_dot(alfi_ctx* ctx, const double* V, int64_t stride, int nv, con
   const int G = red_blocks_for(n);
   for (int v0 = 0; v0 < nv; v0 += 16) {
     const int cnt = nv - v0 < 16 ? nv - v0 : 16;
+    const bool vec = vec2_ok(V + (int64_t)v0 * stride, w, stride);
 #define ALFI_CASE(N)                                                                                              \
   case N:                                                                                                         \
-    hipLaunchKernelGGL(multi_dot_kernel<N>, dim3(G), dim3(256), 0, ctx->stream, V + (int64_t)v0 * stride,          \
-                       stride, w, ctx->red_partial, n);                                                           \
+    if (vec)                                                                                                      \
+      hipLaunchKernelGGL((multi_dot_kernel<N, true>), dim3(G), dim3(256), 0, ctx->stream, V + (int64_t)v0 * stride, \
+                         stride, w, ctx->red_partial, n);                                                         \
+    else                                                                                                          \
+      hipLaunchKernelGGL((multi_dot_kernel<N, false>), dim3(G), dim3(256), 0, ctx->stream, V + (int64_t)v0 * stride, \
+                         stride, w, ctx->red_partial, n);                                                         \
     break;
     ALFI_NV_SWITCH(cnt, ALFI_CASE)
 #undef ALFI_CASE
@@ -964,10 +1040,15 @@ int launch_multi_axpy_norm(alfi_ctx* ctx, const double* V, int64_t stride, int n
   const int G = red_blocks_for(n);
   for (int v0 = 0; v0 < nv; v0 += 16) {
     const int cnt = nv - v0 < 16 ? nv - v0 : 16;
-#define ALFI_CASE(N)                                                                                             \
-  case N:                                                                                                        \
-    hipLaunchKernelGGL(multi_axpy_norm_kernel<N>, dim3(G), dim3(256), 0, ctx->stream,                            \
-                       V + (int64_t)v0 * stride, stride, h + v0, w, norm_partial, n, ctx->red_partial, hblocks); \
+    const bool vec = vec2_ok(V + (int64_t)v0 * stride, w, stride);
+#define ALFI_CASE(N)                                                                                               \
+  case N:                                                                                                          \
+    if (vec)                                                                                                       \
+      hipLaunchKernelGGL((multi_axpy_norm_kernel<N, true>), dim3(G), dim3(256), 0, ctx->stream,                    \
+                         V + (int64_t)v0 * stride, stride, h + v0, w, norm_partial, n, ctx->red_partial, hblocks); \
+    else                                                                                                           \
+      hipLaunchKernelGGL((multi_axpy_norm_kernel<N, false>), dim3(G), dim3(256), 0, ctx->stream,                   \
+                         V + (int64_t)v0 * stride, stride, h + v0, w, norm_partial, n, ctx->red_partial, hblocks); \
     break;
     ALFI_NV_SWITCH(cnt, ALFI_CASE)
 #undef ALFI_CASE
@@ -996,6 +1077,17 @@ __global__ __launch_bounds__(256) void hessenberg_scale_kernel(const double* __r
   const double tt = sqrt(ww ? pythagoras_norm2(ww, h, j) : red[0]);
   if (blockIdx.x == 0 && threadIdx.x == 0) hessenberg_column(hs, K, j, h, tt);
   const double f = tt != 0.0 ? 1.0 / tt : 0.0;
+  if (((reinterpret_cast<uintptr_t>(vnext) | reinterpret_cast<uintptr_t>(w)) & 15) == 0) {     // 16 bytes per lane
+    const int64_t n2 = n >> 1;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n2; i += (int64_t)gridDim.x * 256) {
+      vec_d2 t = ld2(w, i);
+      t.x *= f;
+      t.y *= f;
+      st2(vnext, i, t);
+    }
+    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) vnext[n - 1] = w[n - 1] * f;
+    return;
+  }
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) vnext[i] = w[i] * f;
 }
 
@@ -1016,8 +1108,12 @@ int launch_hessenberg_update(alfi_ctx* ctx, const double* partial, int nblocks, 
 
 int launch_norm_partials(alfi_ctx* ctx, const double* r, int64_t n) {
   // |r|^2 partials (red_blocks_for(n) of them) via the dot kernel with V = w = r
-  hipLaunchKernelGGL(multi_dot_kernel<1>, dim3(red_blocks_for(n)), dim3(256), 0, ctx->stream, r, (int64_t)0, r,
-                     ctx->red_partial, n);
+  if (vec2_ok(r, r, 0))
+    hipLaunchKernelGGL((multi_dot_kernel<1, true>), dim3(red_blocks_for(n)), dim3(256), 0, ctx->stream, r, (int64_t)0, r,
+                       ctx->red_partial, n);
+  else
+    hipLaunchKernelGGL((multi_dot_kernel<1, false>), dim3(red_blocks_for(n)), dim3(256), 0, ctx->stream, r, (int64_t)0, r,
+                       ctx->red_partial, n);
   ALFI_HIP_CHECK(ctx, hipGetLastError());
   return 0;
 }
@@ -1166,10 +1262,16 @@ int launch_update_solution(alfi_ctx* ctx, double* x, const double* Z, int64_t st
                            int64_t n) {
   for (int v0 = 0; v0 < k; v0 += 16) {
     const int cnt = k - v0 < 16 ? k - v0 : 16;
+    const bool vec = vec2_ok(Z + (int64_t)v0 * stride, x, stride);
+    const dim3 grid = ew_grid(vec ? (n + 1) / 2 : n);
 #define ALFI_CASE(N)                                                                                                \
   case N:                                                                                                           \
-    hipLaunchKernelGGL(multi_axpy_add_kernel<N>, ew_grid(n), dim3(256), 0, ctx->stream, Z + (int64_t)v0 * stride,    \
-                       stride, y + v0, x, n);                                                                       \
+    if (vec)                                                                                                        \
+      hipLaunchKernelGGL((multi_axpy_add_kernel<N, true>), grid, dim3(256), 0, ctx->stream, Z + (int64_t)v0 * stride, \
+                         stride, y + v0, x, n);                                                                     \
+    else                                                                                                            \
+      hipLaunchKernelGGL((multi_axpy_add_kernel<N, false>), grid, dim3(256), 0, ctx->stream, Z + (int64_t)v0 * stride, \
+                         stride, y + v0, x, n);                                                                     \
     break;
     ALFI_NV_SWITCH(cnt, ALFI_CASE)
 #undef ALFI_CASE
@@ -1414,5 +1516,29 @@ __global__ void xmy_kernel(double* __restrict__ w, const double* __restrict__ b,
 }
 int launch_xmy(alfi_ctx* ctx, double* w, const double* b, int64_t n) {
   ALFI_LAUNCH_EW(xmy_kernel, n, w, b, n);
+  return 0;
+}
+
+// ---- pieces of the outer solve on partitioned levels (alfi_saddle_*, api.hip) ------------------------------------------
+// *out = sum(x) in one fixed order (the rank's part of a global sum; all-reduced by the caller).  n == 0: *out = 0.
+int launch_sum_to(alfi_ctx* ctx, const double* x, int64_t n, double* out) {
+  hipLaunchKernelGGL(sum_partials_kernel, dim3(RED_BLOCKS), dim3(256), 0, ctx->stream, x, ctx->red_partial, n);
+  ALFI_HIP_CHECK(ctx, hipGetLastError());
+  return launch_reduce_partials(ctx, ctx->red_partial, RED_BLOCKS, 1, out);
+}
+__global__ void sub_scaled_kernel(double* __restrict__ x, const double* __restrict__ s, double f, int64_t n) {
+  const double d = f * *s;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) x[i] -= d;
+}
+int launch_sub_scaled(alfi_ctx* ctx, double* x, int64_t n, const double* s, double f) {
+  ALFI_LAUNCH_EW(sub_scaled_kernel, n, x, s, f, n);
+  return 0;
+}
+__global__ void add_kernel(double* __restrict__ y, const double* __restrict__ a, const double* __restrict__ b, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    y[i] = a[i] + b[i];
+}
+int launch_add(alfi_ctx* ctx, double* y, const double* a, const double* b, int64_t n) {
+  ALFI_LAUNCH_EW(add_kernel, n, y, a, b, n);
   return 0;
 }

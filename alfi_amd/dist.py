@@ -353,6 +353,36 @@ def _map_cols(B, part, nbcols, allow_drop=False):
     return BSR(B.nbrows, nbcols, B.bs, B.rowptr, lc, B.vals)
 
 
+def localize_operator(A, part):
+    """The rank's rows of the (global or lazy) level operator ``A`` in local numbering: owned rows complete, ghost rows
+    restricted to local columns."""
+    bs = A.bs
+    rows = A.select_rows(part.nodes)
+    own = BSR(part.nb_own, A.nbcols, bs, rows.rowptr[:part.nb_own + 1],
+              rows.colidx[:rows.rowptr[part.nb_own]], rows.vals[:rows.rowptr[part.nb_own]])
+    own = _map_cols(own, part, part.nb_loc)                                   # asserts completeness
+    gh_ptr = rows.rowptr[part.nb_own:].astype(np.int64) - rows.rowptr[part.nb_own]
+    gh = BSR(part.nb_ghost, A.nbcols, bs, gh_ptr, rows.colidx[rows.rowptr[part.nb_own]:],
+             rows.vals[rows.rowptr[part.nb_own]:])
+    gh = _map_cols(gh, part, part.nb_loc, allow_drop=True)
+    return BSR(part.nb_loc, part.nb_loc, bs,
+               np.concatenate([own.rowptr.astype(np.int64), own.rowptr[-1] + gh.rowptr[1:].astype(np.int64)]),
+               np.concatenate([own.colidx, gh.colidx]), np.concatenate([own.vals, gh.vals]))
+
+
+def assembly_cells(V, part):
+    """What a rank needs to re-assemble ITS operator rows (owned and ghost) on the device: the mesh cells that touch a
+    local node, their nodes in the numbering of the rank's state vector -- local nodes first (the level's local numbering),
+    then the cells' remaining nodes, ascending global id -- and the global node of every state entry."""
+    gcn = np.asarray(V.cell_nodes, dtype=np.int64)
+    loc = part.g2l(gcn.ravel()).reshape(gcn.shape)
+    cells = np.flatnonzero((loc >= 0).any(axis=1))
+    loc, gcn = loc[cells], gcn[cells]
+    extra = np.unique(gcn[loc < 0])
+    cn = np.where(loc >= 0, loc, part.nb_loc + np.searchsorted(extra, gcn))
+    return cells, cn.astype(np.int32), np.concatenate([part.nodes, extra])
+
+
 def localize_level(L, part):
     """Operator rows of all local nodes (owned rows complete; ghost rows restricted to local columns -- they only feed the
     patch sub-matrix gather), owned Dirichlet dofs, owned patches; everything in local numbering."""
@@ -360,18 +390,7 @@ def localize_level(L, part):
     bs = L.bs
     out.level, out.bs, out.part = L.level, bs, part
     out.n, out.n_own = part.nb_loc * bs, part.nb_own * bs
-    rows = L.A.select_rows(part.nodes)
-    own = BSR(part.nb_own, L.A.nbcols, bs, rows.rowptr[:part.nb_own + 1],
-              rows.colidx[:rows.rowptr[part.nb_own]], rows.vals[:rows.rowptr[part.nb_own]])
-    own = _map_cols(own, part, part.nb_loc)                                   # asserts completeness
-    gh_ptr = rows.rowptr[part.nb_own:].astype(np.int64) - rows.rowptr[part.nb_own]
-    gh = BSR(part.nb_ghost, L.A.nbcols, bs, gh_ptr, rows.colidx[rows.rowptr[part.nb_own]:],
-             rows.vals[rows.rowptr[part.nb_own]:])
-    gh = _map_cols(gh, part, part.nb_loc, allow_drop=True)
-    A = BSR(part.nb_loc, part.nb_loc, bs,
-            np.concatenate([own.rowptr.astype(np.int64), own.rowptr[-1] + gh.rowptr[1:].astype(np.int64)]),
-            np.concatenate([own.colidx, gh.colidx]), np.concatenate([own.vals, gh.vals]))
-    out.A = A
+    out.A = localize_operator(L.A, part)
     bcn = np.asarray(L.bc_dofs, dtype=np.int64)[::bs] // bs
     bcn = np.sort(part.g2l(bcn[(bcn >= part.lo) & (bcn < part.hi)]))
     out.bc_dofs = (bcn[:, None] * bs + np.arange(bs)).ravel().astype(np.int32)
@@ -761,6 +780,18 @@ class DistMultigrid(object):
                 elif LL.part.nb_own > 0:
                     self._coarse(dl, levels[0].A, coarse_inverse)
 
+    def refactor(self, levels=None, coarse_inverse=None):
+        """The operator values changed ON THE DEVICE (alfi_level_assemble): patches re-gathered and re-inverted, the coarse
+        factorisation rebuilt by its owner."""
+        import torch
+        with torch.cuda.stream(self.stream):
+            for dl, LL in zip(self.levels, self.local_levels):
+                if LL.level > 0:
+                    if LL.part.nb_own > 0:
+                        dl.factor_with_fallback()
+                elif LL.part.nb_own > 0:
+                    self._coarse(dl, levels[0].A if levels is not None else None, coarse_inverse)
+
     def local_vec(self, global_array=None):
         """Device vector of the finest level in local numbering (owned + ghost slots), filled from a global array."""
         v = self.ctx.vec(self.n_loc)
@@ -802,19 +833,19 @@ class DistMultigrid(object):
 
 class DistSaddle(object):
     """The outer solve of one Newton step (alfi/solver.py:386-422: FGMRES around PCFIELDSPLIT-Schur-full, fieldsplit_0 = one
-    PCMG full cycle, fieldsplit_1 = DGMassInv) on partitioned levels.  Same algorithm as ``alfi_saddle_solve``; here the
-    host drives the Krylov loop (a handful of iterations, each two full multigrid cycles) with torch tensors on the
-    library's stream, and the library supplies the cycles, the partitioned SpMV, the halo routes and the products with the
-    rank's rows of the discrete divergence.  Velocity dofs are owned with their nodes, pressure dofs with their cells
-    (``localize_pressure``); every reduction is one all-reduce."""
+    PCMG full cycle, fieldsplit_1 = DGMassInv) on partitioned levels.  The whole Krylov loop runs inside the library
+    (``alfi_saddle_solve`` on a partitioned finest level: the same code as on one GPU, every dot product and norm one
+    all-reduce, the products with the rank's rows of the discrete divergence and the halo routes between its kernels); this
+    class cuts the rank's pieces of B and of the pressure mass matrix out of the global ones and hands them over.
+    Velocity dofs are owned with their nodes, pressure dofs with their cells (``localize_pressure``); vectors hold
+    (owned velocity dofs | owned pressure dofs)."""
 
     def __init__(self, dmg, B, mass_diag, cell_nodes, nu, gamma, remove_constant_nullspace=True, mass_inv=None):
         """mass_inv: scipy sparse inverse of the block-diagonal pressure mass matrix (discontinuous P_{k-1} pressure of the
         Scott-Vogelius pair, DGMassInv solver.py:15-38) -- replaces ``mass_diag`` (P0); ``self.cells`` then holds the owned
         pressure ROWS (npc per owned cell)."""
-        import torch
         from . import hip
-        self.dmg, self.nu, self.gamma, self.remove_nullspace = dmg, float(nu), float(gamma), remove_constant_nullspace
+        self.dmg = dmg
         F = dmg.fine
         self.part, self.bs = F.part, F.bs
         self.cells, Bloc, md, Mi = localize_pressure(B, None if mass_inv is not None else mass_diag, cell_nodes, self.part,
@@ -822,120 +853,58 @@ class DistSaddle(object):
         self.n_own, self.n_loc, self.np_own = dmg.n_own, dmg.n_loc, len(self.cells)
         self.n = self.n_own + self.np_own
         self.np_global = int(B.shape[0])
-        dev = dmg.device
-        with torch.cuda.stream(dmg.stream):
-            self.B = hip.Csr(dmg.ctx, Bloc)
-            self.BT = hip.Csr(dmg.ctx, Bloc.T.tocsr())
-            self.Minv = hip.Csr(dmg.ctx, Mi) if Mi is not None else None
-            self.minv = torch.tensor(1.0 / md, dtype=torch.float64, device=dev) if Mi is None else None
-            self.wa, self.wb, self.wc = (torch.zeros(max(self.n_loc, 1), dtype=torch.float64, device=dev) for _ in range(3))
-            self.wq = torch.zeros(max(self.np_own, 1), dtype=torch.float64, device=dev)
-        self.level = dmg.levels[-1]
+        with self._on_stream():
+            # collective: the library all-reduces the number of pressure dofs once
+            self.sad = hip.Saddle(dmg.mg, Bloc, md, nu, gamma, remove_constant_nullspace, mass_inv=Mi, n_u=self.n_own)
 
-    def _raw(self, t):
-        from .hip import RawVec
-        return RawVec(t.data_ptr(), t.numel())
+    def _on_stream(self):
+        """The library's stream current and the callback transport told so (its collectives are torch.distributed calls)."""
+        import contextlib
+        import torch
+        dmg = self.dmg
 
-    def _allsum(self, t):
-        self.dmg.comm.allreduce(t)
-        return t
+        @contextlib.contextmanager
+        def cm():
+            with torch.cuda.stream(dmg.stream):
+                prev, dmg._in_cycle = dmg._in_cycle, True
+                try:
+                    yield
+                finally:
+                    dmg._in_cycle = prev
+        return cm()
+
+    def update(self, nu, gamma):
+        self.sad.update(nu, gamma)
 
     def mult(self, x, y):
-        """y = [A B^T; B 0] x on (owned velocity dofs | owned pressure dofs)."""
-        n_own = self.n_own
-        self.wa[:n_own] = x[:n_own]
-        self.level.spmv(self._raw(self.wa), self._raw(self.wb))                   # ghosts of wa filled, owned rows of A
-        self.B.mult(self._raw(self.wa), self._raw(y[n_own:]))                     # y_p = B u (needs the ghosts)
-        self.BT.mult(self._raw(x[n_own:]), self._raw(self.wc))                    # partial B^T p on all local dofs
-        self.level.halo_reverse_add(self._raw(self.wc))
-        y[:n_own] = self.wb[:n_own] + self.wc[:n_own]
+        """y = [A B^T; B 0] x on (owned velocity dofs | owned pressure dofs); x, y: device vectors (``.ptr``)."""
+        with self._on_stream():
+            self.sad.mult(x, y)
 
     def precond(self, v, z):
         """z = P^-1 v: y_u = MG(b_u); y_p = -(nu + gamma) M^-1 (b_p - B y_u); y_u = MG(b_u - B^T y_p)."""
-        import torch
-        n_own = self.n_own
-        mg = self.dmg.mg
-        self.wa[:n_own] = v[:n_own]
-        mg.fcycle(self._raw(self.wa), self._raw(self.wb))
-        self.level.halo_forward(self._raw(self.wb))
-        self.B.mult(self._raw(self.wb), self._raw(self.wq), b=self._raw(v[n_own:]), alpha=1.0, mode=1)
-        yp = z[n_own:]
-        if self.Minv is not None:                   # block-diagonal M^-1: rows and columns of the rank's own cells only
-            self.Minv.mult(self._raw(self.wq), self._raw(yp))
-        else:
-            torch.mul(self.wq[:self.np_own], self.minv, out=yp)
-        yp.mul_(-(self.nu + self.gamma))
-        self.BT.mult(self._raw(yp), self._raw(self.wc))
-        self.level.halo_reverse_add(self._raw(self.wc))
-        self.wa[:n_own] = v[:n_own] - self.wc[:n_own]
-        mg.fcycle(self._raw(self.wa), self._raw(self.wb))
-        z[:n_own] = self.wb[:n_own]
-        if self.remove_nullspace:
-            tot = self._allsum(yp.sum().reshape(1))
-            yp.sub_(tot[0] / self.np_global)
+        with self._on_stream():
+            self.sad.precond(v, z)
 
     def solve(self, b, rtol=1e-8, atol=1e-8, max_it=500, restart=30):
-        """b: torch tensor (n_own + np_own) on the device, owned entries.  Zero initial guess, KSP's default convergence test
-        on the recurrence residual.  Returns (x, iterations, true residual norm)."""
-        import torch
-        dmg = self.dmg
-        dev = dmg.device
-        n = self.n
-        with torch.cuda.stream(dmg.stream):
-            dmg._in_cycle = True
-            try:
-                x = torch.zeros(n, dtype=torch.float64, device=dev)
-                r = b.clone()
-                bnorm = float(self._allsum((r @ r).reshape(1)).sqrt())
-                tol = max(rtol * bnorm, atol)
-                its, rnorm = 0, bnorm
-                V = torch.zeros((restart + 1, n), dtype=torch.float64, device=dev)
-                Z = torch.zeros((restart, n), dtype=torch.float64, device=dev)
-                w = torch.zeros(n, dtype=torch.float64, device=dev)
-                while rnorm > tol and its < max_it:
-                    beta = rnorm
-                    V[0] = r / beta
-                    H = np.zeros((restart + 1, restart))
-                    cs, sn, grs = np.zeros(restart), np.zeros(restart), np.zeros(restart + 1)
-                    grs[0] = beta
-                    j = 0
-                    while j < restart and its < max_it:
-                        self.precond(V[j], Z[j])
-                        self.mult(Z[j], w)
-                        h = self._allsum(V[:j + 1] @ w)
-                        w -= h @ V[:j + 1]
-                        tt = float(self._allsum((w @ w).reshape(1)).sqrt())
-                        hcol = np.concatenate([h.cpu().numpy(), [tt]])
-                        for i in range(j):
-                            t = hcol[i]
-                            hcol[i] = cs[i] * t + sn[i] * hcol[i + 1]
-                            hcol[i + 1] = -sn[i] * t + cs[i] * hcol[i + 1]
-                        den = np.hypot(hcol[j], hcol[j + 1])
-                        cs[j], sn[j] = hcol[j] / den, hcol[j + 1] / den
-                        grs[j + 1] = -sn[j] * grs[j]
-                        grs[j] = cs[j] * grs[j]
-                        hcol[j], hcol[j + 1] = den, 0.0
-                        H[:j + 2, j] = hcol[:j + 2]
-                        its += 1
-                        rnorm = abs(grs[j + 1])
-                        j += 1
-                        if rnorm <= tol or tt == 0.0:
-                            break
-                        V[j] = w / tt
-                    y = np.linalg.solve(np.triu(H[:j, :j]), grs[:j])
-                    x += torch.as_tensor(y, dtype=torch.float64, device=dev) @ Z[:j]
-                    self.mult(x, w)
-                    r = b - w
-                    rnorm = float(self._allsum((r @ r).reshape(1)).sqrt())
-                return x, its, rnorm
-            finally:
-                dmg._in_cycle = False
+        """b: the rank's entries of the right-hand side (n_own + np_own) as a NumPy array or a torch tensor on the device.
+        Zero initial guess, KSP's default convergence test on the recurrence residual.  Returns (x, iterations, true residual
+        norm), x of the kind b was."""
+        from .hip import RawVec
+        ctx = self.dmg.ctx
+        if hasattr(b, "data_ptr"):            # a torch tensor on the library's device
+            import torch
+            x = torch.empty_like(b)
+            with self._on_stream():
+                its, rn = self.sad.solve(RawVec(b.data_ptr(), self.n), RawVec(x.data_ptr(), self.n), rtol, atol, max_it, restart)
+            return x, its, rn
+        db, dx = ctx.vec(np.ascontiguousarray(b, dtype=np.float64)), ctx.vec(max(self.n, 1))
+        with self._on_stream():
+            its, rn = self.sad.solve(db, dx, rtol, atol, max_it, restart)
+        return dx.get()[:self.n], its, rn
 
     def close(self):
-        self.B.close()
-        self.BT.close()
-        if self.Minv is not None:
-            self.Minv.close()
+        self.sad.close()
 
 
 def _dist_ns_solver_class():
@@ -961,11 +930,108 @@ def _dist_ns_solver_class():
         def _push_operators(self):
             self.dmg.update(self.levels)
 
+        # -- operator refresh on the device, every rank its own rows (alfi/solver.py:320, 325 under solver.py:604-605) ----------
+        def _device_assembly_possible(self):
+            # the Scott-Vogelius hierarchy is not nested (its inject is a sparse product) and SUPG needs the cells' Hessians of
+            # the ghost rows: both keep the host path on partitioned levels
+            return not self.sv and not self.supg
+
+        def _setup_device_assembly(self):
+            """Once per solver: every local level with owned rows gets the cells that touch its local nodes, its rows of the
+            state-independent parts K and D (assembled rank-locally: alfi_amd.lazy) and the contributor lists
+            (alfi_level_set_assembly on a partitioned level); the state of a Newton step is then uploaded per level -- local
+            nodes and the ring of nodes around them, a few megabytes -- and the operators are rebuilt from it on the device.
+            Ranks that hold only ghost copies of a level (the coarse side of the first distributed transfer) skip it: no patch
+            and no product reads those rows."""
+            from .lazy import LazyOperator
+            dmg = self.dmg
+            self._asm = []
+            with self._on_stream():
+                for dl, LL in zip(dmg.levels, dmg.local_levels):
+                    p = LL.part
+                    if p.nb_own == 0:
+                        self._asm.append(None)
+                        continue
+                    L = self.levels[LL.level]
+                    V = L.V
+                    geo, tens = V.mesh.cell_geometry(), V.element.reference_tensors()
+                    K = localize_operator(LazyOperator(V, L.A.rowptr, L.A.colidx, geo, tens, 1.0, 0.0, 0.0, None, with_bc=False), p)
+                    D = localize_operator(LazyOperator(V, L.A.rowptr, L.A.colidx, geo, tens, 0.0, 1.0, 0.0, None, with_bc=False), p)
+                    assert np.array_equal(K.colidx, LL.A.colidx) and np.array_equal(K.rowptr, LL.A.rowptr)
+                    cells, cn, nodes = assembly_cells(V, p)
+                    dl.set_assembly(V, K.vals, D.vals, LL.A.rowptr, LL.A.colidx, cells=cells, cell_nodes=cn)
+                    bcn = np.flatnonzero(V.bc_node_mask[p.nodes])              # Dirichlet nodes among ALL local nodes
+                    dl.set_assembly_bc((bcn[:, None] * L.bs + np.arange(L.bs)).ravel())
+                    self._asm.append((nodes, self.ctx.vec(dl.assembly_state_size())))
+                L = self.levels[-1]
+                self._dres = self.ctx.vec(dmg.n_loc)
+                # the residual's divergence products with ALL columns of B (the Jacobian's B, Dirichlet columns zeroed, lives
+                # in the saddle solver): the rank's cells over its local velocity dofs
+                from . import hip
+                rows, Bloc, _, _ = localize_pressure(self.B_raw, None, L.V.cell_nodes, dmg.fine.part, L.bs)
+                self._res_rows = rows
+                self._dB = hip.Csr(self.ctx, Bloc)
+                self._dBT = hip.Csr(self.ctx, Bloc.T.tocsr())
+                self._dp, self._dFp = self.ctx.vec(max(len(rows), 1)), self.ctx.vec(max(len(rows), 1))
+                self._dwc = self.ctx.vec(dmg.n_loc)
+            self._asm_ready = True
+
+        def _upload_states(self, u):
+            for asm, w in zip(self._asm, self._winds(u)[self.dmg.lmin:]):
+                if asm is not None:
+                    asm[1].set(np.ascontiguousarray(w[asm[0]]).ravel())
+
+        def _rediscretise_device(self, u, adv):
+            import time
+            t0 = time.time()
+            with self._on_stream():
+                self._upload_states(u)
+                for asm, dl in zip(self._asm, self.dmg.levels):
+                    if asm is not None:
+                        dl.assemble(self.nu, self.gamma, adv, asm[1] if adv else None, True)
+                self.dmg.sync()
+            t1 = time.time()
+            for L in self.levels:
+                L.nu = self.nu
+            self.dmg.refactor(self.levels)
+            self.dmg.sync()
+            self.timings["assemble_s"] += t1 - t0
+            self.timings["factor_s"] += time.time() - t1
+
+        def _residual_device(self, u, p, adv):
+            """The rank's rows of F_u = (nu K + gamma D + 1/2 N(u)) u + B^T p on the device -- one product with the operator
+            assembled into the level's second value array (alfi_level_assemble_mult: forward halo of u inside), the rank's
+            cells' share of B^T p reverse-added onto the owners -- and its rows of F_p = B u; the pieces are then gathered
+            (the Newton state is replicated)."""
+            L = self.levels[-1]
+            dmg, fin = self.dmg, self.dmg.levels[-1]
+            nodes, st = self._asm[-1]
+            n_own = dmg.n_own
+            with self._on_stream():
+                st.set(np.ascontiguousarray(u.reshape(-1, L.bs)[nodes]).ravel())
+                fin.assemble_mult(self.nu, self.gamma, 0.5 * adv, st if adv else None, st, self._dres)
+                self._dp.set(np.ascontiguousarray(p[self._res_rows]) if len(self._res_rows) else np.zeros(1))
+                self._dBT.mult(self._dp, self._dwc)
+                fin.halo_reverse_add(self._dwc)
+                self._dB.mult(st, self._dFp)
+                f_own = self._dres.get()[:n_own] + self._dwc.get()[:n_own]
+                fp_own = self._dFp.get()[:len(self._res_rows)]
+            Fu, Fp = np.zeros(self.n_u), np.zeros(self.n_p)
+            for dofs, f, rows, fp in dmg.comm.all_gather_object((dmg.fine.part.own_dofs(), f_own, self._res_rows, fp_own)):
+                Fu[dofs] = f
+                Fp[rows] = fp
+            if self._load is not None:
+                Fu -= self._load
+            Fu[L.bc_dofs] = 0.0
+            return Fu, Fp
+
         def _rediscretise(self, u, adv):
             """Every rank assembles ITS rows only: the level operators become lazy (alfi_amd.lazy.LazyOperator: sparsity now,
             values of a row subset on demand) and DistMultigrid.update cuts the rank's rows out of them -- one rank per mesh
             partition assembling its own cells, as in the reference (alfi/solver.py:604-605).  SUPG terms are assembled by
             the global host pass and keep the replicated path."""
+            if self.device_assembly:
+                return self._rediscretise_device(u, adv)
             if self.supg:
                 return super()._rediscretise(u, adv)
             from .lazy import LazyOperator
@@ -981,6 +1047,8 @@ def _dist_ns_solver_class():
             cells instead of two global assemblies on every rank (the replicated host path of the base class, whose cost per
             rank GROWS with the number of ranks sharing the host's cores) -- and the pieces gathered.  SUPG keeps the
             replicated path."""
+            if self.device_assembly:
+                return self._residual_device(u, p, adv)
             if self.supg:
                 return super().residual(u, p, adv)
             from . import _hostlib
@@ -1017,20 +1085,16 @@ def _dist_ns_solver_class():
                         dt.update(self.nu, self.gamma)
             for T in self.transfers:
                 T.nu = self.nu
-            self.saddle.nu, self.saddle.gamma = self.nu, self.gamma
+            self.saddle.update(self.nu, self.gamma)
 
         def _on_stream(self):
             import torch
             return torch.cuda.stream(self.dmg.stream)
 
         def _linear_solve(self, rhs):
-            import torch
             sad, part = self.saddle, self.dmg.fine.part
             loc = np.concatenate([rhs[:self.n_u][part.own_dofs()], rhs[self.n_u:][sad.cells]])
-            x, its, rn = sad.solve(torch.tensor(loc, dtype=torch.float64, device=self.dmg.device), self.rtol, self.atol,
-                                   self.params["ksp_max_it"], 30)
-            self.dmg.sync()
-            x = x.cpu().numpy()
+            x, its, rn = sad.solve(loc, self.rtol, self.atol, self.params["ksp_max_it"], 30)
             pieces = self.dmg.comm.all_gather_object((part.own_dofs(), sad.cells, x[:sad.n_own], x[sad.n_own:]))
             delta = np.zeros(self.n_u + self.n_p)
             for dofs, cells, xu, xp in pieces:
@@ -1039,6 +1103,9 @@ def _dist_ns_solver_class():
             return delta, its, rn
 
         def close(self):
+            if getattr(self, "_asm_ready", False):
+                self._dB.close()
+                self._dBT.close()
             self.saddle.close()
             self.dmg.close()
 

@@ -184,17 +184,27 @@ class Level(object):
         vals = np.ascontiguousarray(vals, dtype=np.float64)
         self.ctx.check(self.ctx.lib.alfi_level_update_values(self.h, _ptr(vals)))
 
-    def set_assembly(self, V, K_vals, D_vals, rowptr, colidx):
+    def set_assembly(self, V, K_vals, D_vals, rowptr, colidx, cells=None, cell_nodes=None):
         """Hand the level what the device-side operator refresh needs (alfi_level_set_assembly): the cells of the nodal
         space ``V`` (alfi_amd.fespace), the advection tensor of its element and the state-independent parts K (viscous) and
-        D (grad-div) of the operator, both (nnzb, bs, bs) on the level's sparsity."""
+        D (grad-div) of the operator, both (nnzb, bs, bs) on the level's sparsity.
+        Partitioned level (alfi_amd.dist): ``cells`` = the mesh cells that touch a local node, ``cell_nodes`` their nodes in
+        the numbering of the rank's state vector (local nodes first, then the cells' other nodes); rowptr / colidx / K / D
+        the LOCAL operator's."""
         from . import _hostlib
         g, vol = V.mesh.cell_geometry()
         T1 = np.ascontiguousarray(V.element.reference_tensors()["T1"], dtype=np.float64)     # [k, i, b, a]
         Ta = np.ascontiguousarray(np.transpose(T1, (2, 3, 0, 1)))                            # [b, a, k, i]
         Tb = np.ascontiguousarray(np.transpose(T1, (0, 3, 1, 2)))                            # [b, a, i, k] = T1[b, i, k, a]
-        cn = np.ascontiguousarray(V.cell_nodes, dtype=np.int32)
-        cptr, ccell, cba = _hostlib.contributors(cn, V.num_nodes, rowptr, colidx)
+        nrows = len(rowptr) - 1
+        if cells is None:
+            cn = np.ascontiguousarray(V.cell_nodes, dtype=np.int32)
+            cptr, ccell, cba = _hostlib.contributors(cn, V.num_nodes, rowptr, colidx)
+        else:
+            cn = np.ascontiguousarray(cell_nodes, dtype=np.int32)
+            g, vol = g[cells], vol[cells]
+            cptr, ccell, cba = _hostlib.contributors(cn, nrows, rowptr, colidx, nindex=int(cn.max()) + 1 if cn.size else nrows,
+                                                     partial=True)
         g = np.ascontiguousarray(g, dtype=np.float64)
         vol = np.ascontiguousarray(vol, dtype=np.float64)
         K = np.ascontiguousarray(K_vals, dtype=np.float64)
@@ -202,6 +212,22 @@ class Level(object):
         self.ctx.check(self.ctx.lib.alfi_level_set_assembly(self.h, cn.shape[0], cn.shape[1], _ptr(cn), _ptr(g), _ptr(vol),
                                                             _ptr(Ta), _ptr(Tb), _ptr(K), _ptr(D), _ptr(cptr), _ptr(ccell),
                                                             _ptr(cba)))
+
+    def set_assembly_bc(self, bc_dofs):
+        """Partitioned level: the Dirichlet dofs among ALL local dofs, ghosts included (alfi_level_set_assembly_bc)."""
+        b = np.ascontiguousarray(bc_dofs, dtype=np.int32)
+        self.ctx.check(self.ctx.lib.alfi_level_set_assembly_bc(self.h, _ptr(b), b.shape[0]))
+
+    def assembly_state_size(self):
+        n = ctypes.c_int64()
+        self.ctx.check(self.ctx.lib.alfi_level_assembly_state_size(self.h, ctypes.byref(n)))
+        return n.value
+
+    def assemble_mult(self, nu, gamma, adv, state, x, y):
+        """y = (nu K + gamma D + adv N(state)) x without boundary conditions, assembled into a second value array
+        (alfi_level_assemble_mult): the level's operator and patch factors stay as they are."""
+        self.ctx.check(self.ctx.lib.alfi_level_assemble_mult(self.h, float(nu), float(gamma), float(adv),
+                                                             state.ptr if state is not None else None, x.ptr, y.ptr))
 
     def set_supg(self, V, rowptr, colidx, nq=None):
         """Quadrature tables for the device-side SUPG terms (alfi_level_set_supg): the rule and tabulation of
@@ -570,9 +596,11 @@ class Saddle(object):
     """Outer solve of one Newton step (alfi/solver.py:386-422): FGMRES around PCFIELDSPLIT-Schur-full with the device
     multigrid as fieldsplit_0 and DGMassInv (solver.py:15-38) as fieldsplit_1."""
 
-    def __init__(self, mg, B, mass_diag, nu, gamma, remove_constant_nullspace=True, mass_inv=None):
+    def __init__(self, mg, B, mass_diag, nu, gamma, remove_constant_nullspace=True, mass_inv=None, n_u=None):
         """mg: hip.Multigrid; B: scipy CSR (pressure dofs x velocity dofs); mass_diag: diagonal of the P0 mass matrix;
-        mass_inv: scipy sparse inverse of a block-diagonal (discontinuous P_k) pressure mass matrix, replaces mass_diag."""
+        mass_inv: scipy sparse inverse of a block-diagonal (discontinuous P_k) pressure mass matrix, replaces mass_diag.
+        On a PARTITIONED finest level (alfi_amd.dist) B holds the rank's pressure rows over all local velocity dofs (owned
+        + ghost), n_u = the owned velocity dofs (vectors are (owned velocity | owned pressure)) and the call is collective."""
         import scipy.sparse as sp
         self.mg, self.ctx = mg, mg.ctx
         B = sp.csr_matrix(B)
@@ -596,7 +624,7 @@ class Saddle(object):
                                                        float(gamma), 1 if remove_constant_nullspace else 0,
                                                        ctypes.byref(h)))
         self.h = h
-        self.n_u, self.n_p = B.shape[1], B.shape[0]
+        self.n_u, self.n_p = (B.shape[1] if n_u is None else int(n_u)), B.shape[0]
         self.n = self.n_u + self.n_p
         if mass_inv is not None:
             Mi = sp.csr_matrix(mass_inv)

@@ -40,9 +40,11 @@ class LazyOperator(object):
 
     is_lazy = True
 
-    def __init__(self, V, rowptr, colidx, geometry, tensors, nu, gamma, adv, wind, full_div=False):
-        """full_div: the Scott-Vogelius grad-div term gamma (div u, div v) (solver.py:616) instead of the cell-averaged one."""
+    def __init__(self, V, rowptr, colidx, geometry, tensors, nu, gamma, adv, wind, full_div=False, with_bc=True):
+        """full_div: the Scott-Vogelius grad-div term gamma (div u, div v) (solver.py:616) instead of the cell-averaged one.
+        with_bc=False: the raw form, Dirichlet rows / columns as assembled (the parts K, D of the device-side refresh)."""
         self.full_div = bool(full_div)
+        self.with_bc = bool(with_bc)
         self.V = V
         self.nbrows = self.nbcols = V.num_nodes
         self.bs = V.dim
@@ -70,7 +72,8 @@ class LazyOperator(object):
                                      gamma=0.0 if self.full_div else self.gamma,
                                      gamma_full=self.gamma if self.full_div else 0.0, adv=self.adv,
                                      wind=self.wind if self.adv else None, row_map=_row_map(V.num_nodes, rows))
-        _hostlib.apply_bc_bsr(len(rows), d, ptr32, cols, vals, self._bcmask, row_ids=rows)
+        if self.with_bc:
+            _hostlib.apply_bc_bsr(len(rows), d, ptr32, cols, vals, self._bcmask, row_ids=rows)
         return BSR(len(rows), self.nbcols, d, ptr32, cols, vals)
 
     def materialise(self):

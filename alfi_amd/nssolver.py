@@ -94,12 +94,17 @@ class HipNavierStokesSolver(object):
             self.B_raw, _ = build_pressure_coupling(L, zero_bc_columns=False)  # all columns: the residual's B
         self._create_device(restriction)
         self._asm_ready = False
+        if self.device_assembly and not self._device_assembly_possible():
+            self.device_assembly = False
         if self.device_assembly:
-            if not hasattr(self, "hmg"):
-                # partitioned levels (alfi_amd.dist) keep the host path (every rank its own rows)
-                self.device_assembly = False
-            else:
+            try:
                 self._setup_device_assembly()
+            except hip.AlfiHipError as e:
+                # (e.g. ALFI_SPMV=legacy: the refresh writes the lane-major operator layout) -- ADVICE r3: fall back, say so
+                import warnings
+                warnings.warn("device-side operator refresh not available (%s): the operators of every Newton step are "
+                              "assembled on the host" % (e,))
+                self.device_assembly = False
         self.rtol, self.atol = self.params["ksp_rtol"], self.params["ksp_atol"]
         tol2, tol3 = (1e-9, 1e-8), (1e-8, 1e-8)                            # snes_rtol / snes_atol, solver.py:484-499
         self.snes_rtol = snes_rtol if snes_rtol is not None else (tol2 if dim == 2 else tol3)[0]
@@ -129,6 +134,9 @@ class HipNavierStokesSolver(object):
         self.hmg.mg.levels[0].coarse_factor_auto()
 
     # -- operator refresh on the device ---------------------------------------------------------------------------------------
+    def _device_assembly_possible(self):
+        return True
+
     def _setup_device_assembly(self):
         """Once: the state-independent parts K (viscous, nu = 1) and D (grad-div, gamma = 1) of every level operator, the cells
         and the contributor lists go to the device (alfi_level_set_assembly); per-level state vectors for the injected field."""
@@ -185,12 +193,12 @@ class HipNavierStokesSolver(object):
 
     def _residual_device(self, u, p, adv):
         """F_u = (nu K + gamma D) u + 1/2 N(u) u + B^T p - f: one product with the operator assembled with HALF the advection
-        term and without boundary conditions (N(u) u = 2 (u . grad) u); the Jacobian is assembled over it before the solve."""
+        term and without boundary conditions (N(u) u = 2 (u . grad) u)."""
         L = self.levels[-1]
         fin = self.hmg.mg.levels[-1]
         self._dstate[-1].set(u)
-        fin.assemble(self.nu, self.gamma, 0.5 * adv, self._dstate[-1] if adv else None, False)
-        fin.spmv(self._dstate[-1], self._dres)
+        # (into a second value array: the level keeps the Jacobian it was factored from -- ADVICE r3)
+        fin.assemble_mult(self.nu, self.gamma, 0.5 * adv, self._dstate[-1] if adv else None, self._dstate[-1], self._dres)
         if adv and self.supg:         # + the SUPG residual, gathered on the device into the same vector
             fin.supg(self.nu, self.supg_weight, self.supg_magic, self._dstate[-1], False, self._dres)
         self._dp.set(p)

@@ -227,8 +227,12 @@ def main_distributed(args, rank, world, local_rank):
         from alfi_amd import _hostlib
         from alfi_amd.shared import build_shared
         nthr = lambda n: _hostlib.lib().alfi_host_set_num_threads(int(n))
-        lv, tr, k = build_shared(lambda: build_problem(args.config, args.verbose, lazy=lazy), rank, dist.barrier,
-                                 "%s_%s" % (os.environ.get("MASTER_PORT", "0"), args.config), set_threads=nthr,
+        def bcast(x):
+            box = [x]
+            dist.broadcast_object_list(box, src=0)
+            return box[0]
+        lv, tr, k = build_shared(lambda: build_problem(args.config, args.verbose, lazy=lazy), rank, bcast, dist.barrier,
+                                 args.config, set_threads=nthr,
                                  all_threads=cpu_share(), my_threads=max(1, cpu_share() // world))
     else:
         lv, tr, k = build_problem(args.config, args.verbose and rank == 0, lazy=lazy)

@@ -60,8 +60,7 @@ enum {
   ALFI_EV_RESTRICT = 6,      /* SchoeberlRestrict */
   ALFI_EV_COARSE = 7,        /* coarse solve */
   ALFI_EV_COMM = 8,          /* halo pack/exchange/unpack and all-reduces (VecScatter / MPI_Allreduce in the reference) */
-  ALFI_EV_KSP_TINY = 9,      /* a whole KSPSolve(FGMRES(k) + PCPATCH) of a tiny level run as one single-workgroup kernel */
-  ALFI_EV_COUNT = 10
+  ALFI_EV_COUNT = 9
 };
 /* on = 1: a hipEvent pair around every launch of the classes above; on = 2: PATCH_APPLY and COMM only (fewer event
  * records on launch-bound levels); on = 3: PATCH_APPLY only; 0: off */
@@ -158,11 +157,26 @@ int alfi_level_update_values(alfi_level* lvl, const double* bvals_host);
  * the level's sparsity) and the contributor lists (cptr (nnzb+1), ccell, cba = b*nloc+a per pair; fixed order).
  * alfi_level_assemble then writes  A = nu K + gamma D + adv N(state)  into the level's operator (the linearisation of
  * alfi/solver.py:565-568 about the DEVICE-resident nodal field `d_state`, n doubles), Dirichlet rows / columns as identity
- * when apply_bc != 0; the patches must be factored again afterwards (alfi_patches_factor).  Unpartitioned levels only. */
+ * when apply_bc != 0; the patches must be factored again afterwards (alfi_patches_factor).
+ * PARTITIONED levels (alfi_level_set_partition first; one rank per mesh partition re-assembling its own patch operators,
+ * alfi/solver.py:604-605): pass the cells that touch a LOCAL node (owned or ghost); cell_nodes index the level's local nodes
+ * and, beyond them (indices >= nbrows), the cells' remaining nodes in any fixed order -- the state vector then holds
+ * alfi_level_assembly_state_size entries, local nodes first --; K, D on the local sparsity; the contributor lists hold only
+ * the pairs whose two nodes are local (at most ncell * nloc^2).  No exchange is involved: every rank reads its own copy of
+ * the state. */
 int alfi_level_set_assembly(alfi_level* lvl, int64_t ncell, int nloc, const int32_t* cell_nodes, const double* grad,
                             const double* vol, const double* Ta, const double* Tb, const double* Kvals_host,
                             const double* Dvals_host, const int64_t* cptr, const int32_t* ccell, const uint16_t* cba);
 int alfi_level_assemble(alfi_level* lvl, double nu, double gamma, double adv, const double* d_state, int apply_bc);
+/* partitioned levels: Dirichlet dofs among ALL local dofs (owned and ghost) for the refresh's identity rows / columns */
+int alfi_level_set_assembly_bc(alfi_level* lvl, const int32_t* bc_dofs_host, int64_t nbc);
+int alfi_level_assembly_state_size(alfi_level* lvl, int64_t* n);   /* doubles d_state must hold (= n of the level, unpartitioned) */
+/* y = (nu K + gamma D + adv N(state)) x, no boundary conditions, the operator assembled into a second value array: the
+ * level's operator and its patch factors stay valid.  The nonlinear residual F_u of alfi/solver.py:565-568 is this product
+ * with x = state and HALF the advection weight (N(u) u = 2 (u . grad) u).  dx, dy: level vectors (on a partitioned level the
+ * ghost slots of dx are filled by the forward exchange, rows of owned nodes are produced). */
+int alfi_level_assemble_mult(alfi_level* lvl, double nu, double gamma, double adv, const double* d_state, const double* dx,
+                             double* dy);
 /* SUPG stabilisation on the device (alfi/stabilisation.py:47-97 with the Shakib coefficient, alfi/solver.py:204-234; the
  * reference's production option `--stabilisation-type supg`).  alfi_level_set_supg (after alfi_level_set_assembly) hands over the
  * quadrature tables of the element -- weights wq (nq, summing to 1), phi (nq, nloc), dphi (nq, nloc, d+1), d2phi (nq, nloc, d+1,

@@ -23,6 +23,20 @@ def main():
     dmg = DistMultigrid(lv, tr, k, robust_restriction=bool(robust), min_dofs=min_dofs)
     if os.environ.get("ALFI_TEST_EXPECT_TRANSPORT"):
         assert dmg.transport == os.environ["ALFI_TEST_EXPECT_TRANSPORT"], dmg.transport
+    if len(sys.argv) > 4:
+        # the level smoother alone on a given right-hand side: FGMRES(ks) on the finest level, zero guess
+        ks, bfile = int(sys.argv[4]), sys.argv[5]
+        b = np.load(bfile)
+        db, dx = dmg.local_vec(b), dmg.local_vec()
+        with torch.cuda.stream(dmg.stream):
+            dmg._in_cycle = True
+            dmg.levels[-1].smooth(ks, db, dx, nonzero_guess=False)
+            dmg._in_cycle = False
+        np.savez(os.path.join(out, "rank%d.npz" % rank), dofs=dmg.fine.part.own_dofs(), xs=dmg.owned(dx))
+        dmg.close()
+        dist.barrier()
+        dist.destroy_process_group()
+        return
     b = np.random.default_rng(0).standard_normal(lv[-1].n)
     b[lv[-1].bc_dofs] = 0.0
     db, dx = dmg.local_vec(b), dmg.local_vec()

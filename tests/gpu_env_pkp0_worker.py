@@ -1,6 +1,6 @@
 """Worker of tests/test_gpu_env_variants.py::test_smoother_paths: the FGMRES smoother on every level and the V- / F-cycle of a
 2-D [P2]^2 and a 3-D [P2+FB]^3 hierarchy against the oracle, under whatever ALFI_* switches the parent put in the environment
-(they select among the one-workgroup kernel of tiny levels, the four-launch fused iteration and the general launch chain, and
+(they select between the four-launch fused iteration and the general launch chain, and
 between the direct and the de-duplicated x gathers of the large SpMV).  Prints ``SMOOTH <relerr>`` and ``CYCLE <relerr>``."""
 import os
 import sys

@@ -2,7 +2,7 @@
 // A stand-in for librccl that moves data between PROCESSES SHARING ONE GPU through POSIX shared memory, so that the
 // library's native transport (csrc/comm.hip: neighbour tables, grouped ncclSend / ncclRecv, all-reduces, the asynchronous
 // side stream) can run with 2-4 ranks on the one-GPU test box, where RCCL itself refuses several ranks per device.
-// Selected with ALFI_RCCL_LIB=<this library>; exports exactly the nine entry points comm.hip resolves.
+// Selected with ALFI_RCCL_LIB=<this library>; exports exactly the entry points comm.hip resolves.
 //
 // Semantics kept: stream order (every operation first waits for the work queued on its stream and has finished when the
 // call returns), message order per (source, destination) pair, grouped calls progress all their sends and receives
@@ -147,6 +147,16 @@ ncclResult_t ncclCommInitRank(ncclComm_t* out, int nranks, ncclUniqueId id, int 
   if (rank == 0) shm_unlink(id.internal);   // everybody is attached: the name can go
   c->barrier();
   *out = reinterpret_cast<ncclComm_t>(c);
+  return ncclSuccess;
+}
+
+ncclResult_t ncclCommCount(const ncclComm_t comm, int* count) {
+  *count = reinterpret_cast<const Comm*>(comm)->n;
+  return ncclSuccess;
+}
+
+ncclResult_t ncclCommUserRank(const ncclComm_t comm, int* rank) {
+  *rank = reinterpret_cast<const Comm*>(comm)->rank;
   return ncclSuccess;
 }
 

@@ -22,6 +22,8 @@ CASES = {
     # Scott-Vogelius: macro-star patches (wider ghost layer: solver.py:661-662 asks for overlap 2), macro-cell transfer blocks
     "2d-SV": ("sv2", 2, 2, 2, 100.0, 3, 1),
     "3d-SV-P3": ("sv3", 1, 1, 3, 100.0, 2, 1),
+    # a small 2-D level for the nearly-invariant-Krylov-space test of the partitioned smoother (tests/test_gpu_dist.py)
+    "2d-invariant": (2, 2, 1, 2, 10.0, 7, 1),
 }
 
 

@@ -43,11 +43,10 @@ def test_switch(env, tol):
 
 
 @pytest.mark.parametrize("env", [{},                                                  # defaults: four-launch fused iteration on the small levels
-                                 {"ALFI_TINY_BYTES": "1000000"},                      # one-workgroup kernel on the tiny levels
+                                 {"ALFI_PATCH_IL": "0"},                              # small patches applied from the row-piece storage
                                  {"ALFI_FUSED_SMOOTHER": "0"},                        # the general launch chain
                                  {"ALFI_FUSED_ALL": "1"},                             # normalisation folded behind the patch solves on every level
                                  {"ALFI_SMALL_LEVEL_WG": "0"},                        # a wave per patch on every level
-                                 {"ALFI_TINY_BYTES": "1000000000"},                   # every level through the one-workgroup kernel
                                  {"ALFI_SPMV_DEDUP": "0"},                            # direct x gathers in the large SpMV
                                  {"ALFI_SPMV_ALIGNED": "0", "ALFI_FUSED_SMOOTHER": "0"},   # de-duplicated SpMV on small levels too
                                  {"ALFI_SPMV_ALIGNED": "0", "ALFI_XCD_MAP": "1", "ALFI_FUSED_SMOOTHER": "0"},

@@ -73,19 +73,27 @@ def _shared_worker(rank, world, port, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from alfi_amd.problem import ThreeDimLidDrivenCavityProblem, build_hierarchy
-        from alfi_amd.shared import build_shared, _path
-        calls = []
+        import glob
+        from alfi_amd.shared import build_shared, _base
+        calls, names = [], []
 
         def build():
             calls.append(1)
             return build_hierarchy(ThreeDimLidDrivenCavityProblem(2), 1, 2, Re=100.0, lazy=True)
-        lv, tr = build_shared(build, rank, dist.barrier, "test_%d" % port)
+
+        def bcast(x):
+            box = [x]
+            dist.broadcast_object_list(box, src=0)
+            names.append(box[0][1])
+            return box[0]
+        lv, tr = build_shared(build, rank, bcast, dist.barrier, "test_%d" % port)
         L = lv[-1]
         own = L.A.select_rows(np.arange(rank, L.A.nbrows, world))       # rank-local values from the shared integer side
         # copy-on-write: a write by one rank is private to it
         L.patch_dofs[0] = -7 - rank
         dist.barrier()
-        q.put((rank, len(calls), int(L.n), float(np.abs(own.vals).sum()), int(L.patch_dofs[0]), os.path.exists(_path("test_%d" % port))))
+        left = os.path.exists(names[0]) or bool(glob.glob(os.path.join(_base(), "alfi_gen_test_%d_*" % port)))
+        q.put((rank, len(calls), int(L.n), float(np.abs(own.vals).sum()), int(L.patch_dofs[0]), left))
     finally:
         dist.destroy_process_group()
 
@@ -115,44 +123,110 @@ def test_hierarchy_generated_once_and_shared_between_ranks():
     assert not any(o[5] for o in out)                            # file already unlinked
 
 
+def _two_ranks_in_turn(shared, build, tag):
+    """rank 0, then rank 1, in this process: the broadcast is a box rank 0 fills and rank 1 reads"""
+    box = {}
+    r0 = shared.build_shared(build, 0, lambda x: box.setdefault("w", x), lambda: None, tag)
+    return r0, box
+
+
 def test_shared_generation_falls_back_when_the_file_cannot_be_written(tmp_path, monkeypatch):
-    """No room / no /dev/shm: rank 0 leaves a marker (or nothing) instead of the file and every other rank builds its own
-    copy -- slower, never wrong; a partial file is not left behind."""
+    """No room / no /dev/shm: rank 0 broadcasts that there is no file and every other rank builds its own copy -- slower,
+    never wrong; a partial file is not left behind.  A failed GENERATION is broadcast too and raises on every rank."""
     import os
+    import pytest
     from alfi_amd import shared
     made = []
 
     def build():
         made.append(1)
         return {"a": np.arange(1000, dtype=np.int64), "b": [np.ones(7), "x"]}
-    # a directory that does not exist: neither the file nor the marker can be written
-    monkeypatch.setattr(shared, "_path", lambda tag: str(tmp_path / "missing" / ("f_" + tag)))
-    r0 = shared.build_shared(build, 0, lambda: None, "t")
-    r1 = shared.build_shared(build, 1, lambda: None, "t")
+    # a directory that does not exist: the file cannot be created
+    monkeypatch.setattr(shared, "_base", lambda: str(tmp_path / "missing"))
+    r0, box = _two_ranks_in_turn(shared, build, "t")
+    assert box["w"] == ("file", None)
+    r1 = shared.build_shared(build, 1, lambda x: box["w"], lambda: None, "t")
     assert len(made) == 2 and np.array_equal(r0["a"], r1["a"])
-    # the dump dies half way (disk full): the marker is written, no .tmp file stays, rank 1 builds
-    monkeypatch.setattr(shared, "_path", lambda tag: str(tmp_path / ("f_" + tag)))
+    # the dump dies half way (disk full): nothing stays behind, rank 1 builds
+    monkeypatch.setattr(shared, "_base", lambda: str(tmp_path))
     real_dumps = shared.pickle.dumps
-
     monkeypatch.setattr(shared.pickle, "dumps", lambda *a, **k: (_ for _ in ()).throw(OSError(28, "No space left on device")))
     made.clear()
-    # rank 0 and rank 1 in turn; rank 0's second barrier would unlink the marker, so keep its path alive with a no-op unlink
-    monkeypatch.setattr(shared.os, "unlink", lambda p: None)
-    r0 = shared.build_shared(build, 0, lambda: None, "u")
+    r0, box = _two_ranks_in_turn(shared, build, "u")
     monkeypatch.setattr(shared.pickle, "dumps", real_dumps)
-    assert open(str(tmp_path / "f_u"), "rb").read() == b"UNAVAILABLE"
-    r1 = shared.build_shared(build, 1, lambda: None, "u")
+    assert box["w"] == ("file", None) and os.listdir(str(tmp_path)) == []
+    r1 = shared.build_shared(build, 1, lambda x: box["w"], lambda: None, "u")
     assert len(made) == 2 and np.array_equal(r0["a"], r1["a"])
-    assert not [f for f in os.listdir(str(tmp_path)) if ".tmp." in f]
+    # generation fails on rank 0: rank 0 re-raises its error, the others raise instead of waiting or building
+    def bad():
+        raise ValueError("no such config")
+    box = {}
+    with pytest.raises(ValueError):
+        shared.build_shared(bad, 0, lambda x: box.setdefault("w", x), lambda: None, "v")
+    assert box["w"][0] == "error"
+    with pytest.raises(RuntimeError):
+        shared.build_shared(build, 1, lambda x: box["w"], lambda: None, "v")
     # and the normal path round-trips through the file: arrays equal, copy-on-write views
-    monkeypatch.undo()
-    monkeypatch.setattr(shared, "_path", lambda tag: str(tmp_path / ("g_" + tag)))
     obj = build()
     shared.dump(obj, str(tmp_path / "g_v"))
     back = shared.load(str(tmp_path / "g_v"))
     assert np.array_equal(back["a"], obj["a"]) and back["b"][1] == "x"
     back["a"][0] = -1                                   # private write
     assert shared.load(str(tmp_path / "g_v"))["a"][0] == 0
+
+
+def test_shared_file_is_private_and_only_a_private_file_is_unpickled(tmp_path, monkeypatch):
+    """the file rank 0 writes has an unpredictable name, is created exclusively with mode 0600, and a rank
+    unpickles a file only if it is a regular file of its own uid that nobody else can write -- never through a link, never
+    a name somebody else may have planted."""
+    import os
+    import pytest
+    import stat
+    from alfi_amd import shared
+    monkeypatch.setattr(shared, "_base", lambda: str(tmp_path))
+    seen = {}
+
+    def bcast(x):
+        seen["w"] = x
+        st = os.stat(x[1])
+        seen["mode"], seen["uid"] = stat.S_IMODE(st.st_mode), st.st_uid
+        return x
+    obj = {"a": np.arange(10)}
+    shared.build_shared(lambda: obj, 0, bcast, lambda: None, "cfg/with:odd chars")
+    name = os.path.basename(seen["w"][1])
+    assert seen["mode"] == 0o600 and seen["uid"] == os.getuid()
+    assert name.startswith("alfi_gen_cfg_with_odd_chars_") and len(name) > len("alfi_gen_cfg_with_odd_chars_.bin") + 6
+    assert os.listdir(str(tmp_path)) == []                       # unlinked after the barrier
+    # two jobs with the same tag get different files (round 3: one name per uid / MASTER_PORT / config)
+    fd1, p1 = shared._create("same")
+    fd2, p2 = shared._create("same")
+    os.close(fd1), os.close(fd2)
+    assert p1 != p2
+    # dump never overwrites, never follows a link
+    good = str(tmp_path / "good")
+    shared.dump(obj, good)
+    with pytest.raises(FileExistsError):
+        shared.dump(obj, good)
+    os.symlink(good, str(tmp_path / "link"))
+    with pytest.raises(OSError):
+        shared.dump(obj, str(tmp_path / "link"))
+    # load refuses a link and a file others can write
+    with pytest.raises(OSError):
+        shared.load(str(tmp_path / "link"))
+    os.chmod(good, 0o666)
+    with pytest.raises(PermissionError):
+        shared.load(good)
+    os.chmod(good, 0o600)
+    assert np.array_equal(shared.load(good)["a"], obj["a"])
+    # ... and a file of another owner (fstat patched: the test cannot chown)
+    real_fstat = os.fstat
+
+    class _St(object):
+        def __init__(self, st):
+            self.st_mode, self.st_uid = st.st_mode, st.st_uid + 1
+    monkeypatch.setattr(shared.os, "fstat", lambda fd: _St(real_fstat(fd)))
+    with pytest.raises(PermissionError):
+        shared.load(good)
 
 
 def test_lazy_operator_with_the_full_grad_div_term():
