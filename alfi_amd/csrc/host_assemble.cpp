@@ -14,6 +14,7 @@
 #include <cmath>
 #include <cstdint>
 #include <cstring>
+#include <utility>
 #include <vector>
 #include <omp.h>
 
@@ -254,18 +255,24 @@ int alfi_host_contributors(int64_t ncell, int nloc, const int32_t* cell_nodes, i
 #pragma omp parallel
   {
     std::vector<int64_t> cursor;
+    std::vector<std::pair<int32_t, int64_t>> byc;        // the row's (column, block) pairs ascending: a rank's local operator
+                                                         // numbers its columns owned-first, so its rows are not sorted
 #pragma omp for schedule(dynamic, 512)
     for (int64_t r = 0; r < nnode; ++r) {
       const int64_t lo = rowptr[r], hi = rowptr[r + 1];
       if (!counting) cursor.assign(cptr + lo, cptr + hi);
+      byc.resize((size_t)(hi - lo));
+      for (int64_t k = lo; k < hi; ++k) byc[(size_t)(k - lo)] = std::make_pair(colidx[k], k);
+      if (!std::is_sorted(byc.begin(), byc.end())) std::sort(byc.begin(), byc.end());
       for (int64_t q = nptr[r]; q < nptr[r + 1]; ++q) {
         const int32_t cell = ncells[q];
         const int32_t* cn = cell_nodes + (int64_t)cell * nloc;
         int a = 0;
         while (a < nloc && cn[a] != r) ++a;
         for (int b = 0; b < nloc; ++b) {
-          const int64_t pos = find_col(colidx, lo, hi, cn[b]);
-          if (pos >= hi || colidx[pos] != cn[b]) {
+          const auto it = std::lower_bound(byc.begin(), byc.end(), std::make_pair(cn[b], (int64_t)-1));
+          const int64_t pos = (it != byc.end() && it->first == cn[b]) ? it->second : hi;
+          if (pos >= hi) {
             if (!partial) err = 1;
             continue;
           }

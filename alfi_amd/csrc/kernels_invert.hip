@@ -289,6 +289,221 @@ __global__ __launch_bounds__(512) void patch_invert_mfma_kernel(const int64_t* _
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The same elimination with LOOK-AHEAD (round 4).  In the kernel above every one of the 8 waves factors the pivot block,
+// forms its operands, issues its MFMAs and extracts the next panels between the SAME two barriers: the two waves of a SIMD
+// do their vector work together and their matrix work together, so the step costs their SUM (measured: MFMA pipe busy 0.19).
+// Here, per block step s:
+//     all waves      read the factors f(s) of the pivot block and the raw panels from LDS, form the operands
+//     first tiles    the rank-4 update and the fix-ups of the tiles in the tile rows / columns of this AND the next pivot
+//     next panels    their owners put the raw panels of step s + 1 into the other LDS buffer; the ONE wave that owns the next
+//                    pivot tile factors the 4 x 4 block (lu4: four dependent FP64 divisions) and publishes the 28 factors
+//     other tiles    the rank-4 update of the remaining tiles -- the bulk of the MFMAs, issued by waves that have nothing else
+//                    to do while the pivot owner's scalar chain runs                                                -- barrier
+// The LU is done once per step instead of 512 times, the waves of a SIMD are in different phases, and the arithmetic per entry
+// is unchanged (same operands, same order): the inverses are bitwise those of the kernel above.
+struct alignas(16) Lu4Buf {
+  double v[28];
+};
+__device__ __forceinline__ void lu4_store(const Lu4& f, Lu4Buf& o) {
+  o.v[0] = f.l10; o.v[1] = f.l20; o.v[2] = f.l30; o.v[3] = f.l21; o.v[4] = f.l31; o.v[5] = f.l32;
+  o.v[6] = f.u01; o.v[7] = f.u02; o.v[8] = f.u03; o.v[9] = f.u12; o.v[10] = f.u13; o.v[11] = f.u23;
+  o.v[12] = f.i0; o.v[13] = f.i1; o.v[14] = f.i2; o.v[15] = f.i3;
+  o.v[16] = f.s01; o.v[17] = f.s02; o.v[18] = f.s03; o.v[19] = f.s12; o.v[20] = f.s13; o.v[21] = f.s23;
+}
+__device__ __forceinline__ void lu4_load(const Lu4Buf& o, Lu4& f) {
+  f.l10 = o.v[0]; f.l20 = o.v[1]; f.l30 = o.v[2]; f.l21 = o.v[3]; f.l31 = o.v[4]; f.l32 = o.v[5];
+  f.u01 = o.v[6]; f.u02 = o.v[7]; f.u03 = o.v[8]; f.u12 = o.v[9]; f.u13 = o.v[10]; f.u23 = o.v[11];
+  f.i0 = o.v[12]; f.i1 = o.v[13]; f.i2 = o.v[14]; f.i3 = o.v[15];
+  f.s01 = o.v[16]; f.s02 = o.v[17]; f.s03 = o.v[18]; f.s12 = o.v[19]; f.s13 = o.v[20]; f.s23 = o.v[21];
+}
+
+template <int NT>
+__global__ __launch_bounds__(512) void patch_invert_mfma_la_kernel(const int64_t* __restrict__ patch_ptr,
+                                                                    const int64_t* __restrict__ inv_ptr,
+                                                                    double* __restrict__ inv, int* __restrict__ status) {
+  constexpr int N = 16 * NT;
+  constexpr int NA = (NT + 3) / 4;            // tile rows per wave (ti = 4 a + wr)
+  constexpr int NB = (NT + 1) / 2;            // tile columns per wave (tj = 2 b + wc)
+  __shared__ double Rraw[2][4][N];            // raw row panel   A[K, :]
+  __shared__ double Craw[2][N][4];            // raw column panel A[:, K]
+  __shared__ Lu4Buf Fb[2];                    // factors of the pivot block
+  const int64_t p = blockIdx.x;
+  const int n = (int)(patch_ptr[p + 1] - patch_ptr[p]);
+  const int ld = (n + 1) & ~1;
+  double* S = inv + inv_ptr[p];
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int lm = lane & 15, lk = lane >> 4;
+  inv_d4 acc[NA][NB];
+#pragma unroll
+  for (int a = 0; a < NA; ++a)
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      const int ti = 4 * a + wr, tj = 2 * b + wc;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int r = 16 * ti + lk + 4 * g, c = 16 * tj + lm;
+        acc[a][b][g] = (r < n && c < n) ? S[(int64_t)r * ld + c] : (r == c ? 1.0 : 0.0);
+      }
+    }
+  bool bad = false;
+  // panels of step (tk, q) -> LDS buffer s & 1; the owner of the pivot tile factors the block and publishes the factors
+  auto put_panels = [&](auto TK, auto Q) __attribute__((always_inline)) {
+    constexpr int tk = decltype(TK)::value, q = decltype(Q)::value, s = 4 * tk + q, buf = s & 1;
+    constexpr int ar = tk >> 2, bc = tk >> 1;
+    const bool own_r = (tk & 3) == wr, own_c = (tk & 1) == wc;
+    const bool colgrp = (lm >> 2) == q;
+    if (own_r) {
+#pragma unroll
+      for (int b = 0; b < NB; ++b)
+        if (2 * b + wc < NT) Rraw[buf][lk][16 * (2 * b + wc) + lm] = acc[ar][b][q];
+    }
+    if (own_c && colgrp) {
+#pragma unroll
+      for (int a = 0; a < NA; ++a)
+        if (4 * a + wr < NT) {
+#pragma unroll
+          for (int g = 0; g < 4; ++g) Craw[buf][16 * (4 * a + wr) + lk + 4 * g][lm & 3] = acc[a][bc][g];
+        }
+    }
+    if (own_r && own_c) {                      // the 16 entries of the pivot block were written by this wave (LDS is in order)
+      double d[4][4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) d[i][j] = Rraw[buf][i][4 * s + j];
+      Lu4 f;
+      lu4(d, f, bad);
+      if (lane == 0) lu4_store(f, Fb[buf]);
+    }
+  };
+  __syncthreads();  // all loads done before anyone stores (the result goes back in place, in another layout)
+  put_panels(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+  __syncthreads();
+  static_for<0, 4 * NT>([&](auto SS) __attribute__((always_inline)) {
+    constexpr int s = decltype(SS)::value, tk = s >> 2, q = s & 3, buf = s & 1;
+    if (4 * s >= n) return;                   // uniform: the remaining pivots are identity padding
+    constexpr int s1 = s + 1, tk1 = s1 >> 2, q1 = s1 & 3;
+    const bool have_next = s1 < 4 * NT && 4 * s1 < n;        // uniform
+    const bool own_r = (tk & 3) == wr, own_c = (tk & 1) == wc;     // wave-uniform
+    constexpr int ar = tk >> 2, bc = tk >> 1;
+    const bool colgrp = (lm >> 2) == q;
+    Lu4 f;
+    lu4_load(Fb[buf], f);
+    // ---- operands of the rank-4 update (see the kernel above: forward substitutions with the pivots' own L, U entries)
+    const double isel = sel4(lk, f.i0, f.i1, f.i2, f.i3);
+    double bop[NB], aop[NA], vop[NA];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      const int tj = 2 * b + wc;
+      bop[b] = 0.0;
+      if (tj < NT) {
+        const int c = 16 * tj + lm;
+        const double x0 = Rraw[buf][0][c], x1 = Rraw[buf][1][c], x2 = Rraw[buf][2][c], x3 = Rraw[buf][3][c];
+        const double y1 = __builtin_fma(-f.l10, x0, x1);
+        const double y2 = __builtin_fma(-f.l21, y1, __builtin_fma(-f.l20, x0, x2));
+        const double y3 = __builtin_fma(-f.l32, y2, __builtin_fma(-f.l31, y1, __builtin_fma(-f.l30, x0, x3)));
+        const double rv = sel4(lk, x0, y1, y2, y3) * isel;
+        bop[b] = (tj == tk && colgrp) ? 0.0 : rv;
+      }
+    }
+#pragma unroll
+    for (int a = 0; a < NA; ++a) {
+      const int ti = 4 * a + wr;
+      aop[a] = vop[a] = 0.0;
+      if (ti < NT) {
+        const int i = 16 * ti + lm;
+        const double x[4] = {Craw[buf][i][0], Craw[buf][i][1], Craw[buf][i][2], Craw[buf][i][3]};
+        double c[4];
+        col_panel(f, x, c);
+        const double cv = sel4(lk, c[0], c[1], c[2], c[3]);
+        aop[a] = (ti == tk && colgrp) ? 0.0 : cv;
+        vop[a] = cv * isel;
+      }
+    }
+    // ---- first: the tiles of the tile rows / columns tk and tk1 (the fix-ups of this step and the panels of the next read them)
+#pragma unroll
+    for (int a = 0; a < NA; ++a)
+      if (4 * a + wr < NT) {
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+          const int ti = 4 * a + wr, tj = 2 * b + wc;
+          const bool first = ti == tk || ti == tk1 || tj == tk || tj == tk1;       // wave-uniform
+          if (tj < NT && first) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(-aop[a], bop[b], acc[a][b], 0, 0, 0);
+        }
+      }
+    // ---- columns K <- - (A[:, K] U^-1) L^-1, A[K, K] <- U^-1 L^-1
+    if (own_c) {
+      const int cq = lm & 3;
+      const double m10 = -f.l10, m21 = -f.l21, m32 = -f.l32;
+      const double m20 = __builtin_fma(f.l21, f.l10, -f.l20), m31 = __builtin_fma(f.l32, f.l21, -f.l31);
+      const double m30 = __builtin_fma(-m32, f.l20, __builtin_fma(-m31, f.l10, -f.l30));
+      const double li0 = sel4(lk, 1.0, m10, m20, m30), li1 = sel4(lk, 0.0, 1.0, m21, m31), li2 = sel4(lk, 0.0, 0.0, 1.0, m32),
+                   li3 = lk == 3 ? 1.0 : 0.0;
+      const double b2 = colgrp ? -sel4(cq, li0, li1, li2, li3) : 0.0;
+      double dkk = 0.0;
+      {
+        const double x[4] = {lk == 0 ? 1.0 : 0.0, lk == 1 ? 1.0 : 0.0, lk == 2 ? 1.0 : 0.0, lk == 3 ? 1.0 : 0.0};
+        double w[4];
+        times_dinv(f, x, w);
+        dkk = sel4(cq, w[0], w[1], w[2], w[3]);
+      }
+#pragma unroll
+      for (int a = 0; a < NA; ++a)
+        if (4 * a + wr < NT) {
+          const inv_d4 zero = {0.0, 0.0, 0.0, 0.0};
+          const inv_d4 t = __builtin_amdgcn_mfma_f64_16x16x4f64(vop[a], b2, zero, 0, 0, 0);
+          if (colgrp) {
+            const bool pivot_tile = (4 * a + wr) == tk;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) acc[a][bc][g] = (pivot_tile && g == q) ? dkk : t[g];
+          }
+        }
+    }
+    // ---- rows K <- D^-1 A[K, :]
+    if (own_r) {
+#pragma unroll
+      for (int b = 0; b < NB; ++b) {
+        const bool in_k = (2 * b + wc) == tk && colgrp;
+        if (2 * b + wc < NT) {
+          const int c = 16 * (2 * b + wc) + lm;
+          const double x[4] = {Rraw[buf][0][c], Rraw[buf][1][c], Rraw[buf][2][c], Rraw[buf][3][c]};
+          double r[4], z[4];
+          row_panel(f, x, r, z);
+          if (!in_k) acc[ar][b][q] = sel4(lk, z[0], z[1], z[2], z[3]);
+        }
+      }
+    }
+    // ---- the next step's panels (other LDS buffer: everybody finished reading it before the last barrier) and factors
+    if (have_next) put_panels(std::integral_constant<int, (tk1 < NT ? tk1 : 0)>{}, std::integral_constant<int, q1>{});
+    // ---- the other tiles
+#pragma unroll
+    for (int a = 0; a < NA; ++a)
+      if (4 * a + wr < NT) {
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+          const int ti = 4 * a + wr, tj = 2 * b + wc;
+          const bool first = ti == tk || ti == tk1 || tj == tk || tj == tk1;
+          if (tj < NT && !first) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(-aop[a], bop[b], acc[a][b], 0, 0, 0);
+        }
+      }
+    if (have_next) __syncthreads();
+  });
+  if (bad && lane == 0) atomicExch(status, 1);
+#pragma unroll
+  for (int a = 0; a < NA; ++a)
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      const int ti = 4 * a + wr, tj = 2 * b + wc;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int r = 16 * ti + lk + 4 * g, c = 16 * tj + lm;
+        if (ti < NT && tj < NT && r < ld && c < n) S[patch_inv_index(r, c, n, ld)] = (r < n) ? acc[a][b][g] : 0.0;
+      }
+    }
+}
+
 }  // namespace
 
 // in-place inversion (row-major n x ld in, row-piece layout out) of patches with 33 .. 160 dofs on the matrix cores;
@@ -302,14 +517,19 @@ int launch_patch_invert_mfma(alfi_ctx* ctx, int64_t npatch, int max_np, const in
   static const bool all_sizes = getenv("ALFI_INVERT_MFMA") && atoi(getenv("ALFI_INVERT_MFMA")) == 2;
   if (!allow || max_np <= 32 || max_np > 160 || (max_np <= 112 && !all_sizes)) return 0;
   dim3 grid((unsigned)npatch), block(512);
-  if (max_np <= 64)
-    hipLaunchKernelGGL(patch_invert_mfma_kernel<4>, grid, block, 0, ctx->stream, patch_ptr, inv_ptr, inv, status);
-  else if (max_np <= 96)
-    hipLaunchKernelGGL(patch_invert_mfma_kernel<6>, grid, block, 0, ctx->stream, patch_ptr, inv_ptr, inv, status);
-  else if (max_np <= 128)
-    hipLaunchKernelGGL(patch_invert_mfma_kernel<8>, grid, block, 0, ctx->stream, patch_ptr, inv_ptr, inv, status);
-  else
-    hipLaunchKernelGGL(patch_invert_mfma_kernel<10>, grid, block, 0, ctx->stream, patch_ptr, inv_ptr, inv, status);
+  static const bool lookahead = !(getenv("ALFI_INVERT_LA") && atoi(getenv("ALFI_INVERT_LA")) == 0);   // A/B: 0 = round-3 kernel
+#define ALFI_INV(NTV)                                                                                                       \
+  do {                                                                                                                      \
+    if (lookahead)                                                                                                          \
+      hipLaunchKernelGGL(patch_invert_mfma_la_kernel<NTV>, grid, block, 0, ctx->stream, patch_ptr, inv_ptr, inv, status);   \
+    else                                                                                                                    \
+      hipLaunchKernelGGL(patch_invert_mfma_kernel<NTV>, grid, block, 0, ctx->stream, patch_ptr, inv_ptr, inv, status);      \
+  } while (0)
+  if (max_np <= 64) ALFI_INV(4);
+  else if (max_np <= 96) ALFI_INV(6);
+  else if (max_np <= 128) ALFI_INV(8);
+  else ALFI_INV(10);
+#undef ALFI_INV
   ALFI_HIP_CHECK(ctx, hipGetLastError());
   *handled = 1;
   return 0;

@@ -16,4 +16,10 @@ t0 = time.time()
 for _ in range(3):
     dl.factor()
 ctx.sync()
-print("%s FORCE_BIG=%s: factor %.1f ms per call (%d patches, max %d dofs)" % (sys.argv[1], os.environ.get("ALFI_FORCE_BIG_FACTOR", "0"), (time.time() - t0) / 3 * 1e3, len(L.patch_ptr) - 1, np.diff(L.patch_ptr).max()))
+print("%s FORCE_BIG=%s INVERT_LA=%s: factor %.1f ms per call (%d patches, max %d dofs)" % (sys.argv[1], os.environ.get("ALFI_FORCE_BIG_FACTOR", "0"), os.environ.get("ALFI_INVERT_LA", "1"), (time.time() - t0) / 3 * 1e3, len(L.patch_ptr) - 1, np.diff(L.patch_ptr).max()))
+print("patch check (worst residual, flagged, repaired, worst after):", dl.patch_check())
+if len(sys.argv) > 2:      # y = M^-1 x for a fixed x: compared bitwise between kernel variants
+    x = np.random.default_rng(5).standard_normal(L.n)
+    dx, dy = ctx.vec(x), ctx.vec(L.n)
+    dl.patch_apply(dx, dy)
+    np.save(sys.argv[2], dy.get())

@@ -310,3 +310,43 @@ def test_pressure_rows_of_the_dg_pair_are_owned_cell_by_cell():
         assert abs(Mi - sp.csr_matrix(Minv)[prows][:, prows]).max() == 0.0
         assert np.allclose((Mi @ (sp.csr_matrix(M)[prows][:, prows])).toarray(), np.eye(len(prows)), atol=1e-10)
     assert (seen == 1).all()
+
+
+@pytest.mark.parametrize("case,world", [("2d-all-distributed", 2), ("3d-P2FB", 3)])
+def test_assembly_cells_and_contributor_lists_of_a_partition(case, world):
+    """Device-side operator refresh on partitioned levels (alfi/solver.py:320, 325 under :604-605): the cells a rank hands to
+    alfi_level_set_assembly touch a local node, their node numbering puts the local nodes first, and the contributor lists of
+    the rank's LOCAL operator (columns numbered owned-first, i.e. unsorted rows; ghost rows restricted to local columns) hold
+    exactly the (cell, a, b) pairs whose two nodes are row and column of the block -- checked pair by pair."""
+    from alfi_amd import _hostlib
+    from alfi_amd import dist as D
+    lv, tr, k, min_dofs = _hier(case)
+    splits = D.choose_splits(lv, world, min_dofs)
+    for rank in range(world):
+        parts = D.build_parts(lv, tr, splits, rank)
+        L, p = lv[-1], parts[-1]
+        A = D.localize_operator(L.A, p)
+        cells, cn, nodes = D.assembly_cells(L.V, p)
+        gcn = np.asarray(L.V.cell_nodes)
+        assert np.array_equal(nodes[:p.nb_loc], p.nodes) and np.array_equal(nodes[cn], gcn[cells])
+        touched = np.isin(gcn, p.nodes).any(axis=1)
+        assert np.array_equal(np.flatnonzero(touched), cells)
+        cptr, ccell, cba = _hostlib.contributors(cn, p.nb_loc, A.rowptr, A.colidx, nindex=len(nodes), partial=True)
+        nloc = cn.shape[1]
+        rows = np.repeat(np.arange(A.nbrows), np.diff(A.rowptr))
+        blk = np.repeat(np.arange(len(A.colidx)), np.diff(cptr))
+        a, b = cba % nloc, cba // nloc
+        assert np.array_equal(cn[ccell, a], rows[blk]) and np.array_equal(cn[ccell, b], A.colidx[blk])
+        # ... and none is missing: every pair of local nodes of a cell is a block of the local operator or (ghost rows only) a
+        # coupling the rank does not keep
+        have = set(zip(ccell.tolist(), cba.tolist()))
+        key = {(int(r), int(c)): i for i, (r, c) in enumerate(zip(rows, A.colidx))}
+        for c in range(0, cn.shape[0], max(1, cn.shape[0] // 200)):
+            for ia in range(nloc):
+                for ib in range(nloc):
+                    r_, c_ = int(cn[c, ia]), int(cn[c, ib])
+                    if (r_, c_) in key:
+                        assert (c, ib * nloc + ia) in have
+                    else:
+                        assert r_ >= p.nb_own or c_ >= p.nb_loc or r_ >= p.nb_loc
+        assert (np.diff(cptr) > 0).all()
