@@ -94,6 +94,7 @@ SIGNATURES = {
     "alfi_transfer_get_block_inverse": (ctypes.c_int, [vp, ctypes.c_int64, vp]),
     "alfi_prolong": (ctypes.c_int, [vp, vp, vp]),
     "alfi_transfer_set_injection": (ctypes.c_int, [vp, vp]),
+    "alfi_transfer_set_injection_matrix": (ctypes.c_int, [vp, ctypes.POINTER(CsrHost)]),
     "alfi_inject": (ctypes.c_int, [vp, vp, vp]),
     "alfi_restrict": (ctypes.c_int, [vp, vp, vp, ctypes.c_int]),
     "alfi_mg_create": (ctypes.c_int, [vp, ctypes.c_int, ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.c_int,

@@ -62,6 +62,8 @@ static int dev_upload(alfi_ctx* ctx, T** p, const T* host, int64_t count) {
 static void dev_free(void* p) {
   if (p) (void)hipFree(p);
 }
+static int upload_csr(alfi_ctx* ctx, DevCSR* d, const alfi_csr_host* h);
+static void free_csr(DevCSR* d);
 
 // Chunk tables of the flat layout.  Large matrices: equal chunks of SPMV_CHUNK blocks (rows may continue into the next
 // chunk; the fix-up launch completes them).  Small ones (nnzb <= SPMV_ALIGNED_MAX, no row longer than a chunk, unless
@@ -1990,6 +1992,10 @@ int alfi_transfer_destroy(alfi_transfer* T) {
   dev_free(T->bI);
   dev_free(T->tmp_f);
   dev_free(T->inj);
+  if (T->injm) {
+    free_csr(T->injm);
+    delete T->injm;
+  }
   dev_free(T->status);
   delete T;
   return 0;
@@ -2009,7 +2015,37 @@ int alfi_transfer_set_injection(alfi_transfer* T, const int32_t* fine_node) {
   return dev_upload(ctx, &T->inj, fine_node, nc);
 }
 
+int alfi_transfer_set_injection_matrix(alfi_transfer* T, const alfi_csr_host* J) {
+  alfi_ctx* ctx = T->ctx;
+  if (!J) return alfi_set_error(ctx, ALFI_E_ARG, "NULL injection matrix");
+  if (T->fine->has_halo || T->coarse->has_halo)
+    return alfi_set_error(ctx, ALFI_E_ARG, "alfi_inject is not available on partitioned levels");
+  const int64_t nc = T->coarse->n / T->bs, nf = T->fine->n / T->bs;
+  if (J->nrows != nc || J->ncols != nf)
+    return alfi_set_error(ctx, ALFI_E_ARG, "injection matrix must be %lld x %lld (coarse nodes x fine nodes)", (long long)nc, (long long)nf);
+  for (int64_t i = 0; i < nc; ++i)
+    if (J->rowptr[i + 1] < J->rowptr[i]) return alfi_set_error(ctx, ALFI_E_ARG, "row pointer not monotone");
+  for (int64_t k = 0; k < J->rowptr[nc]; ++k)
+    if (J->colidx[k] < 0 || J->colidx[k] >= nf) return alfi_set_error(ctx, ALFI_E_ARG, "injection matrix column out of range");
+  ALFI_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  if (T->injm) {
+    free_csr(T->injm);
+    delete T->injm;
+    T->injm = nullptr;
+  }
+  DevCSR* M = new DevCSR();
+  const int rc = upload_csr(ctx, M, J);
+  if (rc != 0) {
+    free_csr(M);
+    delete M;
+    return rc;
+  }
+  T->injm = M;
+  return 0;
+}
+
 int alfi_inject(alfi_transfer* T, const double* dxf, double* dxc) {
+  if (T->injm) return launch_inject_csr(T->ctx, *T->injm, T->bs, dxf, dxc);
   if (!T->inj) return alfi_set_error(T->ctx, ALFI_E_STATE, "alfi_inject before alfi_transfer_set_injection");
   return launch_halo_pack(T->ctx, dxc, dxf, T->inj, T->coarse->n / T->bs, T->bs);   // coarse[i] = fine[inj[i]]
 }

@@ -396,6 +396,7 @@ struct alfi_transfer {
   double *tI = nullptr, *bI = nullptr;  // compact interior vectors (nblk*m)
   double* tmp_f = nullptr;              // fine work vector
   int32_t* inj = nullptr;               // (coarse nodes) fine node coinciding with each coarse node
+  struct DevCSR* injm = nullptr;        // non-nested hierarchies: (coarse nodes x fine nodes) point-evaluation weights
   double gamma = 0, nu = 0;
   bool ready = false;
   int* status = nullptr;
@@ -515,6 +516,7 @@ int launch_hessenberg_scale(alfi_ctx* ctx, const double* partial, int nblocks, c
 int launch_csr_spmv(alfi_ctx* ctx, const DevCSR& A, const double* x, double* y, const double* b, double alpha, int mode);
 int launch_scale_rows(alfi_ctx* ctx, double* y, const double* x, const double* d, double a, int64_t n);  // y = a d x
 int launch_remove_mean(alfi_ctx* ctx, double* x, int64_t n);
+int launch_inject_csr(alfi_ctx* ctx, const struct DevCSR& J, int bs, const double* xf, double* xc);
 int launch_sum_to(alfi_ctx* ctx, const double* x, int64_t n, double* out);             // *out = sum(x), fixed order
 int launch_sub_scaled(alfi_ctx* ctx, double* x, int64_t n, const double* s, double f); // x -= f * *s
 int launch_add(alfi_ctx* ctx, double* y, const double* a, const double* b, int64_t n); // y = a + b

@@ -868,6 +868,84 @@ __global__ __launch_bounds__(256) void cond_group_kernel(int64_t g_begin, int64_
   else cond_group_body<COND_GMAX>(m, sc, ldm, X, W, lane, status);
 }
 
+// RARE PATH (kernels_check.hip: cond_repair): the groups of a flagged patch by LU WITH PARTIAL PIVOTING -- what the reference's
+// sparse patch factorisation does (UMFPACK, alfi/solver.py:655-659); the elimination above does not pivot, and a zero or tiny
+// leading pivot inside one macro-cell group used to send the whole level back to dense inverses (6.8 x the memory).  One wave
+// per group: P A_gg = L U in LDS (lane = row), then X_g = inv(A_gg) and W_g = inv(A_gg) A[g, S_g] column by column through
+// the factors (lane = column; backward stable per column, no refinement needed).  Dynamic LDS: m * m + 64 * m doubles, m ints.
+__global__ __launch_bounds__(64) void cond_group_pivot_kernel(int64_t g_begin, CondDev cd, int* __restrict__ status) {
+  extern __shared__ double cgp_s[];
+  const int64_t g = g_begin + blockIdx.x;
+  const int lane = threadIdx.x;
+  const int m = cd.g_m[g], sc = cd.g_sc[g];
+  const int ldm = cond_ldim(m);
+  double* X = cd.mat + cd.g_mat[g];
+  double* W = X + (int64_t)ldm * m + (int64_t)cond_ldim(sc) * m;
+  double* A = cgp_s;                               // m x m, row-major: L \ U
+  double* Y = A + (int64_t)m * m;                   // m x 64: work column of lane l at Y[i * 64 + l]
+  int* perm = reinterpret_cast<int*>(Y + (int64_t)m * 64);
+  for (int e = lane; e < m * m; e += 64) A[(e % m) * m + e / m] = X[(int64_t)(e / m) * ldm + e % m];
+  __syncthreads();
+  bool bad = false;
+  for (int k = 0; k < m; ++k) {
+    double v = (lane >= k && lane < m) ? fabs(A[lane * m + k]) : -1.0;
+    if (!(v == v)) v = INFINITY;                     // NaN
+    int idx = lane;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const double ov = __shfl_xor(v, o);
+      const int oi = __shfl_xor(idx, o);
+      if (ov > v || (ov == v && oi < idx)) { v = ov; idx = oi; }
+    }
+    if (!(v > 0.0) || v == INFINITY) { bad = true; break; }     // wave-uniform
+    if (lane == 0) perm[k] = idx;
+    if (idx != k && lane < m) {
+      const double t = A[k * m + lane];
+      A[k * m + lane] = A[idx * m + lane];
+      A[idx * m + lane] = t;
+    }
+    __syncthreads();
+    const double ip = 1.0 / A[k * m + k];
+    if (lane > k && lane < m) {
+      const double l = A[lane * m + k] * ip;
+      A[lane * m + k] = l;
+      for (int j = k + 1; j < m; ++j) A[lane * m + j] = __builtin_fma(-l, A[k * m + j], A[lane * m + j]);
+    }
+    __syncthreads();
+  }
+  if (bad) {
+    if (lane == 0) atomicExch(status, 1);
+    return;
+  }
+  // column `lane` of the right-hand side B (nrhs columns, leading dimension ldm, in place): x = U^-1 L^-1 P b
+  auto solve = [&](double* B, int nrhs, bool identity) {
+    const bool act = lane < nrhs;
+    for (int i = 0; i < m; ++i) Y[i * 64 + lane] = act ? (identity ? (i == lane ? 1.0 : 0.0) : B[(int64_t)lane * ldm + i]) : 0.0;
+    for (int k = 0; k < m; ++k) {                    // P: the row exchanges in the order they were made
+      const int pk = perm[k];
+      if (pk != k) {
+        const double t = Y[k * 64 + lane];
+        Y[k * 64 + lane] = Y[pk * 64 + lane];
+        Y[pk * 64 + lane] = t;
+      }
+    }
+    for (int i = 1; i < m; ++i) {                    // L (unit diagonal)
+      double acc = Y[i * 64 + lane];
+      for (int j = 0; j < i; ++j) acc = __builtin_fma(-A[i * m + j], Y[j * 64 + lane], acc);
+      Y[i * 64 + lane] = acc;
+    }
+    for (int i = m - 1; i >= 0; --i) {               // U
+      double acc = Y[i * 64 + lane];
+      for (int j = i + 1; j < m; ++j) acc = __builtin_fma(-A[i * m + j], Y[j * 64 + lane], acc);
+      Y[i * 64 + lane] = acc / A[i * m + i];
+    }
+    if (act)
+      for (int i = 0; i < m; ++i) B[(int64_t)lane * ldm + i] = Y[i * 64 + lane];
+  };
+  solve(W, sc, false);                               // W_g = inv(A_gg) A[g, S_g]   (reads the raw A[g, S_g] the fill put there)
+  solve(X, m, true);                                 // X_g = inv(A_gg)
+}
+
 // workgroup per patch of the batch: Sigma -= B_g W_g, group after group (a fixed order: deterministic)
 __global__ __launch_bounds__(256) void cond_schur_kernel(int64_t p0, CondDev cd, const int64_t* __restrict__ patch_ptr,
                                                           const int64_t* __restrict__ scr_ptr, double* __restrict__ scr) {
@@ -1398,6 +1476,7 @@ struct BigSource {
   alfi_transfer* T = nullptr;
   alfi_level* C = nullptr;
   alfi_level* K = nullptr;        // condensed patches: the Schur complements of the level's patches
+  bool pivot_groups = false;      // K: the group inverses by LU with partial pivoting (repair of flagged patches)
   void fill(alfi_ctx* ctx, int64_t p0, int64_t nb, const int64_t* d_scr_ptr, double* dst) const {
     dim3 block(256);
     if (M) {
@@ -1412,7 +1491,12 @@ struct BigSource {
                            K->patch_dofs, K->A.rowptr, K->A.colidx, K->A.vals, K->A.flat, d_scr_ptr, dst, K->status);
       // groups of the patches [p0, p0 + nb)
       const int64_t ga = K->h_cond_gptr[p0], gb = K->h_cond_gptr[p0 + nb];
-      if (gb > ga)
+      if (gb > ga && pivot_groups) {
+        const size_t glds = (size_t)(COND_GMAX * COND_GMAX + 64 * COND_GMAX) * sizeof(double) + COND_GMAX * sizeof(int);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&cond_group_pivot_kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)glds);
+        hipLaunchKernelGGL(cond_group_pivot_kernel, dim3((unsigned)(gb - ga)), dim3(64), glds, ctx->stream, ga, K->cd, K->status);
+      } else if (gb > ga)
         hipLaunchKernelGGL(cond_group_kernel, dim3((unsigned)((gb - ga + 3) / 4)), block, 0, ctx->stream, ga, gb, K->cd,
                            K->status);
       hipLaunchKernelGGL(cond_schur_kernel, dim3((unsigned)nb), block, 0, ctx->stream, p0, K->cd, K->patch_ptr, d_scr_ptr, dst);
@@ -1612,11 +1696,13 @@ int launch_cond_factor(alfi_level* L) {
   return big_factor_core(L->ctx, src, L->npatch, L->h_sptr.data(), L->cd.sptr, L->cd.sinv_ptr, L->cd.sinv, L->status);
 }
 
-// the Schur complement of ONE condensed patch into scr (N x N row-major, N = s rounded up to BIG_NB, identity padding);
+// the group matrices of ONE condensed patch again -- X_g, W_g by LU with partial pivoting -- and its Schur complement into scr
+// (N x N row-major, N = s rounded up to BIG_NB, identity padding);
 // d_zero: a device int64 holding 0 (the patch's offset in scr).  The repair path of kernels_check.hip.
 int launch_cond_schur_one(alfi_level* L, int64_t p, const int64_t* d_zero, double* scr) {
   BigSource src;
   src.K = L;
+  src.pivot_groups = true;       // the patch failed the probe: its group inverses by pivoted LU as well
   src.fill(L->ctx, p, 1, d_zero, scr);
   ALFI_HIP_CHECK(L->ctx, hipGetLastError());
   return 0;
@@ -1652,6 +1738,12 @@ int launch_cond_apply_range(alfi_level* L, int64_t p0, int64_t p1, const double*
         hipLaunchKernelGGL((cond_gfront_kernel<false>), dim3((unsigned)(k1 - k0)), dim3(256), lds_f, ctx->stream, k0, L->cd, x);
     }
     if (c1 > c0) {
+      if (lds_s > 64 * 1024) {     // Schur complements beyond ~7.9 k dofs: raise the kernel's dynamic-LDS limit
+        ALFI_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&cond_gsigma_kernel<true>),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_s));
+        ALFI_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&cond_gsigma_kernel<false>),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_s));
+      }
       if (nt)
         hipLaunchKernelGGL((cond_gsigma_kernel<true>), dim3((unsigned)(c1 - c0)), dim3(256), lds_s, ctx->stream, c0, L->cd,
                            L->patch_ptr, L->stage_ptr, x, L->stage);
@@ -1682,6 +1774,12 @@ int launch_cond_apply_range(alfi_level* L, int64_t p0, int64_t p1, const double*
     hipLaunchKernelGGL((cond_front_kernel<GNT, WV, RU>), dim3(grid.x), dim3(64 * WV), lds_f, ctx->stream, p0, p1, L->cd,  \
                        L->patch_ptr, L->stage_ptr, x, L->stage, ordered);                                                 \
     if (c1 > c0) {                                                                                                        \
+      if (lds_s > 64 * 1024) {                                                                                            \
+        ALFI_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&cond_sigma_kernel<true>),                  \
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_s));                 \
+        ALFI_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&cond_sigma_kernel<false>),                 \
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_s));                 \
+      }                                                                                                                   \
       if (nt)                                                                                                             \
         hipLaunchKernelGGL((cond_sigma_kernel<true>), dim3((unsigned)(c1 - c0)), dim3(256), lds_s, ctx->stream, c0, L->cd, \
                            L->patch_ptr, L->stage_ptr, L->stage);                                                         \

@@ -291,11 +291,11 @@ static int read_check(alfi_level* L, double* worst, int* nflag) {
   return 0;
 }
 
-// Condensed factors (CondDev): a patch that fails the probe gets its Schur complement formed again (fill / group / Schur
-// kernels of the setup, one patch at a time: the rare path) and inverted by the pivoted LU above, in place in
-// CondDev::sinv -- the level keeps its condensed storage (round 2 fell back to dense inverses for the whole level: 6.8 x
-// the memory exactly when a patch is ill-conditioned).  The group inverses X_g come from an unpivoted elimination with two
-// refinement steps on W_g (cond_group_kernel); a zero pivot there has already failed the factorisation.
+// Condensed factors (CondDev): a patch that fails the probe -- or met a zero pivot -- gets its group matrices X_g, W_g by LU
+// WITH partial pivoting (cond_group_pivot_kernel), its Schur complement formed again from them (fill / Schur kernels of the
+// setup, one patch at a time: the rare path) and inverted by the pivoted LU above, all in place: the level keeps its condensed
+// storage (round 2 fell back to dense inverses for the whole level, 6.8 x the memory exactly when a patch is ill-conditioned;
+// round 3 repaired the Schur complement only, so a bad pivot inside one macro-cell group still did).
 static int cond_repair(alfi_level* L, double tol, int nflag, double worst) {
   alfi_ctx* ctx = L->ctx;
   const int smax = L->cond_max_s;

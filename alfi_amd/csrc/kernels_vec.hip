@@ -1542,3 +1542,20 @@ int launch_add(alfi_ctx* ctx, double* y, const double* a, const double* b, int64
   ALFI_LAUNCH_EW(add_kernel, n, y, a, b, n);
   return 0;
 }
+
+// inject on a non-nested (barycentric) hierarchy: coarse node i = sum_k w_k fine node c_k (the fine function evaluated at the
+// coarse node: firedrake.inject [3P], alfi/solver.py:645-652), every component alike; one thread per coarse dof, fixed order
+__global__ void inject_csr_kernel(int64_t total, int bs, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colidx,
+                                  const double* __restrict__ vals, const double* __restrict__ xf, double* __restrict__ xc) {
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t i = e / bs;
+    const int c = (int)(e - i * bs);
+    double s = 0.0;
+    for (int32_t k = rowptr[i]; k < rowptr[i + 1]; ++k) s = __builtin_fma(vals[k], xf[(int64_t)colidx[k] * bs + c], s);
+    xc[e] = s;
+  }
+}
+int launch_inject_csr(alfi_ctx* ctx, const DevCSR& J, int bs, const double* xf, double* xc) {
+  ALFI_LAUNCH_EW(inject_csr_kernel, J.nrows * bs, J.nrows * bs, bs, J.rowptr, J.colidx, J.vals, xf, xc);
+  return 0;
+}

@@ -434,9 +434,20 @@ class Transfer(object):
                                                _ptr(D), ctypes.byref(h)))
         self.h = h
         inj = getattr(T, "inject_map", None)
-        if inj is not None and not getattr(coarse, "n_own", None) and not getattr(fine, "n_own", None):
+        serial = not getattr(coarse, "n_own", None) and not getattr(fine, "n_own", None)
+        if inj is not None and serial:
             inj = np.ascontiguousarray(inj, dtype=np.int32)
             ctx.check(ctx.lib.alfi_transfer_set_injection(h, _ptr(inj)))
+        elif getattr(T, "inject_matrix", None) is not None and serial:
+            # non-nested (barycentric) hierarchy: inject = point evaluation at the coarse nodes, a sparse matrix on the device
+            import scipy.sparse as sp
+            J = sp.csr_matrix(T.inject_matrix)
+            J.sort_indices()
+            rp = np.ascontiguousarray(J.indptr, dtype=np.int32)
+            ci = np.ascontiguousarray(J.indices, dtype=np.int32)
+            va = np.ascontiguousarray(J.data, dtype=np.float64)
+            st = CsrHost(J.shape[0], J.shape[1], _ptr(rp), _ptr(ci), _ptr(va))
+            ctx.check(ctx.lib.alfi_transfer_set_injection_matrix(h, ctypes.byref(st)))
 
     def inject(self, xf, xc):
         self.ctx.check(self.ctx.lib.alfi_inject(self.h, xf.ptr, xc.ptr))

@@ -157,15 +157,10 @@ class HipNavierStokesSolver(object):
         self._asm_ready = True
 
     def _device_states(self, u):
-        """Current velocity on every level, on the device: the finest uploaded, the coarser ones by inject (solver.py:595).
-        Nested hierarchy: alfi_inject on the device.  Barycentric hierarchy (Scott-Vogelius): the coarse nodes are not fine
-        nodes, inject is a point evaluation (sv.bary_injection, a sparse matrix) -- applied on the host, where u already is,
-        and uploaded: a few megabytes per Newton step."""
+        """Current velocity on every level, on the device: the finest uploaded, the coarser ones by alfi_inject (solver.py:595) --
+        an index map on the nested hierarchies, the point-evaluation matrix sv.bary_injection on the barycentric ones (the
+        third entry of the reference's transfer triple, solver.py:645-652)."""
         self._dstate[-1].set(u)
-        if any(T.inject_map is None for T in self.transfers):
-            for st, w in zip(self._dstate[:-1], self._winds(u)[:-1]):
-                st.set(np.ascontiguousarray(w).ravel())
-            return
         for l in range(len(self.levels) - 1, 0, -1):
             self.hmg.mg.transfers[l - 1].inject(self._dstate[l], self._dstate[l - 1])
 

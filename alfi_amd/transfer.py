@@ -114,8 +114,6 @@ class AutoSchoeberlTransfer(object):
             self.ctx = hip.Context(0)
         nu, gamma = (float(p) for p in self.parameters)
         T = self._transfer_data(Vc, Vf, nu, gamma)
-        self._inject_matrix = getattr(self, "_inject_matrix", {})
-        self._inject_matrix[Vf.num_dofs] = getattr(T, "inject_matrix", None) if T.inject_map is None else None
 
         def shell(V):       # a level without operator: only sizes and Dirichlet dofs are needed by the transfer
             empty = BSR(V.num_nodes, V.num_nodes, V.dim, np.zeros(V.num_nodes + 1, dtype=np.int32),
@@ -159,10 +157,7 @@ class AutoSchoeberlTransfer(object):
             self.solver[key] = self._setup(Vc, Vf)
             self.prev_parameters[key] = [float(p) for p in self.parameters]
         dev, ctx = self.solver[key][0], self.ctx
-        J = self._inject_matrix.get(key)
-        if J is not None:          # non-nested (bary) hierarchy: point evaluation at the coarse nodes, a host matrix
-            coarse.dat.data[:] = J @ fine.dat.data
-            return
+        # (non-nested bary hierarchy: the device applies the point-evaluation matrix, alfi_transfer_set_injection_matrix)
         dxf, dxc = ctx.vec(fine.dat.data.ravel()), ctx.vec(Vc.num_dofs)
         dev.inject(dxf, dxc)
         coarse.dat.data[:] = dxc.get().reshape(coarse.dat.data.shape)

@@ -366,6 +366,10 @@ int alfi_level_halo_reverse_add(alfi_level* lvl, double* dv);
 /* a scalar CSR matrix on the device (the rank's rows of the discrete divergence and its transpose) */
 typedef struct alfi_csr alfi_csr;
 int alfi_csr_create(alfi_ctx* ctx, const alfi_csr_host* M, alfi_csr** out);
+/* inject on a NON-NESTED hierarchy (the barycentric refinements of the Scott-Vogelius pair, alfi/solver.py:641-652): the coarse
+ * nodes are not fine nodes, the fine function is evaluated at them.  J: (coarse nodes x fine nodes) scalar CSR of basis values,
+ * applied to every component; replaces the index map of alfi_transfer_set_injection for alfi_inject.  Serial levels only. */
+int alfi_transfer_set_injection_matrix(alfi_transfer* tr, const alfi_csr_host* J);
 int alfi_csr_destroy(alfi_csr* m);
 /* mode 0: y = M x;  1: y = b - alpha M x;  2: y += M x;  3: y = alpha M x */
 int alfi_csr_mult(alfi_csr* m, const double* dx, double* dy, const double* db, double alpha, int mode);

@@ -333,6 +333,11 @@ def test_sv_schoeberl_transfer_object_protocol():
     fi, ci = Function(Vf, tr[-1].P.to_scipy() @ q.ravel()), Function(Vc)
     vt.inject(fi, ci)
     assert np.abs(ci.dat.data - q).max() < 1e-12
+    # ... applied ON THE DEVICE (alfi_transfer_set_injection_matrix): equal to the host product with sv.bary_injection
+    rnd = Function(Vf, np.random.default_rng(3).standard_normal(Vf.num_dofs))
+    vt.inject(rnd, ci)
+    ref = tr[-1].inject_matrix @ rnd.dat.data
+    assert np.abs(ci.dat.data - ref).max() < 1e-14 * np.abs(ref).max()
 
     class _PC(object):
         level_data = lv[1]

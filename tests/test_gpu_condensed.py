@@ -125,3 +125,53 @@ def test_flagged_condensed_factors_are_repaired_in_place():
     assert flagged > 0                                     # every patch went through the repair ...
     assert after < 1e-7 and err < 1e-7                     # ... and comes out as accurate as the fast factorisation
     assert int(m.group(5)) < int(m.group(6)) / 2           # still condensed: far below the 8 sum n_p^2 bytes of dense inverses
+
+
+def test_zero_pivot_inside_a_group_is_repaired_in_place(ctx):
+    """a zero (or tiny) leading pivot inside ONE macro-cell group used to fail the unpivoted group
+    elimination, and hip.factor_with_fallback then turned the whole level into dense inverses (6.8 x the memory: 265 GB at
+    config 5L).  The reference's sparse patch LU pivots (alfi/solver.py:655-659).  Here the [P3]^3 operator keeps its sparsity
+    but gets values no unpivoted elimination survives -- the (0, 0) entry of every diagonal 3 x 3 block is zero, so the first
+    pivot of every group and of every Schur complement is zero while the patch matrices stay well conditioned -- and every
+    patch comes back from the repair (cond_group_pivot_kernel + pivoted LU of the Schur complement) with its condensed
+    storage: factor_bytes() unchanged, probe < 1e-7, apply equal to dense solves with numpy."""
+    from alfi_amd import hip
+    from alfi_amd.problem import ThreeDimLidDrivenCavityProblem, BSR
+    from alfi_amd.sv import build_sv_hierarchy
+    lv, _ = build_sv_hierarchy(ThreeDimLidDrivenCavityProblem(1), 1, 3, Re=100.0)
+    L = lv[-1]
+    A0 = L.A
+    rng = np.random.default_rng(0)
+    vals = 0.02 * rng.standard_normal(A0.vals.shape)
+    rows = np.repeat(np.arange(A0.nbrows), np.diff(A0.rowptr))
+    diag = rows == A0.colidx
+    base = np.array([[0.0, 4.0, 0.0], [4.0, 0.0, 1.0], [0.0, 1.0, 5.0]])
+    vals[diag] = base + 0.02 * rng.standard_normal((int(diag.sum()), 3, 3))
+    vals[diag, 0, 0] = 0.0
+    A = BSR(A0.nbrows, A0.nbcols, 3, A0.rowptr, A0.colidx, vals)
+    # reference: healthy values, condensed storage
+    dl0 = hip.Level(ctx, A0, L.bc_dofs)
+    dl0.set_patches(L.patch_ptr, L.patch_dofs)
+    dl0.set_patch_groups(L.patch_groups)
+    dl0.factor()
+    healthy_bytes = dl0.factor_bytes()
+    dl0.close()
+    dl = hip.Level(ctx, A, np.zeros(0, dtype=np.int32))
+    dl.set_patches(L.patch_ptr, L.patch_dofs)
+    dl.set_patch_groups(L.patch_groups)
+    assert dl.factor_with_fallback() is False                 # repaired in place: no dense fallback
+    worst, flagged, repaired, after = dl.patch_check()
+    npatch = len(L.patch_ptr) - 1
+    assert flagged == npatch == repaired and not (worst < 1e-6), (worst, flagged, repaired, after)
+    assert after < 1e-7, after
+    assert dl.factor_bytes() == healthy_bytes                 # still condensed
+    S = A.to_scipy().tocsr()
+    x = rng.standard_normal(L.n)
+    dx, dy = ctx.vec(x), ctx.vec(L.n)
+    dl.patch_apply(dx, dy)
+    y = np.zeros(L.n)
+    for p in range(npatch):
+        dofs = L.patch_dofs[L.patch_ptr[p]:L.patch_ptr[p + 1]]
+        y[dofs] += np.linalg.solve(S[dofs][:, dofs].toarray(), x[dofs])
+    assert np.abs(dy.get() - y).max() < 1e-9 * np.abs(y).max()
+    dl.close()
