@@ -11,6 +11,11 @@
 
 static thread_local std::string g_create_error;
 
+bool alfi_test_large_paths() {
+  static const bool on = getenv("ALFI_TEST_LARGE_PATHS") && atoi(getenv("ALFI_TEST_LARGE_PATHS")) == 1;
+  return on;
+}
+
 int alfi_set_error(alfi_ctx* ctx, int code, const char* fmt, ...) {
   char buf[1024];
   va_list ap;
@@ -76,8 +81,7 @@ static int build_chunk_tables(alfi_ctx* ctx, DevBSR* d, const int32_t* rowptr, i
   dev_free(d->chunk_start);
   d->chunk_row = nullptr;
   d->chunk_start = nullptr;
-  static const bool allow = !(getenv("ALFI_SPMV_ALIGNED") && atoi(getenv("ALFI_SPMV_ALIGNED")) == 0);
-  bool aligned = allow && d->nnzb <= SPMV_ALIGNED_MAX;
+  bool aligned = !alfi_test_large_paths() && d->nnzb <= SPMV_ALIGNED_MAX;
   for (int64_t i = 0; i < nbrows && aligned; ++i) aligned = rowptr[i + 1] - rowptr[i] <= SPMV_CHUNK;
   d->aligned = aligned;
   if (!aligned) {
@@ -118,11 +122,9 @@ static int upload_bsr(alfi_ctx* ctx, DevBSR* d, const alfi_bsr_host* h, int bs) 
   d->bs = bs;
   d->nnzb = h->rowptr[h->nbrows];
   // lane-major layout + segmented SpMV needs every block row non-empty (the row of a block is found by counting row
-  // starts); ALFI_SPMV=legacy keeps the host layout and the row-per-lane-group kernel (A/B measurements)
+  // starts); matrices with empty rows (transfer pieces) keep the host layout and the row-per-lane-group kernel
   bool flat = d->nnzb > 0;
   for (int64_t i = 0; i < h->nbrows && flat; ++i) flat = h->rowptr[i + 1] > h->rowptr[i];
-  const char* env = getenv("ALFI_SPMV");
-  if (env && strcmp(env, "legacy") == 0) flat = false;
   d->flat = flat ? 1 : 0;
   ALFI_CHECK(dev_upload(ctx, &d->rowptr, h->rowptr, h->nbrows + 1));
   if (!flat) {
@@ -953,8 +955,7 @@ static int level_patch_apply(alfi_level* L, const double* dx, double* dy, bool* 
   if (L->distributed) ALFI_CHECK(halo_fwd(L, const_cast<double*>(dx)));
   ALFI_CHECK(launch_patch_apply(L, dx, dy));    // includes y[bc] = x[bc] (no patch holds a Dirichlet dof, so the
                                                 // exchange brings nothing to those entries)
-  static const bool allow_sum = !(getenv("ALFI_DIST_SUM_EXCHANGE") && atoi(getenv("ALFI_DIST_SUM_EXCHANGE")) == 0);
-  if (L->distributed && ghosts_current && L->sum_ready && allow_sum && !L->pou) {
+  if (L->distributed && ghosts_current && L->sum_ready && !L->pou) {
     ALFI_CHECK(halo_sum(L, dy));
     *ghosts_current = true;
   } else if (L->distributed) {
@@ -1260,9 +1261,9 @@ int alfi_patches_set_groups(alfi_level* L, const int32_t* group) {
     ALFI_CHECK(cond_upload(L, &cd.bp_ptr, bp_ptr));
     ALFI_CHECK(cond_upload(L, &cd.bp_grp, bp_grp));
     ALFI_CHECK(cond_upload(L, &cd.g_bp, g_bp));
-    // (only where the chunked form is used: levels with fewer than 1024 patches, or every level with ALFI_COND_SPLIT=3 -- the
-    // descriptors are 80 KB per large macro star)
-    if (npatch < 1024 || (getenv("ALFI_COND_SPLIT") && atoi(getenv("ALFI_COND_SPLIT")) == 3)) {
+    // (only where the chunked form is used: levels with fewer than 1024 patches -- the descriptors are 80 KB per large
+    // macro star)
+    if (npatch < 1024 || alfi_test_large_paths()) {
       // chunks of consecutive groups: at most 256 row pairs of X / W and of B each, with the descriptors of the chunks and of
       // every row pair (CondChunk / CondXPair / CondBPair, common.h)
       std::vector<CondChunk> gc;
@@ -1452,7 +1453,6 @@ int alfi_patches_factor(alfi_level* L) {
   if (!L->patch_ptr) return alfi_set_error(ctx, ALFI_E_STATE, "alfi_patches_factor before alfi_patches_set");
   int t = alfi_prof_begin(ctx, ALFI_EV_PATCH_FACTOR);
   ALFI_HIP_CHECK(ctx, hipMemsetAsync(L->status, 0, sizeof(int), ctx->stream));
-  static const bool force_big = getenv("ALFI_FORCE_BIG_FACTOR") && atoi(getenv("ALFI_FORCE_BIG_FACTOR")) == 1;
   if (!L->cond && L->inv_shrunk) {                 // first dense factorisation of this patch set
     ALFI_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     dev_free(L->inv);
@@ -1462,7 +1462,7 @@ int alfi_patches_factor(alfi_level* L) {
   }
   if (L->cond) {
     ALFI_CHECK(launch_cond_factor(L));            // condensed factors: group inverses + Schur complements
-  } else if (L->max_np > SMALL_PATCH_MAX || force_big) {
+  } else if (L->max_np > SMALL_PATCH_MAX) {
     ALFI_CHECK(launch_big_factor(L));             // macro-star sized patches: blocked Gauss-Jordan on the matrix cores
   } else {
     ALFI_CHECK(launch_patch_gather_dense(L));
@@ -1612,25 +1612,19 @@ int alfi_smooth_fgmres(alfi_level* L, int k, const double* db, double* dx, int n
   {
     // unpartitioned levels with short operator rows: the four-launch iteration (on the small levels a smoother iteration is
     // launch latency, on the large 2-D ones the folded vector passes save BLAS-1 traffic, which is comparable to the patch
-    // traffic there).  ALFI_FUSED_SMOOTHER=0 keeps the general path (A/B measurements).
-    static const bool allow = !(getenv("ALFI_FUSED_SMOOTHER") && atoi(getenv("ALFI_FUSED_SMOOTHER")) == 0);
-    // (uniformly short rows -- the 2-D operators, <= 32 blocks; with the 50 .. 125 blocks per row of the 3-D ones the flat
-    // segmented product of the general path is the faster kernel -- cfg3 19.0 vs 18.9 ms, cfg2 5.10 vs 5.43 ms, same box --
-    // and with the bimodal rows of [P1+FB]^3 (12 blocks on the face nodes, 75 on the vertices, 17 on average) the
-    // lanes-per-row product of the fused iteration idles most of its lanes: config 6 188.8 ms fused, 175.0 ms general)
-    // ... except on levels of <= 50 000 dofs, which are bound by the number of dependent launches whatever the rows look
-    // like: config 3 18.66 -> 18.12-18.23 ms with its two smallest smoothed levels on the fused iteration (same box)
-    static const int64_t small_n = getenv("ALFI_FUSED_SMALL_N") ? atoll(getenv("ALFI_FUSED_SMALL_N")) : 50000;
-    const bool fusable = allow && !L->distributed && L->n_own == L->n && !L->mult && k + 1 <= 16 && L->A_own.flat;
-    // every unpartitioned additive level takes the iteration with the normalisation folded behind the (linear) patch
-    // solves -- patch_sum_scale_kernel writes z_j and v_j in one pass, no separate v = w / |w| launch; the product is the
-    // lanes-per-row kernel with the dots folded in where the rows are short, the nnz-balanced one + a dot pass elsewhere.
-    // ALFI_FUSED_ALL=1 sends the latter levels there too; measured (round 3, same box, ms per V-cycle): config 3 17.33 against
-    // 17.35, config 4 163.1 / 163.3, config 5 27.24 / 27.10 -- the launch it saves is worth nothing on levels whose kernels
-    // run for tens of microseconds, so the default keeps the general launch chain below for them
-    static const bool fused_all = getenv("ALFI_FUSED_ALL") && atoi(getenv("ALFI_FUSED_ALL")) == 1;
+    // traffic there): patch_sum_scale_kernel writes z_j and v_j in one pass (the normalisation follows the linear patch
+    // solves), the product is the lanes-per-row kernel with the dots folded in.
+    // Short rows = the 2-D operators (<= 32 blocks).  With the 50 .. 125 blocks per row of the 3-D ones the flat segmented
+    // product of the general path below is the faster kernel (config 3 19.0 against 18.9 ms, config 2 5.10 against 5.43, same
+    // box; with the bimodal rows of [P1+FB]^3 the lanes-per-row product idles most lanes: config 6 188.8 ms fused, 175.0
+    // general) ... except on levels of <= 50 000 dofs, which are bound by the number of dependent launches whatever the rows
+    // look like (config 3 18.66 -> 18.12-18.23 ms).  Sending every level here was measured too: nothing (config 3 17.33 /
+    // 17.35 ms, config 4 163.1 / 163.3, config 5 27.24 / 27.10).
+    constexpr int64_t small_n = 50000;
+    const bool fusable = !alfi_test_large_paths() && !L->distributed && L->n_own == L->n && !L->mult && k + 1 <= 16 &&
+                         L->A_own.flat;
     const bool short_rows = L->max_row_blocks <= 32 || L->n <= small_n;
-    if (fusable && (short_rows || fused_all)) return smooth_fgmres_fused(L, k, db, dx, nonzero_guess, !short_rows);
+    if (fusable && short_rows) return smooth_fgmres_fused(L, k, db, dx, nonzero_guess, !short_rows);
   }
   const int K = L->kmax;
   const int64_t n = L->n_own;    // vector kernels and reductions run on the owned prefix
@@ -1658,11 +1652,9 @@ int alfi_smooth_fgmres(alfi_level* L, int k, const double* db, double* dx, int n
   // iteration is a chain of launches of a few microseconds each) the kernel that needs a reduced value sums the partials
   // itself -- every block in the same fixed order -- instead of waiting for a one-block reduction launch.
   const int G = red_blocks_for(n);
-  static const bool allow_fused = !(getenv("ALFI_FUSED_REDUCE") && atoi(getenv("ALFI_FUSED_REDUCE")) == 0);   // A/B switch
-  // (G = n / 4096 partials per vector; ALFI_FUSED_REDUCE_MAX = 512 would include config 3's finest level, 319 partials:
-  // measured 18.31 against 18.13 ms per cycle, the re-summation in every consumer block costs more than the launch)
-  static const int fused_max = getenv("ALFI_FUSED_REDUCE_MAX") ? atoi(getenv("ALFI_FUSED_REDUCE_MAX")) : 256;
-  const bool fused = allow_fused && !par && G <= fused_max && k + 1 <= 16;
+  // (G = n / 4096 partials per vector; a limit of 512 would include config 3's finest level, 319 partials: measured 18.31
+  // against 18.13 ms per cycle, the re-summation in every consumer block costs more than the launch)
+  const bool fused = !par && G <= 256 && k + 1 <= 16;
   t = alfi_prof_begin(ctx, ALFI_EV_BLAS1);
   ALFI_CHECK(launch_norm_partials(ctx, w, n));
   if (par) ALFI_CHECK(launch_reduce_partials(ctx, ctx->red_partial, G, 1, nrm2));
@@ -1950,10 +1942,8 @@ int alfi_transfer_create(alfi_ctx* ctx, alfi_level* coarse, alfi_level* fine, co
     if (rc == 0) rc = dev_upload(ctx, &T->pm_iota, iota.data(), nblk * m);
     if (rc == 0) rc = dev_alloc(ctx, &T->binv, nblk * T->bstride);
     if (rc == 0 && T->ld != m) rc = dev_alloc(ctx, &T->pm_tmp, nblk * T->ld);
-    if (!(getenv("ALFI_TRANSFER_REFINE") && atoi(getenv("ALFI_TRANSFER_REFINE")) == 0)) {
-      if (rc == 0) rc = dev_alloc(ctx, &T->pm_res, nblk * m);
-      if (rc == 0) rc = dev_alloc(ctx, &T->pm_cor, nblk * m);
-    }
+    if (rc == 0) rc = dev_alloc(ctx, &T->pm_res, nblk * m);       // one step of iterative refinement per interior solve
+    if (rc == 0) rc = dev_alloc(ctx, &T->pm_cor, nblk * m);
   } else if (rc == 0) {
     rc = dev_alloc(ctx, &T->binv, nblk * m * T->ld);
   }

@@ -55,6 +55,12 @@ constexpr int RED_MAXV = 32;      // max simultaneous dot products
 
 int alfi_set_error(alfi_ctx* ctx, int code, const char* fmt, ...);
 
+// ALFI_TEST_LARGE_PATHS=1 -- a TEST HOOK, not a tuning switch: the size thresholds that select the kernels of the large levels
+// (nnz-balanced SpMV with the fix-up launch and the de-duplicated x gathers instead of whole-row chunks, the general smoother
+// chain instead of the fused iteration of small levels) are lowered to zero, so that the small hierarchies of the test suite
+// run the code the 10 M-dof levels run.  Read once per process.
+bool alfi_test_large_paths();
+
 #define ALFI_HIP_CHECK(ctx, call)                                                                      \
   do {                                                                                                 \
     hipError_t e_ = (call);                                                                            \

@@ -621,7 +621,7 @@ __global__ __launch_bounds__(256) void big_mult_kernel(int64_t count, const int3
 int launch_big_mult_wave(alfi_level* L, const int32_t* seq, int64_t count, const double* x, double* y) {
   alfi_ctx* ctx = L->ctx;
   if (count == 0) return 0;
-  static const bool nt = !(getenv("ALFI_NT") && atoi(getenv("ALFI_NT")) == 0);
+  constexpr bool nt = true;      // factors are read once per apply: nontemporal loads
   dim3 grid((unsigned)count), block(256);
 #define ALFI_BMULT(BSV, NTV)                                                                                          \
   hipLaunchKernelGGL((big_mult_kernel<BSV, NTV>), grid, block, 0, ctx->stream, count, seq, L->patch_ptr, L->patch_dofs, \
@@ -643,8 +643,6 @@ int launch_big_mult_wave(alfi_level* L, const int32_t* seq, int64_t count, const
 // ---------------------------------------------------------------------------------------------------------------------
 // workgroups per patch: enough of them to fill 256 CUs several times over, but no more waves than 128-row pieces
 static int big_split(int64_t npatch, int max_np) {
-  static const int forced = getenv("ALFI_BIG_SPLIT") ? atoi(getenv("ALFI_BIG_SPLIT")) : 0;
-  if (forced > 0) return forced;
   const int64_t want = (2048 + npatch - 1) / npatch;
   const int pieces = (max_np + 127) / 128;
   const int cap = (pieces + 3) / 4;
@@ -654,7 +652,7 @@ static int big_split(int64_t npatch, int max_np) {
 int launch_big_apply_range(alfi_level* L, int64_t p0, int64_t p1, const double* x) {
   alfi_ctx* ctx = L->ctx;
   if (p1 <= p0) return 0;
-  static const bool nt = !(getenv("ALFI_NT") && atoi(getenv("ALFI_NT")) == 0);
+  constexpr bool nt = true;      // factors are read once per apply: nontemporal loads
   const int split = big_split(p1 - p0, L->max_np);
   dim3 grid((unsigned)((p1 - p0) * split)), block(256);
   if (nt)
@@ -686,7 +684,7 @@ int launch_big_apply_arrays(alfi_ctx* ctx, int64_t npatch, int max_np, const int
                             const int32_t* patch_dofs, const int64_t* inv_ptr, const int64_t* stage_ptr, const double* inv,
                             const double* x, double* stage) {
   if (npatch == 0) return 0;
-  static const bool nt = !(getenv("ALFI_NT") && atoi(getenv("ALFI_NT")) == 0);
+  constexpr bool nt = true;      // factors are read once per apply: nontemporal loads
   const int split = big_split(npatch, max_np);
   dim3 grid((unsigned)(npatch * split)), block(256);
   if (nt)
@@ -702,8 +700,7 @@ int launch_big_apply_arrays(alfi_ctx* ctx, int64_t npatch, int max_np, const int
 // ---------------------------------------------------------------------------------------------------------------------
 // 4. Condensed patch factors (CondDev, common.h): setup = fill (operator entries into the group matrices and the Schur
 //    scratch), group step (X_g = inv(A_gg), W_g = X_g A[g, S_g]), Schur step (Sigma -= B_g W_g), blocked inversion of
-//    Sigma by the kernels above; apply = three launches (cond_front / cond_sigma / cond_back below), or the one-launch
-//    kernel of rounds 1-2 (cond_apply_kernel, ALFI_COND_SPLIT=0).
+//    Sigma by the kernels above; apply = three launches (cond_front / cond_sigma / cond_back below).
 // ---------------------------------------------------------------------------------------------------------------------
 constexpr int COND_GMAX = 64;     // a group / its coupled skeleton set holds at most 64 entries (a lane per row)
 
@@ -999,95 +996,7 @@ __device__ __forceinline__ double cond_gemv_shfl(const double* __restrict__ M, i
   return acc;
 }
 
-template <bool NT, int COND_WAVES>
-__global__ __launch_bounds__(64 * COND_WAVES) void cond_apply_kernel(int64_t p0, int64_t p1, CondDev cd,
-                                                                     const int64_t* __restrict__ patch_ptr,
-                                                                     const int64_t* __restrict__ stage_ptr,
-                                                                     const double* __restrict__ x, double* __restrict__ stage,
-                                                                     int umax, int ordered, int balanced) {
-  extern __shared__ double cond_dsmem[];
-  constexpr int NT_ = 64 * COND_WAVES;
-  if (p0 + blockIdx.x >= p1) return;
-  // full-range launches walk the patches largest first (workgroups are dispatched in index order: with ~7 patches per CU
-  // at config 5's size the big patches must not come last); range launches (overlapped exchanges) keep the natural order
-  const int64_t p = ordered ? cd.order[blockIdx.x] : p0 + blockIdx.x;
-  const int64_t off = patch_ptr[p];
-  const int n = (int)(patch_ptr[p + 1] - off);
-  const int nI = cd.p_nI[p];
-  const int s = n - nI;
-  double* xs = cond_dsmem;
-  double* us = xs + n;
-  double* ys = us + umax;
-  for (int i = threadIdx.x; i < n; i += NT_) xs[i] = x[cd.dofs[off + i]];
-  __syncthreads();
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int64_t g0 = cd.gptr[p], g1 = cd.gptr[p + 1];
-  // phase 1: t_g = X_g x_g (kept in the lanes' registers and written over x_g), u_g = B_g t_g
-  for (int64_t g = g0 + wave; g < g1; g += COND_WAVES) {
-    const int m = cd.g_m[g], sc = cd.g_sc[g], o = cd.g_off[g];
-    const int ldm = cond_ldim(m), ldsc = cond_ldim(sc);
-    const double* X = cd.mat + cd.g_mat[g];
-    const double* B = X + (int64_t)ldm * m;
-    const double xg = lane < m ? xs[o + lane] : 0.0;
-    const double t = cond_gemv_shfl<NT>(X, ldm, m, m, xg, lane, 0.0);
-    const double u = cond_gemv_shfl<NT>(B, ldsc, sc, m, t, lane, 0.0);
-    if (lane < m) xs[o + lane] = t;              // only this wave reads or writes the slice of its group
-    if (lane < sc) us[cd.g_uoff[g] + lane] = u;
-  }
-  __syncthreads();
-  // phase 2: the right-hand side of the Schur system, contributions in a fixed order
-  const int64_t srow0 = cd.sptr[p];
-  for (int i = threadIdx.x; i < s; i += NT_) {
-    double acc = xs[nI + i];
-    for (int32_t q = cd.s_uptr[srow0 + i]; q < cd.s_uptr[srow0 + i + 1]; ++q) acc -= us[cd.s_uidx[q]];
-    xs[nI + i] = acc;
-  }
-  __syncthreads();
-  // phase 3: y_S = inv(Sigma) rhs, row pieces dealt to the waves
-  if (s > 0 && balanced) {
-    // rows dealt to the waves in equal shares (multiples of 16 rows: 128-byte segments per column)
-    const int ld = (s + 1) & ~1;
-    const int share = ((ld + COND_WAVES - 1) / COND_WAVES + 15) & ~15;
-    const int r0 = wave * share, r1 = min(ld, r0 + share);
-    if (r0 < r1) big_rows<NT>(cd.sinv + cd.sinv_ptr[p], s, ld, r0, r1, xs + nI, lane, ys);
-  } else if (s > 0) {
-    const int ld = (s + 1) & ~1;
-    const double* T = cd.sinv + cd.sinv_ptr[p];
-    int piece = 0, row0 = 0;
-    // pieces of 64 rows (not 128) so that a skeleton of a few hundred dofs still occupies every wave
-    for (; row0 + 128 <= ld; row0 += 128, ++piece)
-      if (piece % COND_WAVES == wave) big_piece<64, NT>(T + (int64_t)row0 * s, s, xs + nI, lane, ys + row0);
-    const int rem = ld - row0;
-#define ALFI_BIG_PIECE(R)                                                                                   \
-  if (rem & R) {                                                                                            \
-    if (piece % COND_WAVES == wave) big_piece<R / 2, NT>(T + (int64_t)row0 * s, s, xs + nI, lane, ys + row0); \
-    row0 += R;                                                                                              \
-    ++piece;                                                                                                \
-  }
-    ALFI_BIG_PIECE(64)
-    ALFI_BIG_PIECE(32)
-    ALFI_BIG_PIECE(16)
-    ALFI_BIG_PIECE(8)
-    ALFI_BIG_PIECE(4)
-    ALFI_BIG_PIECE(2)
-#undef ALFI_BIG_PIECE
-  }
-  __syncthreads();
-  // phase 4: y_g = t_g - W_g y_S[S_g] and the skeleton part, into the staging slots of the ascending order
-  double* out = stage + stage_ptr[p];
-  for (int64_t g = g0 + wave; g < g1; g += COND_WAVES) {
-    const int m = cd.g_m[g], sc = cd.g_sc[g], o = cd.g_off[g];
-    const int ldm = cond_ldim(m);
-    const double* W = cd.mat + cd.g_mat[g] + (int64_t)ldm * m + (int64_t)cond_ldim(sc) * m;
-    const double yv = lane < sc ? ys[cd.sidx[cd.g_sidx[g] + lane]] : 0.0;      // lane j holds y_S[S_g[j]]
-    const double tg = lane < m ? xs[o + lane] : 0.0;
-    const double acc = cond_gemv_shfl<NT>(W, ldm, m, sc, -yv, lane, tg);
-    if (lane < m) out[cd.slot[off + o + lane]] = acc;
-  }
-  for (int i = threadIdx.x; i < s; i += NT_) out[cd.slot[off + nI + i]] = ys[i];
-}
-
-// The same apply as THREE launches (the default; ALFI_COND_SPLIT=0 keeps the one-kernel form above).  Measured on config 5's
+// The apply as THREE launches (rounds 1-2: one launch per patch, a wave per group with a lane per row -- dropped).  Measured on config 5's
 // finest level (1765 macro stars, 4.85 GB of factors; kernel trace, same box): the one-launch kernel takes 949 us; its
 // group phases -- a wave per group, a lane per row, 8-byte loads, 30-95 % of the lanes without a row for groups of 3, 9 or
 // 45 entries -- run at 4.0 TB/s and its Schur phase leaves waves idle (312 rows = 2 x 128 + 32 + 16 + 8 over 8 waves).
@@ -1531,7 +1440,8 @@ static int big_factor_core(alfi_ctx* ctx, const BigSource& src, int64_t npatch, 
   const int64_t budget = (int64_t)6 << 30;          // bytes of scratch (matrices + panels) per batch
   const char* env = getenv("ALFI_BIG_SCRATCH_MB");
   const int64_t limit = env ? (int64_t)atoll(env) << 20 : budget;
-  const bool polish = !(getenv("ALFI_BIG_POLISH") && atoi(getenv("ALFI_BIG_POLISH")) == 0);
+  constexpr bool polish = true;   // one Newton-Schulz step after the blocked elimination (explicit pivot-block inverses lose
+                                  // cond * eps: 2e-5 against LAPACK without it, 1e-8 with)
   const int64_t nscr = polish ? 3 : 1;            // X | a second copy of A_p | I - A X
   // batches [p0, p1) within the scratch budget
   struct Batch {
@@ -1619,7 +1529,7 @@ static int big_factor_core(alfi_ctx* ctx, const BigSource& src, int64_t npatch, 
       hipLaunchKernelGGL(big_gemm_kernel, dim3((unsigned)(tiles * tiles), (unsigned)nb), block, 0, ctx->stream, 1,
                          d_patch_ptr, p0, d_scr_ptr, scr, scrR, scrA, tiles);
       result = scrA;
-      static const bool mf_ns2 = !(getenv("ALFI_MF_NS2") && atoi(getenv("ALFI_MF_NS2")) == 0);
+      constexpr bool mf_ns2 = true;
       if (dense_out || (src.M && mf_ns2)) {
         // the coarse operator (one matrix, hundreds of pivot blocks; or the fronts of its sparse factorisation, whose errors
         // travel up the elimination tree through the Schur complements): a second Newton-Schulz step.  The matrix is
@@ -1708,131 +1618,61 @@ int launch_cond_schur_one(alfi_level* L, int64_t p, const int64_t* d_zero, doubl
   return 0;
 }
 
+// One condensed apply = three launches (front / sigma / back).  Two forms of the group products:
+//   * launches of fewer than 1024 patches (the lower levels: config 5's level 1 has 303 stars): chunks of <= 8 consecutive
+//     groups per workgroup, one descriptor per workgroup and per lane, the Schur right-hand side formed by the sigma
+//     workgroups (cond_gfront / cond_gsigma / cond_gback): front + back 48 -> 39 us there;
+//   * larger launches (the finest levels): a workgroup of 8 waves per patch (cond_front / cond_sigma / cond_back): 326 against
+//     338 us on config 5's finest level -- the chunk descriptors are 8 % more bytes.
+// Measured and dropped (rounds 2-3, profiles/r03_cond_apply_ab_cfg5.txt): the whole apply as ONE launch per patch (941 against
+// 860 us on config 5's finest level), 4 or 16 waves per patch on large launches, 16 columns in flight per lane, nontemporal
+// loads for the group matrices (a column of 45 doubles shares its first and last line with its neighbours: 218 against 208 us).
 int launch_cond_apply_range(alfi_level* L, int64_t p0, int64_t p1, const double* x) {
   alfi_ctx* ctx = L->ctx;
   if (p1 <= p0) return 0;
-  static const bool nt = !(getenv("ALFI_NT") && atoi(getenv("ALFI_NT")) == 0);
-  // waves per patch: 8 (measured on config 5, finest level, same box: 4 waves 4.16 TB/s, 8 waves 5.00, 16 waves 4.68);
-  // ALFI_COND_WAVES = 4 / 8 / 16 for A/B runs
-  static const int waves = getenv("ALFI_COND_WAVES") ? atoi(getenv("ALFI_COND_WAVES")) : 8;
+  if (!L->cd.tmp) return alfi_set_error(ctx, ALFI_E_STATE, "condensed apply without its scratch (alfi_patches_set_groups)");
   dim3 grid((unsigned)(p1 - p0));
-  static const bool allow_order = !(getenv("ALFI_COND_ORDER") && atoi(getenv("ALFI_COND_ORDER")) == 0);
-  const int ordered = allow_order && p0 == 0 && p1 == L->npatch && L->cd.order ? 1 : 0;
-  static const int split_mode = getenv("ALFI_COND_SPLIT") ? atoi(getenv("ALFI_COND_SPLIT")) : 1;
-  static const bool split = split_mode != 0;
-  // ALFI_COND_SPLIT: 1 (default) the group products by chunks of groups where a launch has fewer than 1024 patches (config 5,
-  // level 1, 303 stars: front + back 48 -> 39 us) and by patch otherwise (finest level, 1765 stars: 326 against 338 us -- the
-  // descriptors of the chunked form are 8 % more bytes, and both forms run at 5.6-5.8 TB/s of actual HBM traffic); 2 always by
-  // patch; 3 always by chunks; 0 the one-launch kernel
-  if ((split_mode == 3 || (split_mode == 1 && p1 - p0 < 1024)) && L->cd.tmp && L->cd.ubuf) {
-    // group products by chunks of groups, the Schur right-hand side formed by the sigma workgroups
-    static const bool gnt = getenv("ALFI_COND_GROUP_NT") && atoi(getenv("ALFI_COND_GROUP_NT")) != 0;
+  // full-range launches walk the patches largest first (workgroups are dispatched in index order: with ~7 patches per CU at
+  // config 5's size the big patches must not come last); range launches (overlapped exchanges) keep the natural order
+  const int ordered = p0 == 0 && p1 == L->npatch && L->cd.order ? 1 : 0;
+  const int64_t c0 = L->h_cond_chptr[p0], c1 = L->h_cond_chptr[p1];
+  if (p1 - p0 < 1024 && L->cd.ubuf) {
     const int64_t k0 = L->h_cond_gcptr[p0], k1 = L->h_cond_gcptr[p1];
-    const int64_t c0 = L->h_cond_chptr[p0], c1 = L->h_cond_chptr[p1];
     const size_t lds_f = (size_t)L->cond_lds_gfront, lds_b = (size_t)L->cond_lds_gback;
     const size_t lds_s = (size_t)(L->cond_max_s + 2 + 256) * sizeof(double);
-    if (k1 > k0) {
-      if (gnt)
-        hipLaunchKernelGGL((cond_gfront_kernel<true>), dim3((unsigned)(k1 - k0)), dim3(256), lds_f, ctx->stream, k0, L->cd, x);
-      else
-        hipLaunchKernelGGL((cond_gfront_kernel<false>), dim3((unsigned)(k1 - k0)), dim3(256), lds_f, ctx->stream, k0, L->cd, x);
-    }
-    if (c1 > c0) {
-      if (lds_s > 64 * 1024) {     // Schur complements beyond ~7.9 k dofs: raise the kernel's dynamic-LDS limit
-        ALFI_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&cond_gsigma_kernel<true>),
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_s));
-        ALFI_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&cond_gsigma_kernel<false>),
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_s));
-      }
-      if (nt)
-        hipLaunchKernelGGL((cond_gsigma_kernel<true>), dim3((unsigned)(c1 - c0)), dim3(256), lds_s, ctx->stream, c0, L->cd,
-                           L->patch_ptr, L->stage_ptr, x, L->stage);
-      else
-        hipLaunchKernelGGL((cond_gsigma_kernel<false>), dim3((unsigned)(c1 - c0)), dim3(256), lds_s, ctx->stream, c0, L->cd,
-                           L->patch_ptr, L->stage_ptr, x, L->stage);
-    }
-    if (k1 > k0) {
-      if (gnt)
-        hipLaunchKernelGGL((cond_gback_kernel<true>), dim3((unsigned)(k1 - k0)), dim3(256), lds_b, ctx->stream, k0, L->cd,
-                           L->stage);
-      else
-        hipLaunchKernelGGL((cond_gback_kernel<false>), dim3((unsigned)(k1 - k0)), dim3(256), lds_b, ctx->stream, k0, L->cd,
-                           L->stage);
-    }
+    if (k1 > k0)
+      hipLaunchKernelGGL((cond_gfront_kernel<false>), dim3((unsigned)(k1 - k0)), dim3(256), lds_f, ctx->stream, k0, L->cd, x);
+    if (c1 > c0)
+      hipLaunchKernelGGL((cond_gsigma_kernel<true>), dim3((unsigned)(c1 - c0)), dim3(256), lds_s, ctx->stream, c0, L->cd,
+                         L->patch_ptr, L->stage_ptr, x, L->stage);
+    if (k1 > k0)
+      hipLaunchKernelGGL((cond_gback_kernel<false>), dim3((unsigned)(k1 - k0)), dim3(256), lds_b, ctx->stream, k0, L->cd,
+                         L->stage);
     ALFI_HIP_CHECK(ctx, hipGetLastError());
     return 0;
   }
-  if (split && L->cd.tmp) {
-    const size_t lds_f = (size_t)L->cond_lds_front, lds_s = (size_t)(L->cond_max_s + 2) * sizeof(double);
-    const size_t lds_b = (size_t)L->cond_lds_back;
-    const int64_t c0 = L->h_cond_chptr[p0], c1 = L->h_cond_chptr[p1];
-#define ALFI_COND_LAUNCH3(GNT, WV, RU)                                                                                    \
+  const size_t lds_f = (size_t)L->cond_lds_front, lds_s = (size_t)(L->cond_max_s + 2) * sizeof(double);
+  const size_t lds_b = (size_t)L->cond_lds_back;
+#define ALFI_COND_LAUNCH3(WV)                                                                                             \
   do {                                                                                                                    \
     if (lds_f > 64 * 1024)                                                                                                \
-      ALFI_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&cond_front_kernel<GNT, WV, RU>),             \
+      ALFI_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&cond_front_kernel<false, WV, 8>),            \
                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_f));                   \
-    hipLaunchKernelGGL((cond_front_kernel<GNT, WV, RU>), dim3(grid.x), dim3(64 * WV), lds_f, ctx->stream, p0, p1, L->cd,  \
+    hipLaunchKernelGGL((cond_front_kernel<false, WV, 8>), dim3(grid.x), dim3(64 * WV), lds_f, ctx->stream, p0, p1, L->cd, \
                        L->patch_ptr, L->stage_ptr, x, L->stage, ordered);                                                 \
-    if (c1 > c0) {                                                                                                        \
-      if (lds_s > 64 * 1024) {                                                                                            \
-        ALFI_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&cond_sigma_kernel<true>),                  \
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_s));                 \
-        ALFI_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&cond_sigma_kernel<false>),                 \
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_s));                 \
-      }                                                                                                                   \
-      if (nt)                                                                                                             \
-        hipLaunchKernelGGL((cond_sigma_kernel<true>), dim3((unsigned)(c1 - c0)), dim3(256), lds_s, ctx->stream, c0, L->cd, \
-                           L->patch_ptr, L->stage_ptr, L->stage);                                                         \
-      else                                                                                                                \
-        hipLaunchKernelGGL((cond_sigma_kernel<false>), dim3((unsigned)(c1 - c0)), dim3(256), lds_s, ctx->stream, c0,      \
-                           L->cd, L->patch_ptr, L->stage_ptr, L->stage);                                                  \
-    }                                                                                                                     \
+    if (c1 > c0)                                                                                                          \
+      hipLaunchKernelGGL((cond_sigma_kernel<true>), dim3((unsigned)(c1 - c0)), dim3(256), lds_s, ctx->stream, c0, L->cd,  \
+                         L->patch_ptr, L->stage_ptr, L->stage);                                                           \
     if (lds_b > 64 * 1024)                                                                                                \
-      ALFI_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&cond_back_kernel<GNT, WV, RU>),              \
+      ALFI_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&cond_back_kernel<false, WV, 8>),             \
                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b));                   \
-    hipLaunchKernelGGL((cond_back_kernel<GNT, WV, RU>), dim3(grid.x), dim3(64 * WV), lds_b, ctx->stream, p0, p1, L->cd,   \
+    hipLaunchKernelGGL((cond_back_kernel<false, WV, 8>), dim3(grid.x), dim3(64 * WV), lds_b, ctx->stream, p0, p1, L->cd,  \
                        L->patch_ptr, L->stage_ptr, L->stage, ordered);                                                    \
   } while (0)
-    // Same-box kernel traces on config 5: the group matrices are read better WITHOUT the nontemporal hint (front 218 ->
-    // 208 us, back 128 -> 123 us on the finest level; a column of 45 doubles shares its first and last 128-byte line with
-    // its neighbours), inv(Sigma) with it (519 against 573 us): ALFI_COND_GROUP_NT=1 for A/B runs.  16 waves per patch
-    // where a launch has fewer patches than the chip has workgroup slots (level 1, 303 patches: front + back 69 -> 58 us;
-    // finest level, 1765 patches: 345 -> 358 us): ALFI_COND_WAVES=8 / 16 forces one.  ALFI_COND_RU=16: 16 columns in
-    // flight per lane instead of 8 (no gain).
-    static const bool gnt = getenv("ALFI_COND_GROUP_NT") && atoi(getenv("ALFI_COND_GROUP_NT")) != 0;
-    static const int ru = getenv("ALFI_COND_RU") ? atoi(getenv("ALFI_COND_RU")) : 8;
-    static const int waves_env = getenv("ALFI_COND_WAVES") ? atoi(getenv("ALFI_COND_WAVES")) : 0;
-    const int wv = waves_env ? waves_env : (p1 - p0 < 1024 ? 16 : 8);
-    if (wv == 16) {
-      if (gnt) ALFI_COND_LAUNCH3(true, 16, 8); else ALFI_COND_LAUNCH3(false, 16, 8);
-    } else if (ru == 16) {
-      if (gnt) ALFI_COND_LAUNCH3(true, 8, 16); else ALFI_COND_LAUNCH3(false, 8, 16);
-    } else {
-      if (gnt) ALFI_COND_LAUNCH3(true, 8, 8); else ALFI_COND_LAUNCH3(false, 8, 8);
-    }
+  // (a range of fewer than 1024 patches of a level WITHOUT chunk descriptors -- an overlapped exchange on a large level --
+  // takes 16 waves per patch: 303 patches, front + back 69 -> 58 us)
+  if (p1 - p0 < 1024) ALFI_COND_LAUNCH3(16); else ALFI_COND_LAUNCH3(8);
 #undef ALFI_COND_LAUNCH3
-    ALFI_HIP_CHECK(ctx, hipGetLastError());
-    return 0;
-  }
-  const size_t lds = (size_t)L->cond_lds_bytes;
-  // ALFI_COND_BALANCE=0: whole row pieces dealt round-robin to the waves (rounds 1-2)
-  static const int balanced = !(getenv("ALFI_COND_BALANCE") && atoi(getenv("ALFI_COND_BALANCE")) == 0);
-#define ALFI_COND_LAUNCH(NTV, WV)                                                                                       \
-  do {                                                                                                                  \
-    if (lds > 64 * 1024)                                                                                                \
-      ALFI_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&cond_apply_kernel<NTV, WV>),               \
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                   \
-    hipLaunchKernelGGL((cond_apply_kernel<NTV, WV>), grid, dim3(64 * WV), lds, ctx->stream, p0, p1, L->cd, L->patch_ptr, \
-                       L->stage_ptr, x, L->stage, L->cond_umax, ordered, balanced);                                     \
-  } while (0)
-  if (waves == 4) {
-    if (nt) ALFI_COND_LAUNCH(true, 4); else ALFI_COND_LAUNCH(false, 4);
-  } else if (waves == 16) {
-    if (nt) ALFI_COND_LAUNCH(true, 16); else ALFI_COND_LAUNCH(false, 16);
-  } else {
-    if (nt) ALFI_COND_LAUNCH(true, 8); else ALFI_COND_LAUNCH(false, 8);
-  }
-#undef ALFI_COND_LAUNCH
   ALFI_HIP_CHECK(ctx, hipGetLastError());
   return 0;
 }

@@ -290,34 +290,18 @@ __global__ __launch_bounds__(512) void patch_invert_mfma_kernel(const int64_t* _
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// The same elimination with LOOK-AHEAD (round 4).  In the kernel above every one of the 8 waves factors the pivot block,
-// forms its operands, issues its MFMAs and extracts the next panels between the SAME two barriers: the two waves of a SIMD
-// do their vector work together and their matrix work together, so the step costs their SUM (measured: MFMA pipe busy 0.19).
-// Here, per block step s:
-//     all waves      read the factors f(s) of the pivot block and the raw panels from LDS, form the operands
+// The same elimination with LOOK-AHEAD (round 4).  In the kernel above every wave factors the pivot block, forms its operands,
+// issues its MFMAs, waits for them (the fix-ups and the next panels read the accumulators) and only then reaches the barrier:
+// the matrix pipes are idle from there until the next step's operands exist (PMC, config 4 size: 45 % of the wave cycles in
+// s_waitcnt / s_barrier, 29 % in issue stalls, MFMA pipe busy 0.19).  Here, per block step s:
 //     first tiles    the rank-4 update and the fix-ups of the tiles in the tile rows / columns of this AND the next pivot
-//     next panels    their owners put the raw panels of step s + 1 into the other LDS buffer; the ONE wave that owns the next
-//                    pivot tile factors the 4 x 4 block (lu4: four dependent FP64 divisions) and publishes the 28 factors
-//     other tiles    the rank-4 update of the remaining tiles -- the bulk of the MFMAs, issued by waves that have nothing else
-//                    to do while the pivot owner's scalar chain runs                                                -- barrier
-// The LU is done once per step instead of 512 times, the waves of a SIMD are in different phases, and the arithmetic per entry
-// is unchanged (same operands, same order): the inverses are bitwise those of the kernel above.
-struct alignas(16) Lu4Buf {
-  double v[28];
-};
-__device__ __forceinline__ void lu4_store(const Lu4& f, Lu4Buf& o) {
-  o.v[0] = f.l10; o.v[1] = f.l20; o.v[2] = f.l30; o.v[3] = f.l21; o.v[4] = f.l31; o.v[5] = f.l32;
-  o.v[6] = f.u01; o.v[7] = f.u02; o.v[8] = f.u03; o.v[9] = f.u12; o.v[10] = f.u13; o.v[11] = f.u23;
-  o.v[12] = f.i0; o.v[13] = f.i1; o.v[14] = f.i2; o.v[15] = f.i3;
-  o.v[16] = f.s01; o.v[17] = f.s02; o.v[18] = f.s03; o.v[19] = f.s12; o.v[20] = f.s13; o.v[21] = f.s23;
-}
-__device__ __forceinline__ void lu4_load(const Lu4Buf& o, Lu4& f) {
-  f.l10 = o.v[0]; f.l20 = o.v[1]; f.l30 = o.v[2]; f.l21 = o.v[3]; f.l31 = o.v[4]; f.l32 = o.v[5];
-  f.u01 = o.v[6]; f.u02 = o.v[7]; f.u03 = o.v[8]; f.u12 = o.v[9]; f.u13 = o.v[10]; f.u23 = o.v[11];
-  f.i0 = o.v[12]; f.i1 = o.v[13]; f.i2 = o.v[14]; f.i3 = o.v[15];
-  f.s01 = o.v[16]; f.s02 = o.v[17]; f.s03 = o.v[18]; f.s12 = o.v[19]; f.s13 = o.v[20]; f.s23 = o.v[21];
-}
-
+//     next panels    their owners put the raw panels of step s + 1 into the other LDS buffer
+//     other tiles    the rank-4 update of the remaining tiles -- the bulk of the MFMAs -- is ISSUED             -- barrier
+//     pivot block    LU of the next block and the operands, while those MFMAs drain
+// Same operands, same order per entry: the inverses are bitwise those of the kernel above.
+// (First attempt, dropped: ONE wave factors the next pivot block before the barrier and publishes the 28 factors -- the LU is
+// done once per step instead of 512 times, but that wave's four dependent divisions then sit in front of everybody's barrier:
+// 106.4 against 98.9 ms on config 4's finest level.)
 template <int NT>
 __global__ __launch_bounds__(512) void patch_invert_mfma_la_kernel(const int64_t* __restrict__ patch_ptr,
                                                                     const int64_t* __restrict__ inv_ptr,
@@ -327,7 +311,6 @@ __global__ __launch_bounds__(512) void patch_invert_mfma_la_kernel(const int64_t
   constexpr int NB = (NT + 1) / 2;            // tile columns per wave (tj = 2 b + wc)
   __shared__ double Rraw[2][4][N];            // raw row panel   A[K, :]
   __shared__ double Craw[2][N][4];            // raw column panel A[:, K]
-  __shared__ Lu4Buf Fb[2];                    // factors of the pivot block
   const int64_t p = blockIdx.x;
   const int n = (int)(patch_ptr[p + 1] - patch_ptr[p]);
   const int ld = (n + 1) & ~1;
@@ -367,16 +350,6 @@ __global__ __launch_bounds__(512) void patch_invert_mfma_la_kernel(const int64_t
           for (int g = 0; g < 4; ++g) Craw[buf][16 * (4 * a + wr) + lk + 4 * g][lm & 3] = acc[a][bc][g];
         }
     }
-    if (own_r && own_c) {                      // the 16 entries of the pivot block were written by this wave (LDS is in order)
-      double d[4][4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) d[i][j] = Rraw[buf][i][4 * s + j];
-      Lu4 f;
-      lu4(d, f, bad);
-      if (lane == 0) lu4_store(f, Fb[buf]);
-    }
   };
   __syncthreads();  // all loads done before anyone stores (the result goes back in place, in another layout)
   put_panels(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
@@ -389,8 +362,15 @@ __global__ __launch_bounds__(512) void patch_invert_mfma_la_kernel(const int64_t
     const bool own_r = (tk & 3) == wr, own_c = (tk & 1) == wc;     // wave-uniform
     constexpr int ar = tk >> 2, bc = tk >> 1;
     const bool colgrp = (lm >> 2) == q;
+    // ---- LU of the pivot block, redundantly on every lane, WHILE the bulk MFMAs of the previous step (issued just before the
+    //      barrier) drain: the four dependent divisions no longer sit between two idle matrix pipes
+    double d[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) d[i][j] = Rraw[buf][i][4 * s + j];
     Lu4 f;
-    lu4_load(Fb[buf], f);
+    lu4(d, f, bad);
     // ---- operands of the rank-4 update (see the kernel above: forward substitutions with the pivots' own L, U entries)
     const double isel = sel4(lk, f.i0, f.i1, f.i2, f.i3);
     double bop[NB], aop[NA], vop[NA];

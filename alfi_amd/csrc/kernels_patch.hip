@@ -216,11 +216,16 @@ __device__ __forceinline__ double2 load_pair(const double* p) {   // one aligned
   return make_double2(v.x, v.y);
 }
 
-template <int G, bool NT>
+#ifndef ALFI_APPLY_U
+#define ALFI_APPLY_U 8                    // tuning builds: -DALFI_APPLY_U=16
+#endif
+// U = loads kept in flight per lane.  8 for the additive apply (a CU holds 16-32 waves there: 8 KiB in flight per wave fill the
+// memory pipeline); the multiplicative sweep runs ONE wave per patch with ~2 waves per CU, where the wave's own bytes in flight
+// bound it (8 KiB / ~2 us of loaded latency = 4 GB/s per wave: the 46 us per wavefront of round 3) -- it asks for 32.
+template <int G, bool NT, int U = ALFI_APPLY_U>
 __device__ __forceinline__ void apply_piece(const double* __restrict__ T, int n, const double* __restrict__ xs,
                                             int lane, double* __restrict__ out) {
   constexpr int C = 64 / G;  // columns handled per wave instruction
-  constexpr int U = 8;       // loads kept in flight per lane
   const int cg = lane / G, l = lane % G;
   const double* base = T + 2 * l;
   double acc0 = 0.0, acc1 = 0.0;
@@ -236,11 +241,18 @@ __device__ __forceinline__ void apply_piece(const double* __restrict__ T, int n,
       acc1 = __builtin_fma(v[u].y, xj, acc1);
     }
   }
-  for (; j < n; j += C) {
-    const double2 v = load_pair<NT>(base + (int64_t)j * (2 * G));
-    const double xj = xs[j];
-    acc0 = __builtin_fma(v.x, xj, acc0);
-    acc1 = __builtin_fma(v.y, xj, acc1);
+  if (j < n) {       // the last, partial group: its loads are requested together too (same summation order: ascending columns)
+    double2 v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      v[u] = j + u * C < n ? load_pair<NT>(base + (int64_t)(j + u * C) * (2 * G)) : make_double2(0.0, 0.0);
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      if (j + u * C < n) {
+        const double xj = xs[j + u * C];
+        acc0 = __builtin_fma(v[u].x, xj, acc0);
+        acc1 = __builtin_fma(v[u].y, xj, acc1);
+      }
   }
   if (C > 1) {
 #pragma unroll
@@ -294,66 +306,13 @@ __global__ __launch_bounds__(256) void patch_apply_kernel(int64_t p0, int64_t np
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// 3a. additive apply for levels of small patches (all n_p <= 2 G, G = 8 or 16: the 2-D stars with n_p = 14): a wave per
-//     patch would stream 1.5 KB per wave, so G lanes share a patch and a wave handles 64 / G patches.  Lane l owns the row
-//     pair (2l, 2l+1) -- a row pair never straddles two row pieces -- and walks the columns of its piece: one aligned
-//     16-byte load per column, x_p broadcast within the lane group by shuffles.  Same storage, same staging as section 3.
-// ---------------------------------------------------------------------------------------------------------------------
-template <int G, bool NT>
-__global__ __launch_bounds__(256) void patch_apply_small_kernel(int64_t p0, int64_t npatch,
-                                                                 const int64_t* __restrict__ patch_ptr,
-                                                                 const int32_t* __restrict__ patch_dofs,
-                                                                 const int64_t* __restrict__ inv_ptr,
-                                                                 const int64_t* __restrict__ stage_ptr,
-                                                                 const double* __restrict__ inv,
-                                                                 const double* __restrict__ x,
-                                                                 double* __restrict__ stage) {
-  const int64_t p = p0 + ((int64_t)blockIdx.x * 256 + threadIdx.x) / G;   // patches [p0, npatch)
-  const int l = threadIdx.x % G;
-  const bool live = p < npatch;
-  int n = 0;
-  int64_t off = 0;
-  if (live) {
-    off = patch_ptr[p];
-    n = (int)(patch_ptr[p + 1] - off);
-  }
-  const int ld = (n + 1) & ~1;
-  double xa = 0.0, xb = 0.0;   // x_p[l], x_p[l + G]
-  if (l < n) xa = x[patch_dofs[off + l]];
-  if (l + G < n) xb = x[patch_dofs[off + l + G]];
-  const int r = 2 * l;
-  const bool active = live && r < ld;
-  // the piece holding this lane's row pair: entry (r, c) sits at base + c * rows
-  const double* base = inv;
-  int rows = 2;
-  if (active) {
-    base = inv + inv_ptr[p] + patch_inv_index(r, 0, n, ld);
-    rows = (int)(patch_inv_index(r, 1, n, ld) - patch_inv_index(r, 0, n, ld));
-  }
-  double acc0 = 0.0, acc1 = 0.0;
-  // ALL 2 G columns of the lane's row pair are requested before the first one is used (a patch is at most 2 G wide): 16 / 32
-  // independent 16-byte loads in flight per lane instead of 4 -- a wave only has 8 (4) patches of 1.5 (6) KB to stream, so
-  // its run time is the latency of its load batches, not their bandwidth
-  double2 v[2 * G];
-#pragma unroll
-  for (int c = 0; c < 2 * G; ++c)
-    v[c] = (active && c < n) ? load_pair<NT>(base + (int64_t)c * rows) : make_double2(0.0, 0.0);
-#pragma unroll
-  for (int c = 0; c < 2 * G; ++c) {
-    const double lo = __shfl(xa, c & (G - 1), G), hi = __shfl(xb, c & (G - 1), G);
-    const double xc = c < G ? lo : hi;
-    acc0 = __builtin_fma(v[c].x, xc, acc0);
-    acc1 = __builtin_fma(v[c].y, xc, acc1);
-  }
-  if (active) *reinterpret_cast<double2*>(stage + stage_ptr[p] + r) = make_double2(acc0, acc1);
-}
-
-// ---------------------------------------------------------------------------------------------------------------------
-// 3a'. the same apply from the INTERLEAVED copy of the inverses (patch_il_index, common.h): G lanes per patch, PW = 64 / G
-//      patches per wave, column c of the wave's PW patches = ONE contiguous request of PW * G * 16 bytes, the whole wave
-//      group nc such requests back to back.  (From the row-piece layout a wave instruction of the kernel above touches
-//      3 pieces x 8 patches: 24 segments of 16 .. 64 bytes in as many lines -- 4.1 TB/s on ldc2d's finest level.)
-//      G = ceil(max_np / 2) need not be a power of two (the 2-D stars: n_p = 14, G = 7, 9 patches per wave).
+// 3a. additive apply for levels of SMALL patches (every n_p <= 32: the 2-D stars with n_p = 14) from the INTERLEAVED copy of
+//     the inverses (patch_il_index, common.h).  A wave per patch would stream 1.5 KB per wave, so G lanes share a patch
+//     (lane l owns the row pair 2l, 2l + 1), PW = 64 / G patches share a wave, and column c of the wave's PW patches is ONE
+//     contiguous request of PW * G * 16 bytes, the whole wave group nc such requests back to back.  (Rounds 2-3 read the
+//     row-piece storage with 8 lanes per patch: a wave instruction touched 3 pieces x 8 patches = 24 segments of 16 .. 64
+//     bytes in as many lines; same box, ldc2d's finest level: 4.93 -> 4.37 ms per V-cycle, profiles/r04_ab_cfg2.txt.)
+//     G = ceil(max_np / 2) need not be a power of two (n_p = 14: G = 7, 9 patches per wave).
 // ---------------------------------------------------------------------------------------------------------------------
 template <int G, bool NT>
 __global__ __launch_bounds__(256) void patch_apply_il_kernel(int64_t p0, int64_t p1, int nc,
@@ -435,6 +394,8 @@ __global__ __launch_bounds__(256) void patch_il_build_kernel(int64_t npatch, int
 // ---------------------------------------------------------------------------------------------------------------------
 constexpr int MAX_PNODES = 64;
 
+constexpr int MULT_U = 32;     // 16-byte loads in flight per lane in the sweep's inverse apply (see apply_piece)
+
 template <int BS, bool NT>
 __global__ __launch_bounds__(256) void patch_mult_kernel(int64_t count, const int32_t* __restrict__ seq,
                                                           const int64_t* __restrict__ patch_ptr,
@@ -489,64 +450,86 @@ __global__ __launch_bounds__(256) void patch_mult_kernel(int64_t count, const in
     double carry[BS];
 #pragma unroll
     for (int r = 0; r < BS; ++r) carry[r] = 0.0;
-    for (int f0 = 0; f0 < total; f0 += 64) {
-      const int f = f0 + lane;
-      const bool valid = f < total;
-      // row of this lane's block: largest i with pre[i] <= f
-      int lo = 0, hi = nn;
-      while (hi - lo > 1) {
-        const int mid = (lo + hi) >> 1;
-        if (pre[mid] <= f) lo = mid; else hi = mid;
-      }
-      const int row = lo;
-      const bool head = valid && f == pre[row];
-      const bool last = valid && f + 1 == pre[row + 1];
-      double s[BS];
+    // MULT_RU sub-steps of 64 blocks per pass: all their index, value and y loads are requested before the first row sum is
+    // formed (a wave alone on its SIMD has nothing else to hide the latency of a pass with); the sums and the carry then
+    // follow in the same order as with one sub-step per pass
+    constexpr int MULT_RU = 4;
+    for (int f0 = 0; f0 < total; f0 += 64 * MULT_RU) {
+      int row_[MULT_RU];
+      bool valid_[MULT_RU], head_[MULT_RU], last_[MULT_RU];
+      int64_t k_[MULT_RU], col_[MULT_RU];
+      double a_[MULT_RU][BB], yv_[MULT_RU][BS];
 #pragma unroll
-      for (int r = 0; r < BS; ++r) s[r] = 0.0;
-      if (valid) {
-        const int64_t k = (int64_t)k0[row] + (f - pre[row]);
-        const int64_t col = colidx[k] & 0x7fffffff;
-        double a[BB], yv[BS];
+      for (int u = 0; u < MULT_RU; ++u) {
+        const int f = f0 + 64 * u + lane;
+        valid_[u] = f < total;
+        // row of this lane's block: largest i with pre[i] <= f
+        int lo = 0, hi = nn;
+        while (hi - lo > 1) {
+          const int mid = (lo + hi) >> 1;
+          if (pre[mid] <= f) lo = mid; else hi = mid;
+        }
+        row_[u] = lo;
+        head_[u] = valid_[u] && f == pre[lo];
+        last_[u] = valid_[u] && f + 1 == pre[lo + 1];
+        k_[u] = valid_[u] ? (int64_t)k0[lo] + (f - pre[lo]) : 0;
+        col_[u] = valid_[u] ? (int64_t)(colidx[k_[u]] & 0x7fffffff) : 0;
+      }
+#pragma unroll
+      for (int u = 0; u < MULT_RU; ++u) {
 #pragma unroll
         for (int e = 0; e < BB; ++e) {
-          const double* v = vals + bsr_val_index(flat, k, e, BB);
-          a[e] = NT ? __builtin_nontemporal_load(v) : *v;
-        }
-#pragma unroll
-        for (int c = 0; c < BS; ++c) yv[c] = y[col * BS + c];
-#pragma unroll
-        for (int r = 0; r < BS; ++r)
-#pragma unroll
-          for (int c = 0; c < BS; ++c) s[r] = __builtin_fma(a[r * BS + c], yv[c], s[r]);
-      }
-      int fl = head ? 1 : 0;
-#pragma unroll
-      for (int d = 1; d < 64; d <<= 1) {
-        double tp[BS];
-#pragma unroll
-        for (int r = 0; r < BS; ++r) tp[r] = __shfl_up(s[r], d);
-        const int tf = __shfl_up(fl, d);
-        if (lane >= d && !fl) {
-#pragma unroll
-          for (int r = 0; r < BS; ++r) s[r] += tp[r];
-          fl = tf;
+          const double* v = vals + bsr_val_index(flat, k_[u], e, BB);
+          a_[u][e] = valid_[u] ? (NT ? __builtin_nontemporal_load(v) : *v) : 0.0;
         }
       }
-      if (!fl) {
 #pragma unroll
-        for (int r = 0; r < BS; ++r) s[r] += carry[r];
+      for (int u = 0; u < MULT_RU; ++u) {
+#pragma unroll
+        for (int c = 0; c < BS; ++c) yv_[u][c] = valid_[u] ? y[col_[u] * BS + c] : 0.0;
       }
-      if (last) {
 #pragma unroll
-        for (int r = 0; r < BS; ++r) rs[row * BS + r] = x[(int64_t)nd[row] * BS + r] - s[r];
-      }
-      // a row running on into the next 64 blocks is carried; a row closed at lane 63 is not
-      const int last63 = __shfl(last ? 1 : 0, 63);
+      for (int u = 0; u < MULT_RU; ++u) {
+        if (f0 + 64 * u >= total) break;          // wave-uniform
+        const int row = row_[u];
+        const bool head = head_[u], last = last_[u];
+        double s[BS];
 #pragma unroll
-      for (int r = 0; r < BS; ++r) {
-        const double c63 = __shfl(s[r], 63);
-        carry[r] = last63 ? 0.0 : c63;
+        for (int r = 0; r < BS; ++r) s[r] = 0.0;
+        if (valid_[u]) {
+#pragma unroll
+          for (int r = 0; r < BS; ++r)
+#pragma unroll
+            for (int c = 0; c < BS; ++c) s[r] = __builtin_fma(a_[u][r * BS + c], yv_[u][c], s[r]);
+        }
+        int fl = head ? 1 : 0;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+          double tp[BS];
+#pragma unroll
+          for (int r = 0; r < BS; ++r) tp[r] = __shfl_up(s[r], d);
+          const int tf = __shfl_up(fl, d);
+          if (lane >= d && !fl) {
+#pragma unroll
+            for (int r = 0; r < BS; ++r) s[r] += tp[r];
+            fl = tf;
+          }
+        }
+        if (!fl) {
+#pragma unroll
+          for (int r = 0; r < BS; ++r) s[r] += carry[r];
+        }
+        if (last) {
+#pragma unroll
+          for (int r = 0; r < BS; ++r) rs[row * BS + r] = x[(int64_t)nd[row] * BS + r] - s[r];
+        }
+        // a row running on into the next 64 blocks is carried; a row closed at lane 63 is not
+        const int last63 = __shfl(last ? 1 : 0, 63);
+#pragma unroll
+        for (int r = 0; r < BS; ++r) {
+          const double c63 = __shfl(s[r], 63);
+          carry[r] = last63 ? 0.0 : c63;
+        }
       }
     }
   }
@@ -555,11 +538,11 @@ __global__ __launch_bounds__(256) void patch_mult_kernel(int64_t count, const in
     const int ld = (n + 1) & ~1;
     const double* T = inv + inv_ptr[p];
     int row0 = 0;
-    for (; row0 + 128 <= ld; row0 += 128) apply_piece<64, NT>(T + (int64_t)row0 * n, n, rs, lane, ys + row0);
+    for (; row0 + 128 <= ld; row0 += 128) apply_piece<64, NT, MULT_U>(T + (int64_t)row0 * n, n, rs, lane, ys + row0);
     const int rem = ld - row0;
 #define ALFI_PIECE(R)                                                      \
   if (rem & R) {                                                           \
-    apply_piece<R / 2, NT>(T + (int64_t)row0 * n, n, rs, lane, ys + row0); \
+    apply_piece<R / 2, NT, MULT_U>(T + (int64_t)row0 * n, n, rs, lane, ys + row0); \
     row0 += R;                                                             \
   }
     ALFI_PIECE(64)
@@ -668,14 +651,9 @@ int launch_patch_apply_arrays(alfi_ctx* ctx, int64_t npatch, const int64_t* patc
                               const int64_t* inv_ptr, const int64_t* stage_ptr, const double* inv, const double* x,
                               double* stage) {
   if (npatch == 0) return 0;
-  static const bool nt = !(getenv("ALFI_NT") && atoi(getenv("ALFI_NT")) == 0);
   dim3 grid((unsigned)((npatch + 3) / 4)), block(256);
-  if (nt)
-    hipLaunchKernelGGL(patch_apply_kernel<true>, grid, block, 0, ctx->stream, (int64_t)0, npatch, patch_ptr, patch_dofs,
-                       inv_ptr, stage_ptr, inv, x, stage);
-  else
-    hipLaunchKernelGGL(patch_apply_kernel<false>, grid, block, 0, ctx->stream, (int64_t)0, npatch, patch_ptr, patch_dofs,
-                       inv_ptr, stage_ptr, inv, x, stage);
+  hipLaunchKernelGGL(patch_apply_kernel<true>, grid, block, 0, ctx->stream, (int64_t)0, npatch, patch_ptr, patch_dofs,
+                     inv_ptr, stage_ptr, inv, x, stage);
   ALFI_HIP_CHECK(ctx, hipGetLastError());
   return 0;
 }
@@ -684,15 +662,14 @@ int launch_patch_mult_wave(alfi_level* L, const int32_t* seq, int64_t count, con
   alfi_ctx* ctx = L->ctx;
   if (count == 0) return 0;
   if (L->mult_big) return launch_big_mult_wave(L, seq, count, x, y);
-  static const bool nt = !(getenv("ALFI_NT") && atoi(getenv("ALFI_NT")) == 0);
   dim3 grid((unsigned)((count + 3) / 4)), block(256);
 #define ALFI_MULT(BSV, NTV)                                                                                           \
   hipLaunchKernelGGL((patch_mult_kernel<BSV, NTV>), grid, block, 0, ctx->stream, count, seq, L->patch_ptr,            \
                      L->patch_dofs, L->inv_ptr, L->inv, L->A.rowptr, L->A.colidx, L->A.vals, L->A.flat, x, y)
   if (L->bs == 2) {
-    if (nt) ALFI_MULT(2, true); else ALFI_MULT(2, false);
+    ALFI_MULT(2, true);
   } else if (L->bs == 3) {
-    if (nt) ALFI_MULT(3, true); else ALFI_MULT(3, false);
+    ALFI_MULT(3, true);
   } else {
     return alfi_set_error(ctx, ALFI_E_ARG, "unsupported block size %d", L->bs);
   }
@@ -714,9 +691,8 @@ int launch_patch_apply_range(alfi_level* L, int64_t p0, int64_t p1, const double
   // levels with FEW star patches of 3-D size (the lower levels of a hierarchy: 125 and 729 patches under config 3's 35 937):
   // a wave per patch streams ~100 KB through one wave -- ~19 us however few patches there are -- so they take the
   // workgroup-per-patch kernel of the macro stars as well (row pieces dealt to 4 waves, several workgroups per patch when
-  // the chip would stay empty): config 3 17.77 -> 17.46 ms per cycle.  ALFI_SMALL_LEVEL_WG = the patch count up to which
-  // (default 1000; 0: never).
-  static const int64_t few = getenv("ALFI_SMALL_LEVEL_WG") ? atoll(getenv("ALFI_SMALL_LEVEL_WG")) : 1000;
+  // the chip would stay empty): config 3 17.77 -> 17.46 ms per cycle
+  constexpr int64_t few = 1000;
   if (L->max_np > SMALL_PATCH_MAX || (L->max_np > 64 && L->npatch <= few)) {   // one workgroup per patch (kernels_bigpatch.hip)
     ALFI_CHECK(launch_big_apply_range(L, p0, p1, x));
     alfi_prof_end(ctx, t);
@@ -724,9 +700,7 @@ int launch_patch_apply_range(alfi_level* L, int64_t p0, int64_t p1, const double
   }
   const int64_t cnt = p1 - p0;
   dim3 grid((unsigned)((cnt + 3) / 4)), block(256);
-  // the inverses are read once per apply: nontemporal loads keep x, the staging buffer and the index arrays in cache
-  static const bool nt = !(getenv("ALFI_NT") && atoi(getenv("ALFI_NT")) == 0);
-  static const bool small_ok = !(getenv("ALFI_SMALL_PATCH") && atoi(getenv("ALFI_SMALL_PATCH")) == 0);
+  // (the inverses are read once per apply: nontemporal loads keep x, the staging buffer and the index arrays in cache)
   if (L->il_valid) {
     // small patches, interleaved copy of the inverses: G lanes per patch, 64 / G patches per wave
     const int PW = 64 / L->il_G;
@@ -734,37 +708,18 @@ int launch_patch_apply_range(alfi_level* L, int64_t p0, int64_t p1, const double
     dim3 igrid((unsigned)((nwave + 3) / 4));
 #define ALFI_IL(GV)                                                                                                      \
   case GV:                                                                                                               \
-    if (nt)                                                                                                              \
-      hipLaunchKernelGGL((patch_apply_il_kernel<GV, true>), igrid, block, 0, ctx->stream, p0, p1, L->il_nc, L->patch_ptr, \
-                         L->patch_dofs, L->stage_ptr, L->inv_il, x, L->stage);                                           \
-    else                                                                                                                 \
-      hipLaunchKernelGGL((patch_apply_il_kernel<GV, false>), igrid, block, 0, ctx->stream, p0, p1, L->il_nc, L->patch_ptr, \
-                         L->patch_dofs, L->stage_ptr, L->inv_il, x, L->stage);                                           \
+    hipLaunchKernelGGL((patch_apply_il_kernel<GV, true>), igrid, block, 0, ctx->stream, p0, p1, L->il_nc, L->patch_ptr,  \
+                       L->patch_dofs, L->stage_ptr, L->inv_il, x, L->stage);                                             \
     break;
     switch (L->il_G) {
       ALFI_IL(4) ALFI_IL(7) ALFI_IL(8) ALFI_IL(12) ALFI_IL(16)
       default: return alfi_set_error(ctx, ALFI_E_STATE, "interleaved patch storage with %d lanes per patch", L->il_G);
     }
 #undef ALFI_IL
-  } else if (small_ok && L->max_np <= 32) {
-    // small patches: G lanes per patch, 64 / G patches per wave
-    const int G = L->max_np <= 16 ? 8 : 16;
-    dim3 sgrid((unsigned)((cnt * G + 255) / 256));
-#define ALFI_SMALL(GV, NTV)                                                                                            \
-  hipLaunchKernelGGL((patch_apply_small_kernel<GV, NTV>), sgrid, block, 0, ctx->stream, p0, p1, L->patch_ptr,          \
-                     L->patch_dofs, L->inv_ptr, L->stage_ptr, L->inv, x, L->stage)
-    if (G == 8) {
-      if (nt) ALFI_SMALL(8, true); else ALFI_SMALL(8, false);
-    } else {
-      if (nt) ALFI_SMALL(16, true); else ALFI_SMALL(16, false);
-    }
-#undef ALFI_SMALL
-  } else if (nt)
+  } else {
     hipLaunchKernelGGL(patch_apply_kernel<true>, grid, block, 0, ctx->stream, p0, p1, L->patch_ptr, L->patch_dofs,
                        L->inv_ptr, L->stage_ptr, L->inv, x, L->stage);
-  else
-    hipLaunchKernelGGL(patch_apply_kernel<false>, grid, block, 0, ctx->stream, p0, p1, L->patch_ptr, L->patch_dofs,
-                       L->inv_ptr, L->stage_ptr, L->inv, x, L->stage);
+  }
   ALFI_HIP_CHECK(ctx, hipGetLastError());
   alfi_prof_end(ctx, t);
   return 0;
@@ -786,13 +741,11 @@ int launch_patch_sum_range(alfi_level* L, int64_t i0, int64_t i1, const double* 
 int launch_patch_sum(alfi_level* L, const double* x, double* y) { return launch_patch_sum_range(L, 0, L->n, x, y); }
 
 // Small-patch levels (every n_p <= 32, dense inverses): (re)build the interleaved copy the additive apply streams.  Called
-// at the end of every factorisation and after a pivoted repair has rewritten some inverses.  ALFI_PATCH_IL=0: the apply
-// keeps reading the row-piece storage (A/B measurements).
+// at the end of every factorisation and after a pivoted repair has rewritten some inverses.
 int build_patch_il(alfi_level* L) {
   alfi_ctx* ctx = L->ctx;
   L->il_valid = false;
-  static const bool allow = !(getenv("ALFI_PATCH_IL") && atoi(getenv("ALFI_PATCH_IL")) == 0);
-  if (!allow || L->cond || L->npatch == 0 || L->max_np > 32 || L->inv_shrunk) return 0;
+  if (L->cond || L->npatch == 0 || L->max_np > 32 || L->inv_shrunk) return 0;
   const int need = (L->max_np + 1) / 2;
   const int G = need <= 4 ? 4 : need <= 7 ? 7 : need <= 8 ? 8 : need <= 12 ? 12 : 16;
   const int PW = 64 / G, LW = PW * G, nc = L->max_np;

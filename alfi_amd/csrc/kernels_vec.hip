@@ -409,8 +409,7 @@ __global__ __launch_bounds__(256) void spmv_dedup_compact_kernel(const int32_t* 
 
 int build_spmv_dedup(alfi_ctx* ctx, DevBSR* d) {
   d->dedup = false;
-  static const bool allow = !(getenv("ALFI_SPMV_DEDUP") && atoi(getenv("ALFI_SPMV_DEDUP")) == 0);
-  if (!allow || !d->flat || d->aligned || d->nnzb < SPMV_WG) return 0;
+  if (!d->flat || d->aligned || d->nnzb < SPMV_WG) return 0;
   const int64_t nnzb = d->nnzb, ng = (nnzb + SPMV_WG - 1) / SPMV_WG;
   int32_t *tmp = nullptr, *nuniq = nullptr;
   ALFI_HIP_CHECK(ctx, hipMalloc((void**)&d->lidx, (size_t)nnzb * sizeof(uint16_t)));
@@ -506,23 +505,16 @@ static int launch_bsr_spmv_bs(alfi_ctx* ctx, const DevBSR& A, const double* x, d
                               int mode) {
   if (A.flat) {
     if (A.nnzb == 0) return 0;
-    // operator values and indices are used once per product: stream them past the caches (nontemporal) so that x and y
-    // keep the L2 / Infinity Cache.  ALFI_NT=0 switches to plain loads (A/B measurements).
-    static const bool nt = !(getenv("ALFI_NT") && atoi(getenv("ALFI_NT")) == 0);
-    // ALFI_XCD_MAP: 0 plain interleaved order, 1 contiguous eighths (measured slower, both kernels), > 1 strips of that many
-    // workgroups per XCD (de-duplicated kernel only).  Default 64: config 4 finest, same box, 6.29 -> 6.45 TB/s for any strip
-    // size 16 .. 1024
-    static const int xcd = getenv("ALFI_XCD_MAP") ? atoi(getenv("ALFI_XCD_MAP")) : 64;
+    // operator values and indices are used once per product: they are streamed past the caches (nontemporal loads) so that x
+    // and y keep the L2 / Infinity Cache.
+    // Workgroups are dealt to the 8 XCDs in strips of 64 (de-duplicated kernel): config 4 finest, same box, 6.29 -> 6.45 TB/s
+    // for any strip size 16 .. 1024; plain interleaved order and contiguous eighths measured slower
+    constexpr int xcd = 64;
     if (A.aligned) {          // whole rows per chunk: one launch, no fix-up
       const int64_t nchunks = A.nchunks;
-      if (nt)
-        hipLaunchKernelGGL((bsr_spmv_flat_kernel<BS, true, true>), dim3((unsigned)((nchunks + 3) / 4)), dim3(256), 0,
-                           ctx->stream, A.kbase, A.nnzb, nchunks, A.chunk_start, A.colidx, A.vals, A.chunk_row, x, y, b,
-                           alpha, mode, A.carry, A.carry_row, 0);
-      else
-        hipLaunchKernelGGL((bsr_spmv_flat_kernel<BS, false, true>), dim3((unsigned)((nchunks + 3) / 4)), dim3(256), 0,
-                           ctx->stream, A.kbase, A.nnzb, nchunks, A.chunk_start, A.colidx, A.vals, A.chunk_row, x, y, b,
-                           alpha, mode, A.carry, A.carry_row, 0);
+      hipLaunchKernelGGL((bsr_spmv_flat_kernel<BS, true, true>), dim3((unsigned)((nchunks + 3) / 4)), dim3(256), 0,
+                         ctx->stream, A.kbase, A.nnzb, nchunks, A.chunk_start, A.colidx, A.vals, A.chunk_row, x, y, b,
+                         alpha, mode, A.carry, A.carry_row, 0);
       ALFI_HIP_CHECK(ctx, hipGetLastError());
       return 0;
     }
@@ -531,12 +523,8 @@ static int launch_bsr_spmv_bs(alfi_ctx* ctx, const DevBSR& A, const double* x, d
       hipLaunchKernelGGL((bsr_spmv_dedup_kernel<BS>), dim3((unsigned)((nchunks + 3) / 4)), dim3(256), 0, ctx->stream,
                          A.nnzb, nchunks, A.lidx, A.ucol, A.uptr, A.colidx, A.vals, A.chunk_row, x, y, b, alpha, mode,
                          A.carry, A.carry_row, xcd);
-    else if (nt)
-      hipLaunchKernelGGL((bsr_spmv_flat_kernel<BS, true, false>), dim3((unsigned)((nchunks + 3) / 4)), dim3(256), 0,
-                         ctx->stream, A.kbase, A.nnzb, nchunks, (const int64_t*)nullptr, A.colidx, A.vals, A.chunk_row, x,
-                         y, b, alpha, mode, A.carry, A.carry_row, xcd);
     else
-      hipLaunchKernelGGL((bsr_spmv_flat_kernel<BS, false, false>), dim3((unsigned)((nchunks + 3) / 4)), dim3(256), 0,
+      hipLaunchKernelGGL((bsr_spmv_flat_kernel<BS, true, false>), dim3((unsigned)((nchunks + 3) / 4)), dim3(256), 0,
                          ctx->stream, A.kbase, A.nnzb, nchunks, (const int64_t*)nullptr, A.colidx, A.vals, A.chunk_row, x,
                          y, b, alpha, mode, A.carry, A.carry_row, xcd);
     ALFI_HIP_CHECK(ctx, hipGetLastError());

@@ -567,7 +567,7 @@ static int mf_analyse(alfi_level* L, const double* coords, int dim, int leaf_nod
   m->n = L->n;
   m->nnode = nt;
   m->H = H;
-  m->refine = getenv("ALFI_MF_REFINE") ? atoi(getenv("ALFI_MF_REFINE")) : 1;
+  m->refine = 1;
   m->leaf = leaf_nodes;
   m->with_coords = coords != nullptr;
   m->nnzb = L->A.nnzb;
@@ -798,7 +798,7 @@ static int mf_numeric(alfi_level* L, MfDev* m) {
         tsb = std::max(tsb, (Ns / BIG_NB) * (Nb / BIG_NB));
         tbb = std::max(tbb, (Nb / BIG_NB) * (Nb / BIG_NB));
       }
-      static const bool corr = !(getenv("ALFI_MF_CORRECT") && atoi(getenv("ALFI_MF_CORRECT")) == 0);
+      constexpr bool corr = true;
       const int modes[7] = {0, 1, 2, 1, 0, 1, 2};
       for (int i = 0; i < 7 && rc == 0; ++i) {
         if (!corr && (i == 1 || i == 2 || i == 5 || i == 6)) continue;
@@ -826,7 +826,7 @@ static int mf_numeric(alfi_level* L, MfDev* m) {
 // (Re-)factorisation of the level operator.  The plan of an earlier call is reused when it was made for the same ordering
 // request (the sparsity of a level never changes; new values arrive through alfi_level_update_values).
 int mf_factor(alfi_level* L, const double* coords, int dim, int leaf_nodes) {
-  if (leaf_nodes <= 0) leaf_nodes = getenv("ALFI_MF_LEAF") ? atoi(getenv("ALFI_MF_LEAF")) : 64;
+  if (leaf_nodes <= 0) leaf_nodes = 64;
   MfDev* m = L->mf;
   if (m && (m->leaf != leaf_nodes || m->with_coords != (coords != nullptr) || m->nnzb != L->A.nnzb || m->n != L->n)) {
     mf_free(m);

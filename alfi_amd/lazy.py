@@ -274,6 +274,15 @@ class LazyTransfer(object):
         self.n_f, self.n_c = Vf.num_dofs, Vc.num_dofs
         self.bc_dofs_f, self.bc_dofs_c = Vf.bc_dofs, Vc.bc_dofs
         self._geom, self._tens = geometry, tensors
+        self._inject_map = None
+
+    @property
+    def inject_map(self):
+        """fine node coinciding with every coarse node (firedrake.inject on the nested hierarchy, alfi/solver.py:595)"""
+        if self._inject_map is None:
+            from .fespace import injection_map
+            self._inject_map = injection_map(self.Vc, self.Vf)
+        return self._inject_map
 
     def interior_mats(self, blocks):
         """(K_II, D_II) of the coarse-cell blocks ``blocks``: (len(blocks), m, m) each (forms of alfi/transfer.py:319-324)."""

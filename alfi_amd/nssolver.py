@@ -74,7 +74,7 @@ class HipNavierStokesSolver(object):
             from .sv import build_sv_hierarchy, build_sv_pressure_coupling
             self.levels, self.transfers = build_sv_hierarchy(problem, nref, k, Re=0.0, gamma=gamma)
         else:
-            self.levels, self.transfers = build_hierarchy(problem, nref, k, Re=0.0, gamma=gamma)
+            self.levels, self.transfers = build_hierarchy(problem, nref, k, Re=0.0, gamma=gamma, lazy=self._lazy_generation())
         if self.sv:      # patch = macro with the problem's relaxation direction (solver.py:339-342), sparse-LU patch options
             from .solver import configure_patch_solver_sv
             mgl = configure_patch_solver_sv(mg_levels_solver(dim, patch="macro", smoothing=smoothing,
@@ -121,6 +121,11 @@ class HipNavierStokesSolver(object):
         self.area = float(self.vol.sum())
 
     # -- device side (overridden by alfi_amd.dist.DistNavierStokesSolver for partitioned levels) -------------------------
+    def _lazy_generation(self):
+        """Operators and transfers as recipes that assemble the rows somebody asks for (alfi_amd.lazy) instead of global
+        values: for the partitioned solver, whose ranks only ever need their own rows."""
+        return False
+
     def _create_device(self, restriction):
         self.ctx = self._ctx_arg or hip.Context(0)
         self.hmg = HipMG(self.ctx, self.levels, self.transfers, self.params["fieldsplit_0"], restriction=restriction)

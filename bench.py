@@ -95,13 +95,13 @@ def build_problem(cfg, verbose, lazy=False):
 def apply_kernel_name(L):
     from alfi_amd.hip import condense_patches
     if condense_patches(L):
-        mode = os.environ.get("ALFI_COND_SPLIT", "1")           # one apply = three launches (kernels_bigpatch.hip)
-        if mode == "3":
+        # one apply = three launches (kernels_bigpatch.hip): a workgroup per patch on launches of >= 1024 patches, chunks of
+        # groups (cond_g* kernels) on smaller ones
+        if len(L.patch_ptr) - 1 < 1024:
             return "cond_gfront_kernel + cond_gsigma_kernel + cond_gback_kernel"
-        if mode != "0":   # (default 1: these on launches of >= 1024 patches, the chunked cond_g* kernels on smaller ones)
-            return "cond_front_kernel + cond_sigma_kernel + cond_back_kernel"
-        return "cond_apply_kernel"
-    return "big_apply_kernel" if np.diff(L.patch_ptr).max() > 160 else "patch_apply_kernel"
+        return "cond_front_kernel + cond_sigma_kernel + cond_back_kernel"
+    n = np.diff(L.patch_ptr).max()
+    return "big_apply_kernel" if n > 160 else ("patch_apply_il_kernel" if n <= 32 else "patch_apply_kernel")
 
 
 def vcycle_bytes(levels, dmg, k):
@@ -503,7 +503,7 @@ def spawn_ranks(n):
         # watchdog (ALFI_BENCH_TIMEOUT_S, 0 = off): a communicator that never forms or an exchange whose send/recv groups
         # do not pair would otherwise spin until the driver's own limit and leave nothing to diagnose; the grace period
         # lets the ranks' own watchdogs (same limit) report first
-        if limit > 0 and time.time() - t_start > limit + 15.0:
+        if limit > 0 and time.time() - t_start > limit + float(os.environ.get("ALFI_BENCH_GRACE_S", "15")):
             timed_out = True
             break
     if failed is not None or timed_out:
