@@ -69,6 +69,16 @@ static void dev_free(void* p) {
 }
 static int upload_csr(alfi_ctx* ctx, DevCSR* d, const alfi_csr_host* h);
 static void free_csr(DevCSR* d);
+static void free_mult_schedule(alfi_level* L);
+// the sticky device-side error word (bounded waits of persistent kernels), read after a synchronisation
+static int check_dev_err(alfi_ctx* ctx) {
+  if (!ctx->dev_err) return 0;
+  int32_t e = 0;
+  if (hipMemcpy(&e, ctx->dev_err, sizeof(e), hipMemcpyDeviceToHost) != hipSuccess) return 0;
+  if (e != 0) return alfi_set_error(ctx, ALFI_E_STATE, "a device-side dependency wait ran into its bound (multiplicative sweep "
+                                    "schedule): results since then are incomplete");
+  return 0;
+}
 
 // Chunk tables of the flat layout.  Large matrices: equal chunks of SPMV_CHUNK blocks (rows may continue into the next
 // chunk; the fix-up launch completes them).  Small ones (nnzb <= SPMV_ALIGNED_MAX, no row longer than a chunk, unless
@@ -336,6 +346,10 @@ int alfi_ctx_create(int device, void* stream, alfi_ctx** out) {
     delete ctx;
     return alfi_set_error(nullptr, ALFI_E_HIP, "hipMalloc failed");
   }
+  if (hipMalloc((void**)&ctx->dev_err, 16) != hipSuccess || hipMemset(ctx->dev_err, 0, 16) != hipSuccess) {
+    delete ctx;
+    return alfi_set_error(nullptr, ALFI_E_HIP, "hipMalloc failed");
+  }
   *out = ctx;
   return 0;
 }
@@ -350,6 +364,7 @@ int alfi_ctx_destroy(alfi_ctx* ctx) {
   }
   dev_free(ctx->red_partial);
   dev_free(ctx->red_partial2);
+  dev_free(ctx->dev_err);
   (void)hipFree(ctx->big_arena);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
@@ -358,7 +373,7 @@ int alfi_ctx_destroy(alfi_ctx* ctx) {
 
 int alfi_ctx_sync(alfi_ctx* ctx) {
   ALFI_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-  return 0;
+  return check_dev_err(ctx);
 }
 
 const char* alfi_last_error(alfi_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
@@ -380,7 +395,7 @@ int alfi_memcpy_h2d(alfi_ctx* ctx, void* dst, const void* src, int64_t bytes) {
 int alfi_memcpy_d2h(alfi_ctx* ctx, void* dst, const void* src, int64_t bytes) {
   ALFI_HIP_CHECK(ctx, hipMemcpyAsync(dst, src, (size_t)bytes, hipMemcpyDeviceToHost, ctx->stream));
   ALFI_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-  return 0;
+  return check_dev_err(ctx);
 }
 int alfi_memset0(alfi_ctx* ctx, void* dst, int64_t bytes) {
   ALFI_HIP_CHECK(ctx, hipMemsetAsync(dst, 0, (size_t)bytes, ctx->stream));
@@ -632,6 +647,7 @@ int alfi_level_destroy(alfi_level* L) {
   dev_free(L->dof_ptr);
   dev_free(L->dof_pos);
   dev_free(L->mult_seq);
+  free_mult_schedule(L);
   dev_free(L->status);
   dev_free(L->chk);
   dev_free(L->chk_list);
@@ -920,6 +936,21 @@ static int level_patch_apply(alfi_level* L, const double* dx, double* dy, bool* 
     ALFI_HIP_CHECK(ctx, hipMemsetAsync(dy, 0, sizeof(double) * L->n, ctx->stream));
     int t = alfi_prof_begin(ctx, ALFI_EV_PATCH_APPLY);
     const int64_t nw = (int64_t)L->mult_wave_ptr.size() - 1;
+    // ALFI_MULT_PERSISTENT=0: one launch per dependency wavefront (the schedule of rounds 1-3; kept for the bitwise comparison)
+    static const bool persistent = !(getenv("ALFI_MULT_PERSISTENT") && atoi(getenv("ALFI_MULT_PERSISTENT")) == 0);
+    if (persistent && L->mult_nitems > 0) {
+      // (a wait that runs into its bound sets the ctx's sticky error word, reported by the next synchronising call: no host
+      // synchronisation inside the smoother)
+      ALFI_CHECK(launch_patch_mult_persistent(L, dx, dy));
+      alfi_prof_end(ctx, t);
+      if (L->distributed) ALFI_CHECK(halo_rev(L, dy));
+      if (L->nbc > 0) {
+        t = alfi_prof_begin(ctx, ALFI_EV_PATCH_SCATTER);
+        ALFI_CHECK(launch_copy_dofs(ctx, dy, dx, L->bc_dofs, L->nbc));
+        alfi_prof_end(ctx, t);
+      }
+      return 0;
+    }
     for (int64_t w = 0; w < nw; ++w)
       ALFI_CHECK(launch_patch_mult_wave(L, L->mult_seq + L->mult_wave_ptr[w], L->mult_wave_ptr[w + 1] - L->mult_wave_ptr[w],
                                         dx, dy));
@@ -1049,6 +1080,7 @@ int alfi_patches_set(alfi_level* L, int64_t npatch, const int64_t* pptr, const i
   L->mult_seq = nullptr;
   L->mult = false;
   L->mult_wave_ptr.clear();
+  free_mult_schedule(L);
   // a new patch set invalidates the interior-patch count of alfi_level_set_overlap: back to the plain exchange until the
   // caller declares the new one
   L->overlap = false;
@@ -1365,6 +1397,13 @@ int alfi_patches_factor_bytes(alfi_level* L, int64_t* bytes) {
   return 0;
 }
 
+static void free_mult_schedule(alfi_level* L) {
+  dev_free(L->mult_items); dev_free(L->mult_pred0); dev_free(L->mult_pred); dev_free(L->mult_succ_ptr);
+  dev_free(L->mult_succ); dev_free(L->mult_ctl);
+  L->mult_items = L->mult_pred0 = L->mult_pred = L->mult_succ_ptr = L->mult_succ = L->mult_ctl = nullptr;
+  L->mult_nitems = 0;
+}
+
 int alfi_patches_set_multiplicative(alfi_level* L, int64_t nit, const int64_t* iterset, int symmetrise) {
   alfi_ctx* ctx = L->ctx;
   if (!L->patch_ptr) return alfi_set_error(ctx, ALFI_E_STATE, "alfi_patches_set_multiplicative before alfi_patches_set");
@@ -1374,6 +1413,7 @@ int alfi_patches_set_multiplicative(alfi_level* L, int64_t nit, const int64_t* i
   L->mult_seq = nullptr;
   L->mult = false;
   L->mult_wave_ptr.clear();
+  free_mult_schedule(L);
   if (nit == 0) return 0;
   if (nit < 0 || !iterset) return alfi_set_error(ctx, ALFI_E_ARG, "bad iteration set");
   if (L->cond) return alfi_set_error(ctx, ALFI_E_STATE, "multiplicative sweeps need dense patch inverses (alfi_patches_set_groups(NULL))");
@@ -1434,6 +1474,61 @@ int alfi_patches_set_multiplicative(alfi_level* L, int64_t nit, const int64_t* i
   ALFI_CHECK(dev_upload(ctx, &L->mult_seq, seq.data(), nit));
   L->mult = true;
   L->mult_symmetrise = symmetrise != 0;
+  // ---- the persistent schedule (wave-per-patch levels): items = the forward sweep in wavefront-major order, then (symmetrised)
+  // the wavefronts in reverse order, each in its listed order -- exactly the launch sequence of the per-wavefront schedule.
+  // Predecessors of an item = the LAST WRITERS (earlier items) of the nodes it reads: patches writing the same node conflict
+  // with each other, so earlier writers are ordered before the last one transitively; a patch that READS a node this item
+  // writes has, by the symmetric sparsity, nodes in this item's closure, whose last writer is that patch or a later conflicting
+  // one.  The list order is a topological order of these dependencies.
+  free_mult_schedule(L);
+  if (!L->mult_big) {
+    std::vector<int32_t> items(seq);
+    if (symmetrise)
+      for (int32_t w = nwave - 1; w >= 0; --w)
+        for (int64_t q = L->mult_wave_ptr[w]; q < L->mult_wave_ptr[w + 1]; ++q) items.push_back(seq[q]);
+    const int64_t N = (int64_t)items.size();
+    if (N > INT32_MAX / 2) return alfi_set_error(ctx, ALFI_E_ARG, "iteration set too long for the persistent schedule");
+    std::vector<int32_t> last_writer(nb, -1), pred0(N, 0), tmp;
+    std::vector<std::vector<int32_t>> succ_of;     // built as (pred, item) pairs to keep memory flat
+    std::vector<int32_t> e_from, e_to;
+    e_from.reserve((size_t)N * 32);
+    e_to.reserve((size_t)N * 32);
+    for (int64_t t = 0; t < N; ++t) {
+      const int64_t p = items[t];
+      const int64_t a = L->h_patch_ptr[p], b = L->h_patch_ptr[p + 1];
+      tmp.clear();
+      for (int64_t q = a; q < b; q += bs) {
+        const int32_t node = L->h_patch_dofs[q] / bs;
+        for (int32_t k = rowptr[node]; k < rowptr[node + 1]; ++k) {
+          const int32_t lw = last_writer[colidx[k] & 0x7fffffff];
+          if (lw >= 0) tmp.push_back(lw);
+        }
+      }
+      std::sort(tmp.begin(), tmp.end());
+      tmp.erase(std::unique(tmp.begin(), tmp.end()), tmp.end());
+      pred0[t] = (int32_t)tmp.size();
+      for (int32_t f : tmp) {
+        e_from.push_back(f);
+        e_to.push_back((int32_t)t);
+      }
+      for (int64_t q = a; q < b; q += bs) last_writer[L->h_patch_dofs[q] / bs] = (int32_t)t;
+    }
+    if (e_from.size() > (size_t)INT32_MAX) return alfi_set_error(ctx, ALFI_E_ARG, "too many dependencies for int32 offsets");
+    std::vector<int32_t> succ_ptr(N + 1, 0), succ(e_from.size() > 0 ? e_from.size() : 1);
+    for (int32_t f : e_from) succ_ptr[f + 1]++;
+    for (int64_t t = 0; t < N; ++t) succ_ptr[t + 1] += succ_ptr[t];
+    {
+      std::vector<int32_t> fill(succ_ptr.begin(), succ_ptr.end() - 1);
+      for (size_t e = 0; e < e_from.size(); ++e) succ[fill[e_from[e]]++] = e_to[e];
+    }
+    ALFI_CHECK(dev_upload(ctx, &L->mult_items, items.data(), N));
+    ALFI_CHECK(dev_upload(ctx, &L->mult_pred0, pred0.data(), N));
+    ALFI_CHECK(dev_alloc(ctx, &L->mult_pred, N));
+    ALFI_CHECK(dev_upload(ctx, &L->mult_succ_ptr, succ_ptr.data(), N + 1));
+    ALFI_CHECK(dev_upload(ctx, &L->mult_succ, succ.data(), (int64_t)succ.size()));
+    ALFI_CHECK(dev_alloc(ctx, &L->mult_ctl, 4));
+    L->mult_nitems = (int32_t)N;
+  }
   return 0;
 }
 

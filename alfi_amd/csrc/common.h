@@ -12,6 +12,8 @@ struct alfi_ctx {
   hipStream_t stream = nullptr;
   // exchange points since alfi_ctx_comm_stats(reset): halo exchanges (forward + reverse), all-reduces, doubles this rank sent
   int64_t comm_nhalo = 0, comm_nred = 0, comm_sent = 0;
+  int32_t* dev_err = nullptr;       // sticky device-side error word (a bounded wait of a persistent kernel ran out); read by
+                                    // every call that synchronises (alfi_ctx_sync, alfi_memcpy_d2h)
   bool use_graph = false;           // alfi_ctx_set_graph: replay whole cycles as hipGraphs (not while profiling / partitioned)
   void* big_arena = nullptr;        // scratch of the large-block factorisation (kernels_bigpatch.hip), kept between calls
   size_t big_arena_bytes = 0;
@@ -361,6 +363,11 @@ struct alfi_level {
   bool mult_big = false;                // a patch holds more than 64 nodes: workgroup-per-patch sweep kernel
   int32_t* mult_seq = nullptr;          // (nit) patch ids, wavefront-major
   std::vector<int64_t> mult_wave_ptr;   // (nwave+1) offsets into mult_seq
+  // persistent schedule of the whole apply (forward sweep, then -- symmetrised -- the wavefronts in reverse): item -> patch,
+  // predecessor counts (the last writers of the nodes an item reads), successor lists
+  int32_t mult_nitems = 0;
+  int32_t *mult_items = nullptr, *mult_pred0 = nullptr, *mult_pred = nullptr, *mult_succ_ptr = nullptr, *mult_succ = nullptr;
+  int32_t* mult_ctl = nullptr;          // [0] ticket counter (zeroed before every launch)
   std::vector<int32_t> h_patch_dofs;    // host copy of the patch dofs (needed to build the wavefronts)
   // FGMRES workspace
   int kmax = 0;
@@ -494,6 +501,8 @@ int launch_patch_sum(alfi_level* lvl, const double* x, double* y);             /
 int launch_patch_sum_range(alfi_level* lvl, int64_t i0, int64_t i1, const double* x, double* y);   // stage 2, dofs [i0, i1)
 // one dependency wavefront of a multiplicative sweep: patches seq[0..count): y_p += inv(A_p) (x - A y)_p
 int launch_patch_mult_wave(alfi_level* lvl, const int32_t* seq, int64_t count, const double* x, double* y);
+// the whole (symmetrised) sweep as one launch of a resident grid walking the schedule with per-item dependency counters
+int launch_patch_mult_persistent(alfi_level* lvl, const double* x, double* y);
 // the same with a workgroup per patch: patches of more than 64 nodes (macro stars)
 int launch_big_mult_wave(alfi_level* lvl, const int32_t* seq, int64_t count, const double* x, double* y);
 int launch_invert_small_any(alfi_ctx* ctx, int nmax, int64_t nmat, const int64_t* ptr, const int64_t* inv_ptr,

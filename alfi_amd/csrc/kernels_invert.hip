@@ -289,200 +289,15 @@ __global__ __launch_bounds__(512) void patch_invert_mfma_kernel(const int64_t* _
     }
 }
 
-// ---------------------------------------------------------------------------------------------------------------------
-// The same elimination with LOOK-AHEAD (round 4).  In the kernel above every wave factors the pivot block, forms its operands,
-// issues its MFMAs, waits for them (the fix-ups and the next panels read the accumulators) and only then reaches the barrier:
-// the matrix pipes are idle from there until the next step's operands exist (PMC, config 4 size: 45 % of the wave cycles in
-// s_waitcnt / s_barrier, 29 % in issue stalls, MFMA pipe busy 0.19).  Here, per block step s:
-//     first tiles    the rank-4 update and the fix-ups of the tiles in the tile rows / columns of this AND the next pivot
-//     next panels    their owners put the raw panels of step s + 1 into the other LDS buffer
-//     other tiles    the rank-4 update of the remaining tiles -- the bulk of the MFMAs -- is ISSUED             -- barrier
-//     pivot block    LU of the next block and the operands, while those MFMAs drain
-// Same operands, same order per entry: the inverses are bitwise those of the kernel above.
-// (First attempt, dropped: ONE wave factors the next pivot block before the barrier and publishes the 28 factors -- the LU is
-// done once per step instead of 512 times, but that wave's four dependent divisions then sit in front of everybody's barrier:
-// 106.4 against 98.9 ms on config 4's finest level.)
-template <int NT>
-__global__ __launch_bounds__(512) void patch_invert_mfma_la_kernel(const int64_t* __restrict__ patch_ptr,
-                                                                    const int64_t* __restrict__ inv_ptr,
-                                                                    double* __restrict__ inv, int* __restrict__ status) {
-  constexpr int N = 16 * NT;
-  constexpr int NA = (NT + 3) / 4;            // tile rows per wave (ti = 4 a + wr)
-  constexpr int NB = (NT + 1) / 2;            // tile columns per wave (tj = 2 b + wc)
-  __shared__ double Rraw[2][4][N];            // raw row panel   A[K, :]
-  __shared__ double Craw[2][N][4];            // raw column panel A[:, K]
-  const int64_t p = blockIdx.x;
-  const int n = (int)(patch_ptr[p + 1] - patch_ptr[p]);
-  const int ld = (n + 1) & ~1;
-  double* S = inv + inv_ptr[p];
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-  const int wr = wave >> 1, wc = wave & 1;
-  const int lm = lane & 15, lk = lane >> 4;
-  inv_d4 acc[NA][NB];
-#pragma unroll
-  for (int a = 0; a < NA; ++a)
-#pragma unroll
-    for (int b = 0; b < NB; ++b) {
-      const int ti = 4 * a + wr, tj = 2 * b + wc;
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int r = 16 * ti + lk + 4 * g, c = 16 * tj + lm;
-        acc[a][b][g] = (r < n && c < n) ? S[(int64_t)r * ld + c] : (r == c ? 1.0 : 0.0);
-      }
-    }
-  bool bad = false;
-  // panels of step (tk, q) -> LDS buffer s & 1; the owner of the pivot tile factors the block and publishes the factors
-  auto put_panels = [&](auto TK, auto Q) __attribute__((always_inline)) {
-    constexpr int tk = decltype(TK)::value, q = decltype(Q)::value, s = 4 * tk + q, buf = s & 1;
-    constexpr int ar = tk >> 2, bc = tk >> 1;
-    const bool own_r = (tk & 3) == wr, own_c = (tk & 1) == wc;
-    const bool colgrp = (lm >> 2) == q;
-    if (own_r) {
-#pragma unroll
-      for (int b = 0; b < NB; ++b)
-        if (2 * b + wc < NT) Rraw[buf][lk][16 * (2 * b + wc) + lm] = acc[ar][b][q];
-    }
-    if (own_c && colgrp) {
-#pragma unroll
-      for (int a = 0; a < NA; ++a)
-        if (4 * a + wr < NT) {
-#pragma unroll
-          for (int g = 0; g < 4; ++g) Craw[buf][16 * (4 * a + wr) + lk + 4 * g][lm & 3] = acc[a][bc][g];
-        }
-    }
-  };
-  __syncthreads();  // all loads done before anyone stores (the result goes back in place, in another layout)
-  put_panels(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
-  __syncthreads();
-  static_for<0, 4 * NT>([&](auto SS) __attribute__((always_inline)) {
-    constexpr int s = decltype(SS)::value, tk = s >> 2, q = s & 3, buf = s & 1;
-    if (4 * s >= n) return;                   // uniform: the remaining pivots are identity padding
-    constexpr int s1 = s + 1, tk1 = s1 >> 2, q1 = s1 & 3;
-    const bool have_next = s1 < 4 * NT && 4 * s1 < n;        // uniform
-    const bool own_r = (tk & 3) == wr, own_c = (tk & 1) == wc;     // wave-uniform
-    constexpr int ar = tk >> 2, bc = tk >> 1;
-    const bool colgrp = (lm >> 2) == q;
-    // ---- LU of the pivot block, redundantly on every lane, WHILE the bulk MFMAs of the previous step (issued just before the
-    //      barrier) drain: the four dependent divisions no longer sit between two idle matrix pipes
-    double d[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) d[i][j] = Rraw[buf][i][4 * s + j];
-    Lu4 f;
-    lu4(d, f, bad);
-    // ---- operands of the rank-4 update (see the kernel above: forward substitutions with the pivots' own L, U entries)
-    const double isel = sel4(lk, f.i0, f.i1, f.i2, f.i3);
-    double bop[NB], aop[NA], vop[NA];
-#pragma unroll
-    for (int b = 0; b < NB; ++b) {
-      const int tj = 2 * b + wc;
-      bop[b] = 0.0;
-      if (tj < NT) {
-        const int c = 16 * tj + lm;
-        const double x0 = Rraw[buf][0][c], x1 = Rraw[buf][1][c], x2 = Rraw[buf][2][c], x3 = Rraw[buf][3][c];
-        const double y1 = __builtin_fma(-f.l10, x0, x1);
-        const double y2 = __builtin_fma(-f.l21, y1, __builtin_fma(-f.l20, x0, x2));
-        const double y3 = __builtin_fma(-f.l32, y2, __builtin_fma(-f.l31, y1, __builtin_fma(-f.l30, x0, x3)));
-        const double rv = sel4(lk, x0, y1, y2, y3) * isel;
-        bop[b] = (tj == tk && colgrp) ? 0.0 : rv;
-      }
-    }
-#pragma unroll
-    for (int a = 0; a < NA; ++a) {
-      const int ti = 4 * a + wr;
-      aop[a] = vop[a] = 0.0;
-      if (ti < NT) {
-        const int i = 16 * ti + lm;
-        const double x[4] = {Craw[buf][i][0], Craw[buf][i][1], Craw[buf][i][2], Craw[buf][i][3]};
-        double c[4];
-        col_panel(f, x, c);
-        const double cv = sel4(lk, c[0], c[1], c[2], c[3]);
-        aop[a] = (ti == tk && colgrp) ? 0.0 : cv;
-        vop[a] = cv * isel;
-      }
-    }
-    // ---- first: the tiles of the tile rows / columns tk and tk1 (the fix-ups of this step and the panels of the next read them)
-#pragma unroll
-    for (int a = 0; a < NA; ++a)
-      if (4 * a + wr < NT) {
-#pragma unroll
-        for (int b = 0; b < NB; ++b) {
-          const int ti = 4 * a + wr, tj = 2 * b + wc;
-          const bool first = ti == tk || ti == tk1 || tj == tk || tj == tk1;       // wave-uniform
-          if (tj < NT && first) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(-aop[a], bop[b], acc[a][b], 0, 0, 0);
-        }
-      }
-    // ---- columns K <- - (A[:, K] U^-1) L^-1, A[K, K] <- U^-1 L^-1
-    if (own_c) {
-      const int cq = lm & 3;
-      const double m10 = -f.l10, m21 = -f.l21, m32 = -f.l32;
-      const double m20 = __builtin_fma(f.l21, f.l10, -f.l20), m31 = __builtin_fma(f.l32, f.l21, -f.l31);
-      const double m30 = __builtin_fma(-m32, f.l20, __builtin_fma(-m31, f.l10, -f.l30));
-      const double li0 = sel4(lk, 1.0, m10, m20, m30), li1 = sel4(lk, 0.0, 1.0, m21, m31), li2 = sel4(lk, 0.0, 0.0, 1.0, m32),
-                   li3 = lk == 3 ? 1.0 : 0.0;
-      const double b2 = colgrp ? -sel4(cq, li0, li1, li2, li3) : 0.0;
-      double dkk = 0.0;
-      {
-        const double x[4] = {lk == 0 ? 1.0 : 0.0, lk == 1 ? 1.0 : 0.0, lk == 2 ? 1.0 : 0.0, lk == 3 ? 1.0 : 0.0};
-        double w[4];
-        times_dinv(f, x, w);
-        dkk = sel4(cq, w[0], w[1], w[2], w[3]);
-      }
-#pragma unroll
-      for (int a = 0; a < NA; ++a)
-        if (4 * a + wr < NT) {
-          const inv_d4 zero = {0.0, 0.0, 0.0, 0.0};
-          const inv_d4 t = __builtin_amdgcn_mfma_f64_16x16x4f64(vop[a], b2, zero, 0, 0, 0);
-          if (colgrp) {
-            const bool pivot_tile = (4 * a + wr) == tk;
-#pragma unroll
-            for (int g = 0; g < 4; ++g) acc[a][bc][g] = (pivot_tile && g == q) ? dkk : t[g];
-          }
-        }
-    }
-    // ---- rows K <- D^-1 A[K, :]
-    if (own_r) {
-#pragma unroll
-      for (int b = 0; b < NB; ++b) {
-        const bool in_k = (2 * b + wc) == tk && colgrp;
-        if (2 * b + wc < NT) {
-          const int c = 16 * (2 * b + wc) + lm;
-          const double x[4] = {Rraw[buf][0][c], Rraw[buf][1][c], Rraw[buf][2][c], Rraw[buf][3][c]};
-          double r[4], z[4];
-          row_panel(f, x, r, z);
-          if (!in_k) acc[ar][b][q] = sel4(lk, z[0], z[1], z[2], z[3]);
-        }
-      }
-    }
-    // ---- the next step's panels (other LDS buffer: everybody finished reading it before the last barrier) and factors
-    if (have_next) put_panels(std::integral_constant<int, (tk1 < NT ? tk1 : 0)>{}, std::integral_constant<int, q1>{});
-    // ---- the other tiles
-#pragma unroll
-    for (int a = 0; a < NA; ++a)
-      if (4 * a + wr < NT) {
-#pragma unroll
-        for (int b = 0; b < NB; ++b) {
-          const int ti = 4 * a + wr, tj = 2 * b + wc;
-          const bool first = ti == tk || ti == tk1 || tj == tk || tj == tk1;
-          if (tj < NT && !first) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(-aop[a], bop[b], acc[a][b], 0, 0, 0);
-        }
-      }
-    if (have_next) __syncthreads();
-  });
-  if (bad && lane == 0) atomicExch(status, 1);
-#pragma unroll
-  for (int a = 0; a < NA; ++a)
-#pragma unroll
-    for (int b = 0; b < NB; ++b) {
-      const int ti = 4 * a + wr, tj = 2 * b + wc;
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int r = 16 * ti + lk + 4 * g, c = 16 * tj + lm;
-        if (ti < NT && tj < NT && r < ld && c < n) S[patch_inv_index(r, c, n, ld)] = (r < n) ? acc[a][b][g] : 0.0;
-      }
-    }
-}
+// Round 4 built this elimination twice more with LOOK-AHEAD -- the tiles of the next pivot's tile row / column updated first,
+// the next panels written, the bulk of the MFMAs issued just before the barrier so that they drain under the next block's LU;
+// once with ONE wave factoring the next pivot block and publishing the 28 factors, once with the LU redundant after the
+// barrier -- bitwise the same inverses, and SLOWER: 106.4 and 105.1 ms against 98.9 ms on config 4's finest level (13.30
+// against 12.65 ms at 24 389 patches, same box).  The PMC counters of this kernel (profiles/r04_pmc_patch_invert.txt: 45 % of
+// the wave cycles in s_waitcnt / s_barrier, 29 % issue stalls, 287 VALU + 113 SALU + 12 MFMA instructions per wave and block
+// step) say why reordering inside a step does not help: the step is a chain of dependent latencies (panel -> LDS -> barrier ->
+// LU -> operands -> MFMA -> fix-up -> panel) that all eight waves walk in lockstep, and no wave of another patch fits beside
+// them (232 VGPRs).  Both variants were removed again (CHANGELOG.md).
 
 }  // namespace
 
@@ -497,14 +312,8 @@ int launch_patch_invert_mfma(alfi_ctx* ctx, int64_t npatch, int max_np, const in
   static const bool all_sizes = getenv("ALFI_INVERT_MFMA") && atoi(getenv("ALFI_INVERT_MFMA")) == 2;
   if (!allow || max_np <= 32 || max_np > 160 || (max_np <= 112 && !all_sizes)) return 0;
   dim3 grid((unsigned)npatch), block(512);
-  static const bool lookahead = !(getenv("ALFI_INVERT_LA") && atoi(getenv("ALFI_INVERT_LA")) == 0);   // A/B: 0 = round-3 kernel
-#define ALFI_INV(NTV)                                                                                                       \
-  do {                                                                                                                      \
-    if (lookahead)                                                                                                          \
-      hipLaunchKernelGGL(patch_invert_mfma_la_kernel<NTV>, grid, block, 0, ctx->stream, patch_ptr, inv_ptr, inv, status);   \
-    else                                                                                                                    \
-      hipLaunchKernelGGL(patch_invert_mfma_kernel<NTV>, grid, block, 0, ctx->stream, patch_ptr, inv_ptr, inv, status);      \
-  } while (0)
+#define ALFI_INV(NTV) \
+  hipLaunchKernelGGL(patch_invert_mfma_kernel<NTV>, grid, block, 0, ctx->stream, patch_ptr, inv_ptr, inv, status)
   if (max_np <= 64) ALFI_INV(4);
   else if (max_np <= 96) ALFI_INV(6);
   else if (max_np <= 128) ALFI_INV(8);

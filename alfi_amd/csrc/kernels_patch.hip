@@ -394,39 +394,39 @@ __global__ __launch_bounds__(256) void patch_il_build_kernel(int64_t npatch, int
 // ---------------------------------------------------------------------------------------------------------------------
 constexpr int MAX_PNODES = 64;
 
-constexpr int MULT_U = 32;     // 16-byte loads in flight per lane in the sweep's inverse apply (see apply_piece)
+#ifndef ALFI_MULT_U
+#define ALFI_MULT_U 32
+#endif
+#ifndef ALFI_MULT_RU
+#define ALFI_MULT_RU 4
+#endif
+constexpr int MULT_U = ALFI_MULT_U;     // 16-byte loads in flight per lane in the sweep's inverse apply (see apply_piece)
 
-template <int BS, bool NT>
-__global__ __launch_bounds__(256) void patch_mult_kernel(int64_t count, const int32_t* __restrict__ seq,
-                                                          const int64_t* __restrict__ patch_ptr,
-                                                          const int32_t* __restrict__ patch_dofs,
-                                                          const int64_t* __restrict__ inv_ptr,
-                                                          const double* __restrict__ inv,
-                                                          const int32_t* __restrict__ rowptr,
-                                                          const int32_t* __restrict__ colidx,
-                                                          const double* __restrict__ vals, int flat,
-                                                          const double* __restrict__ x, double* __restrict__ y) {
+// same-wave LDS hand-off: the LDS serves a wave's instructions in order, so a wave that writes an array and then reads it
+// through other lanes needs no barrier -- only the compiler must keep the order
+#define ALFI_WAVE_LDS_ORDER()                                  \
+  do {                                                         \
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");    \
+    __builtin_amdgcn_wave_barrier();                           \
+  } while (0)
+
+// ONE patch of a sweep by ONE wave: r_p = x_p - (A y)_p, y_p += inv(A_p) r_p.  rs, ys, pre, k0, nd: the wave's own LDS arrays.
+// PUBLISH (persistent schedule): the new y entries leave with agent-scope write-through stores, so that a wave on another CU /
+// XCD that acquires afterwards reads them (cdna_hip_programming.md Guideline 16, R1).
+template <int BS, bool NT, bool PUBLISH>
+__device__ __forceinline__ void mult_one_patch(int64_t p, int lane, double* __restrict__ rs, double* __restrict__ ys,
+                                               int32_t* __restrict__ pre, int32_t* __restrict__ k0, int32_t* __restrict__ nd,
+                                               const int64_t* __restrict__ patch_ptr, const int32_t* __restrict__ patch_dofs,
+                                               const int64_t* __restrict__ inv_ptr, const double* __restrict__ inv,
+                                               const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colidx,
+                                               const double* __restrict__ vals, int flat, const double* __restrict__ x,
+                                               double* __restrict__ y) {
   constexpr int BB = BS * BS;
-  __shared__ double rs_all[4][MAX_NP];          // r_p
-  __shared__ double ys_all[4][MAX_NP];          // inv(A_p) r_p
-  __shared__ int32_t pre_all[4][MAX_PNODES + 1];  // exclusive prefix of the rows' block counts
-  __shared__ int32_t k0_all[4][MAX_PNODES];       // first block of each row
-  __shared__ int32_t nd_all[4][MAX_PNODES];       // node (block row) of each patch node
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int64_t q = (int64_t)blockIdx.x * 4 + wave;
-  double* rs = rs_all[wave];
-  double* ys = ys_all[wave];
-  int32_t* pre = pre_all[wave];
-  int32_t* k0 = k0_all[wave];
-  int32_t* nd = nd_all[wave];
-  const bool live = q < count;
-  int64_t p = 0, off = 0;
-  int n = 0, nn = 0, total = 0;
-  if (live) {
-    p = seq[q];
-    off = patch_ptr[p];
-    n = (int)(patch_ptr[p + 1] - off);
-    nn = n / BS;
+  const int64_t off = patch_ptr[p];
+  const int n = (int)(patch_ptr[p + 1] - off);
+  const int nn = n / BS;
+  int total = 0;
+  {
     int node = 0, len = 0;
     if (lane < nn) {
       node = patch_dofs[off + lane * BS] / BS;
@@ -445,15 +445,15 @@ __global__ __launch_bounds__(256) void patch_mult_kernel(int64_t count, const in
     if (lane == 0) pre[0] = 0;
     total = __shfl(incl, 63);
   }
-  __syncthreads();
-  if (live) {
+  ALFI_WAVE_LDS_ORDER();
+  {
     double carry[BS];
 #pragma unroll
     for (int r = 0; r < BS; ++r) carry[r] = 0.0;
     // MULT_RU sub-steps of 64 blocks per pass: all their index, value and y loads are requested before the first row sum is
     // formed (a wave alone on its SIMD has nothing else to hide the latency of a pass with); the sums and the carry then
     // follow in the same order as with one sub-step per pass
-    constexpr int MULT_RU = 4;
+    constexpr int MULT_RU = ALFI_MULT_RU;
     for (int f0 = 0; f0 < total; f0 += 64 * MULT_RU) {
       int row_[MULT_RU];
       bool valid_[MULT_RU], head_[MULT_RU], last_[MULT_RU];
@@ -533,8 +533,8 @@ __global__ __launch_bounds__(256) void patch_mult_kernel(int64_t count, const in
       }
     }
   }
-  __syncthreads();
-  if (live) {
+  ALFI_WAVE_LDS_ORDER();
+  {
     const int ld = (n + 1) & ~1;
     const double* T = inv + inv_ptr[p];
     int row0 = 0;
@@ -553,12 +553,97 @@ __global__ __launch_bounds__(256) void patch_mult_kernel(int64_t count, const in
     ALFI_PIECE(2)
 #undef ALFI_PIECE
   }
-  __syncthreads();
-  if (live)
-    for (int i = lane; i < n; i += 64) {
-      const int64_t dof = patch_dofs[off + i];
-      y[dof] += ys[i];
+  ALFI_WAVE_LDS_ORDER();
+  for (int i = lane; i < n; i += 64) {
+    const int64_t dof = patch_dofs[off + i];
+    const double v = y[dof] + ys[i];
+    if (PUBLISH)
+      __hip_atomic_store(y + dof, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);    // global_store_dwordx2 ... sc1
+    else
+      y[dof] = v;
+  }
+}
+
+template <int BS, bool NT>
+__global__ __launch_bounds__(256) void patch_mult_kernel(int64_t count, const int32_t* __restrict__ seq,
+                                                          const int64_t* __restrict__ patch_ptr,
+                                                          const int32_t* __restrict__ patch_dofs,
+                                                          const int64_t* __restrict__ inv_ptr,
+                                                          const double* __restrict__ inv,
+                                                          const int32_t* __restrict__ rowptr,
+                                                          const int32_t* __restrict__ colidx,
+                                                          const double* __restrict__ vals, int flat,
+                                                          const double* __restrict__ x, double* __restrict__ y) {
+  __shared__ double rs_all[4][MAX_NP];          // r_p
+  __shared__ double ys_all[4][MAX_NP];          // inv(A_p) r_p
+  __shared__ int32_t pre_all[4][MAX_PNODES + 1];  // exclusive prefix of the rows' block counts
+  __shared__ int32_t k0_all[4][MAX_PNODES];       // first block of each row
+  __shared__ int32_t nd_all[4][MAX_PNODES];       // node (block row) of each patch node
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int64_t q = (int64_t)blockIdx.x * 4 + wave;
+  if (q >= count) return;
+  mult_one_patch<BS, NT, false>(seq[q], lane, rs_all[wave], ys_all[wave], pre_all[wave], k0_all[wave], nd_all[wave], patch_ptr,
+                                patch_dofs, inv_ptr, inv, rowptr, colidx, vals, flat, x, y);
+}
+
+// The whole sweep (both directions of a symmetrised one) as ONE launch of a resident grid: waves draw the items of the
+// wavefront-major schedule in order (a ticket counter) and start an item when its predecessor count has reached zero -- the
+// predecessors of an item are the LAST WRITERS of the nodes it reads (host: alfi_patches_set_multiplicative), each finished
+// item decrements its successors.  The schedule order is a topological order and every ticket is held by a resident wave, so
+// every wait ends; the independent patches of wavefront k + 1 start while the tail of wavefront k is still running, and the 674
+// launch boundaries of config 4's symmetrised sweep are gone.  Results are those of the launch-per-wavefront schedule bit for
+// bit: the same patches see the same y entries (conflicting patches keep their order), one wave computes each.
+// Hand-off (Guideline 16, R1): y entries leave with write-through stores, the storing wave drains them (vmcnt(0)), then
+// decrements; a consumer polls its own counter relaxed, then ONE agent-scope acquire, then plain loads.
+// err[0]: set when a wait ran into its bound (a broken schedule would otherwise spin until the watchdog).
+template <int BS, bool NT>
+__global__ __launch_bounds__(256) void patch_mult_persistent_kernel(int32_t nitems, const int32_t* __restrict__ items,
+                                                                     int32_t* __restrict__ pred, const int32_t* __restrict__ succ_ptr,
+                                                                     const int32_t* __restrict__ succ, int32_t* __restrict__ head,
+                                                                     int32_t* __restrict__ err,
+                                                                     const int64_t* __restrict__ patch_ptr,
+                                                                     const int32_t* __restrict__ patch_dofs,
+                                                                     const int64_t* __restrict__ inv_ptr,
+                                                                     const double* __restrict__ inv,
+                                                                     const int32_t* __restrict__ rowptr,
+                                                                     const int32_t* __restrict__ colidx,
+                                                                     const double* __restrict__ vals, int flat,
+                                                                     const double* __restrict__ x, double* __restrict__ y) {
+  __shared__ double rs_all[4][MAX_NP];
+  __shared__ double ys_all[4][MAX_NP];
+  __shared__ int32_t pre_all[4][MAX_PNODES + 1];
+  __shared__ int32_t k0_all[4][MAX_PNODES];
+  __shared__ int32_t nd_all[4][MAX_PNODES];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  for (;;) {
+    int32_t t = 0;
+    if (lane == 0) t = __hip_atomic_fetch_add(head, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    t = __builtin_amdgcn_readfirstlane(t);
+    if (t >= nitems) break;
+    // wait for the predecessors: ONE lane polls ONE word, relaxed
+    int ok = 1;
+    if (lane == 0) {
+      unsigned spins = 0;
+      while (__hip_atomic_load(pred + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+        __builtin_amdgcn_s_sleep(8);
+        if (++spins > (1u << 24) || __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+          ok = 0;
+          break;
+        }
+      }
     }
+    ok = __builtin_amdgcn_readfirstlane(ok);
+    if (!ok) {
+      if (lane == 0) __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      break;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");          // this CU's L1 forgets what other CUs have rewritten
+    mult_one_patch<BS, NT, true>(items[t], lane, rs_all[wave], ys_all[wave], pre_all[wave], k0_all[wave], nd_all[wave],
+                                 patch_ptr, patch_dofs, inv_ptr, inv, rowptr, colidx, vals, flat, x, y);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // the wave's y stores have left
+    for (int32_t e = succ_ptr[t] + lane; e < succ_ptr[t + 1]; e += 64)
+      __hip_atomic_fetch_sub(pred + succ[e], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
 }
 
 // stage 2: dof-wise sum of the staged patch results in a fixed order (deterministic; replaces PETSc's scatter-add)
@@ -674,6 +759,35 @@ int launch_patch_mult_wave(alfi_level* L, const int32_t* seq, int64_t count, con
     return alfi_set_error(ctx, ALFI_E_ARG, "unsupported block size %d", L->bs);
   }
 #undef ALFI_MULT
+  ALFI_HIP_CHECK(ctx, hipGetLastError());
+  return 0;
+}
+
+int launch_patch_mult_persistent(alfi_level* L, const double* x, double* y) {
+  alfi_ctx* ctx = L->ctx;
+  if (L->mult_nitems == 0) return 0;
+  // fresh counters for this apply: predecessor counts and the ticket (the error word is the ctx's, sticky)
+  ALFI_HIP_CHECK(ctx, hipMemcpyAsync(L->mult_pred, L->mult_pred0, sizeof(int32_t) * (size_t)L->mult_nitems,
+                                     hipMemcpyDeviceToDevice, ctx->stream));
+  ALFI_HIP_CHECK(ctx, hipMemsetAsync(L->mult_ctl, 0, 4 * sizeof(int32_t), ctx->stream));
+  // a grid that is resident whatever the dispatcher does: one workgroup of 4 waves per CU (the kernel's registers and LDS
+  // admit two), every wave a worker
+  static int ncu = 0;
+  if (ncu == 0) {
+    hipDeviceProp_t prop;
+    ALFI_HIP_CHECK(ctx, hipGetDeviceProperties(&prop, ctx->device));
+    ncu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 64;
+  }
+  const int64_t want = ((int64_t)L->mult_nitems + 3) / 4;
+  dim3 grid((unsigned)std::min<int64_t>(want, ncu)), block(256);
+#define ALFI_PMULT(BSV)                                                                                                   \
+  hipLaunchKernelGGL((patch_mult_persistent_kernel<BSV, true>), grid, block, 0, ctx->stream, L->mult_nitems, L->mult_items, \
+                     L->mult_pred, L->mult_succ_ptr, L->mult_succ, L->mult_ctl, ctx->dev_err, L->patch_ptr,               \
+                     L->patch_dofs, L->inv_ptr, L->inv, L->A.rowptr, L->A.colidx, L->A.vals, L->A.flat, x, y)
+  if (L->bs == 2) ALFI_PMULT(2);
+  else if (L->bs == 3) ALFI_PMULT(3);
+  else return alfi_set_error(ctx, ALFI_E_ARG, "unsupported block size %d", L->bs);
+#undef ALFI_PMULT
   ALFI_HIP_CHECK(ctx, hipGetLastError());
   return 0;
 }

@@ -308,13 +308,26 @@ class Level(object):
         True if it fell back."""
         try:
             self.factor()
+            self._warn_if_flagged()
             return False
         except AlfiHipError as e:
             if "condensed" not in str(e):
                 raise
         self.set_patch_groups(None)
         self.factor()
+        self._warn_if_flagged()
         return True
+
+    def _warn_if_flagged(self):
+        """the setup only FAILS beyond 1000 x the probe tolerance; patches that stay above the tolerance after the
+        pivoted repair (ill-conditioned, not mis-factored: LAPACK would return the same inverse) degrade the smoother
+        silently unless somebody says so."""
+        worst, flagged, repaired, after = self.patch_check()
+        if flagged > repaired:
+            import warnings
+            warnings.warn("alfi_patches_factor: %d of %d flagged patch factors stay above the probe tolerance after the "
+                          "pivoted repair (worst residual %.2e): the patch operators are ill-conditioned"
+                          % (flagged - repaired, flagged, after))
 
     def patch_check(self):
         """(worst residual || A_p X_p e - e || of the fast inversion, patches flagged, patches repaired by the pivoted
@@ -393,8 +406,14 @@ class Level(object):
         mode, node_coords = self._coarse_choice
         if mode == "sparse" or (mode == "auto" and self.n >= coarse_sparse_min()):
             use_xy = node_coords is not None and os.environ.get("ALFI_COARSE_COORDS", "0") == "1"
-            return self.coarse_factor_sparse(node_coords if use_xy else None)
-        return self.coarse_factor()
+            rc = self.coarse_factor_sparse(node_coords if use_xy else None)
+        else:
+            rc = self.coarse_factor()
+        res = self.coarse_residual()
+        if res > 1e-5:         # (the setup fails only beyond ALFI_COARSE_CHECK_FAIL = 1e-2; rounds 1-2 failed at 1e-5)
+            import warnings
+            warnings.warn("coarse factorisation: probe residual || A X e - e || = %.2e" % res)
+        return rc
 
     def coarse_factor_bytes(self):
         b = ctypes.c_int64()

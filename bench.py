@@ -43,12 +43,12 @@ CONFIGS = {
     "cfg5s": ("sv", 1, 1, 3, 500.0, 10),
     "cfg5L": ("sv", 1, 3, 3, 500.0, 10),   # one more refinement: 3.4 M velocity dofs, ~40 GB of condensed factors on ONE GPU
     # config 5 on the reference's OWN channel mesh (examples/bfs3d/coarse60.msh, gmsh 2.2 ASCII: 299 nodes, 912 tets, physical
-    # tags 1 / 2 / 3; kept as an input fixture under tests/golden/meshes/): unstructured, macro stars up to 3615 dofs, a
+    # tags 1 / 2 / 3; kept as a workload input under data/meshes/): unstructured, macro stars up to 3615 dofs, a
     # 56 784-dof coarse grid (multifrontal solver).  One refinement: 440 022 velocity dofs; two: 3.47 M
     "cfg5m": ("sv", "bfs3d_coarse60.msh", 1, 3, 500.0, 10),
     "cfg5mL": ("sv", "bfs3d_coarse60.msh", 2, 3, 500.0, 10),
 }
-MESH_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests", "golden", "meshes")
+MESH_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "meshes")
 
 
 def config_mesh(cfg):
@@ -732,10 +732,23 @@ def main():
     pmc_file = os.path.join(ROOT, "profiles", "pmc_patch_apply_%s.json" % args.config)
     if os.path.exists(pmc_file):
         pmc = json.load(open(pmc_file))
-        traffic = pmc.get("hbm_bytes_per_launch")
         traffic_source = {"measured_in_this_run": False, "file": os.path.relpath(pmc_file, ROOT),
-                          "collected": pmc.get("collected", "an earlier rocprofv3 --pmc run on another box; see tag"),
+                          "collected": pmc.get("collected"), "commit": pmc.get("commit"), "box": pmc.get("box"),
                           "tag": pmc.get("tag")}
+        # quoted only while the kernel sources are byte for byte what the counters were collected on (the summary carries
+        # their SHA-256: the GPU box has no .git to ask); otherwise traffic stays null and the reason is given
+        import hashlib
+        csrc = os.path.join(ROOT, "alfi_amd", "csrc")
+        want = pmc.get("kernel_sources_sha256")
+        changed = None if not want else sorted(
+            f for f, h in want.items()
+            if not os.path.exists(os.path.join(csrc, f)) or hashlib.sha256(open(os.path.join(csrc, f), "rb").read()).hexdigest() != h)
+        if want and not changed:
+            traffic = pmc.get("hbm_bytes_per_launch")
+            traffic_source["kernel_sources"] = "unchanged since the collection"
+        else:
+            traffic_source["refused"] = ("the summary carries no source hashes (collected before round 4)" if not want
+                                         else "kernel sources changed since the collection: " + ", ".join(changed))
 
     out = {
         "metric": ("V-cycles/sec on bfs3d SV P3-P2dg (DoF*smooths/sec in dof_smooths_per_s)" if CONFIGS[args.config][0] == "sv"
@@ -768,6 +781,9 @@ def main():
                           else "multifrontal L D U + 1 refinement step", "dofs": lv[0].n,
                           "factor_GB": round(dmg.levels[0].coarse_factor_bytes() / 1e9, 3),
                           "probe_residual": dmg.levels[0].coarse_residual()},
+        # residual probe of the patch factors of every smoothed level (worst before the pivoted repair, flagged, repaired,
+        # worst afterwards): a smoother degraded by ill-conditioned patch operators shows here
+        "patch_probe": [dict(zip(("worst", "flagged", "repaired", "worst_after"), dl.patch_check())) for dl in dmg.levels[1:]],
         "patch_factor_bytes_per_dof_finest": dmg.levels[-1].factor_bytes() / float(L.n),
         "fcycle_ms": fcycle_ms,
         "vcycle_algorithmic_GB": total_bytes / 1e9,

@@ -44,6 +44,24 @@ def per_kernel(d, counter, prefix, first=None, grids=None, skip=0):
     return v[:first] if first else v
 
 
+def provenance():
+    """What the summary was measured ON: the commit the caller names (ALFI_COMMIT: the GPU box holds a snapshot without .git),
+    the box, the time, and the SHA-256 of every kernel source -- bench.py quotes a summary as `roofline.traffic` only while
+    those files are byte for byte what was measured."""
+    import datetime
+    import hashlib
+    import os
+    import socket
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    csrc = os.path.join(root, "alfi_amd", "csrc")
+    sha = {}
+    for f in sorted(os.listdir(csrc)):
+        if f.endswith((".hip", ".h")):
+            sha[f] = hashlib.sha256(open(os.path.join(csrc, f), "rb").read()).hexdigest()
+    return {"commit": os.environ.get("ALFI_COMMIT", "unknown"), "box": socket.gethostname(),
+            "collected": datetime.datetime.utcnow().strftime("%Y-%m-%dT%H:%MZ"), "kernel_sources_sha256": sha}
+
+
 def main():
     fetch_dir, write_dir, prefix, out = sys.argv[1:5]
     tag = sys.argv[5] if len(sys.argv) > 5 else ""
@@ -61,6 +79,7 @@ def main():
            "fetch_bytes_per_launch": fb, "write_bytes_per_launch": wb, "hbm_bytes_per_launch": fb + wb,
            "fetch_bytes_per_launch_max": 2048.0 * float(f.max()),
            "correction": "FETCH_SIZE KiB x 1024 x 2 (gfx950 tallies 128-B requests at 64 B); WRITE_SIZE KiB x 1024"}
+    res.update(provenance())
     json.dump(res, open(out, "w"), indent=1)
     print(json.dumps(res))
 

@@ -4,7 +4,7 @@ Newton with Reynolds continuation (examples/bfs3d/bfs3d.py:49-55), every linear 
 
   python scripts/run_cfg5_newton.py [--mesh file.msh] [nref] [Re ...]
 
---mesh: a gmsh 2.2 ASCII channel (the reference's ``--mesh``, bfs3d.py:13-16), e.g. tests/golden/meshes/bfs3d_coarse60.msh;
+--mesh: a gmsh 2.2 ASCII channel (the reference's ``--mesh``, bfs3d.py:13-16), e.g. data/meshes/bfs3d_coarse60.msh;
 default: the structured stand-in."""
 import os
 import sys

@@ -45,3 +45,23 @@ def test_smoother_paths(env):
     ms, mc = re.search(r"SMOOTH (\S+)", out.stdout), re.search(r"CYCLE (\S+)", out.stdout)
     assert out.returncode == 0 and ms and mc, out.stdout[-2000:] + out.stderr[-3000:]
     assert float(ms.group(1)) < 1e-7 and float(mc.group(1)) < 1e-5, (env, ms.group(1), mc.group(1))
+
+
+def test_persistent_sweep_equals_the_launch_per_wavefront_schedule(tmp_path):
+    """the multiplicative sweep as ONE launch of a resident grid that walks the wavefront schedule with
+    per-item dependency counters (patch_mult_persistent_kernel; alfi/solver.py:322-335, relaxation.py:139-150) gives, bit for
+    bit, what one launch per dependency wavefront gives (ALFI_MULT_PERSISTENT=0: the schedule of rounds 1-3) -- 2-D with two
+    '|'-separated sort orders (every patch twice per sweep) and 3-D, symmetrised, each apply repeated three times."""
+    import numpy as np
+    res = {}
+    for mode in ("1", "0"):
+        f = str(tmp_path / ("sweep%s.npz" % mode))
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "gpu_mult_schedule_worker.py"), f],
+                             # (one host thread: the generator's parallel assembly sums in a run-dependent order)
+                             env=dict(os.environ, ALFI_MULT_PERSISTENT=mode, OMP_NUM_THREADS="1", ALFI_HOST_THREADS="1"),
+                             cwd=ROOT, capture_output=True, text=True, timeout=900)
+        assert out.returncode == 0 and "OK" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
+        res[mode] = np.load(f)
+    for k in ("2d", "3d"):
+        assert int(res["1"][k + "_waves"]) > 4
+        assert np.array_equal(res["1"][k], res["0"][k]), (k, np.abs(res["1"][k] - res["0"][k]).max())

@@ -307,14 +307,14 @@ def test_contributor_lists_of_the_device_assembly(dim, k):
 
 
 def test_the_references_own_channel_mesh():
-    """tests/golden/meshes/bfs3d_coarse60.msh (data shipped with the reference's bfs3d example, bfs3d.py:13-16): read as
+    """data/meshes/bfs3d_coarse60.msh (data shipped with the reference's bfs3d example, bfs3d.py:13-16): read as
     written by gmsh -- 299 nodes, 912 tetrahedra, the channel's volume, every boundary facet tagged, tags 1 / 3 exactly on the
     geometric Dirichlet boundary and tag 2 exactly on the outflow plane (bfs3d.py:23-26) -- and the Scott-Vogelius set-up
     runs on it: Alfeld split, macro-star patches with interiors and skeleton, condensable groups."""
     import os
     from alfi_amd.mesh import read_gmsh
     from alfi_amd.problem import ThreeDimBackwardsFacingStepProblem
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "meshes", "bfs3d_coarse60.msh")
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "data", "meshes", "bfs3d_coarse60.msh")
     r = read_gmsh(path)
     assert r.num_vertices == 299 and r.num_cells == 912
     vol = r.cell_geometry()[1]
