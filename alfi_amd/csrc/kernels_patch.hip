@@ -395,12 +395,20 @@ __global__ __launch_bounds__(256) void patch_il_build_kernel(int64_t npatch, int
 constexpr int MAX_PNODES = 64;
 
 #ifndef ALFI_MULT_U
-#define ALFI_MULT_U 32
+#define ALFI_MULT_U 16
 #endif
 #ifndef ALFI_MULT_RU
 #define ALFI_MULT_RU 4
 #endif
+#ifndef ALFI_MULT_W
+#define ALFI_MULT_W 4
+#endif
 constexpr int MULT_U = ALFI_MULT_U;     // 16-byte loads in flight per lane in the sweep's inverse apply (see apply_piece)
+constexpr int MULT_RU = ALFI_MULT_RU;   // sub-steps of 64 operator blocks whose loads are requested together in the residual
+constexpr int MULT_W = ALFI_MULT_W;     // waves per patch
+#ifndef ALFI_MULT_WG_PER_CU
+#define ALFI_MULT_WG_PER_CU 4           // cap on the resident workgroups per CU of the persistent sweep
+#endif
 
 // same-wave LDS hand-off: the LDS serves a wave's instructions in order, so a wave that writes an array and then reads it
 // through other lanes needs no barrier -- only the compiler must keep the order
@@ -410,51 +418,87 @@ constexpr int MULT_U = ALFI_MULT_U;     // 16-byte loads in flight per lane in t
     __builtin_amdgcn_wave_barrier();                           \
   } while (0)
 
-// ONE patch of a sweep by ONE wave: r_p = x_p - (A y)_p, y_p += inv(A_p) r_p.  rs, ys, pre, k0, nd: the wave's own LDS arrays.
+// A sweep is a chain of dependent patches (config 4: 337 wavefronts per direction), so the time of an apply is the number of
+// wavefronts times the latency of ONE patch whatever the occupancy.  Rounds 1-3 gave a patch to one wave: ~35 dependent passes
+// over its operator rows and ~150 columns of its inverse behind each other, 75-85 us per patch.  Here a WORKGROUP of MULT_W
+// waves shares the patch: the operator rows are dealt to the waves in contiguous ranges of equal block counts (each wave runs
+// the flat segmented scan over its own range), the inverse is applied by COLUMN shares (wave w multiplies its quarter of the
+// columns of every row piece; the partial results are added in the order of the waves: deterministic), and everything that
+// does not depend on y -- the patch's tables -- is read before the wait of the persistent schedule.
+struct MultLds {
+  double rs[MAX_NP];                  // r_p
+  double part[MULT_W][MAX_NP];        // partial products of the waves' column shares
+  int32_t pre[MAX_PNODES + 1];        // exclusive prefix of the rows' block counts
+  int32_t k0[MAX_PNODES];             // first block of each row
+  int32_t nd[MAX_PNODES];             // node (block row) of each patch node
+  int32_t rb[MULT_W + 1];             // rows [rb[w], rb[w + 1]) belong to wave w
+  int32_t ticket, ok;
+};
+
+// tables of patch p (wave 0; the caller synchronises the workgroup afterwards)
+template <int BS>
+__device__ __forceinline__ void mult_wg_setup(int64_t p, MultLds& S, const int64_t* __restrict__ patch_ptr,
+                                              const int32_t* __restrict__ patch_dofs, const int32_t* __restrict__ rowptr) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (wave != 0) return;
+  const int64_t off = patch_ptr[p];
+  const int nn = (int)(patch_ptr[p + 1] - off) / BS;
+  int len = 0;
+  if (lane < nn) {
+    const int node = patch_dofs[off + lane * BS] / BS;
+    const int32_t lo = rowptr[node];
+    len = rowptr[node + 1] - lo;
+    S.k0[lane] = lo;
+    S.nd[lane] = node;
+  }
+  int incl = len;   // inclusive wave scan
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int t = __shfl_up(incl, d);
+    if (lane >= d) incl += t;
+  }
+  if (lane < nn) S.pre[lane + 1] = incl;
+  if (lane == 0) S.pre[0] = 0;
+  const int total = __shfl(incl, 63);
+  ALFI_WAVE_LDS_ORDER();
+  // wave w starts at the first row whose first block is not below w * total / W
+  if (lane <= MULT_W) {
+    int r = nn;
+    if (lane < MULT_W) {
+      const int target = (int)(((int64_t)lane * total) / MULT_W);
+      int lo = 0, hi = nn;
+      while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (S.pre[mid] >= target) hi = mid; else lo = mid + 1;
+      }
+      r = lo;
+    }
+    S.rb[lane] = r;
+  }
+}
+
+// r_p = x_p - (A y)_p, y_p += inv(A_p) r_p by the whole workgroup (tables in S, synchronised).
 // PUBLISH (persistent schedule): the new y entries leave with agent-scope write-through stores, so that a wave on another CU /
 // XCD that acquires afterwards reads them (cdna_hip_programming.md Guideline 16, R1).
 template <int BS, bool NT, bool PUBLISH>
-__device__ __forceinline__ void mult_one_patch(int64_t p, int lane, double* __restrict__ rs, double* __restrict__ ys,
-                                               int32_t* __restrict__ pre, int32_t* __restrict__ k0, int32_t* __restrict__ nd,
-                                               const int64_t* __restrict__ patch_ptr, const int32_t* __restrict__ patch_dofs,
-                                               const int64_t* __restrict__ inv_ptr, const double* __restrict__ inv,
-                                               const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colidx,
-                                               const double* __restrict__ vals, int flat, const double* __restrict__ x,
-                                               double* __restrict__ y) {
+__device__ __forceinline__ void mult_wg_sweep(int64_t p, MultLds& S, const int64_t* __restrict__ patch_ptr,
+                                              const int32_t* __restrict__ patch_dofs, const int64_t* __restrict__ inv_ptr,
+                                              const double* __restrict__ inv, const int32_t* __restrict__ colidx,
+                                              const double* __restrict__ vals, int flat, const double* __restrict__ x,
+                                              double* __restrict__ y) {
   constexpr int BB = BS * BS;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int64_t off = patch_ptr[p];
   const int n = (int)(patch_ptr[p + 1] - off);
-  const int nn = n / BS;
-  int total = 0;
   {
-    int node = 0, len = 0;
-    if (lane < nn) {
-      node = patch_dofs[off + lane * BS] / BS;
-      const int32_t lo = rowptr[node];
-      len = rowptr[node + 1] - lo;
-      k0[lane] = lo;
-      nd[lane] = node;
-    }
-    int incl = len;   // inclusive wave scan
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-      const int t = __shfl_up(incl, d);
-      if (lane >= d) incl += t;
-    }
-    if (lane < nn) pre[lane + 1] = incl;
-    if (lane == 0) pre[0] = 0;
-    total = __shfl(incl, 63);
-  }
-  ALFI_WAVE_LDS_ORDER();
-  {
+    const int ra = S.rb[wave], rz = S.rb[wave + 1];
+    const int fbeg = S.pre[ra], fend = S.pre[rz];
     double carry[BS];
 #pragma unroll
     for (int r = 0; r < BS; ++r) carry[r] = 0.0;
     // MULT_RU sub-steps of 64 blocks per pass: all their index, value and y loads are requested before the first row sum is
-    // formed (a wave alone on its SIMD has nothing else to hide the latency of a pass with); the sums and the carry then
-    // follow in the same order as with one sub-step per pass
-    constexpr int MULT_RU = ALFI_MULT_RU;
-    for (int f0 = 0; f0 < total; f0 += 64 * MULT_RU) {
+    // formed; the sums and the carry then follow in the order of the sub-steps
+    for (int f0 = fbeg; f0 < fend; f0 += 64 * MULT_RU) {
       int row_[MULT_RU];
       bool valid_[MULT_RU], head_[MULT_RU], last_[MULT_RU];
       int64_t k_[MULT_RU], col_[MULT_RU];
@@ -462,17 +506,17 @@ __device__ __forceinline__ void mult_one_patch(int64_t p, int lane, double* __re
 #pragma unroll
       for (int u = 0; u < MULT_RU; ++u) {
         const int f = f0 + 64 * u + lane;
-        valid_[u] = f < total;
-        // row of this lane's block: largest i with pre[i] <= f
-        int lo = 0, hi = nn;
+        valid_[u] = f < fend;
+        // row of this lane's block: largest i in the wave's range with pre[i] <= f
+        int lo = ra, hi = rz;
         while (hi - lo > 1) {
           const int mid = (lo + hi) >> 1;
-          if (pre[mid] <= f) lo = mid; else hi = mid;
+          if (S.pre[mid] <= f) lo = mid; else hi = mid;
         }
         row_[u] = lo;
-        head_[u] = valid_[u] && f == pre[lo];
-        last_[u] = valid_[u] && f + 1 == pre[lo + 1];
-        k_[u] = valid_[u] ? (int64_t)k0[lo] + (f - pre[lo]) : 0;
+        head_[u] = valid_[u] && f == S.pre[lo];
+        last_[u] = valid_[u] && f + 1 == S.pre[lo + 1];
+        k_[u] = valid_[u] ? (int64_t)S.k0[lo] + (f - S.pre[lo]) : 0;
         col_[u] = valid_[u] ? (int64_t)(colidx[k_[u]] & 0x7fffffff) : 0;
       }
 #pragma unroll
@@ -490,7 +534,7 @@ __device__ __forceinline__ void mult_one_patch(int64_t p, int lane, double* __re
       }
 #pragma unroll
       for (int u = 0; u < MULT_RU; ++u) {
-        if (f0 + 64 * u >= total) break;          // wave-uniform
+        if (f0 + 64 * u >= fend) break;          // wave-uniform
         const int row = row_[u];
         const bool head = head_[u], last = last_[u];
         double s[BS];
@@ -521,7 +565,7 @@ __device__ __forceinline__ void mult_one_patch(int64_t p, int lane, double* __re
         }
         if (last) {
 #pragma unroll
-          for (int r = 0; r < BS; ++r) rs[row * BS + r] = x[(int64_t)nd[row] * BS + r] - s[r];
+          for (int r = 0; r < BS; ++r) S.rs[row * BS + r] = x[(int64_t)S.nd[row] * BS + r] - s[r];
         }
         // a row running on into the next 64 blocks is carried; a row closed at lane 63 is not
         const int last63 = __shfl(last ? 1 : 0, 63);
@@ -533,17 +577,21 @@ __device__ __forceinline__ void mult_one_patch(int64_t p, int lane, double* __re
       }
     }
   }
-  ALFI_WAVE_LDS_ORDER();
+  __syncthreads();
   {
     const int ld = (n + 1) & ~1;
     const double* T = inv + inv_ptr[p];
+    const int ca = (int)(((int64_t)wave * n) / MULT_W), cn = (int)(((int64_t)(wave + 1) * n) / MULT_W) - ca;
+    const double* xs = S.rs + ca;
+    double* out = S.part[wave];
     int row0 = 0;
-    for (; row0 + 128 <= ld; row0 += 128) apply_piece<64, NT, MULT_U>(T + (int64_t)row0 * n, n, rs, lane, ys + row0);
+    for (; row0 + 128 <= ld; row0 += 128)
+      apply_piece<64, NT, MULT_U>(T + (int64_t)row0 * n + (int64_t)ca * 128, cn, xs, lane, out + row0);
     const int rem = ld - row0;
-#define ALFI_PIECE(R)                                                      \
-  if (rem & R) {                                                           \
-    apply_piece<R / 2, NT, MULT_U>(T + (int64_t)row0 * n, n, rs, lane, ys + row0); \
-    row0 += R;                                                             \
+#define ALFI_PIECE(R)                                                                                       \
+  if (rem & R) {                                                                                            \
+    apply_piece<R / 2, NT, MULT_U>(T + (int64_t)row0 * n + (int64_t)ca * R, cn, xs, lane, out + row0);      \
+    row0 += R;                                                                                              \
   }
     ALFI_PIECE(64)
     ALFI_PIECE(32)
@@ -553,10 +601,13 @@ __device__ __forceinline__ void mult_one_patch(int64_t p, int lane, double* __re
     ALFI_PIECE(2)
 #undef ALFI_PIECE
   }
-  ALFI_WAVE_LDS_ORDER();
-  for (int i = lane; i < n; i += 64) {
+  __syncthreads();
+  for (int i = threadIdx.x; i < n; i += 64 * MULT_W) {
     const int64_t dof = patch_dofs[off + i];
-    const double v = y[dof] + ys[i];
+    double d = S.part[0][i];
+#pragma unroll
+    for (int w = 1; w < MULT_W; ++w) d += S.part[w][i];
+    const double v = y[dof] + d;
     if (PUBLISH)
       __hip_atomic_store(y + dof, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);    // global_store_dwordx2 ... sc1
     else
@@ -564,84 +615,74 @@ __device__ __forceinline__ void mult_one_patch(int64_t p, int lane, double* __re
   }
 }
 
+// one dependency wavefront per launch, a workgroup per patch
 template <int BS, bool NT>
-__global__ __launch_bounds__(256) void patch_mult_kernel(int64_t count, const int32_t* __restrict__ seq,
-                                                          const int64_t* __restrict__ patch_ptr,
-                                                          const int32_t* __restrict__ patch_dofs,
-                                                          const int64_t* __restrict__ inv_ptr,
-                                                          const double* __restrict__ inv,
-                                                          const int32_t* __restrict__ rowptr,
-                                                          const int32_t* __restrict__ colidx,
-                                                          const double* __restrict__ vals, int flat,
-                                                          const double* __restrict__ x, double* __restrict__ y) {
-  __shared__ double rs_all[4][MAX_NP];          // r_p
-  __shared__ double ys_all[4][MAX_NP];          // inv(A_p) r_p
-  __shared__ int32_t pre_all[4][MAX_PNODES + 1];  // exclusive prefix of the rows' block counts
-  __shared__ int32_t k0_all[4][MAX_PNODES];       // first block of each row
-  __shared__ int32_t nd_all[4][MAX_PNODES];       // node (block row) of each patch node
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int64_t q = (int64_t)blockIdx.x * 4 + wave;
-  if (q >= count) return;
-  mult_one_patch<BS, NT, false>(seq[q], lane, rs_all[wave], ys_all[wave], pre_all[wave], k0_all[wave], nd_all[wave], patch_ptr,
-                                patch_dofs, inv_ptr, inv, rowptr, colidx, vals, flat, x, y);
+__global__ __launch_bounds__(64 * MULT_W) void patch_mult_kernel(int64_t count, const int32_t* __restrict__ seq,
+                                                                  const int64_t* __restrict__ patch_ptr,
+                                                                  const int32_t* __restrict__ patch_dofs,
+                                                                  const int64_t* __restrict__ inv_ptr,
+                                                                  const double* __restrict__ inv,
+                                                                  const int32_t* __restrict__ rowptr,
+                                                                  const int32_t* __restrict__ colidx,
+                                                                  const double* __restrict__ vals, int flat,
+                                                                  const double* __restrict__ x, double* __restrict__ y) {
+  __shared__ MultLds S;
+  const int64_t p = seq[blockIdx.x];
+  mult_wg_setup<BS>(p, S, patch_ptr, patch_dofs, rowptr);
+  __syncthreads();
+  mult_wg_sweep<BS, NT, false>(p, S, patch_ptr, patch_dofs, inv_ptr, inv, colidx, vals, flat, x, y);
 }
 
-// The whole sweep (both directions of a symmetrised one) as ONE launch of a resident grid: waves draw the items of the
+// The whole sweep (both directions of a symmetrised one) as ONE launch of a resident grid: workgroups draw the items of the
 // wavefront-major schedule in order (a ticket counter) and start an item when its predecessor count has reached zero -- the
 // predecessors of an item are the LAST WRITERS of the nodes it reads (host: alfi_patches_set_multiplicative), each finished
-// item decrements its successors.  The schedule order is a topological order and every ticket is held by a resident wave, so
-// every wait ends; the independent patches of wavefront k + 1 start while the tail of wavefront k is still running, and the 674
-// launch boundaries of config 4's symmetrised sweep are gone.  Results are those of the launch-per-wavefront schedule bit for
-// bit: the same patches see the same y entries (conflicting patches keep their order), one wave computes each.
-// Hand-off (Guideline 16, R1): y entries leave with write-through stores, the storing wave drains them (vmcnt(0)), then
-// decrements; a consumer polls its own counter relaxed, then ONE agent-scope acquire, then plain loads.
+// item decrements its successors.  The schedule order is a topological order and every ticket is held by a running workgroup,
+// so every wait ends; the independent patches of wavefront k + 1 start while the tail of wavefront k is still running, a
+// workgroup reads its patch's tables while it waits, and the 674 launch boundaries of config 4's symmetrised sweep are gone.
+// Results are those of the launch-per-wavefront schedule bit for bit: the same patches see the same y entries (conflicting
+// patches keep their order), the same code computes each.
+// Hand-off (Guideline 16, R1): y entries leave with write-through stores, every storing wave drains them (vmcnt(0)), the
+// workgroup meets at a barrier, then the successors are decremented; a consumer polls its own counter relaxed (one lane), then
+// every wave does ONE agent-scope acquire, then plain loads.
 // err[0]: set when a wait ran into its bound (a broken schedule would otherwise spin until the watchdog).
 template <int BS, bool NT>
-__global__ __launch_bounds__(256) void patch_mult_persistent_kernel(int32_t nitems, const int32_t* __restrict__ items,
-                                                                     int32_t* __restrict__ pred, const int32_t* __restrict__ succ_ptr,
-                                                                     const int32_t* __restrict__ succ, int32_t* __restrict__ head,
-                                                                     int32_t* __restrict__ err,
-                                                                     const int64_t* __restrict__ patch_ptr,
-                                                                     const int32_t* __restrict__ patch_dofs,
-                                                                     const int64_t* __restrict__ inv_ptr,
-                                                                     const double* __restrict__ inv,
-                                                                     const int32_t* __restrict__ rowptr,
-                                                                     const int32_t* __restrict__ colidx,
-                                                                     const double* __restrict__ vals, int flat,
-                                                                     const double* __restrict__ x, double* __restrict__ y) {
-  __shared__ double rs_all[4][MAX_NP];
-  __shared__ double ys_all[4][MAX_NP];
-  __shared__ int32_t pre_all[4][MAX_PNODES + 1];
-  __shared__ int32_t k0_all[4][MAX_PNODES];
-  __shared__ int32_t nd_all[4][MAX_PNODES];
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+__global__ __launch_bounds__(64 * MULT_W) void patch_mult_persistent_kernel(
+    int32_t nitems, const int32_t* __restrict__ items, int32_t* __restrict__ pred, const int32_t* __restrict__ succ_ptr,
+    const int32_t* __restrict__ succ, int32_t* __restrict__ head, int32_t* __restrict__ err,
+    const int64_t* __restrict__ patch_ptr, const int32_t* __restrict__ patch_dofs, const int64_t* __restrict__ inv_ptr,
+    const double* __restrict__ inv, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colidx,
+    const double* __restrict__ vals, int flat, const double* __restrict__ x, double* __restrict__ y) {
+  __shared__ MultLds S;
   for (;;) {
-    int32_t t = 0;
-    if (lane == 0) t = __hip_atomic_fetch_add(head, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    t = __builtin_amdgcn_readfirstlane(t);
+    if (threadIdx.x == 0) S.ticket = __hip_atomic_fetch_add(head, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    const int32_t t = S.ticket;
     if (t >= nitems) break;
+    const int64_t p = items[t];
+    mult_wg_setup<BS>(p, S, patch_ptr, patch_dofs, rowptr);      // nothing of this depends on y
     // wait for the predecessors: ONE lane polls ONE word, relaxed
-    int ok = 1;
-    if (lane == 0) {
+    if (threadIdx.x == 0) {
+      int ok = 1;
       unsigned spins = 0;
       while (__hip_atomic_load(pred + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
-        __builtin_amdgcn_s_sleep(8);
+        __builtin_amdgcn_s_sleep(2);
         if (++spins > (1u << 24) || __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
           ok = 0;
           break;
         }
       }
+      S.ok = ok;
     }
-    ok = __builtin_amdgcn_readfirstlane(ok);
-    if (!ok) {
-      if (lane == 0) __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (!S.ok) {
+      if (threadIdx.x == 0) __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       break;
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");          // this CU's L1 forgets what other CUs have rewritten
-    mult_one_patch<BS, NT, true>(items[t], lane, rs_all[wave], ys_all[wave], pre_all[wave], k0_all[wave], nd_all[wave],
-                                 patch_ptr, patch_dofs, inv_ptr, inv, rowptr, colidx, vals, flat, x, y);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // the wave's y stores have left
-    for (int32_t e = succ_ptr[t] + lane; e < succ_ptr[t + 1]; e += 64)
+    mult_wg_sweep<BS, NT, true>(p, S, patch_ptr, patch_dofs, inv_ptr, inv, colidx, vals, flat, x, y);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // this wave's y stores have left
+    __syncthreads();                                            // ... and those of the other waves
+    for (int32_t e = succ_ptr[t] + threadIdx.x; e < succ_ptr[t + 1]; e += 64 * MULT_W)
       __hip_atomic_fetch_sub(pred + succ[e], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
@@ -747,7 +788,7 @@ int launch_patch_mult_wave(alfi_level* L, const int32_t* seq, int64_t count, con
   alfi_ctx* ctx = L->ctx;
   if (count == 0) return 0;
   if (L->mult_big) return launch_big_mult_wave(L, seq, count, x, y);
-  dim3 grid((unsigned)((count + 3) / 4)), block(256);
+  dim3 grid((unsigned)count), block(64 * MULT_W);
 #define ALFI_MULT(BSV, NTV)                                                                                           \
   hipLaunchKernelGGL((patch_mult_kernel<BSV, NTV>), grid, block, 0, ctx->stream, count, seq, L->patch_ptr,            \
                      L->patch_dofs, L->inv_ptr, L->inv, L->A.rowptr, L->A.colidx, L->A.vals, L->A.flat, x, y)
@@ -770,16 +811,20 @@ int launch_patch_mult_persistent(alfi_level* L, const double* x, double* y) {
   ALFI_HIP_CHECK(ctx, hipMemcpyAsync(L->mult_pred, L->mult_pred0, sizeof(int32_t) * (size_t)L->mult_nitems,
                                      hipMemcpyDeviceToDevice, ctx->stream));
   ALFI_HIP_CHECK(ctx, hipMemsetAsync(L->mult_ctl, 0, 4 * sizeof(int32_t), ctx->stream));
-  // a grid that is resident whatever the dispatcher does: one workgroup of 4 waves per CU (the kernel's registers and LDS
-  // admit two), every wave a worker
-  static int ncu = 0;
+  // a resident grid: as many workgroups per CU as the kernel's registers and LDS admit (every ticket holder must be running;
+  // more workgroups in flight = more of the next wavefronts' independent patches started early)
+  static int ncu = 0, per_cu[2] = {0, 0};
   if (ncu == 0) {
     hipDeviceProp_t prop;
     ALFI_HIP_CHECK(ctx, hipGetDeviceProperties(&prop, ctx->device));
+    const auto k2 = &patch_mult_persistent_kernel<2, true>;
+    const auto k3 = &patch_mult_persistent_kernel<3, true>;
+    ALFI_HIP_CHECK(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu[0], k2, 64 * MULT_W, 0));
+    ALFI_HIP_CHECK(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu[1], k3, 64 * MULT_W, 0));
     ncu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 64;
   }
-  const int64_t want = ((int64_t)L->mult_nitems + 3) / 4;
-  dim3 grid((unsigned)std::min<int64_t>(want, ncu)), block(256);
+  const int pc = std::max(1, std::min(per_cu[L->bs == 3 ? 1 : 0], ALFI_MULT_WG_PER_CU));
+  dim3 grid((unsigned)std::min<int64_t>(L->mult_nitems, (int64_t)ncu * pc)), block(64 * MULT_W);
 #define ALFI_PMULT(BSV)                                                                                                   \
   hipLaunchKernelGGL((patch_mult_persistent_kernel<BSV, true>), grid, block, 0, ctx->stream, L->mult_nitems, L->mult_items, \
                      L->mult_pred, L->mult_succ_ptr, L->mult_succ, L->mult_ctl, ctx->dev_err, L->patch_ptr,               \
