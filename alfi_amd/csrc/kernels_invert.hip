@@ -26,6 +26,23 @@
 #include <type_traits>
 #include "common.h"
 
+// -DALFI_INVERT_TIMING (measurement builds, scripts/invert_phases.py): every wave adds up the shader clock spent in the phases
+// of a block step (panels + barrier | LU of the pivot block | operands | update MFMAs issued | column fix-up | row fix-up);
+// alfi_debug_invert_phases copies the sums out
+#ifdef ALFI_INVERT_TIMING
+static __device__ long long* g_invert_phases_dev = nullptr;
+#define ALFI_INV_PH(I)                                   \
+  do {                                                   \
+    __builtin_amdgcn_sched_barrier(0);                   \
+    const long long now_ = (long long)__builtin_readcyclecounter(); \
+    __builtin_amdgcn_sched_barrier(0);                   \
+    tacc[I] += now_ - tprev;                             \
+    tprev = now_;                                        \
+  } while (0)
+#else
+#define ALFI_INV_PH(I) do { } while (0)
+#endif
+
 namespace {
 
 typedef double inv_d4 __attribute__((ext_vector_type(4)));
@@ -66,20 +83,6 @@ __device__ __forceinline__ void lu4(const double (&d)[4][4], Lu4& f, bool& bad) 
 
 __device__ __forceinline__ double sel4(int i, double a0, double a1, double a2, double a3) {
   return i == 0 ? a0 : i == 1 ? a1 : i == 2 ? a2 : a3;
-}
-
-// x = one column of the raw row panel A[K, c].  r[t] = the scaled pivot row t at the time of scalar step t (the B operand of
-// the rank-4 update); z[t] = (D^-1 A[K, c])[t], the final content of the rows K
-__device__ __forceinline__ void row_panel(const Lu4& f, const double (&x)[4], double (&r)[4], double (&z)[4]) {
-  const double y0 = x[0];
-  const double y1 = __builtin_fma(-f.l10, y0, x[1]);
-  const double y2 = __builtin_fma(-f.l21, y1, __builtin_fma(-f.l20, y0, x[2]));
-  const double y3 = __builtin_fma(-f.l32, y2, __builtin_fma(-f.l31, y1, __builtin_fma(-f.l30, y0, x[3])));
-  r[0] = y0 * f.i0; r[1] = y1 * f.i1; r[2] = y2 * f.i2; r[3] = y3 * f.i3;
-  z[3] = r[3];
-  z[2] = __builtin_fma(-f.s23, z[3], r[2]);
-  z[1] = __builtin_fma(-f.s13, z[3], __builtin_fma(-f.s12, z[2], r[1]));
-  z[0] = __builtin_fma(-f.s03, z[3], __builtin_fma(-f.s02, z[2], __builtin_fma(-f.s01, z[1], r[0])));
 }
 
 // x = one row of the raw column panel A[i, K].  c[t] = the column t at the time of scalar step t (the A operand)
@@ -124,8 +127,10 @@ __global__ __launch_bounds__(512) void patch_invert_mfma_kernel(const int64_t* _
   constexpr int N = 16 * NT;
   constexpr int NA = (NT + 3) / 4;            // tile rows per wave (ti = 4 a + wr)
   constexpr int NB = (NT + 1) / 2;            // tile columns per wave (tj = 2 b + wc)
-  __shared__ double Rraw[2][4][N];            // raw row panel   A[K, :]
-  __shared__ double Craw[2][N][4];            // raw column panel A[:, K]
+  // raw panels, four doubles per matrix column / row side by side: a lane fetches the pivot rows of its column (the pivot
+  // columns of its row) with two 16-byte reads
+  __shared__ __attribute__((aligned(16))) double Rraw[2][N][4];   // raw row panel, transposed: Rraw[c][i] = A[K + i][c]
+  __shared__ __attribute__((aligned(16))) double Craw[2][N][4];   // raw column panel: Craw[r][j] = A[r][K + j]
   const int64_t p = blockIdx.x;
   const int n = (int)(patch_ptr[p + 1] - patch_ptr[p]);
   const int ld = (n + 1) & ~1;
@@ -134,6 +139,7 @@ __global__ __launch_bounds__(512) void patch_invert_mfma_kernel(const int64_t* _
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int wr = wave >> 1, wc = wave & 1;
   const int lm = lane & 15, lk = lane >> 4;
+  static_assert(NT % 2 == 0, "tile columns 2 b + wc < NT for every b < NT / 2");
   inv_d4 acc[NA][NB];
 #pragma unroll
   for (int a = 0; a < NA; ++a)
@@ -148,6 +154,15 @@ __global__ __launch_bounds__(512) void patch_invert_mfma_kernel(const int64_t* _
     }
   __syncthreads();  // all loads done before anyone stores (the result goes back in place, in another layout)
   bool bad = false;
+#ifdef ALFI_INVERT_TIMING
+  long long tacc[6] = {0, 0, 0, 0, 0, 0};
+  long long tprev = (long long)__builtin_readcyclecounter();
+  const long long tstart = tprev;
+#endif
+  // the last tile row of a wave may lie outside the matrix (NT = 10: waves 4-7 hold two tile rows, not three): its panel reads
+  // are redirected to a tile row that exists -- straight-line code, the reads of a step leave together -- and only its MFMAs and
+  // stores are skipped
+  const bool last_row_in = 4 * (NA - 1) + wr < NT;               // wave-uniform
   static_for<0, NT>([&](auto TK) __attribute__((always_inline)) {
     constexpr int tk = decltype(TK)::value;   // the pivot tile: a compile-time constant, so is every accumulator index below
     if (16 * tk >= n) return;                 // uniform: the remaining pivots are identity padding
@@ -163,26 +178,41 @@ __global__ __launch_bounds__(512) void patch_invert_mfma_kernel(const int64_t* _
       // ---- raw panels -> LDS
       if (own_r) {
 #pragma unroll
-        for (int b = 0; b < NB; ++b)
-          if (2 * b + wc < NT) Rraw[buf][lk][16 * (2 * b + wc) + lm] = acc[ar][b][q];
+        for (int b = 0; b < NB; ++b) Rraw[buf][16 * (2 * b + wc) + lm][lk] = acc[ar][b][q];
       }
       if (own_c && colgrp) {
 #pragma unroll
         for (int a = 0; a < NA; ++a)
-          if (4 * a + wr < NT) {
+          if (a + 1 < NA || last_row_in) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) Craw[buf][16 * (4 * a + wr) + lk + 4 * g][lm & 3] = acc[a][bc][g];
           }
       }
       __syncthreads();
+      ALFI_INV_PH(0);
+      // ---- every panel read of the step, requested together: the pivot block (16 doubles side by side, the same for all
+      //      lanes), the pivot rows of my tile columns, the pivot columns of my tile rows
+      const inv_d4* Rv = reinterpret_cast<const inv_d4*>(&Rraw[buf][0][0]);
+      const inv_d4* Cv = reinterpret_cast<const inv_d4*>(&Craw[buf][0][0]);
+      inv_d4 dc[4], xb[NB], xa[NA];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) dc[j] = Rv[4 * s + j];
+#pragma unroll
+      for (int b = 0; b < NB; ++b) xb[b] = Rv[16 * (2 * b + wc) + lm];
+#pragma unroll
+      for (int a = 0; a < NA; ++a) xa[a] = Cv[16 * ((a + 1 < NA || last_row_in) ? 4 * a + wr : wr) + lm];
       // ---- LU of the pivot block, redundantly on every lane (no second barrier)
       double d[4][4];
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) d[i][j] = Rraw[buf][i][4 * s + j];
+        for (int j = 0; j < 4; ++j) d[i][j] = dc[j][i];
       Lu4 f;
       lu4(d, f, bad);
+#ifdef ALFI_INVERT_TIMING
+      asm volatile("" : "+v"(f.i3), "+v"(f.s23));
+#endif
+      ALFI_INV_PH(1);
       // ---- operands of the rank-4 update  A <- A - sum_t c_t r_t^T  (the four scalar Gauss-Jordan steps, delayed), by
       //      forward substitution with the SAME rounded L, U entries the pivots were computed with.  (Forming L^-1 and
       //      diag(U)^-1 U explicitly and taking each operand as a 4-term dot product is a third of the FP64 work, and fails the
@@ -190,42 +220,49 @@ __global__ __launch_bounds__(512) void patch_invert_mfma_kernel(const int64_t* _
       //      node's gamma b b^T + nu K block is a cancellation of O(gamma) terms down to O(nu); only substitutions that repeat
       //      the elimination's own roundings stay consistent with it.)
       const double isel = sel4(lk, f.i0, f.i1, f.i2, f.i3);
-      double bop[NB], aop[NA], vop[NA];
+      double bop[NB], aop[NA], vop[NA], zrow[NB];
 #pragma unroll
       for (int b = 0; b < NB; ++b) {
         const int tj = 2 * b + wc;
-        bop[b] = 0.0;
-        if (tj < NT) {
-          const int c = 16 * tj + lm;
-          const double x0 = Rraw[buf][0][c], x1 = Rraw[buf][1][c], x2 = Rraw[buf][2][c], x3 = Rraw[buf][3][c];
-          const double y1 = __builtin_fma(-f.l10, x0, x1);
-          const double y2 = __builtin_fma(-f.l21, y1, __builtin_fma(-f.l20, x0, x2));
-          const double y3 = __builtin_fma(-f.l32, y2, __builtin_fma(-f.l31, y1, __builtin_fma(-f.l30, x0, x3)));
-          const double rv = sel4(lk, x0, y1, y2, y3) * isel;             // r_lk = (L^-1 x)_lk / U_lk,lk
-          bop[b] = (tj == tk && colgrp) ? 0.0 : rv;                      // columns K: left to the fix-up
+        const double x0 = xb[b][0], x1 = xb[b][1], x2 = xb[b][2], x3 = xb[b][3];
+        const double y1 = __builtin_fma(-f.l10, x0, x1);
+        const double y2 = __builtin_fma(-f.l21, y1, __builtin_fma(-f.l20, x0, x2));
+        const double y3 = __builtin_fma(-f.l32, y2, __builtin_fma(-f.l31, y1, __builtin_fma(-f.l30, x0, x3)));
+        const double rv = sel4(lk, x0, y1, y2, y3) * isel;               // r_lk = (L^-1 x)_lk / U_lk,lk
+        bop[b] = (tj == tk && colgrp) ? 0.0 : rv;                        // columns K: left to the fix-up
+        zrow[b] = 0.0;
+        if (own_r) {      // the final content of the rows K, (D^-1 A[K, :])[lk][c]: the back substitution on the same y
+          const double r0 = x0 * f.i0, r1 = y1 * f.i1, r2 = y2 * f.i2, r3 = y3 * f.i3;
+          const double z2 = __builtin_fma(-f.s23, r3, r2);
+          const double z1 = __builtin_fma(-f.s13, r3, __builtin_fma(-f.s12, z2, r1));
+          const double z0 = __builtin_fma(-f.s03, r3, __builtin_fma(-f.s02, z2, __builtin_fma(-f.s01, z1, r0)));
+          zrow[b] = sel4(lk, z0, z1, z2, r3);
         }
       }
 #pragma unroll
       for (int a = 0; a < NA; ++a) {
         const int ti = 4 * a + wr;
-        aop[a] = vop[a] = 0.0;
-        if (ti < NT) {
-          const int i = 16 * ti + lm;
-          const double x[4] = {Craw[buf][i][0], Craw[buf][i][1], Craw[buf][i][2], Craw[buf][i][3]};
-          double c[4];
-          col_panel(f, x, c);
-          const double cv = sel4(lk, c[0], c[1], c[2], c[3]);
-          aop[a] = (ti == tk && colgrp) ? 0.0 : cv;                      // rows K: left to the fix-up
-          vop[a] = cv * isel;                                            // (A[:, K] U^-1)[row][lk]
-        }
+        const double x[4] = {xa[a][0], xa[a][1], xa[a][2], xa[a][3]};
+        double c[4];
+        col_panel(f, x, c);
+        const double cv = sel4(lk, c[0], c[1], c[2], c[3]);
+        aop[a] = (ti == tk && colgrp) ? 0.0 : cv;                        // rows K: left to the fix-up
+        vop[a] = cv * isel;                                              // (A[:, K] U^-1)[row][lk]
       }
+#ifdef ALFI_INVERT_TIMING
+#pragma unroll
+      for (int a = 0; a < NA; ++a) asm volatile("" : "+v"(aop[a]), "+v"(vop[a]));
+#pragma unroll
+      for (int b = 0; b < NB; ++b) asm volatile("" : "+v"(bop[b]));
+#endif
+      ALFI_INV_PH(2);
 #pragma unroll
       for (int a = 0; a < NA; ++a)
-        if (4 * a + wr < NT) {
+        if (a + 1 < NA || last_row_in) {
 #pragma unroll
-          for (int b = 0; b < NB; ++b)
-            if (2 * b + wc < NT) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(-aop[a], bop[b], acc[a][b], 0, 0, 0);
+          for (int b = 0; b < NB; ++b) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(-aop[a], bop[b], acc[a][b], 0, 0, 0);
         }
+      ALFI_INV_PH(3);
       // ---- columns K <- - A[:, K] D^-1 = - (A[:, K] U^-1) L^-1 (rows outside K): one more MFMA per tile of tile column tk,
       //      A-operand v = A[:, K] U^-1 (the c_t scaled by 1 / U_tt), B-operand - L^-1 (unit lower triangular, explicit: 6
       //      entries) placed on the columns K of the tile.  A[K, K] <- D^-1 = U^-1 L^-1 on the 16 lanes that hold it.
@@ -248,7 +285,7 @@ __global__ __launch_bounds__(512) void patch_invert_mfma_kernel(const int64_t* _
         }
 #pragma unroll
         for (int a = 0; a < NA; ++a)
-          if (4 * a + wr < NT) {
+          if (a + 1 < NA || last_row_in) {
             const inv_d4 zero = {0.0, 0.0, 0.0, 0.0};
             const inv_d4 t = __builtin_amdgcn_mfma_f64_16x16x4f64(vop[a], b2, zero, 0, 0, 0);
             if (colgrp) {
@@ -258,23 +295,28 @@ __global__ __launch_bounds__(512) void patch_invert_mfma_kernel(const int64_t* _
             }
           }
       }
+      ALFI_INV_PH(4);
       // ---- rows K <- D^-1 A[K, :] (columns outside K): register q of the tiles of tile row tk
       if (own_r) {
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
           const bool in_k = (2 * b + wc) == tk && colgrp;
-          if (2 * b + wc < NT) {
-            const int c = 16 * (2 * b + wc) + lm;
-            const double x[4] = {Rraw[buf][0][c], Rraw[buf][1][c], Rraw[buf][2][c], Rraw[buf][3][c]};
-            double r[4], z[4];
-            row_panel(f, x, r, z);                                        // two triangular solves: D^-1 is never formed
-            if (!in_k) acc[ar][b][q] = sel4(lk, z[0], z[1], z[2], z[3]);   // (D^-1 A[K, :])[lk][c]
-          }
+          if (!in_k) acc[ar][b][q] = zrow[b];
         }
       }
+      ALFI_INV_PH(5);
     }
   });
   if (bad && threadIdx.x == 0) atomicExch(status, 1);
+#ifdef ALFI_INVERT_TIMING
+  if (g_invert_phases_dev && lane == 0 && p < 4096) {
+    long long* o = g_invert_phases_dev + (p * 8 + wave) * 8;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) o[i] = tacc[i];
+    o[6] = (long long)__builtin_readcyclecounter() - tstart;
+    o[7] = n;
+  }
+#endif
 #pragma unroll
   for (int a = 0; a < NA; ++a)
 #pragma unroll
@@ -301,6 +343,16 @@ __global__ __launch_bounds__(512) void patch_invert_mfma_kernel(const int64_t* _
 
 }  // namespace
 
+#ifdef ALFI_INVERT_TIMING
+static long long* g_invert_phases = nullptr;
+extern "C" int64_t alfi_debug_invert_phases(int64_t* out) {     // out: 4096 x 8 waves x 8 (6 phase sums, total, n)
+  if (!g_invert_phases) return -1;
+  if (hipDeviceSynchronize() != hipSuccess) return -2;
+  if (hipMemcpy(out, g_invert_phases, sizeof(long long) * 4096 * 64, hipMemcpyDeviceToHost) != hipSuccess) return -3;
+  return 4096;
+}
+#endif
+
 // in-place inversion (row-major n x ld in, row-piece layout out) of patches with 33 .. 160 dofs on the matrix cores;
 // returns 1 if the sizes are handled here, 0 if the caller should use the register kernel
 int launch_patch_invert_mfma(alfi_ctx* ctx, int64_t npatch, int max_np, const int64_t* patch_ptr, const int64_t* inv_ptr,
@@ -311,13 +363,25 @@ int launch_patch_invert_mfma(alfi_ctx* ctx, int64_t npatch, int max_np, const in
   // [P1+FB]^3's 111 dofs: 5.5 against 9.8 ms for 35 937 patches; ALFI_INVERT_MFMA=2 sends those sizes here too (tests)
   static const bool all_sizes = getenv("ALFI_INVERT_MFMA") && atoi(getenv("ALFI_INVERT_MFMA")) == 2;
   if (!allow || max_np <= 32 || max_np > 160 || (max_np <= 112 && !all_sizes)) return 0;
+#ifdef ALFI_INVERT_TIMING
+  if (!g_invert_phases) {
+    ALFI_HIP_CHECK(ctx, hipMalloc(&g_invert_phases, sizeof(long long) * 4096 * 64));
+    ALFI_HIP_CHECK(ctx, hipMemset(g_invert_phases, 0, sizeof(long long) * 4096 * 64));
+    ALFI_HIP_CHECK(ctx, hipMemcpyToSymbol(HIP_SYMBOL(g_invert_phases_dev), &g_invert_phases, sizeof(long long*)));
+  }
+#endif
   dim3 grid((unsigned)npatch), block(512);
 #define ALFI_INV(NTV) \
   hipLaunchKernelGGL(patch_invert_mfma_kernel<NTV>, grid, block, 0, ctx->stream, patch_ptr, inv_ptr, inv, status)
+#ifdef ALFI_INVERT_DEV_NT10            // development builds: one instantiation (the file takes minutes per size)
+  if (max_np <= 128) return 0;
+  ALFI_INV(10);
+#else
   if (max_np <= 64) ALFI_INV(4);
   else if (max_np <= 96) ALFI_INV(6);
   else if (max_np <= 128) ALFI_INV(8);
   else ALFI_INV(10);
+#endif
 #undef ALFI_INV
   ALFI_HIP_CHECK(ctx, hipGetLastError());
   *handled = 1;

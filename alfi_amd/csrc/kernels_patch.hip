@@ -265,36 +265,48 @@ __device__ __forceinline__ void apply_piece(const double* __restrict__ T, int n,
   if (cg == 0) *reinterpret_cast<double2*>(out + 2 * l) = make_double2(acc0, acc1);
 }
 
-template <bool NT>
-__global__ __launch_bounds__(256) void patch_apply_kernel(int64_t p0, int64_t npatch,
-                                                           const int64_t* __restrict__ patch_ptr,
-                                                           const int32_t* __restrict__ patch_dofs,
-                                                           const int64_t* __restrict__ inv_ptr,
-                                                           const int64_t* __restrict__ stage_ptr,
-                                                           const double* __restrict__ inv,
-                                                           const double* __restrict__ x, double* __restrict__ stage) {
-  __shared__ double xs_all[4][MAX_NP];
+// A WORKGROUP of APPLY_W waves per patch: wave w takes the w-th share of the columns of every row piece, the partial results
+// are added in the order of the waves (deterministic).  Rounds 1-3 gave a patch to ONE wave, four patches to a workgroup: a
+// wave then streams its patch for as long as a CU's share of the bandwidth lets it (config 3: 78 KB at 32 waves per CU =
+// ~110 us, config 4 ~240 us), workgroups end when their slowest wave ends, and the launch ends with a ramp-down of that length.
+// Cut four times finer (same box, apply + sum, profiles/r04_ab_apply_split.txt): config 4's finest level 5316 -> 5256 us,
+// its level 2 636 -> 615 us, config 3's level 3 (4913 patches) 72.8 -> 63.4 us; giving only the LAST patches of a level to
+// workgroups (one resident round, 8192 patches) gained less than half of that.
+// Waves per patch, same box: config 4 (153 dofs) 2: 4929 / 4: 4912 / 8: 4856 us (level 2: 628 / 624 / 608); config 3 (111 dofs)
+// 2: 517 / 4: 487-509 / 8: 516 us -- eight above 128 dofs, four down to 65, one wave below.
+#ifndef ALFI_APPLY_W
+#define ALFI_APPLY_W 4
+#endif
+constexpr int APPLY_W = ALFI_APPLY_W;     // waves per patch of 65 .. 128 dofs (twice as many above, one wave below)
+template <bool NT, int W>
+__global__ __launch_bounds__(64 * W) void patch_apply_kernel(int64_t p0, int64_t p1,
+                                                                    const int64_t* __restrict__ patch_ptr,
+                                                                    const int32_t* __restrict__ patch_dofs,
+                                                                    const int64_t* __restrict__ inv_ptr,
+                                                                    const int64_t* __restrict__ stage_ptr,
+                                                                    const double* __restrict__ inv,
+                                                                    const double* __restrict__ x, double* __restrict__ stage) {
+  __shared__ double xs[MAX_NP];
+  __shared__ double part[W][MAX_NP];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int64_t p = p0 + (int64_t)blockIdx.x * 4 + wave;   // patches [p0, npatch)
-  double* xs = xs_all[wave];
-  int n = 0;
-  if (p < npatch) {
-    const int64_t off = patch_ptr[p];
-    n = (int)(patch_ptr[p + 1] - off);
-    for (int i = lane; i < n; i += 64) xs[i] = x[patch_dofs[off + i]];
-  }
+  const int64_t p = p0 + blockIdx.x;
+  if (p >= p1) return;
+  const int64_t off = patch_ptr[p];
+  const int n = (int)(patch_ptr[p + 1] - off);
+  for (int i = threadIdx.x; i < n; i += 64 * W) xs[i] = x[patch_dofs[off + i]];
   __syncthreads();
-  if (p >= npatch) return;
   const int ld = (n + 1) & ~1;
   const double* T = inv + inv_ptr[p];
-  double* out = stage + stage_ptr[p];
+  const int ca = (int)(((int64_t)wave * n) / W), cn = (int)(((int64_t)(wave + 1) * n) / W) - ca;
+  double* out = part[wave];
   int row0 = 0;
-  for (; row0 + 128 <= ld; row0 += 128) apply_piece<64, NT>(T + (int64_t)row0 * n, n, xs, lane, out + row0);
+  for (; row0 + 128 <= ld; row0 += 128)
+    apply_piece<64, NT>(T + (int64_t)row0 * n + (int64_t)ca * 128, cn, xs + ca, lane, out + row0);
   const int rem = ld - row0;  // even, < 128: one piece per binary digit
-#define ALFI_PIECE(R)                                                        \
-  if (rem & R) {                                                             \
-    apply_piece<R / 2, NT>(T + (int64_t)row0 * n, n, xs, lane, out + row0);  \
-    row0 += R;                                                               \
+#define ALFI_PIECE(R)                                                                             \
+  if (rem & R) {                                                                                  \
+    apply_piece<R / 2, NT>(T + (int64_t)row0 * n + (int64_t)ca * R, cn, xs + ca, lane, out + row0); \
+    row0 += R;                                                                                    \
   }
   ALFI_PIECE(64)
   ALFI_PIECE(32)
@@ -303,6 +315,14 @@ __global__ __launch_bounds__(256) void patch_apply_kernel(int64_t p0, int64_t np
   ALFI_PIECE(4)
   ALFI_PIECE(2)
 #undef ALFI_PIECE
+  __syncthreads();
+  double* dst = stage + stage_ptr[p];
+  for (int i = threadIdx.x; i < ld; i += 64 * W) {
+    double d = part[0][i];
+#pragma unroll
+    for (int w = 1; w < W; ++w) d += part[w][i];
+    dst[i] = d;
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -395,20 +415,42 @@ __global__ __launch_bounds__(256) void patch_il_build_kernel(int64_t npatch, int
 constexpr int MAX_PNODES = 64;
 
 #ifndef ALFI_MULT_U
-#define ALFI_MULT_U 16
+#define ALFI_MULT_U 32
 #endif
-#ifndef ALFI_MULT_RU
-#define ALFI_MULT_RU 4
+#ifndef ALFI_MULT_G0
+#define ALFI_MULT_G0 5
 #endif
 #ifndef ALFI_MULT_W
 #define ALFI_MULT_W 4
 #endif
-constexpr int MULT_U = ALFI_MULT_U;     // 16-byte loads in flight per lane in the sweep's inverse apply (see apply_piece)
-constexpr int MULT_RU = ALFI_MULT_RU;   // sub-steps of 64 operator blocks whose loads are requested together in the residual
-constexpr int MULT_W = ALFI_MULT_W;     // waves per patch
+// -DALFI_MULT_TIMING (measurement builds, scripts/mult_stamps.py): thread 0 of a workgroup of the persistent sweep records the
+// 100 MHz wall clock at seven points of every item (ticket | tables | wait over | residual | apply | stores drained | successors
+// released); alfi_debug_mult_stamps copies them out
+#ifdef ALFI_MULT_TIMING
+#define ALFI_MULT_STAMP_PARAM , int64_t* __restrict__ stamps
+#define ALFI_MULT_STAMP_ARG , stamps, t
+#define ALFI_MULT_STAMP(K)                                                   \
+  do {                                                                       \
+    if (stamps && threadIdx.x == 0) stamps[(int64_t)t * 8 + (K)] = (int64_t)wall_clock64(); \
+  } while (0)
+#else
+#define ALFI_MULT_STAMP_PARAM
+#define ALFI_MULT_STAMP_ARG
+#define ALFI_MULT_STAMP(K) do { } while (0)
+#endif
 #ifndef ALFI_MULT_WG_PER_CU
 #define ALFI_MULT_WG_PER_CU 4           // cap on the resident workgroups per CU of the persistent sweep
 #endif
+#ifndef ALFI_MULT_OCC
+#define ALFI_MULT_OCC 2                   // waves per SIMD the sweep kernels are compiled for (the LDS admits two workgroups per CU)
+#endif
+#define ALFI_MULT_OCC_ATTR __attribute__((amdgpu_waves_per_eu(ALFI_MULT_OCC, ALFI_MULT_OCC)))
+constexpr int MULT_W = ALFI_MULT_W;         // waves per patch
+constexpr int MULT_NTHR = 64 * MULT_W;
+static_assert(MULT_NTHR >= MAX_NP, "one thread per row entry of a patch in the residual");
+constexpr int MULT_U = ALFI_MULT_U;         // 16-byte loads in flight per lane in the sweep's inverse apply (see apply_piece)
+constexpr int MULT_MAXU = 9;                // operator blocks per thread and round (2304 blocks per round at 4 waves)
+constexpr int MULT_G0 = ALFI_MULT_G0;       // of which the loads of the first MULT_G0 leave together, then those of the rest
 
 // same-wave LDS hand-off: the LDS serves a wave's instructions in order, so a wave that writes an array and then reads it
 // through other lanes needs no barrier -- only the compiler must keep the order
@@ -418,31 +460,38 @@ constexpr int MULT_W = ALFI_MULT_W;     // waves per patch
     __builtin_amdgcn_wave_barrier();                           \
   } while (0)
 
-// A sweep is a chain of dependent patches (config 4: 337 wavefronts per direction), so the time of an apply is the number of
-// wavefronts times the latency of ONE patch whatever the occupancy.  Rounds 1-3 gave a patch to one wave: ~35 dependent passes
-// over its operator rows and ~150 columns of its inverse behind each other, 75-85 us per patch.  Here a WORKGROUP of MULT_W
-// waves shares the patch: the operator rows are dealt to the waves in contiguous ranges of equal block counts (each wave runs
-// the flat segmented scan over its own range), the inverse is applied by COLUMN shares (wave w multiplies its quarter of the
-// columns of every row piece; the partial results are added in the order of the waves: deterministic), and everything that
-// does not depend on y -- the patch's tables -- is read before the wait of the persistent schedule.
+// A sweep is a chain of dependent patches (config 4: 337 wavefronts per direction), so the time of an apply is at least the
+// number of wavefronts times the latency of ONE patch, whatever the occupancy.  Rounds 1-3 gave a patch to one wave: ~35
+// dependent passes over its operator rows and ~150 columns of its inverse behind each other, 75-85 us per patch.  Here a
+// WORKGROUP of MULT_W waves shares the patch and the dependent round trips to memory are counted:
+//   * tables (before the wait of the persistent schedule -- nothing of it depends on y): the rows' block ranges, and for
+//     every operator block of the patch's rows, dealt thread by thread, its index and its column (registers);
+//   * residual: the blocks' values and y entries leave in two groups of loads, each thread writes its blocks' products
+//     A_k y_col to LDS, then one thread per row entry adds the row's products in ascending order -- the order of the CSR row,
+//     whatever the thread layout;
+//   * apply: row pieces of >= 64 rows by COLUMN shares (wave w multiplies its share of the columns; the partial results are
+//     added in the order of the waves), the small pieces a wave each, at most two groups of loads per wave.
+// Clock stamps of config 4's finest level (scripts/mult_stamps.py, profiles/r04_mult_stamps_cfg4.txt) guided this.
 struct MultLds {
-  double rs[MAX_NP];                  // r_p
-  double part[MULT_W][MAX_NP];        // partial products of the waves' column shares
-  int32_t pre[MAX_PNODES + 1];        // exclusive prefix of the rows' block counts
-  int32_t k0[MAX_PNODES];             // first block of each row
-  int32_t nd[MAX_PNODES];             // node (block row) of each patch node
-  int32_t rb[MULT_W + 1];             // rows [rb[w], rb[w + 1]) belong to wave w
+  double rs[MAX_NP];                          // r_p
+  double part[MULT_W][MAX_NP];                // partial products of the waves
+  double prod[MULT_NTHR * MULT_MAXU * 3];     // products of one round of blocks (BS doubles each)
+  int32_t pre[MAX_PNODES + 1];                // exclusive prefix of the rows' block counts
+  int32_t k0[MAX_PNODES];                     // first block of each row
+  int32_t nd[MAX_PNODES];                     // node (block row) of each patch node
   int32_t ticket, ok;
 };
 
-// tables of patch p (wave 0; the caller synchronises the workgroup afterwards)
+// tables of patch p: rows (wave 0), then -- after a barrier -- every thread's blocks of the round starting at block ``base``
 template <int BS>
-__device__ __forceinline__ void mult_wg_setup(int64_t p, MultLds& S, const int64_t* __restrict__ patch_ptr,
-                                              const int32_t* __restrict__ patch_dofs, const int32_t* __restrict__ rowptr) {
+__device__ __forceinline__ void mult_wg_rows(int64_t p, MultLds& S, const int64_t* __restrict__ patch_ptr,
+                                             const int32_t* __restrict__ patch_dofs, const int32_t* __restrict__ rowptr) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  if (wave != 0) return;
   const int64_t off = patch_ptr[p];
-  const int nn = (int)(patch_ptr[p + 1] - off) / BS;
+  const int n = (int)(patch_ptr[p + 1] - off);
+  for (int i = lane; i < ((n + 1) & ~1); i += 64) S.part[wave][i] = 0.0;      // rows this wave does not touch in the apply
+  if (wave != 0) return;
+  const int nn = n / BS;
   int len = 0;
   if (lane < nn) {
     const int node = patch_dofs[off + lane * BS] / BS;
@@ -459,141 +508,133 @@ __device__ __forceinline__ void mult_wg_setup(int64_t p, MultLds& S, const int64
   }
   if (lane < nn) S.pre[lane + 1] = incl;
   if (lane == 0) S.pre[0] = 0;
-  const int total = __shfl(incl, 63);
-  ALFI_WAVE_LDS_ORDER();
-  // wave w starts at the first row whose first block is not below w * total / W
-  if (lane <= MULT_W) {
-    int r = nn;
-    if (lane < MULT_W) {
-      const int target = (int)(((int64_t)lane * total) / MULT_W);
-      int lo = 0, hi = nn;
-      while (lo < hi) {
+}
+
+__device__ __forceinline__ void mult_wg_blocks(const MultLds& S, int nn, int base, const int32_t* __restrict__ colidx,
+                                               int32_t (&kk)[MULT_MAXU], int32_t (&cc)[MULT_MAXU]) {
+  const int total = S.pre[nn];
+#pragma unroll
+  for (int u = 0; u < MULT_MAXU; ++u) {
+    const int f = base + (int)threadIdx.x + MULT_NTHR * u;
+    kk[u] = -1;
+    cc[u] = 0;
+    if (f < total) {
+      int lo = 0, hi = nn;          // row of block f: largest i with pre[i] <= f
+      while (hi - lo > 1) {
         const int mid = (lo + hi) >> 1;
-        if (S.pre[mid] >= target) hi = mid; else lo = mid + 1;
+        if (S.pre[mid] <= f) lo = mid; else hi = mid;
       }
-      r = lo;
+      kk[u] = S.k0[lo] + (f - S.pre[lo]);
     }
-    S.rb[lane] = r;
+  }
+#pragma unroll
+  for (int u = 0; u < MULT_MAXU; ++u)
+    if (kk[u] >= 0) cc[u] = colidx[kk[u]] & 0x7fffffff;
+}
+
+// products of the blocks [U0, U1) of every thread: loads together, then prod[block of the round][0 .. BS)
+template <int BS, bool NT, int U0, int U1>
+__device__ __forceinline__ void mult_wg_products(MultLds& S, const int32_t (&kk)[MULT_MAXU], const int32_t (&cc)[MULT_MAXU],
+                                                 const double* __restrict__ vals, int flat, const double* __restrict__ y) {
+  constexpr int BB = BS * BS;
+  double a_[U1 - U0][BB], yv_[U1 - U0][BS];
+#pragma unroll
+  for (int u = U0; u < U1; ++u) {
+#pragma unroll
+    for (int e = 0; e < BB; ++e) {
+      const double* v = vals + bsr_val_index(flat, kk[u] >= 0 ? kk[u] : 0, e, BB);
+      a_[u - U0][e] = kk[u] >= 0 ? (NT ? __builtin_nontemporal_load(v) : *v) : 0.0;
+    }
+  }
+#pragma unroll
+  for (int u = U0; u < U1; ++u) {
+#pragma unroll
+    for (int c = 0; c < BS; ++c) yv_[u - U0][c] = kk[u] >= 0 ? y[(int64_t)cc[u] * BS + c] : 0.0;
+  }
+#pragma unroll
+  for (int u = U0; u < U1; ++u) {
+    if (kk[u] >= 0) {
+      double* q = S.prod + ((int)threadIdx.x + MULT_NTHR * u) * BS;
+#pragma unroll
+      for (int r = 0; r < BS; ++r) {
+        double sacc = 0.0;
+#pragma unroll
+        for (int c = 0; c < BS; ++c) sacc = __builtin_fma(a_[u - U0][r * BS + c], yv_[u - U0][c], sacc);
+        q[r] = sacc;
+      }
+    }
   }
 }
 
-// r_p = x_p - (A y)_p, y_p += inv(A_p) r_p by the whole workgroup (tables in S, synchronised).
+// r_p = x_p - (A y)_p, y_p += inv(A_p) r_p by the whole workgroup; kk, cc: the blocks of round 0 (mult_wg_blocks).
 // PUBLISH (persistent schedule): the new y entries leave with agent-scope write-through stores, so that a wave on another CU /
 // XCD that acquires afterwards reads them (cdna_hip_programming.md Guideline 16, R1).
 template <int BS, bool NT, bool PUBLISH>
-__device__ __forceinline__ void mult_wg_sweep(int64_t p, MultLds& S, const int64_t* __restrict__ patch_ptr,
-                                              const int32_t* __restrict__ patch_dofs, const int64_t* __restrict__ inv_ptr,
-                                              const double* __restrict__ inv, const int32_t* __restrict__ colidx,
-                                              const double* __restrict__ vals, int flat, const double* __restrict__ x,
-                                              double* __restrict__ y) {
-  constexpr int BB = BS * BS;
+__device__ __forceinline__ void mult_wg_sweep(int64_t p, MultLds& S, int32_t (&kk)[MULT_MAXU], int32_t (&cc)[MULT_MAXU],
+                                              const int64_t* __restrict__ patch_ptr, const int32_t* __restrict__ patch_dofs,
+                                              const int64_t* __restrict__ inv_ptr, const double* __restrict__ inv,
+                                              const int32_t* __restrict__ colidx, const double* __restrict__ vals, int flat,
+                                              const double* __restrict__ x, double* __restrict__ y, int64_t* stamps = nullptr,
+                                              int32_t t = 0) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int64_t off = patch_ptr[p];
   const int n = (int)(patch_ptr[p + 1] - off);
+  const int nn = n / BS;
+  const int total = S.pre[nn];
   {
-    const int ra = S.rb[wave], rz = S.rb[wave + 1];
-    const int fbeg = S.pre[ra], fend = S.pre[rz];
-    double carry[BS];
-#pragma unroll
-    for (int r = 0; r < BS; ++r) carry[r] = 0.0;
-    // MULT_RU sub-steps of 64 blocks per pass: all their index, value and y loads are requested before the first row sum is
-    // formed; the sums and the carry then follow in the order of the sub-steps
-    for (int f0 = fbeg; f0 < fend; f0 += 64 * MULT_RU) {
-      int row_[MULT_RU];
-      bool valid_[MULT_RU], head_[MULT_RU], last_[MULT_RU];
-      int64_t k_[MULT_RU], col_[MULT_RU];
-      double a_[MULT_RU][BB], yv_[MULT_RU][BS];
-#pragma unroll
-      for (int u = 0; u < MULT_RU; ++u) {
-        const int f = f0 + 64 * u + lane;
-        valid_[u] = f < fend;
-        // row of this lane's block: largest i in the wave's range with pre[i] <= f
-        int lo = ra, hi = rz;
-        while (hi - lo > 1) {
-          const int mid = (lo + hi) >> 1;
-          if (S.pre[mid] <= f) lo = mid; else hi = mid;
-        }
-        row_[u] = lo;
-        head_[u] = valid_[u] && f == S.pre[lo];
-        last_[u] = valid_[u] && f + 1 == S.pre[lo + 1];
-        k_[u] = valid_[u] ? (int64_t)S.k0[lo] + (f - S.pre[lo]) : 0;
-        col_[u] = valid_[u] ? (int64_t)(colidx[k_[u]] & 0x7fffffff) : 0;
+    // the row entry of this thread (thread e < n: row e / BS, component e % BS) and its right-hand side
+    const int e = threadIdx.x, row = e / BS, comp = e % BS;
+    const bool mine = e < n;
+    const double xe = mine ? x[(int64_t)S.nd[mine ? row : 0] * BS + comp] : 0.0;
+    const int fa = mine ? S.pre[row] : 0, fz = mine ? S.pre[row + 1] : 0;
+    double racc = 0.0;
+    for (int base = 0; base < total; base += MULT_NTHR * MULT_MAXU) {
+      if (base > 0) {
+        __syncthreads();            // the previous round's products have been added
+        mult_wg_blocks(S, nn, base, colidx, kk, cc);
       }
+      mult_wg_products<BS, NT, 0, MULT_G0>(S, kk, cc, vals, flat, y);
+      if (base + MULT_NTHR * MULT_G0 < total) mult_wg_products<BS, NT, MULT_G0, MULT_MAXU>(S, kk, cc, vals, flat, y);
+      __syncthreads();
+      // the row's products of this round, in ascending block order
+      const int f0 = max(fa, base) - base, f1 = min(fz, base + MULT_NTHR * MULT_MAXU) - base;
+      const double* q = S.prod + comp;
+      int f = f0;
+      for (; f + 8 <= f1; f += 8) {
+        double v[8];
 #pragma unroll
-      for (int u = 0; u < MULT_RU; ++u) {
+        for (int u = 0; u < 8; ++u) v[u] = q[(f + u) * BS];
 #pragma unroll
-        for (int e = 0; e < BB; ++e) {
-          const double* v = vals + bsr_val_index(flat, k_[u], e, BB);
-          a_[u][e] = valid_[u] ? (NT ? __builtin_nontemporal_load(v) : *v) : 0.0;
-        }
+        for (int u = 0; u < 8; ++u) racc += v[u];
       }
-#pragma unroll
-      for (int u = 0; u < MULT_RU; ++u) {
-#pragma unroll
-        for (int c = 0; c < BS; ++c) yv_[u][c] = valid_[u] ? y[col_[u] * BS + c] : 0.0;
-      }
-#pragma unroll
-      for (int u = 0; u < MULT_RU; ++u) {
-        if (f0 + 64 * u >= fend) break;          // wave-uniform
-        const int row = row_[u];
-        const bool head = head_[u], last = last_[u];
-        double s[BS];
-#pragma unroll
-        for (int r = 0; r < BS; ++r) s[r] = 0.0;
-        if (valid_[u]) {
-#pragma unroll
-          for (int r = 0; r < BS; ++r)
-#pragma unroll
-            for (int c = 0; c < BS; ++c) s[r] = __builtin_fma(a_[u][r * BS + c], yv_[u][c], s[r]);
-        }
-        int fl = head ? 1 : 0;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-          double tp[BS];
-#pragma unroll
-          for (int r = 0; r < BS; ++r) tp[r] = __shfl_up(s[r], d);
-          const int tf = __shfl_up(fl, d);
-          if (lane >= d && !fl) {
-#pragma unroll
-            for (int r = 0; r < BS; ++r) s[r] += tp[r];
-            fl = tf;
-          }
-        }
-        if (!fl) {
-#pragma unroll
-          for (int r = 0; r < BS; ++r) s[r] += carry[r];
-        }
-        if (last) {
-#pragma unroll
-          for (int r = 0; r < BS; ++r) S.rs[row * BS + r] = x[(int64_t)S.nd[row] * BS + r] - s[r];
-        }
-        // a row running on into the next 64 blocks is carried; a row closed at lane 63 is not
-        const int last63 = __shfl(last ? 1 : 0, 63);
-#pragma unroll
-        for (int r = 0; r < BS; ++r) {
-          const double c63 = __shfl(s[r], 63);
-          carry[r] = last63 ? 0.0 : c63;
-        }
-      }
+      for (; f < f1; ++f) racc += q[f * BS];
     }
+    if (mine) S.rs[e] = xe - racc;
   }
   __syncthreads();
+  ALFI_MULT_STAMP(3);
   {
     const int ld = (n + 1) & ~1;
     const double* T = inv + inv_ptr[p];
-    const int ca = (int)(((int64_t)wave * n) / MULT_W), cn = (int)(((int64_t)(wave + 1) * n) / MULT_W) - ca;
-    const double* xs = S.rs + ca;
     double* out = S.part[wave];
     int row0 = 0;
+    // pieces of >= 64 rows: column shares
+    const int ca = (int)(((int64_t)wave * n) / MULT_W), cn = (int)(((int64_t)(wave + 1) * n) / MULT_W) - ca;
     for (; row0 + 128 <= ld; row0 += 128)
-      apply_piece<64, NT, MULT_U>(T + (int64_t)row0 * n + (int64_t)ca * 128, cn, xs, lane, out + row0);
+      apply_piece<64, NT, MULT_U>(T + (int64_t)row0 * n + (int64_t)ca * 128, cn, S.rs + ca, lane, out + row0);
     const int rem = ld - row0;
-#define ALFI_PIECE(R)                                                                                       \
-  if (rem & R) {                                                                                            \
-    apply_piece<R / 2, NT, MULT_U>(T + (int64_t)row0 * n + (int64_t)ca * R, cn, xs, lane, out + row0);      \
-    row0 += R;                                                                                              \
+    if (rem & 64) {
+      apply_piece<32, NT, MULT_U>(T + (int64_t)row0 * n + (int64_t)ca * 64, cn, S.rs + ca, lane, out + row0);
+      row0 += 64;
+    }
+    // smaller pieces: a wave each, all columns
+    int piece = 0;
+#define ALFI_PIECE(R)                                                                    \
+  if (rem & R) {                                                                         \
+    if (piece % MULT_W == wave) apply_piece<R / 2, NT, MULT_U>(T + (int64_t)row0 * n, n, S.rs, lane, out + row0); \
+    row0 += R;                                                                           \
+    ++piece;                                                                             \
   }
-    ALFI_PIECE(64)
     ALFI_PIECE(32)
     ALFI_PIECE(16)
     ALFI_PIECE(8)
@@ -602,7 +643,8 @@ __device__ __forceinline__ void mult_wg_sweep(int64_t p, MultLds& S, const int64
 #undef ALFI_PIECE
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < n; i += 64 * MULT_W) {
+  ALFI_MULT_STAMP(4);
+  for (int i = threadIdx.x; i < n; i += MULT_NTHR) {
     const int64_t dof = patch_dofs[off + i];
     double d = S.part[0][i];
 #pragma unroll
@@ -617,20 +659,22 @@ __device__ __forceinline__ void mult_wg_sweep(int64_t p, MultLds& S, const int64
 
 // one dependency wavefront per launch, a workgroup per patch
 template <int BS, bool NT>
-__global__ __launch_bounds__(64 * MULT_W) void patch_mult_kernel(int64_t count, const int32_t* __restrict__ seq,
-                                                                  const int64_t* __restrict__ patch_ptr,
-                                                                  const int32_t* __restrict__ patch_dofs,
-                                                                  const int64_t* __restrict__ inv_ptr,
-                                                                  const double* __restrict__ inv,
-                                                                  const int32_t* __restrict__ rowptr,
-                                                                  const int32_t* __restrict__ colidx,
-                                                                  const double* __restrict__ vals, int flat,
-                                                                  const double* __restrict__ x, double* __restrict__ y) {
+__global__ __launch_bounds__(MULT_NTHR) ALFI_MULT_OCC_ATTR void patch_mult_kernel(int64_t count, const int32_t* __restrict__ seq,
+                                                               const int64_t* __restrict__ patch_ptr,
+                                                               const int32_t* __restrict__ patch_dofs,
+                                                               const int64_t* __restrict__ inv_ptr,
+                                                               const double* __restrict__ inv,
+                                                               const int32_t* __restrict__ rowptr,
+                                                               const int32_t* __restrict__ colidx,
+                                                               const double* __restrict__ vals, int flat,
+                                                               const double* __restrict__ x, double* __restrict__ y) {
   __shared__ MultLds S;
   const int64_t p = seq[blockIdx.x];
-  mult_wg_setup<BS>(p, S, patch_ptr, patch_dofs, rowptr);
+  mult_wg_rows<BS>(p, S, patch_ptr, patch_dofs, rowptr);
   __syncthreads();
-  mult_wg_sweep<BS, NT, false>(p, S, patch_ptr, patch_dofs, inv_ptr, inv, colidx, vals, flat, x, y);
+  int32_t kk[MULT_MAXU], cc[MULT_MAXU];
+  mult_wg_blocks(S, (int)(patch_ptr[p + 1] - patch_ptr[p]) / BS, 0, colidx, kk, cc);
+  mult_wg_sweep<BS, NT, false>(p, S, kk, cc, patch_ptr, patch_dofs, inv_ptr, inv, colidx, vals, flat, x, y);
 }
 
 // The whole sweep (both directions of a symmetrised one) as ONE launch of a resident grid: workgroups draw the items of the
@@ -646,20 +690,26 @@ __global__ __launch_bounds__(64 * MULT_W) void patch_mult_kernel(int64_t count, 
 // every wave does ONE agent-scope acquire, then plain loads.
 // err[0]: set when a wait ran into its bound (a broken schedule would otherwise spin until the watchdog).
 template <int BS, bool NT>
-__global__ __launch_bounds__(64 * MULT_W) void patch_mult_persistent_kernel(
+__global__ __launch_bounds__(MULT_NTHR) ALFI_MULT_OCC_ATTR void patch_mult_persistent_kernel(
     int32_t nitems, const int32_t* __restrict__ items, int32_t* __restrict__ pred, const int32_t* __restrict__ succ_ptr,
     const int32_t* __restrict__ succ, int32_t* __restrict__ head, int32_t* __restrict__ err,
     const int64_t* __restrict__ patch_ptr, const int32_t* __restrict__ patch_dofs, const int64_t* __restrict__ inv_ptr,
     const double* __restrict__ inv, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colidx,
-    const double* __restrict__ vals, int flat, const double* __restrict__ x, double* __restrict__ y) {
+    const double* __restrict__ vals, int flat, const double* __restrict__ x, double* __restrict__ y ALFI_MULT_STAMP_PARAM) {
   __shared__ MultLds S;
   for (;;) {
     if (threadIdx.x == 0) S.ticket = __hip_atomic_fetch_add(head, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
     const int32_t t = S.ticket;
     if (t >= nitems) break;
+    ALFI_MULT_STAMP(0);
     const int64_t p = items[t];
-    mult_wg_setup<BS>(p, S, patch_ptr, patch_dofs, rowptr);      // nothing of this depends on y
+    // nothing of the tables depends on y
+    mult_wg_rows<BS>(p, S, patch_ptr, patch_dofs, rowptr);
+    __syncthreads();
+    int32_t kk[MULT_MAXU], cc[MULT_MAXU];
+    mult_wg_blocks(S, (int)(patch_ptr[p + 1] - patch_ptr[p]) / BS, 0, colidx, kk, cc);
+    ALFI_MULT_STAMP(1);
     // wait for the predecessors: ONE lane polls ONE word, relaxed
     if (threadIdx.x == 0) {
       int ok = 1;
@@ -678,12 +728,15 @@ __global__ __launch_bounds__(64 * MULT_W) void patch_mult_persistent_kernel(
       if (threadIdx.x == 0) __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       break;
     }
+    ALFI_MULT_STAMP(2);
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");          // this CU's L1 forgets what other CUs have rewritten
-    mult_wg_sweep<BS, NT, true>(p, S, patch_ptr, patch_dofs, inv_ptr, inv, colidx, vals, flat, x, y);
+    mult_wg_sweep<BS, NT, true>(p, S, kk, cc, patch_ptr, patch_dofs, inv_ptr, inv, colidx, vals, flat, x, y ALFI_MULT_STAMP_ARG);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // this wave's y stores have left
     __syncthreads();                                            // ... and those of the other waves
-    for (int32_t e = succ_ptr[t] + threadIdx.x; e < succ_ptr[t + 1]; e += 64 * MULT_W)
+    ALFI_MULT_STAMP(5);
+    for (int32_t e = succ_ptr[t] + threadIdx.x; e < succ_ptr[t + 1]; e += MULT_NTHR)
       __hip_atomic_fetch_sub(pred + succ[e], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    ALFI_MULT_STAMP(6);
   }
 }
 
@@ -777,9 +830,8 @@ int launch_patch_apply_arrays(alfi_ctx* ctx, int64_t npatch, const int64_t* patc
                               const int64_t* inv_ptr, const int64_t* stage_ptr, const double* inv, const double* x,
                               double* stage) {
   if (npatch == 0) return 0;
-  dim3 grid((unsigned)((npatch + 3) / 4)), block(256);
-  hipLaunchKernelGGL(patch_apply_kernel<true>, grid, block, 0, ctx->stream, (int64_t)0, npatch, patch_ptr, patch_dofs,
-                     inv_ptr, stage_ptr, inv, x, stage);
+  hipLaunchKernelGGL((patch_apply_kernel<true, APPLY_W>), dim3((unsigned)npatch), dim3(64 * APPLY_W), 0, ctx->stream, (int64_t)0,
+                     npatch, patch_ptr, patch_dofs, inv_ptr, stage_ptr, inv, x, stage);
   ALFI_HIP_CHECK(ctx, hipGetLastError());
   return 0;
 }
@@ -788,7 +840,7 @@ int launch_patch_mult_wave(alfi_level* L, const int32_t* seq, int64_t count, con
   alfi_ctx* ctx = L->ctx;
   if (count == 0) return 0;
   if (L->mult_big) return launch_big_mult_wave(L, seq, count, x, y);
-  dim3 grid((unsigned)count), block(64 * MULT_W);
+  dim3 grid((unsigned)count), block(MULT_NTHR);
 #define ALFI_MULT(BSV, NTV)                                                                                           \
   hipLaunchKernelGGL((patch_mult_kernel<BSV, NTV>), grid, block, 0, ctx->stream, count, seq, L->patch_ptr,            \
                      L->patch_dofs, L->inv_ptr, L->inv, L->A.rowptr, L->A.colidx, L->A.vals, L->A.flat, x, y)
@@ -803,6 +855,17 @@ int launch_patch_mult_wave(alfi_level* L, const int32_t* seq, int64_t count, con
   ALFI_HIP_CHECK(ctx, hipGetLastError());
   return 0;
 }
+
+#ifdef ALFI_MULT_TIMING
+static int64_t* g_mult_stamps = nullptr;
+static int64_t g_mult_stamps_n = 0;
+extern "C" int64_t alfi_debug_mult_stamps(int64_t* out, int64_t nitems) {
+  if (!g_mult_stamps || nitems > g_mult_stamps_n) return -1;
+  if (hipDeviceSynchronize() != hipSuccess) return -2;
+  if (hipMemcpy(out, g_mult_stamps, sizeof(int64_t) * 8 * (size_t)nitems, hipMemcpyDeviceToHost) != hipSuccess) return -3;
+  return nitems;
+}
+#endif
 
 int launch_patch_mult_persistent(alfi_level* L, const double* x, double* y) {
   alfi_ctx* ctx = L->ctx;
@@ -819,20 +882,31 @@ int launch_patch_mult_persistent(alfi_level* L, const double* x, double* y) {
     ALFI_HIP_CHECK(ctx, hipGetDeviceProperties(&prop, ctx->device));
     const auto k2 = &patch_mult_persistent_kernel<2, true>;
     const auto k3 = &patch_mult_persistent_kernel<3, true>;
-    ALFI_HIP_CHECK(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu[0], k2, 64 * MULT_W, 0));
-    ALFI_HIP_CHECK(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu[1], k3, 64 * MULT_W, 0));
+    ALFI_HIP_CHECK(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu[0], k2, MULT_NTHR, 0));
+    ALFI_HIP_CHECK(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu[1], k3, MULT_NTHR, 0));
     ncu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 64;
   }
   const int pc = std::max(1, std::min(per_cu[L->bs == 3 ? 1 : 0], ALFI_MULT_WG_PER_CU));
-  dim3 grid((unsigned)std::min<int64_t>(L->mult_nitems, (int64_t)ncu * pc)), block(64 * MULT_W);
+  dim3 grid((unsigned)std::min<int64_t>(L->mult_nitems, (int64_t)ncu * pc)), block(MULT_NTHR);
+#ifdef ALFI_MULT_TIMING
+  if (g_mult_stamps_n < L->mult_nitems) {
+    if (g_mult_stamps) (void)hipFree(g_mult_stamps);
+    ALFI_HIP_CHECK(ctx, hipMalloc(&g_mult_stamps, sizeof(int64_t) * 8 * (size_t)L->mult_nitems));
+    g_mult_stamps_n = L->mult_nitems;
+  }
+#define ALFI_PMULT_STAMPS , g_mult_stamps
+#else
+#define ALFI_PMULT_STAMPS
+#endif
 #define ALFI_PMULT(BSV)                                                                                                   \
   hipLaunchKernelGGL((patch_mult_persistent_kernel<BSV, true>), grid, block, 0, ctx->stream, L->mult_nitems, L->mult_items, \
                      L->mult_pred, L->mult_succ_ptr, L->mult_succ, L->mult_ctl, ctx->dev_err, L->patch_ptr,               \
-                     L->patch_dofs, L->inv_ptr, L->inv, L->A.rowptr, L->A.colidx, L->A.vals, L->A.flat, x, y)
+                     L->patch_dofs, L->inv_ptr, L->inv, L->A.rowptr, L->A.colidx, L->A.vals, L->A.flat, x, y ALFI_PMULT_STAMPS)
   if (L->bs == 2) ALFI_PMULT(2);
   else if (L->bs == 3) ALFI_PMULT(3);
   else return alfi_set_error(ctx, ALFI_E_ARG, "unsupported block size %d", L->bs);
 #undef ALFI_PMULT
+#undef ALFI_PMULT_STAMPS
   ALFI_HIP_CHECK(ctx, hipGetLastError());
   return 0;
 }
@@ -876,8 +950,15 @@ int launch_patch_apply_range(alfi_level* L, int64_t p0, int64_t p1, const double
     }
 #undef ALFI_IL
   } else {
-    hipLaunchKernelGGL(patch_apply_kernel<true>, grid, block, 0, ctx->stream, p0, p1, L->patch_ptr, L->patch_dofs,
-                       L->inv_ptr, L->stage_ptr, L->inv, x, L->stage);
+    if (L->max_np > 128)
+      hipLaunchKernelGGL((patch_apply_kernel<true, 2 * APPLY_W>), dim3((unsigned)cnt), dim3(128 * APPLY_W), 0, ctx->stream, p0,
+                         p1, L->patch_ptr, L->patch_dofs, L->inv_ptr, L->stage_ptr, L->inv, x, L->stage);
+    else if (L->max_np > 64)
+      hipLaunchKernelGGL((patch_apply_kernel<true, APPLY_W>), dim3((unsigned)cnt), dim3(64 * APPLY_W), 0, ctx->stream, p0, p1,
+                         L->patch_ptr, L->patch_dofs, L->inv_ptr, L->stage_ptr, L->inv, x, L->stage);
+    else
+      hipLaunchKernelGGL((patch_apply_kernel<true, 1>), dim3((unsigned)cnt), dim3(64), 0, ctx->stream, p0, p1, L->patch_ptr,
+                         L->patch_dofs, L->inv_ptr, L->stage_ptr, L->inv, x, L->stage);
   }
   ALFI_HIP_CHECK(ctx, hipGetLastError());
   alfi_prof_end(ctx, t);
