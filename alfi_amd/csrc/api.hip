@@ -1251,7 +1251,7 @@ int alfi_patches_set_groups(alfi_level* L, const int32_t* group) {
     int lds_front = 0, lds_back = 0;
     for (int64_t p = 0; p < npatch; ++p) {
       const int s = (int)(sptr[p + 1] - sptr[p]), ld = (s + 1) & ~1;
-      for (int r = 0; r < ld; r += 256) {
+      for (int r = 0; r < ld; r += COND_SIGMA_ROWS) {
         ch_patch.push_back((int32_t)p);
         ch_row.push_back(r);
       }
@@ -1293,38 +1293,15 @@ int alfi_patches_set_groups(alfi_level* L, const int32_t* group) {
     ALFI_CHECK(cond_upload(L, &cd.bp_ptr, bp_ptr));
     ALFI_CHECK(cond_upload(L, &cd.bp_grp, bp_grp));
     ALFI_CHECK(cond_upload(L, &cd.g_bp, g_bp));
-    // (only where the chunked form is used: levels with fewer than 1024 patches -- the descriptors are 80 KB per large
-    // macro star)
-    if (npatch < 1024 || alfi_test_large_paths()) {
-      // chunks of consecutive groups: at most 256 row pairs of X / W and of B each, with the descriptors of the chunks and of
-      // every row pair (CondChunk / CondXPair / CondBPair, common.h)
+    {
+      // chunks of consecutive groups: at most 256 row pairs of X / W and of B each (a lane per pair), one descriptor per chunk
+      // (CondChunk, common.h)
       std::vector<CondChunk> gc;
-      std::vector<CondXPair> xpd((size_t)xp_ptr[npatch]);
-      std::vector<CondBPair> bpd((size_t)bp_ptr[npatch]);
       std::vector<int64_t> gcptr((size_t)npatch + 1, 0), stage_off((size_t)npatch + 1, 0);
       for (int64_t p = 0; p < npatch; ++p)          // the staging layout of alfi_patches_set: ld_p = n_p rounded up to even
         stage_off[p + 1] = stage_off[p] + ((pp[p + 1] - pp[p] + 1) & ~(int64_t)1);
       int lds_gf = 0, lds_gb = 0;
       for (int64_t p = 0; p < npatch; ++p) {
-        for (int64_t g = gptr[p]; g < gptr[p + 1]; ++g) {
-          const int m = g_m[g], sc = g_sc[g], ldm = cond_ldim(m), ldsc = cond_ldim(sc);
-          for (int q = 0; q < cond_pairs(m); ++q) {
-            CondXPair& d = xpd[(size_t)(xp_ptr[p] + g_xp[g] + q)];
-            d.xoff = g_mat[g] + 2 * q;
-            d.woff = g_mat[g] + (int64_t)ldm * m + (int64_t)ldsc * m + 2 * q;
-            d.ld = ldm; d.m = m; d.sc = sc; d.o = g_off[g]; d.uo = g_uoff[g]; d.i = 2 * q;
-            d.sl0 = c_slot[pp[p] + g_off[g] + 2 * q];
-            d.sl1 = 2 * q + 1 < m ? c_slot[pp[p] + g_off[g] + 2 * q + 1] : -1;
-          }
-          for (int q = 0; q < cond_pairs(sc); ++q) {
-            CondBPair& d = bpd[(size_t)(bp_ptr[p] + g_bp[g] + q)];
-            d.boff = g_mat[g] + (int64_t)ldm * m + 2 * q;
-            d.ld = ldsc; d.m = m; d.o = g_off[g];
-            d.d0 = u_dst[(size_t)(uptr[p] + g_uoff[g] + 2 * q)];
-            d.d1 = 2 * q + 1 < sc ? u_dst[(size_t)(uptr[p] + g_uoff[g] + 2 * q + 1)] : -1;
-            d.pad = 0;
-          }
-        }
         int64_t g = gptr[p];
         while (g < gptr[p + 1]) {
           CondChunk c;
@@ -1341,6 +1318,7 @@ int alfi_patches_set_groups(alfi_level* L, const int32_t* group) {
           c.xq0 = (int32_t)(xp_ptr[p] + g_xp[ga]); c.xq1 = c.xq0 + xp;
           c.bq0 = (int32_t)(bp_ptr[p] + g_bp[ga]); c.bq1 = c.bq0 + bp;
           c.e0 = g_off[ga]; c.ne = ne; c.u0 = g_uoff[ga]; c.nu = nu; c.nI = p_nI[p]; c.pad = 0;
+          c.xp0 = (int32_t)xp_ptr[p]; c.bp0 = (int32_t)bp_ptr[p];
           gc.push_back(c);
           lds_gf = std::max(lds_gf, (int)(2 * ne * sizeof(double)));
           lds_gb = std::max(lds_gb, (int)(nu * sizeof(double)));
@@ -1350,11 +1328,7 @@ int alfi_patches_set_groups(alfi_level* L, const int32_t* group) {
       if (xp_ptr[npatch] > INT32_MAX || bp_ptr[npatch] > INT32_MAX)
         return alfi_set_error(ctx, ALFI_E_ARG, "condensed factors: too many row pairs on one level");
       if (gc.empty()) gc.push_back(CondChunk());
-      xpd.push_back(CondXPair());                   // one entry past the end: lanes without a pair read descriptor [q0]
-      bpd.push_back(CondBPair());
       ALFI_CHECK(cond_upload(L, &cd.gc, gc));
-      ALFI_CHECK(cond_upload(L, &cd.xpd, xpd));
-      ALFI_CHECK(cond_upload(L, &cd.bpd, bpd));
       L->h_cond_gcptr = gcptr;
       L->cond_lds_gfront = lds_gf + 16;
       L->cond_lds_gback = lds_gb + 16;

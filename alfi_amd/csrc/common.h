@@ -211,11 +211,10 @@ struct CondDev {
   const int32_t* bp_grp = nullptr;
   const int32_t* g_bp = nullptr;
   // chunks of consecutive groups of one patch (<= 256 row pairs of X / W and of B): the work units of cond_gfront / cond_gback.
-  // Everything a workgroup / a lane needs is in ONE descriptor each (a chain patch -> groups -> group data of dependent
-  // loads in front of the first matrix byte is what bounds these short workgroups).
+  // One descriptor per workgroup (CondChunk); a lane decodes its row pair from the per-pair group index and the group arrays
+  // (cond_xpair / cond_bpair, kernels_bigpatch.hip).  Round 3 stored a 48 / 32-byte descriptor per LANE: 8 % more bytes than
+  // the factors themselves on config 5's finest level.
   const struct CondChunk* gc = nullptr;   // (nchunk)
-  const struct CondXPair* xpd = nullptr;  // per row pair of X / W, patch after patch (the order of xp_grp)
-  const struct CondBPair* bpd = nullptr;  // per row pair of B
   double* ubuf = nullptr;             // (sum of the u buffer lengths) u_g = B_g t_g in the row-sorted order of u_dst
 };
 struct CondChunk {
@@ -227,8 +226,11 @@ struct CondChunk {
   int32_t bq0, bq1;   // the chunk's B row pairs in bpd
   int32_t e0, ne;     // its interior entries (adjacent in the condensed order)
   int32_t u0, nu;     // its entries of the patch's u layout
-  int32_t nI, pad;
+  int32_t nI;
+  int32_t xp0, bp0;   // first row pair of the PATCH in the X / W and in the B numbering (a pair's place inside its group)
+  int32_t pad;
 };
+// what a lane needs of its row pair (decoded in the kernel, never stored)
 struct CondXPair {
   int64_t xoff, woff; // the pair's rows in X and in W (offsets into CondDev::mat)
   int32_t ld, m, sc;  // leading dimension of X / W, columns of X (= group size), columns of W
@@ -241,6 +243,13 @@ struct CondBPair {
   int32_t d0, d1;     // places of the two results in the row-sorted u buffer (-1: the row does not exist)
   int32_t pad;
 };
+
+// rows of inv(Sigma) per workgroup of the sigma kernels of the condensed apply (4 waves; kernels_bigpatch.hip, chunk table in
+// alfi_patches_set_groups)
+#ifndef ALFI_COND_SIGMA_ROWS
+#define ALFI_COND_SIGMA_ROWS 64
+#endif
+constexpr int COND_SIGMA_ROWS = ALFI_COND_SIGMA_ROWS;
 
 // storage of one group's matrices in CondDev::mat: [X (m x m) | B (sc x m) | W (m x sc)], column-major each, the leading
 // dimensions rounded up to EVEN (a lane streams two rows of a column with one 16-byte load; the pad row is never stored)

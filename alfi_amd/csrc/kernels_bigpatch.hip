@@ -1119,7 +1119,6 @@ __global__ __launch_bounds__(64 * COND_WAVES) void cond_front_kernel(int64_t p0,
   }
 }
 
-constexpr int COND_SIGMA_ROWS = 256;      // rows of inv(Sigma) per workgroup of the sigma kernel (4 waves)
 template <bool NT>
 __global__ __launch_bounds__(256) void cond_sigma_kernel(int64_t c0, CondDev cd, const int64_t* __restrict__ patch_ptr,
                                                          const int64_t* __restrict__ stage_ptr,
@@ -1229,6 +1228,44 @@ __device__ __forceinline__ void cond_row2_finish(const double* __restrict__ M, i
   cond_row2_dot<NT, COND_U>(M + (int64_t)COND_U * ld, ld, rest, v + COND_U, acc0, acc1);
 }
 
+// a lane's row pair of X / W (q: its number in the level's xp_grp order), decoded from the group arrays
+__device__ __forceinline__ CondXPair cond_xpair(const CondDev& cd, const CondChunk& c, int32_t q, bool act) {
+  CondXPair d = {0, 0, 2, 0, 0, 0, 0, 0, -1, -1};
+  if (!act) return d;      // a lane without a pair: nothing is read through this descriptor
+  const int32_t g = cd.xp_grp[q];
+  const int m = cd.g_m[g], sc = cd.g_sc[g], o = cd.g_off[g];
+  const int i = 2 * (q - c.xp0 - cd.g_xp[g]);
+  const int64_t mat = cd.g_mat[g];
+  d.ld = cond_ldim(m);
+  d.m = m;
+  d.sc = sc;
+  d.o = o;
+  d.uo = cd.g_uoff[g];
+  d.i = i;
+  d.xoff = mat + i;
+  d.woff = mat + (int64_t)d.ld * m + (int64_t)cond_ldim(sc) * m + i;
+  d.sl0 = cd.slot[c.off + o + i];
+  d.sl1 = i + 1 < m ? cd.slot[c.off + o + i + 1] : -1;
+  return d;
+}
+// ... and of B
+__device__ __forceinline__ CondBPair cond_bpair(const CondDev& cd, const CondChunk& c, int32_t q, bool act) {
+  CondBPair d = {0, 2, 0, 0, -1, -1, 0};
+  if (!act) return d;
+  const int32_t g = cd.bp_grp[q];
+  const int m = cd.g_m[g], sc = cd.g_sc[g];
+  const int j = 2 * (q - c.bp0 - cd.g_bp[g]);
+  const int64_t ue = c.ubase + cd.g_uoff[g] + j;
+  d.boff = cd.g_mat[g] + (int64_t)cond_ldim(m) * m + j;
+  d.ld = cond_ldim(sc);
+  d.m = m;
+  d.o = cd.g_off[g];
+  d.d0 = cd.u_dst[ue];
+  d.d1 = j + 1 < sc ? cd.u_dst[ue + 1] : -1;
+  d.pad = 0;
+  return d;
+}
+
 template <bool NT>
 __global__ __launch_bounds__(256) void cond_gfront_kernel(int64_t k0, CondDev cd, const double* __restrict__ x) {
   extern __shared__ double cond_dsmem[];
@@ -1237,9 +1274,9 @@ __global__ __launch_bounds__(256) void cond_gfront_kernel(int64_t k0, CondDev cd
   double* ts = xs + c.ne;                            // c.ne
   const int tid = threadIdx.x;
   const bool xact = c.xq0 + tid < c.xq1, bact = c.bq0 + tid < c.bq1;
-  // one descriptor per lane and phase, requested together with the gather of x
-  const CondXPair xd = cd.xpd[xact ? c.xq0 + tid : c.xq0];
-  const CondBPair bd = cd.bpd[bact ? c.bq0 + tid : c.bq0];
+  // the lane's row pairs of the two phases, decoded while the gather of x is under way
+  const CondXPair xd = cond_xpair(cd, c, c.xq0 + tid, xact);
+  const CondBPair bd = cond_bpair(cd, c, c.bq0 + tid, bact);
   for (int i = tid; i < c.ne; i += 256) xs[i] = x[cd.dofs[c.off + c.e0 + i]];
   // the first columns of both products do not depend on anything computed here
   big_d2 xa[COND_U], ba[COND_U];
@@ -1321,7 +1358,7 @@ __global__ __launch_bounds__(256) void cond_gback_kernel(int64_t k0, CondDev cd,
   const CondChunk c = cd.gc[k0 + blockIdx.x];
   const int tid = threadIdx.x;
   const bool act = c.xq0 + tid < c.xq1;
-  const CondXPair xd = cd.xpd[act ? c.xq0 + tid : c.xq0];
+  const CondXPair xd = cond_xpair(cd, c, c.xq0 + tid, act);
   const double* tmp = cd.tmp + c.off;
   // y_S[S_g] of the chunk's groups (adjacent in sidx and in the u layout)
   const int32_t* si = cd.sidx + c.sidx0;
@@ -1619,11 +1656,15 @@ int launch_cond_schur_one(alfi_level* L, int64_t p, const int64_t* d_zero, doubl
 }
 
 // One condensed apply = three launches (front / sigma / back).  Two forms of the group products:
-//   * launches of fewer than 1024 patches (the lower levels: config 5's level 1 has 303 stars): chunks of <= 8 consecutive
-//     groups per workgroup, one descriptor per workgroup and per lane, the Schur right-hand side formed by the sigma
-//     workgroups (cond_gfront / cond_gsigma / cond_gback): front + back 48 -> 39 us there;
-//   * larger launches (the finest levels): a workgroup of 8 waves per patch (cond_front / cond_sigma / cond_back): 326 against
-//     338 us on config 5's finest level -- the chunk descriptors are 8 % more bytes.
+//   * launches of fewer than 1024 patches (the lower levels: config 5's level 1 has 303 stars; ranges of an overlapped exchange):
+//     chunks of <= 8 consecutive groups per workgroup, one descriptor per workgroup, a lane's row pair decoded in the kernel, the
+//     Schur right-hand side formed by the sigma workgroups (cond_gfront / cond_gsigma / cond_gback): front + back 48 -> 39 us
+//     against a workgroup per patch there;
+//   * larger launches (the finest levels): a workgroup of 8 waves per patch (cond_front / cond_sigma / cond_back).  The chunked
+//     form on config 5's finest level, same box: 25.1 against 24.6 ms per cycle (round 4, with the decoded descriptors; round
+//     3 with a descriptor per lane: 338 against 326 us).
+// The sigma launch takes chunks of <= 64 rows (COND_SIGMA_ROWS; 256 in round 3: config 5 24.8 -> 24.1 ms per cycle, the apply
+// from 0.70 to 0.73 of the HBM roofline, profiles/r04_ab_cond_cfg5.txt).
 // Measured and dropped (rounds 2-3, profiles/r03_cond_apply_ab_cfg5.txt): the whole apply as ONE launch per patch (941 against
 // 860 us on config 5's finest level), 4 or 16 waves per patch on large launches, 16 columns in flight per lane, nontemporal
 // loads for the group matrices (a column of 45 doubles shares its first and last line with its neighbours: 218 against 208 us).
@@ -1636,10 +1677,10 @@ int launch_cond_apply_range(alfi_level* L, int64_t p0, int64_t p1, const double*
   // config 5's size the big patches must not come last); range launches (overlapped exchanges) keep the natural order
   const int ordered = p0 == 0 && p1 == L->npatch && L->cd.order ? 1 : 0;
   const int64_t c0 = L->h_cond_chptr[p0], c1 = L->h_cond_chptr[p1];
-  if (p1 - p0 < 1024 && L->cd.ubuf) {
+  if (p1 - p0 < 1024) {
     const int64_t k0 = L->h_cond_gcptr[p0], k1 = L->h_cond_gcptr[p1];
     const size_t lds_f = (size_t)L->cond_lds_gfront, lds_b = (size_t)L->cond_lds_gback;
-    const size_t lds_s = (size_t)(L->cond_max_s + 2 + 256) * sizeof(double);
+    const size_t lds_s = (size_t)(L->cond_max_s + 2 + COND_SIGMA_ROWS) * sizeof(double);
     if (k1 > k0)
       hipLaunchKernelGGL((cond_gfront_kernel<false>), dim3((unsigned)(k1 - k0)), dim3(256), lds_f, ctx->stream, k0, L->cd, x);
     if (c1 > c0)
@@ -1669,9 +1710,7 @@ int launch_cond_apply_range(alfi_level* L, int64_t p0, int64_t p1, const double*
     hipLaunchKernelGGL((cond_back_kernel<false, WV, 8>), dim3(grid.x), dim3(64 * WV), lds_b, ctx->stream, p0, p1, L->cd,  \
                        L->patch_ptr, L->stage_ptr, L->stage, ordered);                                                    \
   } while (0)
-  // (a range of fewer than 1024 patches of a level WITHOUT chunk descriptors -- an overlapped exchange on a large level --
-  // takes 16 waves per patch: 303 patches, front + back 69 -> 58 us)
-  if (p1 - p0 < 1024) ALFI_COND_LAUNCH3(16); else ALFI_COND_LAUNCH3(8);
+  ALFI_COND_LAUNCH3(8);
 #undef ALFI_COND_LAUNCH3
   ALFI_HIP_CHECK(ctx, hipGetLastError());
   return 0;

@@ -58,23 +58,33 @@ struct Lu4 {
   double s01, s02, s03, s12, s13, s23;        // U_ut / U_uu: the scaled pivot rows inside the block
 };
 
+// 1 / u by the hardware estimate and two Newton steps (five dependent instructions; the IEEE division the compiler emits for
+// 1.0 / u is a chain of twelve with two quarter-rate ones, four times per block step on the critical path of all eight waves).
+// Not correctly rounded (<= 1 ulp): the factors stay consistent because every use takes this same value.
+__device__ __forceinline__ double inv_rcp(double u) {
+  double r = __builtin_amdgcn_rcp(u);
+  r = __builtin_fma(__builtin_fma(-u, r, 1.0), r, r);
+  r = __builtin_fma(__builtin_fma(-u, r, 1.0), r, r);
+  return r;
+}
+
 __device__ __forceinline__ void lu4(const double (&d)[4][4], Lu4& f, bool& bad) {
   const double u00 = d[0][0];
-  f.i0 = 1.0 / u00;
+  f.i0 = inv_rcp(u00);
   f.u01 = d[0][1]; f.u02 = d[0][2]; f.u03 = d[0][3];
   f.l10 = d[1][0] * f.i0; f.l20 = d[2][0] * f.i0; f.l30 = d[3][0] * f.i0;
   const double u11 = __builtin_fma(-f.l10, f.u01, d[1][1]);
   f.u12 = __builtin_fma(-f.l10, f.u02, d[1][2]);
   f.u13 = __builtin_fma(-f.l10, f.u03, d[1][3]);
-  f.i1 = 1.0 / u11;
+  f.i1 = inv_rcp(u11);
   f.l21 = __builtin_fma(-f.l20, f.u01, d[2][1]) * f.i1;
   f.l31 = __builtin_fma(-f.l30, f.u01, d[3][1]) * f.i1;
   const double u22 = __builtin_fma(-f.l21, f.u12, __builtin_fma(-f.l20, f.u02, d[2][2]));
   f.u23 = __builtin_fma(-f.l21, f.u13, __builtin_fma(-f.l20, f.u03, d[2][3]));
-  f.i2 = 1.0 / u22;
+  f.i2 = inv_rcp(u22);
   f.l32 = __builtin_fma(-f.l31, f.u12, __builtin_fma(-f.l30, f.u02, d[3][2])) * f.i2;
   const double u33 = __builtin_fma(-f.l32, f.u23, __builtin_fma(-f.l31, f.u13, __builtin_fma(-f.l30, f.u03, d[3][3])));
-  f.i3 = 1.0 / u33;
+  f.i3 = inv_rcp(u33);
   if (u00 == 0.0 || u11 == 0.0 || u22 == 0.0 || u33 == 0.0) bad = true;
   f.s01 = f.u01 * f.i0; f.s02 = f.u02 * f.i0; f.s03 = f.u03 * f.i0;
   f.s12 = f.u12 * f.i1; f.s13 = f.u13 * f.i1;

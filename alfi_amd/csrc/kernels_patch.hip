@@ -415,10 +415,13 @@ __global__ __launch_bounds__(256) void patch_il_build_kernel(int64_t npatch, int
 constexpr int MAX_PNODES = 64;
 
 #ifndef ALFI_MULT_U
-#define ALFI_MULT_U 32
+#define ALFI_MULT_U 16
 #endif
-#ifndef ALFI_MULT_G0
-#define ALFI_MULT_G0 5
+#ifndef ALFI_MULT_G
+#define ALFI_MULT_G 3
+#endif
+#ifndef ALFI_MULT_NG
+#define ALFI_MULT_NG 3
 #endif
 #ifndef ALFI_MULT_W
 #define ALFI_MULT_W 4
@@ -442,15 +445,17 @@ constexpr int MAX_PNODES = 64;
 #define ALFI_MULT_WG_PER_CU 4           // cap on the resident workgroups per CU of the persistent sweep
 #endif
 #ifndef ALFI_MULT_OCC
-#define ALFI_MULT_OCC 2                   // waves per SIMD the sweep kernels are compiled for (the LDS admits two workgroups per CU)
+#define ALFI_MULT_OCC 2                   // waves per SIMD the sweep kernels are compiled for: two workgroups per CU (three --
+                                          // 168 registers, 100-400 bytes of scratch per lane -- ran 27.2 against 25.3 ms)
 #endif
 #define ALFI_MULT_OCC_ATTR __attribute__((amdgpu_waves_per_eu(ALFI_MULT_OCC, ALFI_MULT_OCC)))
 constexpr int MULT_W = ALFI_MULT_W;         // waves per patch
 constexpr int MULT_NTHR = 64 * MULT_W;
 static_assert(MULT_NTHR >= MAX_NP, "one thread per row entry of a patch in the residual");
 constexpr int MULT_U = ALFI_MULT_U;         // 16-byte loads in flight per lane in the sweep's inverse apply (see apply_piece)
-constexpr int MULT_MAXU = 9;                // operator blocks per thread and round (2304 blocks per round at 4 waves)
-constexpr int MULT_G0 = ALFI_MULT_G0;       // of which the loads of the first MULT_G0 leave together, then those of the rest
+constexpr int MULT_G = ALFI_MULT_G;         // operator blocks per thread whose loads leave together (one group)
+constexpr int MULT_NG = ALFI_MULT_NG;       // groups per round (G x NG blocks per thread: 2560 blocks per round at 4 waves)
+constexpr int MULT_MAXU = MULT_G * MULT_NG;
 
 // same-wave LDS hand-off: the LDS serves a wave's instructions in order, so a wave that writes an array and then reads it
 // through other lanes needs no barrier -- only the compiler must keep the order
@@ -475,7 +480,7 @@ constexpr int MULT_G0 = ALFI_MULT_G0;       // of which the loads of the first M
 struct MultLds {
   double rs[MAX_NP];                          // r_p
   double part[MULT_W][MAX_NP];                // partial products of the waves
-  double prod[MULT_NTHR * MULT_MAXU * 3];     // products of one round of blocks (BS doubles each)
+  double prod[2][MULT_NTHR * MULT_G * 3];     // products of one group of blocks (BS doubles each), double-buffered
   int32_t pre[MAX_PNODES + 1];                // exclusive prefix of the rows' block counts
   int32_t k0[MAX_PNODES];                     // first block of each row
   int32_t nd[MAX_PNODES];                     // node (block row) of each patch node
@@ -532,38 +537,59 @@ __device__ __forceinline__ void mult_wg_blocks(const MultLds& S, int nn, int bas
     if (kk[u] >= 0) cc[u] = colidx[kk[u]] & 0x7fffffff;
 }
 
-// products of the blocks [U0, U1) of every thread: loads together, then prod[block of the round][0 .. BS)
-template <int BS, bool NT, int U0, int U1>
-__device__ __forceinline__ void mult_wg_products(MultLds& S, const int32_t (&kk)[MULT_MAXU], const int32_t (&cc)[MULT_MAXU],
-                                                 const double* __restrict__ vals, int flat, const double* __restrict__ y) {
+// group GI of a round: the loads of its blocks (values and y entries) ...
+template <int BS, bool NT>
+__device__ __forceinline__ void mult_wg_load(int GI, const int32_t (&kk)[MULT_MAXU], const int32_t (&cc)[MULT_MAXU],
+                                             const double* __restrict__ vals, int flat, const double* __restrict__ y,
+                                             double (&a_)[MULT_G][BS * BS], double (&yv_)[MULT_G][BS]) {
   constexpr int BB = BS * BS;
-  double a_[U1 - U0][BB], yv_[U1 - U0][BS];
 #pragma unroll
-  for (int u = U0; u < U1; ++u) {
+  for (int g = 0; g < MULT_G; ++g) {
+    const int32_t k = kk[GI * MULT_G + g];
 #pragma unroll
     for (int e = 0; e < BB; ++e) {
-      const double* v = vals + bsr_val_index(flat, kk[u] >= 0 ? kk[u] : 0, e, BB);
-      a_[u - U0][e] = kk[u] >= 0 ? (NT ? __builtin_nontemporal_load(v) : *v) : 0.0;
+      const double* v = vals + bsr_val_index(flat, k >= 0 ? k : 0, e, BB);
+      a_[g][e] = k >= 0 ? (NT ? __builtin_nontemporal_load(v) : *v) : 0.0;
     }
   }
 #pragma unroll
-  for (int u = U0; u < U1; ++u) {
+  for (int g = 0; g < MULT_G; ++g) {
 #pragma unroll
-    for (int c = 0; c < BS; ++c) yv_[u - U0][c] = kk[u] >= 0 ? y[(int64_t)cc[u] * BS + c] : 0.0;
+    for (int c = 0; c < BS; ++c) yv_[g][c] = kk[GI * MULT_G + g] >= 0 ? y[(int64_t)cc[GI * MULT_G + g] * BS + c] : 0.0;
   }
+}
+// ... and their products A_k y_col into prod[buffer GI & 1][block of the group][0 .. BS)
+template <int BS>
+__device__ __forceinline__ void mult_wg_store(int GI, MultLds& S, const int32_t (&kk)[MULT_MAXU], const double (&a_)[MULT_G][BS * BS],
+                                              const double (&yv_)[MULT_G][BS]) {
 #pragma unroll
-  for (int u = U0; u < U1; ++u) {
-    if (kk[u] >= 0) {
-      double* q = S.prod + ((int)threadIdx.x + MULT_NTHR * u) * BS;
+  for (int g = 0; g < MULT_G; ++g) {
+    if (kk[GI * MULT_G + g] >= 0) {
+      double* q = S.prod[GI & 1] + ((int)threadIdx.x + MULT_NTHR * g) * BS;
 #pragma unroll
       for (int r = 0; r < BS; ++r) {
         double sacc = 0.0;
 #pragma unroll
-        for (int c = 0; c < BS; ++c) sacc = __builtin_fma(a_[u - U0][r * BS + c], yv_[u - U0][c], sacc);
+        for (int c = 0; c < BS; ++c) sacc = __builtin_fma(a_[g][r * BS + c], yv_[g][c], sacc);
         q[r] = sacc;
       }
     }
   }
+}
+// the products of the blocks [fa, fz) of a row that lie in the group starting at block gbase, added in ascending order
+template <int BS>
+__device__ __forceinline__ double mult_wg_rowsum(const double* __restrict__ q, int fa, int fz, int gbase, double racc) {
+  const int f1 = min(fz, gbase + MULT_NTHR * MULT_G) - gbase;
+  int f = max(fa, gbase) - gbase;
+  for (; f + 8 <= f1; f += 8) {
+    double v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = q[(f + u) * BS];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) racc += v[u];
+  }
+  for (; f < f1; ++f) racc += q[f * BS];
+  return racc;
 }
 
 // r_p = x_p - (A y)_p, y_p += inv(A_p) r_p by the whole workgroup; kk, cc: the blocks of round 0 (mult_wg_blocks).
@@ -588,26 +614,25 @@ __device__ __forceinline__ void mult_wg_sweep(int64_t p, MultLds& S, int32_t (&k
     const double xe = mine ? x[(int64_t)S.nd[mine ? row : 0] * BS + comp] : 0.0;
     const int fa = mine ? S.pre[row] : 0, fz = mine ? S.pre[row + 1] : 0;
     double racc = 0.0;
+    constexpr int GB = MULT_NTHR * MULT_G;      // blocks per group
     for (int base = 0; base < total; base += MULT_NTHR * MULT_MAXU) {
       if (base > 0) {
-        __syncthreads();            // the previous round's products have been added
+        __syncthreads();            // the previous round's last products have been added
         mult_wg_blocks(S, nn, base, colidx, kk, cc);
       }
-      mult_wg_products<BS, NT, 0, MULT_G0>(S, kk, cc, vals, flat, y);
-      if (base + MULT_NTHR * MULT_G0 < total) mult_wg_products<BS, NT, MULT_G0, MULT_MAXU>(S, kk, cc, vals, flat, y);
-      __syncthreads();
-      // the row's products of this round, in ascending block order
-      const int f0 = max(fa, base) - base, f1 = min(fz, base + MULT_NTHR * MULT_MAXU) - base;
-      const double* q = S.prod + comp;
-      int f = f0;
-      for (; f + 8 <= f1; f += 8) {
-        double v[8];
+      // the groups of the round, software-pipelined: the loads of group g + 1 are in flight while the rows add the products of
+      // group g (two product buffers: a group's buffer is rewritten two barriers after its sums)
+      double a_[2][MULT_G][BS * BS], yv_[2][MULT_G][BS];
+      mult_wg_load<BS, NT>(0, kk, cc, vals, flat, y, a_[0], yv_[0]);
 #pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = q[(f + u) * BS];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) racc += v[u];
+      for (int gi = 0; gi < MULT_NG; ++gi) {
+        if (base + gi * GB >= total) break;                                  // uniform
+        mult_wg_store<BS>(gi, S, kk, a_[gi & 1], yv_[gi & 1]);
+        __syncthreads();
+        if (gi + 1 < MULT_NG && base + (gi + 1) * GB < total)
+          mult_wg_load<BS, NT>(gi + 1, kk, cc, vals, flat, y, a_[(gi + 1) & 1], yv_[(gi + 1) & 1]);
+        racc = mult_wg_rowsum<BS>(S.prod[gi & 1] + comp, fa, fz, base + gi * GB, racc);
       }
-      for (; f < f1; ++f) racc += q[f * BS];
     }
     if (mine) S.rs[e] = xe - racc;
   }

@@ -1,6 +1,7 @@
 #!/bin/bash
 # End-of-round artefacts for profiles/ (round 4).  Outputs: gpurun_out/r04f/.  PART selects what to run: headline | pmc | configs |
-# cfg5 | cfg5L | dist | setup | suite.  ALFI_COMMIT (the commit the snapshot was taken from: the GPU box has no .git) goes into the
+# cfg5 | cfg5L | dist | setup | suite.  setup needs the timing builds libalfi_hip_invtiming.so / libalfi_hip_mtiming.so
+# (-DALFI_INVERT_TIMING / -DALFI_MULT_TIMING).  ALFI_COMMIT (the commit the snapshot was taken from: the GPU box has no .git) goes into the
 # PMC summaries.
 cd "$GRAFT_REPO_ROOT" || exit 1
 export TMPDIR=/tmp
@@ -90,11 +91,28 @@ if [ "$PART" = setup ]; then
   python scripts/factor_time.py cfg4 > $O/factor_cfg4_mfma.txt 2>&1
   ALFI_INVERT_MFMA=0 python scripts/factor_time.py cfg4 > $O/factor_cfg4_reg.txt 2>&1
   tail -n 1 $O/factor_cfg4_mfma.txt $O/factor_cfg4_reg.txt
+  # the inversion kernel on config 4's finest level: duration (kernel trace) and MFMA pipe busy (its own counter pass)
+  cd /tmp
+  rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_factor -- python3 $GRAFT_REPO_ROOT/scripts/factor_time.py cfg4 > $O/prof_factor.out 2>&1
+  rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VALU SQ_ACTIVE_INST_ANY --output-format csv -d $O/pmc_factor -- python3 $GRAFT_REPO_ROOT/scripts/factor_time.py cfg4 > $O/pmc_factor.out 2>&1
+  cd $GRAFT_REPO_ROOT
+  {
+    echo "# round 4 end of round ($STAMP), commit $ALFI_COMMIT: scripts/factor_time.py cfg4 (185 193 patches of <= 153 dofs, 4 factorisations)"
+    echo "# kernel durations (rocprofv3 --kernel-trace --stats), then MFMA pipe busy = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs)"
+    find $O/prof_factor -name "*kernel_stats.csv" | head -1 | xargs -I{} head -6 {}
+    python scripts/mfma_busy_summary.py $O/pmc_factor $O/r04_mfma_busy_patch_invert_cfg4.json "round 4 end of round ($STAMP), commit $ALFI_COMMIT: factor_time.py cfg4"
+  } > $O/r04_mfma_busy_patch_invert_cfg4.txt 2>&1
+  cat $O/r04_mfma_busy_patch_invert_cfg4.txt
+  rm -rf $O/prof_factor $O/pmc_factor
+  ALFI_HIP_LIB=$GRAFT_REPO_ROOT/alfi_amd/libalfi_hip_invtiming.so python scripts/invert_phases.py cfg4s > $O/r04_invert_phases.txt 2>&1; grep -v amdgpu.ids $O/r04_invert_phases.txt | tail -n 18
   python scripts/newton_step_time.py cfg4 --re 10 100 1000 > $O/r04_newton_cfg4_device_assembly.txt 2>&1
   tail -n 4 $O/r04_newton_cfg4_device_assembly.txt
   timeout 1500 python scripts/dist_newton_time.py cfg4 --ranks 4 --re 10 100 1000 > $O/r04_dist_newton_cfg4_4ranks_mock_sharedgpu_functional.txt 2>&1
   grep -v "amdgpu.ids\|Gloo\|socket.cpp" $O/r04_dist_newton_cfg4_4ranks_mock_sharedgpu_functional.txt | tail -n 6
   python scripts/mult_time.py cfg4 > $O/r04_mult_cfg4.txt 2>&1; tail -n 2 $O/r04_mult_cfg4.txt
   ALFI_MULT_PERSISTENT=0 python scripts/mult_time.py cfg4 > $O/r04_mult_cfg4_per_wavefront.txt 2>&1; tail -n 2 $O/r04_mult_cfg4_per_wavefront.txt
+  ALFI_HIP_LIB=$GRAFT_REPO_ROOT/alfi_amd/libalfi_hip_mtiming.so python scripts/mult_stamps.py cfg4 > $O/r04_mult_stamps_cfg4.txt 2>&1; grep -v amdgpu.ids $O/r04_mult_stamps_cfg4.txt | tail -n 12
+  python scripts/apply_time.py cfg4 > $O/r04_apply_time_cfg4.txt 2>&1; grep level $O/r04_apply_time_cfg4.txt
+  python scripts/apply_time.py cfg3 > $O/r04_apply_time_cfg3.txt 2>&1; grep level $O/r04_apply_time_cfg3.txt
 fi
 ls -la $O | tail -30
