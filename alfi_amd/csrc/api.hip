@@ -1373,7 +1373,8 @@ int alfi_patches_factor_bytes(alfi_level* L, int64_t* bytes) {
 
 static void free_mult_schedule(alfi_level* L) {
   dev_free(L->mult_items); dev_free(L->mult_pred0); dev_free(L->mult_pred); dev_free(L->mult_succ_ptr);
-  dev_free(L->mult_succ); dev_free(L->mult_ctl);
+  dev_free(L->mult_succ); dev_free(L->mult_ctl); dev_free(L->mult_rowtab);
+  L->mult_rowtab = nullptr;
   L->mult_items = L->mult_pred0 = L->mult_pred = L->mult_succ_ptr = L->mult_succ = L->mult_ctl = nullptr;
   L->mult_nitems = 0;
 }
@@ -1456,6 +1457,21 @@ int alfi_patches_set_multiplicative(alfi_level* L, int64_t nit, const int64_t* i
   // one.  The list order is a topological order of these dependencies.
   free_mult_schedule(L);
   if (!L->mult_big) {
+    {
+      // row table of the sweep kernels (kernels_patch.hip, mult_wg_rows): per patch node its first block, block count and node
+      std::vector<int32_t> rowtab((size_t)L->npatch * 64 * 3, 0);
+      for (int64_t p = 0; p < L->npatch; ++p) {
+        const int64_t a = L->h_patch_ptr[p], b = L->h_patch_ptr[p + 1];
+        for (int64_t q = a, i = 0; q < b; q += bs, ++i) {
+          const int32_t node = L->h_patch_dofs[q] / bs;
+          int32_t* rt = &rowtab[((size_t)p * 64 + (size_t)i) * 3];
+          rt[0] = rowptr[node];
+          rt[1] = rowptr[node + 1] - rowptr[node];
+          rt[2] = node;
+        }
+      }
+      ALFI_CHECK(dev_upload(ctx, &L->mult_rowtab, rowtab.data(), (int64_t)rowtab.size()));
+    }
     std::vector<int32_t> items(seq);
     if (symmetrise)
       for (int32_t w = nwave - 1; w >= 0; --w)

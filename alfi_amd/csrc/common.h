@@ -377,6 +377,7 @@ struct alfi_level {
   int32_t mult_nitems = 0;
   int32_t *mult_items = nullptr, *mult_pred0 = nullptr, *mult_pred = nullptr, *mult_succ_ptr = nullptr, *mult_succ = nullptr;
   int32_t* mult_ctl = nullptr;          // [0] ticket counter (zeroed before every launch)
+  int32_t* mult_rowtab = nullptr;       // (npatch, 64, 3) first block, block count, node of every patch node (zero-padded)
   std::vector<int32_t> h_patch_dofs;    // host copy of the patch dofs (needed to build the wavefronts)
   // FGMRES workspace
   int kmax = 0;

@@ -487,25 +487,24 @@ struct MultLds {
   int32_t ticket, ok;
 };
 
-// tables of patch p: rows (wave 0), then -- after a barrier -- every thread's blocks of the round starting at block ``base``
+// tables of patch p: rows (wave 0; from the level's row table: first block, block count and node of every patch node, written
+// once by alfi_patches_set_multiplicative -- patch_ptr -> patch_dofs -> rowptr would be three dependent round trips per item),
+// then -- after a barrier -- every thread's blocks of the round starting at block ``base``
 template <int BS>
 __device__ __forceinline__ void mult_wg_rows(int64_t p, MultLds& S, const int64_t* __restrict__ patch_ptr,
-                                             const int32_t* __restrict__ patch_dofs, const int32_t* __restrict__ rowptr) {
+                                             const int32_t* __restrict__ rowtab) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int64_t off = patch_ptr[p];
-  const int n = (int)(patch_ptr[p + 1] - off);
+  const int32_t* rt = rowtab + (p * MAX_PNODES + lane) * 3;
+  const int32_t r0 = rt[0], r1 = rt[1], r2 = rt[2];          // entries beyond the patch's nodes are zero
+  const int n = (int)(patch_ptr[p + 1] - patch_ptr[p]);
   for (int i = lane; i < ((n + 1) & ~1); i += 64) S.part[wave][i] = 0.0;      // rows this wave does not touch in the apply
   if (wave != 0) return;
   const int nn = n / BS;
-  int len = 0;
   if (lane < nn) {
-    const int node = patch_dofs[off + lane * BS] / BS;
-    const int32_t lo = rowptr[node];
-    len = rowptr[node + 1] - lo;
-    S.k0[lane] = lo;
-    S.nd[lane] = node;
+    S.k0[lane] = r0;
+    S.nd[lane] = r2;
   }
-  int incl = len;   // inclusive wave scan
+  int incl = lane < nn ? r1 : 0;   // inclusive wave scan
 #pragma unroll
   for (int d = 1; d < 64; d <<= 1) {
     const int t = __shfl_up(incl, d);
@@ -689,13 +688,13 @@ __global__ __launch_bounds__(MULT_NTHR) ALFI_MULT_OCC_ATTR void patch_mult_kerne
                                                                const int32_t* __restrict__ patch_dofs,
                                                                const int64_t* __restrict__ inv_ptr,
                                                                const double* __restrict__ inv,
-                                                               const int32_t* __restrict__ rowptr,
+                                                               const int32_t* __restrict__ rowtab,
                                                                const int32_t* __restrict__ colidx,
                                                                const double* __restrict__ vals, int flat,
                                                                const double* __restrict__ x, double* __restrict__ y) {
   __shared__ MultLds S;
   const int64_t p = seq[blockIdx.x];
-  mult_wg_rows<BS>(p, S, patch_ptr, patch_dofs, rowptr);
+  mult_wg_rows<BS>(p, S, patch_ptr, rowtab);
   __syncthreads();
   int32_t kk[MULT_MAXU], cc[MULT_MAXU];
   mult_wg_blocks(S, (int)(patch_ptr[p + 1] - patch_ptr[p]) / BS, 0, colidx, kk, cc);
@@ -719,7 +718,7 @@ __global__ __launch_bounds__(MULT_NTHR) ALFI_MULT_OCC_ATTR void patch_mult_persi
     int32_t nitems, const int32_t* __restrict__ items, int32_t* __restrict__ pred, const int32_t* __restrict__ succ_ptr,
     const int32_t* __restrict__ succ, int32_t* __restrict__ head, int32_t* __restrict__ err,
     const int64_t* __restrict__ patch_ptr, const int32_t* __restrict__ patch_dofs, const int64_t* __restrict__ inv_ptr,
-    const double* __restrict__ inv, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colidx,
+    const double* __restrict__ inv, const int32_t* __restrict__ rowtab, const int32_t* __restrict__ colidx,
     const double* __restrict__ vals, int flat, const double* __restrict__ x, double* __restrict__ y ALFI_MULT_STAMP_PARAM) {
   __shared__ MultLds S;
   for (;;) {
@@ -730,7 +729,7 @@ __global__ __launch_bounds__(MULT_NTHR) ALFI_MULT_OCC_ATTR void patch_mult_persi
     ALFI_MULT_STAMP(0);
     const int64_t p = items[t];
     // nothing of the tables depends on y
-    mult_wg_rows<BS>(p, S, patch_ptr, patch_dofs, rowptr);
+    mult_wg_rows<BS>(p, S, patch_ptr, rowtab);
     __syncthreads();
     int32_t kk[MULT_MAXU], cc[MULT_MAXU];
     mult_wg_blocks(S, (int)(patch_ptr[p + 1] - patch_ptr[p]) / BS, 0, colidx, kk, cc);
@@ -868,7 +867,7 @@ int launch_patch_mult_wave(alfi_level* L, const int32_t* seq, int64_t count, con
   dim3 grid((unsigned)count), block(MULT_NTHR);
 #define ALFI_MULT(BSV, NTV)                                                                                           \
   hipLaunchKernelGGL((patch_mult_kernel<BSV, NTV>), grid, block, 0, ctx->stream, count, seq, L->patch_ptr,            \
-                     L->patch_dofs, L->inv_ptr, L->inv, L->A.rowptr, L->A.colidx, L->A.vals, L->A.flat, x, y)
+                     L->patch_dofs, L->inv_ptr, L->inv, L->mult_rowtab, L->A.colidx, L->A.vals, L->A.flat, x, y)
   if (L->bs == 2) {
     ALFI_MULT(2, true);
   } else if (L->bs == 3) {
@@ -926,7 +925,7 @@ int launch_patch_mult_persistent(alfi_level* L, const double* x, double* y) {
 #define ALFI_PMULT(BSV)                                                                                                   \
   hipLaunchKernelGGL((patch_mult_persistent_kernel<BSV, true>), grid, block, 0, ctx->stream, L->mult_nitems, L->mult_items, \
                      L->mult_pred, L->mult_succ_ptr, L->mult_succ, L->mult_ctl, ctx->dev_err, L->patch_ptr,               \
-                     L->patch_dofs, L->inv_ptr, L->inv, L->A.rowptr, L->A.colidx, L->A.vals, L->A.flat, x, y ALFI_PMULT_STAMPS)
+                     L->patch_dofs, L->inv_ptr, L->inv, L->mult_rowtab, L->A.colidx, L->A.vals, L->A.flat, x, y ALFI_PMULT_STAMPS)
   if (L->bs == 2) ALFI_PMULT(2);
   else if (L->bs == 3) ALFI_PMULT(3);
   else return alfi_set_error(ctx, ALFI_E_ARG, "unsupported block size %d", L->bs);
@@ -946,12 +945,14 @@ int launch_patch_apply_range(alfi_level* L, int64_t p0, int64_t p1, const double
     alfi_prof_end(ctx, t);
     return 0;
   }
-  // levels with FEW star patches of 3-D size (the lower levels of a hierarchy: 125 and 729 patches under config 3's 35 937):
-  // a wave per patch streams ~100 KB through one wave -- ~19 us however few patches there are -- so they take the
-  // workgroup-per-patch kernel of the macro stars as well (row pieces dealt to 4 waves, several workgroups per patch when
-  // the chip would stay empty): config 3 17.77 -> 17.46 ms per cycle
-  constexpr int64_t few = 1000;
-  if (L->max_np > SMALL_PATCH_MAX || (L->max_np > 64 && L->npatch <= few)) {   // one workgroup per patch (kernels_bigpatch.hip)
+  // levels with FEW star patches of 3-D size (the lower levels of a hierarchy: 125 and 729 patches under config 3's 35 937)
+  // leave most CUs empty: up to 1000 patches each patch gets 8 waves whatever its size (729 patches: 13.8 us against 15.6 us
+  // through the macro stars' kernel, whose row pieces -- 64 + 32 + 8 + 4 + 2 rows for 111 dofs -- are dealt unevenly to 4
+  // waves); with fewer patches than CUs the macro stars' kernel and its several workgroups per patch win (125 patches: 7.5
+  // against 8.6 us).  Config 3: 17.27 -> 17.1 ms per cycle, same box.
+  // (ALFI_TEST_LARGE_PATHS: no level counts as small, so that test hierarchies take the kernels of the large levels)
+  const int64_t few = alfi_test_large_paths() ? 0 : 1000, fewer = alfi_test_large_paths() ? 0 : 256;
+  if (L->max_np > SMALL_PATCH_MAX || (L->max_np > 64 && L->npatch <= fewer)) {     // kernels_bigpatch.hip
     ALFI_CHECK(launch_big_apply_range(L, p0, p1, x));
     alfi_prof_end(ctx, t);
     return 0;
@@ -975,7 +976,7 @@ int launch_patch_apply_range(alfi_level* L, int64_t p0, int64_t p1, const double
     }
 #undef ALFI_IL
   } else {
-    if (L->max_np > 128)
+    if (L->max_np > 128 || (L->max_np > 64 && L->npatch <= few))
       hipLaunchKernelGGL((patch_apply_kernel<true, 2 * APPLY_W>), dim3((unsigned)cnt), dim3(128 * APPLY_W), 0, ctx->stream, p0,
                          p1, L->patch_ptr, L->patch_dofs, L->inv_ptr, L->stage_ptr, L->inv, x, L->stage);
     else if (L->max_np > 64)
