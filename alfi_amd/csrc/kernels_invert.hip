@@ -91,8 +91,14 @@ __device__ __forceinline__ void lu4(const double (&d)[4][4], Lu4& f, bool& bad) 
   f.s23 = f.u23 * f.i2;
 }
 
+// one of four values by a per-lane index, as three SELECTS: the nested conditional expression compiled to divergent control
+// flow (two s_and_saveexec / s_or pairs and a branch around every pick -- a dozen picks per block step)
 __device__ __forceinline__ double sel4(int i, double a0, double a1, double a2, double a3) {
-  return i == 0 ? a0 : i == 1 ? a1 : i == 2 ? a2 : a3;
+  double r = a0;
+  r = i == 1 ? a1 : r;
+  r = i == 2 ? a2 : r;
+  r = i == 3 ? a3 : r;
+  return r;
 }
 
 // x = one row of the raw column panel A[i, K].  c[t] = the column t at the time of scalar step t (the A operand)
@@ -230,7 +236,7 @@ __global__ __launch_bounds__(512) void patch_invert_mfma_kernel(const int64_t* _
       //      node's gamma b b^T + nu K block is a cancellation of O(gamma) terms down to O(nu); only substitutions that repeat
       //      the elimination's own roundings stay consistent with it.)
       const double isel = sel4(lk, f.i0, f.i1, f.i2, f.i3);
-      double bop[NB], aop[NA], vop[NA], zrow[NB];
+      double bop[NB], aop[NA], vop[NA];
 #pragma unroll
       for (int b = 0; b < NB; ++b) {
         const int tj = 2 * b + wc;
@@ -240,13 +246,15 @@ __global__ __launch_bounds__(512) void patch_invert_mfma_kernel(const int64_t* _
         const double y3 = __builtin_fma(-f.l32, y2, __builtin_fma(-f.l31, y1, __builtin_fma(-f.l30, x0, x3)));
         const double rv = sel4(lk, x0, y1, y2, y3) * isel;               // r_lk = (L^-1 x)_lk / U_lk,lk
         bop[b] = (tj == tk && colgrp) ? 0.0 : rv;                        // columns K: left to the fix-up
-        zrow[b] = 0.0;
-        if (own_r) {      // the final content of the rows K, (D^-1 A[K, :])[lk][c]: the back substitution on the same y
+        if (own_r) {
+          // rows K <- D^-1 A[K, :] (columns outside K), the back substitution on the same y, straight into register q of the
+          // tile: the update below leaves these rows alone (their A operand is zero)
           const double r0 = x0 * f.i0, r1 = y1 * f.i1, r2 = y2 * f.i2, r3 = y3 * f.i3;
           const double z2 = __builtin_fma(-f.s23, r3, r2);
           const double z1 = __builtin_fma(-f.s13, r3, __builtin_fma(-f.s12, z2, r1));
           const double z0 = __builtin_fma(-f.s03, r3, __builtin_fma(-f.s02, z2, __builtin_fma(-f.s01, z1, r0)));
-          zrow[b] = sel4(lk, z0, z1, z2, r3);
+          const double zs = sel4(lk, z0, z1, z2, r3);
+          acc[ar][b][q] = (tj == tk && colgrp) ? acc[ar][b][q] : zs;
         }
       }
 #pragma unroll
@@ -306,14 +314,6 @@ __global__ __launch_bounds__(512) void patch_invert_mfma_kernel(const int64_t* _
           }
       }
       ALFI_INV_PH(4);
-      // ---- rows K <- D^-1 A[K, :] (columns outside K): register q of the tiles of tile row tk
-      if (own_r) {
-#pragma unroll
-        for (int b = 0; b < NB; ++b) {
-          const bool in_k = (2 * b + wc) == tk && colgrp;
-          if (!in_k) acc[ar][b][q] = zrow[b];
-        }
-      }
       ALFI_INV_PH(5);
     }
   });
