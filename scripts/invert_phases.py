@@ -23,6 +23,7 @@ o = out[:npat]
 n = o[:, 0, 7]
 sel = n == n.max()
 o = o[sel]
+o = o[:, o[0, :, 6] > 0]          # the waves of the build (8, or 4 with -DALFI_INVERT_WR=2)
 steps = (n.max() + 3) // 4
 names = ["panels -> LDS + barrier", "LU of the pivot block", "operands (substitutions)", "update MFMAs issued", "column fix-up", "row fix-up"]
 print("%s: %d patches of %d dofs (%d block steps); shader-clock cycles per wave and block step, mean over waves / slowest wave"
