@@ -1,5 +1,4 @@
-"""Patch factorisation time of the finest level of a bench configuration (gather + inversion + residual probe);
-ALFI_FORCE_BIG_FACTOR=1 sends small patches through the blocked MFMA path instead of the register Gauss-Jordan.
+"""Patch factorisation time of the finest level of a bench configuration (gather + inversion + residual probe).
 usage: python scripts/factor_time.py cfg4s"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -16,7 +15,7 @@ t0 = time.time()
 for _ in range(3):
     dl.factor()
 ctx.sync()
-print("%s FORCE_BIG=%s INVERT_LA=%s: factor %.1f ms per call (%d patches, max %d dofs)" % (sys.argv[1], os.environ.get("ALFI_FORCE_BIG_FACTOR", "0"), os.environ.get("ALFI_INVERT_LA", "1"), (time.time() - t0) / 3 * 1e3, len(L.patch_ptr) - 1, np.diff(L.patch_ptr).max()))
+print("%s: factor %.1f ms per call (%d patches, max %d dofs; ALFI_INVERT_MFMA=%s)" % (sys.argv[1], (time.time() - t0) / 3 * 1e3, len(L.patch_ptr) - 1, np.diff(L.patch_ptr).max(), os.environ.get("ALFI_INVERT_MFMA", "default")))
 print("patch check (worst residual, flagged, repaired, worst after):", dl.patch_check())
 if len(sys.argv) > 2:      # y = M^-1 x for a fixed x: compared bitwise between kernel variants
     x = np.random.default_rng(5).standard_normal(L.n)
