@@ -16,6 +16,21 @@ if [ "$PART" = headline ]; then
   rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_cfg4 -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --steps 20 --warmup 5 > $O/r04_bench_cfg4_under_rocprof.json 2> $O/prof_cfg4.err
   cd $GRAFT_REPO_ROOT
   find $O/prof_cfg4 -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $O/r04_cfg4_kernel_stats.csv
+  # the dominant kernel by grid size (= by level): the kernel-stats average mixes the levels in the proportions of the WHOLE run
+  # (warm-up, probe, F-cycle, the cycles of the other restriction setting), the bench line's events cover the timed cycles only
+  python - $O/prof_cfg4 $O/r04_bench_cfg4_under_rocprof.json <<'PY' > $O/r04_cfg4_patch_apply_by_level.txt
+import glob, json, sys, pandas as pd
+t = pd.read_csv(glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True)[0])
+t["dur_us"] = (t["End_Timestamp"] - t["Start_Timestamp"]) / 1e3
+a = t[t["Kernel_Name"].str.contains("patch_apply_kernel")]
+print("rocprofv3 --kernel-trace of `bench.py --no-cpu-baseline --steps 20 --warmup 5`: patch_apply_kernel launches by grid size (largest = finest level)")
+print(a.groupby("Grid_Size_X")["dur_us"].agg(["count", "mean", "min", "max"]).round(1).to_string())
+d = json.loads([l for l in open(sys.argv[2]) if l.startswith("{")][-1])
+r = d["roofline"]
+print("the same run's bench line (HIP events on the library's stream, timed cycles only): finest level %.1f us per launch, all smoothed levels %.1f us over %d launches"
+      % (r["finest_level_avg_launch_us"], r["avg_launch_us"], r["launches"]))
+PY
+  cat $O/r04_cfg4_patch_apply_by_level.txt
   rm -rf $O/prof_cfg4
   head -c 600 $O/r04_bench_cfg4.json; echo
   head -8 $O/r04_cfg4_kernel_stats.csv
