@@ -1,6 +1,10 @@
 """Operator refresh on the device (alfi_level_set_assembly / alfi_level_assemble: what PatchPC.update does inside PCPATCH on
 every Newton step, alfi/solver.py:320, 325) against the host generator's assembly of the same linearisation
-(alfi/solver.py:565-568), and the Newton loop with either.  -m gpu."""
+(alfi/solver.py:565-568), and the Newton loop with either.  -m gpu.
+
+What these tests pin: the DEVICE assembly against the product's own HOST assembler (alfi_amd/problem.py, csrc/host_assemble.cpp)
+-- not against the oracle.  The chain to the oracle closes through the CPU tests: tests/test_exact_pins.py (the host
+assembler's element matrices against the exact rational derivation of oracle/exact_pins.py) and tests/test_supg.py."""
 import numpy as np
 import pytest
 
