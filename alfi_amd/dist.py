@@ -938,9 +938,10 @@ def _dist_ns_solver_class():
 
         # -- operator refresh on the device, every rank its own rows (alfi/solver.py:320, 325 under solver.py:604-605) ----------
         def _device_assembly_possible(self):
-            # the Scott-Vogelius hierarchy is not nested (its inject is a sparse product) and SUPG needs the cells' Hessians of
-            # the ghost rows: both keep the host path on partitioned levels
-            return not self.sv and not self.supg
+            # SUPG needs the cells' Hessians of the ghost rows: it keeps the host path on partitioned levels.  (The Scott-Vogelius
+            # pair takes the device path since round 4: its per-level states come from the replicated state by the sparse bary
+            # injection on the host, _winds, and the full grad-div term is state-independent.)
+            return not self.supg
 
         def _setup_device_assembly(self):
             """Once per solver: every local level with owned rows gets the cells that touch its local nodes, its rows of the
@@ -962,7 +963,8 @@ def _dist_ns_solver_class():
                     V = L.V
                     geo, tens = V.mesh.cell_geometry(), V.element.reference_tensors()
                     K = localize_operator(LazyOperator(V, L.A.rowptr, L.A.colidx, geo, tens, 1.0, 0.0, 0.0, None, with_bc=False), p)
-                    D = localize_operator(LazyOperator(V, L.A.rowptr, L.A.colidx, geo, tens, 0.0, 1.0, 0.0, None, with_bc=False), p)
+                    D = localize_operator(LazyOperator(V, L.A.rowptr, L.A.colidx, geo, tens, 0.0, 1.0, 0.0, None, full_div=self.sv,
+                                                       with_bc=False), p)
                     assert np.array_equal(K.colidx, LL.A.colidx) and np.array_equal(K.rowptr, LL.A.rowptr)
                     cells, cn, nodes = assembly_cells(V, p)
                     dl.set_assembly(V, K.vals, D.vals, LL.A.rowptr, LL.A.colidx, cells=cells, cell_nodes=cn)

@@ -46,7 +46,8 @@ def main():
             L = s.levels[LL.level]
             dl.assemble(s.nu, s.gamma, 1.0, asm[1], True)
             ref = localize_operator(LazyOperator(L.V, L.A.rowptr, L.A.colidx, L.V.mesh.cell_geometry(),
-                                                 L.V.element.reference_tensors(), s.nu, s.gamma, 1.0, np.ascontiguousarray(w)),
+                                                 L.V.element.reference_tensors(), s.nu, s.gamma, 1.0, np.ascontiguousarray(w),
+                                                 full_div=s.sv),
                                     LL.part)
             asm_err = max(asm_err, float(np.abs(dl.get_values() - ref.vals).max() / np.abs(ref.vals).max()))
     gathered = [None] * world
