@@ -938,10 +938,11 @@ def _dist_ns_solver_class():
 
         # -- operator refresh on the device, every rank its own rows (alfi/solver.py:320, 325 under solver.py:604-605) ----------
         def _device_assembly_possible(self):
-            # SUPG needs the cells' Hessians of the ghost rows: it keeps the host path on partitioned levels.  (The Scott-Vogelius
-            # pair takes the device path since round 4: its per-level states come from the replicated state by the sparse bary
-            # injection on the host, _winds, and the full grad-div term is state-independent.)
-            return not self.supg
+            # every discretisation the single-GPU solver refreshes on the device: the P0-pressure pairs, the Scott-Vogelius pair
+            # (its per-level states come from the replicated state by the sparse bary injection on the host, _winds; the full
+            # grad-div term is state-independent) and the SUPG terms (element matrices of the rank's cells -- all cells that
+            # touch a local node -- gathered into the rank's rows)
+            return True
 
         def _setup_device_assembly(self):
             """Once per solver: every local level with owned rows gets the cells that touch its local nodes, its rows of the
@@ -970,6 +971,8 @@ def _dist_ns_solver_class():
                     dl.set_assembly(V, K.vals, D.vals, LL.A.rowptr, LL.A.colidx, cells=cells, cell_nodes=cn)
                     bcn = np.flatnonzero(V.bc_node_mask[p.nodes])              # Dirichlet nodes among ALL local nodes
                     dl.set_assembly_bc((bcn[:, None] * L.bs + np.arange(L.bs)).ravel())
+                    if self.supg:
+                        dl.set_supg(V, LL.A.rowptr, LL.A.colidx, cells=cells)
                     self._asm.append((nodes, self.ctx.vec(dl.assembly_state_size())))
                 L = self.levels[-1]
                 self._dres = self.ctx.vec(dmg.n_loc)
@@ -995,7 +998,13 @@ def _dist_ns_solver_class():
             with self._on_stream():
                 self._upload_states(u)
                 for asm, dl in zip(self._asm, self.dmg.levels):
-                    if asm is not None:
+                    if asm is None:
+                        continue
+                    if adv and self.supg:     # A = nu K + gamma D + N(w) + the linearised SUPG term, THEN the boundary conditions
+                        dl.assemble(self.nu, self.gamma, adv, asm[1], False)
+                        dl.supg(self.nu, self.supg_weight, self.supg_magic, asm[1], True, None)
+                        dl.apply_bc()
+                    else:
                         dl.assemble(self.nu, self.gamma, adv, asm[1] if adv else None, True)
                 self.dmg.sync()
             t1 = time.time()
@@ -1018,6 +1027,8 @@ def _dist_ns_solver_class():
             with self._on_stream():
                 st.set(np.ascontiguousarray(u.reshape(-1, L.bs)[nodes]).ravel())
                 fin.assemble_mult(self.nu, self.gamma, 0.5 * adv, st if adv else None, st, self._dres)
+                if adv and self.supg:         # + the SUPG residual of the rank's rows, gathered on the device into the same vector
+                    fin.supg(self.nu, self.supg_weight, self.supg_magic, st, False, self._dres)
                 self._dp.set(np.ascontiguousarray(p[self._res_rows]) if len(self._res_rows) else np.zeros(1))
                 self._dBT.mult(self._dp, self._dwc)
                 fin.halo_reverse_add(self._dwc)

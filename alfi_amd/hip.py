@@ -229,9 +229,10 @@ class Level(object):
         self.ctx.check(self.ctx.lib.alfi_level_assemble_mult(self.h, float(nu), float(gamma), float(adv),
                                                              state.ptr if state is not None else None, x.ptr, y.ptr))
 
-    def set_supg(self, V, rowptr, colidx, nq=None):
+    def set_supg(self, V, rowptr, colidx, nq=None, cells=None):
         """Quadrature tables for the device-side SUPG terms (alfi_level_set_supg): the rule and tabulation of
-        ``_hostlib.supg`` (degree 2k), cell sizes, diagonal blocks."""
+        ``_hostlib.supg`` (degree 2k), cell sizes, diagonal blocks.  ``cells`` (partitioned level): the cells given to
+        ``set_assembly``; ``rowptr`` / ``colidx`` are then the rank's local rows."""
         from . import _hostlib
         from .elements import simplex_quadrature
         el, d = V.element, V.dim
@@ -240,6 +241,8 @@ class Level(object):
         phi, dphi = el.tabulate(lam)
         d2phi = el.tabulate_hessian(lam)
         h = _hostlib.cell_size(V.mesh)
+        if cells is not None:
+            h = np.asarray(h)[np.asarray(cells)]
         rowptr = np.asarray(rowptr, dtype=np.int64)
         colidx = np.asarray(colidx)
         rows = np.repeat(np.arange(len(rowptr) - 1), np.diff(rowptr))

@@ -291,13 +291,14 @@ def test_partitioned_outer_solve(case, world, tmp_path):
     assert np.abs(xp - xs[L.n:]).max() < 1e-5 * np.abs(xs[L.n:]).max()
 
 
-@pytest.mark.parametrize("disc,world", [("pkp0", 2), ("pkp0-3d", 3), ("sv", 2)])
+@pytest.mark.parametrize("disc,world", [("pkp0", 2), ("pkp0-3d", 3), ("sv", 2), ("pkp0-supg", 2)])
 def test_partitioned_newton(tmp_path, disc, world):
     """Newton + Reynolds continuation with every linear solve on partitioned levels: same Newton / Krylov counts and the same
     solution as the single-GPU solver.  The operators are refreshed ON THE DEVICE, every rank its own rows
     (alfi_level_set_assembly on partitioned levels): no host assembly during the Newton loops, values equal to the rank-local
     host assembly to 1e-12.  ``sv``: the Scott-Vogelius pair on the barycentric hierarchy (macro-star patches as condensed
-    factors, discontinuous P1 pressure owned cell by cell, block DGMassInv)."""
+    factors, discontinuous P1 pressure owned cell by cell, block DGMassInv); ``pkp0-supg``: with the SUPG terms of the reference's
+    production runs (stabilisation.py:47-97), assembled on the device from the rank's cells."""
     from alfi_amd.nssolver import HipNavierStokesSolver, run_solver
     from alfi_amd.problem import TwoDimLidDrivenCavityProblem, ThreeDimLidDrivenCavityProblem
     port = _free_port()
@@ -309,6 +310,7 @@ def test_partitioned_newton(tmp_path, disc, world):
                                        str(tmp_path), disc], env=env, cwd=ROOT))
     s = (HipNavierStokesSolver(TwoDimLidDrivenCavityProblem(4), 2, 2, discretisation="sv") if disc == "sv"
          else HipNavierStokesSolver(ThreeDimLidDrivenCavityProblem(2), 1, 2) if disc == "pkp0-3d"
+         else HipNavierStokesSolver(TwoDimLidDrivenCavityProblem(8), 1, 2, stabilisation_type="supg") if disc == "pkp0-supg"
          else HipNavierStokesSolver(TwoDimLidDrivenCavityProblem(8), 1, 2))
     res = run_solver(s, [10, 100])
     for p in procs:
