@@ -33,14 +33,16 @@ def rank_main(args):
     dim, baseN, nref, ke, Re, k = bench.CONFIGS[args.config]
     prob = TwoDimLidDrivenCavityProblem(baseN) if dim == 2 else ThreeDimLidDrivenCavityProblem(baseN)
     t0 = time.time()
-    s = DistNavierStokesSolver(prob, nref, ke, min_dofs=args.min_dofs)
+    s = DistNavierStokesSolver(prob, nref, ke, min_dofs=args.min_dofs, stabilisation_type="supg" if args.supg is not None else None,
+                               stabilisation_weight=args.supg)
     if rank == 0:
         print("%s on %d ranks (transport %s): %d velocity + %d pressure dofs, setup %.1f s, device assembly %s, levels on "
               "this rank %d.." % (args.config, world, s.dmg.transport, s.n_u, s.n_p, time.time() - t0, s.device_assembly,
                                    s.dmg.lmin), flush=True)
     calls = []
-    real = _hostlib.assemble_bsr
+    real, real_supg = _hostlib.assemble_bsr, _hostlib.supg
     _hostlib.assemble_bsr = lambda *a, **kw: (calls.append(1), real(*a, **kw))[1]
+    _hostlib.supg = lambda *a, **kw: (calls.append(1), real_supg(*a, **kw))[1]
     for re in args.re:
         for kk in s.timings:
             s.timings[kk] = 0 if kk == "newton_steps" else 0.0
@@ -70,6 +72,8 @@ def main():
     ap.add_argument("--ranks", type=int, default=4)
     ap.add_argument("--re", type=float, nargs="+", default=[10.0, 100.0])
     ap.add_argument("--min-dofs", type=int, default=400000)
+    ap.add_argument("--supg", type=float, default=None, metavar="WEIGHT",
+                    help="SUPG stabilisation with this weight (the reference's production runs: 0.05)")
     ap.add_argument("--compare", action="store_true", help="also run the single-GPU solver (counts side by side)")
     ap.add_argument("--rank-process", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
@@ -88,14 +92,16 @@ def main():
                    MASTER_PORT=str(port), OMP_NUM_THREADS=str(threads), ALFI_HOST_THREADS=str(threads),
                    ALFI_DIST_TRANSPORT="rccl", ALFI_RCCL_LIB=lib)
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), args.config, "--ranks", str(args.ranks),
-                                       "--min-dofs", str(args.min_dofs), "--rank-process", "--re"] + [str(x) for x in args.re],
+                                       "--min-dofs", str(args.min_dofs), "--rank-process"] +
+                                      (["--supg", str(args.supg)] if args.supg is not None else []) + ["--re"] + [str(x) for x in args.re],
                                       env=env, cwd=ROOT))
     rc = [p.wait() for p in procs]
     if any(rc):
         raise SystemExit("rank exit codes %s" % rc)
     if args.compare:
-        subprocess.check_call([sys.executable, os.path.join(ROOT, "scripts", "newton_step_time.py"), args.config, "--re"] +
-                              [str(x) for x in args.re], cwd=ROOT)
+        subprocess.check_call([sys.executable, os.path.join(ROOT, "scripts", "newton_step_time.py"), args.config] +
+                              (["--supg", str(args.supg)] if args.supg is not None else []) + ["--re"] + [str(x) for x in args.re],
+                              cwd=ROOT)
 
 
 if __name__ == "__main__":
