@@ -921,9 +921,10 @@ def _dist_ns_solver_class():
 
         def _lazy_generation(self):
             # rank-local generation: every rank assembles the operator / transfer rows of its partition only (config 4 on 8
-            # ranks: 4.5 GB of host memory per rank instead of 25).  The host refresh of SUPG terms works on global values.
+            # ranks: 4.5 GB of host memory per rank instead of 25).  The HOST refresh of SUPG terms works on global values: with
+            # SUPG the generation is rank-local only while the operators are refreshed on the device (the default).
             import os
-            return not self.supg and os.environ.get("ALFI_DIST_GLOBAL_GENERATION") != "1"
+            return (not self.supg or self.device_assembly) and os.environ.get("ALFI_DIST_GLOBAL_GENERATION") != "1"
 
         def _create_device(self, restriction):
             self.dmg = DistMultigrid(self.levels, self.transfers, self.params["fieldsplit_0"]["mg_levels"]["ksp_max_it"],
@@ -935,6 +936,13 @@ def _dist_ns_solver_class():
 
         def _push_operators(self):
             self.dmg.update(self.levels)
+
+        def _supg_host_needs_global_values(self):
+            from .lazy import LazyOperator
+            if isinstance(self.levels[-1].A, LazyOperator):
+                raise RuntimeError("SUPG on partitioned levels without the device-side operator refresh needs the global "
+                                   "operator values: start with ALFI_DIST_GLOBAL_GENERATION=1 (the hierarchy was generated "
+                                   "rank-locally because the device refresh was expected to be available)")
 
         # -- operator refresh on the device, every rank its own rows (alfi/solver.py:320, 325 under solver.py:604-605) ----------
         def _device_assembly_possible(self):
@@ -1052,6 +1060,7 @@ def _dist_ns_solver_class():
             if self.device_assembly:
                 return self._rediscretise_device(u, adv)
             if self.supg:
+                self._supg_host_needs_global_values()
                 return super()._rediscretise(u, adv)
             from .lazy import LazyOperator
             for L, w in zip(self.levels, self._winds(u)):
@@ -1069,6 +1078,7 @@ def _dist_ns_solver_class():
             if self.device_assembly:
                 return self._residual_device(u, p, adv)
             if self.supg:
+                self._supg_host_needs_global_values()
                 return super().residual(u, p, adv)
             from . import _hostlib
             from .lazy import _take_rows, _row_map
