@@ -128,7 +128,7 @@ __global__ __launch_bounds__(256) void assemble_gather_kernel(int64_t nnzb, int 
 // entries of its contributing cells in the fixed order of the contributor lists (the lists of the advection assembly);
 // supg_residual_kernel does the same per node through the diagonal block's list.
 // ---------------------------------------------------------------------------------------------------------------------
-template <int D, int EPL>
+template <int D, int EPL, bool WANT>
 __global__ __launch_bounds__(64) void supg_cell_kernel(int64_t cell0, int64_t ncell, int nloc, const int32_t* __restrict__ cell_nodes,
                                                         const double* __restrict__ grad, const double* __restrict__ vol,
                                                         const double* __restrict__ hcell, int nq, const double* __restrict__ wq,
@@ -148,6 +148,9 @@ __global__ __launch_bounds__(64) void supg_cell_kernel(int64_t cell0, int64_t nc
   double* lap = hs + nloc * D * D;       // nloc
   double* ph = lap + nloc;               // nloc
   double* st = ph + nloc;                // u[D], Gu[D][D], Lu[D]
+  double* saw = st + 2 * D + D * D;      // nloc          wt * (u . grad phi_a)
+  double* c2w = saw + nloc;              // nloc * D      wt * beta * Lu_i * phi_b
+  double* c1 = c2w + nloc * D;           // nloc * D * D  the (b, i, j) factor of the entry that multiplies saw_a (see below)
   const int32_t* cn = cell_nodes + cell * nloc;
   double g[NV][D];
 #pragma unroll
@@ -157,39 +160,62 @@ __global__ __launch_bounds__(64) void supg_cell_kernel(int64_t cell0, int64_t nc
   for (int e = lane; e < ndof; e += 64) Uk[e] = U[(int64_t)cn[e / D] * D + e % D];
   const double hc = hcell[cell], h2 = hc * hc;
   const double vw = vol[cell] * weight;
-  double acc[EPL];
+  double acc[WANT ? EPL : 1];
 #pragma unroll
-  for (int t = 0; t < EPL; ++t) acc[t] = 0.0;
+  for (int t = 0; t < (WANT ? EPL : 1); ++t) acc[t] = 0.0;
   double facc = 0.0;                     // element residual entry `lane` (ndof <= 64)
+  // entry e = (row (a, i), column (b, j)) of this lane's t-th entry, decomposed ONCE: the places of its four factors in the
+  // per-point tables, a byte each (saw[a] | c1[(b D + i) D + j] | c2w[b D + i] | gp[a D + j]).  (Round 3 divided e by ndof and
+  // by D inside the loop over the quadrature points: ~150 integer instructions per entry and point around 25 flops -- the
+  // kernel took 0.9 s per refresh of config 4's finest level, half of a Newton step with SUPG.)
+  uint32_t pk[WANT ? EPL : 1];
+#pragma unroll
+  for (int t = 0; t < (WANT ? EPL : 1); ++t) {
+    const int e = lane + 64 * t;
+    pk[t] = 0;
+    if (e < ndof * ndof) {
+      const int row = e / ndof, col = e % ndof;
+      const int a = row / D, i = row % D, b = col / D, j = col % D;
+      pk[t] = (uint32_t)a | ((uint32_t)((b * D + i) * D + j) << 8) | ((uint32_t)(b * D + i) << 16) | ((uint32_t)(a * D + j) << 24);
+    }
+  }
   __syncthreads();
   for (int q = 0; q < nq; ++q) {
-    // ---- basis at the point: a lane per local node
-    if (lane < nloc) {
-      const int a = lane;
+    // ---- basis at the point: a lane per (local node a, direction y).  Physical gradient component y and column y of the
+    //      physical Hessian G^T H_a G in two steps, M = H_a G[:, y] then G^T M: 28 FMAs on nloc D lanes.  (Round 3: a lane per
+    //      node summed all 16 x 9 products ha_ik g_ix g_ky -- 290 multiply-adds on 14 of the 64 lanes, most of the time of a
+    //      residual-only pass.)
+    if (lane < ndof) {
+      const int a = lane / D, y = lane % D;
       const double* da = dphi + ((int64_t)q * nloc + a) * NV;
       const double* ha = d2phi + ((int64_t)q * nloc + a) * NV * NV;
+      double gy[NV];
+#pragma unroll
+      for (int k = 0; k < NV; ++k) {
+        gy[k] = g[k][0];
+#pragma unroll
+        for (int yy = 1; yy < D; ++yy) gy[k] = y == yy ? g[k][yy] : gy[k];
+      }
+      double t = 0.0;
+#pragma unroll
+      for (int i = 0; i < NV; ++i) t = __builtin_fma(da[i], gy[i], t);
+      gp[a * D + y] = t;
+      double M[NV];
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        double m = 0.0;
+#pragma unroll
+        for (int k = 0; k < NV; ++k) m = __builtin_fma(ha[i * NV + k], gy[k], m);
+        M[i] = m;
+      }
 #pragma unroll
       for (int x = 0; x < D; ++x) {
-        double t = 0.0;
+        double h = 0.0;
 #pragma unroll
-        for (int i = 0; i < NV; ++i) t = __builtin_fma(da[i], g[i][x], t);
-        gp[a * D + x] = t;
+        for (int i = 0; i < NV; ++i) h = __builtin_fma(g[i][x], M[i], h);
+        hs[(a * D + x) * D + y] = h;
       }
-      double l = 0.0;
-#pragma unroll
-      for (int x = 0; x < D; ++x)
-#pragma unroll
-        for (int y = 0; y < D; ++y) {
-          double t = 0.0;
-#pragma unroll
-          for (int i = 0; i < NV; ++i)
-#pragma unroll
-            for (int k = 0; k < NV; ++k) t = __builtin_fma(ha[i * NV + k] * g[i][x], g[k][y], t);
-          hs[(a * D + x) * D + y] = t;
-          if (x == y) l += t;
-        }
-      lap[a] = l;
-      ph[a] = phi[(int64_t)q * nloc + a];
+      if (y == 0) ph[a] = phi[(int64_t)q * nloc + a];
     }
     __syncthreads();
     // ---- state at the point: a lane per output (u_i | Gu_ix | the second-order part of Lu_i)
@@ -206,11 +232,20 @@ __global__ __launch_bounds__(64) void supg_cell_kernel(int64_t cell0, int64_t nc
       const int j = lane - D - D * D;     // Lu_j = -nu sum_a (lap_a U_aj + sum_i hs_a[j][i] U_ai)   (+ convective part below)
       double t = 0.0;
       for (int a = 0; a < nloc; ++a) {
-        t = __builtin_fma(-nu * lap[a], Uk[a * D + j], t);
+        double la = 0.0;                  // lap_a = trace of the Hessian (lap[] is written by other lanes in this phase)
+#pragma unroll
+        for (int x = 0; x < D; ++x) la += hs[(a * D + x) * D + x];
+        t = __builtin_fma(-nu * la, Uk[a * D + j], t);
 #pragma unroll
         for (int i = 0; i < D; ++i) t = __builtin_fma(-nu * hs[(a * D + j) * D + i], Uk[a * D + i], t);
       }
       st[D + D * D + j] = t;
+    } else if (lane >= 32 && lane < 32 + nloc) {
+      const int a = lane - 32;
+      double la = 0.0;
+#pragma unroll
+      for (int x = 0; x < D; ++x) la += hs[(a * D + x) * D + x];
+      lap[a] = la;
     }
     __syncthreads();
     double u[D], Gu[D][D], Lu[D];
@@ -245,41 +280,53 @@ __global__ __launch_bounds__(64) void supg_cell_kernel(int64_t cell0, int64_t nc
       for (int t = 1; t < D; ++t) Li = i == t ? Lu[t] : Li;
       facc = __builtin_fma(wt * beta * Li, sa, facc);
     }
-    // ---- element matrix: entries e = lane, lane + 64, ...
-    if (want_vals) {
+    // ---- element matrix.  Entry ((a, i), (b, j)) at this point is
+    //        wt (b3 u_j phi_b L_i s_a + beta dL_bij s_a + beta L_i phi_b dphi_a/dx_j),   s_a = u . grad phi_a,
+    //        dL_bij = phi_b G_ij - nu H_b[i][j] + delta_ij (- nu lap_b + s_b)
+    //      = saw[a] c1[b, i, j] + c2w[b, i] gp[a, j]   with the three tables below (nloc + nloc D D + nloc D values per point,
+    //      formed once by the wave instead of once per entry): two FMAs and four LDS reads per entry.
+    if (WANT) {
+      if (lane < nloc) {
+        double sa = 0.0;
+#pragma unroll
+        for (int x = 0; x < D; ++x) sa = __builtin_fma(u[x], gp[lane * D + x], sa);
+        saw[lane] = sa;                    // (scaled by wt below, after c1 has read the unscaled value)
+      }
+      __syncthreads();
+      for (int e = lane; e < nloc * D * D; e += 64) {
+        const int b = e / (D * D), i = (e / D) % D, j = e % D;
+        double Li = Lu[0], uj = u[0], Gij = 0.0;
+#pragma unroll
+        for (int tt = 1; tt < D; ++tt) {
+          Li = i == tt ? Lu[tt] : Li;
+          uj = j == tt ? u[tt] : uj;
+        }
+#pragma unroll
+        for (int ii = 0; ii < D; ++ii)
+#pragma unroll
+          for (int jj = 0; jj < D; ++jj) Gij = (i == ii && j == jj) ? Gu[ii][jj] : Gij;
+        double dL = __builtin_fma(ph[b], Gij, -nu * hs[e]);
+        if (i == j) dL += -nu * lap[b] + saw[b];
+        c1[e] = b3 * uj * ph[b] * Li + beta * dL;
+        if (j == 0) c2w[b * D + i] = wt * beta * Li * ph[b];
+      }
+      __syncthreads();
+      if (lane < nloc) saw[lane] *= wt;
+      __syncthreads();
 #pragma unroll
       for (int t = 0; t < EPL; ++t) {
-        const int e = lane + 64 * t;
-        if (e < ndof * ndof) {
-          const int row = e / ndof, col = e % ndof;
-          const int a = row / D, i = row % D, b = col / D, j = col % D;
-          double sa = 0.0, sb = 0.0;
-#pragma unroll
-          for (int x = 0; x < D; ++x) {
-            sa = __builtin_fma(u[x], gp[a * D + x], sa);
-            sb = __builtin_fma(u[x], gp[b * D + x], sb);
-          }
-          double Li = Lu[0], uj = u[0], Gij = 0.0;
-#pragma unroll
-          for (int tt = 1; tt < D; ++tt) {
-            Li = i == tt ? Lu[tt] : Li;
-            uj = j == tt ? u[tt] : uj;
-          }
-#pragma unroll
-          for (int ii = 0; ii < D; ++ii)
-#pragma unroll
-            for (int jj = 0; jj < D; ++jj) Gij = (i == ii && j == jj) ? Gu[ii][jj] : Gij;
-          double dL = __builtin_fma(ph[b], Gij, -nu * hs[(b * D + i) * D + j]);
-          if (i == j) dL += -nu * lap[b] + sb;
-          acc[t] += wt * (b3 * uj * ph[b] * Li * sa + beta * dL * sa + beta * Li * ph[b] * gp[a * D + j]);
-        }
+        // (opaque to the optimiser: otherwise the 4 EPL LDS addresses are hoisted out of the loop over the points and held in
+        // registers -- 256 + 47 of them, one wave per SIMD, every latency of a point exposed)
+        uint32_t k = pk[t];
+        asm volatile("" : "+v"(k));
+        acc[t] = __builtin_fma(saw[k & 255u], c1[(k >> 8) & 255u], __builtin_fma(c2w[(k >> 16) & 255u], gp[k >> 24], acc[t]));
       }
     }
     __syncthreads();     // the next point overwrites gp / hs / st
   }
   const int64_t slot = blockIdx.x;
   if (lane < ndof) Fe_out[slot * ndof + lane] = facc;
-  if (want_vals) {
+  if (WANT) {
 #pragma unroll
     for (int t = 0; t < EPL; ++t) {
       const int e = lane + 64 * t;
@@ -415,16 +462,22 @@ int launch_supg(alfi_level* L, double nu, double weight, double magic, const dou
     (void)hipFree(Ae);
     return alfi_set_error(ctx, ALFI_E_HIP, "SUPG scratch: %s", hipGetErrorString(e));
   }
-  const size_t lds = sizeof(double) * (size_t)(2 * nloc * d + nloc * d * d + 2 * nloc + 2 * d + d * d);
+  const size_t lds = sizeof(double) * (size_t)(2 * nloc * d + nloc * d * d + 2 * nloc + 2 * d + d * d + nloc + nloc * d + nloc * d * d);
   const int epl = (ndof * ndof + 63) / 64;
   const int64_t nnzb = L->A.nnzb, nnode = L->A.nbrows;
   int rc = 0;
   for (int64_t c0 = 0; c0 < S.ncell && rc == 0; c0 += batch) {
     const int64_t nb = std::min<int64_t>(batch, S.ncell - c0);
     dim3 grid((unsigned)nb), block(64);
-#define ALFI_SUPG_CELL(DV, EV)                                                                                              \
-  hipLaunchKernelGGL((supg_cell_kernel<DV, EV>), grid, block, lds, ctx->stream, c0, S.ncell, nloc, S.cell_nodes, S.grad, S.vol, \
-                     S.hcell, S.nq, S.wq, S.phi, S.dphi, S.d2phi, d_state, nu, weight, magic, add_vals, Ae, Fe)
+#define ALFI_SUPG_CELL(DV, EV)                                                                                                  \
+  do {                                                                                                                          \
+    if (add_vals)                                                                                                               \
+      hipLaunchKernelGGL((supg_cell_kernel<DV, EV, true>), grid, block, lds, ctx->stream, c0, S.ncell, nloc, S.cell_nodes,      \
+                         S.grad, S.vol, S.hcell, S.nq, S.wq, S.phi, S.dphi, S.d2phi, d_state, nu, weight, magic, 1, Ae, Fe);    \
+    else                                                                                                                        \
+      hipLaunchKernelGGL((supg_cell_kernel<DV, 1, false>), grid, block, lds, ctx->stream, c0, S.ncell, nloc, S.cell_nodes,      \
+                         S.grad, S.vol, S.hcell, S.nq, S.wq, S.phi, S.dphi, S.d2phi, d_state, nu, weight, magic, 0, Ae, Fe);    \
+  } while (0)
     if (d == 2) {
       if (epl <= 4) ALFI_SUPG_CELL(2, 4); else if (epl <= 16) ALFI_SUPG_CELL(2, 16); else ALFI_SUPG_CELL(2, 64);
     } else {
