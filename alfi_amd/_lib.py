@@ -54,12 +54,15 @@ SIGNATURES = {
                                          ctypes.POINTER(vp)]),
     "alfi_level_destroy": (ctypes.c_int, [vp]),
     "alfi_level_update_values": (ctypes.c_int, [vp, vp]),
-    "alfi_level_set_assembly": (ctypes.c_int, [vp, ctypes.c_int64, ctypes.c_int, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
+    "alfi_level_set_assembly": (ctypes.c_int, [vp, ctypes.c_int64, ctypes.c_int, vp, vp, vp, vp, vp, vp, ctypes.c_int, vp, vp, vp]),
+    "alfi_ctx_set_assembly_scratch": (ctypes.c_int, [vp, ctypes.c_int64]),
+    "alfi_level_assemble_supg": (ctypes.c_int, [vp, ctypes.c_double, ctypes.c_double, ctypes.c_double, vp, ctypes.c_double,
+                                                ctypes.c_double, ctypes.c_int]),
     "alfi_level_assemble": (ctypes.c_int, [vp, ctypes.c_double, ctypes.c_double, ctypes.c_double, vp, ctypes.c_int]),
     "alfi_level_set_assembly_bc": (ctypes.c_int, [vp, vp, ctypes.c_int64]),
     "alfi_level_assembly_state_size": (ctypes.c_int, [vp, ctypes.POINTER(ctypes.c_int64)]),
     "alfi_level_assemble_mult": (ctypes.c_int, [vp, ctypes.c_double, ctypes.c_double, ctypes.c_double, vp, vp, vp]),
-    "alfi_level_set_supg": (ctypes.c_int, [vp, ctypes.c_int, vp, vp, vp, vp, vp, vp]),
+    "alfi_level_set_supg": (ctypes.c_int, [vp, ctypes.c_int, vp, vp, vp, vp, vp]),
     "alfi_level_supg": (ctypes.c_int, [vp, ctypes.c_double, ctypes.c_double, ctypes.c_double, vp, ctypes.c_int, vp]),
     "alfi_level_apply_bc": (ctypes.c_int, [vp]),
     "alfi_level_get_values": (ctypes.c_int, [vp, vp]),

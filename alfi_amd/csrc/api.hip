@@ -366,6 +366,7 @@ int alfi_ctx_destroy(alfi_ctx* ctx) {
   dev_free(ctx->red_partial2);
   dev_free(ctx->dev_err);
   (void)hipFree(ctx->big_arena);
+  (void)hipFree(ctx->asm_scratch);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
   return 0;
@@ -677,19 +678,21 @@ int alfi_level_update_values(alfi_level* L, const double* bvals) {
 
 static void free_assembly(AssemblyDev* S) {
   dev_free(S->cptr); dev_free(S->ccell); dev_free(S->cba); dev_free(S->cell_nodes); dev_free(S->grad); dev_free(S->vol);
-  dev_free(S->Ta); dev_free(S->Tb); dev_free(S->Kv); dev_free(S->Dv); dev_free(S->scratch); dev_free(S->bc_all);
+  dev_free(S->etab); dev_free(S->bItab); dev_free(S->bc_code); dev_free(S->bc_all);
   dev_free(S->wq); dev_free(S->phi); dev_free(S->dphi); dev_free(S->d2phi); dev_free(S->hcell); dev_free(S->diag);
   *S = AssemblyDev();
 }
 
 int alfi_level_set_assembly(alfi_level* L, int64_t ncell, int nloc, const int32_t* cell_nodes, const double* grad,
-                            const double* vol, const double* Ta, const double* Tb, const double* Kvals, const double* Dvals,
+                            const double* vol, const double* Sref, const double* bIref, const double* T1ref, int full_div,
                             const int64_t* cptr, const int32_t* ccell, const uint16_t* cba) {
   alfi_ctx* ctx = L->ctx;
-  if (!cell_nodes || !grad || !vol || !Ta || !Tb || !Kvals || !Dvals || !cptr || !ccell || !cba)
+  if (!cell_nodes || !grad || !vol || !Sref || !bIref || !T1ref || !cptr || !ccell || !cba)
     return alfi_set_error(ctx, ALFI_E_ARG, "NULL argument");
   if (ncell < 1 || nloc < 1 || nloc * nloc > 65535) return alfi_set_error(ctx, ALFI_E_ARG, "bad cell counts (%lld cells, %d nodes each)", (long long)ncell, nloc);
   if (!L->A.flat) return alfi_set_error(ctx, ALFI_E_STATE, "device assembly needs the lane-major operator layout (no empty block rows)");
+  if (!element_kernel_exists(L->bs, nloc))
+    return alfi_set_error(ctx, ALFI_E_ARG, "no element kernel for %d nodes per cell in %d-D", nloc, L->bs);
   const int64_t nnzb = L->A.nnzb, nb = L->A.nbrows;
   const int d = L->bs, nv = d + 1;
   // Unpartitioned: the cells are the mesh, every (cell, a, b) pair contributes to a block.  Partitioned: the cells that touch
@@ -709,38 +712,59 @@ int alfi_level_set_assembly(alfi_level* L, int64_t ncell, int nloc, const int32_
     if (cell_nodes[i] < 0 || (!part && cell_nodes[i] >= nb)) return alfi_set_error(ctx, ALFI_E_ARG, "cell node out of range");
     nstate = std::max<int64_t>(nstate, (int64_t)cell_nodes[i] + 1);
   }
-  for (int64_t q = 0; q < npairs; ++q) {     // the two nodes of a contributing pair are rows / columns of the local operator
-    const int32_t* cn = cell_nodes + (int64_t)ccell[q] * nloc;
-    if (cn[cba[q] % nloc] >= nb || cn[cba[q] / nloc] >= nb) return alfi_set_error(ctx, ALFI_E_ARG, "contributor %lld names a node without an operator row", (long long)q);
+  // the diagonal block of every block row (its contributor list = the cells around the node: the gather of element vectors);
+  // the two nodes of a contributing pair are rows / columns of the local operator
+  std::vector<int32_t> diag((size_t)nb, -1);
+  {
+    std::vector<int32_t> rowptr(nb + 1), colidx((size_t)std::max<int64_t>(nnzb, 1));
+    ALFI_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    ALFI_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    ALFI_HIP_CHECK(ctx, hipMemcpy(rowptr.data(), L->A.rowptr, sizeof(int32_t) * (nb + 1), hipMemcpyDeviceToHost));
+    ALFI_HIP_CHECK(ctx, hipMemcpy(colidx.data(), L->A.colidx, sizeof(int32_t) * nnzb, hipMemcpyDeviceToHost));
+    for (int64_t r = 0; r < nb; ++r) {
+      for (int64_t k = rowptr[r]; k < rowptr[r + 1]; ++k) {
+        const int32_t c = colidx[k] & 0x7fffffff;       // (the sign bit marks the first block of a block row)
+        if (c == r) diag[r] = (int32_t)k;
+        for (int64_t q = cptr[k]; q < cptr[k + 1]; ++q) {
+          const int32_t* cn = cell_nodes + (int64_t)ccell[q] * nloc;
+          if (cn[cba[q] % nloc] != r || cn[cba[q] / nloc] != c)
+            return alfi_set_error(ctx, ALFI_E_ARG, "contributor %lld does not belong to block %lld", (long long)q, (long long)k);
+        }
+      }
+      if (diag[r] < 0) return alfi_set_error(ctx, ALFI_E_ARG, "block row %lld has no diagonal block", (long long)r);
+    }
   }
-  ALFI_HIP_CHECK(ctx, hipSetDevice(ctx->device));
-  ALFI_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  // per (a, b) the slices of the reference tensors the cell kernel reads (kernels_assemble.hip):
+  // T1[k,i,b,a] | T1[b,i,k,a] | S[a,b,i,j];  T1: (nloc, d+1, nloc, nloc), S: (nloc, nloc, d+1, d+1)
+  const int ts = 2 * nv * nloc + nv * nv;
+  std::vector<double> etab((size_t)nloc * nloc * ts);
+  for (int a = 0; a < nloc; ++a)
+    for (int b = 0; b < nloc; ++b) {
+      double* t = etab.data() + (size_t)(a * nloc + b) * ts;
+      for (int i = 0; i < nv; ++i)
+        for (int k = 0; k < nloc; ++k) {
+          t[i * nloc + k] = T1ref[(((size_t)k * nv + i) * nloc + b) * nloc + a];
+          t[nv * nloc + i * nloc + k] = T1ref[(((size_t)b * nv + i) * nloc + k) * nloc + a];
+        }
+      for (int i = 0; i < nv; ++i)
+        for (int j = 0; j < nv; ++j) t[2 * nv * nloc + i * nv + j] = Sref[(((size_t)a * nloc + b) * nv + i) * nv + j];
+    }
   free_assembly(&L->asmb);
   AssemblyDev S;
   S.nloc = nloc;
   S.ncell = ncell;
   S.npairs = npairs;
   S.nstate = nstate;
+  S.full_div = full_div != 0;
   int rc = dev_upload(ctx, &S.cptr, cptr, nnzb + 1);
   if (rc == 0) rc = dev_upload(ctx, &S.ccell, ccell, npairs);
   if (rc == 0) rc = dev_upload(ctx, &S.cba, cba, npairs);
   if (rc == 0) rc = dev_upload(ctx, &S.cell_nodes, cell_nodes, ncell * nloc);
   if (rc == 0) rc = dev_upload(ctx, &S.grad, grad, ncell * nv * d);
   if (rc == 0) rc = dev_upload(ctx, &S.vol, vol, ncell);
-  if (rc == 0) rc = dev_upload(ctx, &S.Ta, Ta, (int64_t)nloc * nloc * nloc * nv);
-  if (rc == 0) rc = dev_upload(ctx, &S.Tb, Tb, (int64_t)nloc * nloc * nloc * nv);
-  // K and D in the operator's own (lane-major) layout: upload through a DevBSR that shares the level's structure
-  const int64_t padded = ((nnzb + 63) / 64) * 64 * d * d;
-  for (int which = 0; which < 2 && rc == 0; ++which) {
-    double** dst = which == 0 ? &S.Kv : &S.Dv;
-    rc = dev_alloc(ctx, dst, padded);
-    if (rc == 0 && hipMemsetAsync(*dst, 0, sizeof(double) * padded, ctx->stream) != hipSuccess) rc = ALFI_E_HIP;
-    if (rc == 0) {
-      DevBSR tmp = L->A;
-      tmp.vals = *dst;
-      rc = upload_bsr_values(ctx, &tmp, which == 0 ? Kvals : Dvals);
-    }
-  }
+  if (rc == 0) rc = dev_upload(ctx, &S.etab, etab.data(), (int64_t)etab.size());
+  if (rc == 0) rc = dev_upload(ctx, &S.bItab, bIref, (int64_t)nloc * nv);
+  if (rc == 0) rc = dev_upload(ctx, &S.diag, diag.data(), nb);
   if (rc != 0) {
     free_assembly(&S);
     return rc;
@@ -750,13 +774,35 @@ int alfi_level_set_assembly(alfi_level* L, int64_t ncell, int nloc, const int32_
   return 0;
 }
 
+int alfi_ctx_set_assembly_scratch(alfi_ctx* ctx, int64_t max_bytes) {
+  if (max_bytes < 1) return alfi_set_error(ctx, ALFI_E_ARG, "scratch limit must be positive");
+  ctx->asm_scratch_limit = max_bytes;
+  return 0;
+}
+
 int alfi_level_assemble(alfi_level* L, double nu, double gamma, double adv, const double* d_state, int apply_bc) {
   alfi_ctx* ctx = L->ctx;
   if (!L->asmb.ready) return alfi_set_error(ctx, ALFI_E_STATE, "alfi_level_assemble before alfi_level_set_assembly");
   if (adv != 0.0 && !d_state) return alfi_set_error(ctx, ALFI_E_ARG, "advection needs the state");
+  ALFI_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   ctx->cur_tag = L->id;
   int t = alfi_prof_begin(ctx, ALFI_EV_PATCH_FACTOR);       // PCPatchComputeOp
-  ALFI_CHECK(launch_assemble_gather(L, nu, gamma, adv, d_state, apply_bc, L->A.vals));
+  ALFI_CHECK(launch_operator_refresh(L, nu, gamma, adv, d_state, true, false, 0.0, 0.0, false, apply_bc != 0, L->A.vals));
+  alfi_prof_end(ctx, t);
+  L->factored = false;
+  return 0;
+}
+
+// The refresh of a stabilised run in one pass: A = nu K + gamma D + adv N(state) + the linearised SUPG term, boundary conditions
+int alfi_level_assemble_supg(alfi_level* L, double nu, double gamma, double adv, const double* d_state, double weight,
+                             double magic, int apply_bc) {
+  alfi_ctx* ctx = L->ctx;
+  if (!L->asmb.supg_ready) return alfi_set_error(ctx, ALFI_E_STATE, "alfi_level_assemble_supg before alfi_level_set_supg");
+  if (!d_state) return alfi_set_error(ctx, ALFI_E_ARG, "SUPG needs the state");
+  ALFI_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  ctx->cur_tag = L->id;
+  int t = alfi_prof_begin(ctx, ALFI_EV_PATCH_FACTOR);
+  ALFI_CHECK(launch_operator_refresh(L, nu, gamma, adv, d_state, true, true, weight, magic, false, apply_bc != 0, L->A.vals));
   alfi_prof_end(ctx, t);
   L->factored = false;
   return 0;
@@ -778,7 +824,9 @@ int alfi_level_set_assembly_bc(alfi_level* L, const int32_t* bc_dofs, int64_t nb
   }
   ALFI_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
   dev_free(L->asmb.bc_all);
+  dev_free(L->asmb.bc_code);
   L->asmb.bc_all = nullptr;
+  L->asmb.bc_code = nullptr;
   return dev_upload(ctx, &L->asmb.bc_all, mask.data(), (int64_t)mask.size());
 }
 
@@ -788,8 +836,9 @@ int alfi_level_assembly_state_size(alfi_level* L, int64_t* n) {
   return 0;
 }
 
-// y = A(state) x with A = nu K + gamma D + adv N(state) WITHOUT boundary conditions, assembled into a second value array: the
-// level's own operator (the Jacobian the patches were factored from) is not touched.  The nonlinear residual of
+// y = A(state) x with A = nu K + gamma D + adv N(state) WITHOUT boundary conditions, matrix-free: every cell multiplies its
+// element matrix with its entries of x as it forms it, the element vectors are gathered per node in a fixed order.  The level's
+// own operator (the Jacobian the patches were factored from) is not touched.  The nonlinear residual of
 // alfi/solver.py:565-568 is one such product: F_u = (nu K + gamma D) u + 1/2 N(u) u = A(u; adv / 2) u.
 int alfi_level_assemble_mult(alfi_level* L, double nu, double gamma, double adv, const double* d_state, const double* dx,
                              double* dy) {
@@ -797,41 +846,28 @@ int alfi_level_assemble_mult(alfi_level* L, double nu, double gamma, double adv,
   AssemblyDev& S = L->asmb;
   if (!S.ready) return alfi_set_error(ctx, ALFI_E_STATE, "alfi_level_assemble_mult before alfi_level_set_assembly");
   if (adv != 0.0 && !d_state) return alfi_set_error(ctx, ALFI_E_ARG, "advection needs the state");
-  if (!S.scratch) ALFI_CHECK(dev_alloc(ctx, &S.scratch, ((L->A.nnzb + 63) / 64) * 64 * (int64_t)L->bs * L->bs));
+  if (!dx || !dy) return alfi_set_error(ctx, ALFI_E_ARG, "NULL argument");
+  ALFI_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   ctx->cur_tag = L->id;
   int t = alfi_prof_begin(ctx, ALFI_EV_PATCH_FACTOR);
-  ALFI_CHECK(launch_assemble_gather(L, nu, gamma, adv, d_state, 0, S.scratch));
+  ALFI_CHECK(launch_element_mult(L, nu, gamma, adv, d_state, dx, dy));
   alfi_prof_end(ctx, t);
-  // the product through the level's own views (owned rows, interior / boundary split) with the value pointer exchanged:
-  // launches are stream-ordered and take their arguments by value, so the exchange is over when level_spmv returns
-  double* keep = L->A.vals;
-  L->A.vals = L->A_own.vals = L->A_int.vals = L->A_bnd.vals = S.scratch;
-  const int rc = level_spmv(L, dx, dy, nullptr, 0, false);
-  L->A.vals = L->A_own.vals = L->A_int.vals = L->A_bnd.vals = keep;
-  return rc;
+  return 0;
 }
 
 int alfi_level_set_supg(alfi_level* L, int nq, const double* wq, const double* phi, const double* dphi, const double* d2phi,
-                        const double* hcell, const int32_t* diag) {
+                        const double* hcell) {
   alfi_ctx* ctx = L->ctx;
   AssemblyDev& S = L->asmb;
   if (!S.ready) return alfi_set_error(ctx, ALFI_E_STATE, "alfi_level_set_supg before alfi_level_set_assembly");
-  if (nq < 1 || !wq || !phi || !dphi || !d2phi || !hcell || !diag) return alfi_set_error(ctx, ALFI_E_ARG, "NULL / empty SUPG tables");
+  if (nq < 1 || !wq || !phi || !dphi || !d2phi || !hcell) return alfi_set_error(ctx, ALFI_E_ARG, "NULL / empty SUPG tables");
   if (S.nloc * L->bs > 64) return alfi_set_error(ctx, ALFI_E_ARG, "SUPG kernel handles elements of at most 64 dofs, got %d", S.nloc * L->bs);
-  const int64_t nb = L->A.nbrows;
-  {
-    std::vector<int32_t> rowptr(nb + 1);
-    ALFI_HIP_CHECK(ctx, hipMemcpy(rowptr.data(), L->A.rowptr, sizeof(int32_t) * (nb + 1), hipMemcpyDeviceToHost));
-    for (int64_t r = 0; r < nb; ++r)
-      if (diag[r] < rowptr[r] || diag[r] >= rowptr[r + 1]) return alfi_set_error(ctx, ALFI_E_ARG, "diagonal block of row %lld out of its row", (long long)r);
-  }
   for (int64_t c = 0; c < S.ncell; ++c)
     if (!(hcell[c] > 0.0)) return alfi_set_error(ctx, ALFI_E_ARG, "cell size of cell %lld is not positive", (long long)c);
   ALFI_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   ALFI_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-  dev_free(S.wq); dev_free(S.phi); dev_free(S.dphi); dev_free(S.d2phi); dev_free(S.hcell); dev_free(S.diag);
+  dev_free(S.wq); dev_free(S.phi); dev_free(S.dphi); dev_free(S.d2phi); dev_free(S.hcell);
   S.wq = S.phi = S.dphi = S.d2phi = S.hcell = nullptr;
-  S.diag = nullptr;
   S.supg_ready = false;
   const int nv = L->bs + 1, nloc = S.nloc;
   ALFI_CHECK(dev_upload(ctx, &S.wq, wq, nq));
@@ -839,7 +875,6 @@ int alfi_level_set_supg(alfi_level* L, int nq, const double* wq, const double* p
   ALFI_CHECK(dev_upload(ctx, &S.dphi, dphi, (int64_t)nq * nloc * nv));
   ALFI_CHECK(dev_upload(ctx, &S.d2phi, d2phi, (int64_t)nq * nloc * nv * nv));
   ALFI_CHECK(dev_upload(ctx, &S.hcell, hcell, S.ncell));
-  ALFI_CHECK(dev_upload(ctx, &S.diag, diag, nb));
   S.nq = nq;
   S.supg_ready = true;
   return 0;
@@ -850,9 +885,12 @@ int alfi_level_supg(alfi_level* L, double nu, double weight, double magic, const
   if (!L->asmb.supg_ready) return alfi_set_error(ctx, ALFI_E_STATE, "alfi_level_supg before alfi_level_set_supg");
   if (!d_state) return alfi_set_error(ctx, ALFI_E_ARG, "SUPG needs the state");
   if (!add_to_operator && !d_F) return 0;
+  ALFI_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   ctx->cur_tag = L->id;
   int t = alfi_prof_begin(ctx, ALFI_EV_PATCH_FACTOR);       // PCPatchComputeOp
-  ALFI_CHECK(launch_supg(L, nu, weight, magic, d_state, add_to_operator, d_F));
+  if (add_to_operator)
+    ALFI_CHECK(launch_operator_refresh(L, nu, 0.0, 0.0, d_state, false, true, weight, magic, true, false, L->A.vals));
+  if (d_F) ALFI_CHECK(launch_supg_residual(L, nu, weight, magic, d_state, d_F));
   alfi_prof_end(ctx, t);
   if (add_to_operator) L->factored = false;
   return 0;

@@ -17,6 +17,9 @@ struct alfi_ctx {
   bool use_graph = false;           // alfi_ctx_set_graph: replay whole cycles as hipGraphs (not while profiling / partitioned)
   void* big_arena = nullptr;        // scratch of the large-block factorisation (kernels_bigpatch.hip), kept between calls
   size_t big_arena_bytes = 0;
+  void* asm_scratch = nullptr;      // element blocks / element vectors of the operator refresh (kernels_assemble.hip), grow-only
+  size_t asm_scratch_bytes = 0;
+  int64_t asm_scratch_limit = (int64_t)24 << 30;   // bytes of element blocks per batch of cells (alfi_ctx_set_assembly_scratch)
   bool own_stream = false;
   std::string err;
   // profiling
@@ -266,7 +269,8 @@ struct AssemblyDev {
   int64_t ncell = 0, npairs = 0;
   int64_t nstate = 0;            // nodes of the state vector the cells index (= the level's nodes; on a partitioned level the
                                  // local nodes followed by the other nodes of the cells that touch them)
-  double* scratch = nullptr;     // a second value array in the operator's layout (alfi_level_assemble_mult)
+  bool full_div = false;         // grad-div term gamma (div u, div v) (Scott-Vogelius) instead of the cell-averaged one
+  uint8_t* bc_code = nullptr;    // (nnzb) Dirichlet flags of every block's row / column dofs (built on first use)
   uint8_t* bc_all = nullptr;     // (n) partitioned levels: Dirichlet dofs among ALL local dofs, ghosts included
                                  // (alfi_level_set_assembly_bc; the level's own mask marks owned dofs only)
   int64_t* cptr = nullptr;       // (nnzb + 1) contributor lists per block
@@ -275,10 +279,10 @@ struct AssemblyDev {
   int32_t* cell_nodes = nullptr; // (ncell, nloc)
   double* grad = nullptr;        // (ncell, d + 1, d) gradients of the barycentric coordinates
   double* vol = nullptr;         // (ncell)
-  double* Ta = nullptr;          // (nloc * nloc, nloc, d + 1): [b * nloc + a][k][i] = T1[k, i, b, a]
-  double* Tb = nullptr;          // (nloc * nloc, d + 1, nloc): [b * nloc + a][i][k] = T1[b, i, k, a]
-  double* Kv = nullptr;          // viscous part, the operator's lane-major layout
-  double* Dv = nullptr;          // grad-div part
+  double* etab = nullptr;        // (nloc * nloc, 2 (d+1) nloc + (d+1)^2): per (a, b) the slices of T1 and S the cell kernel
+                                 // reads as wave-uniform operands (layout: kernels_assemble.hip)
+  double* bItab = nullptr;       // (nloc, d + 1) avg d_i phi_a
+  int32_t* diag = nullptr;       // (nodes) index of the diagonal block of every block row
   // SUPG (alfi_level_set_supg): quadrature tables of the element and the cell sizes
   bool supg_ready = false;
   int nq = 0;
@@ -287,7 +291,6 @@ struct AssemblyDev {
   double* dphi = nullptr;        // (nq, nloc, d + 1) derivatives w.r.t. the barycentric coordinates
   double* d2phi = nullptr;       // (nq, nloc, d + 1, d + 1)
   double* hcell = nullptr;       // (ncell) cell size (2 x circumradius)
-  int32_t* diag = nullptr;       // (nodes) index of the diagonal block of every block row
 };
 
 struct alfi_level {
@@ -566,10 +569,13 @@ int launch_patch_sum_scale(alfi_level* lvl, const double* w, double* z, double* 
 // w = A z with the partials of V_v . w (v < nv <= 16) in the same pass; *nblocks = number of partials per vector
 int launch_bsr_spmv_dot(alfi_ctx* ctx, const DevBSR& A, const double* z, double* w, const double* V, int64_t stride, int nv,
                         double* partial, int* nblocks);
-int launch_assemble_gather(alfi_level* lvl, double nu, double gamma, double adv, const double* d_state, int apply_bc,
-                           double* out_vals);   // out_vals: the operator's layout (lvl->A.vals, or a scratch copy)
+// kernels_assemble.hip: the level operator from its cells (element blocks -> one fixed-order gather); out_vals: the operator's layout
+int launch_operator_refresh(alfi_level* lvl, double nu, double gamma, double adv, const double* d_state, bool with_elements,
+                            bool with_supg, double weight, double magic, bool accumulate, bool apply_bc, double* out_vals);
+int launch_element_mult(alfi_level* lvl, double nu, double gamma, double adv, const double* d_state, const double* dx, double* dy);
+int launch_supg_residual(alfi_level* lvl, double nu, double weight, double magic, const double* d_state, double* d_F);
+bool element_kernel_exists(int d, int nloc);
 int launch_vals_from_lanes(alfi_ctx* ctx, const DevBSR& A, double* d_out);
-int launch_supg(alfi_level* lvl, double nu, double weight, double magic, const double* d_state, int add_vals, double* d_F);
 int launch_apply_bc(alfi_level* lvl);
 int launch_patch_invert_mfma(alfi_ctx* ctx, int64_t npatch, int max_np, const int64_t* patch_ptr, const int64_t* inv_ptr,
                              double* inv, int* status, int* handled);   // kernels_invert.hip

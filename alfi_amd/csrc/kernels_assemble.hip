@@ -4,113 +4,283 @@
 //
 // written straight into the lane-major BSR the SpMV and the patch gather read, from the state w resident in HBM.  In the
 // reference PatchPC.update recomputes the element tensors and re-assembles the patch operators inside PCPATCH on every Newton
-// step (`precompute_element_tensors`, `save_operators`: alfi/solver.py:320, 325; event PCPatchComputeOp, driver.py:80);
-// here the host generator used to rediscretise every level and re-upload 10 GB per step.
+// step (`precompute_element_tensors`, `save_operators`: alfi/solver.py:320, 325; event PCPatchComputeOp, driver.py:80).
 //
-// K (viscous) and D (grad-div) do not depend on the state: they are uploaded once, in the operator's own layout.  N(w) is
-// assembled by GATHER, one thread per d x d block (r, c): the thread walks the block's contributor list -- the (cell, a, b)
-// with r = node a, c = node b of the cell, in a fixed order built on the host (alfi_host_contributors) -- and forms, with the
-// reference tensor T1[k, i, b, a] = avg(phi_k d_i phi_b phi_a) (barycentric derivative i),
-//
-//     N_(a cc),(b dd) = vol [ delta_{cc dd} sum_{k,i} (w_k . g_i) T1[k,i,b,a]  +  sum_i g_i^dd  sum_k T1[b,i,k,a] w_k^cc ] ,
-//
-// the same arithmetic as csrc/host_assemble.cpp:element_matrix.  No atomics: every entry is summed in the same order on
-// every run, consecutive lanes own consecutive blocks, so the nine value planes are written coalesced.  Dirichlet rows and
-// columns become identity in the same pass (firedrake.assemble(a, bcs=...)).
+// CELL-CENTRIC (round 5).  Two passes, no atomics, bitwise reproducible:
+//   (1) element_cell_kernel: a LANE per cell forms the cell's element matrix block by block -- viscous, grad-div and advection
+//       terms from the reference-cell tensors S, bI, T1 (the arithmetic of csrc/host_assemble.cpp:element_matrix) -- with the
+//       cell's state, gradients and volume in registers.  All 64 lanes of a wave work on the same block (a, b) at the same
+//       time, so every tensor entry is a wave-uniform operand that arrives through the scalar cache (s_load) and feeds D FMAs;
+//       the d x d blocks go to a scratch array E[cell][a][b][d d].  (Rounds 3-4 gathered per BSR block: one thread walked its
+//       contributor list and re-derived w . g and both tensor contractions for every (cell, a, b), with per-lane addresses into
+//       the 175-KB tensor -- 112 divergent 8-byte loads per 392 FMAs: 67 ms for config 4's finest level, 0.05 of the HBM peak.)
+//   (2) element_gather_kernel: one thread per BSR block adds the blocks of its contributing (cell, a, b) -- the fixed-order
+//       lists of alfi_host_contributors --, turns Dirichlet rows / columns into identity (firedrake.assemble(a, bcs=...)) and
+//       writes the nine value planes coalesced.
+// The same cell kernel in its second mode multiplies the element matrix with the cell's entries of a vector instead of storing
+// it (alfi_level_assemble_mult: the nonlinear residual needs A(u) u once -- no value array is formed), and the SUPG terms
+// are added to E by their own cell kernel before the one gather.
 #include <algorithm>
 #include <cstdlib>
 #include "common.h"
 
 namespace {
 
-template <int D>
-__global__ __launch_bounds__(256) void assemble_gather_kernel(int64_t nnzb, int nloc, const int64_t* __restrict__ cptr,
-                                                               const int32_t* __restrict__ ccell,
-                                                               const uint16_t* __restrict__ cba,
-                                                               const int32_t* __restrict__ cell_nodes,
-                                                               const double* __restrict__ grad, const double* __restrict__ vol,
-                                                               const double* __restrict__ Ta, const double* __restrict__ Tb,
-                                                               const double* __restrict__ Kv, const double* __restrict__ Dv,
-                                                               const double* __restrict__ w, const uint8_t* __restrict__ bc_mask,
-                                                               double nu, double gamma, double adv, int apply_bc,
-                                                               double* __restrict__ out) {
-  constexpr int NV = D + 1, BB = D * D;
-  const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (k >= nnzb) return;
-  double acc[D][D];
+// 16-byte accesses to 8-byte aligned addresses (a d x d block of E starts at a multiple of 8 d d bytes): global memory
+// instructions need dword alignment only
+typedef double d2u __attribute__((ext_vector_type(2), aligned(8)));
+
+template <int BB>
+__device__ inline void store_block(double* dst, const double (&e)[BB]) {
 #pragma unroll
-  for (int cc = 0; cc < D; ++cc)
-#pragma unroll
-    for (int dd = 0; dd < D; ++dd) acc[cc][dd] = 0.0;
-  const int64_t q0 = cptr[k], q1 = cptr[k + 1];
-  int32_t rnode = 0, cnode = 0;
-  {
-    const int32_t cell = ccell[q0];
-    const int ba = cba[q0];
-    rnode = cell_nodes[(int64_t)cell * nloc + ba % nloc];
-    cnode = cell_nodes[(int64_t)cell * nloc + ba / nloc];
+  for (int t = 0; t + 1 < BB; t += 2) {
+    d2u v;
+    v.x = e[t];
+    v.y = e[t + 1];
+    *(d2u*)(dst + t) = v;
   }
-  if (adv != 0.0) {
-    for (int64_t q = q0; q < q1; ++q) {
-      const int32_t cell = ccell[q];
-      const int ba = cba[q];
-      const int32_t* cn = cell_nodes + (int64_t)cell * nloc;
-      double g[NV][D];
+  if (BB & 1) dst[BB - 1] = e[BB - 1];
+}
+template <int BB>
+__device__ inline void load_block(const double* src, double (&e)[BB]) {
 #pragma unroll
-      for (int i = 0; i < NV; ++i)
+  for (int t = 0; t + 1 < BB; t += 2) {
+    const d2u v = *(const d2u*)(src + t);
+    e[t] = v.x;
+    e[t + 1] = v.y;
+  }
+  if (BB & 1) e[BB - 1] = src[BB - 1];
+}
+
+// Element table, per (a, b) TS = 2 (d+1) nloc + (d+1)^2 doubles (alfi_level_set_assembly builds it from S, T1):
+//   [i * nloc + k]                      T1[k, i, b, a]     ((w . grad) u: the state enters through w_k . g_i)
+//   [(d+1) nloc + i * nloc + k]         T1[b, i, k, a]     ((u . grad) w: the state enters through w_k^cc g_i^dd)
+//   [2 (d+1) nloc + i * (d+1) + j]      S[a, b, i, j]      (avg d_i phi_a d_j phi_b)
+// MODE 0: E[slot][a][b][cc d + dd] = the block;  MODE 1: Fe[slot][a][cc] = sum_b block . x_b (x from LDS, a column per lane).
+template <int D, int NLOC, int MODE>
+__global__ __launch_bounds__(64) void element_cell_kernel(int64_t c0, int64_t c1, const int32_t* __restrict__ cell_nodes,
+                                                           const double* __restrict__ grad, const double* __restrict__ vol,
+                                                           const double* __restrict__ etab, const double* __restrict__ bItab,
+                                                           const double* __restrict__ U, const double* __restrict__ X, double nu,
+                                                           double gamma, double gfull, double adv, double* __restrict__ out) {
+  constexpr int NV = D + 1, BB = D * D, TS = 2 * NV * NLOC + NV * NV;
+  __shared__ double xs[MODE == 1 ? NLOC * D * 64 : 1];
+  const int lane = threadIdx.x;
+  const int64_t slot = (int64_t)blockIdx.x * 64 + lane;
+  const bool valid = c0 + slot < c1;
+  const int64_t cell = valid ? c0 + slot : c1 - 1;     // (idle lanes of the last wave repeat the last cell and store nothing)
+  const bool do_adv = adv != 0.0;
+  double g[NV][D];
 #pragma unroll
-        for (int x = 0; x < D; ++x) g[i][x] = grad[((int64_t)cell * NV + i) * D + x];
-      const double* ta = Ta + (int64_t)ba * nloc * NV;      // [k][i] = T1[k, i, b, a]
-      const double* tb = Tb + (int64_t)ba * nloc * NV;      // [i][k] = T1[b, i, k, a]
-      double t1 = 0.0, s[NV][D];
+  for (int i = 0; i < NV; ++i)
 #pragma unroll
-      for (int i = 0; i < NV; ++i)
+    for (int x = 0; x < D; ++x) g[i][x] = grad[(cell * NV + i) * D + x];
+  const double vc = vol[cell];
+  const int32_t* cn = cell_nodes + cell * NLOC;
+  double w[NLOC][D];
 #pragma unroll
-        for (int cc = 0; cc < D; ++cc) s[i][cc] = 0.0;
-      for (int kk = 0; kk < nloc; ++kk) {
-        const int64_t node = cn[kk];
-        double wv[D];
+  for (int k = 0; k < NLOC; ++k) {
+    const int64_t node = cn[k];
 #pragma unroll
-        for (int x = 0; x < D; ++x) wv[x] = w[node * D + x];
-#pragma unroll
-        for (int i = 0; i < NV; ++i) {
-          double wg = 0.0;
-#pragma unroll
-          for (int x = 0; x < D; ++x) wg = __builtin_fma(wv[x], g[i][x], wg);
-          t1 = __builtin_fma(wg, ta[kk * NV + i], t1);
-          const double tbv = tb[i * nloc + kk];
-#pragma unroll
-          for (int cc = 0; cc < D; ++cc) s[i][cc] = __builtin_fma(tbv, wv[cc], s[i][cc]);
-        }
-      }
-      const double vc = vol[cell];
-#pragma unroll
-      for (int cc = 0; cc < D; ++cc)
-#pragma unroll
-        for (int dd = 0; dd < D; ++dd) {
-          double v = cc == dd ? t1 : 0.0;
-#pragma unroll
-          for (int i = 0; i < NV; ++i) v = __builtin_fma(s[i][cc], g[i][dd], v);
-          acc[cc][dd] = __builtin_fma(vc, v, acc[cc][dd]);
-        }
+    for (int x = 0; x < D; ++x) {
+      w[k][x] = do_adv ? U[node * D + x] : 0.0;
+      if (MODE == 1) xs[(k * D + x) * 64 + lane] = X[node * D + x];
     }
   }
-  // A = nu K + gamma D + adv N, Dirichlet rows / columns -> identity; lane-major planes (bsr_val_index, flat layout)
-  uint8_t rb[D], cb[D];
+  const double fa = adv * vc, fn = nu * vc, fg = gfull * vc, fd = gamma * vc;
+#pragma nounroll
+  for (int a = 0; a < NLOC; ++a) {
+    double ba[D];                       // gamma vol (1 / vol) int d_cc phi_a
+#pragma unroll
+    for (int x = 0; x < D; ++x) {
+      double s = 0.0;
+#pragma unroll
+      for (int i = 0; i < NV; ++i) s = __builtin_fma(g[i][x], bItab[a * NV + i], s);
+      ba[x] = fd * s;
+    }
+    double fe[D];
+#pragma unroll
+    for (int x = 0; x < D; ++x) fe[x] = 0.0;
+#pragma nounroll
+    for (int b = 0; b < NLOC; ++b) {
+      const double* __restrict__ t = etab + (size_t)(a * NLOC + b) * TS;
+      double e[BB];
+      {
+        // H[p][q] = int d_p phi_a d_q phi_b = sum_ij S_ab[i][j] g_i^p g_j^q, in two steps
+        double M1[NV][D];
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+#pragma unroll
+          for (int q = 0; q < D; ++q) {
+            double s = 0.0;
+#pragma unroll
+            for (int j = 0; j < NV; ++j) s = __builtin_fma(t[2 * NV * NLOC + i * NV + j], g[j][q], s);
+            M1[i][q] = s;
+          }
+        double H[D][D], gab = 0.0;
+#pragma unroll
+        for (int p = 0; p < D; ++p)
+#pragma unroll
+          for (int q = 0; q < D; ++q) {
+            double s = 0.0;
+#pragma unroll
+            for (int i = 0; i < NV; ++i) s = __builtin_fma(g[i][p], M1[i][q], s);
+            H[p][q] = s;
+            if (p == q) gab += s;
+          }
+        double bb[D];
+#pragma unroll
+        for (int x = 0; x < D; ++x) {
+          double s = 0.0;
+#pragma unroll
+          for (int i = 0; i < NV; ++i) s = __builtin_fma(g[i][x], bItab[b * NV + i], s);
+          bb[x] = s;
+        }
+        // K_(a,cc),(b,dd) = delta_{cc,dd} G_ab + int d_dd phi_a d_cc phi_b;  (div, div) = int d_cc phi_a d_dd phi_b;
+        // cell-averaged grad-div = vol bvec_a^cc bvec_b^dd                                  (host_assemble.cpp:119-139)
+#pragma unroll
+        for (int cc = 0; cc < D; ++cc)
+#pragma unroll
+          for (int dd = 0; dd < D; ++dd) {
+            double v = fn * (H[dd][cc] + (cc == dd ? gab : 0.0));
+            v = __builtin_fma(fg, H[cc][dd], v);
+            e[cc * D + dd] = __builtin_fma(ba[cc], bb[dd], v);
+          }
+      }
+      if (do_adv) {
+        double R[NV][D], S2[NV][D];
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+#pragma unroll
+          for (int x = 0; x < D; ++x) R[i][x] = S2[i][x] = 0.0;
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+#pragma unroll
+          for (int k = 0; k < NLOC; ++k) {
+            const double ta = t[i * NLOC + k], tb = t[NV * NLOC + i * NLOC + k];
+#pragma unroll
+            for (int x = 0; x < D; ++x) {
+              R[i][x] = __builtin_fma(ta, w[k][x], R[i][x]);
+              S2[i][x] = __builtin_fma(tb, w[k][x], S2[i][x]);
+            }
+          }
+        double t1 = 0.0;                 // sum_{k,i} (w_k . g_i) T1[k,i,b,a]
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+#pragma unroll
+          for (int x = 0; x < D; ++x) t1 = __builtin_fma(g[i][x], R[i][x], t1);
+#pragma unroll
+        for (int cc = 0; cc < D; ++cc)
+#pragma unroll
+          for (int dd = 0; dd < D; ++dd) {
+            double v = cc == dd ? t1 : 0.0;
+#pragma unroll
+            for (int i = 0; i < NV; ++i) v = __builtin_fma(S2[i][cc], g[i][dd], v);
+            e[cc * D + dd] = __builtin_fma(fa, v, e[cc * D + dd]);
+          }
+      }
+      if (MODE == 0) {
+        if (valid) store_block<BB>(out + ((slot * NLOC + a) * NLOC + b) * BB, e);
+      } else {
+#pragma unroll
+        for (int dd = 0; dd < D; ++dd) {
+          const double xv = xs[(b * D + dd) * 64 + lane];
+#pragma unroll
+          for (int cc = 0; cc < D; ++cc) fe[cc] = __builtin_fma(e[cc * D + dd], xv, fe[cc]);
+        }
+      }
+    }
+    if (MODE == 1 && valid) {
+#pragma unroll
+      for (int cc = 0; cc < D; ++cc) out[(slot * NLOC + a) * D + cc] = fe[cc];
+    }
+  }
+}
+
+// bits 0 .. D-1: Dirichlet flags of the block's row dofs, bits 3 .. 3+D-1: of its column dofs, bit 6: diagonal block
+template <int D>
+__global__ __launch_bounds__(256) void bc_code_kernel(int64_t nnzb, int nloc, const int64_t* __restrict__ cptr,
+                                                       const int32_t* __restrict__ ccell, const uint16_t* __restrict__ cba,
+                                                       const int32_t* __restrict__ cell_nodes, const uint8_t* __restrict__ bc_mask,
+                                                       uint8_t* __restrict__ code) {
+  const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (k >= nnzb) return;
+  const int64_t q0 = cptr[k];
+  const int32_t cell = ccell[q0];
+  const int ba = cba[q0];
+  const int64_t rnode = cell_nodes[(int64_t)cell * nloc + ba % nloc], cnode = cell_nodes[(int64_t)cell * nloc + ba / nloc];
+  unsigned c = rnode == cnode ? 64u : 0u;
 #pragma unroll
   for (int x = 0; x < D; ++x) {
-    rb[x] = apply_bc ? bc_mask[(int64_t)rnode * D + x] : 0;
-    cb[x] = apply_bc ? bc_mask[(int64_t)cnode * D + x] : 0;
+    if (bc_mask[rnode * D + x]) c |= 1u << x;
+    if (bc_mask[cnode * D + x]) c |= 8u << x;
   }
+  code[k] = (uint8_t)c;
+}
+
+// vals (lane-major planes of the level operator) = / += the element blocks of the cells [c0, c1) in E, every block adding its
+// contributors in list order; then (apply_bc) identity on Dirichlet rows / columns
+template <int D>
+__global__ __launch_bounds__(256) void element_gather_kernel(int64_t nnzb, int nloc, int64_t c0, int64_t c1,
+                                                              const int64_t* __restrict__ cptr, const int32_t* __restrict__ ccell,
+                                                              const uint16_t* __restrict__ cba, const double* __restrict__ E,
+                                                              const uint8_t* __restrict__ code, int accumulate, int apply_bc,
+                                                              double* __restrict__ vals) {
+  constexpr int BB = D * D;
+  const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (k >= nnzb) return;
+  // (accumulate: continue from the value in place, so that batches of cells add up in the order of one pass over the list)
+  double acc[BB];
+#pragma unroll
+  for (int t = 0; t < BB; ++t) acc[t] = accumulate ? vals[bsr_val_index(1, k, t, BB)] : 0.0;
+  bool any = false;
+  const int64_t q1 = cptr[k + 1];
+  for (int64_t q = cptr[k]; q < q1; ++q) {
+    const int64_t cell = ccell[q];
+    if (cell < c0 || cell >= c1) continue;
+    any = true;
+    const unsigned ba = cba[q], b = ba / (unsigned)nloc, a = ba - b * (unsigned)nloc;
+    double e[BB];
+    load_block<BB>(E + (((cell - c0) * nloc + a) * nloc + b) * BB, e);
+#pragma unroll
+    for (int t = 0; t < BB; ++t) acc[t] += e[t];
+  }
+  if (accumulate && !any && !apply_bc) return;
+  const unsigned c = apply_bc ? code[k] : 0u;
 #pragma unroll
   for (int cc = 0; cc < D; ++cc)
 #pragma unroll
     for (int dd = 0; dd < D; ++dd) {
       const int64_t at = bsr_val_index(1, k, cc * D + dd, BB);
-      double v = __builtin_fma(nu, Kv[at], __builtin_fma(gamma, Dv[at], adv * acc[cc][dd]));
-      if (rb[cc] || cb[dd]) v = (rb[cc] && cb[dd] && rnode == cnode && cc == dd) ? 1.0 : 0.0;
-      out[at] = v;
+      double v = acc[cc * D + dd];
+      const bool rb = (c >> cc) & 1u, cb = (c >> (3 + dd)) & 1u;
+      if (rb || cb) v = (rb && cb && (c & 64u) && cc == dd) ? 1.0 : 0.0;
+      vals[at] = v;
     }
+}
+
+// F (the level's n dofs) = / += the element vectors Fe[cell][a][d]: node r through the contributor list of its diagonal block
+// (which holds exactly the (cell, a, a) with node a of the cell == r), in list order
+template <int D>
+__global__ __launch_bounds__(256) void cell_vector_gather_kernel(int64_t nnode, int nloc, const int32_t* __restrict__ diag,
+                                                                  const int64_t* __restrict__ cptr, const int32_t* __restrict__ ccell,
+                                                                  const uint16_t* __restrict__ cba, const double* __restrict__ Fe,
+                                                                  int add, double* __restrict__ F) {
+  const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (r >= nnode) return;
+  const int64_t k = diag[r];
+  double acc[D];
+#pragma unroll
+  for (int i = 0; i < D; ++i) acc[i] = add ? F[r * D + i] : 0.0;
+  const int64_t q1 = cptr[k + 1];
+  for (int64_t q = cptr[k]; q < q1; ++q) {
+    const int64_t cell = ccell[q];
+    const int a = cba[q] % nloc;
+#pragma unroll
+    for (int i = 0; i < D; ++i) acc[i] += Fe[(cell * nloc + a) * D + i];
+  }
+#pragma unroll
+  for (int i = 0; i < D; ++i) F[r * D + i] = acc[i];
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -121,21 +291,19 @@ __global__ __launch_bounds__(256) void assemble_gather_kernel(int64_t nnzb, int 
 // by quadrature (beta is not polynomial): residual contribution and its exact Newton linearisation, the same formulas as
 // csrc/host_assemble.cpp:alfi_host_supg.
 //
-// Two phases, no atomics.  (1) supg_cell_kernel: one wave per cell forms the element matrix (ndof x ndof, ndof = nloc d) and the
-// element residual over the quadrature points: per point the physical gradients / Hessians of the basis (a lane per local
-// node), the state quantities u, grad u, Lu (a lane per output), then every lane accumulates its ndof^2 / 64 entries in
-// registers; results go to a scratch array (cells x ndof^2).  (2) supg_gather_kernel: one thread per BSR block adds the
-// entries of its contributing cells in the fixed order of the contributor lists (the lists of the advection assembly);
-// supg_residual_kernel does the same per node through the diagonal block's list.
+// The linearisation: supg_cell_kernel, one wave per cell, forms the element matrix (ndof x ndof, ndof = nloc d) over the
+// quadrature points -- per point the physical gradients / Hessians of the basis (a lane per local node and direction), the
+// state quantities u, grad u, Lu (a lane per output), then every lane accumulates its ndof^2 / 64 entries in registers -- and
+// writes (or adds) it into the scratch of the element blocks E; the one gather of the refresh (element_gather_kernel) sums it
+// into the operator together with the other terms.  The residual: supg_residual_cell_kernel below, a lane per cell.
 // ---------------------------------------------------------------------------------------------------------------------
-template <int D, int EPL, bool WANT>
+template <int D, int EPL>
 __global__ __launch_bounds__(64) void supg_cell_kernel(int64_t cell0, int64_t ncell, int nloc, const int32_t* __restrict__ cell_nodes,
                                                         const double* __restrict__ grad, const double* __restrict__ vol,
                                                         const double* __restrict__ hcell, int nq, const double* __restrict__ wq,
                                                         const double* __restrict__ phi, const double* __restrict__ dphi,
                                                         const double* __restrict__ d2phi, const double* __restrict__ U, double nu,
-                                                        double weight, double magic, int want_vals, double* __restrict__ Ae_out,
-                                                        double* __restrict__ Fe_out) {
+                                                        double weight, double magic, int add, double* __restrict__ E) {
   constexpr int NV = D + 1;
   extern __shared__ double sm[];
   const int64_t cell = cell0 + blockIdx.x;
@@ -160,17 +328,16 @@ __global__ __launch_bounds__(64) void supg_cell_kernel(int64_t cell0, int64_t nc
   for (int e = lane; e < ndof; e += 64) Uk[e] = U[(int64_t)cn[e / D] * D + e % D];
   const double hc = hcell[cell], h2 = hc * hc;
   const double vw = vol[cell] * weight;
-  double acc[WANT ? EPL : 1];
+  double acc[EPL];
 #pragma unroll
-  for (int t = 0; t < (WANT ? EPL : 1); ++t) acc[t] = 0.0;
-  double facc = 0.0;                     // element residual entry `lane` (ndof <= 64)
+  for (int t = 0; t < EPL; ++t) acc[t] = 0.0;
   // entry e = (row (a, i), column (b, j)) of this lane's t-th entry, decomposed ONCE: the places of its four factors in the
   // per-point tables, a byte each (saw[a] | c1[(b D + i) D + j] | c2w[b D + i] | gp[a D + j]).  (Round 3 divided e by ndof and
   // by D inside the loop over the quadrature points: ~150 integer instructions per entry and point around 25 flops -- the
   // kernel took 0.9 s per refresh of config 4's finest level, half of a Newton step with SUPG.)
-  uint32_t pk[WANT ? EPL : 1];
+  uint32_t pk[EPL];
 #pragma unroll
-  for (int t = 0; t < (WANT ? EPL : 1); ++t) {
+  for (int t = 0; t < EPL; ++t) {
     const int e = lane + 64 * t;
     pk[t] = 0;
     if (e < ndof * ndof) {
@@ -268,24 +435,12 @@ __global__ __launch_bounds__(64) void supg_cell_kernel(int64_t cell0, int64_t nc
     const double beta = 1.0 / sqrt(4.0 * uu / h2 + magic * vis * vis);
     const double b3 = -4.0 * beta * beta * beta / h2;
     const double wt = wq[q] * vw;
-    // ---- element residual: entry (a, i) = lane
-    if (lane < ndof) {
-      const int a = lane / D, i = lane % D;
-      double sa = 0.0;
-#pragma unroll
-      for (int x = 0; x < D; ++x) sa = __builtin_fma(u[x], gp[a * D + x], sa);
-      // (component select without dynamic register indexing)
-      double Li = Lu[0];
-#pragma unroll
-      for (int t = 1; t < D; ++t) Li = i == t ? Lu[t] : Li;
-      facc = __builtin_fma(wt * beta * Li, sa, facc);
-    }
     // ---- element matrix.  Entry ((a, i), (b, j)) at this point is
     //        wt (b3 u_j phi_b L_i s_a + beta dL_bij s_a + beta L_i phi_b dphi_a/dx_j),   s_a = u . grad phi_a,
     //        dL_bij = phi_b G_ij - nu H_b[i][j] + delta_ij (- nu lap_b + s_b)
     //      = saw[a] c1[b, i, j] + c2w[b, i] gp[a, j]   with the three tables below (nloc + nloc D D + nloc D values per point,
     //      formed once by the wave instead of once per entry): two FMAs and four LDS reads per entry.
-    if (WANT) {
+    {
       if (lane < nloc) {
         double sa = 0.0;
 #pragma unroll
@@ -324,78 +479,144 @@ __global__ __launch_bounds__(64) void supg_cell_kernel(int64_t cell0, int64_t nc
     }
     __syncthreads();     // the next point overwrites gp / hs / st
   }
-  const int64_t slot = blockIdx.x;
-  if (lane < ndof) Fe_out[slot * ndof + lane] = facc;
-  if (WANT) {
+  // into the scratch of the element blocks, E[slot][a][b][i D + j] (element_cell_kernel's layout; add: on top of its values)
+  double* Ec = E + (int64_t)blockIdx.x * nloc * nloc * (D * D);
 #pragma unroll
-    for (int t = 0; t < EPL; ++t) {
-      const int e = lane + 64 * t;
-      if (e < ndof * ndof) Ae_out[slot * (int64_t)ndof * ndof + e] = acc[t];
+  for (int t = 0; t < EPL; ++t) {
+    const int e = lane + 64 * t;
+    if (e < ndof * ndof) {
+      const int row = e / ndof, col = e % ndof;
+      const int at = ((row / D) * nloc + col / D) * (D * D) + (row % D) * D + col % D;
+      Ec[at] = add ? Ec[at] + acc[t] : acc[t];
     }
   }
 }
 
-// vals (lane-major planes of the level operator) += the element matrices of the cells [cell0, cell0 + nslot) -- every block adds
-// the entries of its contributors that lie in that cell range, in list order
-template <int D>
-__global__ __launch_bounds__(256) void supg_gather_kernel(int64_t nnzb, int nloc, int64_t cell0, int64_t nslot,
-                                                           const int64_t* __restrict__ cptr, const int32_t* __restrict__ ccell,
-                                                           const uint16_t* __restrict__ cba, const double* __restrict__ Ae,
-                                                           double* __restrict__ vals) {
-  constexpr int BB = D * D;
-  const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (k >= nnzb) return;
-  const int ndof = nloc * D;
-  double acc[D][D];
+// SUPG residual only (every Newton step evaluates it once more than it refreshes the operator): a LANE per cell, everything in
+// registers -- per quadrature point the physical gradients / Hessians of the basis functions one after the other (tabulated
+// values are wave-uniform scalar operands), the state quantities accumulated on the way, then the element residual
+// F_(a,i) += wt beta Lu_i (u . grad phi_a).  (Round 4: the wave-per-cell kernel with the matrix part compiled out took 99.7 ms
+// for config 4's finest level -- five barriers per point with a handful of lanes busy between them.)
+template <int D, int NLOC>
+__global__ __launch_bounds__(64) void supg_residual_cell_kernel(int64_t ncell, const int32_t* __restrict__ cell_nodes,
+                                                                 const double* __restrict__ grad, const double* __restrict__ vol,
+                                                                 const double* __restrict__ hcell, int nq,
+                                                                 const double* __restrict__ wq, const double* __restrict__ phi,
+                                                                 const double* __restrict__ dphi, const double* __restrict__ d2phi,
+                                                                 const double* __restrict__ U, double nu, double weight, double magic,
+                                                                 double* __restrict__ Fe) {
+  constexpr int NV = D + 1;
+  const int64_t slot = (int64_t)blockIdx.x * 64 + threadIdx.x;
+  const bool valid = slot < ncell;
+  const int64_t cell = valid ? slot : ncell - 1;
+  double g[NV][D];
 #pragma unroll
-  for (int cc = 0; cc < D; ++cc)
+  for (int i = 0; i < NV; ++i)
 #pragma unroll
-    for (int dd = 0; dd < D; ++dd) acc[cc][dd] = 0.0;
-  bool any = false;
-  for (int64_t q = cptr[k]; q < cptr[k + 1]; ++q) {
-    const int64_t cell = ccell[q];
-    if (cell < cell0 || cell >= cell0 + nslot) continue;
-    any = true;
-    const int ba = cba[q], a = ba % nloc, b = ba / nloc;
-    const double* M = Ae + (cell - cell0) * (int64_t)ndof * ndof + (int64_t)(a * D) * ndof + b * D;
+    for (int x = 0; x < D; ++x) g[i][x] = grad[(cell * NV + i) * D + x];
+  const int32_t* cn = cell_nodes + cell * NLOC;
+  double Uk[NLOC][D], F[NLOC][D];
 #pragma unroll
-    for (int cc = 0; cc < D; ++cc)
+  for (int k = 0; k < NLOC; ++k) {
+    const int64_t node = cn[k];
 #pragma unroll
-      for (int dd = 0; dd < D; ++dd) acc[cc][dd] += M[cc * ndof + dd];
-  }
-  if (!any) return;
-#pragma unroll
-  for (int cc = 0; cc < D; ++cc)
-#pragma unroll
-    for (int dd = 0; dd < D; ++dd) {
-      const int64_t at = bsr_val_index(1, k, cc * D + dd, BB);
-      vals[at] += acc[cc][dd];
+    for (int x = 0; x < D; ++x) {
+      Uk[k][x] = U[node * D + x];
+      F[k][x] = 0.0;
     }
-}
-
-// F (n dofs) += the element residuals of the cells [cell0, cell0 + nslot): node r through the contributor list of its diagonal
-// block (which holds exactly the (cell, a, a) with node a of the cell == r)
-template <int D>
-__global__ __launch_bounds__(256) void supg_residual_kernel(int64_t nnode, int nloc, int64_t cell0, int64_t nslot,
-                                                             const int32_t* __restrict__ diag, const int64_t* __restrict__ cptr,
-                                                             const int32_t* __restrict__ ccell, const uint16_t* __restrict__ cba,
-                                                             const double* __restrict__ Fe, double* __restrict__ F) {
-  const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (r >= nnode) return;
-  const int ndof = nloc * D;
-  const int64_t k = diag[r];
-  double acc[D];
-#pragma unroll
-  for (int i = 0; i < D; ++i) acc[i] = 0.0;
-  for (int64_t q = cptr[k]; q < cptr[k + 1]; ++q) {
-    const int64_t cell = ccell[q];
-    if (cell < cell0 || cell >= cell0 + nslot) continue;
-    const int a = cba[q] % nloc;
-#pragma unroll
-    for (int i = 0; i < D; ++i) acc[i] += Fe[(cell - cell0) * ndof + a * D + i];
   }
+  const double hc = hcell[cell], h2 = hc * hc;
+  const double vw = vol[cell] * weight;
+  const double vis = 4.0 * nu / h2;
+#pragma nounroll
+  for (int q = 0; q < nq; ++q) {
+    const double* __restrict__ ph = phi + (size_t)q * NLOC;
+    const double* __restrict__ dp = dphi + (size_t)q * NLOC * NV;
+    const double* __restrict__ hp = d2phi + (size_t)q * NLOC * NV * NV;
+    double u[D], Gu[D][D], Ls[D];
 #pragma unroll
-  for (int i = 0; i < D; ++i) F[r * D + i] += acc[i];
+    for (int i = 0; i < D; ++i) {
+      u[i] = Ls[i] = 0.0;
+#pragma unroll
+      for (int x = 0; x < D; ++x) Gu[i][x] = 0.0;
+    }
+#pragma unroll
+    for (int a = 0; a < NLOC; ++a) {
+      double gp[D];
+#pragma unroll
+      for (int x = 0; x < D; ++x) {
+        double s = 0.0;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) s = __builtin_fma(dp[a * NV + i], g[i][x], s);
+        gp[x] = s;
+      }
+      // physical Hessian G^T H_a G (symmetric), M = H_a G first
+      double M[NV][D];
+#pragma unroll
+      for (int i = 0; i < NV; ++i)
+#pragma unroll
+        for (int y = 0; y < D; ++y) {
+          double s = 0.0;
+#pragma unroll
+          for (int k = 0; k < NV; ++k) s = __builtin_fma(hp[(a * NV + i) * NV + k], g[k][y], s);
+          M[i][y] = s;
+        }
+      double hs[D][D], la = 0.0;
+#pragma unroll
+      for (int x = 0; x < D; ++x)
+#pragma unroll
+        for (int y = x; y < D; ++y) {
+          double s = 0.0;
+#pragma unroll
+          for (int i = 0; i < NV; ++i) s = __builtin_fma(g[i][x], M[i][y], s);
+          hs[x][y] = hs[y][x] = s;
+          if (x == y) la += s;
+        }
+      const double pa = ph[a];
+#pragma unroll
+      for (int i = 0; i < D; ++i) {
+        const double ui = Uk[a][i];
+        u[i] = __builtin_fma(pa, ui, u[i]);
+#pragma unroll
+        for (int x = 0; x < D; ++x) Gu[i][x] = __builtin_fma(gp[x], ui, Gu[i][x]);
+        Ls[i] = __builtin_fma(-nu * la, ui, Ls[i]);                                   // -nu Lap u_i
+#pragma unroll
+        for (int j = 0; j < D; ++j) Ls[j] = __builtin_fma(-nu * hs[j][i], ui, Ls[j]);   // -nu d_j div u
+      }
+    }
+    double uu = 0.0, c[D];
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+      double t = Ls[i];
+#pragma unroll
+      for (int x = 0; x < D; ++x) t = __builtin_fma(u[x], Gu[i][x], t);
+      c[i] = t;
+      uu = __builtin_fma(u[i], u[i], uu);
+    }
+    const double beta = 1.0 / sqrt(4.0 * uu / h2 + magic * vis * vis);
+    const double wb = wq[q] * vw * beta;
+#pragma unroll
+    for (int i = 0; i < D; ++i) c[i] *= wb;
+#pragma unroll
+    for (int a = 0; a < NLOC; ++a) {
+      double sa = 0.0;                   // u . grad phi_a (the gradient formed again: 12 FMAs against 3 registers kept per node)
+#pragma unroll
+      for (int x = 0; x < D; ++x) {
+        double s = 0.0;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) s = __builtin_fma(dp[a * NV + i], g[i][x], s);
+        sa = __builtin_fma(u[x], s, sa);
+      }
+#pragma unroll
+      for (int i = 0; i < D; ++i) F[a][i] = __builtin_fma(c[i], sa, F[a][i]);
+    }
+  }
+  if (valid) {
+#pragma unroll
+    for (int a = 0; a < NLOC; ++a)
+#pragma unroll
+      for (int i = 0; i < D; ++i) Fe[(slot * NLOC + a) * D + i] = F[a][i];
+  }
 }
 
 // Dirichlet rows / columns of the level operator -> identity (what firedrake.assemble(a, bcs=...) produces), after the terms
@@ -427,85 +648,162 @@ __global__ void vals_from_lanes_kernel(const double* __restrict__ src, double* _
     dst[e] = src[bsr_val_index(1, e / bb, (int)(e % bb), bb)];
 }
 
+
 }  // namespace
 
-int launch_assemble_gather(alfi_level* L, double nu, double gamma, double adv, const double* d_state, int apply_bc,
-                           double* out_vals) {
+// ---- launches ----------------------------------------------------------------------------------------------------------
+#define ALFI_ELEMENT_DISPATCH(d, nloc, WHAT)                                   \
+  do {                                                                         \
+    if (d == 2 && nloc == 3) { WHAT(2, 3); }                                   \
+    else if (d == 2 && nloc == 6) { WHAT(2, 6); }                              \
+    else if (d == 2 && nloc == 10) { WHAT(2, 10); }                            \
+    else if (d == 3 && nloc == 4) { WHAT(3, 4); }                              \
+    else if (d == 3 && nloc == 8) { WHAT(3, 8); }                              \
+    else if (d == 3 && nloc == 10) { WHAT(3, 10); }                            \
+    else if (d == 3 && nloc == 14) { WHAT(3, 14); }                            \
+    else if (d == 3 && nloc == 20) { WHAT(3, 20); }                            \
+    else return alfi_set_error(ctx, ALFI_E_ARG, "no element kernel for %d nodes per cell in %d-D", nloc, d); \
+  } while (0)
+
+bool element_kernel_exists(int d, int nloc) {
+  return (d == 2 && (nloc == 3 || nloc == 6 || nloc == 10)) || (d == 3 && (nloc == 4 || nloc == 8 || nloc == 10 || nloc == 14 || nloc == 20));
+}
+
+static int ensure_scratch(alfi_ctx* ctx, size_t bytes) {
+  if (ctx->asm_scratch_bytes >= bytes) return 0;
+  ALFI_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  (void)hipFree(ctx->asm_scratch);
+  ctx->asm_scratch = nullptr;
+  ctx->asm_scratch_bytes = 0;
+  ALFI_HIP_CHECK(ctx, hipMalloc(&ctx->asm_scratch, bytes));
+  ctx->asm_scratch_bytes = bytes;
+  return 0;
+}
+
+static int ensure_bc_code(alfi_level* L) {
   alfi_ctx* ctx = L->ctx;
-  const AssemblyDev& S = L->asmb;
+  AssemblyDev& S = L->asmb;
+  if (S.bc_code) return 0;
   const int64_t nnzb = L->A.nnzb;
+  ALFI_HIP_CHECK(ctx, hipMalloc((void**)&S.bc_code, (size_t)std::max<int64_t>(nnzb, 1)));
   dim3 grid((unsigned)((nnzb + 255) / 256)), block(256);
+  const uint8_t* mask = S.bc_all ? S.bc_all : L->bc_mask;
   if (L->bs == 2)
-    hipLaunchKernelGGL(assemble_gather_kernel<2>, grid, block, 0, ctx->stream, nnzb, S.nloc, S.cptr, S.ccell, S.cba, S.cell_nodes,
-                       S.grad, S.vol, S.Ta, S.Tb, S.Kv, S.Dv, d_state, S.bc_all ? S.bc_all : L->bc_mask, nu, gamma, adv, apply_bc, out_vals);
+    hipLaunchKernelGGL(bc_code_kernel<2>, grid, block, 0, ctx->stream, nnzb, S.nloc, S.cptr, S.ccell, S.cba, S.cell_nodes, mask, S.bc_code);
   else
-    hipLaunchKernelGGL(assemble_gather_kernel<3>, grid, block, 0, ctx->stream, nnzb, S.nloc, S.cptr, S.ccell, S.cba, S.cell_nodes,
-                       S.grad, S.vol, S.Ta, S.Tb, S.Kv, S.Dv, d_state, S.bc_all ? S.bc_all : L->bc_mask, nu, gamma, adv, apply_bc, out_vals);
+    hipLaunchKernelGGL(bc_code_kernel<3>, grid, block, 0, ctx->stream, nnzb, S.nloc, S.cptr, S.ccell, S.cba, S.cell_nodes, mask, S.bc_code);
   ALFI_HIP_CHECK(ctx, hipGetLastError());
   return 0;
 }
 
-// SUPG terms about d_state: the Newton linearisation added to the level operator (add_vals), the residual contribution added to
-// d_F (may be NULL); cells in batches bounded by ALFI_SUPG_SCRATCH_MB (default 4096) of element-matrix scratch
-int launch_supg(alfi_level* L, double nu, double weight, double magic, const double* d_state, int add_vals, double* d_F) {
+// The level operator from its cells: vals = [vals +] sum over the contributing cells of
+//     (nu K_e + gamma D_e + adv N_e(state))   (with_elements)   +   the linearised SUPG term (with_supg),
+// Dirichlet rows / columns -> identity (apply_bc).  Cells in batches when the scratch of element blocks would exceed the ctx's
+// limit (alfi_ctx_set_assembly_scratch; config 4's finest level: 14.9 GB in one batch).
+int launch_operator_refresh(alfi_level* L, double nu, double gamma, double adv, const double* d_state, bool with_elements,
+                            bool with_supg, double weight, double magic, bool accumulate, bool apply_bc, double* out_vals) {
+  alfi_ctx* ctx = L->ctx;
+  AssemblyDev& S = L->asmb;
+  const int d = L->bs, nloc = S.nloc, ndof = nloc * d;
+  const int64_t nnzb = L->A.nnzb;
+  if (apply_bc) ALFI_CHECK(ensure_bc_code(L));
+  const int64_t per_cell = (int64_t)ndof * ndof * 8;
+  int64_t batch = std::max<int64_t>(1, ctx->asm_scratch_limit / per_cell);
+  if (batch > S.ncell) batch = S.ncell;
+  ALFI_CHECK(ensure_scratch(ctx, (size_t)(batch * per_cell)));
+  double* E = (double*)ctx->asm_scratch;
+  const double gcell = S.full_div ? 0.0 : gamma, gfull = S.full_div ? gamma : 0.0;
+  const int epl = (ndof * ndof + 63) / 64;
+  const size_t lds = sizeof(double) * (size_t)(2 * nloc * d + nloc * d * d + 2 * nloc + 2 * d + d * d + nloc + nloc * d + nloc * d * d);
+  for (int64_t c0 = 0; c0 < S.ncell; c0 += batch) {
+    const int64_t c1 = std::min<int64_t>(c0 + batch, S.ncell);
+    if (with_elements) {
+      dim3 grid((unsigned)((c1 - c0 + 63) / 64)), block(64);
+#define ALFI_EL0(DV, NL)                                                                                                          \
+  hipLaunchKernelGGL((element_cell_kernel<DV, NL, 0>), grid, block, 0, ctx->stream, c0, c1, S.cell_nodes, S.grad, S.vol, S.etab, \
+                     S.bItab, d_state, (const double*)nullptr, nu, gcell, gfull, adv, E)
+      ALFI_ELEMENT_DISPATCH(d, nloc, ALFI_EL0);
+#undef ALFI_EL0
+      ALFI_HIP_CHECK(ctx, hipGetLastError());
+    }
+    if (with_supg) {
+      dim3 grid((unsigned)(c1 - c0)), block(64);
+      const int add = with_elements ? 1 : 0;
+#define ALFI_SUPG_CELL(DV, EV)                                                                                                   \
+  hipLaunchKernelGGL((supg_cell_kernel<DV, EV>), grid, block, lds, ctx->stream, c0, S.ncell, nloc, S.cell_nodes, S.grad, S.vol,  \
+                     S.hcell, S.nq, S.wq, S.phi, S.dphi, S.d2phi, d_state, nu, weight, magic, add, E)
+      if (d == 2) {
+        if (epl <= 4) ALFI_SUPG_CELL(2, 4); else if (epl <= 16) ALFI_SUPG_CELL(2, 16); else ALFI_SUPG_CELL(2, 64);
+      } else {
+        if (epl <= 16) ALFI_SUPG_CELL(3, 16); else if (epl <= 32) ALFI_SUPG_CELL(3, 32); else ALFI_SUPG_CELL(3, 64);
+      }
+#undef ALFI_SUPG_CELL
+      ALFI_HIP_CHECK(ctx, hipGetLastError());
+    }
+    dim3 g2((unsigned)((nnzb + 255) / 256)), b2(256);
+    const int acc = (accumulate || c0 > 0) ? 1 : 0, bc = (apply_bc && c1 == S.ncell) ? 1 : 0;
+    if (d == 2)
+      hipLaunchKernelGGL(element_gather_kernel<2>, g2, b2, 0, ctx->stream, nnzb, nloc, c0, c1, S.cptr, S.ccell, S.cba, E, S.bc_code, acc, bc, out_vals);
+    else
+      hipLaunchKernelGGL(element_gather_kernel<3>, g2, b2, 0, ctx->stream, nnzb, nloc, c0, c1, S.cptr, S.ccell, S.cba, E, S.bc_code, acc, bc, out_vals);
+    ALFI_HIP_CHECK(ctx, hipGetLastError());
+  }
+  return 0;
+}
+
+static int gather_cell_vectors(alfi_level* L, const double* Fe, int add, double* d_F) {
   alfi_ctx* ctx = L->ctx;
   const AssemblyDev& S = L->asmb;
-  const int d = L->bs, nloc = S.nloc, ndof = nloc * d;
-  static const int64_t scratch_mb = getenv("ALFI_SUPG_SCRATCH_MB") ? atoll(getenv("ALFI_SUPG_SCRATCH_MB")) : 4096;
-  const int64_t per_cell = (add_vals ? (int64_t)ndof * ndof : 0) + ndof;
-  int64_t batch = std::max<int64_t>(1, (scratch_mb << 20) / (8 * per_cell));
-  if (batch > S.ncell) batch = S.ncell;
-  double *Ae = nullptr, *Fe = nullptr;
-  if (add_vals) ALFI_HIP_CHECK(ctx, hipMalloc((void**)&Ae, sizeof(double) * (size_t)(batch * ndof * ndof)));
-  hipError_t e = hipMalloc((void**)&Fe, sizeof(double) * (size_t)(batch * ndof));
-  if (e != hipSuccess) {
-    (void)hipFree(Ae);
-    return alfi_set_error(ctx, ALFI_E_HIP, "SUPG scratch: %s", hipGetErrorString(e));
-  }
-  const size_t lds = sizeof(double) * (size_t)(2 * nloc * d + nloc * d * d + 2 * nloc + 2 * d + d * d + nloc + nloc * d + nloc * d * d);
-  const int epl = (ndof * ndof + 63) / 64;
-  const int64_t nnzb = L->A.nnzb, nnode = L->A.nbrows;
-  int rc = 0;
-  for (int64_t c0 = 0; c0 < S.ncell && rc == 0; c0 += batch) {
-    const int64_t nb = std::min<int64_t>(batch, S.ncell - c0);
-    dim3 grid((unsigned)nb), block(64);
-#define ALFI_SUPG_CELL(DV, EV)                                                                                                  \
-  do {                                                                                                                          \
-    if (add_vals)                                                                                                               \
-      hipLaunchKernelGGL((supg_cell_kernel<DV, EV, true>), grid, block, lds, ctx->stream, c0, S.ncell, nloc, S.cell_nodes,      \
-                         S.grad, S.vol, S.hcell, S.nq, S.wq, S.phi, S.dphi, S.d2phi, d_state, nu, weight, magic, 1, Ae, Fe);    \
-    else                                                                                                                        \
-      hipLaunchKernelGGL((supg_cell_kernel<DV, 1, false>), grid, block, lds, ctx->stream, c0, S.ncell, nloc, S.cell_nodes,      \
-                         S.grad, S.vol, S.hcell, S.nq, S.wq, S.phi, S.dphi, S.d2phi, d_state, nu, weight, magic, 0, Ae, Fe);    \
-  } while (0)
-    if (d == 2) {
-      if (epl <= 4) ALFI_SUPG_CELL(2, 4); else if (epl <= 16) ALFI_SUPG_CELL(2, 16); else ALFI_SUPG_CELL(2, 64);
-    } else {
-      if (epl <= 16) ALFI_SUPG_CELL(3, 16); else if (epl <= 32) ALFI_SUPG_CELL(3, 32); else ALFI_SUPG_CELL(3, 64);
-    }
-#undef ALFI_SUPG_CELL
-    if (hipGetLastError() != hipSuccess) rc = alfi_set_error(ctx, ALFI_E_HIP, "supg_cell_kernel launch failed");
-    if (rc == 0 && add_vals) {
-      dim3 g2((unsigned)((nnzb + 255) / 256)), b2(256);
-      if (d == 2)
-        hipLaunchKernelGGL(supg_gather_kernel<2>, g2, b2, 0, ctx->stream, nnzb, nloc, c0, nb, S.cptr, S.ccell, S.cba, Ae, L->A.vals);
-      else
-        hipLaunchKernelGGL(supg_gather_kernel<3>, g2, b2, 0, ctx->stream, nnzb, nloc, c0, nb, S.cptr, S.ccell, S.cba, Ae, L->A.vals);
-      if (hipGetLastError() != hipSuccess) rc = alfi_set_error(ctx, ALFI_E_HIP, "supg_gather_kernel launch failed");
-    }
-    if (rc == 0 && d_F) {
-      dim3 g3((unsigned)((nnode + 255) / 256)), b3(256);
-      if (d == 2)
-        hipLaunchKernelGGL(supg_residual_kernel<2>, g3, b3, 0, ctx->stream, nnode, nloc, c0, nb, S.diag, S.cptr, S.ccell, S.cba, Fe, d_F);
-      else
-        hipLaunchKernelGGL(supg_residual_kernel<3>, g3, b3, 0, ctx->stream, nnode, nloc, c0, nb, S.diag, S.cptr, S.ccell, S.cba, Fe, d_F);
-      if (hipGetLastError() != hipSuccess) rc = alfi_set_error(ctx, ALFI_E_HIP, "supg_residual_kernel launch failed");
-    }
-  }
-  (void)hipStreamSynchronize(ctx->stream);
-  (void)hipFree(Ae);
-  (void)hipFree(Fe);
-  return rc;
+  const int64_t nnode = L->A.nbrows;
+  dim3 g3((unsigned)((nnode + 255) / 256)), b3(256);
+  if (L->bs == 2)
+    hipLaunchKernelGGL(cell_vector_gather_kernel<2>, g3, b3, 0, ctx->stream, nnode, S.nloc, S.diag, S.cptr, S.ccell, S.cba, Fe, add, d_F);
+  else
+    hipLaunchKernelGGL(cell_vector_gather_kernel<3>, g3, b3, 0, ctx->stream, nnode, S.nloc, S.diag, S.cptr, S.ccell, S.cba, Fe, add, d_F);
+  ALFI_HIP_CHECK(ctx, hipGetLastError());
+  return 0;
+}
+
+// dy (the level's rows) = sum over the cells of (nu K_e + gamma D_e + adv N_e(state)) x_e, matrix-free: the element matrices are
+// multiplied block by block as they are formed, the element vectors gathered per node in a fixed order
+int launch_element_mult(alfi_level* L, double nu, double gamma, double adv, const double* d_state, const double* dx, double* dy) {
+  alfi_ctx* ctx = L->ctx;
+  AssemblyDev& S = L->asmb;
+  const int d = L->bs, nloc = S.nloc;
+  ALFI_CHECK(ensure_scratch(ctx, sizeof(double) * (size_t)(S.ncell * nloc * d)));
+  double* Fe = (double*)ctx->asm_scratch;
+  const double gcell = S.full_div ? 0.0 : gamma, gfull = S.full_div ? gamma : 0.0;
+  dim3 grid((unsigned)((S.ncell + 63) / 64)), block(64);
+#define ALFI_EL1(DV, NL)                                                                                                         \
+  hipLaunchKernelGGL((element_cell_kernel<DV, NL, 1>), grid, block, 0, ctx->stream, (int64_t)0, S.ncell, S.cell_nodes, S.grad,  \
+                     S.vol, S.etab, S.bItab, d_state, dx, nu, gcell, gfull, adv, Fe)
+  ALFI_ELEMENT_DISPATCH(d, nloc, ALFI_EL1);
+#undef ALFI_EL1
+  ALFI_HIP_CHECK(ctx, hipGetLastError());
+  return gather_cell_vectors(L, Fe, 0, dy);
+}
+
+// d_F += the SUPG residual contribution about d_state
+int launch_supg_residual(alfi_level* L, double nu, double weight, double magic, const double* d_state, double* d_F) {
+  alfi_ctx* ctx = L->ctx;
+  AssemblyDev& S = L->asmb;
+  const int d = L->bs, nloc = S.nloc;
+  ALFI_CHECK(ensure_scratch(ctx, sizeof(double) * (size_t)(S.ncell * nloc * d)));
+  double* Fe = (double*)ctx->asm_scratch;
+  dim3 grid((unsigned)((S.ncell + 63) / 64)), block(64);
+#define ALFI_SR(DV, NL)                                                                                                          \
+  hipLaunchKernelGGL((supg_residual_cell_kernel<DV, NL>), grid, block, 0, ctx->stream, S.ncell, S.cell_nodes, S.grad, S.vol,    \
+                     S.hcell, S.nq, S.wq, S.phi, S.dphi, S.d2phi, d_state, nu, weight, magic, Fe)
+  if (d == 2 && nloc == 3) { ALFI_SR(2, 3); }
+  else if (d == 2 && nloc == 6) { ALFI_SR(2, 6); }
+  else if (d == 3 && nloc == 4) { ALFI_SR(3, 4); }
+  else if (d == 3 && nloc == 8) { ALFI_SR(3, 8); }
+  else if (d == 3 && nloc == 10) { ALFI_SR(3, 10); }
+  else if (d == 3 && nloc == 14) { ALFI_SR(3, 14); }
+  else return alfi_set_error(ctx, ALFI_E_ARG, "no SUPG residual kernel for %d nodes per cell in %d-D", nloc, d);
+#undef ALFI_SR
+  ALFI_HIP_CHECK(ctx, hipGetLastError());
+  return gather_cell_vectors(L, Fe, 1, d_F);
 }
 
 int launch_apply_bc(alfi_level* L) {

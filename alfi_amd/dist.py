@@ -912,8 +912,9 @@ def _dist_ns_solver_class():
 
     class DistNavierStokesSolver(HipNavierStokesSolver):
         """HipNavierStokesSolver with the device side on partitioned levels (one process per GPU): DistMultigrid + DistSaddle.
-        Every rank rediscretises ITS OWN rows of the level operators on its host cores (``_rediscretise``) and uploads them;
-        the Newton state is replicated, the update of each linear solve gathered from its owners."""
+        Every rank rediscretises ITS OWN rows of the level operators -- on its device from the cells that touch its nodes
+        (``_rediscretise_device``; on its host cores only with ALFI_DEVICE_ASSEMBLY=0); the Newton state is replicated, the
+        update of each linear solve gathered from its owners."""
 
         def __init__(self, *args, min_dofs=400000, group=None, **kwargs):
             self._min_dofs, self._group = min_dofs, group
@@ -953,9 +954,9 @@ def _dist_ns_solver_class():
             return True
 
         def _setup_device_assembly(self):
-            """Once per solver: every local level with owned rows gets the cells that touch its local nodes, its rows of the
-            state-independent parts K and D (assembled rank-locally: alfi_amd.lazy) and the contributor lists
-            (alfi_level_set_assembly on a partitioned level); the state of a Newton step is then uploaded per level -- local
+            """Once per solver: every local level with owned rows gets the cells that touch its local nodes and the contributor
+            lists of its local sparsity (alfi_level_set_assembly on a partitioned level: every term of the operator is formed
+            on the device, cell by cell); the state of a Newton step is then uploaded per level -- local
             nodes and the ring of nodes around them, a few megabytes -- and the operators are rebuilt from it on the device.
             Ranks that hold only ghost copies of a level (the coarse side of the first distributed transfer) skip it: no patch
             and no product reads those rows."""
@@ -970,17 +971,12 @@ def _dist_ns_solver_class():
                         continue
                     L = self.levels[LL.level]
                     V = L.V
-                    geo, tens = V.mesh.cell_geometry(), V.element.reference_tensors()
-                    K = localize_operator(LazyOperator(V, L.A.rowptr, L.A.colidx, geo, tens, 1.0, 0.0, 0.0, None, with_bc=False), p)
-                    D = localize_operator(LazyOperator(V, L.A.rowptr, L.A.colidx, geo, tens, 0.0, 1.0, 0.0, None, full_div=self.sv,
-                                                       with_bc=False), p)
-                    assert np.array_equal(K.colidx, LL.A.colidx) and np.array_equal(K.rowptr, LL.A.rowptr)
                     cells, cn, nodes = assembly_cells(V, p)
-                    dl.set_assembly(V, K.vals, D.vals, LL.A.rowptr, LL.A.colidx, cells=cells, cell_nodes=cn)
+                    dl.set_assembly(V, LL.A.rowptr, LL.A.colidx, full_div=self.sv, cells=cells, cell_nodes=cn)
                     bcn = np.flatnonzero(V.bc_node_mask[p.nodes])              # Dirichlet nodes among ALL local nodes
                     dl.set_assembly_bc((bcn[:, None] * L.bs + np.arange(L.bs)).ravel())
                     if self.supg:
-                        dl.set_supg(V, LL.A.rowptr, LL.A.colidx, cells=cells)
+                        dl.set_supg(V, cells=cells)
                     self._asm.append((nodes, self.ctx.vec(dl.assembly_state_size())))
                 L = self.levels[-1]
                 self._dres = self.ctx.vec(dmg.n_loc)
@@ -1009,9 +1005,7 @@ def _dist_ns_solver_class():
                     if asm is None:
                         continue
                     if adv and self.supg:     # A = nu K + gamma D + N(w) + the linearised SUPG term, THEN the boundary conditions
-                        dl.assemble(self.nu, self.gamma, adv, asm[1], False)
-                        dl.supg(self.nu, self.supg_weight, self.supg_magic, asm[1], True, None)
-                        dl.apply_bc()
+                        dl.assemble_supg(self.nu, self.gamma, adv, asm[1], self.supg_weight, self.supg_magic, True)
                     else:
                         dl.assemble(self.nu, self.gamma, adv, asm[1] if adv else None, True)
                 self.dmg.sync()
@@ -1024,10 +1018,10 @@ def _dist_ns_solver_class():
             self.timings["factor_s"] += time.time() - t1
 
         def _residual_device(self, u, p, adv):
-            """The rank's rows of F_u = (nu K + gamma D + 1/2 N(u)) u + B^T p on the device -- one product with the operator
-            assembled into the level's second value array (alfi_level_assemble_mult: forward halo of u inside), the rank's
-            cells' share of B^T p reverse-added onto the owners -- and its rows of F_p = B u; the pieces are then gathered
-            (the Newton state is replicated)."""
+            """The rank's rows of F_u = (nu K + gamma D + 1/2 N(u)) u + B^T p on the device -- one matrix-free product over the
+            rank's cells (alfi_level_assemble_mult: the state carries the ring of nodes around the local ones, no exchange),
+            the rank's cells' share of B^T p reverse-added onto the owners -- and its rows of F_p = B u; the pieces are then
+            gathered (the Newton state is replicated)."""
             L = self.levels[-1]
             dmg, fin = self.dmg, self.dmg.levels[-1]
             nodes, st = self._asm[-1]

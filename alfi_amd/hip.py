@@ -41,6 +41,11 @@ class Context(object):
             self.lib.alfi_ctx_destroy(self.h)
             self.h = None
 
+    def set_assembly_scratch(self, max_bytes):
+        """Bytes of element blocks the operator refresh may hold at once (alfi_ctx_set_assembly_scratch); beyond, the cells
+        are taken in batches."""
+        self.check(self.lib.alfi_ctx_set_assembly_scratch(self.h, int(max_bytes)))
+
     def set_comm(self, callback, dred_ptr, dred_len):
         """callback: a ctypes function pointer of type alfi_amd.dist.CommFn (kept alive by the caller)."""
         self.check(self.lib.alfi_ctx_set_comm(self.h, ctypes.cast(callback, vp), None, vp(int(dred_ptr)), int(dred_len)))
@@ -184,18 +189,17 @@ class Level(object):
         vals = np.ascontiguousarray(vals, dtype=np.float64)
         self.ctx.check(self.ctx.lib.alfi_level_update_values(self.h, _ptr(vals)))
 
-    def set_assembly(self, V, K_vals, D_vals, rowptr, colidx, cells=None, cell_nodes=None):
+    def set_assembly(self, V, rowptr, colidx, full_div=False, cells=None, cell_nodes=None):
         """Hand the level what the device-side operator refresh needs (alfi_level_set_assembly): the cells of the nodal
-        space ``V`` (alfi_amd.fespace), the advection tensor of its element and the state-independent parts K (viscous) and
-        D (grad-div) of the operator, both (nnzb, bs, bs) on the level's sparsity.
+        space ``V`` (alfi_amd.fespace), the reference-cell tensors of its element (viscous / grad-div / advection terms) and
+        the contributor lists of the level's sparsity; ``full_div``: the Scott-Vogelius grad-div term (solver.py:616).
         Partitioned level (alfi_amd.dist): ``cells`` = the mesh cells that touch a local node, ``cell_nodes`` their nodes in
-        the numbering of the rank's state vector (local nodes first, then the cells' other nodes); rowptr / colidx / K / D
-        the LOCAL operator's."""
+        the numbering of the rank's state vector (local nodes first, then the cells' other nodes); rowptr / colidx the LOCAL
+        operator's."""
         from . import _hostlib
         g, vol = V.mesh.cell_geometry()
-        T1 = np.ascontiguousarray(V.element.reference_tensors()["T1"], dtype=np.float64)     # [k, i, b, a]
-        Ta = np.ascontiguousarray(np.transpose(T1, (2, 3, 0, 1)))                            # [b, a, k, i]
-        Tb = np.ascontiguousarray(np.transpose(T1, (0, 3, 1, 2)))                            # [b, a, i, k] = T1[b, i, k, a]
+        tens = V.element.reference_tensors()
+        S, bI, T1 = (np.ascontiguousarray(tens[k], dtype=np.float64) for k in ("S", "bI", "T1"))
         nrows = len(rowptr) - 1
         if cells is None:
             cn = np.ascontiguousarray(V.cell_nodes, dtype=np.int32)
@@ -207,11 +211,9 @@ class Level(object):
                                                      partial=True)
         g = np.ascontiguousarray(g, dtype=np.float64)
         vol = np.ascontiguousarray(vol, dtype=np.float64)
-        K = np.ascontiguousarray(K_vals, dtype=np.float64)
-        D = np.ascontiguousarray(D_vals, dtype=np.float64)
         self.ctx.check(self.ctx.lib.alfi_level_set_assembly(self.h, cn.shape[0], cn.shape[1], _ptr(cn), _ptr(g), _ptr(vol),
-                                                            _ptr(Ta), _ptr(Tb), _ptr(K), _ptr(D), _ptr(cptr), _ptr(ccell),
-                                                            _ptr(cba)))
+                                                            _ptr(S), _ptr(bI), _ptr(T1), 1 if full_div else 0, _ptr(cptr),
+                                                            _ptr(ccell), _ptr(cba)))
 
     def set_assembly_bc(self, bc_dofs):
         """Partitioned level: the Dirichlet dofs among ALL local dofs, ghosts included (alfi_level_set_assembly_bc)."""
@@ -224,15 +226,15 @@ class Level(object):
         return n.value
 
     def assemble_mult(self, nu, gamma, adv, state, x, y):
-        """y = (nu K + gamma D + adv N(state)) x without boundary conditions, assembled into a second value array
-        (alfi_level_assemble_mult): the level's operator and patch factors stay as they are."""
+        """y = (nu K + gamma D + adv N(state)) x without boundary conditions, matrix-free (alfi_level_assemble_mult): the
+        level's operator and patch factors stay as they are."""
         self.ctx.check(self.ctx.lib.alfi_level_assemble_mult(self.h, float(nu), float(gamma), float(adv),
                                                              state.ptr if state is not None else None, x.ptr, y.ptr))
 
-    def set_supg(self, V, rowptr, colidx, nq=None, cells=None):
+    def set_supg(self, V, nq=None, cells=None):
         """Quadrature tables for the device-side SUPG terms (alfi_level_set_supg): the rule and tabulation of
-        ``_hostlib.supg`` (degree 2k), cell sizes, diagonal blocks.  ``cells`` (partitioned level): the cells given to
-        ``set_assembly``; ``rowptr`` / ``colidx`` are then the rank's local rows."""
+        ``_hostlib.supg`` (degree 2k) and the cell sizes.  ``cells`` (partitioned level): the cells given to
+        ``set_assembly``."""
         from . import _hostlib
         from .elements import simplex_quadrature
         el, d = V.element, V.dim
@@ -243,14 +245,15 @@ class Level(object):
         h = _hostlib.cell_size(V.mesh)
         if cells is not None:
             h = np.asarray(h)[np.asarray(cells)]
-        rowptr = np.asarray(rowptr, dtype=np.int64)
-        colidx = np.asarray(colidx)
-        rows = np.repeat(np.arange(len(rowptr) - 1), np.diff(rowptr))
-        diag = np.flatnonzero(colidx == rows).astype(np.int32)
-        assert diag.shape[0] == len(rowptr) - 1, "every block row needs its diagonal block"
         arrs = [np.ascontiguousarray(a, dtype=np.float64) for a in (wq, phi, dphi, d2phi, h)]
         self.ctx.check(self.ctx.lib.alfi_level_set_supg(self.h, len(wq), _ptr(arrs[0]), _ptr(arrs[1]), _ptr(arrs[2]),
-                                                        _ptr(arrs[3]), _ptr(arrs[4]), _ptr(diag)))
+                                                        _ptr(arrs[3]), _ptr(arrs[4])))
+
+    def assemble_supg(self, nu, gamma, adv, state, weight, magic, apply_bc=True):
+        """The refresh of a stabilised run in one pass (alfi_level_assemble_supg): A = nu K + gamma D + adv N(state) + the
+        linearised SUPG term, then the boundary conditions."""
+        self.ctx.check(self.ctx.lib.alfi_level_assemble_supg(self.h, float(nu), float(gamma), float(adv), state.ptr,
+                                                             float(weight), float(magic), 1 if apply_bc else 0))
 
     def supg(self, nu, weight, magic, state, add_to_operator=True, F=None):
         """SUPG terms about ``state`` on the device (alfi_level_supg): the linearisation into the operator and / or the

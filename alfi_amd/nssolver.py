@@ -143,15 +143,14 @@ class HipNavierStokesSolver(object):
         return True
 
     def _setup_device_assembly(self):
-        """Once: the state-independent parts K (viscous, nu = 1) and D (grad-div, gamma = 1) of every level operator, the cells
-        and the contributor lists go to the device (alfi_level_set_assembly); per-level state vectors for the injected field."""
+        """Once: the cells, the reference tensors of the element and the contributor lists of every level go to the device
+        (alfi_level_set_assembly: every term of the operator is formed there, cell by cell); per-level state vectors for the
+        injected field."""
         self._dstate = []
         for L, dl in zip(self.levels, self.hmg.mg.levels):
-            K = _assemble(L, 1.0, 0.0, 0.0, None, False, self.sv)
-            D = _assemble(L, 0.0, 1.0, 0.0, None, False, self.sv)
-            dl.set_assembly(L.V, K, D, L.A.rowptr, L.A.colidx)
+            dl.set_assembly(L.V, L.A.rowptr, L.A.colidx, full_div=self.sv)
             if self.supg:
-                dl.set_supg(L.V, L.A.rowptr, L.A.colidx)
+                dl.set_supg(L.V)
             self._dstate.append(self.ctx.vec(L.n))
         self._dres = self.ctx.vec(self.levels[-1].n)
         # the residual's divergence products on the device too (B with ALL columns; the Jacobian's B lives in the saddle
@@ -175,9 +174,7 @@ class HipNavierStokesSolver(object):
         mgl = self.hmg.mg.levels
         for dl, st in zip(mgl, self._dstate):
             if adv and self.supg:     # A = nu K + gamma D + N(w) + the linearised SUPG term, THEN the boundary conditions
-                dl.assemble(self.nu, self.gamma, adv, st, False)
-                dl.supg(self.nu, self.supg_weight, self.supg_magic, st, True, None)
-                dl.apply_bc()
+                dl.assemble_supg(self.nu, self.gamma, adv, st, self.supg_weight, self.supg_magic, True)
             else:
                 dl.assemble(self.nu, self.gamma, adv, st if adv else None, True)
         self.ctx.sync()
@@ -192,12 +189,11 @@ class HipNavierStokesSolver(object):
         self.timings["factor_s"] += time.time() - t1
 
     def _residual_device(self, u, p, adv):
-        """F_u = (nu K + gamma D) u + 1/2 N(u) u + B^T p - f: one product with the operator assembled with HALF the advection
+        """F_u = (nu K + gamma D) u + 1/2 N(u) u + B^T p - f: one matrix-free product, cell by cell, with HALF the advection
         term and without boundary conditions (N(u) u = 2 (u . grad) u)."""
         L = self.levels[-1]
         fin = self.hmg.mg.levels[-1]
         self._dstate[-1].set(u)
-        # (into a second value array: the level keeps the Jacobian it was factored from -- ADVICE r3)
         fin.assemble_mult(self.nu, self.gamma, 0.5 * adv, self._dstate[-1] if adv else None, self._dstate[-1], self._dres)
         if adv and self.supg:         # + the SUPG residual, gathered on the device into the same vector
             fin.supg(self.nu, self.supg_weight, self.supg_magic, self._dstate[-1], False, self._dres)

@@ -151,42 +151,49 @@ int alfi_level_set_overlap(alfi_level* lvl, int64_t nb_interior, int64_t npatch_
 int alfi_level_update_values(alfi_level* lvl, const double* bvals_host);
 /* Operator refresh on the device (PatchPC.update: `precompute_element_tensors` + `save_operators`, alfi/solver.py:320, 325;
  * PETSc event PCPatchComputeOp, alfi/driver.py:80).  alfi_level_set_assembly hands over, once, what does not change
- * between Newton steps: the cells (nodes, gradients of the barycentric coordinates (ncell, d+1, d), volumes), the reference
- * tensor T1 of the advection term in the two orders the kernel reads -- Ta[b*nloc+a][k][i] = T1[k,i,b,a],
- * Tb[b*nloc+a][i][k] = T1[b,i,k,a] --, the viscous and grad-div parts K, D of the operator (host BSR layout (nnzb, bs, bs),
- * the level's sparsity) and the contributor lists (cptr (nnzb+1), ccell, cba = b*nloc+a per pair; fixed order).
+ * between Newton steps: the cells (nodes, gradients of the barycentric coordinates (ncell, d+1, d), volumes), the
+ * reference-cell tensors of the nodal element -- S (nloc, nloc, d+1, d+1) = avg d_i phi_a d_j phi_b, bI (nloc, d+1) =
+ * avg d_i phi_a, T1 (nloc, d+1, nloc, nloc) = avg phi_k d_i phi_b phi_a (index order k, i, b, a) --, whether the grad-div
+ * term is the full one gamma (div u, div v) of the Scott-Vogelius forms (alfi/solver.py:609-619; full_div != 0) or the
+ * cell-averaged one of the P0-pressure forms (solver.py:565-568), and the contributor lists (cptr (nnzb+1), ccell,
+ * cba = b*nloc+a per pair; fixed order).
  * alfi_level_assemble then writes  A = nu K + gamma D + adv N(state)  into the level's operator (the linearisation of
- * alfi/solver.py:565-568 about the DEVICE-resident nodal field `d_state`, n doubles), Dirichlet rows / columns as identity
- * when apply_bc != 0; the patches must be factored again afterwards (alfi_patches_factor).
+ * alfi/solver.py:565-568 about the DEVICE-resident nodal field `d_state`), Dirichlet rows / columns as identity when
+ * apply_bc != 0: every cell forms its element matrix, every block of the operator sums its contributors in list order
+ * (bitwise reproducible); the patches must be factored again afterwards (alfi_patches_factor).
  * PARTITIONED levels (alfi_level_set_partition first; one rank per mesh partition re-assembling its own patch operators,
  * alfi/solver.py:604-605): pass the cells that touch a LOCAL node (owned or ghost); cell_nodes index the level's local nodes
  * and, beyond them (indices >= nbrows), the cells' remaining nodes in any fixed order -- the state vector then holds
- * alfi_level_assembly_state_size entries, local nodes first --; K, D on the local sparsity; the contributor lists hold only
- * the pairs whose two nodes are local (at most ncell * nloc^2).  No exchange is involved: every rank reads its own copy of
- * the state. */
+ * alfi_level_assembly_state_size entries, local nodes first --; the contributor lists hold only the pairs whose two nodes
+ * are local (at most ncell * nloc^2).  No exchange is involved: every rank reads its own copy of the state. */
 int alfi_level_set_assembly(alfi_level* lvl, int64_t ncell, int nloc, const int32_t* cell_nodes, const double* grad,
-                            const double* vol, const double* Ta, const double* Tb, const double* Kvals_host,
-                            const double* Dvals_host, const int64_t* cptr, const int32_t* ccell, const uint16_t* cba);
+                            const double* vol, const double* S, const double* bI, const double* T1, int full_div,
+                            const int64_t* cptr, const int32_t* ccell, const uint16_t* cba);
 int alfi_level_assemble(alfi_level* lvl, double nu, double gamma, double adv, const double* d_state, int apply_bc);
+/* bytes of element blocks the refresh may hold at once (default 24 GiB; beyond, the cells are taken in batches) */
+int alfi_ctx_set_assembly_scratch(alfi_ctx* ctx, int64_t max_bytes);
 /* partitioned levels: Dirichlet dofs among ALL local dofs (owned and ghost) for the refresh's identity rows / columns */
 int alfi_level_set_assembly_bc(alfi_level* lvl, const int32_t* bc_dofs_host, int64_t nbc);
 int alfi_level_assembly_state_size(alfi_level* lvl, int64_t* n);   /* doubles d_state must hold (= n of the level, unpartitioned) */
-/* y = (nu K + gamma D + adv N(state)) x, no boundary conditions, the operator assembled into a second value array: the
- * level's operator and its patch factors stay valid.  The nonlinear residual F_u of alfi/solver.py:565-568 is this product
- * with x = state and HALF the advection weight (N(u) u = 2 (u . grad) u).  dx, dy: level vectors (on a partitioned level the
- * ghost slots of dx are filled by the forward exchange, rows of owned nodes are produced). */
+/* y = (nu K + gamma D + adv N(state)) x, no boundary conditions, MATRIX-FREE (every cell multiplies its element matrix with
+ * its entries of x; no value array is formed): the level's operator and its patch factors stay valid.  The nonlinear
+ * residual F_u of alfi/solver.py:565-568 is this product with x = state and HALF the advection weight
+ * (N(u) u = 2 (u . grad) u).  dx: alfi_level_assembly_state_size entries (like d_state); dy: the level's rows. */
 int alfi_level_assemble_mult(alfi_level* lvl, double nu, double gamma, double adv, const double* d_state, const double* dx,
                              double* dy);
 /* SUPG stabilisation on the device (alfi/stabilisation.py:47-97 with the Shakib coefficient, alfi/solver.py:204-234; the
  * reference's production option `--stabilisation-type supg`).  alfi_level_set_supg (after alfi_level_set_assembly) hands over the
  * quadrature tables of the element -- weights wq (nq, summing to 1), phi (nq, nloc), dphi (nq, nloc, d+1), d2phi (nq, nloc, d+1,
- * d+1): basis and derivatives w.r.t. the barycentric coordinates --, the cell sizes hcell (ncell; Firedrake's CellSize) and,
- * per block row, the index of its diagonal block.  alfi_level_supg then adds, about the device-resident state, the Newton
- * linearisation of `weight * beta * (Lu, (u . grad) v)` to the level operator (add_to_operator != 0; call between
- * alfi_level_assemble(..., apply_bc = 0) and alfi_level_apply_bc) and / or its residual contribution to d_F (n doubles, may be
- * NULL).  alfi_level_apply_bc turns the Dirichlet rows / columns of the operator into identity afterwards. */
+ * d+1): basis and derivatives w.r.t. the barycentric coordinates -- and the cell sizes hcell (ncell; Firedrake's CellSize).
+ * alfi_level_assemble_supg is the refresh of a stabilised run in one pass: A = nu K + gamma D + adv N(state) + the Newton
+ * linearisation of `weight * beta * (Lu, (u . grad) v)` about the state, then the boundary conditions.  alfi_level_supg adds that
+ * linearisation to the operator as it stands (add_to_operator != 0; between alfi_level_assemble(..., apply_bc = 0) and
+ * alfi_level_apply_bc) and / or the residual contribution of the term to d_F (the level's n doubles, may be NULL).
+ * alfi_level_apply_bc turns the Dirichlet rows / columns of the operator into identity. */
 int alfi_level_set_supg(alfi_level* lvl, int nq, const double* wq, const double* phi, const double* dphi, const double* d2phi,
-                        const double* hcell, const int32_t* diag_block);
+                        const double* hcell);
+int alfi_level_assemble_supg(alfi_level* lvl, double nu, double gamma, double adv, const double* d_state, double weight,
+                             double magic, int apply_bc);
 int alfi_level_supg(alfi_level* lvl, double nu, double weight, double magic, const double* d_state, int add_to_operator,
                     double* d_F);
 int alfi_level_apply_bc(alfi_level* lvl);

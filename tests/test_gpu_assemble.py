@@ -43,11 +43,43 @@ def test_device_assembled_operator_equals_the_host_generators(name, mk, k, nref)
             got = dl.get_values()
             assert got.shape == ref.shape
             assert np.abs(got - ref).max() <= 1e-13 * np.abs(ref).max(), (name, L.level, adv, bc)
-        # deterministic: a second assembly gives the same bits
+        # deterministic: a second assembly gives the same bits -- and so do the cells taken in several batches (the scratch of
+        # element blocks limited to ~7 cells' worth)
         dl.assemble(s.nu, s.gamma, 1.0, st, True)
         a1 = dl.get_values()
         dl.assemble(s.nu, s.gamma, 1.0, st, True)
         assert np.array_equal(a1, dl.get_values())
+        ndof = L.V.cell_nodes.shape[1] * L.V.dim
+        s.ctx.set_assembly_scratch(7 * ndof * ndof * 8 + 100)
+        dl.assemble(s.nu, s.gamma, 1.0, st, True)
+        assert np.array_equal(a1, dl.get_values())
+        s.ctx.set_assembly_scratch(24 << 30)
+    s.close()
+
+
+@pytest.mark.parametrize("name,mk,k,nref", CASES + SV_CASES, ids=[c[0] for c in CASES + SV_CASES])
+def test_matrix_free_product_equals_the_assembled_operator(name, mk, k, nref):
+    """alfi_level_assemble_mult: y = (nu K + gamma D + adv N(w)) x cell by cell, without forming a value array, against the
+    host-assembled operator (no boundary conditions) times x, for x != w; bitwise reproducible."""
+    import scipy.sparse as sp
+    from alfi_amd.nssolver import HipNavierStokesSolver, _assemble
+    s = HipNavierStokesSolver(mk(), nref, k, gamma=1e4, device_assembly=True, discretisation="sv" if "SV" in name else "pkp0")
+    s.nu = 0.021
+    rng = np.random.default_rng(3)
+    for L, dl, st in zip(s.levels, s.hmg.mg.levels, s._dstate):
+        w = rng.standard_normal((L.V.num_nodes, L.V.dim))
+        x = rng.standard_normal(L.n)
+        st.set(w.ravel())
+        dx, dy = s.ctx.vec(x), s.ctx.vec(L.n)
+        for adv in (0.5, 0.0):
+            vals = _assemble(L, s.nu, s.gamma, adv, w if adv else None, False, s.sv)
+            A = sp.bsr_matrix((vals, L.A.colidx, L.A.rowptr), shape=(L.n, L.n))
+            ref = A @ x
+            dl.assemble_mult(s.nu, s.gamma, adv, st if adv else None, dx, dy)
+            got = dy.get()
+            assert np.abs(got - ref).max() <= 1e-12 * np.abs(ref).max(), (name, L.level, adv)
+            dl.assemble_mult(s.nu, s.gamma, adv, st if adv else None, dx, dy)
+            assert np.array_equal(got, dy.get())
     s.close()
 
 
@@ -107,7 +139,7 @@ def test_sv_newton_with_device_and_host_assembly_agree():
 def test_device_supg_terms_equal_the_host_generators(name, mk, k, nref):
     """The SUPG stabilisation (stabilisation.py:47-97, solver.py:204-234) assembled on the device -- element matrices by one wave
     per cell, gathered per block in a fixed order -- against alfi_host_supg on every level: linearisation inside the operator
-    (with advection and boundary conditions) entry by entry, and the residual contribution; several scratch batches."""
+    (with advection and boundary conditions) entry by entry, and the residual contribution (a lane per cell); several batches."""
     from alfi_amd import _hostlib
     from alfi_amd.nssolver import HipNavierStokesSolver
     s = HipNavierStokesSolver(mk(), nref, k, gamma=1e4, device_assembly=True, stabilisation_type="supg", stabilisation_weight=0.05)
@@ -118,11 +150,19 @@ def test_device_supg_terms_equal_the_host_generators(name, mk, k, nref):
         w = rng.standard_normal((L.V.num_nodes, L.V.dim))
         st.set(w.ravel())
         ref = s.level_values(L, w, 1.0, True)                       # host: assemble + supg + bc
-        dl.assemble(s.nu, s.gamma, 1.0, st, False)
+        dl.assemble(s.nu, s.gamma, 1.0, st, False)                  # the three-call sequence ...
         dl.supg(s.nu, s.supg_weight, s.supg_magic, st, True, None)
         dl.apply_bc()
         got = dl.get_values()
         assert np.abs(got - ref).max() <= 1e-12 * np.abs(ref).max(), (name, L.level, np.abs(got - ref).max(), np.abs(ref).max())
+        dl.assemble_supg(s.nu, s.gamma, 1.0, st, s.supg_weight, s.supg_magic, True)     # ... and the one-pass refresh
+        one = dl.get_values()
+        assert np.abs(one - ref).max() <= 1e-12 * np.abs(ref).max(), (name, L.level)
+        ndof = L.V.cell_nodes.shape[1] * L.V.dim
+        s.ctx.set_assembly_scratch(5 * ndof * ndof * 8 + 100)        # several batches of cells: the same bits
+        dl.assemble_supg(s.nu, s.gamma, 1.0, st, s.supg_weight, s.supg_magic, True)
+        assert np.array_equal(one, dl.get_values())
+        s.ctx.set_assembly_scratch(24 << 30)
         Fh = np.zeros(L.n)
         _hostlib.supg(L.V, w, s.nu, s.supg_weight, s.supg_magic, F=Fh)
         dF = s.ctx.vec(L.n)
