@@ -680,6 +680,7 @@ static void free_assembly(AssemblyDev* S) {
   dev_free(S->cptr); dev_free(S->ccell); dev_free(S->cba); dev_free(S->cell_nodes); dev_free(S->grad); dev_free(S->vol);
   dev_free(S->etab); dev_free(S->bItab); dev_free(S->bc_code); dev_free(S->bc_all);
   dev_free(S->wq); dev_free(S->phi); dev_free(S->dphi); dev_free(S->d2phi); dev_free(S->hcell); dev_free(S->diag);
+  dev_free(S->wq8); dev_free(S->qtab);
   *S = AssemblyDev();
 }
 
@@ -861,13 +862,13 @@ int alfi_level_set_supg(alfi_level* L, int nq, const double* wq, const double* p
   AssemblyDev& S = L->asmb;
   if (!S.ready) return alfi_set_error(ctx, ALFI_E_STATE, "alfi_level_set_supg before alfi_level_set_assembly");
   if (nq < 1 || !wq || !phi || !dphi || !d2phi || !hcell) return alfi_set_error(ctx, ALFI_E_ARG, "NULL / empty SUPG tables");
-  if (S.nloc * L->bs > 64) return alfi_set_error(ctx, ALFI_E_ARG, "SUPG kernel handles elements of at most 64 dofs, got %d", S.nloc * L->bs);
+  if (S.nloc > 16) return alfi_set_error(ctx, ALFI_E_ARG, "SUPG kernels handle elements of at most 16 nodes, got %d", S.nloc);
   for (int64_t c = 0; c < S.ncell; ++c)
     if (!(hcell[c] > 0.0)) return alfi_set_error(ctx, ALFI_E_ARG, "cell size of cell %lld is not positive", (long long)c);
   ALFI_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   ALFI_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-  dev_free(S.wq); dev_free(S.phi); dev_free(S.dphi); dev_free(S.d2phi); dev_free(S.hcell);
-  S.wq = S.phi = S.dphi = S.d2phi = S.hcell = nullptr;
+  dev_free(S.wq); dev_free(S.phi); dev_free(S.dphi); dev_free(S.d2phi); dev_free(S.hcell); dev_free(S.wq8); dev_free(S.qtab);
+  S.wq = S.phi = S.dphi = S.d2phi = S.hcell = S.wq8 = S.qtab = nullptr;
   S.supg_ready = false;
   const int nv = L->bs + 1, nloc = S.nloc;
   ALFI_CHECK(dev_upload(ctx, &S.wq, wq, nq));
@@ -875,6 +876,27 @@ int alfi_level_set_supg(alfi_level* L, int nq, const double* wq, const double* p
   ALFI_CHECK(dev_upload(ctx, &S.dphi, dphi, (int64_t)nq * nloc * nv));
   ALFI_CHECK(dev_upload(ctx, &S.d2phi, d2phi, (int64_t)nq * nloc * nv * nv));
   ALFI_CHECK(dev_upload(ctx, &S.hcell, hcell, S.ncell));
+  {
+    // the linearisation kernel takes eight points per chunk (two matrix-core steps of four): pad with zero-weight copies of point 0, and pack per
+    // (point, node) phi | dphi | the upper triangle of the (symmetric) second derivatives
+    const int nq8 = (nq + 7) / 8 * 8, nh2 = nv * (nv + 1) / 2, qt = 1 + nv + nh2;
+    std::vector<double> w8((size_t)nq8, 0.0), tab((size_t)nq8 * nloc * qt);
+    for (int p = 0; p < nq8; ++p) {
+      const int ps = p < nq ? p : 0;
+      if (p < nq) w8[p] = wq[p];
+      for (int a = 0; a < nloc; ++a) {
+        double* t = tab.data() + ((size_t)p * nloc + a) * qt;
+        t[0] = phi[(size_t)ps * nloc + a];
+        for (int m = 0; m < nv; ++m) t[1 + m] = dphi[((size_t)ps * nloc + a) * nv + m];
+        int at = 1 + nv;
+        for (int m = 0; m < nv; ++m)
+          for (int n = m; n < nv; ++n) t[at++] = d2phi[(((size_t)ps * nloc + a) * nv + m) * nv + n];
+      }
+    }
+    ALFI_CHECK(dev_upload(ctx, &S.wq8, w8.data(), nq8));
+    ALFI_CHECK(dev_upload(ctx, &S.qtab, tab.data(), (int64_t)tab.size()));
+    S.nq8 = nq8;
+  }
   S.nq = nq;
   S.supg_ready = true;
   return 0;

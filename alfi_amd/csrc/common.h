@@ -291,6 +291,9 @@ struct AssemblyDev {
   double* dphi = nullptr;        // (nq, nloc, d + 1) derivatives w.r.t. the barycentric coordinates
   double* d2phi = nullptr;       // (nq, nloc, d + 1, d + 1)
   double* hcell = nullptr;       // (ncell) cell size (2 x circumradius)
+  int nq8 = 0;                   // nq rounded up to a multiple of eight (zero-weight copies of point 0): two k-steps of the MFMA per chunk
+  double* wq8 = nullptr;         // (nq8)
+  double* qtab = nullptr;        // (nq8, nloc, 1 + (d+1) + (d+1)(d+2)/2): phi | dphi | upper triangle of d2phi per (point, node)
 };
 
 struct alfi_level {

@@ -291,205 +291,259 @@ __global__ __launch_bounds__(256) void cell_vector_gather_kernel(int64_t nnode, 
 // by quadrature (beta is not polynomial): residual contribution and its exact Newton linearisation, the same formulas as
 // csrc/host_assemble.cpp:alfi_host_supg.
 //
-// The linearisation: supg_cell_kernel, one wave per cell, forms the element matrix (ndof x ndof, ndof = nloc d) over the
-// quadrature points -- per point the physical gradients / Hessians of the basis (a lane per local node and direction), the
-// state quantities u, grad u, Lu (a lane per output), then every lane accumulates its ndof^2 / 64 entries in registers -- and
-// writes (or adds) it into the scratch of the element blocks E; the one gather of the refresh (element_gather_kernel) sums it
-// into the operator together with the other terms.  The residual: supg_residual_cell_kernel below, a lane per cell.
+// The linearisation (supg_matrix_kernel below): with, per quadrature point q,
+//     s_a = u . grad phi_a,   dL_bij = phi_b G_ij - nu H_b[i][j] + delta_ij (- nu lap_b + s_b),   wt = w_q vol weight,
+// entry ((a, i), (b, j)) of the element matrix is  sum_q wt (b3 u_j phi_b L_i s_a + beta dL_bij s_a + beta L_i phi_b dphi_a/dx_j)
+//     = sum_q SAW[a][q] C1[q][(b,i,j)]  +  sum_q GP[(a,j)][q] C2W[q][(b,i)]
+// -- two small GEMMs over the quadrature points, (nloc x nq)(nq x nloc d^2) and (nloc d x nq)(nq x nloc d), on the FP64 matrix
+// cores (v_mfma_f64_16x16x4: k = 4 points per step).  A workgroup of TWO waves per cell, eight points per chunk: lane (q, a) of
+// wave w forms the physical gradient / Hessian of basis function a at point 4 w + q and its contributions to the state
+// quantities (u, grad u, the second-order part of Lu), 15 lanes per point sum them, every lane then has beta, Lu, ... of ITS point
+// in registers and writes ITS node's rows of the operands -- wt s_a, the nine C1[q][(a, i, j)], the three C2W[q][(a, i)], static
+// indices throughout -- to LDS; then wave 0 runs GEMM 1 (8 accumulator tiles for [P2+FB]^3) and wave 1 GEMM 2 (9 tiles) over the
+// chunk's two k-steps: one LDS read per operand tile and the MFMAs, nothing else.
+// The result goes through LDS into the scratch of element blocks E, coalesced (added to what element_cell_kernel left there).
+// (Rounds 3-4: one wave per cell, every lane accumulated 28 entries with two FMAs and four LDS reads per entry and point behind
+// five barriers per POINT with 14-42 lanes busy: 7000 cycles per point, 197 ms for config 4's finest level.  All 17 tiles in one
+// wave: the register allocator keeps four of them in VGPRs and moves them to the accumulation registers and back around every
+// chunk, 272 moves, at one wave per SIMD: 58.7 ms.  Two waves with the B operands decoded per column in the consuming lane --
+// index arithmetic, four look-ups and selects per tile and k-step: 40.0 ms.)
 // ---------------------------------------------------------------------------------------------------------------------
-template <int D, int EPL>
-__global__ __launch_bounds__(64) void supg_cell_kernel(int64_t cell0, int64_t ncell, int nloc, const int32_t* __restrict__ cell_nodes,
-                                                        const double* __restrict__ grad, const double* __restrict__ vol,
-                                                        const double* __restrict__ hcell, int nq, const double* __restrict__ wq,
-                                                        const double* __restrict__ phi, const double* __restrict__ dphi,
-                                                        const double* __restrict__ d2phi, const double* __restrict__ U, double nu,
-                                                        double weight, double magic, int add, double* __restrict__ E) {
-  constexpr int NV = D + 1;
-  extern __shared__ double sm[];
-  const int64_t cell = cell0 + blockIdx.x;
+typedef double supg_d4 __attribute__((ext_vector_type(4)));
+
+// 1 / sqrt(x): v_rsq_f64 + two Newton steps (the division-and-square-root sequence of `1.0 / sqrt(x)` is 40 instructions)
+__device__ inline double supg_rsqrt(double x) {
+  double y = __builtin_amdgcn_rsq(x);
+  y = y * __builtin_fma(-0.5 * x * y, y, 1.5);
+  y = y * __builtin_fma(-0.5 * x * y, y, 1.5);
+  return y;
+}
+
+// qtab: per point p (padded to a multiple of EIGHT with zero-weight copies of point 0) and local node a:
+//       [phi | dphi (d+1) | d2phi, upper triangle (d+1)(d+2)/2], derivatives w.r.t. the barycentric coordinates
+template <int D, int NLOC>
+__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2))) void supg_matrix_kernel(int64_t c0, int64_t ncell, const int32_t* __restrict__ cell_nodes,
+                                                           const double* __restrict__ grad, const double* __restrict__ vol,
+                                                           const double* __restrict__ hcell, int nchunk,
+                                                           const double* __restrict__ wq8, const double* __restrict__ qtab,
+                                                           const double* __restrict__ U, double nu, double weight, double magic,
+                                                           int add, double* __restrict__ E) {
+  constexpr int NV = D + 1, DD = D * D, ND = NLOC * D, ND2 = NLOC * DD;
+  constexpr int NT1 = (ND2 + 15) / 16, NR2 = (ND + 15) / 16;       // column tiles of GEMM 1, row = column tiles of GEMM 2
+  constexpr int NA = NT1 > NR2 * NR2 ? NT1 : NR2 * NR2;            // accumulator tiles of a wave
+  constexpr int NS = 2 * D + DD, NH2 = NV * (NV + 1) / 2, QT = 1 + NV + NH2;
+  static_assert(NLOC <= 16 && NS <= 16, "a lane per (point, local node)");
+  constexpr int LDS_CHUNK = 8 * NS * 16 + 2 * 128 * NR2 + 2 * 128 + 128 * NT1;
+  constexpr int LDS_N = LDS_CHUNK > NLOC * ND2 ? LDS_CHUNK : NLOC * ND2;
+  __shared__ double sm[LDS_N];
+  double* CON = sm;                    // [8][NS][16]     contributions of basis function a to state quantity v at point p
+  double* GPs = CON + 8 * NS * 16;     // [8][16 NR2]     physical gradients, (a, x) -> a D + x: the A operand of GEMM 2
+  double* C2Ws = GPs + 128 * NR2;      // [8][16 NR2]     wt beta L_i phi_b at (b, i) -> b D + i: the B operand of GEMM 2
+  double* ST = C2Ws + 128 * NR2;       // [8][16]         u | grad u | second-order part of Lu
+  double* SAWT = ST + 128;             // [8][16]         wt s_a: the A operand of GEMM 1
+  double* C1s = SAWT + 128;            // [8][16 NT1]     C1 at (b, i, j) -> (b D + i) D + j: the B operand of GEMM 1
+                                       // (operand entries beyond the element's are zero: written once, before the loop)
+  const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, q = lane >> 4, r = lane & 15, p = 4 * wv + q;
+  const int64_t cell = c0 + blockIdx.x;
   if (cell >= ncell) return;
-  const int lane = threadIdx.x;
-  const int ndof = nloc * D;
-  double* Uk = sm;                       // nloc * D
-  double* gp = Uk + nloc * D;            // nloc * D     physical gradient of basis a
-  double* hs = gp + nloc * D;            // nloc * D * D physical Hessian of basis a
-  double* lap = hs + nloc * D * D;       // nloc
-  double* ph = lap + nloc;               // nloc
-  double* st = ph + nloc;                // u[D], Gu[D][D], Lu[D]
-  double* saw = st + 2 * D + D * D;      // nloc          wt * (u . grad phi_a)
-  double* c2w = saw + nloc;              // nloc * D      wt * beta * Lu_i * phi_b
-  double* c1 = c2w + nloc * D;           // nloc * D * D  the (b, i, j) factor of the entry that multiplies saw_a (see below)
-  const int32_t* cn = cell_nodes + cell * nloc;
+  const int aa = r < NLOC ? r : NLOC - 1;
   double g[NV][D];
 #pragma unroll
   for (int i = 0; i < NV; ++i)
 #pragma unroll
     for (int x = 0; x < D; ++x) g[i][x] = grad[(cell * NV + i) * D + x];
-  for (int e = lane; e < ndof; e += 64) Uk[e] = U[(int64_t)cn[e / D] * D + e % D];
-  const double hc = hcell[cell], h2 = hc * hc;
-  const double vw = vol[cell] * weight;
-  double acc[EPL];
+  double Ua[D];
+  {
+    const int64_t node = cell_nodes[cell * NLOC + aa];
 #pragma unroll
-  for (int t = 0; t < EPL; ++t) acc[t] = 0.0;
-  // entry e = (row (a, i), column (b, j)) of this lane's t-th entry, decomposed ONCE: the places of its four factors in the
-  // per-point tables, a byte each (saw[a] | c1[(b D + i) D + j] | c2w[b D + i] | gp[a D + j]).  (Round 3 divided e by ndof and
-  // by D inside the loop over the quadrature points: ~150 integer instructions per entry and point around 25 flops -- the
-  // kernel took 0.9 s per refresh of config 4's finest level, half of a Newton step with SUPG.)
-  uint32_t pk[EPL];
+    for (int x = 0; x < D; ++x) Ua[x] = r < NLOC ? U[node * D + x] : 0.0;
+  }
+  const double hc = hcell[cell], ih2 = 1.0 / (hc * hc), vw = vol[cell] * weight, vis = 4.0 * nu * ih2;
+  for (int e = tid; e < LDS_CHUNK - 8 * NS * 16; e += 128) GPs[e] = 0.0;
+  supg_d4 acc[NA];
 #pragma unroll
-  for (int t = 0; t < EPL; ++t) {
-    const int e = lane + 64 * t;
-    pk[t] = 0;
-    if (e < ndof * ndof) {
-      const int row = e / ndof, col = e % ndof;
-      const int a = row / D, i = row % D, b = col / D, j = col % D;
-      pk[t] = (uint32_t)a | ((uint32_t)((b * D + i) * D + j) << 8) | ((uint32_t)(b * D + i) << 16) | ((uint32_t)(a * D + j) << 24);
+  for (int t = 0; t < NA; ++t) acc[t] = supg_d4{0.0, 0.0, 0.0, 0.0};
+  // tabulated values of this lane's (point, node) pair, requested one chunk ahead
+  double qt[QT];
+  {
+    const double* src = qtab + ((size_t)p * NLOC + aa) * QT;
+#pragma unroll
+    for (int t = 0; t < QT; ++t) qt[t] = src[t];
+  }
+  __syncthreads();
+#pragma nounroll
+  for (int ch = 0; ch < nchunk; ++ch) {
+    // ---- basis function aa at point 8 ch + p: physical gradient, Hessian G^T H G (M = H G first), contributions to the state
+    double gp[D], hs[D][D], ph, la = 0.0;
+    {
+#pragma unroll
+      for (int x = 0; x < D; ++x) {
+        double sgp = 0.0;
+#pragma unroll
+        for (int m = 0; m < NV; ++m) sgp = __builtin_fma(qt[1 + m], g[m][x], sgp);
+        gp[x] = sgp;
+      }
+      double M[NV][D];
+#pragma unroll
+      for (int m = 0; m < NV; ++m)
+#pragma unroll
+        for (int y = 0; y < D; ++y) {
+          double sm_ = 0.0;
+#pragma unroll
+          for (int n = 0; n < NV; ++n) {
+            const int lo = m < n ? m : n, hi = m < n ? n : m;
+            sm_ = __builtin_fma(qt[1 + NV + lo * NV - lo * (lo - 1) / 2 + hi - lo], g[n][y], sm_);
+          }
+          M[m][y] = sm_;
+        }
+#pragma unroll
+      for (int x = 0; x < D; ++x)
+#pragma unroll
+        for (int y = x; y < D; ++y) {
+          double sh = 0.0;
+#pragma unroll
+          for (int m = 0; m < NV; ++m) sh = __builtin_fma(g[m][x], M[m][y], sh);
+          hs[x][y] = hs[y][x] = sh;
+          if (x == y) la += sh;
+        }
+      ph = qt[0];
+      double* con = CON + (p * NS) * 16 + r;
+#pragma unroll
+      for (int i = 0; i < D; ++i) {
+        con[i * 16] = ph * Ua[i];
+#pragma unroll
+        for (int x = 0; x < D; ++x) con[(D + i * D + x) * 16] = gp[x] * Ua[i];
+        double cl = la * Ua[i];                       // - nu (lap_a U_ai + sum_x H_a[i][x] U_ax)
+#pragma unroll
+        for (int x = 0; x < D; ++x) cl = __builtin_fma(hs[i][x], Ua[x], cl);
+        con[(D + DD + i) * 16] = -nu * cl;
+      }
+      if (r < NLOC) {
+#pragma unroll
+        for (int x = 0; x < D; ++x) GPs[p * 16 * NR2 + r * D + x] = gp[x];
+      }
+    }
+    if (ch + 1 < nchunk) {
+      const double* src = qtab + ((size_t)(8 * (ch + 1) + p) * NLOC + aa) * QT;
+#pragma unroll
+      for (int t = 0; t < QT; ++t) qt[t] = src[t];
+    }
+    __syncthreads();
+    // ---- state quantity r of point p: the sum over the basis functions
+    if (r < NS) {
+      const double* con = CON + (p * NS + r) * 16;
+      double sv = 0.0;
+#pragma unroll
+      for (int a = 0; a < 16; ++a) sv += con[a];
+      ST[p * 16 + r] = sv;
+    }
+    __syncthreads();
+    // ---- every lane: the state at ITS point
+    {
+      double u[D], Gu[D][D], Lu[D], uu = 0.0;
+#pragma unroll
+      for (int i = 0; i < D; ++i) {
+        u[i] = ST[p * 16 + i];
+#pragma unroll
+        for (int x = 0; x < D; ++x) Gu[i][x] = ST[p * 16 + D + i * D + x];
+      }
+#pragma unroll
+      for (int i = 0; i < D; ++i) {
+        double t = ST[p * 16 + D + DD + i];
+#pragma unroll
+        for (int x = 0; x < D; ++x) t = __builtin_fma(u[x], Gu[i][x], t);
+        Lu[i] = t;
+        uu = __builtin_fma(u[i], u[i], uu);
+      }
+      const double beta = supg_rsqrt(__builtin_fma(4.0 * uu, ih2, magic * vis * vis));
+      const double b3 = -4.0 * beta * beta * beta * ih2;
+      const double wt = wq8[8 * ch + p] * vw;
+      double saw = 0.0;
+#pragma unroll
+      for (int x = 0; x < D; ++x) saw = __builtin_fma(u[x], gp[x], saw);
+      // this lane's node as COLUMN node b = r: C1[(b, i, j)] = phi_b (b3 u_j L_i + beta G_ij) + beta (- nu H_b[i][j] + delta_ij
+      // (- nu lap_b + s_b)),  C2W[(b, i)] = wt beta L_i phi_b;  as ROW node a = r: wt s_a
+      if (r < NLOC) {
+        const double dgb = __builtin_fma(-nu, la, saw), nb = -nu * beta, wb = wt * beta * ph;
+        SAWT[p * 16 + r] = wt * saw;
+#pragma unroll
+        for (int i = 0; i < D; ++i) {
+#pragma unroll
+          for (int j = 0; j < D; ++j) {
+            const double wij = __builtin_fma(b3 * u[j], Lu[i], beta * Gu[i][j]);
+            double t = nb * hs[i][j];
+            if (i == j) t = __builtin_fma(beta, dgb, t);
+            C1s[p * 16 * NT1 + (r * D + i) * D + j] = __builtin_fma(ph, wij, t);
+          }
+          C2Ws[p * 16 * NR2 + r * D + i] = wb * Lu[i];
+        }
+      }
+    }
+    __syncthreads();
+    if (wv == 0) {
+      // ---- GEMM 1: A = SAWT[a = lane & 15][k = point lane >> 4], B = C1s[k][column lane & 15 of tile t]
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const int pp = 4 * ks + q;
+        const double aop1 = SAWT[pp * 16 + r];
+#pragma unroll
+        for (int t = 0; t < NT1; ++t)
+          acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop1, C1s[pp * 16 * NT1 + 16 * t + r], acc[t], 0, 0, 0);
+      }
+    } else {
+      // ---- GEMM 2: rows (a, j) of GP, columns (b, i) of C2W
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const int pp = 4 * ks + q;
+        double aop2[NR2], bop2[NR2];
+#pragma unroll
+        for (int tr = 0; tr < NR2; ++tr) {
+          aop2[tr] = GPs[pp * 16 * NR2 + 16 * tr + r];
+          bop2[tr] = C2Ws[pp * 16 * NR2 + 16 * tr + r];
+        }
+#pragma unroll
+        for (int tr = 0; tr < NR2; ++tr)
+#pragma unroll
+          for (int tc = 0; tc < NR2; ++tc)
+            acc[tr * NR2 + tc] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop2[tr], bop2[tc], acc[tr * NR2 + tc], 0, 0, 0);
+      }
+    }
+    __syncthreads();     // the next chunk overwrites the tables
+  }
+  // ---- the element matrix in E's layout, E[a][b][i D + j] = EB[a ND2 + (b D + i) D + j], through LDS.  Results of an MFMA:
+  //      column = lane & 15, rows (lane >> 4) + 4 reg
+  double* EB = sm;
+  if (wv == 0) {
+#pragma unroll
+    for (int t = 0; t < NT1; ++t) {
+      const int col = 16 * t + r;
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        const int a = q + 4 * reg;
+        if (a < NLOC && col < ND2) EB[a * ND2 + col] = acc[t][reg];
+      }
     }
   }
   __syncthreads();
-  for (int q = 0; q < nq; ++q) {
-    // ---- basis at the point: a lane per (local node a, direction y).  Physical gradient component y and column y of the
-    //      physical Hessian G^T H_a G in two steps, M = H_a G[:, y] then G^T M: 28 FMAs on nloc D lanes.  (Round 3: a lane per
-    //      node summed all 16 x 9 products ha_ik g_ix g_ky -- 290 multiply-adds on 14 of the 64 lanes, most of the time of a
-    //      residual-only pass.)
-    if (lane < ndof) {
-      const int a = lane / D, y = lane % D;
-      const double* da = dphi + ((int64_t)q * nloc + a) * NV;
-      const double* ha = d2phi + ((int64_t)q * nloc + a) * NV * NV;
-      double gy[NV];
+  if (wv == 1) {
 #pragma unroll
-      for (int k = 0; k < NV; ++k) {
-        gy[k] = g[k][0];
+    for (int tr = 0; tr < NR2; ++tr)
 #pragma unroll
-        for (int yy = 1; yy < D; ++yy) gy[k] = y == yy ? g[k][yy] : gy[k];
-      }
-      double t = 0.0;
+      for (int tc = 0; tc < NR2; ++tc) {
+        const int c2 = 16 * tc + r;
 #pragma unroll
-      for (int i = 0; i < NV; ++i) t = __builtin_fma(da[i], gy[i], t);
-      gp[a * D + y] = t;
-      double M[NV];
-#pragma unroll
-      for (int i = 0; i < NV; ++i) {
-        double m = 0.0;
-#pragma unroll
-        for (int k = 0; k < NV; ++k) m = __builtin_fma(ha[i * NV + k], gy[k], m);
-        M[i] = m;
-      }
-#pragma unroll
-      for (int x = 0; x < D; ++x) {
-        double h = 0.0;
-#pragma unroll
-        for (int i = 0; i < NV; ++i) h = __builtin_fma(g[i][x], M[i], h);
-        hs[(a * D + x) * D + y] = h;
-      }
-      if (y == 0) ph[a] = phi[(int64_t)q * nloc + a];
-    }
-    __syncthreads();
-    // ---- state at the point: a lane per output (u_i | Gu_ix | the second-order part of Lu_i)
-    if (lane < D) {
-      double t = 0.0;
-      for (int a = 0; a < nloc; ++a) t = __builtin_fma(ph[a], Uk[a * D + lane], t);
-      st[lane] = t;
-    } else if (lane < D + D * D) {
-      const int i = (lane - D) / D, x = (lane - D) % D;
-      double t = 0.0;
-      for (int a = 0; a < nloc; ++a) t = __builtin_fma(gp[a * D + x], Uk[a * D + i], t);
-      st[D + i * D + x] = t;
-    } else if (lane < 2 * D + D * D) {
-      const int j = lane - D - D * D;     // Lu_j = -nu sum_a (lap_a U_aj + sum_i hs_a[j][i] U_ai)   (+ convective part below)
-      double t = 0.0;
-      for (int a = 0; a < nloc; ++a) {
-        double la = 0.0;                  // lap_a = trace of the Hessian (lap[] is written by other lanes in this phase)
-#pragma unroll
-        for (int x = 0; x < D; ++x) la += hs[(a * D + x) * D + x];
-        t = __builtin_fma(-nu * la, Uk[a * D + j], t);
-#pragma unroll
-        for (int i = 0; i < D; ++i) t = __builtin_fma(-nu * hs[(a * D + j) * D + i], Uk[a * D + i], t);
-      }
-      st[D + D * D + j] = t;
-    } else if (lane >= 32 && lane < 32 + nloc) {
-      const int a = lane - 32;
-      double la = 0.0;
-#pragma unroll
-      for (int x = 0; x < D; ++x) la += hs[(a * D + x) * D + x];
-      lap[a] = la;
-    }
-    __syncthreads();
-    double u[D], Gu[D][D], Lu[D];
-#pragma unroll
-    for (int i = 0; i < D; ++i) u[i] = st[i];
-#pragma unroll
-    for (int i = 0; i < D; ++i)
-#pragma unroll
-      for (int x = 0; x < D; ++x) Gu[i][x] = st[D + i * D + x];
-    double uu = 0.0;
-#pragma unroll
-    for (int i = 0; i < D; ++i) {
-      double t = st[D + D * D + i];
-#pragma unroll
-      for (int x = 0; x < D; ++x) t = __builtin_fma(u[x], Gu[i][x], t);
-      Lu[i] = t;
-      uu = __builtin_fma(u[i], u[i], uu);
-    }
-    const double vis = 4.0 * nu / h2;
-    const double beta = 1.0 / sqrt(4.0 * uu / h2 + magic * vis * vis);
-    const double b3 = -4.0 * beta * beta * beta / h2;
-    const double wt = wq[q] * vw;
-    // ---- element matrix.  Entry ((a, i), (b, j)) at this point is
-    //        wt (b3 u_j phi_b L_i s_a + beta dL_bij s_a + beta L_i phi_b dphi_a/dx_j),   s_a = u . grad phi_a,
-    //        dL_bij = phi_b G_ij - nu H_b[i][j] + delta_ij (- nu lap_b + s_b)
-    //      = saw[a] c1[b, i, j] + c2w[b, i] gp[a, j]   with the three tables below (nloc + nloc D D + nloc D values per point,
-    //      formed once by the wave instead of once per entry): two FMAs and four LDS reads per entry.
-    {
-      if (lane < nloc) {
-        double sa = 0.0;
-#pragma unroll
-        for (int x = 0; x < D; ++x) sa = __builtin_fma(u[x], gp[lane * D + x], sa);
-        saw[lane] = sa;                    // (scaled by wt below, after c1 has read the unscaled value)
-      }
-      __syncthreads();
-      for (int e = lane; e < nloc * D * D; e += 64) {
-        const int b = e / (D * D), i = (e / D) % D, j = e % D;
-        double Li = Lu[0], uj = u[0], Gij = 0.0;
-#pragma unroll
-        for (int tt = 1; tt < D; ++tt) {
-          Li = i == tt ? Lu[tt] : Li;
-          uj = j == tt ? u[tt] : uj;
+        for (int reg = 0; reg < 4; ++reg) {
+          const int r2 = 16 * tr + q + 4 * reg;
+          if (r2 < ND && c2 < ND) {
+            const int a = r2 / D, j = r2 - a * D;
+            EB[a * ND2 + c2 * D + j] += acc[tr * NR2 + tc][reg];
+          }
         }
-#pragma unroll
-        for (int ii = 0; ii < D; ++ii)
-#pragma unroll
-          for (int jj = 0; jj < D; ++jj) Gij = (i == ii && j == jj) ? Gu[ii][jj] : Gij;
-        double dL = __builtin_fma(ph[b], Gij, -nu * hs[e]);
-        if (i == j) dL += -nu * lap[b] + saw[b];
-        c1[e] = b3 * uj * ph[b] * Li + beta * dL;
-        if (j == 0) c2w[b * D + i] = wt * beta * Li * ph[b];
       }
-      __syncthreads();
-      if (lane < nloc) saw[lane] *= wt;
-      __syncthreads();
-#pragma unroll
-      for (int t = 0; t < EPL; ++t) {
-        // (opaque to the optimiser: otherwise the 4 EPL LDS addresses are hoisted out of the loop over the points and held in
-        // registers -- 256 + 47 of them, one wave per SIMD, every latency of a point exposed)
-        uint32_t k = pk[t];
-        asm volatile("" : "+v"(k));
-        acc[t] = __builtin_fma(saw[k & 255u], c1[(k >> 8) & 255u], __builtin_fma(c2w[(k >> 16) & 255u], gp[k >> 24], acc[t]));
-      }
-    }
-    __syncthreads();     // the next point overwrites gp / hs / st
   }
-  // into the scratch of the element blocks, E[slot][a][b][i D + j] (element_cell_kernel's layout; add: on top of its values)
-  double* Ec = E + (int64_t)blockIdx.x * nloc * nloc * (D * D);
-#pragma unroll
-  for (int t = 0; t < EPL; ++t) {
-    const int e = lane + 64 * t;
-    if (e < ndof * ndof) {
-      const int row = e / ndof, col = e % ndof;
-      const int at = ((row / D) * nloc + col / D) * (D * D) + (row % D) * D + col % D;
-      Ec[at] = add ? Ec[at] + acc[t] : acc[t];
-    }
-  }
+  __syncthreads();
+  double* Ec = E + (int64_t)blockIdx.x * (NLOC * ND2);
+  for (int e = tid; e < NLOC * ND2; e += 128) Ec[e] = add ? Ec[e] + EB[e] : EB[e];
 }
 
 // SUPG residual only (every Newton step evaluates it once more than it refreshes the operator): a LANE per cell, everything in
@@ -713,8 +767,6 @@ int launch_operator_refresh(alfi_level* L, double nu, double gamma, double adv, 
   ALFI_CHECK(ensure_scratch(ctx, (size_t)(batch * per_cell)));
   double* E = (double*)ctx->asm_scratch;
   const double gcell = S.full_div ? 0.0 : gamma, gfull = S.full_div ? gamma : 0.0;
-  const int epl = (ndof * ndof + 63) / 64;
-  const size_t lds = sizeof(double) * (size_t)(2 * nloc * d + nloc * d * d + 2 * nloc + 2 * d + d * d + nloc + nloc * d + nloc * d * d);
   for (int64_t c0 = 0; c0 < S.ncell; c0 += batch) {
     const int64_t c1 = std::min<int64_t>(c0 + batch, S.ncell);
     if (with_elements) {
@@ -727,17 +779,19 @@ int launch_operator_refresh(alfi_level* L, double nu, double gamma, double adv, 
       ALFI_HIP_CHECK(ctx, hipGetLastError());
     }
     if (with_supg) {
-      dim3 grid((unsigned)(c1 - c0)), block(64);
+      dim3 grid((unsigned)(c1 - c0)), block(128);
       const int add = with_elements ? 1 : 0;
-#define ALFI_SUPG_CELL(DV, EV)                                                                                                   \
-  hipLaunchKernelGGL((supg_cell_kernel<DV, EV>), grid, block, lds, ctx->stream, c0, S.ncell, nloc, S.cell_nodes, S.grad, S.vol,  \
-                     S.hcell, S.nq, S.wq, S.phi, S.dphi, S.d2phi, d_state, nu, weight, magic, add, E)
-      if (d == 2) {
-        if (epl <= 4) ALFI_SUPG_CELL(2, 4); else if (epl <= 16) ALFI_SUPG_CELL(2, 16); else ALFI_SUPG_CELL(2, 64);
-      } else {
-        if (epl <= 16) ALFI_SUPG_CELL(3, 16); else if (epl <= 32) ALFI_SUPG_CELL(3, 32); else ALFI_SUPG_CELL(3, 64);
-      }
-#undef ALFI_SUPG_CELL
+#define ALFI_SUPG_M(DV, NL)                                                                                                      \
+  hipLaunchKernelGGL((supg_matrix_kernel<DV, NL>), grid, block, 0, ctx->stream, c0, c1, S.cell_nodes, S.grad, S.vol, S.hcell,   \
+                     S.nq8 / 8, S.wq8, S.qtab, d_state, nu, weight, magic, add, E)
+      if (d == 2 && nloc == 3) { ALFI_SUPG_M(2, 3); }
+      else if (d == 2 && nloc == 6) { ALFI_SUPG_M(2, 6); }
+      else if (d == 3 && nloc == 4) { ALFI_SUPG_M(3, 4); }
+      else if (d == 3 && nloc == 8) { ALFI_SUPG_M(3, 8); }
+      else if (d == 3 && nloc == 10) { ALFI_SUPG_M(3, 10); }
+      else if (d == 3 && nloc == 14) { ALFI_SUPG_M(3, 14); }
+      else return alfi_set_error(ctx, ALFI_E_ARG, "no SUPG kernel for %d nodes per cell in %d-D", nloc, d);
+#undef ALFI_SUPG_M
       ALFI_HIP_CHECK(ctx, hipGetLastError());
     }
     dim3 g2((unsigned)((nnzb + 255) / 256)), b2(256);
