@@ -54,6 +54,8 @@ SIGNATURES = {
                                          ctypes.POINTER(vp)]),
     "alfi_level_destroy": (ctypes.c_int, [vp]),
     "alfi_level_update_values": (ctypes.c_int, [vp, vp]),
+    "alfi_ctx_comm_allow_self": (ctypes.c_int, [vp, ctypes.c_int]),
+    "alfi_level_halo_sum": (ctypes.c_int, [vp, vp]),
     "alfi_level_set_assembly": (ctypes.c_int, [vp, ctypes.c_int64, ctypes.c_int, vp, vp, vp, vp, vp, vp, ctypes.c_int, vp, vp, vp]),
     "alfi_ctx_set_assembly_scratch": (ctypes.c_int, [vp, ctypes.c_int64]),
     "alfi_level_assemble_supg": (ctypes.c_int, [vp, ctypes.c_double, ctypes.c_double, ctypes.c_double, vp, ctypes.c_double,

@@ -2492,6 +2492,15 @@ int alfi_level_halo_reverse_add(alfi_level* L, double* dv) {
   return halo_rev(L, dv);
 }
 
+// the merged exchange of the smoother (alfi_level_set_sum_exchange): every holder of a shared node ends with the sum of all
+// holders' values
+int alfi_level_halo_sum(alfi_level* L, double* dv) {
+  if (!L->distributed) return 0;
+  if (!L->sum_ready) return alfi_set_error(L->ctx, ALFI_E_STATE, "alfi_level_halo_sum before alfi_level_set_sum_exchange");
+  L->ctx->cur_tag = L->id;
+  return halo_sum(L, dv);
+}
+
 struct alfi_csr {
   alfi_ctx* ctx = nullptr;
   DevCSR M;

@@ -239,6 +239,14 @@ int alfi_ctx_comm_size(alfi_ctx* ctx, int* rank, int* nranks) {
   return 0;
 }
 
+// TEST HOOK: a rank may name ITSELF as a neighbour.  RCCL accepts a grouped ncclSend + ncclRecv to one's own rank, so the one
+// GPU of a test box runs the real point-to-point path -- pack, group of send / receive pairs on the library's stream, unpack --
+// with non-empty buffers (tests/test_gpu_dist.py::test_real_rccl_send_recv_to_self).  No partition of a mesh produces this.
+int alfi_ctx_comm_allow_self(alfi_ctx* ctx, int on) {
+  ctx->comm_allow_self = on != 0;
+  return 0;
+}
+
 int alfi_ctx_comm_destroy(alfi_ctx* ctx) {
   native_destroy(ctx);
   return 0;
@@ -254,7 +262,7 @@ int alfi_level_set_neighbours(alfi_level* L, int nnbr, const int32_t* ranks, con
   std::vector<int> nr;
   std::vector<int64_t> soff, scnt, roff, rcnt;
   for (int i = 0; i < nnbr; ++i) {
-    if (ranks[i] < 0 || ranks[i] >= world || ranks[i] == me || (i > 0 && ranks[i] <= ranks[i - 1]))
+    if (ranks[i] < 0 || ranks[i] >= world || (ranks[i] == me && !ctx->comm_allow_self) || (i > 0 && ranks[i] <= ranks[i - 1]))
       return alfi_set_error(ctx, ALFI_E_ARG, "neighbour ranks must be ascending, distinct from this rank and inside the group");
     if (send_nodes[i] < 0 || recv_nodes[i] < 0) return alfi_set_error(ctx, ALFI_E_ARG, "negative neighbour count");
     nr.push_back(ranks[i]);
@@ -290,7 +298,7 @@ int alfi_level_set_sum_exchange(alfi_level* L, int nnbr, const int32_t* ranks, c
   std::vector<int64_t> off, cnt;
   int64_t total = 0;
   for (int i = 0; i < nnbr; ++i) {
-    if (ranks[i] < 0 || ranks[i] >= world || ranks[i] == me || (i > 0 && ranks[i] <= ranks[i - 1]))
+    if (ranks[i] < 0 || ranks[i] >= world || (ranks[i] == me && !ctx->comm_allow_self) || (i > 0 && ranks[i] <= ranks[i - 1]))
       return alfi_set_error(ctx, ALFI_E_ARG, "neighbour ranks must be ascending, distinct from this rank and inside the group");
     if (counts[i] <= 0) return alfi_set_error(ctx, ALFI_E_ARG, "a sum-exchange neighbour shares no node");
     nr.push_back(ranks[i]);

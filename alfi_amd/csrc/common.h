@@ -39,6 +39,7 @@ struct alfi_ctx {
   // mesh-partition parallelism (alfi_ctx_set_comm)
   alfi_comm_fn comm = nullptr;
   void* comm_user = nullptr;
+  bool comm_allow_self = false;   // test hook (alfi_ctx_comm_allow_self): a rank may be its own neighbour
   bool exact_norm = true;   // partitioned FGMRES: second all-reduce for |w - V h| (PETSc's VecNorm); false: Pythagorean identity
   double* dred = nullptr;  // device buffer that is all-reduced: [0, RED_MAXV) dots, [RED_MAXV] norm^2 (caller-owned with
                            // alfi_ctx_set_comm, owned by the ctx with alfi_ctx_comm_init)

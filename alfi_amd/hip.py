@@ -55,6 +55,10 @@ class Context(object):
         buf = ctypes.create_string_buffer(bytes(unique_id), _lib.COMM_ID_BYTES)
         self.check(self.lib.alfi_ctx_comm_init(self.h, ctypes.cast(buf, vp), int(rank), int(nranks)))
 
+    def comm_allow_self(self, on=True):
+        """TEST HOOK (alfi_ctx_comm_allow_self): a rank may name itself as a neighbour."""
+        self.check(self.lib.alfi_ctx_comm_allow_self(self.h, 1 if on else 0))
+
     def comm_size(self):
         """(rank, ranks) of the communicator the library itself exchanges over (alfi_ctx_comm_size)."""
         r, n = ctypes.c_int(), ctypes.c_int()
@@ -363,6 +367,10 @@ class Level(object):
     def halo_forward(self, v):
         """Partitioned level: ghost slots of v <- their owners' values (no-op otherwise)."""
         self.ctx.check(self.ctx.lib.alfi_level_halo_forward(self.h, v.ptr))
+
+    def halo_sum(self, v):
+        """Partitioned level with a sum-exchange plan: every holder of a shared node gets the sum of all holders' values."""
+        self.ctx.check(self.ctx.lib.alfi_level_halo_sum(self.h, v.ptr))
 
     def halo_reverse_add(self, v):
         """Partitioned level: ghost slots of v added onto their owners' entries (no-op otherwise)."""

@@ -309,6 +309,32 @@ def main_distributed(args, rank, world, local_rank):
     for dl, p in zip(dmg.levels, dmg.parts[dmg.lmin:]):
         if not p.distributed and p.nb_own > 0:
             single_ms += sum(v[0] for v in ctx.prof_get(dl.id).values())
+    from alfi_amd._lib import EVENTS
+    ev_v = [ctx.prof_get()[kname][0] for kname in EVENTS]          # this rank's device time per event class, one V-cycle
+    ctx.prof_enable(False)
+    # the cycle the reference actually applies is the FULL cycle (pc_mg_type full, solver.py:366): every level below the finest
+    # is visited more often than in a V-cycle, so the single-owner levels weigh more.  Two timed F-cycles (max over ranks), then
+    # one fully instrumented one for the per-rank event table and the single-owner share.
+    dxf = dmg.local_vec()
+    dmg.fcycle(db, dxf)
+    dmg.sync()
+    dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(2):
+        dmg.fcycle(db, dxf)
+    dmg.sync()
+    torch.cuda.synchronize()
+    f_ms = 1e3 * (time.perf_counter() - t0) / 2
+    ctx.prof_enable(True)
+    ctx.prof_reset()
+    dmg.fcycle(db, dxf)
+    dmg.sync()
+    single_f_ms = 0.0
+    for dl, p in zip(dmg.levels, dmg.parts[dmg.lmin:]):
+        if not p.distributed and p.nb_own > 0:
+            single_f_ms += sum(v[0] for v in ctx.prof_get(dl.id).values())
+    ev_f = [ctx.prof_get()[kname][0] for kname in EVENTS]
     ctx.prof_enable(False)
     lib_rank, lib_world = ctx.comm_size() if dmg.transport == "rccl" else (rank, None)
     nbr_max = max([int(np.count_nonzero((p.send_counts > 0) | (p.recv_counts > 0))) for p in dmg.parts] + [0])
@@ -345,13 +371,16 @@ def main_distributed(args, rank, world, local_rank):
     rss_gb = resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 1e6
     stats = torch.tensor([float(npatch), float(dmg.n_own), float(dmg.n_loc - dmg.n_own), local_gbs, comm_ms, rss_gb,
                           t_gen, t_setup, float(n_halo), float(n_red), 8e-6 * sent, float(nbr_max), single_ms,
-                          float(lib_world if lib_world is not None else -1)] + [dmg.setup_s.get(kk, 0.0) for kk in SETUP_KEYS],
+                          float(lib_world if lib_world is not None else -1)] + [dmg.setup_s.get(kk, 0.0) for kk in SETUP_KEYS]
+                         + [f_ms, single_f_ms] + ev_v + ev_f,
                          dtype=torch.float64, device="cuda")
     allstats = [torch.zeros_like(stats) for _ in range(world)]
     dist.all_gather(allstats, stats)
     if rank == 0:
         vps = args.steps / elapsed
         per_rank = [[float(v) for v in t.tolist()] for t in allstats]
+        o_f = 14 + len(SETUP_KEYS)                # [f_ms, single_f_ms, events of a V-cycle, events of an F-cycle]
+        ne = len(EVENTS)
         out = {
             "metric": ("V-cycles/sec on bfs3d SV P3-P2dg (DoF*smooths/sec in dof_smooths_per_s)" if CONFIGS[args.config][0] == "sv"
                    else "V-cycles/sec on ldc%dd P2-P0 (DoF*smooths/sec in dof_smooths_per_s)" % CONFIGS[args.config][0]),
@@ -365,6 +394,10 @@ def main_distributed(args, rank, world, local_rank):
             "process_group_size": int(dist.get_world_size()),
             "neighbours_max": int(max(r[11] for r in per_rank)),
             "single_owner_levels_ms": round(per_rank[0][12], 3),
+            # the FULL cycle (what the reference applies per MG application, solver.py:366): wall time (max over ranks, two
+            # cycles between barriers) and rank 0's device time on the levels it owns alone -- the Amdahl term of that cycle
+            "fcycle_ms": round(max(r[o_f] for r in per_rank), 3),
+            "fcycle_single_owner_levels_ms": round(per_rank[0][o_f + 1], 3),
             "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
@@ -394,6 +427,11 @@ def main_distributed(args, rank, world, local_rank):
                          "MB_sent_per_cycle": [round(r[10], 2) for r in per_rank],
                          "neighbours_max": [int(r[11]) for r in per_rank],
                          "single_owner_levels_ms": [round(r[12], 3) for r in per_rank],
+                         "fcycle_ms": [round(r[o_f], 3) for r in per_rank],
+                         "fcycle_single_owner_levels_ms": [round(r[o_f + 1], 3) for r in per_rank],
+                         # device time per event class and rank (HIP events on each rank's stream), one fully instrumented cycle
+                         "events_ms_vcycle": {kname: [round(r[o_f + 2 + i], 3) for r in per_rank] for i, kname in enumerate(EVENTS)},
+                         "events_ms_fcycle": {kname: [round(r[o_f + 2 + ne + i], 3) for r in per_rank] for i, kname in enumerate(EVENTS)},
                          "setup_s": {kk: [round(r[14 + i], 2) for r in per_rank] for i, kk in enumerate(SETUP_KEYS)}},
             "rel_residual_after_timed_cycles": res,
             "setup_s": {"host_generation": round(max(r[6] for r in per_rank), 1),

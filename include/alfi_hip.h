@@ -86,6 +86,9 @@ int alfi_prof_get_level(alfi_ctx* ctx, int ev, int level_id, double* total_ms, i
 #define ALFI_COMM_ID_BYTES 128
 int alfi_comm_unique_id(void* id_out, int64_t len);                                  /* ncclGetUniqueId */
 int alfi_ctx_comm_init(alfi_ctx* ctx, const void* id, int rank, int nranks);        /* ncclCommInitRank on the ctx's device */
+/* TEST HOOK: allow a rank to name itself as a neighbour (a grouped ncclSend + ncclRecv to one's own rank), so that a
+ * one-GPU box exercises the real point-to-point path with non-empty halos */
+int alfi_ctx_comm_allow_self(alfi_ctx* ctx, int on);
 int alfi_ctx_comm_size(alfi_ctx* ctx, int* rank, int* nranks);
 /* exchange points issued since the last reset: halo exchanges (forward and reverse-add), all-reduces, and the doubles this
  * rank sent in them (either transport).  What the reference spends in PetscSF scatters and MPI_Allreduce [3P]. */
@@ -370,6 +373,7 @@ int alfi_saddle_solve(alfi_saddle* s, const double* db, double* dx, double rtol,
  * (PETSc's VecScatter forward / reverse-add on the velocity DM).  No-ops on levels that are not distributed. */
 int alfi_level_halo_forward(alfi_level* lvl, double* dv);
 int alfi_level_halo_reverse_add(alfi_level* lvl, double* dv);
+int alfi_level_halo_sum(alfi_level* lvl, double* dv);   /* the merged exchange of alfi_level_set_sum_exchange */
 /* a scalar CSR matrix on the device (the rank's rows of the discrete divergence and its transpose) */
 typedef struct alfi_csr alfi_csr;
 int alfi_csr_create(alfi_ctx* ctx, const alfi_csr_host* M, alfi_csr** out);

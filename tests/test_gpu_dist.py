@@ -407,3 +407,77 @@ def test_two_rank_rccl_run():
     assert out.returncode == 0 and d is not None, out.stderr[-3000:]
     assert d["n_ranks_seen"] == 2 and d["config"]["transport"] == "rccl" and d["config"]["backend"] == "nccl"
     assert d["rel_residual_after_timed_cycles"] < 0.5
+
+
+def test_real_rccl_send_recv_to_self(tmp_path):
+    """The REAL point-to-point path of the native transport with NON-EMPTY buffers on the one GPU of the box: a 1-rank RCCL
+    communicator whose rank names itself as its neighbour (test hook alfi_ctx_comm_allow_self; RCCL accepts a grouped
+    ncclSend + ncclRecv to one's own rank).  alfi_level_halo_forward, alfi_level_halo_reverse_add and the merged sum exchange
+    (pack kernel, ONE group of send / receive pairs on the library's stream, unpack / add kernels: csrc/comm.hip:native_exchange)
+    against the same index arithmetic in NumPy.  Reference: PETSc's VecScatter forward / reverse-add around PCApply_PATCH
+    and MatMult under alfi/solver.py:604-605, alfi/relaxation.py:120-121."""
+    import textwrap
+    script = tmp_path / "self_exchange.py"
+    script.write_text(textwrap.dedent('''
+        import sys
+        import numpy as np
+        sys.path.insert(0, %r)
+        from alfi_amd import hip, _lib
+        from alfi_amd.problem import BSR
+        rng = np.random.default_rng(7)
+        bs, n_own, n_ghost = 3, 5000, 1300
+        nb = n_own + n_ghost
+        A = BSR(nb, nb, bs, np.arange(nb + 1, dtype=np.int32), np.arange(nb, dtype=np.int32), np.tile(np.eye(bs), (nb, 1, 1)))
+        ctx = hip.Context(0)
+        ctx.comm_init(_lib.comm_unique_id(), 0, 1)
+        assert ctx.comm_size() == (0, 1)
+        ctx.comm_allow_self(True)
+        L = hip.Level(ctx, A, np.zeros(0, dtype=np.int32))
+        # ghost slot j is a copy of owned node send_nodes[j] (several ghosts may copy one node)
+        send_nodes = rng.integers(0, n_own, n_ghost).astype(np.int32)
+        L.set_partition(n_own, True, send_nodes, None, None, n_ghost)
+        L.set_neighbours([0], [n_ghost], [n_ghost])
+        v = rng.standard_normal(nb * bs)
+        V = v.reshape(nb, bs)
+        # forward: owner -> ghost copies
+        dv = ctx.vec(v)
+        ctx.comm_stats(reset=True)
+        L.halo_forward(dv)
+        got = dv.get().reshape(nb, bs)
+        want = V.copy(); want[n_own:] = V[send_nodes]
+        assert np.array_equal(got, want), "forward"
+        # reverse-add: ghost values summed onto their owners, in buffer order
+        dv = ctx.vec(v)
+        L.halo_reverse_add(dv)
+        got = dv.get().reshape(nb, bs)
+        want = V.copy()
+        for j in np.argsort(send_nodes, kind="stable"):
+            want[send_nodes[j]] += V[n_own + j]
+        assert np.abs(got - want).max() <= 1e-15 * np.abs(want).max() and np.array_equal(got[n_own:], V[n_own:]), "reverse-add"
+        # merged sum exchange: every shared node = its own value + the values received for it, in list order
+        ns = 900
+        sum_send = rng.integers(0, nb, ns).astype(np.int32)              # what this rank sends (and, to itself, receives)
+        shared = np.sort(rng.choice(nb, 400, replace=False)).astype(np.int32)
+        ptr, src = [0], []
+        for u in shared:
+            k = int(rng.integers(1, 4))
+            lst = list(rng.integers(0, ns, k))
+            lst.insert(int(rng.integers(0, k + 1)), -1)                    # exactly one own value, at a random place
+            src += lst; ptr.append(len(src))
+        L.set_sum_exchange([0], [ns], sum_send, shared, np.asarray(ptr, dtype=np.int32), np.asarray(src, dtype=np.int32))
+        dv = ctx.vec(v)
+        L.halo_sum(dv)
+        got = dv.get().reshape(nb, bs)
+        want = V.copy()
+        for i, u in enumerate(shared):
+            acc = np.zeros(bs)
+            for s_ in src[ptr[i]:ptr[i + 1]]:
+                acc = acc + (V[u] if s_ < 0 else V[sum_send[s_]])
+            want[u] = acc
+        assert np.abs(got - want).max() <= 1e-15 * np.abs(want).max(), "sum exchange"
+        halos, reds, sent = ctx.comm_stats()
+        assert halos == 3 and sent == (n_ghost + n_ghost + ns) * bs, (halos, sent)
+        print("SELF-EXCHANGE-OK")
+    ''' % (ROOT,)))
+    out = subprocess.run([sys.executable, str(script)], cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "SELF-EXCHANGE-OK" in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]
