@@ -81,6 +81,30 @@ def overlap_decision(splits, bs, distributed, overlap, overlap_min_dofs):
     return bool(shares.size > 0 and int(shares.min()) * bs >= overlap_min_dofs)
 
 
+# The overlap rule (scripts/overlap_rule.py measures its two constants on one GPU: profiles/r05_overlap_rule.txt).
+# The overlapped smoother iteration splits every patch apply / product into interior | boundary launches around asynchronous
+# begin / end pairs on RCCL's own stream (two cross-stream waits each) and needs three exchanges where the plain one needs two:
+# a FIXED cost per iteration, OVERLAP_FIXED_US.  What it can hide is the time one halo exchange takes on the critical path,
+#     t_exchange = EXCHANGE_LATENCY_US + bytes to the busiest neighbour / link bandwidth
+# (xGMI is point to point: the messages to the <= 7 neighbours of a box partition travel over separate links at the same time).
+# An exchange hides only behind work that needs no ghost value: the patch solves / rows of the rank's interior, t_interior.
+# The plain iteration exposes two exchanges, so overlap pays when 2 min(t_exchange, t_interior) exceeds the fixed cost.
+OVERLAP_FIXED_US = 65.7           # per smoother iteration, measured: (overlapped - plain) iteration with a 1-rank RCCL group
+EXCHANGE_LATENCY_US = 17.5        # one grouped ncclSend / ncclRecv exchange of a few KB incl. pack / unpack kernels, measured
+XGMI_LINK_GBPS = 0.8 * 153.0      # MI355X: 153 GB/s per link and direction, 80 % reachable (MI355X_MICROARCH.md)
+HBM_STREAM_GBPS = 6000.0          # what the patch apply streams its inverses at
+
+
+def overlap_rule(max_neighbour_bytes, min_interior_bytes):
+    """True when hiding the exchanges of a smoother iteration behind interior work is expected to pay:
+    2 min(t_exchange, t_interior) > OVERLAP_FIXED_US.  ``max_neighbour_bytes``: the largest message of the level's halo
+    exchange; ``min_interior_bytes``: the patch-inverse bytes of the interior patches (what the interior launch streams);
+    maximum / minimum over ALL ranks -- the decision must be collective, see overlap_decision."""
+    t_exchange = EXCHANGE_LATENCY_US + max_neighbour_bytes / (XGMI_LINK_GBPS * 1e3)
+    t_interior = min_interior_bytes / (HBM_STREAM_GBPS * 1e3)
+    return 2.0 * min(t_exchange, t_interior) > OVERLAP_FIXED_US
+
+
 class LevelPart(object):
     """One rank's view of one level: owned range, ghosts, local numbering, halo plan."""
 
@@ -631,9 +655,16 @@ class DistMultigrid(object):
         self.overlap = overlap
         self._in_cycle = False
         self._red_views = {}
+        # which levels overlap: ALFI_DIST_OVERLAP_MIN_DOFS (smallest per-rank share that overlaps; tests, measurements) or,
+        # without it, the rule above from the halo sizes of the partition (ALFI_DIST_OVERLAP_RULE=0: never)
+        use_rule = False
         if overlap_min_dofs is None:
             import os
-            overlap_min_dofs = int(os.environ.get("ALFI_DIST_OVERLAP_MIN_DOFS", str(1 << 62)))
+            if "ALFI_DIST_OVERLAP_MIN_DOFS" in os.environ:
+                overlap_min_dofs = int(os.environ["ALFI_DIST_OVERLAP_MIN_DOFS"])
+            else:
+                overlap_min_dofs = 1 << 62
+                use_rule = overlap and os.environ.get("ALFI_DIST_OVERLAP_RULE", "1") != "0"
         if device is None:
             device = torch.device("cuda", torch.cuda.current_device())
         self.device = device
@@ -671,6 +702,23 @@ class DistMultigrid(object):
                 ctx.set_comm(self._cb, self.red.data_ptr(), RED_LEN)
             self.halos = {}
             self.levels = []
+            self.overlap_levels = []
+            rule = {}
+            if use_rule:
+                # collective, once, over the global list of levels: the largest message of every level's exchange on any rank
+                # (and the fewest inverse bytes of interior patches)
+                mine = []
+                for i, p in enumerate(self.parts):
+                    msg = 8 * p.bs * int(max(p.send_counts.max(initial=0), p.recv_counts.max(initial=0))) if p.distributed else 0
+                    LL = llev[i - self.lmin] if i >= self.lmin else None
+                    inner = float("inf")
+                    if LL is not None and LL.level > 0 and p.nb_own > 0:
+                        sizes = np.diff(np.asarray(LL.patch_ptr[:LL.npatch_int + 1], dtype=np.int64)).astype(np.float64)
+                        inner = 8.0 * float((sizes * sizes).sum())
+                    mine.append((msg, inner))
+                every = self.comm.all_gather_object(mine)
+                rule = {p.level: bool(p.distributed and overlap_rule(max(e[i][0] for e in every), min(e[i][1] for e in every)))
+                        for i, p in enumerate(self.parts)}
             stage("upload_factor")
             t0 = time.time()
             for LL in llev:
@@ -695,13 +743,11 @@ class DistMultigrid(object):
                     if hip.condense_patches(LL):
                         dl.set_patch_groups(LL.patch_groups)
                     dl.factor_with_fallback()
-                    if overlap_decision(p.splits, p.bs, p.distributed, overlap, overlap_min_dofs):
-                        # interior rows / patches are worked on while the forward halo is in flight.  Opt-in
-                        # (ALFI_DIST_OVERLAP_MIN_DOFS = smallest per-rank share that overlaps): the split launches and the
-                        # asynchronous begin/end pairs (RCCL's own stream, two cross-stream waits each) have a fixed cost
-                        # -- measured with a 1-rank RCCL group and all exchange points on: 173 k dofs 8.9 ms per cycle
-                        # with, 7.0 ms without (plain path 5.2); 1.35 M dofs +7.4 ms with, +3.3 ms without -- which is
-                        # more than the ~3 ms of wire time per cycle the overlap can hide on config 4 at 2 to 8 ranks
+                    decided = rule[LL.level] if use_rule else overlap_decision(p.splits, p.bs, p.distributed, overlap,
+                                                                               overlap_min_dofs)
+                    if decided:
+                        # interior rows / patches are worked on while the forward halo is in flight (overlap_rule above)
+                        self.overlap_levels.append(LL.level)
                         dl.set_overlap(p.nb_int, LL.npatch_int)
                 elif p.nb_own > 0:
                     self._coarse(dl, levels[0].A, coarse_inverse)
