@@ -19,6 +19,11 @@ What is derived, and from which lines of the reference (/root/reference/alfi):
 * nodal interpolation (firedrake.prolong [3P], transfer.py:284-286): row of a fine node = coarse basis at that node.  For
   2-D P2 the values are {1, 3/8, 3/4, -1/8, 1/2, 1/4, 0} with at most 6 non-zeros per row.
 
+* the state-dependent terms the operator refresh of a Newton step forms (solver.py:565-568, 204-234; stabilisation.py:47-97):
+  the linearised advection term about a field of the element space, exactly; the SUPG linearisation about a constant state,
+  exactly up to the scalar weight * beta; the SUPG terms about a general state by a quadrature rule handed in (beta is not
+  polynomial), from the exact basis.  Consumer: tests/test_gpu_exact_pins.py -- the DEVICE assembly against these.
+
 Consumers: tests/test_exact_pins.py (CPU) compares the product's tabulation, assembled element matrices and prolongation
 matrices -- and the NumPy oracle's quadrature assembly -- with these, matching nodes by POSITION, never by index.
 """
@@ -222,6 +227,182 @@ def sv_matrices(dim, name, pname, vertices, nu, gamma):
     B = [[[-vol * p_average(p_mul(pbasis[j], dphi[a][x])) for x in range(dim)] for a in range(n)] for j in range(m)]
     M = [[vol * p_average(p_mul(pbasis[j], pbasis[l])) for l in range(m)] for j in range(m)]
     return nodes, pnodes, A, B, M
+
+
+# -- state-dependent terms: advection (exact) and SUPG (exact for a constant state; by a given quadrature rule otherwise) ----------
+def _physical_gradients(dim, basis, grads):
+    """dphi[a][x]: d phi_a / d x_x as a polynomial in the barycentric coordinates."""
+    out = []
+    for b in basis:
+        dl = [p_diff(b, i) for i in range(dim + 1)]
+        row = []
+        for x in range(dim):
+            acc = {}
+            for i in range(dim + 1):
+                acc = p_add(acc, p_scale(dl[i], grads[i][x]))
+            row.append(acc)
+        out.append(row)
+    return out
+
+
+def _to_int(poly):
+    """(integer-coefficient polynomial, denominator): products of many polynomials are taken in integers (Fractions are slow)."""
+    den = 1
+    for c in poly.values():
+        c = Fraction(c)
+        den = den * c.denominator // _gcd(den, c.denominator)
+    return {e: int(Fraction(c) * den) for e, c in poly.items()}, den
+
+
+def _gcd(a, b):
+    while b:
+        a, b = b, a % b
+    return a
+
+
+def advection_matrix(dim, name, vertices, w):
+    """Exact element matrix of the Newton-linearised advection term of alfi/solver.py:565-568 about the field
+    w = sum_k w[k] phi_k (w[k]: ``dim`` rationals per node of element_nodes(dim, name)):
+        N[a][c][b][d] = int ((w . grad) phi_b delta_cd + phi_b d_d w_c) phi_a .
+    Returns (nodes, N) with Fractions."""
+    nodes, basis = cached_basis(dim, name)
+    grads, vol = barycentric_gradients(vertices)
+    n = len(nodes)
+    dphi = _physical_gradients(dim, basis, grads)
+    bi = [_to_int(b) for b in basis]
+    di = [[_to_int(dphi[a][x]) for x in range(dim)] for a in range(n)]
+    # T[k][x][b][a] = int phi_k d_x phi_b phi_a
+    T = [[[[None] * n for _ in range(n)] for _ in range(dim)] for _ in range(n)]
+    for k in range(n):
+        for a in range(k, n):
+            pk, dk = bi[k]
+            pa, da = bi[a]
+            prod = p_mul(pk, pa)
+            for b in range(n):
+                for x in range(dim):
+                    pb, db = di[b][x]
+                    v = vol * p_average(p_mul(prod, pb)) / (dk * da * db) if pb else Fraction(0)
+                    T[k][x][b][a] = v
+                    T[a][x][b][k] = v
+    w = [[Fraction(v) for v in wk] for wk in w]
+    N = [[[[Fraction(0) for _ in range(dim)] for _ in range(n)] for _ in range(dim)] for _ in range(n)]
+    for a in range(n):
+        for b in range(n):
+            t1 = sum(w[k][x] * T[k][x][b][a] for k in range(n) for x in range(dim))
+            for c in range(dim):
+                for d in range(dim):
+                    # phi_b d_d w_c phi_a = sum_k w[k][c] int phi_b d_d phi_k phi_a = sum_k w[k][c] T[b][d][k][a]
+                    N[a][c][b][d] = (t1 if c == d else 0) + sum(w[k][c] * T[b][d][k][a] for k in range(n))
+    return nodes, N
+
+
+def circumradius_squared(vertices):
+    """R^2 of the simplex, exactly (the circumcentre solves a linear system with rational coefficients); Firedrake's CellSize
+    is 2 R [3P] (alfi/problem.py:46-52 -> stabilisation.py)."""
+    dim = len(vertices) - 1
+    v0 = vertices[0]
+    A = sp.Matrix(dim, dim, lambda i, j: sp.Rational(*_frac(2 * (vertices[i + 1][j] - v0[j]))))
+    rhs = sp.Matrix(dim, 1, lambda i, _: sp.Rational(*_frac(sum(Fraction(vertices[i + 1][j]) ** 2 - Fraction(v0[j]) ** 2 for j in range(dim)))))
+    c = A.solve(rhs)
+    r2 = sum((c[j] - sp.Rational(*_frac(v0[j]))) ** 2 for j in range(dim))
+    return Fraction(int(r2.p), int(r2.q))
+
+
+def supg_matrix_constant_state(dim, name, vertices, nu, c):
+    """SUPG linearisation (alfi/stabilisation.py:47-97, solver.py:204-234) about a CONSTANT state u = c, divided by
+    weight * beta: with grad u = 0 the strong residual Lu vanishes, beta is a constant and what is left of the Newton
+    linearisation of  weight * beta * inner(Lu, dot(grad(v), u))  is
+        M[a][i][b][j] = int (dLu)_ij (c . grad phi_a),   (dLu)_ij = - nu (delta_ij Lap phi_b + d_i d_j phi_b) + delta_ij c . grad phi_b
+    -- a polynomial integrand: exact.  Returns (nodes, M) with Fractions."""
+    nodes, basis = cached_basis(dim, name)
+    grads, vol = barycentric_gradients(vertices)
+    nu = Fraction(nu)
+    c = [Fraction(x) for x in c]
+    n = len(nodes)
+    dphi = _physical_gradients(dim, basis, grads)
+    s = []
+    for a in range(n):
+        acc = {}
+        for x in range(dim):
+            acc = p_add(acc, p_scale(dphi[a][x], c[x]))
+        s.append(acc)
+    # second physical derivatives d_x d_y phi_b
+    d2 = []
+    for b in range(n):
+        rows = []
+        for x in range(dim):
+            dl = [p_diff(dphi[b][x], i) for i in range(dim + 1)]
+            row = []
+            for y in range(dim):
+                acc = {}
+                for i in range(dim + 1):
+                    acc = p_add(acc, p_scale(dl[i], grads[i][y]))
+                row.append(acc)
+            rows.append(row)
+        d2.append(rows)
+    M = [[[[Fraction(0) for _ in range(dim)] for _ in range(n)] for _ in range(dim)] for _ in range(n)]
+    for b in range(n):
+        lap = {}
+        for x in range(dim):
+            lap = p_add(lap, d2[b][x][x])
+        for i in range(dim):
+            for j in range(dim):
+                dL = p_scale(d2[b][i][j], -nu)
+                if i == j:
+                    dL = p_add(p_add(dL, p_scale(lap, -nu)), s[b])
+                for a in range(n):
+                    M[a][i][b][j] = vol * p_average(p_mul(dL, s[a]))
+    return nodes, M
+
+
+def supg_by_quadrature(dim, name, vertices, nu, weight, magic, U, lam_pts, wts):
+    """The SUPG terms about a general state U (U[k]: ``dim`` floats per node of element_nodes) by a GIVEN quadrature rule
+    (barycentric points, weights summing to 1) -- beta is not polynomial --, from the exact nodal basis of this module
+    evaluated in floating point: (F[a][i], A[a][i][b][j]) with
+        F = weight int beta Lu_i s_a,    Lu = - nu div(2 sym grad u) + (grad u) u,    s_a = u . grad phi_a,
+        beta = (4 u.u / h^2 + magic (4 nu / h^2)^2)^(-1/2),   h = 2 x circumradius,
+        A = dF / dU[b][j]  (alfi/stabilisation.py:86-97; the derivative of beta included)."""
+    import math
+    nodes, basis = cached_basis(dim, name)
+    grads, vol = barycentric_gradients(vertices)
+    n = len(nodes)
+    dphi = _physical_gradients(dim, basis, grads)
+    d2 = [[[None] * dim for _ in range(dim)] for _ in range(n)]
+    for b in range(n):
+        for x in range(dim):
+            dl = [p_diff(dphi[b][x], i) for i in range(dim + 1)]
+            for y in range(dim):
+                acc = {}
+                for i in range(dim + 1):
+                    acc = p_add(acc, p_scale(dl[i], grads[i][y]))
+                d2[b][x][y] = acc
+    h2 = float(4 * circumradius_squared(vertices))
+    nu, vol = float(nu), float(vol)
+    F = [[0.0] * dim for _ in range(n)]
+    A = [[[[0.0] * dim for _ in range(n)] for _ in range(dim)] for _ in range(n)]
+    for lam, wq in zip(lam_pts, wts):
+        lam = [float(x) for x in lam]
+        ph = [float(p_eval(basis[a], lam)) for a in range(n)]
+        gp = [[float(p_eval(dphi[a][x], lam)) for x in range(dim)] for a in range(n)]
+        hs = [[[float(p_eval(d2[a][x][y], lam)) for y in range(dim)] for x in range(dim)] for a in range(n)]
+        lap = [sum(hs[a][x][x] for x in range(dim)) for a in range(n)]
+        u = [sum(ph[a] * U[a][i] for a in range(n)) for i in range(dim)]
+        Gu = [[sum(gp[a][x] * U[a][i] for a in range(n)) for x in range(dim)] for i in range(dim)]
+        Lu = [sum(-nu * (lap[a] * U[a][i] + sum(hs[a][i][j] * U[a][j] for j in range(dim))) for a in range(n))
+              + sum(u[x] * Gu[i][x] for x in range(dim)) for i in range(dim)]
+        uu = sum(x * x for x in u)
+        beta = 1.0 / math.sqrt(4.0 * uu / h2 + magic * (4.0 * nu / h2) ** 2)
+        s = [sum(u[x] * gp[a][x] for x in range(dim)) for a in range(n)]
+        wt = float(wq) * vol * weight
+        for a in range(n):
+            for i in range(dim):
+                F[a][i] += wt * beta * Lu[i] * s[a]
+                for b in range(n):
+                    for j in range(dim):
+                        dbeta = -4.0 * beta ** 3 * u[j] * ph[b] / h2
+                        dL = -nu * hs[b][i][j] + ph[b] * Gu[i][j] + ((-nu * lap[b] + s[b]) if i == j else 0.0)
+                        A[a][i][b][j] += wt * (dbeta * Lu[i] * s[a] + beta * dL * s[a] + beta * Lu[i] * ph[b] * gp[a][j])
+    return nodes, F, A
 
 
 def interpolation_row(dim, name, lam):

@@ -188,3 +188,67 @@ def test_scott_vogelius_matrices_are_exact(dim, name, pname, args):
                 for e in range(dim):
                     diff = A[a][c][b][e] - A0[a][c][b][e]
                     assert G[a * dim + c, b * dim + e] == sympy.Rational(diff.numerator, diff.denominator)
+
+
+@pytest.mark.parametrize("ncell", [1, 2])
+@pytest.mark.parametrize("dim,name,args", ELEMENTS[:3])
+def test_state_dependent_terms_of_the_host_assembler_are_exact(dim, name, args, ncell):
+    """The terms a Newton step re-forms (solver.py:565-568, 204-234; stabilisation.py:47-97) on a one- and a two-cell mesh with
+    rational vertices, the product's HOST assembler (csrc/host_assemble.cpp) against oracle/exact_pins.py: nu K + gamma D +
+    adv N(w) exactly; the SUPG linearisation about a constant state exactly up to weight * beta (and its vanishing residual);
+    the SUPG terms about a general state from the exact basis by an independently built Gauss-Jacobi rule.  Nodes matched by
+    position.  The DEVICE assembly meets the same values in tests/test_gpu_exact_pins.py."""
+    import scipy.sparse as sp
+    from tests import exact_cases as C
+    mesh, V = C.build_space(dim, args, ncell)
+    d = V.dim
+    nu, gamma, adv = Fraction(3, 70), Fraction(1250, 3), Fraction(3, 4)
+    w = C.rational_field(dim, V)
+    exact = C.exact_operator(dim, name, ncell, V, nu, gamma, adv, w)
+    rowptr, colidx = _hostlib.node_graph(V.cell_nodes, V.num_nodes)
+    g, vol = mesh.cell_geometry()
+    wf = np.array([[float(x) for x in r] for r in w])
+    vals = _hostlib.assemble_bsr(V.cell_nodes, g, vol, V.element.reference_tensors(), d, rowptr, colidx, nu=float(nu),
+                                 gamma=float(gamma), adv=float(adv), wind=wf)
+    prod = sp.bsr_matrix((vals, colidx, rowptr), shape=(V.num_nodes * d,) * 2).toarray()
+    assert np.abs(prod - exact).max() < 1e-12 * np.abs(exact).max()
+    # cell size: Firedrake's CellSize = 2 x circumradius, exactly
+    h = _hostlib.cell_size(mesh)
+    for c, cell in enumerate(C.cells_of(dim, ncell)):
+        assert abs(h[c] ** 2 - float(4 * X.circumradius_squared([C.VERTS[dim][v] for v in cell]))) < 1e-12 * h[c] ** 2
+    # SUPG about a constant state
+    maps = C.exact_node_maps(dim, name, ncell, V)
+    weight, magic = 0.05, 9.0
+    cst = [Fraction(3, 2), Fraction(-2, 3), Fraction(5, 7)][:dim]
+    per = []
+    for cell in C.cells_of(dim, ncell):
+        verts = [C.VERTS[dim][v] for v in cell]
+        _, M = X.supg_matrix_constant_state(dim, name, verts, nu, cst)
+        h2 = float(4 * X.circumradius_squared(verts))
+        beta = (4.0 * float(sum(x * x for x in cst)) / h2 + magic * (4.0 * float(nu) / h2) ** 2) ** -0.5
+        n = len(M)
+        per.append([[[[weight * beta * float(M[a][i][b][j]) for j in range(d)] for b in range(n)] for i in range(d)] for a in range(n)])
+    exact_s = C.scatter(dim, maps, per, V.num_nodes)
+    U = np.tile(np.array([float(x) for x in cst]), (V.num_nodes, 1))
+    vals = np.zeros((len(colidx), d, d))
+    Fh = np.zeros(V.num_nodes * d)
+    _hostlib.supg(V, U, float(nu), weight, magic, rowptr, colidx, vals, Fh)
+    prod = sp.bsr_matrix((vals, colidx, rowptr), shape=(V.num_nodes * d,) * 2).toarray()
+    assert np.abs(prod - exact_s).max() < 1e-12 * np.abs(exact_s).max()
+    assert np.abs(Fh).max() < 1e-13 * np.abs(exact_s).max()
+    # SUPG about a general state, same rule built independently
+    deg = 3 if name.endswith("+FB") else int(name[1])
+    pts, wts = C.gauss_jacobi_rule(dim, deg + 1)
+    perA, perF = [], []
+    for cell, m in zip(C.cells_of(dim, ncell), maps):
+        verts = [C.VERTS[dim][v] for v in cell]
+        _, F, A = X.supg_by_quadrature(dim, name, verts, nu, weight, magic, [wf[gn] for gn in m], pts, wts)
+        perA.append(A)
+        perF.append(F)
+    exact_a, exact_f = C.scatter(dim, maps, perA, V.num_nodes), C.scatter_vec(dim, maps, perF, V.num_nodes)
+    vals = np.zeros((len(colidx), d, d))
+    Fh = np.zeros(V.num_nodes * d)
+    _hostlib.supg(V, wf, float(nu), weight, magic, rowptr, colidx, vals, Fh)
+    prod = sp.bsr_matrix((vals, colidx, rowptr), shape=(V.num_nodes * d,) * 2).toarray()
+    assert np.abs(prod - exact_a).max() < 1e-11 * np.abs(exact_a).max()
+    assert np.abs(Fh - exact_f).max() < 1e-11 * np.abs(exact_f).max()
