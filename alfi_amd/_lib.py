@@ -55,6 +55,12 @@ SIGNATURES = {
     "alfi_level_destroy": (ctypes.c_int, [vp]),
     "alfi_level_update_values": (ctypes.c_int, [vp, vp]),
     "alfi_ctx_comm_allow_self": (ctypes.c_int, [vp, ctypes.c_int]),
+    "alfi_vec_axpy": (ctypes.c_int, [vp, vp, vp, ctypes.c_double, ctypes.c_int64]),
+    "alfi_vec_copy": (ctypes.c_int, [vp, vp, vp, ctypes.c_int64]),
+    "alfi_vec_gather": (ctypes.c_int, [vp, vp, vp, vp, ctypes.c_int64, ctypes.c_int]),
+    "alfi_level_zero_bc": (ctypes.c_int, [vp, vp]),
+    "alfi_saddle_dot": (ctypes.c_int, [vp, vp, vp, ctypes.POINTER(ctypes.c_double)]),
+    "alfi_transfer_stats": (ctypes.c_int, [ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64), ctypes.c_int]),
     "alfi_level_halo_sum": (ctypes.c_int, [vp, vp]),
     "alfi_level_set_assembly": (ctypes.c_int, [vp, ctypes.c_int64, ctypes.c_int, vp, vp, vp, vp, vp, vp, ctypes.c_int, vp, vp, vp]),
     "alfi_ctx_set_assembly_scratch": (ctypes.c_int, [vp, ctypes.c_int64]),

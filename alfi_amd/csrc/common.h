@@ -1,11 +1,28 @@
 // Internal structures of libalfi_hip.so (not part of the ABI).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <cstdint>
 #include <cstdio>
 #include <string>
 #include <vector>
 #include "alfi_hip.h"
+
+// Every host <-> device copy the library makes is counted (alfi_transfer_stats): that a Newton step moves nothing but scalars
+// across PCIe is tested (tests/test_gpu_newton_state.py), not asserted.  Process-wide counters.
+inline std::atomic<int64_t> g_alfi_h2d_bytes{0}, g_alfi_d2h_bytes{0};
+inline hipError_t alfi_counted_memcpy(void* dst, const void* src, size_t n, hipMemcpyKind kind) {
+  if (kind == hipMemcpyHostToDevice) g_alfi_h2d_bytes += (int64_t)n;
+  else if (kind == hipMemcpyDeviceToHost) g_alfi_d2h_bytes += (int64_t)n;
+  return hipMemcpy(dst, src, n, kind);
+}
+inline hipError_t alfi_counted_memcpy_async(void* dst, const void* src, size_t n, hipMemcpyKind kind, hipStream_t s) {
+  if (kind == hipMemcpyHostToDevice) g_alfi_h2d_bytes += (int64_t)n;
+  else if (kind == hipMemcpyDeviceToHost) g_alfi_d2h_bytes += (int64_t)n;
+  return hipMemcpyAsync(dst, src, n, kind, s);
+}
+#define hipMemcpy(dst, src, n, kind) alfi_counted_memcpy(dst, src, n, kind)
+#define hipMemcpyAsync(dst, src, n, kind, stream) alfi_counted_memcpy_async(dst, src, n, kind, stream)
 
 struct alfi_ctx {
   int device = 0;
@@ -479,6 +496,7 @@ struct alfi_saddle {
   int restart = 0;
   int64_t ldv = 0;            // stride of V, Z: n rounded up to even
   double *V = nullptr, *Z = nullptr, *w = nullptr, *hs = nullptr, *tmp_u = nullptr, *tmp_p = nullptr;
+  double* dotbuf = nullptr;   // result of alfi_saddle_dot (serial levels)
 };
 
 // ---- kernel launch wrappers (defined in the .hip files) --------------------------------------------------------------
@@ -580,6 +598,8 @@ int launch_element_mult(alfi_level* lvl, double nu, double gamma, double adv, co
 int launch_supg_residual(alfi_level* lvl, double nu, double weight, double magic, const double* d_state, double* d_F);
 bool element_kernel_exists(int d, int nloc);
 int launch_vals_from_lanes(alfi_ctx* ctx, const DevBSR& A, double* d_out);
+int launch_probe_fill(alfi_ctx* ctx, double* e, int64_t n);                                    // the +-1 probe vector of the coarse solvers
+int launch_probe_residual(alfi_ctx* ctx, const double* r, int64_t n, double* worst_host);   // max | r - e |, reduced on the device
 int launch_apply_bc(alfi_level* lvl);
 int launch_patch_invert_mfma(alfi_ctx* ctx, int64_t npatch, int max_np, const int64_t* patch_ptr, const int64_t* inv_ptr,
                              double* inv, int* status, int* handled);   // kernels_invert.hip

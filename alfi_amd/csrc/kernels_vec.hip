@@ -1,6 +1,7 @@
 // Level SpMV / residual (PETSc MatMult on BAIJ), FGMRES vector kernels, small dense block kernels of the Schoeberl
 // transfer and the dense coarse GEMV.  All HBM-bound; wave64, FP64.
 #include <cstdlib>
+#include <cstring>
 #include "common.h"
 #include "hs_layout.h"
 
@@ -1545,5 +1546,57 @@ __global__ void inject_csr_kernel(int64_t total, int bs, const int32_t* __restri
 }
 int launch_inject_csr(alfi_ctx* ctx, const DevCSR& J, int bs, const double* xf, double* xc) {
   ALFI_LAUNCH_EW(inject_csr_kernel, J.nrows * bs, J.nrows * bs, bs, J.rowptr, J.colidx, J.vals, xf, xc);
+  return 0;
+}
+
+// ---- residual probe of the coarse solvers (alfi_coarse_factor / _sparse): e = a +-1 vector that is a function of the index, made
+// on the device, and || r - e ||_inf reduced there -- a refactorisation per Newton step moves 8 bytes, not two coarse vectors
+__device__ inline double probe_entry(int64_t i) {
+  uint32_t h = (uint32_t)i * 2654435761u + 12345u;
+  h ^= h >> 15;
+  h *= 2246822519u;
+  h ^= h >> 13;
+  return (h & 1u) ? 1.0 : -1.0;
+}
+__global__ void probe_fill_kernel(double* __restrict__ e, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) e[i] = probe_entry(i);
+}
+__global__ void probe_residual_kernel(const double* __restrict__ r, int64_t n, unsigned long long* __restrict__ worst) {
+  double w = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    double d = fabs(r[i] - probe_entry(i));
+    if (!(d == d)) d = INFINITY;
+    w = d > w ? d : w;
+  }
+  // (non-negative doubles order like their bit patterns)
+  if (w > 0.0) atomicMax(worst, (unsigned long long)__double_as_longlong(w));
+}
+
+int launch_probe_fill(alfi_ctx* ctx, double* e, int64_t n) {
+  if (n == 0) return 0;
+  int64_t blocks = std::min<int64_t>((n + 255) / 256, 1024);
+  hipLaunchKernelGGL(probe_fill_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, e, n);
+  ALFI_HIP_CHECK(ctx, hipGetLastError());
+  return 0;
+}
+
+// *worst_host = max_i | r_i - e_i | (infinity if any entry is not a number); synchronises
+int launch_probe_residual(alfi_ctx* ctx, const double* r, int64_t n, double* worst_host) {
+  unsigned long long* d = nullptr;
+  ALFI_HIP_CHECK(ctx, hipMalloc((void**)&d, sizeof(unsigned long long)));
+  hipError_t e = hipMemsetAsync(d, 0, sizeof(unsigned long long), ctx->stream);
+  if (e == hipSuccess && n > 0) {
+    int64_t blocks = std::min<int64_t>((n + 255) / 256, 1024);
+    hipLaunchKernelGGL(probe_residual_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, r, n, d);
+    e = hipGetLastError();
+  }
+  unsigned long long bits = 0;
+  if (e == hipSuccess) e = hipMemcpyAsync(&bits, d, sizeof(bits), hipMemcpyDeviceToHost, ctx->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  (void)hipFree(d);
+  if (e != hipSuccess) return alfi_set_error(ctx, ALFI_E_HIP, "coarse probe: %s", hipGetErrorString(e));
+  double w;
+  std::memcpy(&w, &bits, sizeof(w));
+  *worst_host = w;
   return 0;
 }

@@ -966,6 +966,9 @@ def _dist_ns_solver_class():
             self._min_dofs, self._group = min_dofs, group
             super().__init__(*args, **kwargs)
 
+        def _device_state_resident(self):
+            return False          # (the partitioned loop keeps its own, see _solve_on_device below when it exists)
+
         def _lazy_generation(self):
             # rank-local generation: every rank assembles the operator / transfer rows of its partition only (config 4 on 8
             # ranks: 4.5 GB of host memory per rank instead of 25).  The HOST refresh of SUPG terms works on global values: with

@@ -77,6 +77,23 @@ class Context(object):
         return v
 
     # profiling (PETSc-event style report, driver.py:77-92) ----------------------------------------------------------------
+    def transfer_stats(self, reset=False):
+        """(bytes host -> device, bytes device -> host) of every copy the library made since the last reset, process-wide
+        (alfi_transfer_stats)."""
+        a, b = ctypes.c_int64(), ctypes.c_int64()
+        self.check(self.lib.alfi_transfer_stats(ctypes.byref(a), ctypes.byref(b), 1 if reset else 0))
+        return a.value, b.value
+
+    def axpy(self, y, x, a, n=None, y_off=0, x_off=0):
+        """y[y_off : y_off + n] += a x[x_off : x_off + n] on the device (alfi_vec_axpy)."""
+        n = min(y.n - y_off, x.n - x_off) if n is None else int(n)
+        self.check(self.lib.alfi_vec_axpy(self.h, vp(y.ptr.value + 8 * y_off), vp(x.ptr.value + 8 * x_off), float(a), n))
+
+    def copy(self, y, x, n=None, y_off=0, x_off=0):
+        """y[y_off : y_off + n] = x[x_off : x_off + n] on the device (alfi_vec_copy)."""
+        n = min(y.n - y_off, x.n - x_off) if n is None else int(n)
+        self.check(self.lib.alfi_vec_copy(self.h, vp(y.ptr.value + 8 * y_off), vp(x.ptr.value + 8 * x_off), n))
+
     def comm_stats(self, reset=False):
         """(halo exchanges, all-reduces, doubles sent by this rank) since the last reset (alfi_ctx_comm_stats)."""
         a, b, c = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int64()
@@ -364,6 +381,10 @@ class Level(object):
     def spmv(self, x, y):
         self.ctx.check(self.ctx.lib.alfi_spmv(self.h, x.ptr, y.ptr))
 
+    def zero_bc(self, v):
+        """v[Dirichlet dofs of the level] = 0 on the device (alfi_level_zero_bc)."""
+        self.ctx.check(self.ctx.lib.alfi_level_zero_bc(self.h, v.ptr))
+
     def halo_forward(self, v):
         """Partitioned level: ghost slots of v <- their owners' values (no-op otherwise)."""
         self.ctx.check(self.ctx.lib.alfi_level_halo_forward(self.h, v.ptr))
@@ -603,10 +624,27 @@ class Multigrid(object):
 
 
 class RawVec(object):
-    """A device buffer owned by someone else (a torch tensor) in the shape the wrappers expect (``.ptr``)."""
+    """A device buffer owned by someone else (a torch tensor, a slice of a DeviceVec) in the shape the wrappers expect
+    (``.ptr``); with a ctx it can be filled and read like a DeviceVec."""
 
-    def __init__(self, ptr, n):
-        self.ptr, self.n = vp(int(ptr)), int(n)
+    def __init__(self, ptr, n, ctx=None, parent=None):
+        self.ptr, self.n, self.ctx, self._parent = vp(int(ptr)), int(n), ctx, parent
+
+    def set(self, a):
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        assert a.shape == (self.n,)
+        self.ctx.check(self.ctx.lib.alfi_memcpy_h2d(self.ctx.h, self.ptr, _ptr(a), self.n * 8))
+
+    def get(self):
+        out = np.empty(self.n, dtype=np.float64)
+        self.ctx.check(self.ctx.lib.alfi_memcpy_d2h(self.ctx.h, _ptr(out), self.ptr, self.n * 8))
+        return out
+
+
+def view(v, off, n):
+    """Entries [off, off + n) of a device vector as a vector of its own (no copy; keeps its parent alive)."""
+    assert 0 <= off and off + n <= v.n
+    return RawVec(v.ptr.value + 8 * int(off), n, ctx=getattr(v, "ctx", None), parent=v)
 
 
 class Csr(object):
@@ -678,6 +716,12 @@ class Saddle(object):
 
     def update(self, nu, gamma):
         self.ctx.check(self.ctx.lib.alfi_saddle_update(self.h, float(nu), float(gamma)))
+
+    def dot(self, x, y):
+        """x . y of two (velocity | pressure) device vectors, summed over the ranks on partitioned levels (alfi_saddle_dot)."""
+        out = ctypes.c_double()
+        self.ctx.check(self.ctx.lib.alfi_saddle_dot(self.h, x.ptr, y.ptr, ctypes.byref(out)))
+        return out.value
 
     def mult(self, x, y):
         self.ctx.check(self.ctx.lib.alfi_saddle_mult(self.h, x.ptr, y.ptr))

@@ -112,13 +112,45 @@ class HipNavierStokesSolver(object):
         self.snes_stol = snes_stol                                          # solver.py:490, 498
         self.snes_max_it = snes_max_it
         self.n_u, self.n_p = L.n, self.B.shape[0]
-        # state z = (u, p): zero with the Dirichlet values imposed (what Firedrake does to the initial guess)
-        self.u = np.zeros(self.n_u)
+        # state z = (u, p): zero with the Dirichlet values imposed (what Firedrake does to the initial guess).  With the
+        # device-side refresh the state LIVES on the device (``_dz``); ``u`` / ``p`` fetch it when somebody asks.
+        self._host_u = np.zeros(self.n_u)
         bc_nodes = L.V.bc_nodes
-        self.u.reshape(-1, dim)[bc_nodes] = problem.driver(L.V.node_coords[bc_nodes])
-        self.p = np.zeros(self.n_p)
+        self._host_u.reshape(-1, dim)[bc_nodes] = problem.driver(L.V.node_coords[bc_nodes])
+        self._host_p = np.zeros(self.n_p)
+        self._device_newer = False          # the device copy of the state is ahead of the host arrays
+        self._device_current = False        # the device copy equals the host arrays
         self._load = None
         self.area = float(self.vol.sum())
+
+    # -- the state: host arrays on request, resident on the device during the solves -------------------------------------
+    def _fetch_state(self):
+        if self._device_newer:
+            z = self._dz.get()
+            self._host_u, self._host_p = z[:self.n_u].copy(), z[self.n_u:].copy()
+            self._device_newer, self._device_current = False, True
+
+    @property
+    def u(self):
+        self._fetch_state()
+        return self._host_u
+
+    @u.setter
+    def u(self, value):
+        self._fetch_state()
+        self._host_u = np.asarray(value, dtype=np.float64)
+        self._device_current = False
+
+    @property
+    def p(self):
+        self._fetch_state()
+        return self._host_p
+
+    @p.setter
+    def p(self, value):
+        self._fetch_state()
+        self._host_p = np.asarray(value, dtype=np.float64)
+        self._device_current = False
 
     # -- device side (overridden by alfi_amd.dist.DistNavierStokesSolver for partitioned levels) -------------------------
     def _lazy_generation(self):
@@ -152,6 +184,11 @@ class HipNavierStokesSolver(object):
             if self.supg:
                 dl.set_supg(L.V)
             self._dstate.append(self.ctx.vec(L.n))
+        # the Newton state z = (u | p), the residual F and the update live on the device; the finest level's state vector IS
+        # the velocity part of z
+        n = self.levels[-1].n + self.B_raw.shape[0]
+        self._dz, self._dF, self._dd = self.ctx.vec(n), self.ctx.vec(n), self.ctx.vec(n)
+        self._dstate[-1] = hip.view(self._dz, 0, self.levels[-1].n)
         self._dres = self.ctx.vec(self.levels[-1].n)
         # the residual's divergence products on the device too (B with ALL columns; the Jacobian's B lives in the saddle
         # solver): at config-4 size the two host products were 0.13 s of a 0.2 s residual
@@ -161,10 +198,14 @@ class HipNavierStokesSolver(object):
         self._asm_ready = True
 
     def _device_states(self, u):
-        """Current velocity on every level, on the device: the finest uploaded, the coarser ones by alfi_inject (solver.py:595) --
-        an index map on the nested hierarchies, the point-evaluation matrix sv.bary_injection on the barycentric ones (the
-        third entry of the reference's transfer triple, solver.py:645-652)."""
-        self._dstate[-1].set(u)
+        """Current velocity on every level, on the device: the finest is the velocity part of the resident state (``u`` given:
+        uploaded into it first), the coarser ones by alfi_inject (solver.py:595) -- an index map on the nested hierarchies, the
+        point-evaluation matrix sv.bary_injection on the barycentric ones (the third entry of the reference's transfer triple,
+        solver.py:645-652)."""
+        if u is not None:
+            self._fetch_state()
+            self._dstate[-1].set(u)
+            self._device_current = False
         for l in range(len(self.levels) - 1, 0, -1):
             self.hmg.mg.transfers[l - 1].inject(self._dstate[l], self._dstate[l - 1])
 
@@ -191,20 +232,27 @@ class HipNavierStokesSolver(object):
     def _residual_device(self, u, p, adv):
         """F_u = (nu K + gamma D) u + 1/2 N(u) u + B^T p - f: one matrix-free product, cell by cell, with HALF the advection
         term and without boundary conditions (N(u) u = 2 (u . grad) u)."""
-        L = self.levels[-1]
+        self._fetch_state()                                                # (the host arrays keep what the device held)
+        self._dz.set(np.concatenate([u, p]))
+        self._device_current = False
+        self._residual_on_device(adv)
+        F = self._dF.get()
+        return F[:self.n_u], F[self.n_u:]
+
+    def _residual_on_device(self, adv):
+        """F(z) for the state resident in ``_dz`` into ``_dF`` = (F_u | F_p); nothing crosses to the host."""
         fin = self.hmg.mg.levels[-1]
-        self._dstate[-1].set(u)
-        fin.assemble_mult(self.nu, self.gamma, 0.5 * adv, self._dstate[-1] if adv else None, self._dstate[-1], self._dres)
+        n_u, n_p = self.n_u, self.n_p
+        du, dp = self._dstate[-1], hip.view(self._dz, n_u, n_p)
+        Fu, Fp = hip.view(self._dF, 0, n_u), hip.view(self._dF, n_u, n_p)
+        fin.assemble_mult(self.nu, self.gamma, 0.5 * adv, du if adv else None, du, Fu)
         if adv and self.supg:         # + the SUPG residual, gathered on the device into the same vector
-            fin.supg(self.nu, self.supg_weight, self.supg_magic, self._dstate[-1], False, self._dres)
-        self._dp.set(p)
-        self._dBT.mult(self._dp, self._dres, mode=2)                      # F_u += B^T p
-        self._dB.mult(self._dstate[-1], self._dFp)                        # F_p = B u
-        Fu = self._dres.get()
-        if self._load is not None:
-            Fu -= self._load
-        Fu[L.bc_dofs] = 0.0
-        return Fu, self._dFp.get()
+            fin.supg(self.nu, self.supg_weight, self.supg_magic, du, False, Fu)
+        self._dBT.mult(dp, Fu, mode=2)                                    # F_u += B^T p
+        if self._load is not None:                                         # body force: F_u -= (f, v)
+            self.ctx.axpy(Fu, self._dload, -1.0)
+        fin.zero_bc(Fu)                                                    # bc.zero(F), solver.py:282-286
+        self._dB.mult(du, Fp)                                              # F_p = B u
 
     def _set_parameters(self):
         for T, dt in zip(self.transfers, self.hmg.mg.transfers):            # AutoSchoeberlTransfer.rebuild, transfer.py:173-184
@@ -212,6 +260,59 @@ class HipNavierStokesSolver(object):
                 T.nu = self.nu
                 dt.update(self.nu, self.gamma)
         self.saddle.update(self.nu, self.gamma)
+
+    def _solve_on_device(self, re, adv):
+        """The Newton loop of ``solve`` with the state, the residual and the update resident in HBM: per step the operators
+        are refreshed from the state in place, J e = F is solved on the device (e = - update; the Krylov iterates of b and
+        - b mirror each other), z -= e, and only scalars -- norms, iteration counts -- reach the host."""
+        ctx, sad = self.ctx, self.saddle
+        if not (self._device_newer or self._device_current):
+            self._dz.set(np.concatenate([self._host_u, self._host_p]))
+            self._device_current = True
+        if self._load is not None:
+            if getattr(self, "_dload", None) is None:
+                self._dload = ctx.vec(self.n_u)
+            self._dload.set(self._load)
+        norm = lambda v: float(np.sqrt(sad.dot(v, v)))
+        lin_its, newton_its = 0, 0
+        t_r = time.time()
+        self._residual_on_device(adv)
+        f0 = fnorm = norm(self._dF)
+        self.timings["residual_s"] += time.time() - t_r
+        hist = [fnorm]
+        small_step = False
+        while fnorm > max(self.snes_rtol * f0, self.snes_atol) and newton_its < self.snes_max_it and not small_step:
+            self._rediscretise_device(None, adv)
+            t_s = time.time()
+            its, rn = sad.solve(self._dF, self._dd, self.rtol, self.atol, self.params["ksp_max_it"], 30)
+            ctx.axpy(self._dz, self._dd, -1.0)
+            self._device_newer, self._device_current = True, False
+            self.timings["solve_s"] += time.time() - t_s
+            lin_its += its
+            newton_its += 1
+            self.timings["newton_steps"] += 1
+            t_r = time.time()
+            self._residual_on_device(adv)
+            fnorm = norm(self._dF)
+            self.timings["residual_s"] += time.time() - t_r
+            hist.append(fnorm)
+            # SNESConvergedDefault [3P] with snes_stol (solver.py:490, 498): the step is small relative to the iterate
+            if norm(self._dd) < self.snes_stol * norm(self._dz):
+                small_step = True
+            if self.verbose:
+                print("[alfi_amd] Re %g  Newton %d  |F| %.3e  (%d Krylov its, linear residual %.2e)"
+                      % (re, newton_its, fnorm, its, rn), flush=True)
+        if self.nullspace:                                                   # zero pressure integral, solver.py:273-277
+            if getattr(self, "_dvolz", None) is None:
+                self._dvolz = ctx.vec(np.concatenate([np.zeros(self.n_u), self.vol]))
+                self._dones = ctx.vec(np.ones(self.n_p))
+            ctx.axpy(self._dz, self._dones, -sad.dot(self._dvolz, self._dz) / self.area, n=self.n_p, y_off=self.n_u)
+            self._device_newer, self._device_current = True, False
+        return lin_its, newton_its, hist, small_step, fnorm, f0
+
+    def _device_state_resident(self):
+        """Whether the Newton loop runs with the state on the device (the operators are refreshed there anyway)."""
+        return self.device_assembly
 
     def _linear_solve(self, rhs):
         """J d = rhs for the current operators: (d, Krylov iterations, true residual norm)."""
@@ -298,6 +399,13 @@ class HipNavierStokesSolver(object):
                                           "86-91) would have to carry it; built for rhs = 0 only")
             from .mms import load_vector
             self._load = load_vector(self.levels[-1].V, lambda x: self.problem.rhs(x, re))
+        if self._device_state_resident():
+            lin_its, newton_its, hist, small_step, fnorm, f0 = self._solve_on_device(re, adv)
+            info = {"Re": re, "nu": self.nu, "linear_iter": lin_its, "nonlinear_iter": newton_its,
+                    "time": (time.time() - t0) / 60.0, "residual_history": hist,
+                    "converged": small_step or fnorm <= max(self.snes_rtol * f0, self.snes_atol),
+                    "converged_reason": "SNORM_RELATIVE" if small_step else "FNORM"}
+            return _StateHandle(self), info
         u, p = self.u.copy(), self.p.copy()
         lin_its, newton_its = 0, 0
         t_r = time.time()
@@ -336,6 +444,17 @@ class HipNavierStokesSolver(object):
                 "converged": small_step or fnorm <= max(self.snes_rtol * f0, self.snes_atol),
                 "converged_reason": "SNORM_RELATIVE" if small_step else "FNORM"}
         return (u, p), info
+
+
+class _StateHandle(object):
+    """What ``solve`` returns for the state while it lives on the device (the reference returns the Function z, a handle as
+    well): unpacking it -- ``u, p = z`` -- fetches the arrays."""
+
+    def __init__(self, solver):
+        self._s = solver
+
+    def __iter__(self):
+        return iter((self._s.u, self._s.p))
 
 
 def run_solver(solver, res):

@@ -384,6 +384,18 @@ int alfi_transfer_set_injection_matrix(alfi_transfer* tr, const alfi_csr_host* J
 int alfi_csr_destroy(alfi_csr* m);
 /* mode 0: y = M x;  1: y = b - alpha M x;  2: y += M x;  3: y = alpha M x */
 int alfi_csr_mult(alfi_csr* m, const double* dx, double* dy, const double* db, double alpha, int mode);
+/* The Newton loop around the path keeps its state, update and residual in HBM (the reference's NonlinearVariationalSolver
+ * keeps z as a distributed Function, alfi/solver.py:245-273): small vector operations on device vectors, stream-ordered;
+ * only scalars come back.  alfi_saddle_dot: x . y of two (velocity | pressure) vectors of the outer solve, summed over the
+ * ranks on a partitioned finest level (every rank gets the same value), fixed summation order.  alfi_level_zero_bc: dv[Dirichlet
+ * dofs of the level] = 0 (bc.zero(F), solver.py:282-286).  alfi_vec_gather: dst[i] = src[idx[i]], bs doubles per index (idx a
+ * DEVICE array).  alfi_transfer_stats: bytes every host <-> device copy of the library has moved (process-wide). */
+int alfi_vec_axpy(alfi_ctx* ctx, double* dy, const double* dx, double a, int64_t n);   /* y += a x */
+int alfi_vec_copy(alfi_ctx* ctx, double* dy, const double* dx, int64_t n);
+int alfi_vec_gather(alfi_ctx* ctx, double* dst, const double* dsrc, const int32_t* d_idx, int64_t nidx, int bs);
+int alfi_level_zero_bc(alfi_level* lvl, double* dv);
+int alfi_saddle_dot(alfi_saddle* s, const double* dx, const double* dy, double* out_host);
+int alfi_transfer_stats(int64_t* h2d_bytes, int64_t* d2h_bytes, int reset);
 /* y = [A B^T; B 0] x and y = P^-1 x on device vectors (tests, monitors) */
 int alfi_saddle_mult(alfi_saddle* s, const double* dx, double* dy);
 int alfi_saddle_precond(alfi_saddle* s, const double* dx, double* dy);
