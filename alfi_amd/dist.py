@@ -953,21 +953,102 @@ class DistSaddle(object):
         self.sad.close()
 
 
+class _StatePart(object):
+    """What HaloBuffers reads of a LevelPart."""
+
+    def __init__(self, bs, send_counts, recv_counts):
+        self.bs, self.send_counts, self.recv_counts = bs, send_counts, recv_counts
+
+
+class StateExchange(object):
+    """The distributed Newton state as input of the rank's operator refresh: every level's state vector (the level's local
+    nodes and the ring of nodes of the cells around them, alfi_level_set_assembly) filled ON THE DEVICE from the velocity the
+    ranks own on the finest level -- one halo exchange per refresh, then an index gather per level (on the nested hierarchies
+    a node of level l IS a node of the finest level: the composition of the ``inject`` maps, alfi/solver.py:595).
+    The exchange runs through a level that exists only for its halo plan (identity operator): owned block = the rank's owned
+    finest nodes in the finest level's local order, ghosts = every other finest node some level's refresh reads here; it
+    therefore takes whichever transport the multigrid levels take (the library's RCCL communicator, or the callback)."""
+
+    def __init__(self, dmg, levels, transfers, asm_nodes, device):
+        """asm_nodes[i]: global node ids (numbering of level dmg.lmin + i) of the state entries of local level i, or None."""
+        from . import hip
+        from .problem import BSR
+        p = dmg.fine.part
+        bs, rank, world = p.bs, dmg.comm.rank, dmg.comm.world
+        nlev = len(levels)
+        to_fine = [None] * nlev                       # node of level l -> finest node at the same position
+        to_fine[-1] = np.arange(levels[-1].A.nbrows, dtype=np.int64)
+        for l in range(nlev - 2, -1, -1):
+            T = transfers[l]
+            if T.inject_map is None:
+                raise ValueError("non-nested hierarchy: no node-to-node inject")
+            to_fine[l] = to_fine[l + 1][np.asarray(T.inject_map, dtype=np.int64)]
+        need = [None if a is None else to_fine[dmg.lmin + i][np.asarray(a, dtype=np.int64)] for i, a in enumerate(asm_nodes)]
+        allneed = np.unique(np.concatenate([n for n in need if n is not None] + [np.zeros(0, dtype=np.int64)]))
+        ghosts = allneed[(allneed < p.lo) | (allneed >= p.hi)]               # ascending => grouped by owner
+        owner = np.searchsorted(p.splits, ghosts, side="right") - 1
+        recv_counts = np.bincount(owner, minlength=world).astype(np.int64)
+        off = np.concatenate([[0], np.cumsum(recv_counts)])
+        wanted = dmg.comm.all_gather_object([ghosts[off[q]:off[q + 1]] for q in range(world)])
+        send_lists = [p.own_perm[np.asarray(wanted[q][rank], dtype=np.int64) - p.lo] for q in range(world)]
+        send_counts = np.array([len(x) for x in send_lists], dtype=np.int64)
+        send_nodes = np.concatenate(send_lists).astype(np.int32) if send_counts.sum() else np.zeros(0, dtype=np.int32)
+        nb = p.nb_own + len(ghosts)
+        ctx = dmg.ctx
+        A = BSR(nb, nb, bs, np.arange(nb + 1, dtype=np.int32), np.arange(nb, dtype=np.int32), np.tile(np.eye(bs), (nb, 1, 1)))
+        self.level = hip.Level(ctx, A, np.zeros(0, dtype=np.int32))
+        if dmg.transport == "rccl":
+            self.level.set_partition(p.nb_own, True, send_nodes, None, None, len(ghosts))
+            nbr = np.flatnonzero((send_counts > 0) | (recv_counts > 0))
+            self.level.set_neighbours(nbr, send_counts[nbr], recv_counts[nbr])
+        else:
+            hb = HaloBuffers(_StatePart(bs, send_counts, recv_counts), device)
+            self.level.set_partition(p.nb_own, True, send_nodes, hb.sendbuf.data_ptr(), hb.recvbuf.data_ptr(), len(ghosts))
+            dmg.halos[self.level.id] = hb
+        self.ctx, self.bs, self.n_own = ctx, bs, p.nb_own * bs
+        self.vec = ctx.vec(max(nb * bs, 1))
+        # position of a finest node in that vector: owned -> its local index, ghost -> behind the owned block
+        def pos(g):
+            own = (g >= p.lo) & (g < p.hi)
+            out = np.empty(g.shape[0], dtype=np.int64)
+            out[own] = p.own_perm[g[own] - p.lo]
+            out[~own] = p.nb_own + np.searchsorted(ghosts, g[~own])
+            return out
+        self.idx = [None if n is None else ctx.ivec(pos(n)) for n in need]
+        self.bytes_received = int(len(ghosts)) * bs * 8
+
+    def refresh(self, du_owned, states):
+        """du_owned: device vector that starts with the rank's owned finest velocity; states[i]: device state of local level i."""
+        self.ctx.copy(self.vec, du_owned, n=self.n_own)
+        self.level.halo_forward(self.vec)
+        for ix, st in zip(self.idx, states):
+            if ix is not None:
+                self.ctx.gather(st, self.vec, ix, self.bs)
+
+    def close(self):
+        self.level.close()
+
+
 def _dist_ns_solver_class():
     from .nssolver import HipNavierStokesSolver
 
     class DistNavierStokesSolver(HipNavierStokesSolver):
         """HipNavierStokesSolver with the device side on partitioned levels (one process per GPU): DistMultigrid + DistSaddle.
         Every rank rediscretises ITS OWN rows of the level operators -- on its device from the cells that touch its nodes
-        (``_rediscretise_device``; on its host cores only with ALFI_DEVICE_ASSEMBLY=0); the Newton state is replicated, the
-        update of each linear solve gathered from its owners."""
+        (``_rediscretise_device``; on its host cores only with ALFI_DEVICE_ASSEMBLY=0).  The Newton state is DISTRIBUTED on the
+        devices, every rank its owned velocity and pressure dofs (``StateExchange`` feeds the levels' refresh states from it;
+        ``u`` / ``p`` gather it, collectively, when somebody asks); the barycentric hierarchy of the Scott-Vogelius pair and
+        the host-assembly path keep a replicated host state."""
 
         def __init__(self, *args, min_dofs=400000, group=None, **kwargs):
             self._min_dofs, self._group = min_dofs, group
             super().__init__(*args, **kwargs)
 
         def _device_state_resident(self):
-            return False          # (the partitioned loop keeps its own, see _solve_on_device below when it exists)
+            # the state lives distributed on the devices -- every rank its owned velocity and pressure dofs -- whenever the
+            # operators are refreshed there and the hierarchy is nested (the barycentric one of the Scott-Vogelius pair injects
+            # by point evaluation: it keeps the replicated host state)
+            return self.device_assembly and not self.sv and getattr(self, "_exch", None) is not None
 
         def _lazy_generation(self):
             # rank-local generation: every rank assembles the operator / transfer rows of its partition only (config 4 on 8
@@ -1038,7 +1119,94 @@ def _dist_ns_solver_class():
                 self._dBT = hip.Csr(self.ctx, Bloc.T.tocsr())
                 self._dp, self._dFp = self.ctx.vec(max(len(rows), 1)), self.ctx.vec(max(len(rows), 1))
                 self._dwc = self.ctx.vec(dmg.n_loc)
+                self._exch = None
+                import os
+                if not self.sv and os.environ.get("ALFI_DIST_DEVICE_STATE", "1") != "0":
+                    # the distributed device-resident state: (owned velocity | owned pressure) per rank, and the exchange that
+                    # feeds every level's refresh from it
+                    assert np.array_equal(self._res_rows, self.saddle.cells)
+                    n = self.saddle.n
+                    self._dz, self._dF, self._dd = self.ctx.vec(n + 1), self.ctx.vec(n + 1), self.ctx.vec(n + 1)
+                    self._exch = StateExchange(dmg, self.levels, self.transfers, [None if a is None else a[0] for a in self._asm],
+                                               dmg.device)
             self._asm_ready = True
+
+        # -- the device-resident loop on partitions (nssolver.HipNavierStokesSolver._solve_on_device) ------------------------
+        def _refresh_states(self):
+            self._exch.refresh(self._dz, [None if a is None else a[1] for a in self._asm])
+
+        def _push_state(self):
+            part, sad = self.dmg.fine.part, self.saddle
+            with self._on_stream():
+                self._dz.set(np.concatenate([self._host_u[part.own_dofs()], self._host_p[sad.cells],
+                                             np.zeros(self._dz.n - sad.n)]))
+
+        def _fetch_state(self):
+            """COLLECTIVE: every rank contributes its owned entries (``u`` / ``p`` after a solve must be read on all ranks)."""
+            if self._device_newer:
+                part, sad = self.dmg.fine.part, self.saddle
+                with self._on_stream():
+                    z = self._dz.get()
+                u, p = np.zeros(self.n_u), np.zeros(self.n_p)
+                for dofs, cells, zu, zp in self.dmg.comm.all_gather_object((part.own_dofs(), sad.cells, z[:sad.n_own],
+                                                                            z[sad.n_own:sad.n])):
+                    u[dofs] = zu
+                    p[np.asarray(cells)] = zp
+                self._host_u, self._host_p = u, p
+                self._device_newer, self._device_current = False, True
+
+        def _push_load(self):
+            part = self.dmg.fine.part
+            if getattr(self, "_dload", None) is None:
+                self._dload = self.ctx.vec(max(self.dmg.n_own, 1))
+            with self._on_stream():
+                self._dload.set(np.ascontiguousarray(self._load[part.own_dofs()]) if self.dmg.n_own else np.zeros(1))
+
+        def _zdot(self, x, y):
+            with self._on_stream():
+                return self.saddle.sad.dot(x, y)
+
+        def _zsolve(self, b, x):
+            with self._on_stream():
+                return self.saddle.sad.solve(b, x, self.rtol, self.atol, self.params["ksp_max_it"], 30)
+
+        def _zaxpy(self, y, x, a):
+            with self._on_stream():
+                self.ctx.axpy(y, x, a, n=self.saddle.n)
+
+        def _shift_pressure(self):
+            from . import hip
+            sad = self.saddle
+            if getattr(self, "_dvolz", None) is None:
+                with self._on_stream():
+                    self._dvolz = self.ctx.vec(np.concatenate([np.zeros(sad.n_own), self.vol[sad.cells], np.zeros(self._dz.n - sad.n)]))
+                    self._dones = self.ctx.vec(np.ones(max(sad.np_own, 1)))
+            c = self._zdot(self._dvolz, self._dz) / self.area
+            with self._on_stream():
+                self.ctx.axpy(self._dz, self._dones, -c, n=sad.np_own, y_off=sad.n_own)
+
+        def _residual_on_device(self, adv):
+            """The rank's rows of F(z) for the distributed state in ``_dz`` into ``_dF`` = (F_u owned | F_p owned): the state of
+            the finest level's refresh comes through the exchange, the matrix-free product and the divergence products run over
+            the rank's cells, the rank's share of B^T p is reverse-added onto the owners; nothing crosses to the host."""
+            from . import hip
+            dmg, fin, sad = self.dmg, self.dmg.levels[-1], self.saddle
+            n_own, np_own = sad.n_own, sad.np_own
+            st = self._asm[-1][1]
+            with self._on_stream():
+                self._refresh_states()
+                fin.assemble_mult(self.nu, self.gamma, 0.5 * adv, st if adv else None, st, self._dres)
+                if adv and self.supg:
+                    fin.supg(self.nu, self.supg_weight, self.supg_magic, st, False, self._dres)
+                dp = hip.view(self._dz, n_own, max(np_own, 1))
+                self._dBT.mult(dp, self._dwc)
+                fin.halo_reverse_add(self._dwc)
+                self.ctx.copy(self._dF, self._dres, n=n_own)
+                self.ctx.axpy(self._dF, self._dwc, 1.0, n=n_own)
+                if self._load is not None:
+                    self.ctx.axpy(self._dF, self._dload, -1.0, n=n_own)
+                fin.zero_bc(self._dF)
+                self._dB.mult(st, hip.view(self._dF, n_own, max(np_own, 1)))
 
         def _upload_states(self, u):
             for asm, w in zip(self._asm, self._winds(u)[self.dmg.lmin:]):
@@ -1049,7 +1217,10 @@ def _dist_ns_solver_class():
             import time
             t0 = time.time()
             with self._on_stream():
-                self._upload_states(u)
+                if u is None:                 # the state lives on the devices: one exchange feeds every level's refresh
+                    self._refresh_states()
+                else:
+                    self._upload_states(u)
                 for asm, dl in zip(self._asm, self.dmg.levels):
                     if asm is None:
                         continue
@@ -1178,6 +1349,8 @@ def _dist_ns_solver_class():
             if getattr(self, "_asm_ready", False):
                 self._dB.close()
                 self._dBT.close()
+                if self._exch is not None:
+                    self._exch.close()
             self.saddle.close()
             self.dmg.close()
 

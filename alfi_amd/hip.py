@@ -94,6 +94,15 @@ class Context(object):
         n = min(y.n - y_off, x.n - x_off) if n is None else int(n)
         self.check(self.lib.alfi_vec_copy(self.h, vp(y.ptr.value + 8 * y_off), vp(x.ptr.value + 8 * x_off), n))
 
+    def ivec(self, a):
+        """A device array of int32 (index lists of alfi_vec_gather)."""
+        return IntVec(self, a)
+
+    def gather(self, dst, src, idx, bs=1):
+        """dst[i] = src[idx[i]], bs consecutive doubles per index, on the device (alfi_vec_gather; idx: an IntVec)."""
+        assert dst.n >= idx.n * bs
+        self.check(self.lib.alfi_vec_gather(self.h, dst.ptr, src.ptr, idx.ptr, idx.n, int(bs)))
+
     def comm_stats(self, reset=False):
         """(halo exchanges, all-reduces, doubles sent by this rank) since the last reset (alfi_ctx_comm_stats)."""
         a, b, c = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int64()
@@ -142,6 +151,27 @@ class DeviceVec(object):
 
     def zero(self):
         self.ctx.check(self.ctx.lib.alfi_memset0(self.ctx.h, self.ptr, self.n * 8))
+
+    def __del__(self):
+        try:
+            if self.ptr and self.ctx.h:
+                self.ctx.lib.alfi_free(self.ctx.h, self.ptr)
+        except Exception:
+            pass
+        self.ptr = None
+
+
+class IntVec(object):
+    """int32 indices resident on the device."""
+
+    def __init__(self, ctx, a):
+        a = np.ascontiguousarray(a, dtype=np.int32)
+        self.ctx, self.n = ctx, int(a.shape[0])
+        p = vp()
+        ctx.check(ctx.lib.alfi_malloc(ctx.h, max(self.n, 1) * 4, ctypes.byref(p)))
+        self.ptr = p
+        if self.n:
+            ctx.check(ctx.lib.alfi_memcpy_h2d(ctx.h, p, _ptr(a), self.n * 4))
 
     def __del__(self):
         try:

@@ -265,15 +265,12 @@ class HipNavierStokesSolver(object):
         """The Newton loop of ``solve`` with the state, the residual and the update resident in HBM: per step the operators
         are refreshed from the state in place, J e = F is solved on the device (e = - update; the Krylov iterates of b and
         - b mirror each other), z -= e, and only scalars -- norms, iteration counts -- reach the host."""
-        ctx, sad = self.ctx, self.saddle
         if not (self._device_newer or self._device_current):
-            self._dz.set(np.concatenate([self._host_u, self._host_p]))
+            self._push_state()
             self._device_current = True
         if self._load is not None:
-            if getattr(self, "_dload", None) is None:
-                self._dload = ctx.vec(self.n_u)
-            self._dload.set(self._load)
-        norm = lambda v: float(np.sqrt(sad.dot(v, v)))
+            self._push_load()
+        norm = lambda v: float(np.sqrt(self._zdot(v, v)))
         lin_its, newton_its = 0, 0
         t_r = time.time()
         self._residual_on_device(adv)
@@ -284,8 +281,8 @@ class HipNavierStokesSolver(object):
         while fnorm > max(self.snes_rtol * f0, self.snes_atol) and newton_its < self.snes_max_it and not small_step:
             self._rediscretise_device(None, adv)
             t_s = time.time()
-            its, rn = sad.solve(self._dF, self._dd, self.rtol, self.atol, self.params["ksp_max_it"], 30)
-            ctx.axpy(self._dz, self._dd, -1.0)
+            its, rn = self._zsolve(self._dF, self._dd)
+            self._zaxpy(self._dz, self._dd, -1.0)
             self._device_newer, self._device_current = True, False
             self.timings["solve_s"] += time.time() - t_s
             lin_its += its
@@ -303,12 +300,35 @@ class HipNavierStokesSolver(object):
                 print("[alfi_amd] Re %g  Newton %d  |F| %.3e  (%d Krylov its, linear residual %.2e)"
                       % (re, newton_its, fnorm, its, rn), flush=True)
         if self.nullspace:                                                   # zero pressure integral, solver.py:273-277
-            if getattr(self, "_dvolz", None) is None:
-                self._dvolz = ctx.vec(np.concatenate([np.zeros(self.n_u), self.vol]))
-                self._dones = ctx.vec(np.ones(self.n_p))
-            ctx.axpy(self._dz, self._dones, -sad.dot(self._dvolz, self._dz) / self.area, n=self.n_p, y_off=self.n_u)
+            self._shift_pressure()
             self._device_newer, self._device_current = True, False
         return lin_its, newton_its, hist, small_step, fnorm, f0
+
+    # -- the pieces of the device-resident loop a partitioned solver replaces (alfi_amd.dist.DistNavierStokesSolver) ------
+    def _push_state(self):
+        self._dz.set(np.concatenate([self._host_u, self._host_p]))
+
+    def _push_load(self):
+        if getattr(self, "_dload", None) is None:
+            self._dload = self.ctx.vec(self.n_u)
+        self._dload.set(self._load)
+
+    def _zdot(self, x, y):
+        return self.saddle.dot(x, y)
+
+    def _zsolve(self, b, x):
+        return self.saddle.solve(b, x, self.rtol, self.atol, self.params["ksp_max_it"], 30)
+
+    def _zaxpy(self, y, x, a):
+        self.ctx.axpy(y, x, a)
+
+    def _shift_pressure(self):
+        """p -= (int p) / |domain| on the device."""
+        ctx = self.ctx
+        if getattr(self, "_dvolz", None) is None:
+            self._dvolz = ctx.vec(np.concatenate([np.zeros(self.n_u), self.vol]))
+            self._dones = ctx.vec(np.ones(self.n_p))
+        ctx.axpy(self._dz, self._dones, -self._zdot(self._dvolz, self._dz) / self.area, n=self.n_p, y_off=self.n_u)
 
     def _device_state_resident(self):
         """Whether the Newton loop runs with the state on the device (the operators are refreshed there anyway)."""

@@ -34,7 +34,15 @@ def main():
     real, real_supg = _hostlib.assemble_bsr, _hostlib.supg
     _hostlib.assemble_bsr = lambda *a, **k: (calls.append(1), real(*a, **k))[1]
     _hostlib.supg = lambda *a, **k: (calls.append(1), real_supg(*a, **k))[1]
-    res = run_solver(s, [10, 100])
+    # what crosses PCIe per Newton step of the SECOND solve (alfi_transfer_stats: every copy the library makes): with the state
+    # distributed on the devices only scalars
+    res = {10: s.solve(10)[1]}
+    s.ctx.transfer_stats(reset=True)
+    res[100] = s.solve(100)[1]
+    h2d, d2h = s.ctx.transfer_stats()
+    per_step = max(h2d, d2h) / max(res[100]["nonlinear_iter"], 1)
+    resident = bool(s._device_state_resident())
+    u_all, p_all = s.u, s.p                      # COLLECTIVE: every rank contributes its owned entries
     _hostlib.assemble_bsr, _hostlib.supg = real, real_supg
     asm_err = -1.0
     if s.device_assembly:
@@ -54,9 +62,10 @@ def main():
                                     LL.part)
             asm_err = max(asm_err, float(np.abs(dl.get_values() - ref.vals).max() / np.abs(ref.vals).max()))
     gathered = [None] * world
-    dist.all_gather_object(gathered, (len(calls), asm_err, bool(s.device_assembly)))
+    dist.all_gather_object(gathered, (len(calls), asm_err, bool(s.device_assembly), per_step, resident))
     if rank == 0:
-        np.savez(os.path.join(out, "newton.npz"), u=s.u, p=s.p, its=[res[r]["linear_iter"] for r in (10, 100)],
+        np.savez(os.path.join(out, "newton.npz"), u=u_all, p=p_all, its=[res[r]["linear_iter"] for r in (10, 100)],
+                 bytes_per_step=[g[3] for g in gathered], resident=[g[4] for g in gathered],
                  newton=[res[r]["nonlinear_iter"] for r in (10, 100)], conv=[res[r]["converged"] for r in (10, 100)],
                  host_assemblies=[g[0] for g in gathered], asm_err=[g[1] for g in gathered],
                  device_assembly=[g[2] for g in gathered])

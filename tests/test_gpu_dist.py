@@ -291,14 +291,19 @@ def test_partitioned_outer_solve(case, world, tmp_path):
     assert np.abs(xp - xs[L.n:]).max() < 1e-5 * np.abs(xs[L.n:]).max()
 
 
-@pytest.mark.parametrize("disc,world", [("pkp0", 2), ("pkp0-3d", 3), ("sv", 2), ("pkp0-supg", 2)])
-def test_partitioned_newton(tmp_path, disc, world):
+@pytest.mark.parametrize("disc,world,transport", [("pkp0", 2, "callback"), ("pkp0-3d", 3, "callback"), ("sv", 2, "callback"),
+                                                  ("pkp0-supg", 2, "callback"), ("pkp0", 3, "rccl"), ("pkp0-3d", 2, "rccl")])
+def test_partitioned_newton(tmp_path, disc, world, transport):
     """Newton + Reynolds continuation with every linear solve on partitioned levels: same Newton / Krylov counts and the same
     solution as the single-GPU solver.  The operators are refreshed ON THE DEVICE, every rank its own rows
     (alfi_level_set_assembly on partitioned levels): no host assembly during the Newton loops, values equal to the rank-local
     host assembly to 1e-12.  ``sv``: the Scott-Vogelius pair on the barycentric hierarchy (macro-star patches as condensed
     factors, discontinuous P1 pressure owned cell by cell, block DGMassInv); ``pkp0-supg``: with the SUPG terms of the reference's
-    production runs (stabilisation.py:47-97), assembled on the device from the rank's cells."""
+    production runs (stabilisation.py:47-97), assembled on the device from the rank's cells.
+    The Newton state lives DISTRIBUTED on the devices (nested hierarchies: every rank its owned velocity and pressure dofs; the
+    levels' refresh states come from it by one halo exchange and index gathers, alfi_amd.dist.StateExchange): per Newton step
+    the library copies less than 1 KB between host and device on every rank (alfi_transfer_stats).  ``rccl``: the product
+    transport over tests/mock_rccl (several ranks on one device), ``callback``: gloo."""
     from alfi_amd.nssolver import HipNavierStokesSolver, run_solver
     from alfi_amd.problem import TwoDimLidDrivenCavityProblem, ThreeDimLidDrivenCavityProblem
     port = _free_port()
@@ -306,6 +311,9 @@ def test_partitioned_newton(tmp_path, disc, world):
     for r in range(world):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), OMP_NUM_THREADS="4")
+        if transport == "rccl":
+            from tests.mock_rccl.build import build
+            env.update(ALFI_DIST_TRANSPORT="rccl", ALFI_RCCL_LIB=build())
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dist_gpu_newton_worker.py"),
                                        str(tmp_path), disc], env=env, cwd=ROOT))
     s = (HipNavierStokesSolver(TwoDimLidDrivenCavityProblem(4), 2, 2, discretisation="sv") if disc == "sv"
@@ -317,6 +325,8 @@ def test_partitioned_newton(tmp_path, disc, world):
         assert p.wait(timeout=600) == 0
     z = np.load(os.path.join(str(tmp_path), "newton.npz"))
     assert all(z["device_assembly"]) and list(z["host_assemblies"]) == [0] * world, (z["device_assembly"], z["host_assemblies"])
+    if disc != "sv":
+        assert all(z["resident"]) and max(z["bytes_per_step"]) <= 1024, (z["resident"], z["bytes_per_step"])
     assert max(z["asm_err"]) < 1e-12, z["asm_err"]
     assert all(z["conv"]) and all(res[r]["converged"] for r in (10, 100))
     assert list(z["newton"]) == [res[r]["nonlinear_iter"] for r in (10, 100)]
