@@ -1449,6 +1449,9 @@ int alfi_patches_set_multiplicative(alfi_level* L, int64_t nit, const int64_t* i
   L->mult = false;
   L->mult_wave_ptr.clear();
   free_mult_schedule(L);
+  // a new schedule starts with a clean device-side error word: after a timeout every later sweep on this ctx would stop at its
+  // first wait (the word is tested inside the spin loop); (re)setting the sweeps is how a context recovers
+  if (ctx->dev_err) ALFI_HIP_CHECK(ctx, hipMemset(ctx->dev_err, 0, 16));
   if (nit == 0) return 0;
   if (nit < 0 || !iterset) return alfi_set_error(ctx, ALFI_E_ARG, "bad iteration set");
   if (L->cond) return alfi_set_error(ctx, ALFI_E_STATE, "multiplicative sweeps need dense patch inverses (alfi_patches_set_groups(NULL))");
@@ -2849,7 +2852,9 @@ int alfi_saddle_solve(alfi_saddle* S, const double* db, double* dx, double rtol,
   ALFI_CHECK(read(hs + hl.beta, &tn));
   if (iterations) *iterations = its;
   if (residual_norm) *residual_norm = tn;
-  return 0;
+  // a persistent multiplicative sweep inside a cycle may have run into its wait bound: the iterates above were then computed
+  // from an incomplete smoother result -- report it instead of returning counts and norms of garbage
+  return check_dev_err(ctx);
 }
 
 }  // extern "C"

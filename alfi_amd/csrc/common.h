@@ -56,6 +56,7 @@ struct alfi_ctx {
   // mesh-partition parallelism (alfi_ctx_set_comm)
   alfi_comm_fn comm = nullptr;
   void* comm_user = nullptr;
+  int mult_ncu = 0, mult_per_cu[2] = {0, 0};   // resident-grid size of the persistent multiplicative sweep on THIS ctx's device
   bool comm_allow_self = false;   // test hook (alfi_ctx_comm_allow_self): a rank may be its own neighbour
   bool exact_norm = true;   // partitioned FGMRES: second all-reduce for |w - V h| (PETSc's VecNorm); false: Pythagorean identity
   double* dred = nullptr;  // device buffer that is all-reduced: [0, RED_MAXV) dots, [RED_MAXV] norm^2 (caller-owned with

@@ -17,7 +17,7 @@ struct HsLayout {
 };
 
 #ifdef __HIPCC__
-// ---- one-thread pieces of the FGMRES smoother, shared by kernels_vec.hip and kernels_tiny.hip -------------------------------
+// ---- one-thread pieces of the FGMRES smoother, used by the kernels of kernels_vec.hip -------------------------------
 // column j of the Hessenberg: h[0..j] = the CGS dots, h[j+1] = tt = sqrt(sum of nblocks partials); Givens update
 // (KSPFGMRESUpdateHessenberg [3P]).  Partitioned levels pass the all-reduced values (nblocks = 1).
 // ww != nullptr (partitioned levels, one all-reduce per iteration): |w_new|^2 = |w|^2 - sum_i h_i^2 with the all-reduced

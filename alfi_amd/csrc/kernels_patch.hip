@@ -738,7 +738,9 @@ __global__ __launch_bounds__(MULT_NTHR) ALFI_MULT_OCC_ATTR void patch_mult_persi
     if (threadIdx.x == 0) {
       int ok = 1;
       unsigned spins = 0;
-      while (__hip_atomic_load(pred + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+      // (acquire: pairs with the release decrement of the predecessors below -- ADVICE r4; the fence after the barrier makes
+      // the other waves of the workgroup see what this lane acquired)
+      while (__hip_atomic_load(pred + t, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != 0) {
         __builtin_amdgcn_s_sleep(2);
         if (++spins > (1u << 24) || __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
           ok = 0;
@@ -758,8 +760,9 @@ __global__ __launch_bounds__(MULT_NTHR) ALFI_MULT_OCC_ATTR void patch_mult_persi
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // this wave's y stores have left
     __syncthreads();                                            // ... and those of the other waves
     ALFI_MULT_STAMP(5);
+    // release: the y stores of this item (drained above, barrier) happen-before whatever a successor reads after its acquire
     for (int32_t e = succ_ptr[t] + threadIdx.x; e < succ_ptr[t + 1]; e += MULT_NTHR)
-      __hip_atomic_fetch_sub(pred + succ[e], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_fetch_sub(pred + succ[e], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     ALFI_MULT_STAMP(6);
   }
 }
@@ -900,18 +903,18 @@ int launch_patch_mult_persistent(alfi_level* L, const double* x, double* y) {
   ALFI_HIP_CHECK(ctx, hipMemsetAsync(L->mult_ctl, 0, 4 * sizeof(int32_t), ctx->stream));
   // a resident grid: as many workgroups per CU as the kernel's registers and LDS admit (every ticket holder must be running;
   // more workgroups in flight = more of the next wavefronts' independent patches started early)
-  static int ncu = 0, per_cu[2] = {0, 0};
-  if (ncu == 0) {
+  // (per ctx -- ADVICE r4: function-local statics sized every later ctx's grid from the first ctx's device)
+  if (ctx->mult_ncu == 0) {
     hipDeviceProp_t prop;
     ALFI_HIP_CHECK(ctx, hipGetDeviceProperties(&prop, ctx->device));
     const auto k2 = &patch_mult_persistent_kernel<2, true>;
     const auto k3 = &patch_mult_persistent_kernel<3, true>;
-    ALFI_HIP_CHECK(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu[0], k2, MULT_NTHR, 0));
-    ALFI_HIP_CHECK(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu[1], k3, MULT_NTHR, 0));
-    ncu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 64;
+    ALFI_HIP_CHECK(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&ctx->mult_per_cu[0], k2, MULT_NTHR, 0));
+    ALFI_HIP_CHECK(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&ctx->mult_per_cu[1], k3, MULT_NTHR, 0));
+    ctx->mult_ncu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 64;
   }
-  const int pc = std::max(1, std::min(per_cu[L->bs == 3 ? 1 : 0], ALFI_MULT_WG_PER_CU));
-  dim3 grid((unsigned)std::min<int64_t>(L->mult_nitems, (int64_t)ncu * pc)), block(MULT_NTHR);
+  const int pc = std::max(1, std::min(ctx->mult_per_cu[L->bs == 3 ? 1 : 0], ALFI_MULT_WG_PER_CU));
+  dim3 grid((unsigned)std::min<int64_t>(L->mult_nitems, (int64_t)ctx->mult_ncu * pc)), block(MULT_NTHR);
 #ifdef ALFI_MULT_TIMING
   if (g_mult_stamps_n < L->mult_nitems) {
     if (g_mult_stamps) (void)hipFree(g_mult_stamps);

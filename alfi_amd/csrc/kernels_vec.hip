@@ -858,7 +858,7 @@ __global__ __launch_bounds__(256) void norm_init_finish_kernel(const double* __r
   }
 }
 
-// (pythagoras_norm2, hessenberg_column, fgmres_back_substitution: hs_layout.h -- shared with kernels_tiny.hip)
+// (pythagoras_norm2, hessenberg_column, fgmres_back_substitution: hs_layout.h)
 
 // ---------------------------------------------------------------------------------------------------------------------
 // Fused smoother iteration for small levels (a smoother iteration there is a chain of launches of a few microseconds

@@ -1050,6 +1050,9 @@ def _dist_ns_solver_class():
             # by point evaluation: it keeps the replicated host state)
             return self.device_assembly and not self.sv and getattr(self, "_exch", None) is not None
 
+        def _any_rank(self, flag):
+            return any(self.dmg.comm.all_gather_object(bool(flag)))
+
         def _lazy_generation(self):
             # rank-local generation: every rank assembles the operator / transfer rows of its partition only (config 4 on 8
             # ranks: 4.5 GB of host memory per rank instead of 25).  The HOST refresh of SUPG terms works on global values: with

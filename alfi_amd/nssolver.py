@@ -97,13 +97,18 @@ class HipNavierStokesSolver(object):
         if self.device_assembly and not self._device_assembly_possible():
             self.device_assembly = False
         if self.device_assembly:
+            failure = None
             try:
                 self._setup_device_assembly()
             except hip.AlfiHipError as e:
+                failure = e
+            # (partitioned: the outcome is agreed over the ranks -- one rank on the host path and the others on the device path
+            # would call different collectives)
+            if self._any_rank(failure is not None):
                 # (e.g. ALFI_SPMV=legacy: the refresh writes the lane-major operator layout) -- ADVICE r3: fall back, say so
                 import warnings
                 warnings.warn("device-side operator refresh not available (%s): the operators of every Newton step are "
-                              "assembled on the host" % (e,))
+                              "assembled on the host" % (failure if failure is not None else "another rank failed to set it up",))
                 self.device_assembly = False
         self.rtol, self.atol = self.params["ksp_rtol"], self.params["ksp_atol"]
         tol2, tol3 = (1e-9, 1e-8), (1e-8, 1e-8)                            # snes_rtol / snes_atol, solver.py:484-499
@@ -153,6 +158,10 @@ class HipNavierStokesSolver(object):
         self._device_current = False
 
     # -- device side (overridden by alfi_amd.dist.DistNavierStokesSolver for partitioned levels) -------------------------
+    def _any_rank(self, flag):
+        """True if ``flag`` holds on any rank (one rank here)."""
+        return bool(flag)
+
     def _lazy_generation(self):
         """Operators and transfers as recipes that assemble the rows somebody asks for (alfi_amd.lazy) instead of global
         values: for the partitioned solver, whose ranks only ever need their own rows."""

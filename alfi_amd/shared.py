@@ -124,7 +124,17 @@ def build_shared(build, rank, broadcast, barrier, tag, set_threads=None, all_thr
         if rank != 0:
             if word[0] == "error":
                 raise RuntimeError("rank 0 failed to generate the hierarchy: %s" % word[1])
-            obj = load(word[1]) if word[1] else build()
+            obj = None
+            if word[1]:
+                # (a rank that cannot map the file -- wrong owner or mode, another node's /dev/shm, a truncated file --
+                # builds its own copy, as promised above, instead of raising alone after the barrier)
+                try:
+                    obj = load(word[1])
+                except (OSError, ValueError, EOFError, pickle.UnpicklingError) as e:
+                    import sys
+                    sys.stderr.write("[alfi_amd.shared] rank %d cannot map %s (%s): building its own copy\n" % (rank, word[1], e))
+            if obj is None:
+                obj = build()
     finally:
         barrier()
         if rank == 0 and path:
