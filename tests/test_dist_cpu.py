@@ -111,7 +111,9 @@ def test_spmd_oracle_matches_serial(case, world, robust):
     # 2-D: 1e-8.  3-D (patch condition numbers ~1e7 at Re 1000): LAPACK inverts the same patch operators with the dofs in
     # local instead of global order, a cond*eps ~ 1e-9 difference per apply that the chained FGMRES least-squares problems
     # amplify exactly as in tests/test_gpu_parity.py (CYCLE_TOL 1e-5); a wrong halo or a missing ghost shows up at 1e-2.
-    tol = 1e-8 if case.startswith("2d") else 1e-5
+    # (2-D Scott-Vogelius: macro-star patches of 50-90 dofs; the host generator sums the cell contributions with OpenMP atomics,
+    # so the operator's last bits change from run to run -- 1.06e-8 has been seen under load)
+    tol = 1e-7 if case == "2d-SV" else 1e-8 if case.startswith("2d") else 1e-5
     assert np.abs(dv - xv).max() / np.abs(xv).max() < tol
     assert np.abs(df - xf).max() / np.abs(xf).max() < tol
 
