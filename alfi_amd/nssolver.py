@@ -90,8 +90,8 @@ class HipNavierStokesSolver(object):
             self.B, self.B_raw, M, self.Minv = build_sv_pressure_coupling(L, both=True)
             self.vol = np.asarray(M.sum(axis=1)).ravel()                    # int psi_j: weights of the pressure integral
         else:
-            self.B, self.vol = build_pressure_coupling(L)                     # Dirichlet columns zeroed: the Jacobian's B
-            self.B_raw, _ = build_pressure_coupling(L, zero_bc_columns=False)  # all columns: the residual's B
+            # Dirichlet columns zeroed: the Jacobian's B; all columns: the residual's B
+            self.B, self.B_raw, self.vol = build_pressure_coupling(L, both=True)
         self._create_device(restriction)
         self._asm_ready = False
         if self.device_assembly and not self._device_assembly_possible():

@@ -250,11 +250,12 @@ def build_transfer_data(Vc, Vf, nu, gamma, graph=None):
     return T
 
 
-def build_pressure_coupling(L, zero_bc_columns=True):
+def build_pressure_coupling(L, zero_bc_columns=True, both=False):
     """P0 pressure space of the finest level (solver.py:574-586: ``Q = FunctionSpace(mesh, "DG", 0)``): the discrete
     divergence B (cells x velocity dofs, B[c, (a, x)] = -int_c d_x phi_a, Dirichlet velocity columns zeroed) and the
     diagonal pressure mass matrix (cell volumes).  With these the augmented-Lagrangian term of the level operator is
-    gamma B^T M_p^-1 B (solver.py:565-568: ``gamma * inner(cell_avg(div(u)), div(v))``).  Returns scipy CSR B, vol."""
+    gamma B^T M_p^-1 B (solver.py:565-568: ``gamma * inner(cell_avg(div(u)), div(v))``).  Returns scipy CSR B, vol; with
+    ``both``: (B with the Dirichlet columns zeroed, B with all columns, vol)."""
     V = L.V
     mesh, d, el = V.mesh, V.dim, V.element
     g, vol = mesh.cell_geometry()
@@ -265,10 +266,21 @@ def build_pressure_coupling(L, zero_bc_columns=True):
     cols = (V.cell_nodes[:, :, None] * d + np.arange(d)[None, None, :]).reshape(nc, -1).ravel()
     vals = (-vol[:, None, None] * bdiv).reshape(nc, -1).ravel()
     B = sp.csr_matrix((vals, (rows, cols)), shape=(nc, V.num_dofs))
-    if zero_bc_columns:        # the Jacobian's block; with all columns it is the divergence used in the nonlinear residual
+    B.sort_indices()
+
+    def jacobian_block(M):     # the Jacobian's block; with all columns it is the divergence used in the nonlinear residual
         keep = np.ones(V.num_dofs)
         keep[V.bc_dofs] = 0.0
-        B = (B @ sp.diags(keep)).tocsr()
+        M = (M @ sp.diags(keep)).tocsr()
+        M.eliminate_zeros()
+        M.sort_indices()
+        return M
+    if both:                   # (B with the Dirichlet columns zeroed, B with all columns, vol): one pass over the cells
+        Bz = jacobian_block(B)
+        B.eliminate_zeros()
+        return Bz, B, vol
+    if zero_bc_columns:
+        B = jacobian_block(B)
     B.eliminate_zeros()
     B.sort_indices()
     return B, vol

@@ -21,7 +21,7 @@ if [ "$PART" = refresh ]; then
 import glob, sys, pandas as pd
 t = pd.read_csv(glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True)[0])
 t["dur_us"] = (t["End_Timestamp"] - t["Start_Timestamp"]) / 1e3
-t["name"] = t["Kernel_Name"].str.replace(r"\(.*", "", regex=True).str.replace("void ", "").str.replace("(anonymous namespace)::", "", regex=False)
+t["name"] = t["Kernel_Name"].str.replace("(anonymous namespace)::", "", regex=False).str.replace(r"\(.*", "", regex=True).str.replace("void ", "")
 c = t[t["name"].str.contains("element_cell|element_gather|supg_matrix|supg_residual|cell_vector_gather|bc_code")]
 print("config 4, operator refresh / residual kernels by grid size (the largest grid of each kernel = the finest level), durations in us")
 print(c.groupby(["name", "Grid_Size_X", "VGPR_Count"])["dur_us"].agg(["count", "mean", "min", "max"]).round(1).to_string())
