@@ -46,7 +46,6 @@ static __device__ long long* g_invert_phases_dev = nullptr;
 namespace {
 
 typedef double inv_d4 __attribute__((ext_vector_type(4)));
-typedef double inv_d2 __attribute__((ext_vector_type(2)));
 
 // Unpivoted LU of the 4 x 4 pivot block D = L U (L unit lower) in registers.  The block step never forms D^-1: with patch
 // operators of condition ~ gamma / nu = 1e7 the 4 x 4 diagonal blocks are that ill-conditioned themselves (gamma b b^T + nu K
@@ -342,281 +341,6 @@ __global__ __launch_bounds__(512) void patch_invert_mfma_kernel(const int64_t* _
     }
 }
 
-// ---------------------------------------------------------------------------------------------------------------------
-// Round 5: a 16-WIDE pivot panel.  The kernel above pays its fixed cost -- panels to LDS, barrier, LU of the 4 x 4 pivot block
-// on every lane, substitutions for the operands, fix-ups: 5400 of the 6290 cycles of a block step -- once per FOUR pivots, with
-// all eight waves walking the chain in lockstep.  Here a tile step takes 16 pivots:
-//   (A) the owners put the row strip A[K, :] (16 x N) and the column strip A[:, K] (N x 16) into LDS;
-//   (B) PANEL THREADS take them into registers -- thread j two COLUMNS (2 j, 2 j + 1) of the row strip, thread 128 + i two ROWS of
-//       the column strip, 32 entries each: one panel wave per SIMD -- and run the 16 scalar Gauss-Jordan pivots on the strips
-//       alone: per pivot the pivot block's column and row (32 doubles) go through LDS, ONE barrier, then 32 FMAs per thread on
-//       static registers; the multipliers c_t[i] and the scaled pivot rows r_t[j] of every pivot are kept as operands;
-//   (C) the finished strips go back to LDS;
-//   (D) every wave applies the sixteen delayed pivots to its tiles outside the strips, A <- A - sum_t c_t r_t^T, as FOUR CHAINED
-//       MFMAs per tile (k = 4 pivots each), and the owners reload their strips.
-// This IS the scalar elimination (row scaled, then eliminated; the same products in the strips and in the block), so the
-// roundings the ill-conditioned node blocks need (Lu4 above) are kept.  The loop over the pivot tiles is a RUN-TIME loop: one
-// tile step is ~35 KB of code (16 unrolled pivots with static register indices) that stays in the instruction cache; the
-// accumulator tiles of the current strips are picked by wave-uniform compares over the few candidates.  (Fully unrolled over the
-// tiles -- 360 KB for NT = 10 -- the panel ran instruction-fetch bound.)
-template <int NT>
-__global__ __launch_bounds__(512) void patch_invert_panel_kernel(const int64_t* __restrict__ patch_ptr,
-                                                                  const int64_t* __restrict__ inv_ptr,
-                                                                  double* __restrict__ inv, int* __restrict__ status) {
-  constexpr int N = 16 * NT;
-  constexpr int NA = (NT + 3) / 4;            // tile rows per wave (ti = 4 a + wr)
-  constexpr int NB = (NT + 1) / 2;            // tile columns per wave (tj = 2 b + wc)
-  constexpr int NP = N + 16;                  // row stride of the 16-row strips: rows 128 B apart modulo the 256-B bank period
-  constexpr int CP = 17;                      // row stride of the column strip: a thread per row pair reads its entries conflict-free
-  constexpr int NH = N / 2;                   // panel threads per role
-  static_assert(NH <= 128 && NT % 2 == 0, "panel threads: tid < N / 2 own two columns, 128 <= tid < 128 + N / 2 two rows");
-  __shared__ __attribute__((aligned(16))) double RS[16][NP];    // row strip A[K, :]
-  __shared__ double CS[N][CP];                                  // column strip A[:, K]
-  __shared__ __attribute__((aligned(16))) double ROP[16][NP];   // r_t[j]: the scaled pivot row t at the time of pivot t (B operands)
-  __shared__ __attribute__((aligned(16))) double COP[16][NP];   // c_t[i]: column K_t at the time of pivot t (A operands)
-  __shared__ __attribute__((aligned(16))) double PCR[2][40];    // [0, 16) pivot column of the block | [16] 1 / pivot | [20, 36) pivot row
-  const int64_t p = blockIdx.x;
-  const int n = (int)(patch_ptr[p + 1] - patch_ptr[p]);
-  const int ld = (n + 1) & ~1;
-  double* S = inv + inv_ptr[p];
-  const int tid = threadIdx.x;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-  const int wr = wave >> 1, wc = wave & 1;
-  const int lm = lane & 15, lk = lane >> 4;
-  inv_d4 acc[NA][NB];
-#pragma unroll
-  for (int a = 0; a < NA; ++a)
-#pragma unroll
-    for (int b = 0; b < NB; ++b) {
-      const int ti = 4 * a + wr, tj = 2 * b + wc;
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int r = 16 * ti + lk + 4 * g, c = 16 * tj + lm;
-        acc[a][b][g] = (r < n && c < n) ? S[(int64_t)r * ld + c] : (r == c ? 1.0 : 0.0);
-      }
-    }
-  __syncthreads();  // all loads done before anyone stores (the result goes back in place, in another layout)
-  bool bad = false;
-#ifdef ALFI_INVERT_TIMING
-  long long tacc[6] = {0, 0, 0, 0, 0, 0};
-  long long tprev = (long long)__builtin_readcyclecounter();
-  const long long tstart = tprev;
-#endif
-  const bool last_row_in = 4 * (NA - 1) + wr < NT;               // wave-uniform
-  // panel roles: two adjacent columns of the row strip (they lie in one tile), or two adjacent rows of the column strip
-  const bool is_r = tid < NH, is_c = tid >= 128 && tid < 128 + NH;
-  const int e0 = is_r ? 2 * tid : 2 * (tid - 128);               // my first column / row
-#pragma nounroll
-  for (int tk = 0; tk < NT; ++tk) {
-    if (16 * tk >= n) break;                  // uniform: the remaining pivots are identity padding
-    const int tmax = n - 16 * tk < 16 ? n - 16 * tk : 16;          // real pivots of this tile (uniform)
-    const bool own_r = (tk & 3) == wr, own_c = (tk & 1) == wc;     // wave-uniform
-    const int ar = tk >> 2, bc = tk >> 1;
-    // ---- (A) strips -> LDS
-    if (own_r) {
-#pragma unroll
-      for (int a = 0; a < NA; ++a)
-        if (a == ar) {
-#pragma unroll
-          for (int b = 0; b < NB; ++b)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) RS[lk + 4 * g][16 * (2 * b + wc) + lm] = acc[a][b][g];
-        }
-    }
-    if (own_c) {
-#pragma unroll
-      for (int b = 0; b < NB; ++b)
-        if (b == bc) {
-#pragma unroll
-          for (int a = 0; a < NA; ++a)
-            if (a + 1 < NA || last_row_in) {
-#pragma unroll
-              for (int g = 0; g < 4; ++g) CS[16 * (4 * a + wr) + lk + 4 * g][lm] = acc[a][b][g];
-            }
-        }
-    }
-    if (tmax < 16) {                          // the last tile of a patch whose size is no multiple of 16: no operands beyond tmax
-      for (int e = tid; e < 16 * NP; e += 512)
-        if (e / NP >= tmax) {
-          ROP[e / NP][e % NP] = 0.0;
-          COP[e / NP][e % NP] = 0.0;
-        }
-    }
-    __syncthreads();
-    ALFI_INV_PH(0);
-    // ---- (B) the panel: 16 scalar Gauss-Jordan pivots on the strips, in registers
-    const bool in_k = (e0 >> 4) == tk;
-    const bool c_act = is_c && !in_k;         // (the rows K of the column strip are the pivot block: the column threads have it)
-    double r0[16], r1[16];
-    if (is_r) {
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const inv_d2 v = *reinterpret_cast<const inv_d2*>(&RS[i][e0]);
-        r0[i] = v.x;
-        r1[i] = v.y;
-      }
-    } else if (is_c) {
-#pragma unroll
-      for (int j = 0; j < 16; ++j) {
-        r0[j] = CS[e0][j];
-        r1[j] = CS[e0 + 1][j];
-      }
-    }
-    const int roff = is_r ? 0 : 20;           // what I look up at every pivot: the block's pivot column (column threads) / row
-#pragma unroll
-    for (int t = 0; t < 16; ++t) {
-      if (t < tmax) {                         // uniform
-        const int buf = t & 1;
-        const bool piv = is_r && in_k && ((e0 & 15) >> 1) == (t >> 1);   // I hold pivot column t: r0 (t even) or r1 (t odd)
-        if (is_r && in_k) {
-          if (piv) {
-            const double pv0 = (t & 1) ? r1[t] : r0[t];
-            if (pv0 == 0.0) bad = true;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) PCR[buf][i] = (t & 1) ? r1[i] : r0[i];
-            PCR[buf][16] = inv_rcp(pv0);
-          }
-          PCR[buf][20 + (e0 & 15)] = r0[t];
-          PCR[buf][21 + (e0 & 15)] = r1[t];
-        }
-        __syncthreads();
-        // all look-ups of the pivot requested together, then the arithmetic
-        double pv[16];
-#pragma unroll
-        for (int i = 0; i < 16; i += 2) {
-          const inv_d2 v = *reinterpret_cast<const inv_d2*>(&PCR[buf][roff + i]);
-          pv[i] = v.x;
-          pv[i + 1] = v.y;
-        }
-        const double ip = PCR[buf][16];
-        __builtin_amdgcn_sched_barrier(0);
-        if (is_r) {
-          // column 0 of mine
-          if (piv && !(t & 1)) {              // the pivot column itself: - f_i / pivot, 1 / pivot
-#pragma unroll
-            for (int i = 0; i < 16; ++i) r0[i] = i == t ? ip : -r0[i] * ip;
-          } else {
-            const double sv = r0[t] * ip;     // the scaled pivot row's entry of my column
-#pragma unroll
-            for (int i = 0; i < 16; ++i) r0[i] = i == t ? sv : __builtin_fma(-pv[i], sv, r0[i]);
-            if (!in_k) ROP[t][e0] = sv;
-          }
-          if (piv && (t & 1)) {
-#pragma unroll
-            for (int i = 0; i < 16; ++i) r1[i] = i == t ? ip : -r1[i] * ip;
-          } else {
-            const double sv = r1[t] * ip;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) r1[i] = i == t ? sv : __builtin_fma(-pv[i], sv, r1[i]);
-            if (!in_k) ROP[t][e0 + 1] = sv;
-          }
-        } else if (c_act) {
-          double sc[16];                      // the scaled pivot row inside the block (the same products the column threads form)
-#pragma unroll
-          for (int j = 0; j < 16; ++j) sc[j] = pv[j] * ip;
-          const double f0 = r0[t], f1 = r1[t];        // my rows' multipliers
-#pragma unroll
-          for (int j = 0; j < 16; ++j) {
-            r0[j] = j == t ? -f0 * ip : __builtin_fma(-f0, sc[j], r0[j]);
-            r1[j] = j == t ? -f1 * ip : __builtin_fma(-f1, sc[j], r1[j]);
-          }
-          COP[t][e0] = f0;
-          COP[t][e0 + 1] = f1;
-        }
-      }
-    }
-    ALFI_INV_PH(1);
-    // ---- (C) finished strips -> LDS
-    if (is_r) {
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        inv_d2 v;
-        v.x = r0[i];
-        v.y = r1[i];
-        *reinterpret_cast<inv_d2*>(&RS[i][e0]) = v;
-      }
-    } else if (c_act) {
-#pragma unroll
-      for (int j = 0; j < 16; ++j) {
-        CS[e0][j] = r0[j];
-        CS[e0 + 1][j] = r1[j];
-      }
-    }
-    __syncthreads();
-    ALFI_INV_PH(2);
-    // ---- (D) the sixteen delayed pivots on my tiles outside the strips: four chained MFMAs per tile; my strips back
-    const int nkk = (tmax + 3) >> 2;          // uniform
-    double aop[NA][4], bop[NB][4];
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-#pragma unroll
-      for (int a = 0; a < NA; ++a) {
-        const int ti = (a + 1 < NA || last_row_in) ? 4 * a + wr : wr;
-        aop[a][kk] = -COP[4 * kk + lk][16 * ti + lm];
-      }
-#pragma unroll
-      for (int b = 0; b < NB; ++b) bop[b][kk] = ROP[4 * kk + lk][16 * (2 * b + wc) + lm];
-    }
-#pragma unroll
-    for (int a = 0; a < NA; ++a)
-      if ((a + 1 < NA || last_row_in) && 4 * a + wr != tk) {
-#pragma unroll
-        for (int b = 0; b < NB; ++b)
-          if (2 * b + wc != tk) {
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk)
-              if (kk < nkk) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[a][kk], bop[b][kk], acc[a][b], 0, 0, 0);
-          }
-      }
-    ALFI_INV_PH(3);
-    if (own_r) {
-#pragma unroll
-      for (int a = 0; a < NA; ++a)
-        if (a == ar) {
-#pragma unroll
-          for (int b = 0; b < NB; ++b)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) acc[a][b][g] = RS[lk + 4 * g][16 * (2 * b + wc) + lm];
-        }
-    }
-    if (own_c) {
-#pragma unroll
-      for (int b = 0; b < NB; ++b)
-        if (b == bc) {
-#pragma unroll
-          for (int a = 0; a < NA; ++a)
-            if ((a + 1 < NA || last_row_in) && 4 * a + wr != tk) {
-#pragma unroll
-              for (int g = 0; g < 4; ++g) acc[a][b][g] = CS[16 * (4 * a + wr) + lk + 4 * g][lm];
-            }
-        }
-    }
-    __syncthreads();                          // the next tile step rewrites the strips
-    ALFI_INV_PH(4);
-  }
-  if (bad) atomicExch(status, 1);
-#ifdef ALFI_INVERT_TIMING
-  if (g_invert_phases_dev && lane == 0 && p < 4096) {
-    long long* o = g_invert_phases_dev + (p * 8 + wave) * 8;
-#pragma unroll
-    for (int i = 0; i < 6; ++i) o[i] = tacc[i];
-    o[6] = (long long)__builtin_readcyclecounter() - tstart;
-    o[7] = n;
-  }
-#endif
-#pragma unroll
-  for (int a = 0; a < NA; ++a)
-#pragma unroll
-    for (int b = 0; b < NB; ++b) {
-      const int ti = 4 * a + wr, tj = 2 * b + wc;
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int r = 16 * ti + lk + 4 * g, c = 16 * tj + lm;
-        if (ti < NT && tj < NT && r < ld && c < n) S[patch_inv_index(r, c, n, ld)] = (r < n) ? acc[a][b][g] : 0.0;
-      }
-    }
-}
-
 // Round 4 built this elimination twice more with LOOK-AHEAD -- the tiles of the next pivot's tile row / column updated first,
 // the next panels written, the bulk of the MFMAs issued just before the barrier so that they drain under the next block's LU;
 // once with ONE wave factoring the next pivot block and publishing the 28 factors, once with the LU redundant after the
@@ -657,13 +381,8 @@ int launch_patch_invert_mfma(alfi_ctx* ctx, int64_t npatch, int max_np, const in
   }
 #endif
   dim3 grid((unsigned)npatch), block(512);
-  // ALFI_INVERT_PANEL=0: the 4-wide block steps of round 4 (A/B measurements; different roundings, same probe bar)
-  static const bool panel = !(getenv("ALFI_INVERT_PANEL") && atoi(getenv("ALFI_INVERT_PANEL")) == 0);
-#define ALFI_INV(NTV)                                                                                                       \
-  do {                                                                                                                      \
-    if (panel) hipLaunchKernelGGL(patch_invert_panel_kernel<NTV>, grid, block, 0, ctx->stream, patch_ptr, inv_ptr, inv, status); \
-    else hipLaunchKernelGGL(patch_invert_mfma_kernel<NTV>, grid, block, 0, ctx->stream, patch_ptr, inv_ptr, inv, status);   \
-  } while (0)
+#define ALFI_INV(NTV) \
+  hipLaunchKernelGGL(patch_invert_mfma_kernel<NTV>, grid, block, 0, ctx->stream, patch_ptr, inv_ptr, inv, status)
 #ifdef ALFI_INVERT_DEV_NT10            // development builds: one instantiation (the file takes minutes per size)
   if (max_np <= 128) return 0;
   ALFI_INV(10);

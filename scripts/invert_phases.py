@@ -26,8 +26,6 @@ o = o[sel]
 o = o[:, o[0, :, 6] > 0]          # the waves of the build (8, or 4 with -DALFI_INVERT_WR=2)
 steps = (n.max() + 3) // 4
 names = ["panels -> LDS + barrier", "LU of the pivot block", "operands (substitutions)", "update MFMAs issued", "column fix-up", "row fix-up"]
-if os.environ.get("ALFI_INVERT_PANEL") != "0":      # the 16-wide panel kernel of round 5 (cycles still per FOUR pivots)
-    names = ["(A) strips -> LDS + barrier", "(B) panel: 16 pivots", "(C) strips back + barrier", "(D) operands + MFMAs", "(D) reload strips + barrier", "-"]
 print("%s: %d patches of %d dofs (%d block steps); shader-clock cycles per wave and block step, mean over waves / slowest wave"
       % (sys.argv[1], int(sel.sum()), int(n.max()), steps))
 tot = o[:, :, 6].mean() / steps
