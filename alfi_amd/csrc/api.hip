@@ -1519,8 +1519,8 @@ int alfi_patches_set_multiplicative(alfi_level* L, int64_t nit, const int64_t* i
   // writes has, by the symmetric sparsity, nodes in this item's closure, whose last writer is that patch or a later conflicting
   // one.  The list order is a topological order of these dependencies.
   free_mult_schedule(L);
-  if (!L->mult_big) {
-    {
+  {
+    if (!L->mult_big) {
       // row table of the sweep kernels (kernels_patch.hip, mult_wg_rows): per patch node its first block, block count and node
       std::vector<int32_t> rowtab((size_t)L->npatch * 64 * 3, 0);
       for (int64_t p = 0; p < L->npatch; ++p) {

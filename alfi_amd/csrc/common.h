@@ -56,6 +56,7 @@ struct alfi_ctx {
   // mesh-partition parallelism (alfi_ctx_set_comm)
   alfi_comm_fn comm = nullptr;
   void* comm_user = nullptr;
+  int big_mult_ncu = 0, big_mult_per_cu[2] = {0, 0};   // the same for the large-patch sweep (kernels_bigpatch.hip)
   int mult_ncu = 0, mult_per_cu[2] = {0, 0};   // resident-grid size of the persistent multiplicative sweep on THIS ctx's device
   bool comm_allow_self = false;   // test hook (alfi_ctx_comm_allow_self): a rank may be its own neighbour
   bool exact_norm = true;   // partitioned FGMRES: second all-reduce for |w - V h| (PETSc's VecNorm); false: Pythagorean identity
@@ -541,6 +542,7 @@ int launch_patch_mult_wave(alfi_level* lvl, const int32_t* seq, int64_t count, c
 int launch_patch_mult_persistent(alfi_level* lvl, const double* x, double* y);
 // the same with a workgroup per patch: patches of more than 64 nodes (macro stars)
 int launch_big_mult_wave(alfi_level* lvl, const int32_t* seq, int64_t count, const double* x, double* y);
+int launch_big_mult_persistent(alfi_level* lvl, const double* x, double* y);   // ... as one launch over the ticketed schedule
 int launch_invert_small_any(alfi_ctx* ctx, int nmax, int64_t nmat, const int64_t* ptr, const int64_t* inv_ptr,
                             int fixed_n, int64_t fixed_stride, double* inv, int* status);
 int launch_block_build_invert(alfi_transfer* tr);

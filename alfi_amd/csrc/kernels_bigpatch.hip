@@ -547,18 +547,16 @@ __global__ __launch_bounds__(256) void big_apply_kernel(int64_t p0, int64_t npat
 //     apply.  Patches of one wavefront neither read what another one writes nor write the same dofs: plain stores, the
 //     result is that of the sequential sweep.
 // ---------------------------------------------------------------------------------------------------------------------
+// one patch of a multiplicative sweep by a workgroup of 4 waves: r = (x - A y) on the patch's rows (a wave per node, lanes over
+// the row's blocks), ys = inv(A_p) r by row pieces, y += ys
 template <int BS, bool NT>
-__global__ __launch_bounds__(256) void big_mult_kernel(int64_t count, const int32_t* __restrict__ seq,
-                                                        const int64_t* __restrict__ patch_ptr,
-                                                        const int32_t* __restrict__ patch_dofs,
-                                                        const int64_t* __restrict__ inv_ptr, const double* __restrict__ inv,
-                                                        const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colidx,
-                                                        const double* __restrict__ vals, int flat,
-                                                        const double* __restrict__ x, double* __restrict__ y) {
+__device__ __forceinline__ void big_mult_patch(int64_t p, double* __restrict__ rs, double* __restrict__ ys,
+                                               const int64_t* __restrict__ patch_ptr, const int32_t* __restrict__ patch_dofs,
+                                               const int64_t* __restrict__ inv_ptr, const double* __restrict__ inv,
+                                               const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colidx,
+                                               const double* __restrict__ vals, int flat, const double* __restrict__ x,
+                                               double* y) {
   constexpr int BB = BS * BS;
-  __shared__ double rs[BIG_MAX_NP];
-  __shared__ double ys[BIG_MAX_NP];
-  const int64_t p = seq[blockIdx.x];
   const int64_t off = patch_ptr[p];
   const int n = (int)(patch_ptr[p + 1] - off);
   const int nn = n / BS;
@@ -616,6 +614,91 @@ __global__ __launch_bounds__(256) void big_mult_kernel(int64_t count, const int3
 #undef ALFI_BIG_PIECE
   __syncthreads();
   for (int i = threadIdx.x; i < n; i += 256) y[patch_dofs[off + i]] += ys[i];
+}
+
+
+template <int BS, bool NT>
+__global__ __launch_bounds__(256) void big_mult_kernel(int64_t count, const int32_t* __restrict__ seq,
+                                                        const int64_t* __restrict__ patch_ptr,
+                                                        const int32_t* __restrict__ patch_dofs,
+                                                        const int64_t* __restrict__ inv_ptr, const double* __restrict__ inv,
+                                                        const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colidx,
+                                                        const double* __restrict__ vals, int flat,
+                                                        const double* __restrict__ x, double* __restrict__ y) {
+  __shared__ double rs[BIG_MAX_NP];
+  __shared__ double ys[BIG_MAX_NP];
+  big_mult_patch<BS, NT>(seq[blockIdx.x], rs, ys, patch_ptr, patch_dofs, inv_ptr, inv, rowptr, colidx, vals, flat, x, y);
+}
+
+// The whole (symmetrised) sweep of a level of LARGE patches (macro stars: more than 64 nodes) as ONE launch of a resident grid
+// (round 5; rounds 2-4 launched once per dependency wavefront): the schedule, the ticket counter and the per-item dependency
+// counters of patch_mult_persistent_kernel (kernels_patch.hip; alfi_patches_set_multiplicative builds them for every level), a
+// workgroup per item.  Release / acquire at agent scope: the y entries an item reads were written by items on other CUs / XCDs.
+template <int BS, bool NT>
+__global__ __launch_bounds__(256) void big_mult_persistent_kernel(
+    int32_t nitems, const int32_t* __restrict__ items, int32_t* __restrict__ pred, const int32_t* __restrict__ succ_ptr,
+    const int32_t* __restrict__ succ, int32_t* __restrict__ head, int32_t* __restrict__ err,
+    const int64_t* __restrict__ patch_ptr, const int32_t* __restrict__ patch_dofs, const int64_t* __restrict__ inv_ptr,
+    const double* __restrict__ inv, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colidx,
+    const double* __restrict__ vals, int flat, const double* __restrict__ x, double* y) {
+  __shared__ double rs[BIG_MAX_NP];
+  __shared__ double ys[BIG_MAX_NP];
+  __shared__ int32_t s_ticket, s_ok;
+  for (;;) {
+    if (threadIdx.x == 0) s_ticket = __hip_atomic_fetch_add(head, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    const int32_t t = s_ticket;
+    if (t >= nitems) break;
+    if (threadIdx.x == 0) {
+      int ok = 1;
+      unsigned spins = 0;
+      while (__hip_atomic_load(pred + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+        __builtin_amdgcn_s_sleep(2);
+        if (++spins > (1u << 24) || __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+          ok = 0;
+          break;
+        }
+      }
+      s_ok = ok;
+    }
+    __syncthreads();
+    if (!s_ok) {
+      if (threadIdx.x == 0) __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      break;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");          // every wave: forget what other CUs have rewritten
+    big_mult_patch<BS, NT>(items[t], rs, ys, patch_ptr, patch_dofs, inv_ptr, inv, rowptr, colidx, vals, flat, x, y);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");          // this wave's y stores are out
+    __syncthreads();                                            // ... and those of the other waves (rs / ys free again)
+    // (the release is the fence above, once per wave: a release on every decrement costs an L2 write-back each)
+    for (int32_t e = succ_ptr[t] + threadIdx.x; e < succ_ptr[t + 1]; e += 256)
+      __hip_atomic_fetch_sub(pred + succ[e], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+int launch_big_mult_persistent(alfi_level* L, const double* x, double* y) {
+  alfi_ctx* ctx = L->ctx;
+  if (ctx->big_mult_ncu == 0) {
+    hipDeviceProp_t prop;
+    ALFI_HIP_CHECK(ctx, hipGetDeviceProperties(&prop, ctx->device));
+    const auto k2 = &big_mult_persistent_kernel<2, true>;
+    const auto k3 = &big_mult_persistent_kernel<3, true>;
+    ALFI_HIP_CHECK(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&ctx->big_mult_per_cu[0], k2, 256, 0));
+    ALFI_HIP_CHECK(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&ctx->big_mult_per_cu[1], k3, 256, 0));
+    ctx->big_mult_ncu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 64;
+  }
+  const int pc = std::max(1, ctx->big_mult_per_cu[L->bs == 3 ? 1 : 0]);
+  dim3 grid((unsigned)std::min<int64_t>(L->mult_nitems, (int64_t)ctx->big_mult_ncu * pc)), block(256);
+#define ALFI_BPM(BSV)                                                                                                     \
+  hipLaunchKernelGGL((big_mult_persistent_kernel<BSV, true>), grid, block, 0, ctx->stream, L->mult_nitems, L->mult_items, \
+                     L->mult_pred, L->mult_succ_ptr, L->mult_succ, L->mult_ctl, ctx->dev_err, L->patch_ptr, L->patch_dofs, \
+                     L->inv_ptr, L->inv, L->A.rowptr, L->A.colidx, L->A.vals, L->A.flat, x, y)
+  if (L->bs == 2) ALFI_BPM(2);
+  else if (L->bs == 3) ALFI_BPM(3);
+  else return alfi_set_error(ctx, ALFI_E_ARG, "unsupported block size %d", L->bs);
+#undef ALFI_BPM
+  ALFI_HIP_CHECK(ctx, hipGetLastError());
+  return 0;
 }
 
 int launch_big_mult_wave(alfi_level* L, const int32_t* seq, int64_t count, const double* x, double* y) {

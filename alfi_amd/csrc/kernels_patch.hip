@@ -738,9 +738,10 @@ __global__ __launch_bounds__(MULT_NTHR) ALFI_MULT_OCC_ATTR void patch_mult_persi
     if (threadIdx.x == 0) {
       int ok = 1;
       unsigned spins = 0;
-      // (acquire: pairs with the release decrement of the predecessors below -- ADVICE r4; the fence after the barrier makes
-      // the other waves of the workgroup see what this lane acquired)
-      while (__hip_atomic_load(pred + t, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+      // (a RELAXED poll: an acquire load invalidates the caches at every iteration of the spin -- measured on the macro-star
+      // sweep: 3.6 x slower; the acquire is the agent fence every wave executes after the barrier, pairing with the RELEASE
+      // decrement of the predecessors below -- ADVICE r4)
+      while (__hip_atomic_load(pred + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
         __builtin_amdgcn_s_sleep(2);
         if (++spins > (1u << 24) || __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
           ok = 0;
@@ -760,9 +761,13 @@ __global__ __launch_bounds__(MULT_NTHR) ALFI_MULT_OCC_ATTR void patch_mult_persi
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // this wave's y stores have left
     __syncthreads();                                            // ... and those of the other waves
     ALFI_MULT_STAMP(5);
-    // release: the y stores of this item (drained above, barrier) happen-before whatever a successor reads after its acquire
+    // release, at the level of the ISA: the y stores of this item are WRITE-THROUGH (sc1: they bypass this XCD's L2 as far as
+    // other agents' reads are concerned), drained by the s_waitcnt above, and the barrier orders the other waves' stores before
+    // the decrements -- so a RELAXED decrement publishes them.  (A __ATOMIC_RELEASE decrement, as ADVICE r4 proposed, makes the
+    // compiler put an L2 write-back, buffer_wbl2 sc1, in front of EVERY atomic: config 4's sweep 25.5 -> 41.8 ms.  The acquire side
+    // is the agent fence each consumer wave executes after its wait.)
     for (int32_t e = succ_ptr[t] + threadIdx.x; e < succ_ptr[t + 1]; e += MULT_NTHR)
-      __hip_atomic_fetch_sub(pred + succ[e], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_fetch_sub(pred + succ[e], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     ALFI_MULT_STAMP(6);
   }
 }
@@ -901,6 +906,7 @@ int launch_patch_mult_persistent(alfi_level* L, const double* x, double* y) {
   ALFI_HIP_CHECK(ctx, hipMemcpyAsync(L->mult_pred, L->mult_pred0, sizeof(int32_t) * (size_t)L->mult_nitems,
                                      hipMemcpyDeviceToDevice, ctx->stream));
   ALFI_HIP_CHECK(ctx, hipMemsetAsync(L->mult_ctl, 0, 4 * sizeof(int32_t), ctx->stream));
+  if (L->mult_big) return launch_big_mult_persistent(L, x, y);      // macro stars: a workgroup per item (kernels_bigpatch.hip)
   // a resident grid: as many workgroups per CU as the kernel's registers and LDS admit (every ticket holder must be running;
   // more workgroups in flight = more of the next wavefronts' independent patches started early)
   // (per ctx -- ADVICE r4: function-local statics sized every later ctx's grid from the first ctx's device)

@@ -1,6 +1,6 @@
 """Worker of tests/test_gpu_env_variants.py::test_persistent_sweep_equals_the_launch_per_wavefront_schedule: symmetrised
-multiplicative sweeps (two '|'-separated sort orders, so patches appear twice) on a 2-D [P2]^2 and a 3-D [P2+FB]^3 level, applied
-three times each; saves the results to argv[1] (npz).  The parent runs it under ALFI_MULT_PERSISTENT=1 and =0."""
+multiplicative sweeps (two '|'-separated sort orders, so patches appear twice) on a 2-D [P2]^2, a 3-D [P2+FB]^3 and a 3-D
+Scott-Vogelius [P3]^3 macro-star level (patches of more than 64 nodes: the workgroup-per-patch sweep), applied three times each; saves the results to argv[1] (npz).  The parent runs it under ALFI_MULT_PERSISTENT=1 and =0."""
 import os
 import sys
 
@@ -17,8 +17,13 @@ def main():
     ctx = hip.Context(0)
     out = {}
     for name, prob, nref, order in (("2d", TwoDimLidDrivenCavityProblem(8), 2, "0+:1-|1+:0-"),
-                                    ("3d", ThreeDimLidDrivenCavityProblem(2), 2, "0+:1-:2+")):
-        lv, _ = build_hierarchy(prob, nref, 2, Re=100.0)
+                                    ("3d", ThreeDimLidDrivenCavityProblem(2), 2, "0+:1-:2+"),
+                                    ("sv3d", ThreeDimLidDrivenCavityProblem(1), 1, "0+:1-:2+")):
+        if name == "sv3d":      # macro stars of the Scott-Vogelius [P3]^3 pair: several hundred dofs, a WORKGROUP per patch
+            from alfi_amd.sv import build_sv_hierarchy
+            lv, _ = build_sv_hierarchy(prob, nref, 3, Re=100.0, gamma=1e4)
+        else:
+            lv, _ = build_hierarchy(prob, nref, 2, Re=100.0)
         L = lv[-1]
         dl = hip.Level(ctx, L.A, L.bc_dofs)
         dl.set_patches(L.patch_ptr, L.patch_dofs)

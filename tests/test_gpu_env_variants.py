@@ -51,7 +51,8 @@ def test_persistent_sweep_equals_the_launch_per_wavefront_schedule(tmp_path):
     """the multiplicative sweep as ONE launch of a resident grid that walks the wavefront schedule with
     per-item dependency counters (patch_mult_persistent_kernel; alfi/solver.py:322-335, relaxation.py:139-150) gives, bit for
     bit, what one launch per dependency wavefront gives (ALFI_MULT_PERSISTENT=0: the schedule of rounds 1-3) -- 2-D with two
-    '|'-separated sort orders (every patch twice per sweep) and 3-D, symmetrised, each apply repeated three times."""
+    '|'-separated sort orders (every patch twice per sweep), 3-D, and the macro stars of the 3-D Scott-Vogelius pair (more than
+    64 nodes per patch: big_mult_persistent_kernel, round 5), symmetrised, each apply repeated three times."""
     import numpy as np
     res = {}
     for mode in ("1", "0"):
@@ -62,6 +63,6 @@ def test_persistent_sweep_equals_the_launch_per_wavefront_schedule(tmp_path):
                              cwd=ROOT, capture_output=True, text=True, timeout=900)
         assert out.returncode == 0 and "OK" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
         res[mode] = np.load(f)
-    for k in ("2d", "3d"):
+    for k in ("2d", "3d", "sv3d"):
         assert int(res["1"][k + "_waves"]) > 4
         assert np.array_equal(res["1"][k], res["0"][k]), (k, np.abs(res["1"][k] - res["0"][k]).max())
