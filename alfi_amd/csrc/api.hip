@@ -140,6 +140,7 @@ static int upload_bsr(alfi_ctx* ctx, DevBSR* d, const alfi_bsr_host* h, int bs) 
   if (!flat) {
     ALFI_CHECK(dev_upload(ctx, &d->colidx, h->colidx, d->nnzb));
     ALFI_CHECK(dev_alloc(ctx, &d->vals, d->nnzb * bs * bs));
+    if (!h->vals) ALFI_HIP_CHECK(ctx, hipMemsetAsync(d->vals, 0, sizeof(double) * d->nnzb * bs * bs, ctx->stream));
   } else {
     std::vector<int32_t> cf(h->colidx, h->colidx + d->nnzb);
     for (int64_t i = 0; i < h->nbrows; ++i) cf[h->rowptr[i]] |= (int32_t)0x80000000;
@@ -154,7 +155,7 @@ static int upload_bsr(alfi_ctx* ctx, DevBSR* d, const alfi_bsr_host* h, int bs) 
     // it could land after the value upload below
     ALFI_HIP_CHECK(ctx, hipMemsetAsync(d->vals, 0, sizeof(double) * padded, ctx->stream));
   }
-  return upload_bsr_values(ctx, d, h->vals);
+  return h->vals ? upload_bsr_values(ctx, d, h->vals) : 0;     // (no values: zeros, see alfi_level_create)
 }
 static void free_assembly(AssemblyDev* S);
 static void free_bsr(DevBSR* d) {
@@ -447,7 +448,8 @@ int alfi_prof_get_level(alfi_ctx* ctx, int ev, int level_id, double* total_ms, i
 // ---- level ---------------------------------------------------------------------------------------------------------------
 int alfi_level_create(alfi_ctx* ctx, int64_t nbrows, int bs, const int32_t* browptr, const int32_t* bcolidx,
                       const double* bvals, const int32_t* bc_dofs, int64_t nbc, alfi_level** out) {
-  if (!ctx || !out || !browptr || !bcolidx || !bvals) return alfi_set_error(ctx, ALFI_E_ARG, "NULL argument");
+  // bvals == NULL: the operator starts as zeros and is formed on the device (alfi_level_set_assembly + alfi_level_assemble)
+  if (!ctx || !out || !browptr || !bcolidx) return alfi_set_error(ctx, ALFI_E_ARG, "NULL argument");
   if (bs != 2 && bs != 3) return alfi_set_error(ctx, ALFI_E_ARG, "block size must be 2 or 3, got %d", bs);
   if (nbrows * bs > INT32_MAX) return alfi_set_error(ctx, ALFI_E_ARG, "level too large for int32 dof indices");
   ALFI_HIP_CHECK(ctx, hipSetDevice(ctx->device));
@@ -704,15 +706,29 @@ int alfi_level_set_assembly(alfi_level* L, int64_t ncell, int nloc, const int32_
   if (cptr[0] != 0 || (part ? npairs > ncell * nloc * nloc : npairs != ncell * nloc * nloc))
     return alfi_set_error(ctx, ALFI_E_ARG, "contributor lists hold %lld pairs, expected %scells x nodes^2 = %lld", (long long)npairs,
                           part ? "at most " : "", (long long)(ncell * nloc * nloc));
-  for (int64_t k = 0; k < nnzb; ++k)
-    if (cptr[k + 1] <= cptr[k]) return alfi_set_error(ctx, ALFI_E_ARG, "block %lld has no contributing cell", (long long)k);
-  for (int64_t q = 0; q < npairs; ++q)
-    if (ccell[q] < 0 || ccell[q] >= ncell || cba[q] >= nloc * nloc) return alfi_set_error(ctx, ALFI_E_ARG, "contributor %lld out of range", (long long)q);
-  int64_t nstate = nb;
-  for (int64_t i = 0; i < ncell * nloc; ++i) {
-    if (cell_nodes[i] < 0 || (!part && cell_nodes[i] >= nb)) return alfi_set_error(ctx, ALFI_E_ARG, "cell node out of range");
-    nstate = std::max<int64_t>(nstate, (int64_t)cell_nodes[i] + 1);
-  }
+  // (the checks below walk 200 M contributors at config-4 size: over host threads, each reporting its first finding)
+  std::atomic<int64_t> bad_block(-1), bad_pair(-1), bad_node(-1), max_node(nb - 1);
+  host_parallel_ranges(nnzb, [&](int64_t k0, int64_t k1) {
+    for (int64_t k = k0; k < k1; ++k)
+      if (cptr[k + 1] <= cptr[k]) { bad_block = k; return; }
+  });
+  if (bad_block >= 0) return alfi_set_error(ctx, ALFI_E_ARG, "block %lld has no contributing cell", (long long)bad_block.load());
+  host_parallel_ranges(npairs, [&](int64_t q0, int64_t q1) {
+    for (int64_t q = q0; q < q1; ++q)
+      if (ccell[q] < 0 || ccell[q] >= ncell || cba[q] >= nloc * nloc) { bad_pair = q; return; }
+  });
+  if (bad_pair >= 0) return alfi_set_error(ctx, ALFI_E_ARG, "contributor %lld out of range", (long long)bad_pair.load());
+  host_parallel_ranges(ncell * nloc, [&](int64_t i0, int64_t i1) {
+    int64_t m = 0;
+    for (int64_t i = i0; i < i1; ++i) {
+      if (cell_nodes[i] < 0 || (!part && cell_nodes[i] >= nb)) { bad_node = i; return; }
+      m = std::max<int64_t>(m, cell_nodes[i]);
+    }
+    int64_t cur = max_node.load();
+    while (m > cur && !max_node.compare_exchange_weak(cur, m)) {}
+  });
+  if (bad_node >= 0) return alfi_set_error(ctx, ALFI_E_ARG, "cell node out of range");
+  const int64_t nstate = max_node.load() + 1;
   // the diagonal block of every block row (its contributor list = the cells around the node: the gather of element vectors);
   // the two nodes of a contributing pair are rows / columns of the local operator
   std::vector<int32_t> diag((size_t)nb, -1);
@@ -722,18 +738,24 @@ int alfi_level_set_assembly(alfi_level* L, int64_t ncell, int nloc, const int32_
     ALFI_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     ALFI_HIP_CHECK(ctx, hipMemcpy(rowptr.data(), L->A.rowptr, sizeof(int32_t) * (nb + 1), hipMemcpyDeviceToHost));
     ALFI_HIP_CHECK(ctx, hipMemcpy(colidx.data(), L->A.colidx, sizeof(int32_t) * nnzb, hipMemcpyDeviceToHost));
-    for (int64_t r = 0; r < nb; ++r) {
-      for (int64_t k = rowptr[r]; k < rowptr[r + 1]; ++k) {
-        const int32_t c = colidx[k] & 0x7fffffff;       // (the sign bit marks the first block of a block row)
-        if (c == r) diag[r] = (int32_t)k;
-        for (int64_t q = cptr[k]; q < cptr[k + 1]; ++q) {
-          const int32_t* cn = cell_nodes + (int64_t)ccell[q] * nloc;
-          if (cn[cba[q] % nloc] != r || cn[cba[q] / nloc] != c)
-            return alfi_set_error(ctx, ALFI_E_ARG, "contributor %lld does not belong to block %lld", (long long)q, (long long)k);
+    std::atomic<int64_t> stray(-1), stray_block(-1), no_diag(-1);
+    host_parallel_ranges(nb, [&](int64_t r0, int64_t r1) {
+      for (int64_t r = r0; r < r1; ++r) {
+        for (int64_t k = rowptr[r]; k < rowptr[r + 1]; ++k) {
+          const int32_t c = colidx[k] & 0x7fffffff;       // (the sign bit marks the first block of a block row)
+          if (c == r) diag[r] = (int32_t)k;
+          for (int64_t q = cptr[k]; q < cptr[k + 1]; ++q) {
+            const int32_t* cn = cell_nodes + (int64_t)ccell[q] * nloc;
+            if (cn[cba[q] % nloc] != r || cn[cba[q] / nloc] != c) { stray = q; stray_block = k; return; }
+          }
         }
+        if (diag[r] < 0) { no_diag = r; return; }
       }
-      if (diag[r] < 0) return alfi_set_error(ctx, ALFI_E_ARG, "block row %lld has no diagonal block", (long long)r);
-    }
+    });
+    if (stray >= 0)
+      return alfi_set_error(ctx, ALFI_E_ARG, "contributor %lld does not belong to block %lld", (long long)stray.load(),
+                            (long long)stray_block.load());
+    if (no_diag >= 0) return alfi_set_error(ctx, ALFI_E_ARG, "block row %lld has no diagonal block", (long long)no_diag.load());
   }
   // per (a, b) the slices of the reference tensors the cell kernel reads (kernels_assemble.hip):
   // T1[k,i,b,a] | T1[b,i,k,a] | S[a,b,i,j];  T1: (nloc, d+1, nloc, nloc), S: (nloc, nloc, d+1, d+1)
@@ -2247,11 +2269,9 @@ int alfi_mg_create(alfi_ctx* ctx, int nlevels, alfi_level** levels, alfi_transfe
   for (int l = 1; l < nlevels; ++l) {
     if (transfers[l - 1]->coarse != levels[l - 1] || transfers[l - 1]->fine != levels[l])
       return alfi_set_error(ctx, ALFI_E_ARG, "transfer %d does not link levels %d and %d", l - 1, l - 1, l);
-    if (levels[l]->n_own > 0 && !levels[l]->factored)
-      return alfi_set_error(ctx, ALFI_E_STATE, "level %d: patches not factored", l);
   }
-  // a rank that only holds ghost copies of its lowest level (the owner solves it) needs no coarse inverse
-  if (levels[0]->n_own > 0 && !levels[0]->cinv && !levels[0]->mf) return alfi_set_error(ctx, ALFI_E_STATE, "coarse level has no inverse");
+  // (patch factors and the coarse inverse are asked for when a cycle runs -- mg_ready -- not here: a hierarchy whose operators
+  // are formed on the device is linked before its first refresh)
   alfi_mg* mg = new alfi_mg();
   mg->ctx = ctx;
   mg->levels.assign(levels, levels + nlevels);
@@ -2368,8 +2388,21 @@ static void cycle_signature(alfi_mg* mg, std::vector<uint64_t>* sig) {
   }
 }
 
+// every level has what a cycle multiplies with: factored patches, a coarse inverse
+static int mg_ready(alfi_mg* mg) {
+  alfi_ctx* ctx = mg->ctx;
+  for (size_t l = 1; l < mg->levels.size(); ++l)
+    if (mg->levels[l]->n_own > 0 && !mg->levels[l]->factored)
+      return alfi_set_error(ctx, ALFI_E_STATE, "level %d: patches not factored", (int)l);
+  // a rank that only holds ghost copies of its lowest level (the owner solves it) needs no coarse inverse
+  alfi_level* C = mg->levels[0];
+  if (C->n_own > 0 && !C->cinv && !C->mf) return alfi_set_error(ctx, ALFI_E_STATE, "coarse level has no inverse");
+  return 0;
+}
+
 static int run_cycle(alfi_mg* mg, int kind, const double* db, double* dx) {
   alfi_ctx* ctx = mg->ctx;
+  ALFI_CHECK(mg_ready(mg));
   auto eager = [&]() { return kind ? fcycle(mg, db, dx) : vcycle(mg, (int)mg->levels.size() - 1, db, dx, false); };
   bool ok = ctx->use_graph && ctx->prof == 0;
   for (alfi_level* L : mg->levels) ok = ok && !L->has_halo;

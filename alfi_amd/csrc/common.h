@@ -5,6 +5,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <string>
+#include <thread>
 #include <vector>
 #include "alfi_hip.h"
 
@@ -23,6 +24,29 @@ inline hipError_t alfi_counted_memcpy_async(void* dst, const void* src, size_t n
 }
 #define hipMemcpy(dst, src, n, kind) alfi_counted_memcpy(dst, src, n, kind)
 #define hipMemcpyAsync(dst, src, n, kind, stream) alfi_counted_memcpy_async(dst, src, n, kind, stream)
+
+// HOST helper for the set-up passes over large index arrays (validation of contributor lists, layout conversions): fn(begin,
+// end) on disjoint ranges of [0, n) over up to 16 host threads (a GPU box gives one process about that many cores); the
+// ranges are contiguous and fixed by n and the thread count only.  Small n: the calling thread.
+template <class F>
+inline void host_parallel_ranges(int64_t n, F&& fn) {
+  if (n <= 0) return;
+  unsigned hw = std::thread::hardware_concurrency();
+  int64_t nt = hw ? (hw < 16 ? hw : 16) : 4;
+  if (n < ((int64_t)1 << 16)) nt = 1;
+  if (nt <= 1) {
+    fn((int64_t)0, n);
+    return;
+  }
+  const int64_t step = (n + nt - 1) / nt;
+  std::vector<std::thread> th;
+  for (int64_t t = 1; t < nt; ++t) {
+    const int64_t a = t * step, b = a + step < n ? a + step : n;
+    if (a < b) th.emplace_back([&fn, a, b] { fn(a, b); });
+  }
+  fn((int64_t)0, step < n ? step : n);
+  for (auto& t : th) t.join();
+}
 
 struct alfi_ctx {
   int device = 0;

@@ -77,9 +77,16 @@ static inline int64_t find_col(const int32_t* colidx, int64_t lo, int64_t hi, in
 // bI: (nloc,d+1) avg d_i phi_a; T1: (nloc,d+1,nloc,nloc) avg phi_k d_i phi_b phi_a (index order k,i,b,a);
 // wk: (nloc, d) wind at the cell's nodes (only read when adv != 0).
 struct ElemWork {
-  std::vector<double> G, Hij, bvec, cki;
-  ElemWork(int nloc, int d) : G((d + 1) * (d + 1)), Hij((size_t)(d + 1) * (d + 1) * d * d), bvec(nloc * d),
-                               cki((size_t)nloc * (d + 1)) {}
+  std::vector<double> bvec, cki, t1, r, out, St;
+  // S: (nloc, nloc, d+1, d+1), kept here transposed to (d+1, d+1, nloc, nloc)
+  ElemWork(int nloc, int d, const double* S = nullptr)
+      : bvec(nloc * d), cki((size_t)nloc * (d + 1)), t1((size_t)nloc * nloc), r((size_t)nloc * nloc * (d + 1) * d),
+        out((size_t)(1 + d * d) * nloc * nloc), St((size_t)(d + 1) * (d + 1) * nloc * nloc) {
+    const int nv = d + 1, nn = nloc * nloc;
+    if (S)
+      for (int ab = 0; ab < nn; ++ab)
+        for (int ij = 0; ij < nv * nv; ++ij) St[(size_t)ij * nn + ab] = S[(size_t)ab * nv * nv + ij];
+  }
 };
 
 // gfull: coefficient of the FULL grad-div term (div u, div v) of the Scott-Vogelius forms (alfi/solver.py:609-619,
@@ -89,41 +96,46 @@ static void element_matrix(int nloc, int d, const double* gc, double vc, const d
                            double* Ae, double gfull = 0.0) {
   const int nv = d + 1;
   const int ndof = nloc * d;
-  double* G = W.G.data();
-  double* Hij = W.Hij.data();
   double* bvec = W.bvec.data();
   double* cki = W.cki.data();
-  std::fill(Ae, Ae + (size_t)ndof * ndof, 0.0);
   if (nu != 0.0 || gfull != 0.0) {
+    // out[q][ab] = sum_ij M[ij][q] St[ij][ab]: q = 0 the Gram entry g_i . g_j (-> G_ab), q = 1 + dd d + cc the product
+    // g_i^dd g_j^cc (-> h[dd][cc] = int d_dd phi_a d_cc phi_b); the (a, b) index is innermost and contiguous in St
+    const int nn = nloc * nloc, nq = 1 + d * d;
+    double* out = W.out.data();
+    std::fill(out, out + (size_t)nq * nn, 0.0);
     for (int i = 0; i < nv; ++i)
       for (int j = 0; j < nv; ++j) {
+        const double* St = W.St.data() + (size_t)(i * nv + j) * nn;
+        double m[10];
         double s = 0;
         for (int x = 0; x < d; ++x) s += gc[i * d + x] * gc[j * d + x];
-        G[i * nv + j] = s;
+        m[0] = s;
         for (int dd = 0; dd < d; ++dd)
-          for (int cc = 0; cc < d; ++cc) Hij[((i * nv + j) * d + dd) * d + cc] = gc[i * d + dd] * gc[j * d + cc];
+          for (int cc = 0; cc < d; ++cc) m[1 + dd * d + cc] = gc[i * d + dd] * gc[j * d + cc];
+        for (int q = 0; q < nq; ++q) {
+          const double mq = m[q];
+          double* oq = out + (size_t)q * nn;
+#pragma omp simd
+          for (int ab = 0; ab < nn; ++ab) oq[ab] += mq * St[ab];
+        }
       }
+    // K_(a,c),(b,dd) = delta_{c,dd} G_ab + int d_dd phi_a d_c phi_b ;  (div, div)_(a,c),(b,dd) = int d_c phi_a d_dd phi_b
+    const double fn = nu * vc, fg = gfull * vc;
     for (int a = 0; a < nloc; ++a)
-      for (int b = 0; b < nloc; ++b) {
-        const double* Sab = S + ((size_t)(a * nloc + b)) * nv * nv;
-        double gab = 0;
-        double h[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};  // h[dd][cc] = int d_dd phi_a d_cc phi_b
-        for (int i = 0; i < nv; ++i)
-          for (int j = 0; j < nv; ++j) {
-            const double s = Sab[i * nv + j];
-            if (s == 0.0) continue;
-            gab += s * G[i * nv + j];
-            const double* hh = &Hij[((i * nv + j) * d) * d];
-            for (int q = 0; q < d * d; ++q) h[q] += s * hh[q];
-          }
-        // K_(a,c),(b,dd) = delta_{c,dd} G_ab + int d_dd phi_a d_c phi_b ;  (div, div)_(a,c),(b,dd) = int d_c phi_a d_dd phi_b
-        for (int cc = 0; cc < d; ++cc)
+      for (int cc = 0; cc < d; ++cc) {
+        double* row = Ae + (size_t)(a * d + cc) * ndof;
+        for (int b = 0; b < nloc; ++b) {
+          const int ab = a * nloc + b;
           for (int dd = 0; dd < d; ++dd) {
-            double v = h[dd * d + cc];
-            if (cc == dd) v += gab;
-            Ae[(size_t)(a * d + cc) * ndof + b * d + dd] += nu * vc * v + gfull * vc * h[cc * d + dd];
+            double v = out[(size_t)(1 + dd * d + cc) * nn + ab];
+            if (cc == dd) v += out[ab];
+            row[b * d + dd] = fn * v + fg * out[(size_t)(1 + cc * d + dd) * nn + ab];
           }
+        }
       }
+  } else {
+    std::fill(Ae, Ae + (size_t)ndof * ndof, 0.0);
   }
   if (gamma != 0.0) {
     for (int a = 0; a < nloc; ++a)
@@ -140,38 +152,55 @@ static void element_matrix(int nloc, int d, const double* gc, double vc, const d
     }
   }
   if (adv != 0.0) {
-    // term 1: delta_{cd} * vol * sum_{k,i} (w_k . g_i) T1[k,i,b,a]
+    // Both terms as small dense products with the (b, a) / a index innermost (contiguous in T1: the loops vectorise), then one
+    // pass over Ae.  (Until round 5 the second term updated d x d entries of Ae per (b, i, k, a): 100 k dependent
+    // read-modify-writes per cell, 4/5 of the time of the advective assembly.)
+    //   t1[b][a]       = sum_{k,i} (w_k . g_i) T1[k,i,b,a]
+    //   r[b][i][c][a]  = sum_k w_k^c T1[b,i,k,a]
+    //   Ae[(a,c),(b,dd)] += adv vol (delta_{c,dd} t1[b][a] + sum_i r[b][i][c][a] g_i^dd)
+    const int nn = nloc * nloc;
+    double* t1 = W.t1.data();
+    double* r = W.r.data();
     for (int k = 0; k < nloc; ++k)
       for (int i = 0; i < nv; ++i) {
         double s = 0;
         for (int x = 0; x < d; ++x) s += wk[k * d + x] * gc[i * d + x];
         cki[k * nv + i] = s;
       }
-    const double f = adv * vc;
-    for (int k = 0; k < nloc; ++k)
-      for (int i = 0; i < nv; ++i) {
-        const double cc1 = f * cki[k * nv + i];
-        if (cc1 == 0.0) continue;
-        const double* T = T1 + ((size_t)(k * nv + i)) * nloc * nloc;  // T[b][a]
-        for (int b = 0; b < nloc; ++b)
-          for (int a = 0; a < nloc; ++a) {
-            const double t = cc1 * T[b * nloc + a];
-            for (int x = 0; x < d; ++x) Ae[(size_t)(a * d + x) * ndof + b * d + x] += t;
-          }
+    std::fill(t1, t1 + nn, 0.0);
+    for (int ki = 0; ki < nloc * nv; ++ki) {
+      const double cc1 = cki[ki];
+      const double* T = T1 + (size_t)ki * nn;  // T[b][a]
+#pragma omp simd
+      for (int q = 0; q < nn; ++q) t1[q] += cc1 * T[q];
+    }
+    std::fill(r, r + (size_t)nn * nv * d, 0.0);
+    for (int bi = 0; bi < nloc * nv; ++bi) {
+      const double* T = T1 + (size_t)bi * nn;  // T[k][a]
+      double* rb = r + (size_t)bi * d * nloc;   // rb[c][a]
+      for (int k = 0; k < nloc; ++k) {
+        const double* Tk = T + k * nloc;
+        for (int cc = 0; cc < d; ++cc) {
+          const double wc = wk[k * d + cc];
+          double* rc = rb + cc * nloc;
+#pragma omp simd
+          for (int a = 0; a < nloc; ++a) rc[a] += wc * Tk[a];
+        }
       }
-    // term 2: (a,c),(b,dd) += vol * w_k^c g_i^dd * T1[b,i,k,a]
-    for (int b = 0; b < nloc; ++b)
-      for (int i = 0; i < nv; ++i) {
-        const double* T = T1 + ((size_t)(b * nv + i)) * nloc * nloc;  // T[k][a]
-        for (int k = 0; k < nloc; ++k)
-          for (int a = 0; a < nloc; ++a) {
-            const double t = f * T[k * nloc + a];
-            if (t == 0.0) continue;
-            for (int cc = 0; cc < d; ++cc) {
-              const double tw = t * wk[k * d + cc];
-              for (int dd = 0; dd < d; ++dd) Ae[(size_t)(a * d + cc) * ndof + b * d + dd] += tw * gc[i * d + dd];
-            }
+    }
+    const double f = adv * vc;
+    for (int a = 0; a < nloc; ++a)
+      for (int cc = 0; cc < d; ++cc) {
+        double* row = Ae + (size_t)(a * d + cc) * ndof;
+        for (int b = 0; b < nloc; ++b) {
+          double acc[3] = {0.0, 0.0, 0.0};
+          for (int i = 0; i < nv; ++i) {
+            const double rv = r[((size_t)(b * nv + i) * d + cc) * nloc + a];
+            for (int dd = 0; dd < d; ++dd) acc[dd] += rv * gc[i * d + dd];
           }
+          acc[cc] += t1[b * nloc + a];
+          for (int dd = 0; dd < d; ++dd) row[b * d + dd] += f * acc[dd];
+        }
       }
   }
 }
@@ -188,7 +217,7 @@ int alfi_host_assemble_bsr(int64_t ncell, int nloc, int d, const int32_t* cell_n
   int err = 0;
 #pragma omp parallel
   {
-    ElemWork W(nloc, d);
+    ElemWork W(nloc, d, S);
     std::vector<double> Ae((size_t)ndof * ndof), wk((size_t)nloc * d);
 #pragma omp for schedule(dynamic, 256)
     for (int64_t c = 0; c < ncell; ++c) {
@@ -302,7 +331,7 @@ int alfi_host_interior_blocks(int64_t nblk, int nch, int nloc, int d, const int3
   const int ndof = nloc * d;
 #pragma omp parallel
   {
-    ElemWork W(nloc, d);
+    ElemWork W(nloc, d, S);
     std::vector<double> Ke((size_t)ndof * ndof), De((size_t)ndof * ndof);
 #pragma omp for schedule(static)
     for (int64_t blk = 0; blk < nblk; ++blk) {

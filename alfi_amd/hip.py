@@ -198,8 +198,10 @@ class Level(object):
         self.n, self.bs = A.nbrows * A.bs, A.bs
         bc = np.ascontiguousarray(bc_dofs, dtype=np.int32)
         h = vp()
-        ctx.check(ctx.lib.alfi_level_create(ctx.h, A.nbrows, A.bs, _ptr(A.rowptr), _ptr(A.colidx),
-                                            _ptr(np.ascontiguousarray(A.vals)), _ptr(bc), len(bc), ctypes.byref(h)))
+        # (A.vals None: the sparsity only, the values are formed on the device -- set_assembly + assemble)
+        vals = None if A.vals is None else np.ascontiguousarray(A.vals)
+        ctx.check(ctx.lib.alfi_level_create(ctx.h, A.nbrows, A.bs, _ptr(A.rowptr), _ptr(A.colidx), _ptr(vals), _ptr(bc), len(bc),
+                                            ctypes.byref(h)))
         self.h = h
         self.nnzb = A.nnzb
         i = ctypes.c_int()

@@ -26,8 +26,16 @@ def _unique_rows(rows, nv):
     key = rows[:, 0].astype(np.int64)
     for j in range(1, rows.shape[1]):
         key = key * nv + rows[:, j]
-    ukey, first, inv = np.unique(key, return_index=True, return_inverse=True)
-    return rows[first].astype(np.int32), inv.astype(np.int32)
+    # (no return_index: np.unique then sorts with the vectorised quicksort instead of a stable merge sort; the rows are read
+    # back out of the unique keys)
+    ukey, inv = np.unique(key, return_inverse=True)
+    k = rows.shape[1]
+    out = np.empty((ukey.shape[0], k), dtype=np.int32)
+    for j in range(k - 1, 0, -1):
+        out[:, j] = ukey % nv
+        ukey = ukey // nv
+    out[:, 0] = ukey
+    return out, inv.astype(np.int32)
 
 
 class SimplexMesh(object):

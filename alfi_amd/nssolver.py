@@ -70,11 +70,17 @@ class HipNavierStokesSolver(object):
         self.char_L, self.char_U = problem.char_length(), problem.char_velocity()
         self.nullspace = bool(problem.has_nullspace())
         # hierarchy and device objects are created once (Stokes operator); values are replaced per Newton step
+        self._values_on_device = False
         if self.sv:
             from .sv import build_sv_hierarchy, build_sv_pressure_coupling
             self.levels, self.transfers = build_sv_hierarchy(problem, nref, k, Re=0.0, gamma=gamma)
         else:
-            self.levels, self.transfers = build_hierarchy(problem, nref, k, Re=0.0, gamma=gamma, lazy=self._lazy_generation())
+            # with the device-side refresh nobody reads a host copy of the operators: the generator then delivers the sparsity
+            # only and the first (Stokes) operator is formed on the device as well (no host assembly, no 8 GB upload at config 4)
+            self._values_on_device = (self.device_assembly and self._device_assembly_possible()
+                                      and not self._lazy_generation())
+            self.levels, self.transfers = build_hierarchy(problem, nref, k, Re=0.0, gamma=gamma, lazy=self._lazy_generation(),
+                                                          operator_values=not self._values_on_device)
         if self.sv:      # patch = macro with the problem's relaxation direction (solver.py:339-342), sparse-LU patch options
             from .solver import configure_patch_solver_sv
             mgl = configure_patch_solver_sv(mg_levels_solver(dim, patch="macro", smoothing=smoothing,
@@ -110,6 +116,15 @@ class HipNavierStokesSolver(object):
                 warnings.warn("device-side operator refresh not available (%s): the operators of every Newton step are "
                               "assembled on the host" % (failure if failure is not None else "another rank failed to set it up",))
                 self.device_assembly = False
+        if self._values_on_device:
+            if self.device_assembly:
+                self._first_operators_on_device()
+            else:                           # the refresh could not be set up after all: the host assembler's Stokes operators
+                for Lv in self.levels:
+                    Lv.A = BSR(Lv.A.nbrows, Lv.A.nbcols, Lv.bs, Lv.A.rowptr, Lv.A.colidx,
+                               _assemble(Lv, self.nu, self.gamma, 0.0, None, True, full_div=self.sv))
+                self._values_on_device = False
+                self._push_operators()
         self.rtol, self.atol = self.params["ksp_rtol"], self.params["ksp_atol"]
         tol2, tol3 = (1e-9, 1e-8), (1e-8, 1e-8)                            # snes_rtol / snes_atol, solver.py:484-499
         self.snes_rtol = snes_rtol if snes_rtol is not None else (tol2 if dim == 2 else tol3)[0]
@@ -205,6 +220,18 @@ class HipNavierStokesSolver(object):
         self._dBT = hip.Csr(self.ctx, self.B_raw.T.tocsr())
         self._dp, self._dFp = self.ctx.vec(self.B_raw.shape[0]), self.ctx.vec(self.B_raw.shape[0])
         self._asm_ready = True
+
+    def _first_operators_on_device(self):
+        """The Stokes operators the hierarchy is created with (what build_hierarchy(Re=0) assembles on the host otherwise),
+        formed on the device; patches and coarse grid factored."""
+        mgl = self.hmg.mg.levels
+        for dl in mgl:
+            dl.assemble(self.nu, self.gamma, 0.0, None, True)
+        for L, dl in zip(self.levels, mgl):
+            if L.level > 0:
+                dl.factor_with_fallback()
+        mgl[0].coarse_factor_auto()
+        self.ctx.sync()
 
     def _device_states(self, u):
         """Current velocity on every level, on the device: the finest is the velocity part of the resident state (``u`` given:

@@ -165,7 +165,8 @@ class BSR(object):
         self.nbrows, self.nbcols, self.bs = int(nbrows), int(nbcols), int(bs)
         self.rowptr = np.ascontiguousarray(rowptr, dtype=np.int32)
         self.colidx = np.ascontiguousarray(colidx, dtype=np.int32)
-        self.vals = np.ascontiguousarray(vals, dtype=np.float64).reshape(-1, bs, bs)
+        # vals None: the sparsity alone (operator values formed on the device, build_hierarchy(operator_values=False))
+        self.vals = None if vals is None else np.ascontiguousarray(vals, dtype=np.float64).reshape(-1, bs, bs)
 
     @property
     def shape(self):
@@ -262,38 +263,41 @@ def build_pressure_coupling(L, zero_bc_columns=True, both=False):
     bI = el.reference_tensors()["bI"]                          # (nloc, d+1): cell average of d_i phi_a
     bdiv = np.einsum("cix,ai->cax", g, bI)                     # cell average of d_x phi_a
     nc, nloc = V.cell_nodes.shape
-    rows = np.repeat(np.arange(nc), nloc * d)
-    cols = (V.cell_nodes[:, :, None] * d + np.arange(d)[None, None, :]).reshape(nc, -1).ravel()
-    vals = (-vol[:, None, None] * bdiv).reshape(nc, -1).ravel()
-    B = sp.csr_matrix((vals, (rows, cols)), shape=(nc, V.num_dofs))
-    B.sort_indices()
+    # every row holds the nloc * d dofs of one cell: the CSR arrays directly (no COO pass, no duplicates)
+    cols = (V.cell_nodes[:, :, None] * d + np.arange(d, dtype=V.cell_nodes.dtype)[None, None, :]).reshape(nc, -1)
+    vals = (-vol[:, None, None] * bdiv).reshape(nc, -1)
+    itype = np.int32 if nc * nloc * d < 2 ** 31 else np.int64
 
-    def jacobian_block(M):     # the Jacobian's block; with all columns it is the divergence used in the nonlinear residual
-        keep = np.ones(V.num_dofs)
-        keep[V.bc_dofs] = 0.0
-        M = (M @ sp.diags(keep)).tocsr()
-        M.eliminate_zeros()
+    nonzero = vals != 0.0
+
+    def csr(keep):             # the entries with keep (None: all) and a non-zero value
+        nz = nonzero if keep is None else nonzero & keep[cols]
+        ptr = np.concatenate([[0], np.cumsum(nz.sum(axis=1))])
+        M = sp.csr_matrix((vals[nz], cols[nz].astype(itype), ptr.astype(itype)), shape=(nc, V.num_dofs))
         M.sort_indices()
         return M
+
+    def free_columns():        # the Jacobian's block; with all columns it is the divergence used in the nonlinear residual
+        keep = np.ones(V.num_dofs, dtype=bool)
+        keep[V.bc_dofs] = False
+        return keep
     if both:                   # (B with the Dirichlet columns zeroed, B with all columns, vol): one pass over the cells
-        Bz = jacobian_block(B)
-        B.eliminate_zeros()
-        return Bz, B, vol
-    if zero_bc_columns:
-        B = jacobian_block(B)
-    B.eliminate_zeros()
-    B.sort_indices()
-    return B, vol
+        return csr(free_columns()), csr(None), vol
+    return csr(free_columns() if zero_bc_columns else None), vol
 
 
-def build_hierarchy(problem, nref, k, Re, gamma=1e4, advect=True, patches=True, verbose=False, lazy=False):
+def build_hierarchy(problem, nref, k, Re, gamma=1e4, advect=True, patches=True, verbose=False, lazy=False,
+                    operator_values=True):
     """Levels 0..nref of the velocity block for ``problem`` at Reynolds number Re.
 
     nu = char_length * char_velocity / Re (alfi/solver.py:261-267); gamma default 1e4 (alfi/driver.py:30).
 
     lazy: rank-local generation (alfi_amd.lazy): meshes, numbering, graphs, patches and coarse-cell blocks as usual --
     what the mesh partitioner needs -- but operators and transfers as recipes that assemble the rows a rank asks for
-    (``alfi_amd.dist.DistMultigrid`` then never holds global values)."""
+    (``alfi_amd.dist.DistMultigrid`` then never holds global values).
+
+    operator_values False: the level operators as sparsity only (``L.A.vals`` None) -- for a caller that forms them on the
+    device (alfi_level_assemble; HipNavierStokesSolver does, every Newton step) and has no use for a host copy."""
     t0 = time.time()
     dim = problem.dim
     element = velocity_element(dim, k)
@@ -315,6 +319,8 @@ def build_hierarchy(problem, nref, k, Re, gamma=1e4, advect=True, patches=True, 
         if lazy:
             from .lazy import LazyOperator, LazyTransfer
             L.A = LazyOperator(V, rowptr, colidx, (g, vol), tens, nu, gamma, adv, wind)
+        elif not operator_values:
+            L.A = BSR(V.num_nodes, V.num_nodes, d, rowptr, colidx, None)
         else:
             # level operator in one pass over the cells
             A = _hostlib.assemble_bsr(V.cell_nodes, g, vol, tens, d, rowptr, colidx, nu=nu, gamma=gamma, adv=adv,

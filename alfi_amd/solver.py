@@ -230,7 +230,10 @@ class HipPatchPC(object):
             from .sv import macro_cell_groups
             self.level.set_patch_groups(macro_cell_groups(L.V, dofs))
             self.condensed = True
-        self.level.factor()
+        # (operator values not there yet -- formed on the device by the caller, who then factors: problem.build_hierarchy
+        # with operator_values=False)
+        if L.A.vals is not None:
+            self.level.factor()
         if self.partition_of_unity:
             self.level.set_partition_of_unity(True)
         self.wavefronts = self.level.set_multiplicative(self.iterset, self.symmetrise) if self.multiplicative else 0
@@ -275,6 +278,8 @@ class HipMG(object):
                 dl = hip.Level(ctx, L.A, L.bc_dofs)
                 if coarse_inv is not None:
                     dl.set_coarse_inverse(coarse_inv)
+                elif L.A.vals is None:      # values formed on the device later: remember the choice, factor then
+                    dl._coarse_choice = ("auto", getattr(getattr(L, "V", None), "node_coords", None))
                 else:
                     dl.coarse_factor_auto(getattr(getattr(L, "V", None), "node_coords", None))
                 dlevels.append(dl)

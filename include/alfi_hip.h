@@ -114,7 +114,9 @@ int alfi_ctx_set_comm(alfi_ctx* ctx, alfi_comm_fn fn, void* user, double* dred, 
 
 /* ---- level operator: PETSc MatMult on the BAIJ level matrix [3P], alfi/solver.py:512 ----------------------------- */
 /* Block-CSR, bs x bs row-major blocks (bs = 2 or 3), nbrows block rows; bc_dofs: Dirichlet dofs of the level
- * (their rows/columns of the operator are expected to be the identity, as firedrake.assemble(a, bcs) gives [3P]). */
+ * (their rows/columns of the operator are expected to be the identity, as firedrake.assemble(a, bcs) gives [3P]).
+ * bvals_host == NULL: the sparsity only; the values start as zeros and are formed on the device by alfi_level_set_assembly +
+ * alfi_level_assemble (the patch factors and the coarse inverse are then asked for when the first cycle runs). */
 int alfi_level_create(alfi_ctx* ctx, int64_t nbrows, int bs, const int32_t* browptr_host, const int32_t* bcolidx_host,
                       const double* bvals_host, const int32_t* bc_dofs_host, int64_t nbc, alfi_level** out);
 int alfi_level_destroy(alfi_level* lvl);
@@ -323,7 +325,8 @@ int alfi_transfer_set_injection(alfi_transfer* tr, const int32_t* fine_node_host
 int alfi_inject(alfi_transfer* tr, const double* dxf, double* dxc);
 
 /* ---- multigrid cycle: PETSc PCMG [3P], alfi/solver.py:359-379 ------------------------------------------------------ */
-/* levels[0] = coarsest (needs alfi_coarse_set_inverse), levels[l] l >= 1 need factored patches; transfers[l-1] links
+/* levels[0] = coarsest (needs a coarse inverse / factorisation), levels[l] l >= 1 need factored patches -- both by the time a
+ * cycle runs (alfi_mg_vcycle / _fcycle return ALFI_E_STATE otherwise), not at creation; transfers[l-1] links
  * level l-1 and l.  k = smoother iterations (solver.py:309-310), robust_restriction = the --restriction flag. */
 int alfi_mg_create(alfi_ctx* ctx, int nlevels, alfi_level** levels, alfi_transfer** transfers, int k,
                    int robust_restriction, alfi_mg** out);

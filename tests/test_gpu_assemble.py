@@ -183,3 +183,37 @@ def test_newton_with_supg_on_the_device_and_on_the_host_agree():
     assert all(c for _, _, c in out[True][2]) and out[True][2] == out[False][2]
     assert np.abs(out[True][0] - out[False][0]).max() <= 1e-8 * np.abs(out[False][0]).max()
     assert np.abs(out[True][1] - out[False][1]).max() <= 1e-7 * np.abs(out[False][1]).max()
+
+
+def test_hierarchy_without_host_operator_values():
+    """With the device-side refresh the generator delivers the SPARSITY of the level operators only
+    (build_hierarchy(operator_values=False), alfi_level_create with NULL values) and the first -- Stokes -- operators are formed on
+    the device: they equal the host assembler's to 1e-13; a hierarchy linked before its operators exist refuses to cycle."""
+    from alfi_amd import hip
+    from alfi_amd.nssolver import HipNavierStokesSolver, _assemble
+    s = HipNavierStokesSolver(ThreeDimLidDrivenCavityProblem(2), 2, 1, device_assembly=True)
+    assert s.device_assembly and all(L.A.vals is None for L in s.levels)
+    for L, dl in zip(s.levels, s.hmg.mg.levels):
+        ref = _assemble(L, s.nu, s.gamma, 0.0, None, True)
+        got = dl.get_values()
+        assert np.abs(got - ref).max() <= 1e-13 * np.abs(ref).max()
+    # the hierarchy is usable as created: one full cycle on a random right-hand side reduces the residual
+    n = s.levels[-1].n
+    b = np.random.default_rng(0).standard_normal(n)
+    b[s.levels[-1].bc_dofs] = 0.0
+    db, dx = s.ctx.vec(b), s.ctx.vec(n)
+    s.hmg.mg.fcycle(db, dx)
+    A = _assemble(s.levels[-1], s.nu, s.gamma, 0.0, None, True)
+    import scipy.sparse as sp
+    Af = sp.bsr_matrix((A, s.levels[-1].A.colidx, s.levels[-1].A.rowptr), shape=(n, n))
+    assert np.linalg.norm(b - Af @ dx.get()) < 0.5 * np.linalg.norm(b)
+    # linked, operators zero, nothing factored: a cycle is a state error, not a crash
+    from alfi_amd.problem import build_hierarchy
+    from alfi_amd.solver import HipMG, fieldsplit_0_mg, mg_levels_solver
+    lv, tr = build_hierarchy(ThreeDimLidDrivenCavityProblem(2), 1, 1, Re=0.0, operator_values=False)
+    hmg = HipMG(s.ctx, lv, tr, fieldsplit_0_mg(mg_levels_solver(3)))
+    m = lv[-1].n
+    with pytest.raises(hip.AlfiHipError, match="not factored"):
+        hmg.mg.vcycle(s.ctx.vec(m), s.ctx.vec(m))
+    hmg.mg.close()
+    s.close()
