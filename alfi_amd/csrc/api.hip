@@ -2093,6 +2093,7 @@ int alfi_transfer_create(alfi_ctx* ctx, alfi_level* coarse, alfi_level* fine, co
     if (rc == 0 && T->ld != m) rc = dev_alloc(ctx, &T->pm_tmp, nblk * T->ld);
     if (rc == 0) rc = dev_alloc(ctx, &T->pm_res, nblk * m);       // one step of iterative refinement per interior solve
     if (rc == 0) rc = dev_alloc(ctx, &T->pm_cor, nblk * m);
+    if (rc == 0) rc = dev_alloc(ctx, &T->AIIt, nblk * m * T->ld);
   } else if (rc == 0) {
     rc = dev_alloc(ctx, &T->binv, nblk * m * T->ld);
   }
@@ -2127,6 +2128,7 @@ int alfi_transfer_destroy(alfi_transfer* T) {
   dev_free(T->pm_tmp);
   dev_free(T->pm_res);
   dev_free(T->pm_cor);
+  dev_free(T->AIIt);
   dev_free(T->tI);
   dev_free(T->bI);
   dev_free(T->tmp_f);

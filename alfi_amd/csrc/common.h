@@ -300,6 +300,8 @@ constexpr int COND_SIGMA_ROWS = ALFI_COND_SIGMA_ROWS;
 
 // storage of one group's matrices in CondDev::mat: [X (m x m) | B (sc x m) | W (m x sc)], column-major each, the leading
 // dimensions rounded up to EVEN (a lane streams two rows of a column with one 16-byte load; the pad row is never stored)
+// (Measured and dropped, round 5: leading dimensions of > 8 rows rounded up to whole 128-byte lines and every group on a line
+// boundary -- no column shares a line with its neighbour, +3.8 % bytes: config 5 24.13 against 23.60-23.68 ms per cycle, same box.)
 __host__ __device__ inline int cond_ldim(int rows) { return (rows + 1) & ~1; }
 __host__ __device__ inline int cond_pairs(int rows) { return (rows + 1) / 2; }     // row pairs a lane each
 __host__ __device__ inline int64_t cond_group_doubles(int m, int sc) {
@@ -466,6 +468,8 @@ struct alfi_transfer {
   double* pm_tmp = nullptr;             // (nblk*ld) only for odd m: output of the patch kernel before compaction
   double* pm_res = nullptr;             // (nblk*m) residual b - A t of the refinement step (NULL: ALFI_TRANSFER_REFINE=0)
   double* pm_cor = nullptr;             // (nblk*m) its correction X r
+  double* AIIt = nullptr;               // (nblk, m, ld) nu K_II + gamma D_II, COLUMN-major per block (entry (i, j) at j * ld + i): what
+                                        // the refinement's residual reads -- one matrix instead of K_II and D_II, lanes along a column
   double *tI = nullptr, *bI = nullptr;  // compact interior vectors (nblk*m)
   double* tmp_f = nullptr;              // fine work vector
   int32_t* inj = nullptr;               // (coarse nodes) fine node coinciding with each coarse node

@@ -1285,10 +1285,25 @@ __global__ void block_build_kernel(int64_t nblk, int m, int ld, int64_t stride, 
   }
 }
 
+// A_II = nu K_II + gamma D_II, column-major with leading dimension ld (even), built once per alfi_transfer_update: the operator of
+// the refinement residual (block_residual_kernel below)
+__global__ void block_operator_t_kernel(int64_t nblk, int m, int ld, const double* __restrict__ K, const double* __restrict__ D,
+                                        double nu, double gamma, double* __restrict__ At) {
+  const int64_t total = nblk * m * ld;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t blk = e / ((int64_t)m * ld);
+    const int64_t in = e - blk * (int64_t)m * ld;
+    const int j = (int)(in / ld), i = (int)(in % ld);
+    At[e] = i < m ? nu * K[(blk * m + i) * m + j] + gamma * D[(blk * m + i) * m + j] : 0.0;
+  }
+}
+
 int launch_block_build_invert(alfi_transfer* tr) {
   alfi_ctx* ctx = tr->ctx;
-  if (tr->m > SMALL_PATCH_MAX) return launch_big_factor_transfer(tr);   // blocked MFMA inversion (kernels_bigpatch.hip)
   const int64_t total = tr->nblk * tr->m * tr->ld;
+  if (tr->patch_mode && tr->AIIt)   // the operator of the refinement step's residual
+    ALFI_LAUNCH_EW(block_operator_t_kernel, total, tr->nblk, tr->m, tr->ld, tr->KII, tr->DII, tr->nu, tr->gamma, tr->AIIt);
+  if (tr->m > SMALL_PATCH_MAX) return launch_big_factor_transfer(tr);   // blocked MFMA inversion (kernels_bigpatch.hip)
   const int64_t stride = tr->patch_mode ? tr->bstride : (int64_t)tr->m * tr->ld;
   ALFI_LAUNCH_EW(block_build_kernel, total, tr->nblk, tr->m, tr->ld, stride, tr->KII, tr->DII, tr->nu, tr->gamma,
                  tr->binv);
@@ -1325,27 +1340,44 @@ __global__ void compact_rows_kernel(double* __restrict__ out, const double* __re
     out[e] = in[(e / m) * ld + e % m];
 }
 
-// r = b - (nu K + gamma D) t per interior block (one workgroup per block, t in LDS, a wave per row).  One step of
-// iterative refinement around the explicit inverse: the reference solves these blocks by LU (patch_sub_pc_type lu,
-// transfer.py:100-113), and nu K + gamma D of a macro cell has condition number ~gamma / nu, which an explicit inverse
-// alone turns into a relative error of cond * eps in the transferred vector.
-__global__ __launch_bounds__(256) void block_residual_kernel(int m, const double* __restrict__ K, const double* __restrict__ D,
-                                                              double nu, double gamma, const int32_t* __restrict__ idx,
-                                                              const double* __restrict__ in, const double* __restrict__ t,
-                                                              double* __restrict__ r) {
+// One step of iterative refinement around the explicit inverse of an interior block: the reference solves these blocks by LU
+// (patch_sub_pc_type lu, transfer.py:100-113), and nu K + gamma D of a macro cell has condition number ~gamma / nu, which an
+// explicit inverse alone turns into a relative error of cond * eps in the transferred vector.
+//
+// r = b - A_II t per interior block (A_II column-major: block_operator_t_kernel): one workgroup per block, t in LDS, a lane per PAIR of rows (one 16-byte load per
+// column, the lanes of a wave along the column: whole lines), BR_U columns in flight.  (Until round 5: K_II and D_II read
+// row-major with a wave per row and a shuffle reduction per row -- 2.6 TB/s for twice the bytes; 63 % of config 5's PROLONG.)
+constexpr int BR_U = 8;
+__global__ __launch_bounds__(256) void block_residual_kernel(int m, int ld, const double* __restrict__ At,
+                                                              const int32_t* __restrict__ idx, const double* __restrict__ in,
+                                                              const double* __restrict__ t, double* __restrict__ r) {
   __shared__ double ts[PATCH_MAX];
   const int64_t blk = blockIdx.x;
   for (int i = threadIdx.x; i < m; i += 256) ts[i] = t[blk * m + i];
   __syncthreads();
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const double* Kb = K + blk * (int64_t)m * m;
-  const double* Db = D + blk * (int64_t)m * m;
-  for (int row = wave; row < m; row += 4) {
-    double acc = 0.0;
-    for (int j = lane; j < m; j += 64)
-      acc = __builtin_fma(nu * Kb[(int64_t)row * m + j] + gamma * Db[(int64_t)row * m + j], ts[j], acc);
-    acc = wave_sum(acc);
-    if (lane == 0) r[blk * m + row] = in[idx[blk * m + row]] - acc;
+  const double* A = At + blk * (int64_t)m * ld;
+  for (int p = threadIdx.x; 2 * p < m; p += 256) {
+    const double* col = A + 2 * p;
+    double a0 = 0.0, a1 = 0.0;
+    int j = 0;
+    for (; j + BR_U <= m; j += BR_U) {
+      vec_d2 a[BR_U];
+#pragma unroll
+      for (int u = 0; u < BR_U; ++u) a[u] = __builtin_nontemporal_load(reinterpret_cast<const vec_d2*>(col + (int64_t)(j + u) * ld));
+#pragma unroll
+      for (int u = 0; u < BR_U; ++u) {
+        a0 = __builtin_fma(a[u].x, ts[j + u], a0);
+        a1 = __builtin_fma(a[u].y, ts[j + u], a1);
+      }
+    }
+    for (; j < m; ++j) {
+      const vec_d2 a = __builtin_nontemporal_load(reinterpret_cast<const vec_d2*>(col + (int64_t)j * ld));
+      a0 = __builtin_fma(a.x, ts[j], a0);
+      a1 = __builtin_fma(a.y, ts[j], a1);
+    }
+    const int i0 = 2 * p;
+    r[blk * m + i0] = in[idx[blk * m + i0]] - a0;
+    if (i0 + 1 < m) r[blk * m + i0 + 1] = in[idx[blk * m + i0 + 1]] - a1;
   }
 }
 
@@ -1372,8 +1404,8 @@ int launch_block_gemv(alfi_transfer* tr, const double* in, double* out, bool gat
     const int32_t* idx = gather_in ? tr->blk_dofs : tr->pm_iota;
     ALFI_CHECK(pm_apply(tr, idx, in, out));
     if (tr->pm_res) {   // t += X (b - A t)
-      hipLaunchKernelGGL(block_residual_kernel, dim3((unsigned)tr->nblk), dim3(256), 0, ctx->stream, tr->m, tr->KII,
-                         tr->DII, tr->nu, tr->gamma, idx, in, out, tr->pm_res);
+      hipLaunchKernelGGL(block_residual_kernel, dim3((unsigned)tr->nblk), dim3(256), 0, ctx->stream, tr->m, tr->ld, tr->AIIt,
+                         idx, in, out, tr->pm_res);
       ALFI_HIP_CHECK(ctx, hipGetLastError());
       ALFI_CHECK(pm_apply(tr, tr->pm_iota, tr->pm_res, tr->pm_cor));
       ALFI_CHECK(launch_axpy(ctx, out, tr->pm_cor, 1.0, tr->nblk * tr->m));

@@ -312,8 +312,12 @@ def compute_ghosts(levels, transfers, splits, l, rank):
                     need.append(np.flatnonzero(_rows_with_cols_in(T.PT_plain, flo, fhi)))
     if not need:
         return np.zeros(0, dtype=np.int64)
-    g = np.unique(np.concatenate([np.asarray(x, dtype=np.int64) for x in need]))
-    return g[(g < lo) | (g >= hi)]
+    # a mark per node of the level instead of a sort of the tens of millions of column indices
+    mark = np.zeros(int(L.A.nbrows), dtype=bool)
+    for x in need:
+        mark[np.asarray(x)] = True
+    mark[lo:hi] = False
+    return np.flatnonzero(mark).astype(np.int64)
 
 
 def build_parts(levels, transfers, splits, rank, exchange_lists=None, force_distributed_above=None):
@@ -381,17 +385,25 @@ def localize_operator(A, part):
     """The rank's rows of the (global or lazy) level operator ``A`` in local numbering: owned rows complete, ghost rows
     restricted to local columns."""
     bs = A.bs
-    rows = A.select_rows(part.nodes)
-    own = BSR(part.nb_own, A.nbcols, bs, rows.rowptr[:part.nb_own + 1],
-              rows.colidx[:rows.rowptr[part.nb_own]], rows.vals[:rows.rowptr[part.nb_own]])
-    own = _map_cols(own, part, part.nb_loc)                                   # asserts completeness
-    gh_ptr = rows.rowptr[part.nb_own:].astype(np.int64) - rows.rowptr[part.nb_own]
-    gh = BSR(part.nb_ghost, A.nbcols, bs, gh_ptr, rows.colidx[rows.rowptr[part.nb_own]:],
-             rows.vals[rows.rowptr[part.nb_own]:])
-    gh = _map_cols(gh, part, part.nb_loc, allow_drop=True)
-    return BSR(part.nb_loc, part.nb_loc, bs,
-               np.concatenate([own.rowptr.astype(np.int64), own.rowptr[-1] + gh.rowptr[1:].astype(np.int64)]),
-               np.concatenate([own.colidx, gh.colidx]), np.concatenate([own.vals, gh.vals]))
+    rows = A.select_rows(part.nodes)                 # fresh arrays (assembled or cut for this call): edited in place below
+    nnz_own = int(rows.rowptr[part.nb_own])
+    lc = part.g2l(rows.colidx)
+    if (lc[:nnz_own] < 0).any():
+        raise AssertionError("a needed column is not in the local node set")
+    keep = lc[nnz_own:] >= 0
+    if keep.all():
+        return BSR(part.nb_loc, part.nb_loc, bs, rows.rowptr, lc, rows.vals)
+    # the owned rows are a prefix and stay where they are (2 GB of values per rank at config 4 over 4 ranks: no copy of them);
+    # the ghost rows' kept blocks are packed behind them in the same arrays
+    kept = np.flatnonzero(keep)
+    nk = kept.shape[0]
+    vals = rows.vals
+    vals[nnz_own:nnz_own + nk] = vals[nnz_own:][kept]
+    lc[nnz_own:nnz_own + nk] = lc[nnz_own:][kept]
+    csum = np.concatenate([[0], np.cumsum(keep)])
+    gh_ptr = rows.rowptr[part.nb_own:].astype(np.int64) - nnz_own
+    rowptr = np.concatenate([rows.rowptr[:part.nb_own].astype(np.int64), nnz_own + csum[gh_ptr]])
+    return BSR(part.nb_loc, part.nb_loc, bs, rowptr, lc[:nnz_own + nk], vals[:nnz_own + nk])
 
 
 def assembly_cells(V, part):
@@ -465,7 +477,7 @@ def localize_transfer(T, Lf, pc, pf):
     rows = (blocks[:, None] * mb + np.arange(mb)).ravel()
     out.D_I = _map_cols(T.D_I.select_rows(rows), pf, pf.nb_loc)
     # rows of D_I^T for the owned fine nodes only: s = r - gamma D_I^T t is formed on owned rows
-    out.D_IT = out.D_I.transpose().select_rows(np.arange(pf.nb_own))
+    out.D_IT = out.D_I.transpose().row_range(0, pf.nb_own)
     P = _map_cols(T.P.select_rows(pf.own_nodes), pc, pc.nb_loc)
     out.P = P
     out.PT = P.transpose()                                  # (coarse local) x (fine owned): partial sums, reverse-added

@@ -163,10 +163,11 @@ class LazyProlongation(object):
         Ploc[np.abs(Ploc) < 1e-14] = 0.0
         vals = Ploc[mf.child_index[cell], loc, :]
         cols = ccn[mf.parent_cell[cell]]
-        rows = np.repeat(np.arange(len(nodes)), ccn.shape[1])
-        nz = vals.ravel() != 0.0
-        P = sp.csr_matrix((vals.ravel()[nz], (rows[nz], cols.ravel()[nz])), shape=(len(nodes), ncoarse))
-        P.sum_duplicates()
+        # one row per fine node, its entries on distinct coarse nodes: the CSR arrays directly (fespace.nodal_prolongation)
+        nz = vals != 0.0
+        indptr = np.concatenate([[0], np.cumsum(nz.sum(axis=1))])
+        itype = np.int32 if max(indptr[-1], ncoarse) < 2 ** 31 else np.int64
+        P = sp.csr_matrix((vals[nz], cols[nz].astype(itype), indptr.astype(itype)), shape=(len(nodes), ncoarse))
         P.sort_indices()
         return P
 
@@ -236,6 +237,8 @@ class LazyProlongation(object):
     def cols_of_row_range(self, lo, hi):
         if hi <= lo:
             return np.zeros(0, dtype=np.int64)
+        if not self.bubble:      # the scalar rows carry the sparsity: no need to expand their d x d blocks for it
+            return self._nodal_rows(np.arange(lo, hi)).indices
         return self.select_rows(np.arange(lo, hi)).colidx
 
     def transpose(self):

@@ -193,6 +193,11 @@ class BSR(object):
         idx = np.repeat(self.rowptr[rows].astype(np.int64) - ptr[:-1], cnt) + np.arange(ptr[-1])
         return BSR(len(rows), self.nbcols, self.bs, ptr, self.colidx[idx], self.vals[idx])
 
+    def row_range(self, lo, hi):
+        """Block rows lo .. hi-1 as a BSR over the same arrays (views, no copy)."""
+        k0, k1 = int(self.rowptr[lo]), int(self.rowptr[hi])
+        return BSR(hi - lo, self.nbcols, self.bs, self.rowptr[lo:hi + 1] - self.rowptr[lo], self.colidx[k0:k1], self.vals[k0:k1])
+
     def transpose(self):
         rp, ci, v = _hostlib.bsr_transpose(self.nbrows, self.nbcols, self.bs, self.rowptr, self.colidx, self.vals)
         return BSR(self.nbcols, self.nbrows, self.bs, rp, ci, v)
