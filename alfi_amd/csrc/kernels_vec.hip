@@ -1540,7 +1540,7 @@ int launch_xmy(alfi_ctx* ctx, double* w, const double* b, int64_t n) {
   return 0;
 }
 
-// ---- pieces of the outer solve on partitioned levels (alfi_saddle_*, api.hip) ------------------------------------------
+// ---- pieces of the outer solve on partitioned levels (alfi_saddle_*, api_saddle.hip) ------------------------------------------
 // *out = sum(x) in one fixed order (the rank's part of a global sum; all-reduced by the caller).  n == 0: *out = 0.
 int launch_sum_to(alfi_ctx* ctx, const double* x, int64_t n, double* out) {
   hipLaunchKernelGGL(sum_partials_kernel, dim3(RED_BLOCKS), dim3(256), 0, ctx->stream, x, ctx->red_partial, n);

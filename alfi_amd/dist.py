@@ -642,7 +642,7 @@ class DistMultigrid(object):
 
     def __init__(self, levels, transfers, k, robust_restriction=False, group=None, device=None, min_dofs=400000,
                  coarse_inverse=None, verbose=False, force_distributed=False, overlap=None, overlap_min_dofs=None,
-                 transport=None, on_stage=None):
+                 transport=None, on_stage=None, overlap_rule=True):
         """transport: "rccl" -- the library's own RCCL communicator serves every exchange point of a cycle (no Python
         between the kernels; the default whenever the process group's backend is nccl) -- or "callback": the library
         calls back into this module, which exchanges through torch.distributed (the test transport: gloo, ranks sharing
@@ -668,7 +668,7 @@ class DistMultigrid(object):
         self._in_cycle = False
         self._red_views = {}
         # which levels overlap: ALFI_DIST_OVERLAP_MIN_DOFS (smallest per-rank share that overlaps; tests, measurements) or,
-        # without it, the rule above from the halo sizes of the partition (ALFI_DIST_OVERLAP_RULE=0: never)
+        # without it, the rule above from the halo sizes of the partition (overlap_rule=False: never)
         use_rule = False
         if overlap_min_dofs is None:
             import os
@@ -676,7 +676,7 @@ class DistMultigrid(object):
                 overlap_min_dofs = int(os.environ["ALFI_DIST_OVERLAP_MIN_DOFS"])
             else:
                 overlap_min_dofs = 1 << 62
-                use_rule = overlap and os.environ.get("ALFI_DIST_OVERLAP_RULE", "1") != "0"
+                use_rule = overlap and overlap_rule
         if device is None:
             device = torch.device("cuda", torch.cuda.current_device())
         self.device = device
@@ -1052,8 +1052,10 @@ def _dist_ns_solver_class():
         ``u`` / ``p`` gather it, collectively, when somebody asks); the barycentric hierarchy of the Scott-Vogelius pair and
         the host-assembly path keep a replicated host state."""
 
-        def __init__(self, *args, min_dofs=400000, group=None, **kwargs):
-            self._min_dofs, self._group = min_dofs, group
+        def __init__(self, *args, min_dofs=400000, group=None, device_state=True, **kwargs):
+            """device_state False: the Newton state replicated on the hosts and gathered after every linear solve (the loop of
+            round 4; kept for comparisons)."""
+            self._min_dofs, self._group, self._want_device_state = min_dofs, group, bool(device_state)
             super().__init__(*args, **kwargs)
 
         def _device_state_resident(self):
@@ -1135,8 +1137,7 @@ def _dist_ns_solver_class():
                 self._dp, self._dFp = self.ctx.vec(max(len(rows), 1)), self.ctx.vec(max(len(rows), 1))
                 self._dwc = self.ctx.vec(dmg.n_loc)
                 self._exch = None
-                import os
-                if not self.sv and os.environ.get("ALFI_DIST_DEVICE_STATE", "1") != "0":
+                if not self.sv and self._want_device_state:
                     # the distributed device-resident state: (owned velocity | owned pressure) per rank, and the exchange that
                     # feeds every level's refresh from it
                     assert np.array_equal(self._res_rows, self.saddle.cells)

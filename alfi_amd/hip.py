@@ -462,18 +462,16 @@ class Level(object):
             self.ctx.check(self.ctx.lib.alfi_coarse_factor_sparse(self.h, _ptr(xy), int(xy.shape[1]), int(leaf_nodes)))
         return self.coarse_residual()
 
-    def coarse_factor_auto(self, node_coords=None, mode=None):
+    def coarse_factor_auto(self, node_coords=None, mode=None, geometric=False):
         """The coarse factorisation the front ends use: ``mode`` "dense", "sparse" or "auto" (sparse from
         ``coarse_sparse_min()`` dofs on).  The choice is remembered, so a later call without arguments (new operator values,
-        every Newton step) repeats it.  The sparse path bisects by graph level sets unless ALFI_COARSE_COORDS=1 asks for
-        the geometric bisection with ``node_coords`` (measured on ldc3d coarse grids: level sets give 13-15 % less fill)."""
-        import os
+        every Newton step) repeats it.  The sparse path bisects by graph level sets; ``geometric``: by ``node_coords`` instead
+        (measured on ldc3d coarse grids: level sets give 13-15 % less fill, hence the default)."""
         if mode is not None or node_coords is not None or not hasattr(self, "_coarse_choice"):
-            self._coarse_choice = (mode or "auto", node_coords)
+            self._coarse_choice = (mode or "auto", node_coords if geometric else None)
         mode, node_coords = self._coarse_choice
         if mode == "sparse" or (mode == "auto" and self.n >= coarse_sparse_min()):
-            use_xy = node_coords is not None and os.environ.get("ALFI_COARSE_COORDS", "0") == "1"
-            rc = self.coarse_factor_sparse(node_coords if use_xy else None)
+            rc = self.coarse_factor_sparse(node_coords)
         else:
             rc = self.coarse_factor()
         res = self.coarse_residual()

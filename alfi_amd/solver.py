@@ -279,7 +279,7 @@ class HipMG(object):
                 if coarse_inv is not None:
                     dl.set_coarse_inverse(coarse_inv)
                 elif L.A.vals is None:      # values formed on the device later: remember the choice, factor then
-                    dl._coarse_choice = ("auto", getattr(getattr(L, "V", None), "node_coords", None))
+                    dl._coarse_choice = ("auto", None)
                 else:
                     dl.coarse_factor_auto(getattr(getattr(L, "V", None), "node_coords", None))
                 dlevels.append(dl)

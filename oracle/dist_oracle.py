@@ -6,7 +6,7 @@ distributed with a vertex-star overlap (alfi/solver.py:604-605), patches exist f
 before every operator or patch apply, reverse-add halo after the patch apply, all-reduced dot products.  It runs on the
 rank-local data produced by alfi_amd.dist.localize (the product's own partitioner) and exchanges through
 alfi_amd.dist.Comm on CPU tensors (gloo), so a world-size-2 CPU run checks partition + halo plans + exchange order
-against the serial oracle.  The HIP library performs the same sequence of exchanges (csrc/api.hip).
+against the serial oracle.  The HIP library performs the same sequence of exchanges (csrc/api_level.hip, api_smoother.hip, api_cycles.hip).
 
 Only tests/ import this module.
 """
