@@ -133,6 +133,11 @@ SIGNATURES = {
 COMM_ID_BYTES = 128      # ALFI_COMM_ID_BYTES
 
 EVENTS = ["PATCH_APPLY", "PATCH_SCATTER", "PATCH_FACTOR", "MATMULT", "BLAS1", "PROLONG", "RESTRICT", "COARSE", "COMM"]
+# the PETSc log events the reference's report prints for the same work (alfi/driver.py:80; COMM: the PetscSF scatters around
+# every patch apply and MatMult, alfi/solver.py:604-605)
+PETSC_EVENT_NAMES = {"PATCH_APPLY": "PCPATCHApply", "PATCH_SCATTER": "PCPATCHScatter", "PATCH_FACTOR": "PCPatchComputeOp",
+                     "MATMULT": "MatMult", "BLAS1": "KSPGMRESOrthog", "PROLONG": "SchoeberlProlong", "RESTRICT": "SchoeberlRestrict",
+                     "COARSE": "MatSolve", "COMM": "SFBcastOpBegin"}
 
 _lib = None
 

@@ -642,7 +642,7 @@ class DistMultigrid(object):
 
     def __init__(self, levels, transfers, k, robust_restriction=False, group=None, device=None, min_dofs=400000,
                  coarse_inverse=None, verbose=False, force_distributed=False, overlap=None, overlap_min_dofs=None,
-                 transport=None, on_stage=None, overlap_rule=True):
+                 transport=None, on_stage=None, use_overlap_rule=True):
         """transport: "rccl" -- the library's own RCCL communicator serves every exchange point of a cycle (no Python
         between the kernels; the default whenever the process group's backend is nccl) -- or "callback": the library
         calls back into this module, which exchanges through torch.distributed (the test transport: gloo, ranks sharing
@@ -668,7 +668,7 @@ class DistMultigrid(object):
         self._in_cycle = False
         self._red_views = {}
         # which levels overlap: ALFI_DIST_OVERLAP_MIN_DOFS (smallest per-rank share that overlaps; tests, measurements) or,
-        # without it, the rule above from the halo sizes of the partition (overlap_rule=False: never)
+        # without it, the rule above from the halo sizes of the partition (use_overlap_rule=False: never)
         use_rule = False
         if overlap_min_dofs is None:
             import os
@@ -676,7 +676,7 @@ class DistMultigrid(object):
                 overlap_min_dofs = int(os.environ["ALFI_DIST_OVERLAP_MIN_DOFS"])
             else:
                 overlap_min_dofs = 1 << 62
-                use_rule = overlap and overlap_rule
+                use_rule = overlap and use_overlap_rule
         if device is None:
             device = torch.device("cuda", torch.cuda.current_device())
         self.device = device

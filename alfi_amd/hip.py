@@ -120,13 +120,14 @@ class Context(object):
     def prof_reset(self):
         self.check(self.lib.alfi_prof_reset(self.h))
 
-    def prof_get(self, level_id=-1):
-        """{event name: (total device ms, launches)} since the last reset, optionally for one level only."""
+    def prof_get(self, level_id=-1, petsc_names=False):
+        """{event name: (total device ms, launches)} since the last reset, optionally for one level only; ``petsc_names``: keyed
+        by the PETSc log events of the reference's report (alfi/driver.py:80) instead of the library's class names."""
         out = {}
         for i, name in enumerate(_lib.EVENTS):
             ms, cnt = ctypes.c_double(), ctypes.c_int64()
             self.check(self.lib.alfi_prof_get_level(self.h, i, int(level_id), ctypes.byref(ms), ctypes.byref(cnt)))
-            out[name] = (ms.value, cnt.value)
+            out[_lib.PETSC_EVENT_NAMES[name] if petsc_names else name] = (ms.value, cnt.value)
         return out
 
 

@@ -522,9 +522,9 @@ def run_solver(solver, res):
 
 
 # PETSc event names the reference's report prints (driver.py:80) -> the library's profiling classes
-_EVENT_NAMES = [("PCPATCHApply", "PATCH_APPLY"), ("PCPATCHScatter", "PATCH_SCATTER"), ("PCPatchComputeOp", "PATCH_FACTOR"),
-                ("MatMult", "MATMULT"), ("KSPGMRESOrthog", "BLAS1"), ("SchoeberlProlong", "PROLONG"),
-                ("SchoeberlRestrict", "RESTRICT"), ("MatSolve", "COARSE")]
+from ._lib import PETSC_EVENT_NAMES as _PETSC
+_EVENT_NAMES = [(_PETSC[k], k) for k in ("PATCH_APPLY", "PATCH_SCATTER", "PATCH_FACTOR", "MATMULT", "BLAS1", "PROLONG", "RESTRICT",
+                                         "COARSE")]
 
 
 def performance_info(solver, out=print):

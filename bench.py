@@ -620,6 +620,7 @@ def main():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
     torch.cuda.set_device(0)
     from alfi_amd import hip
+    from alfi_amd import _lib as _alfi_lib
 
     t0 = time.time()
     lv, tr, k = build_problem(args.config, args.verbose)
@@ -834,6 +835,7 @@ def main():
         "spmv_finest": {"achieved_GBps": spmv_gbs, "frac": spmv_gbs / HBM_PEAK_GBS,
                         "avg_launch_us": 1e3 * t_spmv_ms / max(n_spmv, 1)},
         "events_ms": {kname: round(v[0], 3) for kname, v in prof_all.items()},
+        "events_petsc_names": dict(_alfi_lib.PETSC_EVENT_NAMES),
         "events_note": "device time per event class of ONE extra, fully instrumented V-cycle after the timed region; on "
                        "launch-bound configurations (cfg2, cfg3) the event records lengthen the intervals they bracket and "
                        "the classes sum to more than the cycle: use the kernel trace (profiles/r02_kernel_trace_*.txt) there",
