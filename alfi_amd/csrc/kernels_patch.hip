@@ -591,83 +591,87 @@ __device__ __forceinline__ double mult_wg_rowsum(const double* __restrict__ q, i
   return racc;
 }
 
-// r_p = x_p - (A y)_p, y_p += inv(A_p) r_p by the whole workgroup; kk, cc: the blocks of round 0 (mult_wg_blocks).
-// PUBLISH (persistent schedule): the new y entries leave with agent-scope write-through stores, so that a wave on another CU /
-// XCD that acquires afterwards reads them (cdna_hip_programming.md Guideline 16, R1).
-template <int BS, bool NT, bool PUBLISH>
-__device__ __forceinline__ void mult_wg_sweep(int64_t p, MultLds& S, int32_t (&kk)[MULT_MAXU], int32_t (&cc)[MULT_MAXU],
-                                              const int64_t* __restrict__ patch_ptr, const int32_t* __restrict__ patch_dofs,
-                                              const int64_t* __restrict__ inv_ptr, const double* __restrict__ inv,
-                                              const int32_t* __restrict__ colidx, const double* __restrict__ vals, int flat,
-                                              const double* __restrict__ x, double* __restrict__ y, int64_t* stamps = nullptr,
-                                              int32_t t = 0) {
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int64_t off = patch_ptr[p];
-  const int n = (int)(patch_ptr[p + 1] - off);
+// r_p = x_p - (A y)_p, y_p += inv(A_p) r_p by the whole workgroup, in three pieces (the persistent schedule puts the loads of the
+// NEXT item's tables between them); kk, cc: the blocks of round 0 (mult_wg_blocks).
+// (1) residual into S.rs -- the caller's barrier follows
+template <int BS, bool NT>
+__device__ __forceinline__ void mult_wg_residual(int64_t p, MultLds& S, int32_t (&kk)[MULT_MAXU], int32_t (&cc)[MULT_MAXU],
+                                                 const int64_t* __restrict__ patch_ptr, const int32_t* __restrict__ colidx,
+                                                 const double* __restrict__ vals, int flat, const double* __restrict__ x,
+                                                 const double* __restrict__ y) {
+  const int n = (int)(patch_ptr[p + 1] - patch_ptr[p]);
   const int nn = n / BS;
   const int total = S.pre[nn];
-  {
-    // the row entry of this thread (thread e < n: row e / BS, component e % BS) and its right-hand side
-    const int e = threadIdx.x, row = e / BS, comp = e % BS;
-    const bool mine = e < n;
-    const double xe = mine ? x[(int64_t)S.nd[mine ? row : 0] * BS + comp] : 0.0;
-    const int fa = mine ? S.pre[row] : 0, fz = mine ? S.pre[row + 1] : 0;
-    double racc = 0.0;
-    constexpr int GB = MULT_NTHR * MULT_G;      // blocks per group
-    for (int base = 0; base < total; base += MULT_NTHR * MULT_MAXU) {
-      if (base > 0) {
-        __syncthreads();            // the previous round's last products have been added
-        mult_wg_blocks(S, nn, base, colidx, kk, cc);
-      }
-      // the groups of the round, software-pipelined: the loads of group g + 1 are in flight while the rows add the products of
-      // group g (two product buffers: a group's buffer is rewritten two barriers after its sums)
-      double a_[2][MULT_G][BS * BS], yv_[2][MULT_G][BS];
-      mult_wg_load<BS, NT>(0, kk, cc, vals, flat, y, a_[0], yv_[0]);
+  // the row entry of this thread (thread e < n: row e / BS, component e % BS) and its right-hand side
+  const int e = threadIdx.x, row = e / BS, comp = e % BS;
+  const bool mine = e < n;
+  const double xe = mine ? x[(int64_t)S.nd[mine ? row : 0] * BS + comp] : 0.0;
+  const int fa = mine ? S.pre[row] : 0, fz = mine ? S.pre[row + 1] : 0;
+  double racc = 0.0;
+  constexpr int GB = MULT_NTHR * MULT_G;      // blocks per group
+  for (int base = 0; base < total; base += MULT_NTHR * MULT_MAXU) {
+    if (base > 0) {
+      __syncthreads();            // the previous round's last products have been added
+      mult_wg_blocks(S, nn, base, colidx, kk, cc);
+    }
+    // the groups of the round, software-pipelined: the loads of group g + 1 are in flight while the rows add the products of
+    // group g (two product buffers: a group's buffer is rewritten two barriers after its sums)
+    double a_[2][MULT_G][BS * BS], yv_[2][MULT_G][BS];
+    mult_wg_load<BS, NT>(0, kk, cc, vals, flat, y, a_[0], yv_[0]);
 #pragma unroll
-      for (int gi = 0; gi < MULT_NG; ++gi) {
-        if (base + gi * GB >= total) break;                                  // uniform
-        mult_wg_store<BS>(gi, S, kk, a_[gi & 1], yv_[gi & 1]);
-        __syncthreads();
-        if (gi + 1 < MULT_NG && base + (gi + 1) * GB < total)
-          mult_wg_load<BS, NT>(gi + 1, kk, cc, vals, flat, y, a_[(gi + 1) & 1], yv_[(gi + 1) & 1]);
-        racc = mult_wg_rowsum<BS>(S.prod[gi & 1] + comp, fa, fz, base + gi * GB, racc);
-      }
+    for (int gi = 0; gi < MULT_NG; ++gi) {
+      if (base + gi * GB >= total) break;                                  // uniform
+      mult_wg_store<BS>(gi, S, kk, a_[gi & 1], yv_[gi & 1]);
+      __syncthreads();
+      if (gi + 1 < MULT_NG && base + (gi + 1) * GB < total)
+        mult_wg_load<BS, NT>(gi + 1, kk, cc, vals, flat, y, a_[(gi + 1) & 1], yv_[(gi + 1) & 1]);
+      racc = mult_wg_rowsum<BS>(S.prod[gi & 1] + comp, fa, fz, base + gi * GB, racc);
     }
-    if (mine) S.rs[e] = xe - racc;
   }
-  __syncthreads();
-  ALFI_MULT_STAMP(3);
-  {
-    const int ld = (n + 1) & ~1;
-    const double* T = inv + inv_ptr[p];
-    double* out = S.part[wave];
-    int row0 = 0;
-    // pieces of >= 64 rows: column shares
-    const int ca = (int)(((int64_t)wave * n) / MULT_W), cn = (int)(((int64_t)(wave + 1) * n) / MULT_W) - ca;
-    for (; row0 + 128 <= ld; row0 += 128)
-      apply_piece<64, NT, MULT_U>(T + (int64_t)row0 * n + (int64_t)ca * 128, cn, S.rs + ca, lane, out + row0);
-    const int rem = ld - row0;
-    if (rem & 64) {
-      apply_piece<32, NT, MULT_U>(T + (int64_t)row0 * n + (int64_t)ca * 64, cn, S.rs + ca, lane, out + row0);
-      row0 += 64;
-    }
-    // smaller pieces: a wave each, all columns
-    int piece = 0;
+  if (mine) S.rs[e] = xe - racc;
+}
+// (2) the waves' partial products inv(A_p) r_p into S.part -- the caller's barrier follows
+template <bool NT>
+__device__ __forceinline__ void mult_wg_apply(int64_t p, MultLds& S, const int64_t* __restrict__ patch_ptr,
+                                              const int64_t* __restrict__ inv_ptr, const double* __restrict__ inv) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int n = (int)(patch_ptr[p + 1] - patch_ptr[p]);
+  const int ld = (n + 1) & ~1;
+  const double* T = inv + inv_ptr[p];
+  double* out = S.part[wave];
+  int row0 = 0;
+  // pieces of >= 64 rows: column shares
+  const int ca = (int)(((int64_t)wave * n) / MULT_W), cn = (int)(((int64_t)(wave + 1) * n) / MULT_W) - ca;
+  for (; row0 + 128 <= ld; row0 += 128)
+    apply_piece<64, NT, MULT_U>(T + (int64_t)row0 * n + (int64_t)ca * 128, cn, S.rs + ca, lane, out + row0);
+  const int rem = ld - row0;
+  if (rem & 64) {
+    apply_piece<32, NT, MULT_U>(T + (int64_t)row0 * n + (int64_t)ca * 64, cn, S.rs + ca, lane, out + row0);
+    row0 += 64;
+  }
+  // smaller pieces: a wave each, all columns
+  int piece = 0;
 #define ALFI_PIECE(R)                                                                    \
   if (rem & R) {                                                                         \
     if (piece % MULT_W == wave) apply_piece<R / 2, NT, MULT_U>(T + (int64_t)row0 * n, n, S.rs, lane, out + row0); \
     row0 += R;                                                                           \
     ++piece;                                                                             \
   }
-    ALFI_PIECE(32)
-    ALFI_PIECE(16)
-    ALFI_PIECE(8)
-    ALFI_PIECE(4)
-    ALFI_PIECE(2)
+  ALFI_PIECE(32)
+  ALFI_PIECE(16)
+  ALFI_PIECE(8)
+  ALFI_PIECE(4)
+  ALFI_PIECE(2)
 #undef ALFI_PIECE
-  }
-  __syncthreads();
-  ALFI_MULT_STAMP(4);
+}
+// (3) y_p += the sum of the partial products, in the order of the waves.  PUBLISH (persistent schedule): the new y entries leave
+// with agent-scope write-through stores, so that a wave on another CU / XCD that acquires afterwards reads them
+// (cdna_hip_programming.md Guideline 16, R1).
+template <bool PUBLISH>
+__device__ __forceinline__ void mult_wg_update(int64_t p, const MultLds& S, const int64_t* __restrict__ patch_ptr,
+                                               const int32_t* __restrict__ patch_dofs, double* __restrict__ y) {
+  const int64_t off = patch_ptr[p];
+  const int n = (int)(patch_ptr[p + 1] - off);
   for (int i = threadIdx.x; i < n; i += MULT_NTHR) {
     const int64_t dof = patch_dofs[off + i];
     double d = S.part[0][i];
@@ -698,7 +702,11 @@ __global__ __launch_bounds__(MULT_NTHR) ALFI_MULT_OCC_ATTR void patch_mult_kerne
   __syncthreads();
   int32_t kk[MULT_MAXU], cc[MULT_MAXU];
   mult_wg_blocks(S, (int)(patch_ptr[p + 1] - patch_ptr[p]) / BS, 0, colidx, kk, cc);
-  mult_wg_sweep<BS, NT, false>(p, S, kk, cc, patch_ptr, patch_dofs, inv_ptr, inv, colidx, vals, flat, x, y);
+  mult_wg_residual<BS, NT>(p, S, kk, cc, patch_ptr, colidx, vals, flat, x, y);
+  __syncthreads();
+  mult_wg_apply<NT>(p, S, patch_ptr, inv_ptr, inv);
+  __syncthreads();
+  mult_wg_update<false>(p, S, patch_ptr, patch_dofs, y);
 }
 
 // The whole sweep (both directions of a symmetrised one) as ONE launch of a resident grid: workgroups draw the items of the
@@ -713,6 +721,14 @@ __global__ __launch_bounds__(MULT_NTHR) ALFI_MULT_OCC_ATTR void patch_mult_kerne
 // workgroup meets at a barrier, then the successors are decremented; a consumer polls its own counter relaxed (one lane), then
 // every wave does ONE agent-scope acquire, then plain loads.
 // err[0]: set when a wait ran into its bound (a broken schedule would otherwise spin until the watchdog).
+// Round 5: the tables of the NEXT item are fetched in the shadow of the current one.  A resident workgroup used to spend 7.4 us
+// of its 34 us per item on the chain ticket -> item -> row table -> block columns before it even looked at its predecessor count
+// (profiles/r04_mult_stamps_cfg4.txt), and the sweep is bound by slots x time per item.  Now the ticket of the next item is drawn
+// when the wait of the current one ends, its patch number is read after the residual, its row table during the apply, and the rows
+// go to LDS behind the update (the residual is the only reader of the row tables) -- each of the dependent round trips behind one
+// phase of the current item; only the block columns (one round trip) stay in front of the next wait.  Drawing a ticket early
+// keeps the schedule safe: a workgroup still works its tickets in order, every drawn ticket belongs to a resident workgroup, and
+// the predecessors of ticket t carry smaller tickets.
 template <int BS, bool NT>
 __global__ __launch_bounds__(MULT_NTHR) ALFI_MULT_OCC_ATTR void patch_mult_persistent_kernel(
     int32_t nitems, const int32_t* __restrict__ items, int32_t* __restrict__ pred, const int32_t* __restrict__ succ_ptr,
@@ -721,18 +737,18 @@ __global__ __launch_bounds__(MULT_NTHR) ALFI_MULT_OCC_ATTR void patch_mult_persi
     const double* __restrict__ inv, const int32_t* __restrict__ rowtab, const int32_t* __restrict__ colidx,
     const double* __restrict__ vals, int flat, const double* __restrict__ x, double* __restrict__ y ALFI_MULT_STAMP_PARAM) {
   __shared__ MultLds S;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  // the first item of this workgroup: tables in the open
+  if (threadIdx.x == 0) S.ticket = __hip_atomic_fetch_add(head, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();
+  int32_t t = S.ticket;
+  if (t >= nitems) return;
+  int64_t p = items[t];
+  mult_wg_rows<BS>(p, S, patch_ptr, rowtab);
+  __syncthreads();
+  int32_t kk[MULT_MAXU], cc[MULT_MAXU];
+  mult_wg_blocks(S, (int)(patch_ptr[p + 1] - patch_ptr[p]) / BS, 0, colidx, kk, cc);
   for (;;) {
-    if (threadIdx.x == 0) S.ticket = __hip_atomic_fetch_add(head, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __syncthreads();
-    const int32_t t = S.ticket;
-    if (t >= nitems) break;
-    ALFI_MULT_STAMP(0);
-    const int64_t p = items[t];
-    // nothing of the tables depends on y
-    mult_wg_rows<BS>(p, S, patch_ptr, rowtab);
-    __syncthreads();
-    int32_t kk[MULT_MAXU], cc[MULT_MAXU];
-    mult_wg_blocks(S, (int)(patch_ptr[p + 1] - patch_ptr[p]) / BS, 0, colidx, kk, cc);
     ALFI_MULT_STAMP(1);
     // wait for the predecessors: ONE lane polls ONE word, relaxed
     if (threadIdx.x == 0) {
@@ -757,9 +773,46 @@ __global__ __launch_bounds__(MULT_NTHR) ALFI_MULT_OCC_ATTR void patch_mult_persi
     }
     ALFI_MULT_STAMP(2);
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");          // this CU's L1 forgets what other CUs have rewritten
-    mult_wg_sweep<BS, NT, true>(p, S, kk, cc, patch_ptr, patch_dofs, inv_ptr, inv, colidx, vals, flat, x, y ALFI_MULT_STAMP_ARG);
+    // (next item, 1) its ticket: the atomic returns behind the residual
+    int32_t tk = 0;
+    if (threadIdx.x == 0) tk = __hip_atomic_fetch_add(head, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    mult_wg_residual<BS, NT>(p, S, kk, cc, patch_ptr, colidx, vals, flat, x, y);
+    if (threadIdx.x == 0) S.ticket = tk;
+    __syncthreads();                                            // S.rs complete; the ticket is there
+    ALFI_MULT_STAMP(3);
+    const int32_t tn = S.ticket;
+    const bool more = tn < nitems;
+    // (next item, 2) its patch and, in wave 0, its row table: requested now, consumed behind the apply
+    const int64_t pn = more ? items[tn] : 0;
+    mult_wg_apply<NT>(p, S, patch_ptr, inv_ptr, inv);
+    int32_t r0 = 0, r1 = 0, r2 = 0, nnx = 0;
+    if (more && wave == 0) {
+      const int32_t* rt = rowtab + (pn * MAX_PNODES + lane) * 3;
+      r0 = rt[0];
+      r1 = rt[1];
+      r2 = rt[2];          // entries beyond the patch's nodes are zero
+      nnx = (int)(patch_ptr[pn + 1] - patch_ptr[pn]) / BS;
+    }
+    __syncthreads();                                            // the partial products are complete
+    ALFI_MULT_STAMP(4);
+    mult_wg_update<true>(p, S, patch_ptr, patch_dofs, y);
+    // (next item, 3) its rows into the tables: their last reader was this item's residual
+    if (more && wave == 0) {
+      if (lane < nnx) {
+        S.k0[lane] = r0;
+        S.nd[lane] = r2;
+      }
+      int incl = lane < nnx ? r1 : 0;   // inclusive wave scan
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        const int v = __shfl_up(incl, d);
+        if (lane >= d) incl += v;
+      }
+      if (lane < nnx) S.pre[lane + 1] = incl;
+      if (lane == 0) S.pre[0] = 0;
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // this wave's y stores have left
-    __syncthreads();                                            // ... and those of the other waves
+    __syncthreads();                                            // ... and those of the other waves; the next tables are there
     ALFI_MULT_STAMP(5);
     // release, at the level of the ISA: the y stores of this item are WRITE-THROUGH (sc1: they bypass this XCD's L2 as far as
     // other agents' reads are concerned), drained by the s_waitcnt above, and the barrier orders the other waves' stores before
@@ -769,6 +822,16 @@ __global__ __launch_bounds__(MULT_NTHR) ALFI_MULT_OCC_ATTR void patch_mult_persi
     for (int32_t e = succ_ptr[t] + threadIdx.x; e < succ_ptr[t + 1]; e += MULT_NTHR)
       __hip_atomic_fetch_sub(pred + succ[e], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     ALFI_MULT_STAMP(6);
+    if (!more) break;
+    // (next item, 4) the partial-product rows its waves will not touch, and its blocks of round 0
+    t = tn;
+    p = pn;
+    ALFI_MULT_STAMP(0);
+    {
+      const int n = (int)(patch_ptr[p + 1] - patch_ptr[p]);
+      for (int i = lane; i < ((n + 1) & ~1); i += 64) S.part[wave][i] = 0.0;
+      mult_wg_blocks(S, n / BS, 0, colidx, kk, cc);
+    }
   }
 }
 
