@@ -392,18 +392,19 @@ def localize_operator(A, part):
         raise AssertionError("a needed column is not in the local node set")
     keep = lc[nnz_own:] >= 0
     if keep.all():
-        return BSR(part.nb_loc, part.nb_loc, bs, rows.rowptr, lc, rows.vals)
+        return BSR(part.nb_loc, part.nb_loc, bs, rows.rowptr, lc, rows.vals)      # (vals None: the sparsity only, values on the device)
     # the owned rows are a prefix and stay where they are (2 GB of values per rank at config 4 over 4 ranks: no copy of them);
     # the ghost rows' kept blocks are packed behind them in the same arrays
     kept = np.flatnonzero(keep)
     nk = kept.shape[0]
     vals = rows.vals
-    vals[nnz_own:nnz_own + nk] = vals[nnz_own:][kept]
+    if vals is not None:
+        vals[nnz_own:nnz_own + nk] = vals[nnz_own:][kept]
     lc[nnz_own:nnz_own + nk] = lc[nnz_own:][kept]
     csum = np.concatenate([[0], np.cumsum(keep)])
     gh_ptr = rows.rowptr[part.nb_own:].astype(np.int64) - nnz_own
     rowptr = np.concatenate([rows.rowptr[:part.nb_own].astype(np.int64), nnz_own + csum[gh_ptr]])
-    return BSR(part.nb_loc, part.nb_loc, bs, rowptr, lc[:nnz_own + nk], vals[:nnz_own + nk])
+    return BSR(part.nb_loc, part.nb_loc, bs, rowptr, lc[:nnz_own + nk], None if vals is None else vals[:nnz_own + nk])
 
 
 def assembly_cells(V, part):
@@ -754,14 +755,15 @@ class DistMultigrid(object):
                     dl.set_patches(LL.patch_ptr, LL.patch_dofs)
                     if hip.condense_patches(LL):
                         dl.set_patch_groups(LL.patch_groups)
-                    dl.factor_with_fallback()
+                    if LL.A.vals is not None:          # (None: the operators are formed on the device first, the caller factors)
+                        dl.factor_with_fallback()
                     decided = rule[LL.level] if use_rule else overlap_decision(p.splits, p.bs, p.distributed, overlap,
                                                                                overlap_min_dofs)
                     if decided:
                         # interior rows / patches are worked on while the forward halo is in flight (overlap_rule above)
                         self.overlap_levels.append(LL.level)
                         dl.set_overlap(p.nb_int, LL.npatch_int)
-                elif p.nb_own > 0:
+                elif p.nb_own > 0 and LL.A.vals is not None:
                     self._coarse(dl, levels[0].A, coarse_inverse)
                 self.levels.append(dl)
             self.mg = hip.Multigrid.__new__(hip.Multigrid)
@@ -1228,6 +1230,17 @@ def _dist_ns_solver_class():
             for asm, w in zip(self._asm, self._winds(u)[self.dmg.lmin:]):
                 if asm is not None:
                     asm[1].set(np.ascontiguousarray(w[asm[0]]).ravel())
+
+        def _first_operators_on_device(self):
+            """Every rank forms the Stokes operators of ITS rows on its device (the hierarchy was generated without operator
+            values); patches and coarse grid factored."""
+            with self._on_stream():
+                for asm, dl in zip(self._asm, self.dmg.levels):
+                    if asm is not None:
+                        dl.assemble(self.nu, self.gamma, 0.0, None, True)
+                self.dmg.sync()
+            self.dmg.refactor(self.levels)
+            self.dmg.sync()
 
         def _rediscretise_device(self, u, adv):
             import time

@@ -40,9 +40,12 @@ class LazyOperator(object):
 
     is_lazy = True
 
-    def __init__(self, V, rowptr, colidx, geometry, tensors, nu, gamma, adv, wind, full_div=False, with_bc=True):
+    def __init__(self, V, rowptr, colidx, geometry, tensors, nu, gamma, adv, wind, full_div=False, with_bc=True, values=True):
         """full_div: the Scott-Vogelius grad-div term gamma (div u, div v) (solver.py:616) instead of the cell-averaged one.
-        with_bc=False: the raw form, Dirichlet rows / columns as assembled (the parts K, D of the device-side refresh)."""
+        with_bc=False: the raw form, Dirichlet rows / columns as assembled (the parts K, D of the device-side refresh).
+        values=False: ``select_rows`` delivers the sparsity of the rows only (``vals`` None): the caller forms the values on the
+        device (build_hierarchy(operator_values=False))."""
+        self.values = bool(values)
         self.full_div = bool(full_div)
         self.with_bc = bool(with_bc)
         self.V = V
@@ -68,6 +71,8 @@ class LazyOperator(object):
         V, d = self.V, self.bs
         ptr, cols = _take_rows(self.rowptr, self.colidx, rows)
         ptr32 = ptr.astype(np.int32)
+        if not self.values:
+            return BSR(len(rows), self.nbcols, d, ptr32, cols, None)
         vals = _hostlib.assemble_bsr(V.cell_nodes, self.g, self.vol, self.tens, d, ptr32, cols, nu=self.nu,
                                      gamma=0.0 if self.full_div else self.gamma,
                                      gamma_full=self.gamma if self.full_div else 0.0, adv=self.adv,

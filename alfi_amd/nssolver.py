@@ -77,8 +77,7 @@ class HipNavierStokesSolver(object):
         else:
             # with the device-side refresh nobody reads a host copy of the operators: the generator then delivers the sparsity
             # only and the first (Stokes) operator is formed on the device as well (no host assembly, no 8 GB upload at config 4)
-            self._values_on_device = (self.device_assembly and self._device_assembly_possible()
-                                      and not self._lazy_generation())
+            self._values_on_device = self.device_assembly and self._device_assembly_possible()
             self.levels, self.transfers = build_hierarchy(problem, nref, k, Re=0.0, gamma=gamma, lazy=self._lazy_generation(),
                                                           operator_values=not self._values_on_device)
         if self.sv:      # patch = macro with the problem's relaxation direction (solver.py:339-342), sparse-LU patch options

@@ -191,7 +191,7 @@ class BSR(object):
         cnt = (self.rowptr[rows + 1] - self.rowptr[rows]).astype(np.int64)
         ptr = np.concatenate([[0], np.cumsum(cnt)])
         idx = np.repeat(self.rowptr[rows].astype(np.int64) - ptr[:-1], cnt) + np.arange(ptr[-1])
-        return BSR(len(rows), self.nbcols, self.bs, ptr, self.colidx[idx], self.vals[idx])
+        return BSR(len(rows), self.nbcols, self.bs, ptr, self.colidx[idx], None if self.vals is None else self.vals[idx])
 
     def row_range(self, lo, hi):
         """Block rows lo .. hi-1 as a BSR over the same arrays (views, no copy)."""
@@ -323,7 +323,7 @@ def build_hierarchy(problem, nref, k, Re, gamma=1e4, advect=True, patches=True, 
         wind = problem.driver(V.node_coords)
         if lazy:
             from .lazy import LazyOperator, LazyTransfer
-            L.A = LazyOperator(V, rowptr, colidx, (g, vol), tens, nu, gamma, adv, wind)
+            L.A = LazyOperator(V, rowptr, colidx, (g, vol), tens, nu, gamma, adv, wind, values=operator_values)
         elif not operator_values:
             L.A = BSR(V.num_nodes, V.num_nodes, d, rowptr, colidx, None)
         else:

@@ -193,6 +193,24 @@ def test_bsr_helpers():
     sub = B.select_rows(rows).to_scipy().toarray()
     full = B.to_scipy().toarray().reshape(12, 2, -1)
     assert np.array_equal(sub, full[rows].reshape(6, -1))
+    # a range of block rows as views of the same arrays
+    rr = B.row_range(3, 9)
+    assert np.array_equal(rr.to_scipy().toarray(), full[3:9].reshape(12, -1))
+    assert np.shares_memory(rr.vals, B.vals) and np.shares_memory(rr.colidx, B.colidx)
+
+
+def test_sparsity_only_hierarchy_and_event_names():
+    """build_hierarchy(operator_values=False): the same integers, no operator values (they are formed on the device,
+    tests/test_gpu_assemble.py); the profile classes carry the PETSc event names of the reference's report (alfi/driver.py:80)."""
+    from alfi_amd import _lib
+    full, _ = build_hierarchy(ThreeDimLidDrivenCavityProblem(2), 1, 1, Re=0.0)
+    bare, _ = build_hierarchy(ThreeDimLidDrivenCavityProblem(2), 1, 1, Re=0.0, operator_values=False)
+    for a, b in zip(full, bare):
+        assert b.A.vals is None and a.A.vals is not None
+        assert np.array_equal(a.A.rowptr, b.A.rowptr) and np.array_equal(a.A.colidx, b.A.colidx) and a.A.nnzb == b.A.nnzb
+    assert set(_lib.PETSC_EVENT_NAMES) == set(_lib.EVENTS)
+    for name in ("PCPATCHApply", "PCPATCHScatter", "PCPatchComputeOp", "MatMult", "SchoeberlProlong", "SchoeberlRestrict", "MatSolve"):
+        assert name in _lib.PETSC_EVENT_NAMES.values()      # names of driver.py:80
 
 
 @pytest.mark.parametrize("mk,k", [(lambda: TwoDimLidDrivenCavityProblem(3), 2),
