@@ -782,6 +782,8 @@ def main():
         changed = None if not want else sorted(
             f for f, h in want.items()
             if not os.path.exists(os.path.join(csrc, f)) or hashlib.sha256(open(os.path.join(csrc, f), "rb").read()).hexdigest() != h)
+        if want:       # ... and no kernel source has appeared since
+            changed += sorted(f for f in os.listdir(csrc) if f.endswith((".hip", ".h")) and f not in want)
         if want and not changed:
             traffic = pmc.get("hbm_bytes_per_launch")
             traffic_source["kernel_sources"] = "unchanged since the collection"
