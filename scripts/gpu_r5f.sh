@@ -72,7 +72,8 @@ if [ "$PART" = configs ]; then
     python bench.py --config $C --steps 20 --warmup 5 > $O/r05_bench_$C.json 2> $O/bench_$C.err
   done
   python bench.py --config cfg5 --steps 10 --warmup 3 > $O/r05_bench_cfg5.json 2> $O/bench_cfg5.err
-  for C in cfg2 cfg3 cfg5 cfg6; do head -c 300 $O/r05_bench_$C.json; echo; done
+  python bench.py --config cfg5L --no-cpu-baseline --steps 10 --warmup 3 > $O/r05_bench_cfg5L.json 2> $O/bench_cfg5L.err
+  for C in cfg2 cfg3 cfg5 cfg5L cfg6; do head -c 300 $O/r05_bench_$C.json; echo; done
 fi
 if [ "$PART" = suite ]; then
   timeout 2400 python -m pytest tests -q -m gpu --durations=25 > $O/r05_pytest_gpu.txt 2>&1
@@ -90,5 +91,10 @@ if [ "$PART" = newton ]; then
   python scripts/mult_time.py cfg4 > $O/r05_mult_cfg4.txt 2>&1; tail -n 2 $O/r05_mult_cfg4.txt
   python scripts/mult_time.py cfg5 > $O/r05_mult_cfg5_macro_stars.txt 2>&1; tail -n 2 $O/r05_mult_cfg5_macro_stars.txt
   ALFI_MULT_PERSISTENT=0 python scripts/mult_time.py cfg5 > $O/r05_mult_cfg5_macro_stars_per_wavefront.txt 2>&1; tail -n 2 $O/r05_mult_cfg5_macro_stars_per_wavefront.txt
+fi
+if [ "$PART" = setup ]; then
+  python scripts/generation_profile.py cfg4 > $O/r05_generation_profile_cfg4.txt 2>&1; grep "^total" $O/r05_generation_profile_cfg4.txt
+  python scripts/setup_profile.py cfg4 --lines 60 > $O/r05_setup_profile_cfg4.txt 2>&1; grep "set-up" $O/r05_setup_profile_cfg4.txt
+  python scripts/setup_profile.py cfg4 --supg 0.05 --lines 30 > $O/r05_setup_profile_cfg4_supg.txt 2>&1; grep "set-up" $O/r05_setup_profile_cfg4_supg.txt
 fi
 ls $O | tail -40
