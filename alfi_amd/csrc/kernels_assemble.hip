@@ -62,7 +62,8 @@ __global__ __launch_bounds__(64) void element_cell_kernel(int64_t c0, int64_t c1
                                                            const double* __restrict__ grad, const double* __restrict__ vol,
                                                            const double* __restrict__ etab, const double* __restrict__ bItab,
                                                            const double* __restrict__ U, const double* __restrict__ X, double nu,
-                                                           double gamma, double gfull, double adv, double* __restrict__ out) {
+                                                           double gamma, double gfull, double adv, double* __restrict__ out,
+                                                           int elay) {
   constexpr int NV = D + 1, BB = D * D, TS = 2 * NV * NLOC + NV * NV;
   __shared__ double xs[MODE == 1 ? NLOC * D * 64 : 1];
   const int lane = threadIdx.x;
@@ -180,7 +181,10 @@ __global__ __launch_bounds__(64) void element_cell_kernel(int64_t c0, int64_t c1
           }
       }
       if (MODE == 0) {
-        if (valid) store_block<BB>(out + ((slot * NLOC + a) * NLOC + b) * BB, e);
+        // elay: the blocks (a, b) of the wave's 64 cells side by side (whole lines per store group) instead of a cell's blocks
+        if (valid)
+          store_block<BB>(out + (elay ? (((int64_t)blockIdx.x * (NLOC * NLOC) + a * NLOC + b) * 64 + lane) * BB
+                                      : ((slot * NLOC + a) * NLOC + b) * BB), e);
       } else {
 #pragma unroll
         for (int dd = 0; dd < D; ++dd) {
@@ -225,7 +229,7 @@ __global__ __launch_bounds__(256) void element_gather_kernel(int64_t nnzb, int n
                                                               const int64_t* __restrict__ cptr, const int32_t* __restrict__ ccell,
                                                               const uint16_t* __restrict__ cba, const double* __restrict__ E,
                                                               const uint8_t* __restrict__ code, int accumulate, int apply_bc,
-                                                              double* __restrict__ vals) {
+                                                              double* __restrict__ vals, int elay) {
   constexpr int BB = D * D;
   const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (k >= nnzb) return;
@@ -241,7 +245,8 @@ __global__ __launch_bounds__(256) void element_gather_kernel(int64_t nnzb, int n
     any = true;
     const unsigned ba = cba[q], b = ba / (unsigned)nloc, a = ba - b * (unsigned)nloc;
     double e[BB];
-    load_block<BB>(E + (((cell - c0) * nloc + a) * nloc + b) * BB, e);
+    const int64_t cs = cell - c0;
+    load_block<BB>(E + (elay ? (((cs >> 6) * (nloc * nloc) + a * nloc + b) * 64 + (cs & 63)) * BB : ((cs * nloc + a) * nloc + b) * BB), e);
 #pragma unroll
     for (int t = 0; t < BB; ++t) acc[t] += e[t];
   }
@@ -764,7 +769,13 @@ int launch_operator_refresh(alfi_level* L, double nu, double gamma, double adv, 
   const int64_t per_cell = (int64_t)ndof * ndof * 8;
   int64_t batch = std::max<int64_t>(1, ctx->asm_scratch_limit / per_cell);
   if (batch > S.ncell) batch = S.ncell;
-  ALFI_CHECK(ensure_scratch(ctx, (size_t)(batch * per_cell)));
+  // element blocks of a wave's 64 cells interleaved by (a, b) -- unless the SUPG kernel, which writes a cell's matrix as one piece,
+  // adds into the same scratch
+#ifndef ALFI_ELAY
+#define ALFI_ELAY 1
+#endif
+  const int elay = (ALFI_ELAY && !with_supg) ? 1 : 0;
+  ALFI_CHECK(ensure_scratch(ctx, (size_t)(((batch + 63) / 64 * 64) * per_cell)));
   double* E = (double*)ctx->asm_scratch;
   const double gcell = S.full_div ? 0.0 : gamma, gfull = S.full_div ? gamma : 0.0;
   for (int64_t c0 = 0; c0 < S.ncell; c0 += batch) {
@@ -773,7 +784,7 @@ int launch_operator_refresh(alfi_level* L, double nu, double gamma, double adv, 
       dim3 grid((unsigned)((c1 - c0 + 63) / 64)), block(64);
 #define ALFI_EL0(DV, NL)                                                                                                          \
   hipLaunchKernelGGL((element_cell_kernel<DV, NL, 0>), grid, block, 0, ctx->stream, c0, c1, S.cell_nodes, S.grad, S.vol, S.etab, \
-                     S.bItab, d_state, (const double*)nullptr, nu, gcell, gfull, adv, E)
+                     S.bItab, d_state, (const double*)nullptr, nu, gcell, gfull, adv, E, elay)
       ALFI_ELEMENT_DISPATCH(d, nloc, ALFI_EL0);
 #undef ALFI_EL0
       ALFI_HIP_CHECK(ctx, hipGetLastError());
@@ -797,9 +808,9 @@ int launch_operator_refresh(alfi_level* L, double nu, double gamma, double adv, 
     dim3 g2((unsigned)((nnzb + 255) / 256)), b2(256);
     const int acc = (accumulate || c0 > 0) ? 1 : 0, bc = (apply_bc && c1 == S.ncell) ? 1 : 0;
     if (d == 2)
-      hipLaunchKernelGGL(element_gather_kernel<2>, g2, b2, 0, ctx->stream, nnzb, nloc, c0, c1, S.cptr, S.ccell, S.cba, E, S.bc_code, acc, bc, out_vals);
+      hipLaunchKernelGGL(element_gather_kernel<2>, g2, b2, 0, ctx->stream, nnzb, nloc, c0, c1, S.cptr, S.ccell, S.cba, E, S.bc_code, acc, bc, out_vals, elay);
     else
-      hipLaunchKernelGGL(element_gather_kernel<3>, g2, b2, 0, ctx->stream, nnzb, nloc, c0, c1, S.cptr, S.ccell, S.cba, E, S.bc_code, acc, bc, out_vals);
+      hipLaunchKernelGGL(element_gather_kernel<3>, g2, b2, 0, ctx->stream, nnzb, nloc, c0, c1, S.cptr, S.ccell, S.cba, E, S.bc_code, acc, bc, out_vals, elay);
     ALFI_HIP_CHECK(ctx, hipGetLastError());
   }
   return 0;
@@ -830,7 +841,7 @@ int launch_element_mult(alfi_level* L, double nu, double gamma, double adv, cons
   dim3 grid((unsigned)((S.ncell + 63) / 64)), block(64);
 #define ALFI_EL1(DV, NL)                                                                                                         \
   hipLaunchKernelGGL((element_cell_kernel<DV, NL, 1>), grid, block, 0, ctx->stream, (int64_t)0, S.ncell, S.cell_nodes, S.grad,  \
-                     S.vol, S.etab, S.bItab, d_state, dx, nu, gcell, gfull, adv, Fe)
+                     S.vol, S.etab, S.bItab, d_state, dx, nu, gcell, gfull, adv, Fe, 0)
   ALFI_ELEMENT_DISPATCH(d, nloc, ALFI_EL1);
 #undef ALFI_EL1
   ALFI_HIP_CHECK(ctx, hipGetLastError());
