@@ -8,13 +8,18 @@ mkdir -p $O
 STAMP=$(date -u +%Y-%m-%dT%H:%MZ)
 PART=${PART:-refresh}
 if [ "$PART" = refresh ]; then
-  # the operator refresh / residual kernels of a Newton step at config-4 size: device times, kernel stats, HBM traffic
-  timeout 900 python scripts/refresh_time.py cfg4 --supg 0.05 > $O/r05_refresh_time_cfg4.txt 2> $O/refresh.err
-  cat $O/r05_refresh_time_cfg4.txt
+  # the operator refresh / residual kernels of a Newton step at config-4 size: device times, kernel stats, HBM traffic.  Two
+  # passes: without SUPG (the element blocks in the interleaved layout) and with it (cell-contiguous layout, shared with the SUPG kernel)
+  timeout 900 python scripts/refresh_time.py cfg4 > $O/r05_refresh_time_cfg4.txt 2> $O/refresh.err
+  timeout 900 python scripts/refresh_time.py cfg4 --supg 0.05 >> $O/r05_refresh_time_cfg4.txt 2>> $O/refresh.err
+  grep -v amdgpu $O/r05_refresh_time_cfg4.txt
   cd /tmp
   timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_refresh -- python3 $GRAFT_REPO_ROOT/scripts/refresh_time.py cfg4 --supg 0.05 --reps 2 > $O/prof_refresh.out 2> $O/prof_refresh.err
-  timeout 900 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_refresh_fetch -- python3 $GRAFT_REPO_ROOT/scripts/refresh_time.py cfg4 --supg 0.05 --reps 1 > $O/pmc_refresh_fetch.out 2> $O/pmc_refresh_fetch.err
-  timeout 900 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_refresh_write -- python3 $GRAFT_REPO_ROOT/scripts/refresh_time.py cfg4 --supg 0.05 --reps 1 > $O/pmc_refresh_write.out 2> $O/pmc_refresh_write.err
+  for V in plain supg; do
+    if [ $V = supg ]; then A="--supg 0.05"; else A=""; fi
+    timeout 900 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_refresh_fetch_$V -- python3 $GRAFT_REPO_ROOT/scripts/refresh_time.py cfg4 $A --reps 1 > $O/pmc_refresh_fetch.out 2> $O/pmc_refresh_fetch.err
+    timeout 900 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_refresh_write_$V -- python3 $GRAFT_REPO_ROOT/scripts/refresh_time.py cfg4 $A --reps 1 > $O/pmc_refresh_write.out 2> $O/pmc_refresh_write.err
+  done
   cd $GRAFT_REPO_ROOT
   find $O/prof_refresh -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $O/r05_refresh_cfg4_kernel_stats.csv
   python - $O/prof_refresh <<'PY' > $O/r05_refresh_cfg4_by_level.txt
@@ -24,14 +29,19 @@ t["dur_us"] = (t["End_Timestamp"] - t["Start_Timestamp"]) / 1e3
 t["name"] = t["Kernel_Name"].str.replace("(anonymous namespace)::", "", regex=False).str.replace(r"\(.*", "", regex=True).str.replace("void ", "")
 c = t[t["name"].str.contains("element_cell|element_gather|supg_matrix|supg_residual|cell_vector_gather|bc_code")]
 print("config 4, operator refresh / residual kernels by grid size (the largest grid of each kernel = the finest level), durations in us")
+print("(scripts/refresh_time.py cfg4 --supg 0.05: the launches of the plain refresh -- interleaved element blocks -- and of the stabilised one mix in the element / gather rows)")
 print(c.groupby(["name", "Grid_Size_X", "VGPR_Count"])["dur_us"].agg(["count", "mean", "min", "max"]).round(1).to_string())
 PY
   cat $O/r05_refresh_cfg4_by_level.txt
-  for K in "void (anonymous namespace)::element_cell_kernel<3, 14, 0>" "void (anonymous namespace)::element_gather_kernel<3>" "void (anonymous namespace)::supg_matrix_kernel<3, 14>" "void (anonymous namespace)::element_cell_kernel<3, 14, 1>" "void (anonymous namespace)::supg_residual_cell_kernel<3, 14>"; do
+  for K in "void (anonymous namespace)::element_cell_kernel<3, 14, 0>" "void (anonymous namespace)::element_gather_kernel<3>" "void (anonymous namespace)::element_cell_kernel<3, 14, 1>"; do
     N=$(echo "$K" | sed 's/.*:://; s/[<>, ]/_/g; s/__*/_/g; s/_$//')
-    python scripts/pmc_summary.py $O/pmc_refresh_fetch $O/pmc_refresh_write "$K" $O/r05_pmc_${N}_cfg4.json "r05 ($STAMP) $K on config 4's finest level (largest grid), scripts/refresh_time.py cfg4 --supg 0.05" 0 max
+    python scripts/pmc_summary.py $O/pmc_refresh_fetch_plain $O/pmc_refresh_write_plain "$K" $O/r05_pmc_${N}_cfg4.json "r05 ($STAMP) $K on config 4's finest level (largest grid), scripts/refresh_time.py cfg4 (no SUPG: interleaved element blocks)" 0 max
   done
-  rm -rf $O/prof_refresh $O/pmc_refresh_fetch $O/pmc_refresh_write
+  for K in "void (anonymous namespace)::supg_matrix_kernel<3, 14>" "void (anonymous namespace)::supg_residual_cell_kernel<3, 14>"; do
+    N=$(echo "$K" | sed 's/.*:://; s/[<>, ]/_/g; s/__*/_/g; s/_$//')
+    python scripts/pmc_summary.py $O/pmc_refresh_fetch_supg $O/pmc_refresh_write_supg "$K" $O/r05_pmc_${N}_cfg4.json "r05 ($STAMP) $K on config 4's finest level (largest grid), scripts/refresh_time.py cfg4 --supg 0.05 (cell-contiguous element blocks)" 0 max
+  done
+  rm -rf $O/prof_refresh $O/pmc_refresh_fetch_* $O/pmc_refresh_write_*
   ls $O
 fi
 if [ "$PART" = headline ]; then
