@@ -19,6 +19,13 @@
 // 1. gather A_p = A[dofs_p, dofs_p] from the BSR operator into row-major dense storage (ld_p columns per row)
 // ---------------------------------------------------------------------------------------------------------------------
 constexpr int MAX_NP = 160;
+// same-wave LDS hand-off: a wave that writes an LDS array and reads it through other lanes needs no workgroup barrier (the LDS
+// serves a wave's instructions in order), only the compiler must keep the order
+#define ALFI_WAVE_LDS_ORDER_GATHER()                           \
+  do {                                                         \
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");    \
+    __builtin_amdgcn_wave_barrier();                           \
+  } while (0)
 
 template <int BS>
 __global__ __launch_bounds__(256) void patch_gather_dense_kernel(const int32_t* __restrict__ rowptr,
@@ -38,32 +45,29 @@ __global__ __launch_bounds__(256) void patch_gather_dense_kernel(const int32_t* 
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   for (int i = threadIdx.x; i < n; i += 256) dofs_s[i] = patch_dofs[off + i];
   __syncthreads();
-  for (int r0 = 0; r0 < n; r0 += 4) {
-    const int r = r0 + wave;
-    const bool active = r < n;
-    if (active)
-      for (int c = lane; c < ld; c += 64) rowbuf[wave][c] = 0.0;
-    __syncthreads();
-    if (active) {
-      const int gr = dofs_s[r];
-      const int brow = gr / BS, rr = gr % BS;
-      const int32_t lo = rowptr[brow], hi = rowptr[brow + 1];
-      const int nent = (hi - lo) * BS;
-      for (int e = lane; e < nent; e += 64) {
-        const int blk = e / BS, cc = e % BS;
-        const int gcol = (colidx[lo + blk] & 0x7fffffff) * BS + cc;  // sign bit = row-start mark (flat layout)
-        // binary search gcol in dofs_s[0..n)
-        int a = 0, b = n;
-        while (a < b) {
-          const int mid = (a + b) >> 1;
-          if (dofs_s[mid] < gcol) a = mid + 1; else b = mid;
-        }
-        if (a < n && dofs_s[a] == gcol) rowbuf[wave][a] = vals[bsr_val_index(flat, lo + blk, rr * BS + cc, BS * BS)];
+  // every wave takes rows of its own through its own row buffer: no workgroup barrier inside the loop (the LDS serves a wave's
+  // accesses in order; until round 5 the four waves met at two barriers per four rows, 76 per patch of 153 dofs)
+  for (int r = wave; r < n; r += 4) {
+    for (int c = lane; c < ld; c += 64) rowbuf[wave][c] = 0.0;
+    ALFI_WAVE_LDS_ORDER_GATHER();
+    const int gr = dofs_s[r];
+    const int brow = gr / BS, rr = gr % BS;
+    const int32_t lo = rowptr[brow], hi = rowptr[brow + 1];
+    const int nent = (hi - lo) * BS;
+    for (int e = lane; e < nent; e += 64) {
+      const int blk = e / BS, cc = e % BS;
+      const int gcol = (colidx[lo + blk] & 0x7fffffff) * BS + cc;  // sign bit = row-start mark (flat layout)
+      // binary search gcol in dofs_s[0..n)
+      int a = 0, b = n;
+      while (a < b) {
+        const int mid = (a + b) >> 1;
+        if (dofs_s[mid] < gcol) a = mid + 1; else b = mid;
       }
+      if (a < n && dofs_s[a] == gcol) rowbuf[wave][a] = vals[bsr_val_index(flat, lo + blk, rr * BS + cc, BS * BS)];
     }
-    __syncthreads();
-    if (active)
-      for (int c = lane; c < ld; c += 64) S[(int64_t)r * ld + c] = rowbuf[wave][c];
+    ALFI_WAVE_LDS_ORDER_GATHER();
+    for (int c = lane; c < ld; c += 64) S[(int64_t)r * ld + c] = rowbuf[wave][c];
+    ALFI_WAVE_LDS_ORDER_GATHER();        // the copy out has read the buffer before the next row clears it
   }
 }
 
