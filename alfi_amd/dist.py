@@ -596,6 +596,36 @@ class Comm(object):
             self.dist.all_to_all_single(recv, send, rc, sc, group=self.group)
 
 
+class SoloComm(object):
+    """ONE rank of a ``world``-rank job alone in its process (``DistMultigrid(solo=(rank, world))``): the partition, the
+    localisation and every kernel launch are those of that rank, the exchange points do nothing (ghost values stay as they are,
+    reductions keep the local value).  The numbers such a run produces are meaningless; the DEVICE TIME of its kernels is that of
+    the rank's share -- a measurement of the per-rank compute of an N-GPU run on a box with one GPU (scripts/solo_rank_time.py)."""
+
+    backend = "solo"
+    dist = None
+    group = None
+
+    def __init__(self, rank, world):
+        self.rank, self.world = int(rank), int(world)
+
+    def all_gather_object(self, obj):
+        return [obj] * self.world
+
+    def allreduce(self, t):
+        pass
+
+    def exchange_begin(self, send, recv, send_counts, recv_counts):
+        return None
+
+    @staticmethod
+    def exchange_end(work):
+        pass
+
+    def exchange(self, send, recv, send_counts, recv_counts):
+        pass
+
+
 class HaloBuffers(object):
     """Per level: the torch-owned buffers the library packs into / unpacks from, and the exchange split sizes."""
 
@@ -643,7 +673,7 @@ class DistMultigrid(object):
 
     def __init__(self, levels, transfers, k, robust_restriction=False, group=None, device=None, min_dofs=400000,
                  coarse_inverse=None, verbose=False, force_distributed=False, overlap=None, overlap_min_dofs=None,
-                 transport=None, on_stage=None, use_overlap_rule=True):
+                 transport=None, on_stage=None, use_overlap_rule=True, solo=None):
         """transport: "rccl" -- the library's own RCCL communicator serves every exchange point of a cycle (no Python
         between the kernels; the default whenever the process group's backend is nccl) -- or "callback": the library
         calls back into this module, which exchanges through torch.distributed (the test transport: gloo, ranks sharing
@@ -655,8 +685,11 @@ class DistMultigrid(object):
         from . import hip
         stage = on_stage or (lambda name: None)
         self.setup_s = {}
-        self.comm = Comm(group)
+        # solo = (rank, world): that rank of a world-rank job alone in this process, exchange points stubbed (SoloComm: timing only)
+        self.comm = SoloComm(*solo) if solo is not None else Comm(group)
         rank = self.comm.rank
+        if solo is not None:
+            transport = "callback"
         if transport is None:
             transport = os.environ.get("ALFI_DIST_TRANSPORT") or ("rccl" if self.comm.backend == "nccl" else "callback")
         if transport not in ("rccl", "callback"):
@@ -685,7 +718,7 @@ class DistMultigrid(object):
         stage("partition")
         t0 = time.time()
         self.splits = choose_splits(levels, self.comm.world, min_dofs)
-        self.parts = build_parts(levels, transfers, self.splits, rank, self.comm.all_gather_object,
+        self.parts = build_parts(levels, transfers, self.splits, rank, None if solo is not None else self.comm.all_gather_object,
                                  force_distributed_above=min_dofs if force_distributed else None)
         self.setup_s["partition"] = time.time() - t0
         stage("localize")

@@ -491,3 +491,28 @@ def test_real_rccl_send_recv_to_self(tmp_path):
     ''' % (ROOT,)))
     out = subprocess.run([sys.executable, str(script)], cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "SELF-EXCHANGE-OK" in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]
+
+
+def test_solo_rank_mode_runs_every_rank_of_a_partition_alone():
+    """DistMultigrid(solo=(rank, world)): one rank of a partitioned job alone in the process, exchange points stubbed (SoloComm) --
+    the measurement mode of scripts/solo_rank_time.py.  Every rank sets up and cycles, the owned dofs of the ranks add up to the
+    level sizes, the library's events see device time in the rank's kernels."""
+    from alfi_amd.dist import DistMultigrid
+    from alfi_amd.problem import TwoDimLidDrivenCavityProblem, build_hierarchy
+    lv, tr = build_hierarchy(TwoDimLidDrivenCavityProblem(8), 2, 2, Re=10.0, lazy=True)
+    world = 3
+    owned = np.zeros(len(lv), dtype=np.int64)
+    for r in range(world):
+        dmg = DistMultigrid(lv, tr, 3, solo=(r, world), min_dofs=200)
+        b = np.random.default_rng(r).standard_normal(lv[-1].n)
+        db, dx = dmg.local_vec(b), dmg.local_vec()
+        dmg.ctx.prof_enable(True)
+        dmg.ctx.prof_reset()
+        dmg.vcycle(db, dx)
+        dmg.sync()
+        prof = dmg.ctx.prof_get()
+        assert prof["PATCH_APPLY"][0] > 0.0 and prof["MATMULT"][0] > 0.0
+        assert np.all(np.isfinite(dmg.owned(dx)))
+        owned += np.array([int(p.nb_own) * p.bs for p in dmg.parts])
+        dmg.close()
+    assert np.array_equal(owned, np.array([L.n for L in lv]))
