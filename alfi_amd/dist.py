@@ -45,17 +45,35 @@ def level_weights(L):
     return w
 
 
-def choose_splits(levels, world, min_dofs=400000):
+# Time of a node of a SINGLE-OWNER level relative to its bytes: those levels are small (launch latency, not bandwidth) and their
+# owner also solves the coarse grid.  Measured with every rank of config 4's 8-way partition alone on the GPU (scripts/
+# solo_rank_time.py, profiles/r05_solo_rank_time_cfg4_8ranks.txt): rank 0 spends 4.2 ms per V-cycle on levels 0-1 next to 21.0 ms
+# of partitioned work per rank, 1.8 x what the bytes of those levels would cost at the rate of the partitioned ones.
+SINGLE_OWNER_TIME_FACTOR = 1.8
+
+
+def choose_splits(levels, world, min_dofs=400000, balance_single_owner=True):
     """splits[l]: int64 (world+1) node split points of level l.  Levels with fewer than ``min_dofs`` dofs -- and, so that
-    the coarse solve needs no exchange, always level 0 -- belong to rank 0 entirely."""
+    the coarse solve needs no exchange, always level 0 -- belong to rank 0 entirely.  balance_single_owner: rank 0 gets a
+    smaller share of the partitioned levels, by the work it does alone on the single-owner ones (round 5: the equal split left
+    rank 0 at 25.3 ms of kernels per config-4 V-cycle against 21.0 ms on the other seven ranks)."""
+    single = [world == 1 or L.level == 0 or L.n < min_dofs for L in levels]
+    totals = [float(level_weights(L).sum()) for L in levels]
+    w_single = SINGLE_OWNER_TIME_FACTOR * sum(t for t, s_ in zip(totals, single) if s_)
+    w_dist = sum(t for t, s_ in zip(totals, single) if not s_)
+    # rank 0's share f0 of every partitioned level: f0 w_dist + w_single = (w_dist + w_single) / world, at least half a share
+    f0 = 1.0 / world
+    if balance_single_owner and world > 1 and w_dist > 0.0:
+        f0 = max(0.5 / world, (w_dist + w_single) / (world * w_dist) - w_single / w_dist)
+    fractions = np.concatenate([[f0], f0 + (1.0 - f0) * np.arange(1, world - 1) / (world - 1)]) if world > 1 else np.zeros(0)
     out = []
-    for L in levels:
+    for L, one in zip(levels, single):
         nb = L.A.nbrows
-        if world == 1 or L.level == 0 or L.n < min_dofs:
+        if one:
             out.append(np.array([0] + [nb] * world, dtype=np.int64))
             continue
         c = np.cumsum(level_weights(L))
-        s = np.searchsorted(c, c[-1] * np.arange(1, world) / world, side="left") + 1
+        s = np.searchsorted(c, c[-1] * fractions, side="left") + 1
         s = np.maximum.accumulate(np.concatenate([[0], np.minimum(s, nb), [nb]]).astype(np.int64))
         if (np.diff(s) <= 0).any():
             raise ValueError("level %d (%d nodes) is too small to split over %d ranks" % (L.level, nb, world))
