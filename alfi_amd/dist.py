@@ -52,13 +52,16 @@ def level_weights(L):
 SINGLE_OWNER_TIME_FACTOR = 1.8
 
 
-def choose_splits(levels, world, min_dofs=400000, balance_single_owner=True):
+def choose_splits(levels, world, min_dofs=400000, balance_single_owner=True, full_cycle=False):
     """splits[l]: int64 (world+1) node split points of level l.  Levels with fewer than ``min_dofs`` dofs -- and, so that
     the coarse solve needs no exchange, always level 0 -- belong to rank 0 entirely.  balance_single_owner: rank 0 gets a
     smaller share of the partitioned levels, by the work it does alone on the single-owner ones (round 5: the equal split left
-    rank 0 at 25.3 ms of kernels per config-4 V-cycle against 21.0 ms on the other seven ranks)."""
+    rank 0 at 25.3 ms of kernels per config-4 V-cycle against 21.0 ms on the other seven ranks).  full_cycle: the work is that of
+    a full cycle (``pc_mg_type full``, what the outer solves apply, alfi/solver.py:366): level l of nl is visited nl - l times
+    instead of once, which weighs the single-owner levels more."""
     single = [world == 1 or L.level == 0 or L.n < min_dofs for L in levels]
-    totals = [float(level_weights(L).sum()) for L in levels]
+    visits = [(len(levels) - L.level) if full_cycle else 1 for L in levels]
+    totals = [v * float(level_weights(L).sum()) for L, v in zip(levels, visits)]
     w_single = SINGLE_OWNER_TIME_FACTOR * sum(t for t, s_ in zip(totals, single) if s_)
     w_dist = sum(t for t, s_ in zip(totals, single) if not s_)
     # rank 0's share f0 of every partitioned level: f0 w_dist + w_single = (w_dist + w_single) / world, at least half a share
@@ -691,7 +694,7 @@ class DistMultigrid(object):
 
     def __init__(self, levels, transfers, k, robust_restriction=False, group=None, device=None, min_dofs=400000,
                  coarse_inverse=None, verbose=False, force_distributed=False, overlap=None, overlap_min_dofs=None,
-                 transport=None, on_stage=None, use_overlap_rule=True, solo=None):
+                 transport=None, on_stage=None, use_overlap_rule=True, solo=None, full_cycle=False):
         """transport: "rccl" -- the library's own RCCL communicator serves every exchange point of a cycle (no Python
         between the kernels; the default whenever the process group's backend is nccl) -- or "callback": the library
         calls back into this module, which exchanges through torch.distributed (the test transport: gloo, ranks sharing
@@ -735,7 +738,8 @@ class DistMultigrid(object):
         self.stream = torch.cuda.Stream(device=device)
         stage("partition")
         t0 = time.time()
-        self.splits = choose_splits(levels, self.comm.world, min_dofs)
+        # full_cycle: the caller applies full cycles (the outer solves of a Newton step): the partition balances THEIR work
+        self.splits = choose_splits(levels, self.comm.world, min_dofs, full_cycle=full_cycle)
         self.parts = build_parts(levels, transfers, self.splits, rank, None if solo is not None else self.comm.all_gather_object,
                                  force_distributed_above=min_dofs if force_distributed else None)
         self.setup_s["partition"] = time.time() - t0
@@ -1129,7 +1133,8 @@ def _dist_ns_solver_class():
 
         def _create_device(self, restriction):
             self.dmg = DistMultigrid(self.levels, self.transfers, self.params["fieldsplit_0"]["mg_levels"]["ksp_max_it"],
-                                     robust_restriction=restriction, group=self._group, min_dofs=self._min_dofs)
+                                     robust_restriction=restriction, group=self._group, min_dofs=self._min_dofs,
+                                     full_cycle=self.params["fieldsplit_0"].get("pc_mg_type") == "full")
             self.ctx = self.dmg.ctx
             L = self.levels[-1]
             self.saddle = DistSaddle(self.dmg, self.B, self.vol, L.V.cell_nodes, self.nu, self.gamma,

@@ -26,6 +26,8 @@ def main():
     ap.add_argument("--ranks", type=int, nargs="*", default=None)
     ap.add_argument("--cycles", type=int, default=5)
     ap.add_argument("--min-dofs", type=int, default=400000)
+    ap.add_argument("--cycle", choices=["v", "f"], default="v", help="time V-cycles, or full cycles (pc_mg_type full: what the outer "
+                    "solves apply) with the partition balanced for them")
     args = ap.parse_args()
     import torch
     import bench
@@ -41,18 +43,19 @@ def main():
     for world, ranks in ((1, [0]), (args.world, args.ranks if args.ranks else list(range(args.world)))):
         for r in ranks:
             t0 = time.time()
-            dmg = DistMultigrid(lv, tr, k, solo=(r, world), min_dofs=args.min_dofs)
+            dmg = DistMultigrid(lv, tr, k, solo=(r, world), min_dofs=args.min_dofs, full_cycle=args.cycle == "f")
+            cycle = dmg.fcycle if args.cycle == "f" else dmg.vcycle
             dmg.sync()
             t_setup = time.time() - t0
             db, dx = dmg.local_vec(b), dmg.local_vec()
             for _ in range(2):
-                dmg.vcycle(db, dx)
+                cycle(db, dx)
             dmg.sync()
             dmg.ctx.prof_enable(True)
             dmg.ctx.prof_reset()
             t0 = time.time()
             for _ in range(args.cycles):
-                dmg.vcycle(db, dx)
+                cycle(db, dx)
             dmg.sync()
             wall = 1e3 * (time.time() - t0) / args.cycles
             prof = dmg.ctx.prof_get()
@@ -70,9 +73,9 @@ def main():
             torch.cuda.empty_cache()
     one = rows[0]["compute_ms"]
     many = [x["compute_ms"] for x in rows[1:]]
-    print("device time of the kernels per V-cycle: 1 rank %.2f ms; %d ranks: max %.2f / mean %.2f / min %.2f ms "
+    print("device time of the kernels per %s-cycle: 1 rank %.2f ms; %d ranks: max %.2f / mean %.2f / min %.2f ms "
           "-> compute-only speed-up %.2f (ideal %d); sum over ranks / 1 rank = %.3f (ghost redundancy + small-launch inefficiency)"
-          % (one, args.world, max(many), sum(many) / len(many), min(many), one / max(many), args.world,
+          % ("F" if args.cycle == "f" else "V", one, args.world, max(many), sum(many) / len(many), min(many), one / max(many), args.world,
              sum(many) / one if len(many) == args.world else float("nan")))
 
 
