@@ -352,3 +352,35 @@ def test_assembly_cells_and_contributor_lists_of_a_partition(case, world):
                     else:
                         assert r_ >= p.nb_own or c_ >= p.nb_loc or r_ >= p.nb_loc
         assert (np.diff(cptr) > 0).all()
+
+
+def test_rank_zero_gets_a_smaller_share_for_its_single_owner_levels():
+    """choose_splits: rank 0 owns the levels below ``min_dofs`` alone, so its share of every partitioned level is smaller by that work
+    (single-owner bytes x SINGLE_OWNER_TIME_FACTOR; more so for full cycles, which visit the low levels more often), never below
+    half an equal share; the other ranks share the rest equally (by bytes per smoother iteration); every node has exactly one owner."""
+    from alfi_amd.dist import SINGLE_OWNER_TIME_FACTOR, choose_splits, level_weights
+    from alfi_amd.problem import ThreeDimLidDrivenCavityProblem, build_hierarchy
+    lv, _ = build_hierarchy(ThreeDimLidDrivenCavityProblem(2), 2, 2, Re=10.0, lazy=True)
+    world, min_dofs = 4, 5000
+    single = [L.level == 0 or L.n < min_dofs for L in lv]
+    assert any(single) and not all(single)
+    w = [float(level_weights(L).sum()) for L in lv]
+    shares = {}
+    for full in (False, True):
+        splits = choose_splits(lv, world, min_dofs, full_cycle=full)
+        equal = choose_splits(lv, world, min_dofs, balance_single_owner=False)
+        visits = [(len(lv) - L.level) if full else 1 for L in lv]
+        ws = SINGLE_OWNER_TIME_FACTOR * sum(v * x for v, x, s in zip(visits, w, single) if s)
+        wd = sum(v * x for v, x, s in zip(visits, w, single) if not s)
+        f0 = max(0.5 / world, (wd + ws) / (world * wd) - ws / wd)
+        for L, s, e, one in zip(lv, splits, equal, single):
+            assert s[0] == 0 and s[-1] == L.A.nbrows and np.all(np.diff(s) >= 0)
+            if one:
+                assert np.array_equal(s, e) and s[1] == L.A.nbrows
+                continue
+            c = np.concatenate([[0.0], np.cumsum(level_weights(L))])
+            sh = np.diff(c[s]) / c[-1]
+            assert abs(sh[0] - f0) < 2e-3 and sh[0] < 1.0 / world
+            assert np.abs(sh[1:] - (1.0 - f0) / (world - 1)).max() < 2e-3
+            shares[full] = sh[0]
+    assert shares[True] <= shares[False]
