@@ -568,6 +568,9 @@ def spawn_ranks(n):
 
 
 def main():
+    # dmabuf IPC is the only mode the host driver of the GPU boxes supports (RCCL / tensor sharing across the rank processes);
+    # before anything initialises the GPU, also when the ranks come from torch.distributed.run with a bare environment
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
